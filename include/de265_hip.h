@@ -1,0 +1,331 @@
+/*
+ * de265_hip.h -- C ABI of the MI355X (gfx950) HEVC pixel-reconstruction back end.
+ *
+ * This is the drop-in boundary for libde265's reconstruction path.  All entry
+ * points are extern "C", take plain pointers and sizes, and return
+ * de265_error-compatible ints (0 == DE265_OK, libde265/de265.h:82-139).
+ *
+ * Two interfaces are declared here:
+ *
+ *  Interface 2 (frame level, this file, part A): the host parser records one
+ *    picture's worth of reconstruction commands (what decode_TU,
+ *    generate_inter_prediction_samples, read_pcm_samples, apply_deblocking_filter
+ *    and apply_sample_adaptive_offset_sequential would have consumed) into a
+ *    de265hip_picture_desc and the device reconstructs the whole picture.
+ *    Replaces, per picture:
+ *      libde265/slice.cc:3424      decode_TU            -> de265hip_tu records
+ *      libde265/motion.cc:279      generate_inter_prediction_samples -> de265hip_pu
+ *      libde265/slice.cc:4143      read_pcm_samples_internal -> de265hip_pcm
+ *      libde265/deblock.cc:1020    apply_deblocking_filter
+ *      libde265/sao.cc:318         apply_sample_adaptive_offset_sequential
+ *    Hook site for submit: libde265/decctx.cc:757-766 (decode_some, after
+ *    mark_all_CTB_progress(PREFILTER)).
+ *
+ *  Interface 1 (function level, part B): batched forms of the
+ *    acceleration_functions slots (libde265/acceleration.h:29-201) that work
+ *    on host pointers, for per-function parity tests and for a maintainer who
+ *    wants to call single DSP functions.
+ *
+ * Units: all positions/sizes of TUs are in samples of their own component,
+ * PUs/PCM/metadata in luma samples.  Only ChromaArrayType==1 (4:2:0) is
+ * supported (Main / Main10); others return DE265_ERROR_NOT_IMPLEMENTED_YET.
+ */
+#ifndef DE265_HIP_H
+#define DE265_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes: numeric values of de265_error (de265.h:82-139) ---- */
+#define DE265HIP_OK                          0
+#define DE265HIP_ERROR_OUT_OF_MEMORY         7
+#define DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE 8   /* DE265_ERROR_CODED_PARAMETER_OUT_OF_RANGE */
+#define DE265HIP_ERROR_INIT_FAILED           11  /* DE265_ERROR_LIBRARY_INITIALIZATION_FAILED */
+#define DE265HIP_ERROR_DECODING              18  /* DE265_ERROR_UNSPECIFIED_DECODING_ERROR (device fault) */
+#define DE265HIP_ERROR_NOT_IMPLEMENTED       502 /* DE265_ERROR_NOT_IMPLEMENTED_YET */
+
+/* Proposed value for enum de265_acceleration (de265.h:391-402), above NEON=80. */
+#define DE265HIP_ACCELERATION_LEVEL 90
+
+#define DE265HIP_MAX_DPB_SLOTS 20
+#define DE265HIP_MAX_REFS      16   /* MAX_NUM_REF_PICS */
+
+/* ------------------------------------------------------------------ */
+/* Part A: frame-level interface                                        */
+/* ------------------------------------------------------------------ */
+
+/* Picture constants: the SPS/PPS-derived values the reconstruction reads
+ * (sps.h:188-236, pps.h:150-157). */
+typedef struct de265hip_pic_params {
+  int32_t width, height;              /* pic_{width,height}_in_luma_samples */
+  int32_t bit_depth_luma;             /* BitDepth_Y */
+  int32_t bit_depth_chroma;           /* BitDepth_C */
+  int32_t chroma_format_idc;          /* must be 1 */
+  int32_t log2_ctb_size;              /* Log2CtbSizeY 4..6 */
+  int32_t log2_min_cb_size;           /* Log2MinCbSizeY >=3 */
+  int32_t log2_min_tb_size;           /* Log2MinTrafoSize 2..5 */
+  int32_t pcm_loop_filter_disable_flag;
+  int32_t strong_intra_smoothing_enable_flag;
+  int32_t constrained_intra_pred_flag;
+  int32_t sample_adaptive_offset_enabled_flag;
+  int32_t scaling_list_enable_flag;
+  int32_t weighted_pred_flag;
+  int32_t weighted_bipred_flag;
+  int32_t pic_cb_qp_offset;
+  int32_t pic_cr_qp_offset;
+  int32_t loop_filter_across_tiles_enabled_flag;
+  int32_t num_tile_columns;           /* >=1 */
+  int32_t num_tile_rows;              /* >=1 */
+  uint16_t col_bd[24];                /* colBd[0..num_tile_columns], CTB units */
+  uint16_t row_bd[24];                /* rowBd[0..num_tile_rows],    CTB units */
+  int32_t disable_deblocking;         /* DE265_DECODER_PARAM_DISABLE_DEBLOCKING */
+  int32_t disable_sao;                /* DE265_DECODER_PARAM_DISABLE_SAO */
+} de265hip_pic_params;
+
+/* Size of the flat scaling-factor blob: ScalingFactor_Size0[6][4][4],
+ * Size1[6][8][8], Size2[6][16][16], Size3[2][32][32] back to back (sps.h:51-58). */
+#define DE265HIP_SCALING_BLOB_BYTES (6*16 + 6*64 + 6*256 + 2*1024)
+
+/* Per slice segment values read by MC weighting, deblocking and SAO
+ * (slice.h:147-248). */
+typedef struct de265hip_slice_params {
+  int32_t slice_type;                 /* 0=B 1=P 2=I (slice.h SLICE_TYPE_*) */
+  int32_t slice_addr_rs;              /* SliceAddrRS */
+  int32_t slice_deblocking_filter_disabled_flag;
+  int32_t slice_beta_offset;          /* already *2 */
+  int32_t slice_tc_offset;            /* already *2 */
+  int32_t slice_loop_filter_across_slices_enabled_flag;
+  int32_t slice_sao_luma_flag;
+  int32_t slice_sao_chroma_flag;
+  int32_t luma_log2_weight_denom;
+  int32_t chroma_log2_weight_denom;   /* ChromaLog2WeightDenom */
+  int16_t luma_weight[2][16];
+  int16_t luma_offset[2][16];
+  int16_t chroma_weight[2][16][2];
+  int16_t chroma_offset[2][16][2];
+  int8_t  ref_pic_list[2][16];        /* RefPicList -> DPB slot id */
+} de265hip_slice_params;
+
+/* Per CTB (image.h:180-190 CTB_info + slice.h:267-275 sao_info). */
+typedef struct de265hip_ctb_info {
+  uint16_t slice_addr_rs;             /* SliceAddrRS of the slice covering the CTB */
+  uint16_t slice_idx;                 /* SliceHeaderIndex into the slice table */
+  uint8_t  sao_type_idx;              /* (>>2*cIdx)&3: 0 off, 1 band, 2 edge */
+  uint8_t  sao_eo_class;              /* (>>2*cIdx)&3 */
+  uint8_t  sao_band_position[3];
+  int8_t   sao_offset_val[3][4];      /* already sign-applied and << log2OffsetScale */
+  uint8_t  pad[3];
+} de265hip_ctb_info;
+
+/* TU flags */
+#define DE265HIP_TU_INTRA      0x01   /* cuPredMode == MODE_INTRA: predict, DST for 4x4 luma */
+#define DE265HIP_TU_CBF        0x02   /* residual present */
+#define DE265HIP_TU_TSKIP      0x04   /* transform_skip_flag[cIdx] */
+#define DE265HIP_TU_BYPASS     0x08   /* cu_transquant_bypass_flag */
+
+/* One transform unit of one colour component, in decode order
+ * (arguments of decode_TU, slice.cc:3424, plus the thread_context values it
+ * reads: qP*Prime, transform_skip_flag, cu_transquant_bypass_flag, coeffList). */
+typedef struct de265hip_tu {
+  uint16_t x0, y0;                    /* component samples */
+  uint8_t  log2_size;                 /* 2..5 */
+  uint8_t  c_idx;                     /* 0..2 */
+  uint8_t  flags;                     /* DE265HIP_TU_* */
+  uint8_t  intra_mode;                /* 0..34 (only if INTRA) */
+  int8_t   qp;                        /* qP{Y,Cb,Cr}Prime (transform.cc:362-368) */
+  uint8_t  pad;
+  uint16_t n_coeff;                   /* nCoeff[cIdx] */
+  uint32_t coeff_offset;              /* first entry in coeff_val/coeff_pos */
+} de265hip_tu;
+
+/* One prediction unit (arguments of generate_inter_prediction_samples,
+ * motion.cc:279, and PBMotion motion.h:36-44). */
+typedef struct de265hip_pu {
+  uint16_t x, y;                      /* xP,yP luma samples */
+  uint8_t  w, h;                      /* nPbW,nPbH */
+  uint8_t  pred_flag;                 /* bit0 L0, bit1 L1 */
+  uint8_t  pad;
+  uint16_t slice_idx;                 /* slice table index (weights, RefPicList) */
+  int8_t   ref_idx[2];
+  int16_t  mv[2][2];                  /* [list][x,y] quarter-pel */
+} de265hip_pu;
+
+/* One PCM coding unit (slice.cc:4143-4183); samples already << (bitDepth-pcmBits),
+ * stored Y (size^2) then Cb, Cr ((size/2)^2 each) as uint16. */
+typedef struct de265hip_pcm {
+  uint16_t x0, y0;
+  uint8_t  log2_cb_size;
+  uint8_t  pad[3];
+  uint32_t sample_offset;
+} de265hip_pcm;
+
+/* Per 4x4 luma unit flags: flattened view of deblk_info (image.h:70-74),
+ * cb_info.PredMode/pcm_flag/cu_transquant_bypass (image.h:193-216) and
+ * tu_info bit 7 (image.h:67). */
+#define DE265HIP_BLK_INTRA       0x01
+#define DE265HIP_BLK_NONZERO     0x02  /* TU_FLAG_NONZERO_COEFF of the covering TU */
+#define DE265HIP_BLK_PCM         0x04  /* pcm_flag */
+#define DE265HIP_BLK_BYPASS      0x08  /* cu_transquant_bypass */
+#define DE265HIP_BLK_EDGE_TU_V   0x10  /* DEBLOCK_FLAG_VERTI */
+#define DE265HIP_BLK_EDGE_TU_H   0x20  /* DEBLOCK_FLAG_HORIZ */
+#define DE265HIP_BLK_EDGE_PB_V   0x40  /* DEBLOCK_PB_EDGE_VERTI */
+#define DE265HIP_BLK_EDGE_PB_H   0x80  /* DEBLOCK_PB_EDGE_HORIZ */
+
+/* Per 4x4 luma unit motion (PBMotion with RefPicList already resolved to DPB
+ * slot ids, as derive_boundaryStrength compares them, deblock.cc:295-304). */
+typedef struct de265hip_motion {
+  int16_t mv[2][2];
+  int8_t  ref_slot[2];                /* -1 when predFlag[l]==0 */
+  uint8_t pad[2];
+} de265hip_motion;
+
+/* Everything the device needs for one picture.  Arrays are caller-owned and
+ * only read during de265hip_picture_build(). */
+typedef struct de265hip_picture_desc {
+  de265hip_pic_params params;
+  const uint8_t* scaling_factors;     /* DE265HIP_SCALING_BLOB_BYTES or NULL */
+  int32_t n_slices;  const de265hip_slice_params* slices;
+  int32_t n_ctbs;    const de265hip_ctb_info* ctbs;      /* raster, PicSizeInCtbsY */
+  int32_t n_tus;     const de265hip_tu* tus;             /* decode order */
+  int32_t n_coeffs;  const int16_t* coeff_val; const uint16_t* coeff_pos;
+  int32_t n_pus;     const de265hip_pu* pus;
+  int32_t n_pcms;    const de265hip_pcm* pcms;
+  int32_t n_pcm_samples; const uint16_t* pcm_samples;
+  /* metadata planes, ceil(W/4) x ceil(H/4), row-major */
+  const uint8_t* blk_flags;
+  const int8_t*  blk_qp_y;
+  const de265hip_motion* blk_motion;  /* may be NULL when no inter CU exists */
+} de265hip_picture_desc;
+
+typedef struct de265hip_decoder de265hip_decoder;
+typedef struct de265hip_picture de265hip_picture;
+
+/* stage selector for de265hip_picture_run / get planes */
+#define DE265HIP_STAGE_PREFILTER 0   /* after MC + residual + intra (pre-lf) */
+#define DE265HIP_STAGE_DEBLOCKED 1
+#define DE265HIP_STAGE_FINAL     2   /* after SAO */
+
+/* Library / device */
+const char* de265hip_version(void);
+int  de265hip_device_count(void);
+
+/* Decoder context: owns a HIP stream and the device-resident DPB.
+ * device < 0 selects the current device. */
+int  de265hip_decoder_new(de265hip_decoder** out, int device);
+void de265hip_decoder_free(de265hip_decoder*);
+/* Allocate (or re-use) DPB slot `slot` for a picture of this geometry. */
+int  de265hip_dpb_alloc(de265hip_decoder*, int slot, int width, int height,
+                        int bit_depth_luma, int bit_depth_chroma);
+/* Copy host planes into / out of a DPB slot.  stride_bytes as in
+ * de265_get_image_plane (de265.h:173-174).  Sample type is uint8_t when the
+ * component's bit depth is <=8, else uint16_t. */
+int  de265hip_dpb_upload(de265hip_decoder*, int slot, int c_idx,
+                         const void* src, ptrdiff_t stride_bytes);
+int  de265hip_dpb_download(de265hip_decoder*, int slot, int c_idx,
+                           void* dst, ptrdiff_t stride_bytes);
+/* Device pointer + stride (bytes) of a DPB plane (for zero-copy consumers). */
+int  de265hip_dpb_plane(de265hip_decoder*, int slot, int c_idx,
+                        void** dev_ptr, ptrdiff_t* stride_bytes);
+
+/* Build: host-side preprocessing (intra availability + dependency levels,
+ * level sort, MC task split) and upload of the command buffers.  After this
+ * call every input of the picture is resident in HBM. */
+int  de265hip_picture_build(de265hip_decoder*, int dst_slot,
+                            const de265hip_picture_desc*, de265hip_picture** out);
+/* Run: enqueue all reconstruction kernels of the picture on the decoder's
+ * stream (asynchronous).  last_stage: DE265HIP_STAGE_*. */
+int  de265hip_picture_run(de265hip_decoder*, de265hip_picture*, int last_stage);
+/* Wait for everything enqueued on the decoder's stream. */
+int  de265hip_decoder_sync(de265hip_decoder*);
+void de265hip_picture_free(de265hip_picture*);
+/* Convenience: build + run(FINAL) + sync + free. */
+int  de265hip_decode_picture(de265hip_decoder*, int dst_slot,
+                             const de265hip_picture_desc*);
+
+/* Introspection used by bench/tests */
+typedef struct de265hip_picture_stats {
+  int32_t n_levels;          /* intra dependency levels (kernel launches) */
+  int32_t n_tu_tasks;
+  int32_t n_mc_tasks;
+  int64_t device_bytes;      /* command-buffer bytes resident in HBM */
+  int64_t alg_bytes_mc;      /* algorithmic bytes, SURVEY 8d definitions */
+  int64_t alg_bytes_resid;
+  int64_t alg_bytes_intra;
+  int64_t alg_bytes_deblock;
+  int64_t alg_bytes_sao;
+} de265hip_picture_stats;
+int  de265hip_picture_get_stats(const de265hip_picture*, de265hip_picture_stats*);
+
+/* Per-kernel device time of the last N runs, measured with hipEvents on the
+ * decoder's stream.  kernel ids: */
+#define DE265HIP_K_MC        0
+#define DE265HIP_K_RESID     1   /* level-0 TU kernel (inter residual) */
+#define DE265HIP_K_INTRA     2   /* sum of intra level launches */
+#define DE265HIP_K_BS        3
+#define DE265HIP_K_DEBLOCK_V 4
+#define DE265HIP_K_DEBLOCK_H 5
+#define DE265HIP_K_SAO       6
+#define DE265HIP_K_PCM       7
+#define DE265HIP_K_COUNT     8
+int  de265hip_set_profiling(de265hip_decoder*, int enable);
+/* Accumulated ms and launch counts since the last reset (sync first). */
+int  de265hip_get_kernel_times(de265hip_decoder*, double ms[DE265HIP_K_COUNT],
+                               int64_t launches[DE265HIP_K_COUNT], int reset);
+
+/* Host helper: edge-flag derivation (deblock.cc:31-225 derive_edgeFlags) from
+ * CU/TU structure, for hosts that do not already run it.  cb_log2_size /
+ * cb_part_mode are per MinCb unit (top-left only, 0 elsewhere), tu_split per
+ * MinTb unit with bit d set when split_transform_flag at depth d
+ * (image.h:67-68).  ORs DE265HIP_BLK_EDGE_* into blk_flags. */
+int  de265hip_derive_edge_flags(const de265hip_pic_params*,
+                                const de265hip_slice_params* slices, int n_slices,
+                                const de265hip_ctb_info* ctbs,
+                                const uint8_t* cb_log2_size, const uint8_t* cb_part_mode,
+                                const uint8_t* tu_split, uint8_t* blk_flags);
+
+/* ------------------------------------------------------------------ */
+/* Part B: function-level (vtable-shaped) interface, batched            */
+/* ------------------------------------------------------------------ */
+/* Each call processes `n` independent blocks that live in ONE host plane.
+ * xy[2*i],xy[2*i+1] is the block origin in the plane.  Semantics per block
+ * are those of the acceleration_functions slot named in the comment. */
+
+/* transform_add_{8,16}[log2-2] / transform_4x4_dst_add_{8,16}
+ * (acceleration.h:152-159).  coeffs: n * nT*nT dense row-major int16. */
+int de265hip_fn_transform_add(int log2_size, int dst_type /*0 DCT,1 DST*/, int bit_depth,
+                              void* plane, ptrdiff_t stride_samples, int plane_h,
+                              int n, const int32_t* xy, const int16_t* coeffs);
+/* transform_skip_residual + add_residual (acceleration.h:169-178) */
+int de265hip_fn_transform_skip_add(int log2_size, int bit_depth,
+                                   void* plane, ptrdiff_t stride_samples, int plane_h,
+                                   int n, const int32_t* xy, const int16_t* coeffs);
+/* transform_bypass + add_residual (acceleration.h:143,169) */
+int de265hip_fn_transform_bypass_add(int log2_size, int bit_depth,
+                                     void* plane, ptrdiff_t stride_samples, int plane_h,
+                                     int n, const int32_t* xy, const int16_t* coeffs);
+/* put_hevc_qpel_{8,16}[dX][dY] (acceleration.h:100,118): src plane -> int16
+ * out blocks (n * w*h, stride w).  Source blocks must lie inside the plane
+ * including their filter margins (the vtable contract). */
+int de265hip_fn_put_qpel(int bit_depth, const void* src_plane, ptrdiff_t stride_samples,
+                         int plane_w, int plane_h, int w, int h, int dx, int dy,
+                         int n, const int32_t* xy, int16_t* out);
+/* put_hevc_epel{,_h,_v,_hv}_{8,16} (acceleration.h:87-116) */
+int de265hip_fn_put_epel(int bit_depth, const void* src_plane, ptrdiff_t stride_samples,
+                         int plane_w, int plane_h, int w, int h, int mx, int my,
+                         int n, const int32_t* xy, int16_t* out);
+/* put_unweighted_pred / put_weighted_pred / put_weighted_bipred /
+ * put_weighted_pred_avg (acceleration.h:31-64).  mode: 0 unweighted,
+ * 1 weighted uni, 2 avg, 3 weighted bi.  src blocks: n * w*h int16. */
+int de265hip_fn_put_pred(int mode, int bit_depth, void* plane, ptrdiff_t stride_samples,
+                         int plane_h, int w, int h, int n, const int32_t* xy,
+                         const int16_t* src0, const int16_t* src1,
+                         int w0, int o0, int w1, int o1, int log2wd);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DE265_HIP_H */
