@@ -1,0 +1,245 @@
+"""Host-side Python mirror of the C ABI in include/de265_hip.h.
+
+This is plumbing only: every call goes straight into libde265_hip.so (hand
+written HIP for gfx950).  There is no CPU fallback: if the shared library is
+missing or no GPU is present the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libde265_hip.so")
+
+# every symbol include/de265_hip.h declares (tests/test_abi.py checks the .so exports them all)
+EXPORTS = [
+    "de265hip_version", "de265hip_device_count",
+    "de265hip_decoder_new", "de265hip_decoder_free",
+    "de265hip_dpb_alloc", "de265hip_dpb_upload", "de265hip_dpb_download", "de265hip_dpb_plane",
+    "de265hip_picture_build", "de265hip_picture_run", "de265hip_decoder_sync", "de265hip_picture_free",
+    "de265hip_decode_picture", "de265hip_picture_get_stats",
+    "de265hip_set_profiling", "de265hip_get_kernel_times", "de265hip_derive_edge_flags",
+    "de265hip_fn_transform_add", "de265hip_fn_transform_skip_add", "de265hip_fn_transform_bypass_add",
+    "de265hip_fn_put_qpel", "de265hip_fn_put_epel", "de265hip_fn_put_pred",
+]
+
+
+class De265HipError(RuntimeError):
+    def __init__(self, code, where):
+        super().__init__("%s failed with de265_error %d" % (where, code))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Loads libde265_hip.so; raises (never falls back) if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError("%s not found: run `python -m libde265_amd.build` (hipcc, gfx950)" % SO_PATH)
+    L = C.CDLL(SO_PATH)
+    vp, i32, pp = C.c_void_p, C.c_int, C.POINTER
+    L.de265hip_version.restype = C.c_char_p
+    L.de265hip_device_count.restype = i32
+    L.de265hip_decoder_new.argtypes = [pp(vp), i32]
+    L.de265hip_decoder_free.argtypes = [vp]
+    L.de265hip_decoder_free.restype = None
+    L.de265hip_dpb_alloc.argtypes = [vp, i32, i32, i32, i32, i32]
+    L.de265hip_dpb_upload.argtypes = [vp, i32, i32, vp, C.c_ssize_t]
+    L.de265hip_dpb_download.argtypes = [vp, i32, i32, vp, C.c_ssize_t]
+    L.de265hip_dpb_plane.argtypes = [vp, i32, i32, pp(vp), pp(C.c_ssize_t)]
+    L.de265hip_picture_build.argtypes = [vp, i32, pp(_abi.PictureDesc), pp(vp)]
+    L.de265hip_picture_run.argtypes = [vp, vp, i32]
+    L.de265hip_decoder_sync.argtypes = [vp]
+    L.de265hip_picture_free.argtypes = [vp]
+    L.de265hip_picture_free.restype = None
+    L.de265hip_decode_picture.argtypes = [vp, i32, pp(_abi.PictureDesc)]
+    L.de265hip_picture_get_stats.argtypes = [vp, pp(_abi.PictureStats)]
+    L.de265hip_set_profiling.argtypes = [vp, i32]
+    L.de265hip_get_kernel_times.argtypes = [vp, pp(C.c_double), pp(C.c_int64), i32]
+    L.de265hip_derive_edge_flags.argtypes = [pp(_abi.PicParams), pp(_abi.SliceParams), i32, pp(_abi.CtbInfo),
+                                             vp, vp, vp, vp]
+    for n in ("de265hip_fn_transform_add",):
+        getattr(L, n).argtypes = [i32, i32, i32, vp, C.c_ssize_t, i32, i32, vp, vp]
+    for n in ("de265hip_fn_transform_skip_add", "de265hip_fn_transform_bypass_add"):
+        getattr(L, n).argtypes = [i32, i32, vp, C.c_ssize_t, i32, i32, vp, vp]
+    for n in ("de265hip_fn_put_qpel", "de265hip_fn_put_epel"):
+        getattr(L, n).argtypes = [i32, vp, C.c_ssize_t, i32, i32, i32, i32, i32, i32, i32, vp, vp]
+    L.de265hip_fn_put_pred.argtypes = [i32, i32, vp, C.c_ssize_t, i32, i32, i32, i32, vp, vp, vp] + [i32] * 5
+    _lib = L
+    return L
+
+
+def _chk(rc, where):
+    if rc != 0:
+        raise De265HipError(rc, where)
+
+
+def device_count():
+    return lib().de265hip_device_count()
+
+
+class Picture:
+    """Device-resident command buffers of one picture (de265hip_picture)."""
+
+    def __init__(self, dec, handle):
+        self.dec, self._h = dec, handle
+
+    def stats(self):
+        s = _abi.PictureStats()
+        _chk(lib().de265hip_picture_get_stats(self._h, C.byref(s)), "picture_get_stats")
+        return s
+
+    def free(self):
+        if self._h:
+            lib().de265hip_picture_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Decoder:
+    """Mirror of de265hip_decoder: one HIP stream + device-resident DPB."""
+
+    def __init__(self, device=-1):
+        h = C.c_void_p()
+        _chk(lib().de265hip_decoder_new(C.byref(h), device), "decoder_new")
+        self._h = h
+
+    def close(self):
+        if self._h:
+            lib().de265hip_decoder_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- DPB ---
+    def dpb_alloc(self, slot, width, height, bit_depth_luma, bit_depth_chroma=None):
+        bdc = bit_depth_luma if bit_depth_chroma is None else bit_depth_chroma
+        _chk(lib().de265hip_dpb_alloc(self._h, slot, width, height, bit_depth_luma, bdc), "dpb_alloc")
+
+    def upload(self, slot, planes):
+        for c, p in enumerate(planes):
+            p = np.ascontiguousarray(p)
+            _chk(lib().de265hip_dpb_upload(self._h, slot, c, p.ctypes.data, p.strides[0]), "dpb_upload")
+
+    def download(self, slot, width, height, bit_depth):
+        dt = np.uint16 if bit_depth > 8 else np.uint8
+        out = []
+        for c, (w, h) in enumerate([(width, height), (width // 2, height // 2), (width // 2, height // 2)]):
+            a = np.empty((h, w), dt)
+            _chk(lib().de265hip_dpb_download(self._h, slot, c, a.ctypes.data, a.strides[0]), "dpb_download")
+            out.append(a)
+        return out
+
+    def plane(self, slot, c_idx):
+        p, s = C.c_void_p(), C.c_ssize_t()
+        _chk(lib().de265hip_dpb_plane(self._h, slot, c_idx, C.byref(p), C.byref(s)), "dpb_plane")
+        return p.value, s.value
+
+    # --- pictures ---
+    def build(self, dst_slot, desc):
+        dptr = desc if isinstance(desc, C.POINTER(_abi.PictureDesc)) else C.pointer(desc)
+        h = C.c_void_p()
+        _chk(lib().de265hip_picture_build(self._h, dst_slot, dptr, C.byref(h)), "picture_build")
+        return Picture(self, h)
+
+    def run(self, pic, last_stage=_abi.STAGE_FINAL):
+        _chk(lib().de265hip_picture_run(self._h, pic._h, last_stage), "picture_run")
+
+    def sync(self):
+        _chk(lib().de265hip_decoder_sync(self._h), "decoder_sync")
+
+    def decode_picture(self, dst_slot, desc):
+        dptr = desc if isinstance(desc, C.POINTER(_abi.PictureDesc)) else C.pointer(desc)
+        _chk(lib().de265hip_decode_picture(self._h, dst_slot, dptr), "decode_picture")
+
+    # --- profiling ---
+    def set_profiling(self, on):
+        _chk(lib().de265hip_set_profiling(self._h, int(bool(on))), "set_profiling")
+
+    def kernel_times(self, reset=True):
+        ms = (C.c_double * len(_abi.K_NAMES))()
+        n = (C.c_int64 * len(_abi.K_NAMES))()
+        _chk(lib().de265hip_get_kernel_times(self._h, ms, n, int(reset)), "get_kernel_times")
+        return {k: (ms[i], n[i]) for i, k in enumerate(_abi.K_NAMES)}
+
+
+def derive_edge_flags(params, slices, n_slices, ctbs, cb_log2_size, cb_part_mode, tu_split, blk_flags):
+    """a11 host helper; ORs the edge bits into blk_flags (numpy uint8, in place)."""
+    _chk(lib().de265hip_derive_edge_flags(C.byref(params), slices, n_slices, ctbs,
+                                          cb_log2_size.ctypes.data, cb_part_mode.ctypes.data,
+                                          tu_split.ctypes.data, blk_flags.ctypes.data), "derive_edge_flags")
+    return blk_flags
+
+
+# ---------------- function-level (vtable-shaped) interface ----------------
+def _xy(blocks):
+    return np.ascontiguousarray(np.asarray(blocks, dtype=np.int32).reshape(-1, 2))
+
+
+def fn_transform_add(plane, bit_depth, log2_size, blocks, coeffs, dst=False):
+    xy = _xy(blocks)
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.int16)
+    _chk(lib().de265hip_fn_transform_add(log2_size, int(dst), bit_depth, plane.ctypes.data, plane.shape[1],
+                                         plane.shape[0], len(xy), xy.ctypes.data, coeffs.ctypes.data),
+         "fn_transform_add")
+
+
+def fn_transform_skip_add(plane, bit_depth, log2_size, blocks, coeffs):
+    xy = _xy(blocks)
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.int16)
+    _chk(lib().de265hip_fn_transform_skip_add(log2_size, bit_depth, plane.ctypes.data, plane.shape[1],
+                                              plane.shape[0], len(xy), xy.ctypes.data, coeffs.ctypes.data),
+         "fn_transform_skip_add")
+
+
+def fn_transform_bypass_add(plane, bit_depth, log2_size, blocks, coeffs):
+    xy = _xy(blocks)
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.int16)
+    _chk(lib().de265hip_fn_transform_bypass_add(log2_size, bit_depth, plane.ctypes.data, plane.shape[1],
+                                                plane.shape[0], len(xy), xy.ctypes.data, coeffs.ctypes.data),
+         "fn_transform_bypass_add")
+
+
+def fn_put_qpel(plane, bit_depth, w, h, dx, dy, blocks):
+    xy = _xy(blocks)
+    out = np.empty((len(xy), h, w), np.int16)
+    _chk(lib().de265hip_fn_put_qpel(bit_depth, plane.ctypes.data, plane.shape[1], plane.shape[1], plane.shape[0],
+                                    w, h, dx, dy, len(xy), xy.ctypes.data, out.ctypes.data), "fn_put_qpel")
+    return out
+
+
+def fn_put_epel(plane, bit_depth, w, h, mx, my, blocks):
+    xy = _xy(blocks)
+    out = np.empty((len(xy), h, w), np.int16)
+    _chk(lib().de265hip_fn_put_epel(bit_depth, plane.ctypes.data, plane.shape[1], plane.shape[1], plane.shape[0],
+                                    w, h, mx, my, len(xy), xy.ctypes.data, out.ctypes.data), "fn_put_epel")
+    return out
+
+
+def fn_put_pred(plane, bit_depth, mode, blocks, src0, src1=None, w0=0, o0=0, w1=0, o1=0, log2wd=1):
+    xy = _xy(blocks)
+    src0 = np.ascontiguousarray(src0, dtype=np.int16)
+    h, w = src0.shape[1], src0.shape[2]
+    s1 = None
+    if src1 is not None:
+        src1 = np.ascontiguousarray(src1, dtype=np.int16)
+        s1 = src1.ctypes.data
+    _chk(lib().de265hip_fn_put_pred(mode, bit_depth, plane.ctypes.data, plane.shape[1], plane.shape[0], w, h,
+                                    len(xy), xy.ctypes.data, src0.ctypes.data, s1, w0, o0, w1, o1, log2wd),
+         "fn_put_pred")

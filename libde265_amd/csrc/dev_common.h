@@ -1,0 +1,65 @@
+// dev_common.h -- structures shared between the host library and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/de265_hip.h"
+
+namespace d265 {
+
+// One device-resident plane.
+struct PlaneRef {
+  void* ptr;
+  int32_t stride;   // samples
+  int32_t pad;
+};
+
+// Plane table passed by value to kernels: [slot][component].
+struct DpbTable {
+  PlaneRef p[DE265HIP_MAX_DPB_SLOTS][3];
+};
+
+// Picture constants needed on the device.
+struct PicDev {
+  int32_t width, height;            // luma
+  int32_t bd_luma, bd_chroma;
+  int32_t log2_ctb, ctbs_w, ctbs_h;
+  int32_t w4, h4;                   // ceil(W/4), ceil(H/4)
+  int32_t strong_intra, pcm_lf_disable;
+  int32_t weighted_pred, weighted_bipred;
+  int32_t cb_qp_offset, cr_qp_offset;
+  int32_t lf_across_tiles;
+  int32_t scaling_list;
+};
+
+// TU task: de265hip_tu plus the host-derived neighbour availability.
+// avail bit u (scan order of intrapred.cc:577-688): u < 2nT/4 left column
+// bottom->top in 4-sample units, u == 2nT/4 corner, then top row left->right.
+struct TuTask {
+  uint16_t x0, y0;
+  uint8_t  log2_size, c_idx, flags, intra_mode;
+  int8_t   qp;
+  uint8_t  pad;
+  uint16_t n_coeff;
+  uint32_t coeff_offset;
+  uint64_t avail;
+};
+static_assert(sizeof(TuTask) == 24, "TuTask layout");
+
+// MC task: a <=16x16 luma tile of one PU (plus its two 4:2:0 chroma tiles).
+struct McTask {
+  uint16_t x, y;          // luma position of the tile
+  uint8_t  w, h;          // luma size (multiples of 4, <=16)
+  int8_t   slot[2];       // DPB slot per list, -1 = list unused
+  int16_t  mv[2][2];
+  uint16_t slice_idx;
+  int8_t   ref_idx[2];
+};
+static_assert(sizeof(McTask) == 20, "McTask layout");
+
+struct PcmTask {
+  uint16_t x0, y0;
+  uint32_t log2_cb_size;
+  uint32_t sample_offset;
+};
+
+}  // namespace d265

@@ -1,0 +1,836 @@
+// host.hip -- host side of the MI355X reconstruction back end: C ABI of
+// include/de265_hip.h, device-resident DPB, per-picture command-buffer build
+// (intra availability + dependency levels, MC tile split) and kernel sequencing.
+//
+// Order of device work for one picture (last paragraph):
+//   MC (all PUs) -> PCM copy -> TU level 0 (inter residual) -> TU levels 1..N
+//   (intra prediction + residual, dependency-ordered) -> bS -> deblock V ->
+//   deblock H -> SAO (out of place, then the slot's plane pointers are swapped).
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace d265;
+
+#define HIPCHK(expr, code)                                                      \
+  do {                                                                          \
+    hipError_t e_ = (expr);                                                     \
+    if (e_ != hipSuccess) {                                                     \
+      fprintf(stderr, "de265hip: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return (code);                                                            \
+    }                                                                           \
+  } while (0)
+
+namespace {
+
+struct Slot {
+  PlaneRef pl[3] = {};
+  int w = 0, h = 0, bdY = 0, bdC = 0;
+  bool valid = false;
+};
+
+struct PendingEvent { int kid; hipEvent_t a, b; };
+
+}  // namespace
+
+struct de265hip_decoder {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  Slot slots[DE265HIP_MAX_DPB_SLOTS];
+  Slot spare;                         // SAO output target, swapped with the decoded slot
+  bool profiling = false;
+  std::vector<PendingEvent> pending;
+  double ms[DE265HIP_K_COUNT] = {};
+  int64_t launches[DE265HIP_K_COUNT] = {};
+};
+
+struct de265hip_picture {
+  de265hip_decoder* dec = nullptr;
+  int dst_slot = 0;
+  de265hip_pic_params params;
+  PicDev P;
+  void* arena = nullptr;              // one device allocation for all command buffers
+  size_t arena_bytes = 0;
+  // device pointers into the arena
+  TuTask* d_tus = nullptr;
+  int16_t* d_cval = nullptr; uint16_t* d_cpos = nullptr;
+  uint8_t* d_scaling = nullptr;
+  McTask* d_mc = nullptr;
+  PcmTask* d_pcm = nullptr; uint16_t* d_pcm_samples = nullptr;
+  de265hip_slice_params* d_slices = nullptr;
+  de265hip_ctb_info* d_ctbs = nullptr;
+  uint16_t* d_tile_id = nullptr;
+  uint8_t* d_flags = nullptr; int8_t* d_qp = nullptr; de265hip_motion* d_motion = nullptr;
+  uint8_t* d_bs = nullptr;
+  std::vector<int> level_start;       // level_start[l] .. level_start[l+1] in d_tus
+  int n_mc = 0, n_pcm = 0, n_tus = 0;
+  bool any_edges = false;
+  de265hip_picture_stats stats = {};
+};
+
+namespace {
+
+size_t px_bytes(int bd) { return bd > 8 ? 2 : 1; }
+
+int free_slot(Slot& s)
+{
+  for (int c = 0; c < 3; c++) if (s.pl[c].ptr) { (void)hipFree(s.pl[c].ptr); s.pl[c].ptr = nullptr; }
+  s.valid = false;
+  return 0;
+}
+
+int alloc_slot(Slot& s, int w, int h, int bdY, int bdC)
+{
+  if (s.valid && s.w == w && s.h == h && s.bdY == bdY && s.bdC == bdC) return 0;
+  free_slot(s);
+  for (int c = 0; c < 3; c++) {
+    int cw = c ? w / 2 : w, ch = c ? h / 2 : h;
+    int stride = (cw + 63) & ~63;                         // samples; rows start 128/64-byte aligned
+    size_t bytes = (size_t)stride * ch * px_bytes(c ? bdC : bdY) + 256;
+    HIPCHK(hipMalloc(&s.pl[c].ptr, bytes), DE265HIP_ERROR_OUT_OF_MEMORY);
+    s.pl[c].stride = stride;
+  }
+  s.w = w; s.h = h; s.bdY = bdY; s.bdC = bdC; s.valid = true;
+  return 0;
+}
+
+struct Geometry {
+  int ctbs_w, ctbs_h, w4, h4, tbs_w, tbs_h;
+  std::vector<int> rs2ts;
+  std::vector<uint16_t> tile_id;
+  std::vector<int> min_tb_zs;
+};
+
+// CtbAddrRStoTS, TileIdRS and MinTbAddrZS (6.5.1 / 6.5.2; pps.cc:560-690)
+int make_geometry(const de265hip_pic_params& p, Geometry& g)
+{
+  const int ctb = 1 << p.log2_ctb_size;
+  g.ctbs_w = (p.width + ctb - 1) >> p.log2_ctb_size;
+  g.ctbs_h = (p.height + ctb - 1) >> p.log2_ctb_size;
+  g.w4 = (p.width + 3) / 4; g.h4 = (p.height + 3) / 4;
+  const int dl = p.log2_ctb_size - p.log2_min_tb_size;
+  g.tbs_w = g.ctbs_w << dl; g.tbs_h = g.ctbs_h << dl;
+  const int n = g.ctbs_w * g.ctbs_h;
+  g.rs2ts.assign(n, 0); g.tile_id.assign(n, 0);
+  const int nc = p.num_tile_columns, nr = p.num_tile_rows;
+  if (p.col_bd[0] != 0 || p.row_bd[0] != 0 || p.col_bd[nc] != g.ctbs_w || p.row_bd[nr] != g.ctbs_h)
+    return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  int ts = 0, tid = 0;
+  for (int j = 0; j < nr; j++)
+    for (int i = 0; i < nc; i++, tid++) {
+      if (p.col_bd[i + 1] <= p.col_bd[i] || p.row_bd[j + 1] <= p.row_bd[j]) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+      for (int y = p.row_bd[j]; y < p.row_bd[j + 1]; y++)
+        for (int x = p.col_bd[i]; x < p.col_bd[i + 1]; x++) {
+          g.rs2ts[y * g.ctbs_w + x] = ts++;                // tiles in raster order, CTBs raster inside a tile
+          g.tile_id[y * g.ctbs_w + x] = (uint16_t)tid;
+        }
+    }
+  g.min_tb_zs.assign((size_t)g.tbs_w * g.tbs_h, 0);
+  for (int y = 0; y < g.tbs_h; y++)
+    for (int x = 0; x < g.tbs_w; x++) {
+      int cx = x >> dl, cy = y >> dl;
+      int v = g.rs2ts[cy * g.ctbs_w + cx] << (2 * dl);
+      for (int i = 0; i < dl; i++) v |= (((x >> i) & 1) << (2 * i)) | (((y >> i) & 1) << (2 * i + 1));   // Morton interleave
+      g.min_tb_zs[x + (size_t)y * g.tbs_w] = v;
+    }
+  return 0;
+}
+
+// Neighbour availability of one intra TU (8.4.4.2.2; intrapred.cc:437-527 preproc,
+// :577-688 fill_from_image) as a unit bitmask, and the TU's dependency level.
+uint64_t intra_availability(const de265hip_picture_desc& d, const Geometry& g, const de265hip_tu& tu,
+                            const std::vector<uint16_t>& lvl, int map_w, int* level_out)
+{
+  const de265hip_pic_params& p = d.params;
+  const int nT = 1 << tu.log2_size, sub = tu.c_idx ? 2 : 1;
+  const int xB = tu.x0, yB = tu.y0, xL = xB * sub, yL = yB * sub;
+  bool aL = xL > 0, aT = yL > 0, aTL = aL && aT, aTR = aT && (xL + nT * sub < p.width);
+  const int lc = p.log2_ctb_size;
+  const int cx = xL >> lc, cy = yL >> lc;
+  auto same_ctb_group = [&](int ox, int oy) {
+    const int a = cx + cy * g.ctbs_w, b = ox + oy * g.ctbs_w;
+    return d.ctbs[a].slice_addr_rs == d.ctbs[b].slice_addr_rs && g.tile_id[a] == g.tile_id[b];
+  };
+  if (aL) aL = same_ctb_group((xL - 1) >> lc, cy);
+  if (aT) aT = same_ctb_group(cx, (yL - 1) >> lc);
+  if (aTL) aTL = same_ctb_group((xL - 1) >> lc, (yL - 1) >> lc);
+  if (aTR) aTR = same_ctb_group((xL + nT * sub) >> lc, (yL - 1) >> lc);
+
+  int nBottom = (p.height - yL + sub - 1) / sub; if (nBottom > 2 * nT) nBottom = 2 * nT;
+  int nRight = (p.width - xL + sub - 1) / sub;   if (nRight > 2 * nT) nRight = 2 * nT;
+  const int lt = p.log2_min_tb_size;
+  const int cur = g.min_tb_zs[(xL >> lt) + (size_t)(yL >> lt) * g.tbs_w];
+  auto usable = [&](int xs, int ys) {                     // component-sample position of the neighbour
+    int nx = xs * sub, ny = ys * sub;
+    if (g.min_tb_zs[(nx >> lt) + (size_t)(ny >> lt) * g.tbs_w] > cur) return false;
+    if (p.constrained_intra_pred_flag && !(d.blk_flags[(nx >> 2) + (ny >> 2) * g.w4] & DE265HIP_BLK_INTRA)) return false;
+    return true;
+  };
+  uint64_t mask = 0; int lev = 0;
+  const int corner = nT >> 1;
+  auto take = [&](int u, int xs, int ys) {
+    mask |= 1ull << u;
+    lev = std::max(lev, (int)lvl[(xs >> 2) + (ys >> 2) * map_w]);
+  };
+  if (aL)
+    for (int y = nBottom - 1; y >= 0; y -= 4)
+      if (usable(xB - 1, yB + y)) take((2 * nT - 1 - y) >> 2, xB - 1, yB + y);
+  if (aTL && usable(xB - 1, yB - 1)) take(corner, xB - 1, yB - 1);
+  for (int x = 0; x < nRight; x += 4)
+    if ((x < nT ? aT : aTR) && usable(xB + x, yB - 1)) take(corner + 1 + (x >> 2), xB + x, yB - 1);
+  *level_out = lev + 1;
+  return mask;
+}
+
+struct ArenaLayout {
+  size_t total = 0;
+  size_t add(size_t bytes) { size_t o = total; total = (total + bytes + 255) & ~(size_t)255; return o; }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* de265hip_version(void) { return "libde265-hip 0.1 (gfx950)"; }
+
+int de265hip_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int de265hip_decoder_new(de265hip_decoder** out, int device)
+{
+  if (!out) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  *out = nullptr;
+  int n = 0;
+  HIPCHK(hipGetDeviceCount(&n), DE265HIP_ERROR_INIT_FAILED);
+  if (n <= 0) return DE265HIP_ERROR_INIT_FAILED;
+  if (device >= 0) HIPCHK(hipSetDevice(device), DE265HIP_ERROR_INIT_FAILED);
+  de265hip_decoder* d = new (std::nothrow) de265hip_decoder();
+  if (!d) return DE265HIP_ERROR_OUT_OF_MEMORY;
+  HIPCHK(hipGetDevice(&d->device), DE265HIP_ERROR_INIT_FAILED);
+  HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking), DE265HIP_ERROR_INIT_FAILED);
+  *out = d;
+  return DE265HIP_OK;
+}
+
+void de265hip_decoder_free(de265hip_decoder* d)
+{
+  if (!d) return;
+  (void)hipStreamSynchronize(d->stream);
+  for (auto& e : d->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  for (auto& s : d->slots) free_slot(s);
+  free_slot(d->spare);
+  (void)hipStreamDestroy(d->stream);
+  delete d;
+}
+
+int de265hip_dpb_alloc(de265hip_decoder* d, int slot, int width, int height, int bdY, int bdC)
+{
+  if (!d || slot < 0 || slot >= DE265HIP_MAX_DPB_SLOTS) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  if (width <= 0 || height <= 0 || (width & 7) || (height & 7) || bdY < 8 || bdY > 12 || bdC < 8 || bdC > 12)
+    return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  if ((bdY > 8) != (bdC > 8)) return DE265HIP_ERROR_NOT_IMPLEMENTED;
+  return alloc_slot(d->slots[slot], width, height, bdY, bdC);
+}
+
+static int plane_geom(de265hip_decoder* d, int slot, int c, Slot** s, int* w, int* h, size_t* bpp)
+{
+  if (!d || slot < 0 || slot >= DE265HIP_MAX_DPB_SLOTS || c < 0 || c > 2 || !d->slots[slot].valid)
+    return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  *s = &d->slots[slot];
+  *w = c ? (*s)->w / 2 : (*s)->w; *h = c ? (*s)->h / 2 : (*s)->h;
+  *bpp = px_bytes(c ? (*s)->bdC : (*s)->bdY);
+  return 0;
+}
+
+int de265hip_dpb_upload(de265hip_decoder* d, int slot, int c, const void* src, ptrdiff_t stride_bytes)
+{
+  Slot* s; int w, h; size_t bpp;
+  int rc = plane_geom(d, slot, c, &s, &w, &h, &bpp); if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(d->stream), DE265HIP_ERROR_DECODING);
+  HIPCHK(hipMemcpy2D(s->pl[c].ptr, s->pl[c].stride * bpp, src, (size_t)stride_bytes, w * bpp, h, hipMemcpyHostToDevice),
+         DE265HIP_ERROR_DECODING);
+  return 0;
+}
+
+int de265hip_dpb_download(de265hip_decoder* d, int slot, int c, void* dst, ptrdiff_t stride_bytes)
+{
+  Slot* s; int w, h; size_t bpp;
+  int rc = plane_geom(d, slot, c, &s, &w, &h, &bpp); if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(d->stream), DE265HIP_ERROR_DECODING);
+  HIPCHK(hipMemcpy2D(dst, (size_t)stride_bytes, s->pl[c].ptr, s->pl[c].stride * bpp, w * bpp, h, hipMemcpyDeviceToHost),
+         DE265HIP_ERROR_DECODING);
+  return 0;
+}
+
+int de265hip_dpb_plane(de265hip_decoder* d, int slot, int c, void** dev_ptr, ptrdiff_t* stride_bytes)
+{
+  Slot* s; int w, h; size_t bpp;
+  int rc = plane_geom(d, slot, c, &s, &w, &h, &bpp); if (rc) return rc;
+  if (dev_ptr) *dev_ptr = s->pl[c].ptr;
+  if (stride_bytes) *stride_bytes = (ptrdiff_t)(s->pl[c].stride * bpp);
+  return 0;
+}
+
+void de265hip_picture_free(de265hip_picture* p)
+{
+  if (!p) return;
+  if (p->arena) { (void)hipStreamSynchronize(p->dec->stream); (void)hipFree(p->arena); }
+  delete p;
+}
+
+int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_picture_desc* d,
+                           de265hip_picture** out)
+{
+  if (!dec || !d || !out) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  *out = nullptr;
+  const de265hip_pic_params& p = d->params;
+  if (p.chroma_format_idc != 1) return DE265HIP_ERROR_NOT_IMPLEMENTED;
+  if ((p.bit_depth_luma > 8) != (p.bit_depth_chroma > 8)) return DE265HIP_ERROR_NOT_IMPLEMENTED;
+  if (p.bit_depth_luma < 8 || p.bit_depth_luma > 12 || p.bit_depth_chroma < 8 || p.bit_depth_chroma > 12 ||
+      p.width <= 0 || p.height <= 0 || (p.width & 7) || (p.height & 7) ||
+      p.log2_ctb_size < 4 || p.log2_ctb_size > 6 || p.log2_min_tb_size < 2 || p.log2_min_tb_size > 5 ||
+      p.log2_min_tb_size > p.log2_ctb_size || p.num_tile_columns < 1 || p.num_tile_columns > 20 ||
+      p.num_tile_rows < 1 || p.num_tile_rows > 22 || d->n_slices < 1 || !d->slices || !d->ctbs ||
+      !d->blk_flags || !d->blk_qp_y)
+    return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  if (p.scaling_list_enable_flag && !d->scaling_factors) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  if (dst_slot < 0 || dst_slot >= DE265HIP_MAX_DPB_SLOTS) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  int rc = alloc_slot(dec->slots[dst_slot], p.width, p.height, p.bit_depth_luma, p.bit_depth_chroma);
+  if (rc) return rc;
+  rc = alloc_slot(dec->spare, p.width, p.height, p.bit_depth_luma, p.bit_depth_chroma);
+  if (rc) return rc;
+
+  Geometry g;
+  rc = make_geometry(p, g);
+  if (rc) return rc;
+  if (d->n_ctbs != g.ctbs_w * g.ctbs_h) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  for (int i = 0; i < d->n_ctbs; i++)
+    if (d->ctbs[i].slice_idx >= d->n_slices) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+
+  de265hip_picture* pic = new (std::nothrow) de265hip_picture();
+  if (!pic) return DE265HIP_ERROR_OUT_OF_MEMORY;
+  pic->dec = dec; pic->dst_slot = dst_slot; pic->params = p;
+  PicDev& P = pic->P;
+  P.width = p.width; P.height = p.height; P.bd_luma = p.bit_depth_luma; P.bd_chroma = p.bit_depth_chroma;
+  P.log2_ctb = p.log2_ctb_size; P.ctbs_w = g.ctbs_w; P.ctbs_h = g.ctbs_h; P.w4 = g.w4; P.h4 = g.h4;
+  P.strong_intra = p.strong_intra_smoothing_enable_flag; P.pcm_lf_disable = p.pcm_loop_filter_disable_flag;
+  P.weighted_pred = p.weighted_pred_flag; P.weighted_bipred = p.weighted_bipred_flag;
+  P.cb_qp_offset = p.pic_cb_qp_offset; P.cr_qp_offset = p.pic_cr_qp_offset;
+  P.lf_across_tiles = p.loop_filter_across_tiles_enabled_flag; P.scaling_list = p.scaling_list_enable_flag;
+
+  // ---- TU tasks: availability, dependency level, stable sort by level
+  std::vector<TuTask> tasks; tasks.reserve(d->n_tus);
+  std::vector<int> levels; levels.reserve(d->n_tus);
+  std::vector<uint16_t> lvl[3];
+  const int map_w[3] = { g.w4, (p.width / 2 + 3) / 4, (p.width / 2 + 3) / 4 };
+  const int map_h[3] = { g.h4, (p.height / 2 + 3) / 4, (p.height / 2 + 3) / 4 };
+  for (int c = 0; c < 3; c++) lvl[c].assign((size_t)map_w[c] * map_h[c], 0);
+  int max_level = 0;
+  int64_t alg_resid = 0, alg_intra = 0;
+  for (int i = 0; i < d->n_tus; i++) {
+    const de265hip_tu& tu = d->tus[i];
+    const int nT = 1 << tu.log2_size;
+    const int cw = tu.c_idx ? p.width / 2 : p.width, ch = tu.c_idx ? p.height / 2 : p.height;
+    if (tu.c_idx > 2 || tu.log2_size < 2 || tu.log2_size > 5 || (tu.x0 & 3) || (tu.y0 & 3) ||
+        tu.x0 + nT > cw || tu.y0 + nT > ch || tu.qp < 0 ||
+        ((tu.flags & DE265HIP_TU_CBF) && ((int64_t)tu.coeff_offset + tu.n_coeff > d->n_coeffs || tu.n_coeff > nT * nT))) {
+      delete pic; return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+    }
+    if (tu.flags & DE265HIP_TU_CBF)
+      for (int k = 0; k < tu.n_coeff; k++)
+        if (d->coeff_pos[tu.coeff_offset + k] >= nT * nT) { delete pic; return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE; }
+    if (!(tu.flags & (DE265HIP_TU_INTRA | DE265HIP_TU_CBF))) continue;       // nothing to reconstruct
+    TuTask t; memset(&t, 0, sizeof(t));
+    t.x0 = tu.x0; t.y0 = tu.y0; t.log2_size = tu.log2_size; t.c_idx = tu.c_idx; t.flags = tu.flags;
+    t.intra_mode = tu.intra_mode; t.qp = tu.qp; t.n_coeff = (tu.flags & DE265HIP_TU_CBF) ? tu.n_coeff : 0;
+    t.coeff_offset = tu.coeff_offset;
+    if (t.n_coeff == 0) t.flags &= (uint8_t)~DE265HIP_TU_CBF;
+    int level = 0;
+    const size_t bpp = px_bytes(tu.c_idx ? p.bit_depth_chroma : p.bit_depth_luma);
+    if (tu.flags & DE265HIP_TU_INTRA) {
+      t.avail = intra_availability(*d, g, tu, lvl[tu.c_idx], map_w[tu.c_idx], &level);
+      for (int y = tu.y0 >> 2; y < (tu.y0 + nT) >> 2; y++)
+        for (int x = tu.x0 >> 2; x < (tu.x0 + nT) >> 2; x++) lvl[tu.c_idx][x + (size_t)y * map_w[tu.c_idx]] = (uint16_t)level;
+      alg_intra += (int64_t)bpp * (4 * nT + 1) + (int64_t)bpp * nT * nT;
+      if (level >= 65535) { delete pic; return DE265HIP_ERROR_NOT_IMPLEMENTED; }
+    }
+    if (t.flags & DE265HIP_TU_CBF)
+      alg_resid += std::min<int64_t>(4 * (int64_t)t.n_coeff, 2 * (int64_t)nT * nT) +
+                   ((tu.flags & DE265HIP_TU_INTRA) ? 0 : 2 * (int64_t)bpp * nT * nT);
+    max_level = std::max(max_level, level);
+    tasks.push_back(t); levels.push_back(level);
+  }
+  pic->level_start.assign(max_level + 2, 0);
+  for (int l : levels) pic->level_start[l + 1]++;
+  for (int l = 0; l <= max_level; l++) pic->level_start[l + 1] += pic->level_start[l];
+  std::vector<TuTask> sorted(tasks.size());
+  { std::vector<int> cursor(pic->level_start.begin(), pic->level_start.end() - 1);
+    for (size_t i = 0; i < tasks.size(); i++) sorted[cursor[levels[i]]++] = tasks[i]; }
+  pic->n_tus = (int)sorted.size();
+
+  // ---- MC tasks: resolve references, bi->uni shortcut, split into <=16x16 tiles
+  std::vector<McTask> mcs;
+  int64_t alg_mc = 0;
+  for (int i = 0; i < d->n_pus; i++) {
+    const de265hip_pu& pu = d->pus[i];
+    if (pu.slice_idx >= d->n_slices || pu.w == 0 || pu.h == 0 || (pu.w & 3) || (pu.h & 3) || pu.w > 64 || pu.h > 64 ||
+        (pu.x & 3) || (pu.y & 3) || pu.x + pu.w > p.width || pu.y + pu.h > p.height) {
+      delete pic; return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+    }
+    const de265hip_slice_params& sh = d->slices[pu.slice_idx];
+    int pf[2] = { pu.pred_flag & 1, (pu.pred_flag >> 1) & 1 };
+    bool bad_ref = false;
+    for (int l = 0; l < 2; l++)
+      if (pf[l] && (pu.ref_idx[l] < 0 || pu.ref_idx[l] >= DE265HIP_MAX_REFS)) bad_ref = true;
+    if (bad_ref) continue;                       // motion.cc:344-348: warning, PU left untouched
+    // motion.cc:326-335 (tests weighted_pred_flag also in B slices)
+    if (p.weighted_pred_flag == 0 && pf[0] && pf[1] && pu.mv[0][0] == pu.mv[1][0] && pu.mv[0][1] == pu.mv[1][1] &&
+        sh.ref_pic_list[0][pu.ref_idx[0]] == sh.ref_pic_list[1][pu.ref_idx[1]])
+      pf[1] = 0;
+    if (sh.slice_type == 1) { if (!(pf[0] && !pf[1])) continue; }      // motion.cc:440-500
+    else if (sh.slice_type == 0) { if (!pf[0] && !pf[1]) continue; }
+    else continue;                                                       // I slice carries no PUs
+    McTask t; memset(&t, 0, sizeof(t));
+    t.slice_idx = pu.slice_idx;
+    for (int l = 0; l < 2; l++) {
+      t.slot[l] = -1; t.ref_idx[l] = pu.ref_idx[l];
+      if (!pf[l]) continue;
+      int slot = sh.ref_pic_list[l][pu.ref_idx[l]];
+      if (slot < 0 || slot >= DE265HIP_MAX_DPB_SLOTS || !dec->slots[slot].valid || dec->slots[slot].w != p.width ||
+          dec->slots[slot].h != p.height || dec->slots[slot].bdY != p.bit_depth_luma || slot == dst_slot) {
+        delete pic; return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+      }
+      t.slot[l] = (int8_t)slot; t.mv[l][0] = pu.mv[l][0]; t.mv[l][1] = pu.mv[l][1];
+    }
+    const int nref = (t.slot[0] >= 0) + (t.slot[1] >= 0);
+    const int64_t bppY = px_bytes(p.bit_depth_luma);
+    alg_mc += (int64_t)pu.w * pu.h * 3 / 2 * bppY * (nref + 1);
+    for (int ty = 0; ty < pu.h; ty += 16)
+      for (int tx = 0; tx < pu.w; tx += 16) {
+        McTask q = t;
+        q.x = (uint16_t)(pu.x + tx); q.y = (uint16_t)(pu.y + ty);
+        q.w = (uint8_t)std::min(16, pu.w - tx); q.h = (uint8_t)std::min(16, pu.h - ty);
+        mcs.push_back(q);
+      }
+  }
+  pic->n_mc = (int)mcs.size();
+
+  // ---- PCM tasks
+  std::vector<PcmTask> pcms;
+  for (int i = 0; i < d->n_pcms; i++) {
+    const de265hip_pcm& pc = d->pcms[i];
+    const int n = 1 << pc.log2_cb_size;
+    if (pc.log2_cb_size < 3 || pc.log2_cb_size > 5 || (pc.x0 & 7) || (pc.y0 & 7) || pc.x0 + n > p.width ||
+        pc.y0 + n > p.height || (int64_t)pc.sample_offset + n * n * 3 / 2 > d->n_pcm_samples) {
+      delete pic; return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+    }
+    PcmTask t; t.x0 = pc.x0; t.y0 = pc.y0; t.log2_cb_size = pc.log2_cb_size; t.sample_offset = pc.sample_offset;
+    pcms.push_back(t);
+  }
+  pic->n_pcm = (int)pcms.size();
+
+  const size_t nblk = (size_t)g.w4 * g.h4;
+  for (size_t i = 0; i < nblk && !pic->any_edges; i++) pic->any_edges = (d->blk_flags[i] & 0xF0) != 0;
+
+  // ---- one arena, one upload
+  ArenaLayout L;
+  const size_t o_tus = L.add(sorted.size() * sizeof(TuTask));
+  const size_t o_cval = L.add((size_t)d->n_coeffs * 2), o_cpos = L.add((size_t)d->n_coeffs * 2);
+  const size_t o_scal = L.add(DE265HIP_SCALING_BLOB_BYTES);
+  const size_t o_mc = L.add(mcs.size() * sizeof(McTask));
+  const size_t o_pcm = L.add(pcms.size() * sizeof(PcmTask)), o_pcms = L.add((size_t)d->n_pcm_samples * 2);
+  const size_t o_sl = L.add((size_t)d->n_slices * sizeof(de265hip_slice_params));
+  const size_t o_ctb = L.add((size_t)d->n_ctbs * sizeof(de265hip_ctb_info));
+  const size_t o_tile = L.add((size_t)d->n_ctbs * 2);
+  const size_t o_flags = L.add(nblk), o_qp = L.add(nblk), o_mot = L.add(nblk * sizeof(de265hip_motion));
+  const size_t o_bs = L.add(nblk);
+  std::vector<uint8_t> host(L.total, 0);
+  auto put = [&](size_t off, const void* src, size_t bytes) { if (bytes && src) memcpy(host.data() + off, src, bytes); };
+  put(o_tus, sorted.data(), sorted.size() * sizeof(TuTask));
+  put(o_cval, d->coeff_val, (size_t)d->n_coeffs * 2); put(o_cpos, d->coeff_pos, (size_t)d->n_coeffs * 2);
+  if (p.scaling_list_enable_flag) put(o_scal, d->scaling_factors, DE265HIP_SCALING_BLOB_BYTES);
+  put(o_mc, mcs.data(), mcs.size() * sizeof(McTask));
+  put(o_pcm, pcms.data(), pcms.size() * sizeof(PcmTask)); put(o_pcms, d->pcm_samples, (size_t)d->n_pcm_samples * 2);
+  put(o_sl, d->slices, (size_t)d->n_slices * sizeof(de265hip_slice_params));
+  put(o_ctb, d->ctbs, (size_t)d->n_ctbs * sizeof(de265hip_ctb_info));
+  put(o_tile, g.tile_id.data(), (size_t)d->n_ctbs * 2);
+  put(o_flags, d->blk_flags, nblk); put(o_qp, d->blk_qp_y, nblk);
+  if (d->blk_motion) put(o_mot, d->blk_motion, nblk * sizeof(de265hip_motion));
+  else memset(host.data() + o_mot, 0xFF, nblk * sizeof(de265hip_motion));       // ref_slot = -1 everywhere
+
+  if (hipMalloc(&pic->arena, L.total) != hipSuccess) { delete pic; return DE265HIP_ERROR_OUT_OF_MEMORY; }
+  pic->arena_bytes = L.total;
+  if (hipMemcpy(pic->arena, host.data(), L.total, hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(pic->arena); delete pic; return DE265HIP_ERROR_DECODING;
+  }
+  uint8_t* base = (uint8_t*)pic->arena;
+  pic->d_tus = (TuTask*)(base + o_tus);
+  pic->d_cval = (int16_t*)(base + o_cval); pic->d_cpos = (uint16_t*)(base + o_cpos);
+  pic->d_scaling = base + o_scal;
+  pic->d_mc = (McTask*)(base + o_mc);
+  pic->d_pcm = (PcmTask*)(base + o_pcm); pic->d_pcm_samples = (uint16_t*)(base + o_pcms);
+  pic->d_slices = (de265hip_slice_params*)(base + o_sl);
+  pic->d_ctbs = (de265hip_ctb_info*)(base + o_ctb);
+  pic->d_tile_id = (uint16_t*)(base + o_tile);
+  pic->d_flags = base + o_flags; pic->d_qp = (int8_t*)(base + o_qp);
+  pic->d_motion = (de265hip_motion*)(base + o_mot);
+  pic->d_bs = base + o_bs;
+
+  const int64_t Pbytes = (int64_t)p.width * p.height * 3 / 2 * px_bytes(p.bit_depth_luma);
+  pic->stats.n_levels = max_level + (pic->level_start[1] > 0 ? 1 : 0);
+  pic->stats.n_tu_tasks = pic->n_tus; pic->stats.n_mc_tasks = pic->n_mc;
+  pic->stats.device_bytes = (int64_t)L.total;
+  pic->stats.alg_bytes_mc = alg_mc; pic->stats.alg_bytes_resid = alg_resid; pic->stats.alg_bytes_intra = alg_intra;
+  pic->stats.alg_bytes_deblock = pic->any_edges ? 2 * Pbytes : 0;       // one read + one write
+  pic->stats.alg_bytes_sao = p.sample_adaptive_offset_enabled_flag ? 2 * Pbytes + 16 * (int64_t)d->n_ctbs : 0;
+  *out = pic;
+  return DE265HIP_OK;
+}
+
+int de265hip_picture_get_stats(const de265hip_picture* p, de265hip_picture_stats* s)
+{
+  if (!p || !s) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  *s = p->stats;
+  return 0;
+}
+
+}  // extern "C"
+
+namespace {
+
+struct KTimer {
+  de265hip_decoder* d; int kid; hipEvent_t a = nullptr, b = nullptr; bool on;
+  KTimer(de265hip_decoder* dec, int k, int n_launches) : d(dec), kid(k), on(dec->profiling)
+  {
+    d->launches[kid] += n_launches;
+    if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, d->stream); }
+  }
+  ~KTimer() { if (on) { (void)hipEventRecord(b, d->stream); d->pending.push_back({ kid, a, b }); } }
+};
+
+template <typename PX>
+int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
+{
+  Slot& dst = dec->slots[pic->dst_slot];
+  if (!dst.valid) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  hipStream_t st = dec->stream;
+  const PicDev& P = pic->P;
+  const PlaneRef d0 = dst.pl[0], d1 = dst.pl[1], d2 = dst.pl[2];
+
+  if (pic->n_mc) {
+    DpbTable tab; memset(&tab, 0, sizeof(tab));
+    for (int s = 0; s < DE265HIP_MAX_DPB_SLOTS; s++)
+      if (dec->slots[s].valid) for (int c = 0; c < 3; c++) tab.p[s][c] = dec->slots[s].pl[c];
+    KTimer t(dec, DE265HIP_K_MC, 1);
+    hipLaunchKernelGGL(k_mc<PX>, dim3(pic->n_mc), dim3(64), 0, st, P, tab, d0, d1, d2, pic->d_mc, pic->d_slices);
+  }
+  if (pic->n_pcm) {
+    KTimer t(dec, DE265HIP_K_PCM, 1);
+    hipLaunchKernelGGL(k_pcm<PX>, dim3(pic->n_pcm), dim3(256), 0, st, d0, d1, d2, pic->d_pcm, pic->d_pcm_samples);
+  }
+  const int nlev = (int)pic->level_start.size() - 1;
+  if (nlev > 0 && pic->level_start[1] > pic->level_start[0]) {
+    KTimer t(dec, DE265HIP_K_RESID, 1);
+    hipLaunchKernelGGL(k_tu<PX>, dim3(pic->level_start[1] - pic->level_start[0]), dim3(64), 0, st, P, d0, d1, d2,
+                       pic->d_tus, pic->level_start[0], pic->d_cval, pic->d_cpos, pic->d_scaling);
+  }
+  if (nlev > 1) {
+    KTimer t(dec, DE265HIP_K_INTRA, nlev - 1);
+    for (int l = 1; l < nlev; l++) {
+      int cnt = pic->level_start[l + 1] - pic->level_start[l];
+      if (cnt <= 0) continue;
+      hipLaunchKernelGGL(k_tu<PX>, dim3(cnt), dim3(64), 0, st, P, d0, d1, d2, pic->d_tus, pic->level_start[l],
+                         pic->d_cval, pic->d_cpos, pic->d_scaling);
+    }
+  }
+  if (last_stage >= DE265HIP_STAGE_DEBLOCKED && !pic->params.disable_deblocking && pic->any_edges) {
+    {
+      KTimer t(dec, DE265HIP_K_BS, 1);
+      hipLaunchKernelGGL(k_bs, dim3((P.w4 + 255) / 256, P.h4), dim3(256), 0, st, P, pic->d_flags, pic->d_motion, pic->d_bs);
+    }
+    LfMeta M{ pic->d_flags, pic->d_qp, pic->d_bs, pic->d_ctbs, pic->d_slices };
+    {
+      KTimer t(dec, DE265HIP_K_DEBLOCK_V, 1);
+      hipLaunchKernelGGL((k_deblock<PX, true>), dim3(((P.w4 + 1) / 2 + 255) / 256, P.h4, 3), dim3(256), 0, st, P, d0, d1, d2, M);
+    }
+    {
+      KTimer t(dec, DE265HIP_K_DEBLOCK_H, 1);
+      hipLaunchKernelGGL((k_deblock<PX, false>), dim3((P.w4 + 255) / 256, (P.h4 + 1) / 2, 3), dim3(256), 0, st, P, d0, d1, d2, M);
+    }
+  }
+  if (last_stage >= DE265HIP_STAGE_FINAL && !pic->params.disable_sao && pic->params.sample_adaptive_offset_enabled_flag) {
+    Slot& sp = dec->spare;
+    SaoMeta M{ pic->d_flags, pic->d_ctbs, pic->d_slices, pic->d_tile_id };
+    {
+      KTimer t(dec, DE265HIP_K_SAO, 1);
+      hipLaunchKernelGGL(k_sao<PX>, dim3((P.width / 8 + 255) / 256, P.height, 3), dim3(256), 0, st, P, d0, d1, d2,
+                         sp.pl[0], sp.pl[1], sp.pl[2], M);
+    }
+    for (int c = 0; c < 3; c++) std::swap(dst.pl[c], sp.pl[c]);      // output picture now lives in the slot
+  }
+  if (hipGetLastError() != hipSuccess) return DE265HIP_ERROR_DECODING;
+  return DE265HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int de265hip_picture_run(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
+{
+  if (!dec || !pic || pic->dec != dec || last_stage < 0 || last_stage > 2) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  if (pic->P.bd_luma > 8) return run_picture<uint16_t>(dec, pic, last_stage);
+  return run_picture<uint8_t>(dec, pic, last_stage);
+}
+
+int de265hip_decoder_sync(de265hip_decoder* dec)
+{
+  if (!dec) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  HIPCHK(hipStreamSynchronize(dec->stream), DE265HIP_ERROR_DECODING);
+  return 0;
+}
+
+int de265hip_decode_picture(de265hip_decoder* dec, int dst_slot, const de265hip_picture_desc* d)
+{
+  de265hip_picture* pic = nullptr;
+  int rc = de265hip_picture_build(dec, dst_slot, d, &pic);
+  if (rc) return rc;
+  rc = de265hip_picture_run(dec, pic, DE265HIP_STAGE_FINAL);
+  int rc2 = de265hip_decoder_sync(dec);
+  de265hip_picture_free(pic);
+  return rc ? rc : rc2;
+}
+
+int de265hip_set_profiling(de265hip_decoder* dec, int enable)
+{
+  if (!dec) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  dec->profiling = enable != 0;
+  return 0;
+}
+
+int de265hip_get_kernel_times(de265hip_decoder* dec, double ms[DE265HIP_K_COUNT],
+                              int64_t launches[DE265HIP_K_COUNT], int reset)
+{
+  if (!dec) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  HIPCHK(hipStreamSynchronize(dec->stream), DE265HIP_ERROR_DECODING);
+  for (auto& e : dec->pending) {
+    float t = 0;
+    if (hipEventElapsedTime(&t, e.a, e.b) == hipSuccess) dec->ms[e.kid] += t;
+    (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+  }
+  dec->pending.clear();
+  for (int k = 0; k < DE265HIP_K_COUNT; k++) {
+    if (ms) ms[k] = dec->ms[k];
+    if (launches) launches[k] = dec->launches[k];
+    if (reset) { dec->ms[k] = 0; dec->launches[k] = 0; }
+  }
+  return 0;
+}
+
+// ---- a11 host helper: derive_edgeFlags (deblock.cc:31-225)
+int de265hip_derive_edge_flags(const de265hip_pic_params* pp, const de265hip_slice_params* slices, int n_slices,
+                               const de265hip_ctb_info* ctbs, const uint8_t* cb_log2_size,
+                               const uint8_t* cb_part_mode, const uint8_t* tu_split, uint8_t* blk_flags)
+{
+  if (!pp || !slices || !ctbs || !cb_log2_size || !cb_part_mode || !tu_split || !blk_flags)
+    return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  const de265hip_pic_params& p = *pp;
+  Geometry g;
+  int rc = make_geometry(p, g);
+  if (rc) return rc;
+  const int w4 = g.w4, h4 = g.h4;
+  const int mincb = 1 << p.log2_min_cb_size;
+  const int cbs_w = (p.width + mincb - 1) / mincb, cbs_h = (p.height + mincb - 1) / mincb;
+  auto mark = [&](int x, int y, int bits) {
+    int xd = x >> 2, yd = y >> 2;
+    if (bits && xd < w4 && yd < h4) blk_flags[xd + yd * w4] |= (uint8_t)bits;
+  };
+  struct Node { int x, y, log2, depth, left, top; };
+  std::vector<Node> stack;
+  for (int cy = 0; cy < cbs_h; cy++)
+    for (int cx = 0; cx < cbs_w; cx++) {
+      const int lcb = cb_log2_size[cx + cy * cbs_w];
+      if (!lcb) continue;
+      const int x0 = cx * mincb, y0 = cy * mincb;
+      const int ctb_a = (x0 >> p.log2_ctb_size) + (y0 >> p.log2_ctb_size) * g.ctbs_w;
+      if (ctbs[ctb_a].slice_idx >= n_slices) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+      const de265hip_slice_params& sh = slices[ctbs[ctb_a].slice_idx];
+      int left = x0 ? DE265HIP_BLK_EDGE_TU_V : 0, top = y0 ? DE265HIP_BLK_EDGE_TU_H : 0;
+      const int mask = (1 << p.log2_ctb_size) - 1;
+      if (x0 && !(x0 & mask)) {
+        const int nb = ctb_a - 1;
+        if (!sh.slice_loop_filter_across_slices_enabled_flag && ctbs[nb].slice_addr_rs != ctbs[ctb_a].slice_addr_rs) left = 0;
+        else if (!p.loop_filter_across_tiles_enabled_flag && g.tile_id[nb] != g.tile_id[ctb_a]) left = 0;
+      }
+      if (y0 && !(y0 & mask)) {
+        const int nb = ctb_a - g.ctbs_w;
+        if (!sh.slice_loop_filter_across_slices_enabled_flag && ctbs[nb].slice_addr_rs != ctbs[ctb_a].slice_addr_rs) top = 0;
+        else if (!p.loop_filter_across_tiles_enabled_flag && g.tile_id[nb] != g.tile_id[ctb_a]) top = 0;
+      }
+      if (sh.slice_deblocking_filter_disabled_flag) continue;
+      // transform tree walk (markTransformBlockBoundary)
+      stack.clear(); stack.push_back({ x0, y0, lcb, 0, left, top });
+      while (!stack.empty()) {
+        Node n = stack.back(); stack.pop_back();
+        const int split = (tu_split[(n.x >> p.log2_min_tb_size) + (n.y >> p.log2_min_tb_size) * g.tbs_w] >> n.depth) & 1;
+        if (split) {
+          const int hh = 1 << (n.log2 - 1);
+          stack.push_back({ n.x, n.y, n.log2 - 1, n.depth + 1, n.left, n.top });
+          stack.push_back({ n.x + hh, n.y, n.log2 - 1, n.depth + 1, DE265HIP_BLK_EDGE_TU_V, n.top });
+          stack.push_back({ n.x, n.y + hh, n.log2 - 1, n.depth + 1, n.left, DE265HIP_BLK_EDGE_TU_H });
+          stack.push_back({ n.x + hh, n.y + hh, n.log2 - 1, n.depth + 1, DE265HIP_BLK_EDGE_TU_V, DE265HIP_BLK_EDGE_TU_H });
+        } else {
+          for (int k = 0; k < (1 << n.log2); k += 4) { mark(n.x, n.y + k, n.left); mark(n.x + k, n.y, n.top); }
+        }
+      }
+      // prediction block boundaries (markPredictionBlockBoundary)
+      const int cb = 1 << lcb, h2 = cb >> 1, q4 = cb >> 2;
+      int vx = -1, hy = -1, vx2 = -1;
+      switch (cb_part_mode[cx + cy * cbs_w]) {
+        case 1: hy = h2; break;            // PART_2NxN
+        case 2: vx = h2; break;            // PART_Nx2N
+        case 3: vx = h2; hy = h2; break;   // PART_NxN
+        case 4: hy = q4; break;            // PART_2NxnU
+        case 5: hy = h2 + q4; break;       // PART_2NxnD
+        case 6: vx = q4; break;            // PART_nLx2N
+        case 7: vx = h2 + q4; break;       // PART_nRx2N
+        default: break;
+      }
+      (void)vx2;
+      for (int k = 0; k < cb; k += 4) {
+        if (vx >= 0) mark(x0 + vx, y0 + k, DE265HIP_BLK_EDGE_PB_V);
+        if (hy >= 0) mark(x0 + k, y0 + hy, DE265HIP_BLK_EDGE_PB_H);
+      }
+    }
+  return 0;
+}
+
+// ------------------------------------------------------------------ Part B
+namespace {
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t n) { return hipMalloc(&p, n ? n : 1) == hipSuccess ? 0 : DE265HIP_ERROR_OUT_OF_MEMORY; }
+};
+int fn_check_blocks(int n, const int32_t* xy, int w, int h, int pw, int ph, int mx0, int my0, int mx1, int my1)
+{
+  if (n < 0 || (n && !xy)) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  for (int i = 0; i < n; i++) {
+    int x = xy[2 * i], y = xy[2 * i + 1];
+    if (x - mx0 < 0 || y - my0 < 0 || x + w + mx1 > pw || y + h + my1 > ph) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  }
+  return 0;
+}
+}  // namespace
+
+static int fn_residual(int kind, int log2_size, int bit_depth, void* plane, ptrdiff_t stride, int plane_h, int n,
+                       const int32_t* xy, const int16_t* coeffs)
+{
+  if (!plane || !coeffs || log2_size < 2 || log2_size > 5 || bit_depth < 8 || bit_depth > 12 || stride <= 0 ||
+      (kind == 1 && log2_size != 2))
+    return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  const int nT = 1 << log2_size;
+  int rc = fn_check_blocks(n, xy, nT, nT, (int)stride, plane_h, 0, 0, 0, 0);
+  if (rc || n == 0) return rc;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return DE265HIP_ERROR_INIT_FAILED;
+  const size_t bpp = px_bytes(bit_depth), pbytes = (size_t)stride * plane_h * bpp;
+  DevBuf dp, dxy, dc;
+  if (dp.alloc(pbytes) || dxy.alloc((size_t)n * 8) || dc.alloc((size_t)n * nT * nT * 2)) return DE265HIP_ERROR_OUT_OF_MEMORY;
+  HIPCHK(hipMemcpy(dp.p, plane, pbytes, hipMemcpyHostToDevice), DE265HIP_ERROR_DECODING);
+  HIPCHK(hipMemcpy(dxy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice), DE265HIP_ERROR_DECODING);
+  HIPCHK(hipMemcpy(dc.p, coeffs, (size_t)n * nT * nT * 2, hipMemcpyHostToDevice), DE265HIP_ERROR_DECODING);
+  if (bit_depth > 8)
+    hipLaunchKernelGGL(k_fn_residual<uint16_t>, dim3(n), dim3(64), 0, 0, kind, log2_size, bit_depth, (uint16_t*)dp.p,
+                       (int)stride, (const int32_t*)dxy.p, (const int16_t*)dc.p);
+  else
+    hipLaunchKernelGGL(k_fn_residual<uint8_t>, dim3(n), dim3(64), 0, 0, kind, log2_size, bit_depth, (uint8_t*)dp.p,
+                       (int)stride, (const int32_t*)dxy.p, (const int16_t*)dc.p);
+  HIPCHK(hipDeviceSynchronize(), DE265HIP_ERROR_DECODING);
+  HIPCHK(hipMemcpy(plane, dp.p, pbytes, hipMemcpyDeviceToHost), DE265HIP_ERROR_DECODING);
+  return 0;
+}
+
+int de265hip_fn_transform_add(int log2_size, int dst_type, int bit_depth, void* plane, ptrdiff_t stride, int plane_h,
+                              int n, const int32_t* xy, const int16_t* coeffs)
+{ return fn_residual(dst_type ? 1 : 0, log2_size, bit_depth, plane, stride, plane_h, n, xy, coeffs); }
+int de265hip_fn_transform_skip_add(int log2_size, int bit_depth, void* plane, ptrdiff_t stride, int plane_h, int n,
+                                   const int32_t* xy, const int16_t* coeffs)
+{ return fn_residual(2, log2_size, bit_depth, plane, stride, plane_h, n, xy, coeffs); }
+int de265hip_fn_transform_bypass_add(int log2_size, int bit_depth, void* plane, ptrdiff_t stride, int plane_h, int n,
+                                     const int32_t* xy, const int16_t* coeffs)
+{ return fn_residual(3, log2_size, bit_depth, plane, stride, plane_h, n, xy, coeffs); }
+
+static int fn_interp(int luma, int bit_depth, const void* plane, ptrdiff_t stride, int pw, int ph, int w, int h,
+                     int fx, int fy, int n, const int32_t* xy, int16_t* out)
+{
+  if (!plane || !out || bit_depth < 8 || bit_depth > 12 || w <= 0 || h <= 0 || w > 64 || h > 64 || stride < pw ||
+      fx < 0 || fy < 0 || fx > (luma ? 3 : 7) || fy > (luma ? 3 : 7))
+    return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  // the vtable contract: source block including filter margins lies inside the plane
+  const int b = luma ? 3 : 1, a = luma ? 4 : 2;
+  int rc = fn_check_blocks(n, xy, w, h, pw, ph, fx ? b : 0, fy ? b : 0, fx ? a : 0, fy ? a : 0);
+  if (rc || n == 0) return rc;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return DE265HIP_ERROR_INIT_FAILED;
+  const size_t bpp = px_bytes(bit_depth), pbytes = (size_t)stride * ph * bpp, obytes = (size_t)n * w * h * 2;
+  DevBuf dp, dxy, dout;
+  if (dp.alloc(pbytes) || dxy.alloc((size_t)n * 8) || dout.alloc(obytes)) return DE265HIP_ERROR_OUT_OF_MEMORY;
+  HIPCHK(hipMemcpy(dp.p, plane, pbytes, hipMemcpyHostToDevice), DE265HIP_ERROR_DECODING);
+  HIPCHK(hipMemcpy(dxy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice), DE265HIP_ERROR_DECODING);
+  if (bit_depth > 8)
+    hipLaunchKernelGGL(k_fn_interp<uint16_t>, dim3(n), dim3(64), 0, 0, luma, bit_depth, (const uint16_t*)dp.p, (int)stride,
+                       pw, ph, w, h, fx, fy, (const int32_t*)dxy.p, (int16_t*)dout.p);
+  else
+    hipLaunchKernelGGL(k_fn_interp<uint8_t>, dim3(n), dim3(64), 0, 0, luma, bit_depth, (const uint8_t*)dp.p, (int)stride,
+                       pw, ph, w, h, fx, fy, (const int32_t*)dxy.p, (int16_t*)dout.p);
+  HIPCHK(hipDeviceSynchronize(), DE265HIP_ERROR_DECODING);
+  HIPCHK(hipMemcpy(out, dout.p, obytes, hipMemcpyDeviceToHost), DE265HIP_ERROR_DECODING);
+  return 0;
+}
+
+int de265hip_fn_put_qpel(int bit_depth, const void* src_plane, ptrdiff_t stride, int pw, int ph, int w, int h,
+                         int dx, int dy, int n, const int32_t* xy, int16_t* out)
+{ return fn_interp(1, bit_depth, src_plane, stride, pw, ph, w, h, dx, dy, n, xy, out); }
+int de265hip_fn_put_epel(int bit_depth, const void* src_plane, ptrdiff_t stride, int pw, int ph, int w, int h,
+                         int mx, int my, int n, const int32_t* xy, int16_t* out)
+{ return fn_interp(0, bit_depth, src_plane, stride, pw, ph, w, h, mx, my, n, xy, out); }
+
+int de265hip_fn_put_pred(int mode, int bit_depth, void* plane, ptrdiff_t stride, int plane_h, int w, int h, int n,
+                         const int32_t* xy, const int16_t* src0, const int16_t* src1, int w0, int o0, int w1, int o1,
+                         int log2wd)
+{
+  if (!plane || !src0 || mode < 0 || mode > 3 || ((mode == 2 || mode == 3) && !src1) || bit_depth < 8 ||
+      bit_depth > 12 || w <= 0 || h <= 0 || stride <= 0 || ((mode == 1 || mode == 3) && log2wd < 1))
+    return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  int rc = fn_check_blocks(n, xy, w, h, (int)stride, plane_h, 0, 0, 0, 0);
+  if (rc || n == 0) return rc;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return DE265HIP_ERROR_INIT_FAILED;
+  const size_t bpp = px_bytes(bit_depth), pbytes = (size_t)stride * plane_h * bpp, sbytes = (size_t)n * w * h * 2;
+  DevBuf dp, dxy, d0, d1;
+  if (dp.alloc(pbytes) || dxy.alloc((size_t)n * 8) || d0.alloc(sbytes) || d1.alloc(sbytes)) return DE265HIP_ERROR_OUT_OF_MEMORY;
+  HIPCHK(hipMemcpy(dp.p, plane, pbytes, hipMemcpyHostToDevice), DE265HIP_ERROR_DECODING);
+  HIPCHK(hipMemcpy(dxy.p, xy, (size_t)n * 8, hipMemcpyHostToDevice), DE265HIP_ERROR_DECODING);
+  HIPCHK(hipMemcpy(d0.p, src0, sbytes, hipMemcpyHostToDevice), DE265HIP_ERROR_DECODING);
+  if (src1) HIPCHK(hipMemcpy(d1.p, src1, sbytes, hipMemcpyHostToDevice), DE265HIP_ERROR_DECODING);
+  if (bit_depth > 8)
+    hipLaunchKernelGGL(k_fn_put<uint16_t>, dim3(n), dim3(64), 0, 0, mode, bit_depth, (uint16_t*)dp.p, (int)stride, w, h,
+                       (const int32_t*)dxy.p, (const int16_t*)d0.p, src1 ? (const int16_t*)d1.p : nullptr, w0, o0, w1, o1, log2wd);
+  else
+    hipLaunchKernelGGL(k_fn_put<uint8_t>, dim3(n), dim3(64), 0, 0, mode, bit_depth, (uint8_t*)dp.p, (int)stride, w, h,
+                       (const int32_t*)dxy.p, (const int16_t*)d0.p, src1 ? (const int16_t*)d1.p : nullptr, w0, o0, w1, o1, log2wd);
+  HIPCHK(hipDeviceSynchronize(), DE265HIP_ERROR_DECODING);
+  HIPCHK(hipMemcpy(plane, dp.p, pbytes, hipMemcpyDeviceToHost), DE265HIP_ERROR_DECODING);
+  return 0;
+}
+
+}  // extern "C"

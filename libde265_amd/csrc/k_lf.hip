@@ -1,0 +1,362 @@
+// k_lf.hip -- in-loop filter kernels for gfx950: boundary strength, deblocking
+// edge filters (luma + chroma, vertical and horizontal pass) and SAO.
+//
+// HBM-bound streaming kernels: one lane owns one 8x4 (luma) edge segment and
+// moves it with 8-byte vector accesses; lanes run along x so that every row a
+// wavefront touches is one contiguous span.  Behaviour follows (libde265/):
+//   deblock.cc:241-375  derive_boundaryStrength
+//   deblock.cc:405-699  edge_filtering_luma_internal
+//   deblock.cc:730-871  edge_filtering_chroma_internal
+//   sao.cc:29-254       apply_sao_internal
+#include "kernels.h"
+
+namespace d265 {
+
+__device__ __constant__ uint8_t c_beta[52] = {
+  0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0, 6,7,8,9,10,11,12,13,14,15,16,17,18,
+  20,22,24,26,28,30,32,34,36,38,40,42,44,46,48,50,52,54,56,58,60,62,64 };
+__device__ __constant__ uint8_t c_tc[54] = {
+  0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0, 1,1,1,1,1,1,1,1,1, 2,2,2,2, 3,3,3,3, 4,4,4,
+  5,5, 6,6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24 };
+__device__ __constant__ uint8_t c_qpc[14] = { 29,30,31,32,33,33,34,34,35,35,36,36,37,37 };
+
+__device__ __forceinline__ int lf_clip3(int lo, int hi, int v) { return min(max(v, lo), hi); }
+__device__ __forceinline__ int lf_qpc(int q) { return q < 30 ? q : (q >= 43 ? q - 6 : c_qpc[q - 30]); }
+
+// ---------------------------------------------------------------- bS
+// One lane per 4x4 unit; bits 0-1: bS of the vertical edge on the unit's left
+// side (x on the 8-sample grid), bits 2-3: bS of the horizontal edge on top.
+__device__ __forceinline__ int bs_motion(const de265hip_motion& mP, const de265hip_motion& mQ)
+{
+  int rP0 = mP.ref_slot[0], rP1 = mP.ref_slot[1], rQ0 = mQ.ref_slot[0], rQ1 = mQ.ref_slot[1];
+  bool same = (rP0 == rQ0 && rP1 == rQ1) || (rP0 == rQ1 && rP1 == rQ0);
+  if (!same) return 1;
+  int p0x = rP0 >= 0 ? mP.mv[0][0] : 0, p0y = rP0 >= 0 ? mP.mv[0][1] : 0;
+  int p1x = rP1 >= 0 ? mP.mv[1][0] : 0, p1y = rP1 >= 0 ? mP.mv[1][1] : 0;
+  int q0x = rQ0 >= 0 ? mQ.mv[0][0] : 0, q0y = rQ0 >= 0 ? mQ.mv[0][1] : 0;
+  int q1x = rQ1 >= 0 ? mQ.mv[1][0] : 0, q1y = rQ1 >= 0 ? mQ.mv[1][1] : 0;
+  bool d00 = abs(p0x - q0x) >= 4 || abs(p0y - q0y) >= 4 || abs(p1x - q1x) >= 4 || abs(p1y - q1y) >= 4;
+  bool d01 = abs(p0x - q1x) >= 4 || abs(p0y - q1y) >= 4 || abs(p1x - q0x) >= 4 || abs(p1y - q0y) >= 4;
+  if (rP0 != rP1) return (rP0 == rQ0) ? d00 : d01;
+  return d00 && d01;
+}
+
+__global__ __launch_bounds__(256)
+void k_bs(PicDev P, const uint8_t* __restrict__ flags, const de265hip_motion* __restrict__ motion,
+          uint8_t* __restrict__ bs)
+{
+  int x = blockIdx.x * blockDim.x + threadIdx.x;
+  int y = blockIdx.y;
+  if (x >= P.w4) return;
+  int idx = x + y * P.w4;
+  int f = flags[idx];
+  int out = 0;
+  if (!(x & 1) && (f & (DE265HIP_BLK_EDGE_TU_V | DE265HIP_BLK_EDGE_PB_V)) && x > 0) {
+    int fp = flags[idx - 1];
+    int b;
+    if ((f | fp) & DE265HIP_BLK_INTRA) b = 2;
+    else if ((f & DE265HIP_BLK_EDGE_TU_V) && ((f | fp) & DE265HIP_BLK_NONZERO)) b = 1;
+    else b = bs_motion(motion[idx - 1], motion[idx]);
+    out |= b;
+  }
+  if (!(y & 1) && (f & (DE265HIP_BLK_EDGE_TU_H | DE265HIP_BLK_EDGE_PB_H)) && y > 0) {
+    int fp = flags[idx - P.w4];
+    int b;
+    if ((f | fp) & DE265HIP_BLK_INTRA) b = 2;
+    else if ((f & DE265HIP_BLK_EDGE_TU_H) && ((f | fp) & DE265HIP_BLK_NONZERO)) b = 1;
+    else b = bs_motion(motion[idx - P.w4], motion[idx]);
+    out |= b << 2;
+  }
+  bs[idx] = (uint8_t)out;
+}
+
+// ---------------------------------------------------------------- vector helpers
+template <typename PX> struct Vec4;
+template <> struct Vec4<uint16_t> { typedef uint2 T; };
+template <> struct Vec4<uint8_t> { typedef uint32_t T; };
+
+template <typename PX>
+__device__ __forceinline__ void load4(const PX* p, int v[4])
+{
+  typename Vec4<PX>::T raw = *reinterpret_cast<const typename Vec4<PX>::T*>(p);
+  if constexpr (sizeof(PX) == 2) {
+    v[0] = raw.x & 0xFFFF; v[1] = raw.x >> 16; v[2] = raw.y & 0xFFFF; v[3] = raw.y >> 16;
+  } else {
+    v[0] = raw & 0xFF; v[1] = (raw >> 8) & 0xFF; v[2] = (raw >> 16) & 0xFF; v[3] = raw >> 24;
+  }
+}
+template <typename PX>
+__device__ __forceinline__ void store4(PX* p, const int v[4])
+{
+  typename Vec4<PX>::T raw;
+  if constexpr (sizeof(PX) == 2) {
+    raw.x = (uint32_t)v[0] | ((uint32_t)v[1] << 16); raw.y = (uint32_t)v[2] | ((uint32_t)v[3] << 16);
+  } else {
+    raw = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+  }
+  *reinterpret_cast<typename Vec4<PX>::T*>(p) = raw;
+}
+
+__device__ __forceinline__ bool lf_exempt(const PicDev& P, int f)
+{ return ((f & DE265HIP_BLK_PCM) && P.pcm_lf_disable) || (f & DE265HIP_BLK_BYPASS); }
+
+// Luma filter of one segment held as p[line][i], q[line][i] (i = distance from the edge).
+__device__ __forceinline__ bool luma_filter_segment(int p[4][4], int q[4][4], int beta, int tc, int bd,
+                                                    bool filterP, bool filterQ)
+{
+  int dp0 = abs(p[0][2] - 2 * p[0][1] + p[0][0]);
+  int dp3 = abs(p[3][2] - 2 * p[3][1] + p[3][0]);
+  int dq0 = abs(q[0][2] - 2 * q[0][1] + q[0][0]);
+  int dq3 = abs(q[3][2] - 2 * q[3][1] + q[3][0]);
+  int dpq0 = dp0 + dq0, dpq3 = dp3 + dq3;
+  int dp = dp0 + dp3, dq = dq0 + dq3, d = dpq0 + dpq3;
+  if (d >= beta) return false;
+  bool dSam0 = 2 * dpq0 < (beta >> 2) && abs(p[0][3] - p[0][0]) + abs(q[0][0] - q[0][3]) < (beta >> 3) &&
+               abs(p[0][0] - q[0][0]) < ((5 * tc + 1) >> 1);
+  bool dSam3 = 2 * dpq3 < (beta >> 2) && abs(p[3][3] - p[3][0]) + abs(q[3][0] - q[3][3]) < (beta >> 3) &&
+               abs(p[3][0] - q[3][0]) < ((5 * tc + 1) >> 1);
+  bool strong = dSam0 && dSam3;
+  bool dEp = dp < ((beta + (beta >> 1)) >> 3);
+  bool dEq = dq < ((beta + (beta >> 1)) >> 3);
+  const int maxv = (1 << bd) - 1;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    int p0 = p[k][0], p1 = p[k][1], p2 = p[k][2], p3 = p[k][3];
+    int q0 = q[k][0], q1 = q[k][1], q2 = q[k][2], q3 = q[k][3];
+    if (strong) {
+      if (filterP) {
+        p[k][0] = lf_clip3(p0 - 2 * tc, p0 + 2 * tc, (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3);
+        p[k][1] = lf_clip3(p1 - 2 * tc, p1 + 2 * tc, (p2 + p1 + p0 + q0 + 2) >> 2);
+        p[k][2] = lf_clip3(p2 - 2 * tc, p2 + 2 * tc, (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3);
+      }
+      if (filterQ) {
+        q[k][0] = lf_clip3(q0 - 2 * tc, q0 + 2 * tc, (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3);
+        q[k][1] = lf_clip3(q1 - 2 * tc, q1 + 2 * tc, (p0 + q0 + q1 + q2 + 2) >> 2);
+        q[k][2] = lf_clip3(q2 - 2 * tc, q2 + 2 * tc, (p0 + q0 + q1 + 3 * q2 + 2 * q3 + 4) >> 3);
+      }
+    } else {
+      int delta = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
+      if (abs(delta) < tc * 10) {
+        delta = lf_clip3(-tc, tc, delta);
+        if (filterP) p[k][0] = lf_clip3(0, maxv, p0 + delta);
+        if (filterQ) q[k][0] = lf_clip3(0, maxv, q0 - delta);
+        if (dEp && filterP) {
+          int dP = lf_clip3(-(tc >> 1), tc >> 1, (((p2 + p0 + 1) >> 1) - p1 + delta) >> 1);
+          p[k][1] = lf_clip3(0, maxv, p1 + dP);
+        }
+        if (dEq && filterQ) {
+          int dQ = lf_clip3(-(tc >> 1), tc >> 1, (((q2 + q0 + 1) >> 1) - q1 - delta) >> 1);
+          q[k][1] = lf_clip3(0, maxv, q1 + dQ);
+        }
+      }
+    }
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------- deblock
+// blockIdx.z: 0 luma, 1 Cb, 2 Cr.  VERT: vertical edges (filtering across x).
+template <typename PX, bool VERT>
+__global__ __launch_bounds__(256)
+void k_deblock(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, LfMeta M)
+{
+  const int comp = blockIdx.z;
+  const int tx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ty = blockIdx.y;
+  if (comp == 0) {
+    // luma: unit grid; vertical edges at even x, horizontal at even y
+    const int x = VERT ? tx * 2 : tx;
+    const int y = VERT ? ty : ty * 2;
+    if (x >= P.w4 || y >= P.h4) return;
+    const int idx = x + y * P.w4;
+    const int bS = VERT ? (M.bs[idx] & 3) : ((M.bs[idx] >> 2) & 3);
+    if (bS == 0) return;
+    const int xDi = x << 2, yDi = y << 2;
+    const int stride = pl0.stride;
+    PX* ptr = (PX*)pl0.ptr + xDi + yDi * stride;
+    int p[4][4], q[4][4];
+    if (VERT) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        int a[4];
+        load4<PX>(ptr + k * stride - 4, a);
+        p[k][3] = a[0]; p[k][2] = a[1]; p[k][1] = a[2]; p[k][0] = a[3];
+        load4<PX>(ptr + k * stride, q[k]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        int a[4], b[4];
+        load4<PX>(ptr - (i + 1) * stride, a);
+        load4<PX>(ptr + i * stride, b);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { p[k][i] = a[k]; q[k][i] = b[k]; }
+      }
+    }
+    const int pidx = VERT ? idx - 1 : idx - P.w4;
+    const int qP_L = ((int)M.qp[idx] + (int)M.qp[pidx] + 1) >> 1;
+    const de265hip_slice_params* sh =
+      &M.slices[M.ctbs[(xDi >> P.log2_ctb) + (yDi >> P.log2_ctb) * P.ctbs_w].slice_idx];
+    const int bd = P.bd_luma;
+    const int beta = c_beta[lf_clip3(0, 51, qP_L + sh->slice_beta_offset)] * (1 << (bd - 8));
+    const int tc = c_tc[lf_clip3(0, 53, qP_L + 2 * (bS - 1) + sh->slice_tc_offset)] * (1 << (bd - 8));
+    const bool filterP = !lf_exempt(P, M.flags[pidx]);
+    const bool filterQ = !lf_exempt(P, M.flags[idx]);
+    if (!luma_filter_segment(p, q, beta, tc, bd, filterP, filterQ)) return;
+    if (VERT) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        int a[4] = { p[k][3], p[k][2], p[k][1], p[k][0] };
+        if (filterP) store4<PX>(ptr + k * stride - 4, a);
+        if (filterQ) store4<PX>(ptr + k * stride, q[k]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        int a[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { a[k] = p[k][i]; b[k] = q[k][i]; }
+        if (filterP) store4<PX>(ptr - (i + 1) * stride, a);
+        if (filterQ) store4<PX>(ptr + i * stride, b);
+      }
+    }
+  } else {
+    // chroma 4:2:0: edges on the 8-sample chroma grid = every 4th unit across the
+    // edge, one segment of 4 chroma lines = 2 units along it; only bS == 2.
+    const int x = VERT ? tx * 4 : tx * 2;
+    const int y = VERT ? ty * 2 : ty * 4;
+    if (x >= P.w4 || y >= P.h4) return;
+    const int idx = x + y * P.w4;
+    const int bS = VERT ? (M.bs[idx] & 3) : ((M.bs[idx] >> 2) & 3);
+    if (bS < 2) return;
+    const PlaneRef pl = comp == 1 ? pl1 : pl2;
+    const int stride = pl.stride;
+    const int xDi = x << 1, yDi = y << 1;            // chroma samples
+    PX* ptr = (PX*)pl.ptr + xDi + yDi * stride;
+    const int pidx = VERT ? idx - 1 : idx - P.w4;
+    const int cQpPicOffset = comp == 1 ? P.cb_qp_offset : P.cr_qp_offset;
+    const int qPi = (((int)M.qp[idx] + (int)M.qp[pidx] + 1) >> 1) + cQpPicOffset;
+    const int QPc = lf_qpc(qPi);
+    const de265hip_slice_params* sh =
+      &M.slices[M.ctbs[((x << 2) >> P.log2_ctb) + ((y << 2) >> P.log2_ctb) * P.ctbs_w].slice_idx];
+    const int bd = P.bd_chroma;
+    const int maxv = (1 << bd) - 1;
+    const int tc = c_tc[lf_clip3(0, 53, QPc + 2 * (bS - 1) + sh->slice_tc_offset)] * (1 << (bd - 8));
+    const bool filterP = !lf_exempt(P, M.flags[pidx]);
+    const bool filterQ = !lf_exempt(P, M.flags[idx]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      int p0, p1, q0, q1;
+      PX *pp0, *pq0;
+      if (VERT) {
+        PX* row = ptr + k * stride;
+        p1 = row[-2]; p0 = row[-1]; q0 = row[0]; q1 = row[1];
+        pp0 = row - 1; pq0 = row;
+      } else {
+        p1 = ptr[k - 2 * stride]; p0 = ptr[k - stride]; q0 = ptr[k]; q1 = ptr[k + stride];
+        pp0 = ptr + k - stride; pq0 = ptr + k;
+      }
+      int delta = lf_clip3(-tc, tc, ((((q0 - p0) << 2) + p1 - q1 + 4) >> 3));
+      if (filterP) *pp0 = (PX)lf_clip3(0, maxv, p0 + delta);
+      if (filterQ) *pq0 = (PX)lf_clip3(0, maxv, q0 - delta);
+    }
+  }
+}
+
+template __global__ void k_deblock<uint8_t, true>(PicDev, PlaneRef, PlaneRef, PlaneRef, LfMeta);
+template __global__ void k_deblock<uint8_t, false>(PicDev, PlaneRef, PlaneRef, PlaneRef, LfMeta);
+template __global__ void k_deblock<uint16_t, true>(PicDev, PlaneRef, PlaneRef, PlaneRef, LfMeta);
+template __global__ void k_deblock<uint16_t, false>(PicDev, PlaneRef, PlaneRef, PlaneRef, LfMeta);
+
+// ---------------------------------------------------------------- SAO
+// Out of place: src = deblocked picture, dst = output picture (every sample is
+// written, so dst needs no initialisation).  One lane per 8 samples of a row.
+template <typename PX>
+__global__ __launch_bounds__(256)
+void k_sao(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, PlaneRef d1, PlaneRef d2,
+           SaoMeta M)
+{
+  const int comp = blockIdx.z;
+  const int cs = comp ? 1 : 0;
+  const int width = P.width >> cs, height = P.height >> cs;
+  const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  const int y = blockIdx.y;
+  if (x0 >= width || y >= height) return;
+  const PlaneRef sp = comp == 0 ? s0 : (comp == 1 ? s1 : s2);
+  const PlaneRef dp = comp == 0 ? d0 : (comp == 1 ? d1 : d2);
+  const PX* src = (const PX*)sp.ptr;
+  PX* dst = (PX*)dp.ptr;
+  const int sstride = sp.stride, dstride = dp.stride;
+  const int ctbshift = P.log2_ctb - cs;
+  const int ctbX = x0 >> ctbshift, ctbY = y >> ctbshift;
+  const int ctbAddr = ctbX + ctbY * P.ctbs_w;
+  const de265hip_ctb_info ci = M.ctbs[ctbAddr];
+  const de265hip_slice_params* sh = &M.slices[ci.slice_idx];
+  const int bd = comp ? P.bd_chroma : P.bd_luma;
+  const int maxv = (1 << bd) - 1;
+  int type = (ci.sao_type_idx >> (2 * comp)) & 3;
+  if (comp == 0 ? !sh->slice_sao_luma_flag : !sh->slice_sao_chroma_flag) type = 0;
+
+  int cur[8];
+  load4<PX>(src + x0 + y * sstride, cur);
+  load4<PX>(src + x0 + 4 + y * sstride, cur + 4);
+  int out[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) out[i] = cur[i];
+
+  if (type == 1) {
+    const int bandShift = bd - 5;
+    const int left = ci.sao_band_position[comp];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      int xs = x0 + i;
+      if (xs >= width) break;
+      int f = M.flags[((xs << cs) >> 2) + ((y << cs) >> 2) * P.w4];
+      if (lf_exempt(P, f)) continue;
+      int k = ((cur[i] >> bandShift) - left) & 31;         // bandTable[(k+left)&31] = k+1
+      if (k < 4) out[i] = lf_clip3(0, maxv, cur[i] + ci.sao_offset_val[comp][k]);
+    }
+  } else if (type == 2) {
+    const int eo = (ci.sao_eo_class >> (2 * comp)) & 3;
+    const int hx0 = (eo == 1) ? 0 : (eo == 3 ? 1 : -1), hy0 = (eo == 0) ? 0 : -1;
+    const int hx1 = -hx0, hy1 = -hy0;
+    const int ctbSlice = ci.slice_addr_rs;
+    const int tileCur = M.tile_id[ctbAddr];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      int xs = x0 + i;
+      if (xs >= width) break;
+      int f = M.flags[((xs << cs) >> 2) + ((y << cs) >> 2) * P.w4];
+      if (lf_exempt(P, f)) continue;
+      bool ok = true;
+      int nb[2];
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        int xS = xs + (k ? hx1 : hx0), yS = y + (k ? hy1 : hy0);
+        if (xS < 0 || yS < 0 || xS >= width || yS >= height) { ok = false; nb[k] = 0; continue; }
+        int nAddr = (xS >> ctbshift) + (yS >> ctbshift) * P.ctbs_w;
+        if (nAddr != ctbAddr) {
+          const de265hip_ctb_info* nci = &M.ctbs[nAddr];
+          int ns = nci->slice_addr_rs;
+          if (ns < ctbSlice && !sh->slice_loop_filter_across_slices_enabled_flag) ok = false;
+          if (ns > ctbSlice && !M.slices[nci->slice_idx].slice_loop_filter_across_slices_enabled_flag) ok = false;
+          if (!P.lf_across_tiles && M.tile_id[nAddr] != tileCur) ok = false;
+        }
+        nb[k] = src[xS + yS * sstride];
+      }
+      if (!ok) continue;
+      int c = cur[i];
+      int e = (c > nb[0]) - (c < nb[0]) + (c > nb[1]) - (c < nb[1]);
+      // offsets {o1,o2,0,o3,o4} indexed by e+2 (sao.cc:95-100)
+      int off = e == 0 ? 0 : ci.sao_offset_val[comp][e < 0 ? e + 2 : e + 1];
+      out[i] = lf_clip3(0, maxv, c + off);
+    }
+  }
+  store4<PX>(dst + x0 + y * dstride, out);
+  store4<PX>(dst + x0 + 4 + y * dstride, out + 4);
+}
+
+template __global__ void k_sao<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, SaoMeta);
+template __global__ void k_sao<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, SaoMeta);
+
+}  // namespace d265

@@ -1,0 +1,346 @@
+// k_tu.hip -- transform-unit kernel for gfx950: intra prediction (border fetch,
+// substitution, smoothing, planar/DC/angular) fused with dequantisation,
+// inverse DCT/DST / transform-skip / bypass and the residual add.
+//
+// One 64-lane wavefront (= one workgroup) reconstructs one TU.  Coefficients,
+// the intermediate of the separable transform, the neighbour border and the
+// prediction live in LDS; the picture is touched once for the border read and
+// once for the final store.  Behaviour follows (libde265/):
+//   transform.cc:353-625  scale_coefficients_internal (dequant, dispatch)
+//   fallback-dct.cc:270-408, :551-692, :80-90, :216-224  (DST, IDCT, skip, bypass)
+//   intrapred.cc:395-431, :577-688, :816-1111            (border, filter, predictors)
+#include "kernels.h"
+
+namespace d265 {
+
+__device__ __constant__ int8_t c_dct_mat[32 * 32] = {
+#include "dct_table.inc"
+};
+__device__ __constant__ int8_t c_dst_mat[16] = { 29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29 };
+__device__ __constant__ int8_t c_level_scale[6] = { 40, 45, 51, 57, 64, 72 };
+__device__ __constant__ int8_t c_intra_angle[35] = {
+  0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26,
+  -32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };
+__device__ __constant__ int16_t c_inv_angle[15] = {
+  -4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096 };
+
+__device__ __forceinline__ int clip3(int lo, int hi, int v) { return min(max(v, lo), hi); }
+
+template <typename PX>
+struct TuShared {
+  int8_t  mat[32 * 32];        // DCT matrix
+  int16_t coeff[32 * 32];      // dequantised coefficients
+  int16_t g[32 * 32];          // first-stage output
+  uint16_t pred[32 * 32];      // intra prediction
+  int32_t border[4 * 32 + 4];  // unfiltered neighbours, centre at [64]
+  int32_t bfilt[4 * 32 + 4];   // filtered neighbours / angular ref array
+  int32_t last_row, last_col;
+};
+
+// wave-wide sum over 64 lanes
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename PX>
+__device__ void intra_predict(const PicDev& P, const TuTask& t, const PX* plane, int stride,
+                              TuShared<PX>& S, int lane)
+{
+  const int nT = 1 << t.log2_size;
+  const int cIdx = t.c_idx;
+  const int bd = cIdx ? P.bd_chroma : P.bd_luma;
+  const int xB = t.x0, yB = t.y0;
+  int* border = &S.border[64];
+  int* bf = &S.bfilt[64];
+  const uint64_t avail = t.avail;
+  const int nLeftUnits = nT >> 1;            // 2nT/4
+  const int cornerUnit = nLeftUnits;
+
+  // ---- border fetch + substitution (fill_from_image + reference_sample_substitution)
+  for (int p = lane; p <= 4 * nT; p += 64) {
+    int i = p - 2 * nT;                      // border index
+    int u = (i < 0) ? (p >> 2) : (i == 0 ? cornerUnit : cornerUnit + 1 + ((i - 1) >> 2));
+    int val;
+    if (avail == 0) val = 1 << (bd - 1);
+    else {
+      int src = i;
+      if (!((avail >> u) & 1)) {
+        uint64_t below = avail & ((2ull << u) - 1ull);
+        if (below) {
+          int su = 63 - __clzll((long long)below);   // nearest available unit before
+          // last sample of that unit in scan order
+          src = (su < cornerUnit) ? (-2 * nT + 4 * su + 3) : (su == cornerUnit ? 0 : 4 * (su - cornerUnit));
+        } else {
+          int su = __ffsll((long long)avail) - 1;    // first available unit: its first sample
+          src = (su < cornerUnit) ? (-2 * nT + 4 * su) : (su == cornerUnit ? 0 : 4 * (su - cornerUnit - 1) + 1);
+        }
+      }
+      int sx, sy;
+      if (src < 0) { sx = xB - 1; sy = yB - src - 1; }
+      else if (src == 0) { sx = xB - 1; sy = yB - 1; }
+      else { sx = xB + src - 1; sy = yB - 1; }
+      val = plane[sx + sy * stride];
+    }
+    border[i] = val;
+  }
+  __syncthreads();
+
+  // ---- smoothing (intra_prediction_sample_filtering), luma only in 4:2:0
+  const int mode = t.intra_mode >= 35 ? 1 : t.intra_mode;
+  int filterFlag = 0;
+  if (cIdx == 0 && mode != 1 && nT != 4) {
+    int minDist = min(abs(mode - 26), abs(mode - 10));
+    filterFlag = (nT == 8) ? (minDist > 7) : (nT == 16 ? (minDist > 1) : (minDist > 0));
+  }
+  if (filterFlag) {
+    bool biInt = false;
+    if (P.strong_intra && nT == 32) {
+      int th = 1 << (P.bd_luma - 5);
+      biInt = abs(border[0] + border[64] - 2 * border[32]) < th &&
+              abs(border[0] + border[-64] - 2 * border[-32]) < th;
+    }
+    for (int p = lane; p <= 4 * nT; p += 64) {
+      int i = p - 2 * nT;
+      int v;
+      if (i == -2 * nT || i == 2 * nT) v = border[i];
+      else if (biInt) {
+        if (i == 0) v = border[0];
+        else if (i < 0) v = (PX)(border[0] + (((-i) * (border[-64] - border[0]) + 32) >> 6));
+        else v = (PX)(border[0] + ((i * (border[64] - border[0]) + 32) >> 6));
+      } else v = (border[i + 1] + 2 * border[i] + border[i - 1] + 2) >> 2;
+      bf[i] = v;
+    }
+    __syncthreads();
+    for (int p = lane; p <= 4 * nT; p += 64) border[p - 2 * nT] = bf[p - 2 * nT];
+    __syncthreads();
+  }
+
+  const int log2 = t.log2_size;
+  const int nS = nT * nT;
+  if (mode == 0) {                           // planar
+    for (int s = lane; s < nS; s += 64) {
+      int y = s >> log2, x = s & (nT - 1);
+      S.pred[s] = (uint16_t)(((nT - 1 - x) * border[-1 - y] + (x + 1) * border[1 + nT] +
+                              (nT - 1 - y) * border[1 + x] + (y + 1) * border[-1 - nT] + nT) >> (log2 + 1));
+    }
+  } else if (mode == 1) {                    // DC, wavefront-shuffle reduction
+    int v = 0;
+    if (lane < nT) v = border[lane + 1] + border[-lane - 1];
+    int dc = (wave_sum(v) + nT) >> (log2 + 1);
+    bool edge = (cIdx == 0 && nT < 32);
+    for (int s = lane; s < nS; s += 64) {
+      int y = s >> log2, x = s & (nT - 1);
+      int o = dc;
+      if (edge) {
+        if (x == 0 && y == 0) o = (border[-1] + 2 * dc + border[1] + 2) >> 2;
+        else if (y == 0) o = (border[x + 1] + 3 * dc + 2) >> 2;
+        else if (x == 0) o = (border[-y - 1] + 3 * dc + 2) >> 2;
+      }
+      S.pred[s] = (uint16_t)o;
+    }
+  } else {                                   // angular
+    const int angle = c_intra_angle[mode];
+    const bool vert = mode >= 18;
+    // ref[] in bf (index -nT..2nT)
+    for (int x = lane; x <= 2 * nT; x += 64) {
+      if (x <= nT || angle >= 0) bf[x] = vert ? border[x] : border[-x];
+    }
+    if (angle < 0) {
+      int inv = c_inv_angle[mode - 11];
+      int lo = (nT * angle) >> 5;
+      if (lo < -1)
+        for (int x = lo + lane; x <= -1; x += 64) {
+          int k = (x * inv + 128) >> 8;
+          bf[x] = vert ? border[-k] : border[k];
+        }
+    }
+    __syncthreads();
+    for (int s = lane; s < nS; s += 64) {
+      int y = s >> log2, x = s & (nT - 1);
+      int a = vert ? y : x, b = vert ? x : y;      // a: along prediction direction
+      int iIdx = ((a + 1) * angle) >> 5;
+      int iFact = ((a + 1) * angle) & 31;
+      int o;
+      if (iFact) o = ((32 - iFact) * bf[b + iIdx + 1] + iFact * bf[b + iIdx + 2] + 16) >> 5;
+      else o = bf[b + iIdx + 1];
+      if (cIdx == 0 && nT < 32) {
+        if (mode == 26 && x == 0) o = clip3(0, (1 << bd) - 1, border[1] + ((border[-1 - y] - border[0]) >> 1));
+        if (mode == 10 && y == 0) o = clip3(0, (1 << bd) - 1, border[-1] + ((border[1 + x] - border[0]) >> 1));
+      }
+      S.pred[s] = (uint16_t)o;
+    }
+  }
+  __syncthreads();
+}
+
+// Residual reconstruction from the dense coefficient block in S.coeff.
+// kind: 0 inverse DCT, 1 inverse DST 4x4, 2 transform skip, 3 transquant bypass.
+// has_pred: prediction comes from S.pred (intra) instead of the picture.
+template <typename PX>
+__device__ void tu_residual_add(TuShared<PX>& S, int lane, PX* dst, int stride, int log2, int bd,
+                                int kind, bool has_pred, int lastRow, int lastCol)
+{
+  const int nT = 1 << log2, nS = nT * nT;
+  const int maxv = (1 << bd) - 1;
+  if (kind >= 2) {
+    const bool bypass = kind == 3;
+    const int bdShift = 20 - bd, tsShift = 5 + log2, rnd = 1 << (bdShift - 1);
+    for (int s = lane; s < nS; s += 64) {
+      int x = s & (nT - 1), y = s >> log2;
+      int r = bypass ? (int)S.coeff[s]
+                     : (((int32_t)((uint32_t)(int32_t)S.coeff[s] << tsShift) + rnd) >> bdShift);
+      int p = has_pred ? (int)S.pred[s] : (int)dst[x + y * stride];
+      dst[x + y * stride] = (PX)clip3(0, maxv, p + r);
+    }
+    return;
+  }
+
+  const int post = 20 - bd, rnd2 = 1 << (post - 1);
+  if (kind == 1) {
+    if (lane < 16) {
+      int i = lane >> 2, c = lane & 3;
+      int sum = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) sum += c_dst_mat[j * 4 + i] * S.coeff[c + j * 4];
+      S.g[i * 4 + c] = (int16_t)clip3(-32768, 32767, (sum + 64) >> 7);
+    }
+    __syncthreads();
+    if (lane < 16) {
+      int y = lane >> 2, i = lane & 3;
+      int sum = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) sum += c_dst_mat[j * 4 + i] * S.g[y * 4 + j];
+      int out = clip3(-32768, 32767, (sum + rnd2) >> post);
+      int p = has_pred ? (int)S.pred[lane] : (int)dst[i + y * stride];
+      dst[i + y * stride] = (PX)clip3(0, maxv, p + out);
+    }
+    return;
+  }
+
+  // ---- separable inverse DCT; rows/cols beyond the last nonzero are skipped
+  const int fact = 32 >> log2;                 // row subsampling of the 32-point matrix
+  const int ncols = lastCol + 1;
+  for (int tix = lane; tix < nT * ncols; tix += 64) {
+    int c = tix % ncols, i = tix / ncols;
+    int sum = 0;
+    for (int j = 0; j <= lastRow; j++) sum += S.mat[fact * j * 32 + i] * S.coeff[c + j * nT];
+    S.g[i * nT + c] = (int16_t)clip3(-32768, 32767, (sum + 64) >> 7);
+  }
+  __syncthreads();
+  for (int s = lane; s < nS; s += 64) {
+    int y = s >> log2, i = s & (nT - 1);
+    int sum = 0;
+    for (int j = 0; j <= lastCol; j++) sum += S.mat[fact * j * 32 + i] * S.g[y * nT + j];
+    int out = (sum + rnd2) >> post;            // second stage is not clipped (fallback-dct.cc:682)
+    int p = has_pred ? (int)S.pred[s] : (int)dst[i + y * stride];
+    dst[i + y * stride] = (PX)clip3(0, maxv, p + out);
+  }
+}
+
+template <typename PX>
+__global__ __launch_bounds__(64)
+void k_tu(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const TuTask* __restrict__ tasks,
+          int first, const int16_t* __restrict__ coeff_val, const uint16_t* __restrict__ coeff_pos,
+          const uint8_t* __restrict__ scaling)
+{
+  __shared__ TuShared<PX> S;
+  const int lane = threadIdx.x;
+  const TuTask t = tasks[first + blockIdx.x];
+  const int cIdx = t.c_idx;
+  const PlaneRef pr = cIdx == 0 ? pl0 : (cIdx == 1 ? pl1 : pl2);
+  PX* plane = (PX*)pr.ptr;
+  const int stride = pr.stride;
+  const int log2 = t.log2_size;
+  const int nT = 1 << log2, nS = nT * nT;
+  const int bd = cIdx ? P.bd_chroma : P.bd_luma;
+  const bool intra = t.flags & DE265HIP_TU_INTRA;
+  const bool cbf = t.flags & DE265HIP_TU_CBF;
+  PX* dst = plane + t.x0 + t.y0 * stride;
+
+  if (intra) intra_predict<PX>(P, t, plane, stride, S, lane);
+
+  if (!cbf) {
+    if (intra)
+      for (int s = lane; s < nS; s += 64) dst[(s & (nT - 1)) + (s >> log2) * stride] = (PX)S.pred[s];
+    return;
+  }
+
+  // ---- scatter (dequantised) coefficients into the dense LDS block
+  const bool bypass = t.flags & DE265HIP_TU_BYPASS;
+  const bool tskip = t.flags & DE265HIP_TU_TSKIP;
+  const bool is_dst = (nT == 4 && cIdx == 0 && intra);
+  for (int s = lane; s < nS; s += 64) S.coeff[s] = 0;
+  if (lane == 0) { S.last_row = 0; S.last_col = 0; }
+  if (!bypass && !tskip && !is_dst)
+    for (int s = lane; s < 256; s += 64) ((int32_t*)S.mat)[s] = ((const int32_t*)c_dct_mat)[s];
+  __syncthreads();
+  {
+    const int16_t* vals = coeff_val + t.coeff_offset;
+    const uint16_t* pos = coeff_pos + t.coeff_offset;
+    int lr = 0, lc = 0;
+    if (bypass) {
+      for (int i = lane; i < t.n_coeff; i += 64) S.coeff[pos[i]] = vals[i];
+    } else if (!P.scaling_list) {
+      const int bdShift = bd + log2 - 9;
+      const int32_t offset = 1 << (bdShift - 1);
+      const int32_t fact = (int32_t)c_level_scale[t.qp % 6] << (t.qp / 6);
+      for (int i = lane; i < t.n_coeff; i += 64) {
+        int p = pos[i];
+        int32_t cc = (int32_t)((uint32_t)(int32_t)vals[i] * (uint32_t)fact + (uint32_t)offset);   // 32-bit wrap
+        S.coeff[p] = (int16_t)clip3(-32768, 32767, cc >> bdShift);
+        lr = max(lr, p >> log2); lc = max(lc, p & (nT - 1));
+      }
+    } else {
+      const int bdShift = bd + log2 - 5;
+      const long long offset = 1ll << (bdShift - 1);
+      int matrixID = cIdx;
+      if (!intra) matrixID += (nT < 32) ? 3 : 1;
+      const uint8_t* scl = scaling + (log2 == 2 ? 0 : (log2 == 3 ? 96 : (log2 == 4 ? 96 + 384 : 96 + 384 + 1536))) +
+                           matrixID * nS;
+      for (int i = lane; i < t.n_coeff; i += 64) {
+        int p = pos[i];
+        int fact = ((int)scl[p] * c_level_scale[t.qp % 6]) << (t.qp / 6);
+        long long cc = ((long long)vals[i] * fact + offset) >> bdShift;
+        cc = cc < -32768 ? -32768 : (cc > 32767 ? 32767 : cc);
+        S.coeff[p] = (int16_t)cc;
+        lr = max(lr, p >> log2); lc = max(lc, p & (nT - 1));
+      }
+    }
+    if (lr) atomicMax(&S.last_row, lr);
+    if (lc) atomicMax(&S.last_col, lc);
+  }
+  __syncthreads();
+
+  const int kind = bypass ? 3 : (tskip ? 2 : (is_dst ? 1 : 0));
+  tu_residual_add<PX>(S, lane, dst, stride, log2, bd, kind, intra, S.last_row, S.last_col);
+}
+
+// Function-level form (acceleration.h:143-178 slot semantics): dense coefficient
+// blocks added into a plane.  kind as in tu_residual_add.
+template <typename PX>
+__global__ __launch_bounds__(64)
+void k_fn_residual(int kind, int log2_size, int bit_depth, PX* plane, int stride,
+                   const int32_t* __restrict__ xy, const int16_t* __restrict__ coeffs)
+{
+  __shared__ TuShared<PX> S;
+  const int lane = threadIdx.x;
+  const int nT = 1 << log2_size, nS = nT * nT;
+  const int16_t* c = coeffs + (size_t)blockIdx.x * nS;
+  for (int s = lane; s < nS; s += 64) S.coeff[s] = c[s];
+  for (int s = lane; s < 256; s += 64) ((int32_t*)S.mat)[s] = ((const int32_t*)c_dct_mat)[s];
+  __syncthreads();
+  PX* dst = plane + xy[2 * blockIdx.x] + xy[2 * blockIdx.x + 1] * stride;
+  tu_residual_add<PX>(S, lane, dst, stride, log2_size, bit_depth, kind, false, nT - 1, nT - 1);
+}
+
+template __global__ void k_tu<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int,
+                                       const int16_t*, const uint16_t*, const uint8_t*);
+template __global__ void k_tu<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int,
+                                        const int16_t*, const uint16_t*, const uint8_t*);
+template __global__ void k_fn_residual<uint8_t>(int, int, int, uint8_t*, int, const int32_t*, const int16_t*);
+template __global__ void k_fn_residual<uint16_t>(int, int, int, uint16_t*, int, const int32_t*, const int16_t*);
+
+}  // namespace d265

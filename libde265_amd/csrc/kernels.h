@@ -1,0 +1,47 @@
+// kernels.h -- declarations of the gfx950 kernels (defined in k_*.hip).
+#pragma once
+#include "dev_common.h"
+
+namespace d265 {
+
+struct LfMeta {
+  const uint8_t* flags;
+  const int8_t* qp;
+  const uint8_t* bs;
+  const de265hip_ctb_info* ctbs;
+  const de265hip_slice_params* slices;
+};
+struct SaoMeta {
+  const uint8_t* flags;
+  const de265hip_ctb_info* ctbs;
+  const de265hip_slice_params* slices;
+  const uint16_t* tile_id;
+};
+
+template <typename PX>
+__global__ void k_tu(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int,
+                     const int16_t*, const uint16_t*, const uint8_t*);
+template <typename PX>
+__global__ void k_mc(PicDev, DpbTable, PlaneRef, PlaneRef, PlaneRef, const McTask*,
+                     const de265hip_slice_params*);
+template <typename PX>
+__global__ void k_pcm(PlaneRef, PlaneRef, PlaneRef, const PcmTask*, const uint16_t*);
+__global__ void k_bs(PicDev, const uint8_t*, const de265hip_motion*, uint8_t*);
+template <typename PX, bool VERT>
+__global__ void k_deblock(PicDev, PlaneRef, PlaneRef, PlaneRef, LfMeta);
+template <typename PX>
+__global__ void k_sao(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, SaoMeta);
+
+// function-level kernels (k_fn.hip)
+template <typename PX>
+__global__ void k_fn_residual(int kind, int log2_size, int bit_depth, PX* plane, int stride,
+                              const int32_t* xy, const int16_t* coeffs);
+template <typename PX>
+__global__ void k_fn_interp(int luma, int bit_depth, const PX* plane, int stride, int pw, int ph,
+                            int w, int h, int fx, int fy, const int32_t* xy, int16_t* out);
+template <typename PX>
+__global__ void k_fn_put(int mode, int bit_depth, PX* plane, int stride, int w, int h,
+                         const int32_t* xy, const int16_t* s0, const int16_t* s1,
+                         int w0, int o0, int w1, int o1, int log2wd);
+
+}  // namespace d265
