@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""bench.py -- decoded frames/s of the MI355X HEVC reconstruction back end.
+
+Workload (BASELINE.json configs[3] / SURVEY.md 8d config 4): one closed GOP of
+3840x2160 10-bit 4:2:0 pictures (1 I + 15 B, each B referencing the two
+previously decoded pictures), synthetic command buffers (seed 0xDE265000+4),
+all stages on the device: MC -> residual -> intra -> deblock -> SAO.
+One "step" = one pass over the GOP; all command buffers and reference pictures
+are resident in HBM before the timed region starts.  value = pictures/s over
+all ranks (weak scaling: every rank decodes its own independent GOP, no
+data-path collective).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+CONFIG_ID = 4                  # SURVEY 8d config 4 -> seed 0xDE265000 + 4
+
+ALG_KEY = {"mc": "alg_bytes_mc", "resid": "alg_bytes_resid", "intra": "alg_bytes_intra",
+           "deblock_v": "alg_bytes_deblock", "deblock_h": "alg_bytes_deblock", "sao": "alg_bytes_sao"}
+
+
+def make_gop(pysynth, farm, width, height, bit_depth, gop, seed):
+    """Picture k is decoded into DPB slot k; B pictures reference slots k-1 and k-2 (farm.gop_plan)."""
+    pics = []
+    for k, (slice_type, refs) in enumerate(farm.gop_plan(gop)):
+        over = dict(ref_slots=refs, weighted_pred=1 if (k % 10) == 5 else 0) if refs else {}
+        pics.append(pysynth.SynthPicture(pysynth.default_config(width, height, bit_depth, slice_type,
+                                                                seed=seed + k, **over)))
+    return pics
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--bit-depth", type=int, default=10)
+    ap.add_argument("--gop", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+    import pysynth
+    from libde265_amd import backend, farm, _abi
+
+    if not torch.cuda.is_available() or backend.device_count() == 0:
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    W, H, BD, GOP = args.width, args.height, args.bit_depth, args.gop
+    gop = make_gop(pysynth, farm, W, H, BD, GOP, farm.gop_seed(CONFIG_ID, rank))
+    dec = backend.Decoder(device=local_rank)
+    for k in range(GOP):
+        dec.dpb_alloc(k, W, H, BD)
+    pics = [dec.build(k, gop[k].desc) for k in range(GOP)]       # inputs now resident in HBM
+    stats = [p.stats() for p in pics]
+
+    def step():
+        for p in pics:
+            dec.run(p, _abi.STAGE_FINAL)
+
+    def sync():
+        dec.sync()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    dec.set_profiling(True)
+    dec.kernel_times(reset=True)
+    timer = farm.RankTimer(dist, sync, device="cuda")
+    timer.start()                       # barrier + synchronize
+    for _ in range(args.steps):
+        step()
+    elapsed = timer.stop()              # synchronize + barrier, MAX over ranks
+    ktimes = dec.kernel_times(reset=True)
+    dec.set_profiling(False)
+
+    if rank == 0:
+        frames = world * args.steps * GOP
+        fps = frames / elapsed
+        # ---- roofline of the dominant kernel (device time from hipEvents on the decoder's stream)
+        dom = max(ktimes, key=lambda k: ktimes[k][0])
+        dom_ms, dom_launches = ktimes[dom]
+        alg_total = sum(getattr(s, ALG_KEY[dom]) for s in stats) * args.steps if dom in ALG_KEY else 0
+        if dom in ("deblock_v", "deblock_h"):
+            alg_total //= 2                       # SURVEY 8d counts 2P for the two passes together
+        achieved = (alg_total / 1e9) / (dom_ms / 1e3) if dom_ms > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "launches": int(dom_launches), "avg_launch_us": round(1e3 * dom_ms / max(dom_launches, 1), 3),
+                    "alg_bytes_per_launch": int(alg_total / max(dom_launches, 1))}
+        kernels = {k: {"ms_per_step": round(v[0] / args.steps, 4), "launches_per_step": v[1] // args.steps,
+                       "alg_GBs": round((sum(getattr(s, ALG_KEY[k]) for s in stats) / (2 if k.startswith("deblock") else 1)
+                                         / 1e9) / (v[0] / args.steps / 1e3), 1) if k in ALG_KEY and v[0] > 0 else None}
+                   for k, v in ktimes.items()}
+
+        cpu = None
+        parity = "not checked"
+        if not args.no_cpu_baseline:
+            import numpy as np
+            import pyoracle
+            planes = {}
+            tc0 = time.perf_counter()
+            for k in range(GOP):
+                out = pyoracle.alloc_planes(W, H, BD)
+                pyoracle.reconstruct(gop[k].desc, gop[k].order, planes, out)
+                planes[k] = out
+                if k >= 2:
+                    planes.pop(k - 3, None)
+            tc1 = time.perf_counter()
+            cpu = {"value": round(GOP / (tc1 - tc0), 3), "unit": "frames/s", "cores": 1, "kind": "port",
+                   "sample": "the same %d-picture GOP (1 I + %d B, %dx%d %d-bit), one pass, scalar C oracle"
+                             % (GOP, GOP - 1, W, H, BD)}
+            got = dec.download(GOP - 1, W, H, BD)
+            parity = "bit-exact" if all(np.array_equal(g, e) for g, e in zip(got, planes[GOP - 1])) else "MISMATCH"
+
+        line = {
+            "metric": "decoded frames/sec (4K Main10)", "value": round(fps, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u16" if BD > 8 else "u8", "data": "synthetic",
+            "config": {"workload": "%dx%d %d-bit 4:2:0 random-access closed GOP, %d pictures (1 I + %d B, 2 refs), "
+                                   "all stages on device" % (W, H, BD, GOP, GOP - 1),
+                       "gop": GOP, "pictures_per_step": GOP, "parallelism": "gop-per-gpu x%d" % world},
+            "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity, "kernels": kernels,
+        }
+        print(json.dumps(line))
+        if parity == "MISMATCH":
+            sys.exit(2)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,79 @@
+"""Frame-parallel farming of independent closed GOPs over the GPUs of one node
+(SURVEY.md 8e): one process per GPU, every rank decodes its own GOPs, no
+collective on the data path.  torch.distributed is used only for the timing
+barrier and the max-over-ranks reduction (and, optionally, to hand a finished
+reference picture to another rank -- the open-GOP case).
+"""
+import time
+
+BASE_SEED = 0xDE265000
+
+
+def gop_seed(config_id, rank, gop_index=0):
+    """Seeds of SURVEY 8d (0xDE265000 + config id), spread so that ranks and GOPs never collide."""
+    return BASE_SEED + config_id + 1000 * rank + 100000 * gop_index
+
+
+def gop_plan(gop_len):
+    """Closed GOP: picture k -> DPB slot k; k=0 is intra, k>0 is a B picture that
+    references the two previously decoded pictures.  Returns [(slice_type, [ref slots])]."""
+    plan = [(2, [])]
+    for k in range(1, gop_len):
+        plan.append((0, [k - 1, max(k - 2, 0)]))
+    return plan
+
+
+def shard(units, rank, world):
+    """Units (GOPs / independent pictures) owned by `rank`: round-robin, no exchange needed."""
+    return [u for i, u in enumerate(units) if i % world == rank]
+
+
+class RankTimer:
+    """barrier + sync on both sides of the timed region, MAX over ranks (bench.py contract).
+    `dist` is torch.distributed or None; `sync` synchronises the local device (or is a no-op on CPU)."""
+
+    def __init__(self, dist=None, sync=lambda: None, device="cpu"):
+        self.dist, self.sync, self.device = dist, sync, device
+        self.t0 = None
+
+    def _barrier(self):
+        if self.dist is not None and self.dist.is_initialized():
+            self.dist.barrier()
+
+    def start(self):
+        self.sync()
+        self._barrier()
+        self.t0 = time.perf_counter()
+
+    def stop(self):
+        self.sync()
+        self._barrier()
+        elapsed = time.perf_counter() - self.t0
+        if self.dist is not None and self.dist.is_initialized():
+            import torch
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
+
+
+def total_units(dist, local_units, device="cpu"):
+    """Sum over ranks of the units each rank processed."""
+    if dist is None or not dist.is_initialized():
+        return local_units
+    import torch
+    t = torch.tensor([local_units], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
+def send_reference_picture(dist, planes, src, dst, rank, device="cpu"):
+    """Open-GOP exchange step: rank `src` hands a finished reference picture
+    (list of 3 torch tensors) to rank `dst` point-to-point; other ranks do nothing."""
+    if rank == src:
+        for p in planes:
+            dist.send(p, dst=dst)
+    elif rank == dst:
+        for p in planes:
+            dist.recv(p, src=src)
+    return planes
