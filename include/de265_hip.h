@@ -248,9 +248,12 @@ int  de265hip_decode_picture(de265hip_decoder*, int dst_slot,
 
 /* Introspection used by bench/tests */
 typedef struct de265hip_picture_stats {
-  int32_t n_levels;          /* intra dependency levels (kernel launches) */
+  int32_t n_levels;          /* intra dependency levels at TU granularity */
   int32_t n_tu_tasks;
   int32_t n_mc_tasks;
+  int32_t n_runs;            /* intra runs (wavefront tasks of the single-launch run kernel) */
+  int32_t n_run_levels;      /* longest producer->consumer chain of runs */
+  int32_t pad;
   int64_t device_bytes;      /* command-buffer bytes resident in HBM */
   int64_t alg_bytes_mc;      /* algorithmic bytes, SURVEY 8d definitions */
   int64_t alg_bytes_resid;

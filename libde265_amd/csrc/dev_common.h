@@ -56,6 +56,19 @@ struct McTask {
 };
 static_assert(sizeof(McTask) == 20, "McTask layout");
 
+// Run task: a run of consecutive (decode order) intra TUs of ONE colour component that
+// one wavefront reconstructs serially with its pixel window resident in LDS.
+// Runs are ordered so that every producer run has a smaller index (ticket).
+struct RunTask {
+  uint16_t x0, y0, x1, y1;   // bounding box of the run's TUs, component samples, x1/y1 exclusive
+  uint8_t  c_idx, pad0;
+  uint16_t n_tus;
+  uint32_t first_tu;         // into the run-ordered TuTask array
+  uint32_t dep_offset;       // into the producer-run id array
+  uint16_t n_deps, pad1;
+};
+static_assert(sizeof(RunTask) == 24, "RunTask layout");
+
 struct PcmTask {
   uint16_t x0, y0;
   uint32_t log2_cb_size;

@@ -8,6 +8,7 @@
 //   deblock H -> SAO (out of place, then the slot's plane pointers are swapped).
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -42,6 +43,9 @@ struct de265hip_decoder {
   hipStream_t stream = nullptr;
   Slot slots[DE265HIP_MAX_DPB_SLOTS];
   Slot spare;                         // SAO output target, swapped with the decoded slot
+  uint32_t* d_err = nullptr;          // set by a kernel whose bounded spin expired
+  int dbg = 0;                        // DE265HIP_DEBUG: timing-only ablations of k_run (results invalid)
+  bool intra_levels = false;          // DE265HIP_INTRA_MODE=levels: one launch per dependency level
   bool profiling = false;
   std::vector<PendingEvent> pending;
   double ms[DE265HIP_K_COUNT] = {};
@@ -66,6 +70,9 @@ struct de265hip_picture {
   uint16_t* d_tile_id = nullptr;
   uint8_t* d_flags = nullptr; int8_t* d_qp = nullptr; de265hip_motion* d_motion = nullptr;
   uint8_t* d_bs = nullptr;
+  RunTask* d_runs = nullptr; uint32_t* d_deps = nullptr; uint32_t* d_sync = nullptr;
+  TuTask* d_run_tus = nullptr;
+  int n_runs = 0; size_t sync_bytes = 0;
   std::vector<int> level_start;       // level_start[l] .. level_start[l+1] in d_tus
   int n_mc = 0, n_pcm = 0, n_tus = 0;
   bool any_edges = false;
@@ -143,8 +150,10 @@ int make_geometry(const de265hip_pic_params& p, Geometry& g)
 // Neighbour availability of one intra TU (8.4.4.2.2; intrapred.cc:437-527 preproc,
 // :577-688 fill_from_image) as a unit bitmask, and the TU's dependency level.
 uint64_t intra_availability(const de265hip_picture_desc& d, const Geometry& g, const de265hip_tu& tu,
-                            const std::vector<uint16_t>& lvl, int map_w, int* level_out)
+                            const std::vector<uint16_t>& lvl, int map_w, int* level_out,
+                            const std::vector<int32_t>& runmap, std::vector<int>& producers)
 {
+  producers.clear();
   const de265hip_pic_params& p = d.params;
   const int nT = 1 << tu.log2_size, sub = tu.c_idx ? 2 : 1;
   const int xB = tu.x0, yB = tu.y0, xL = xB * sub, yL = yB * sub;
@@ -175,6 +184,8 @@ uint64_t intra_availability(const de265hip_picture_desc& d, const Geometry& g, c
   auto take = [&](int u, int xs, int ys) {
     mask |= 1ull << u;
     lev = std::max(lev, (int)lvl[(xs >> 2) + (ys >> 2) * map_w]);
+    const int r = runmap[(xs >> 2) + (ys >> 2) * map_w];
+    if (r >= 0 && std::find(producers.begin(), producers.end(), r) == producers.end()) producers.push_back(r);
   };
   if (aL)
     for (int y = nBottom - 1; y >= 0; y -= 4)
@@ -216,6 +227,11 @@ int de265hip_decoder_new(de265hip_decoder** out, int device)
   if (!d) return DE265HIP_ERROR_OUT_OF_MEMORY;
   HIPCHK(hipGetDevice(&d->device), DE265HIP_ERROR_INIT_FAILED);
   HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking), DE265HIP_ERROR_INIT_FAILED);
+  HIPCHK(hipMalloc((void**)&d->d_err, 256), DE265HIP_ERROR_OUT_OF_MEMORY);
+  HIPCHK(hipMemset(d->d_err, 0, 256), DE265HIP_ERROR_INIT_FAILED);
+  const char* mode = getenv("DE265HIP_INTRA_MODE");
+  d->intra_levels = mode && !strcmp(mode, "levels");
+  if (const char* dbg = getenv("DE265HIP_DEBUG")) d->dbg = atoi(dbg);
   *out = d;
   return DE265HIP_OK;
 }
@@ -227,6 +243,7 @@ void de265hip_decoder_free(de265hip_decoder* d)
   for (auto& e : d->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& s : d->slots) free_slot(s);
   free_slot(d->spare);
+  if (d->d_err) (void)hipFree(d->d_err);
   (void)hipStreamDestroy(d->stream);
   delete d;
 }
@@ -335,6 +352,14 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   for (int c = 0; c < 3; c++) lvl[c].assign((size_t)map_w[c] * map_h[c], 0);
   int max_level = 0;
   int64_t alg_resid = 0, alg_intra = 0;
+  // runs: maximal intervals of the per-component intra TU sequence inside one CTB in which
+  // every TU reads from the run so far (see k_run); independent TUs start a new run
+  struct RunBuild { int c, ctu, x0, y0, x1, y1, level; std::vector<TuTask> tus; std::vector<int> deps; };
+  std::vector<RunBuild> rb;
+  std::vector<int32_t> runmap[3];
+  for (int c = 0; c < 3; c++) runmap[c].assign((size_t)map_w[c] * map_h[c], -1);
+  int cur_run[3] = { -1, -1, -1 };
+  std::vector<int> producers;
   for (int i = 0; i < d->n_tus; i++) {
     const de265hip_tu& tu = d->tus[i];
     const int nT = 1 << tu.log2_size;
@@ -356,9 +381,28 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     int level = 0;
     const size_t bpp = px_bytes(tu.c_idx ? p.bit_depth_chroma : p.bit_depth_luma);
     if (tu.flags & DE265HIP_TU_INTRA) {
-      t.avail = intra_availability(*d, g, tu, lvl[tu.c_idx], map_w[tu.c_idx], &level);
+      const int c = tu.c_idx, sub = c ? 2 : 1;
+      t.avail = intra_availability(*d, g, tu, lvl[c], map_w[c], &level, runmap[c], producers);
+      const int ctu = ((tu.x0 * sub) >> p.log2_ctb_size) + ((tu.y0 * sub) >> p.log2_ctb_size) * g.ctbs_w;
+      int r = cur_run[c];
+      const bool extends = r >= 0 && rb[r].ctu == ctu && rb[r].tus.size() < 60000 &&
+                           std::find(producers.begin(), producers.end(), r) != producers.end();
+      if (!extends) {
+        r = (int)rb.size();
+        rb.push_back(RunBuild{ c, ctu, tu.x0, tu.y0, tu.x0 + nT, tu.y0 + nT, 0, {}, {} });
+        cur_run[c] = r;
+      }
+      RunBuild& R = rb[r];
+      R.x0 = std::min(R.x0, (int)tu.x0); R.y0 = std::min(R.y0, (int)tu.y0);
+      R.x1 = std::max(R.x1, tu.x0 + nT); R.y1 = std::max(R.y1, tu.y0 + nT);
+      for (int pr : producers)
+        if (pr != r && std::find(R.deps.begin(), R.deps.end(), pr) == R.deps.end()) R.deps.push_back(pr);
+      R.tus.push_back(t);
       for (int y = tu.y0 >> 2; y < (tu.y0 + nT) >> 2; y++)
-        for (int x = tu.x0 >> 2; x < (tu.x0 + nT) >> 2; x++) lvl[tu.c_idx][x + (size_t)y * map_w[tu.c_idx]] = (uint16_t)level;
+        for (int x = tu.x0 >> 2; x < (tu.x0 + nT) >> 2; x++) {
+          lvl[c][x + (size_t)y * map_w[c]] = (uint16_t)level;
+          runmap[c][x + (size_t)y * map_w[c]] = r;
+        }
       alg_intra += (int64_t)bpp * (4 * nT + 1) + (int64_t)bpp * nT * nT;
       if (level >= 65535) { delete pic; return DE265HIP_ERROR_NOT_IMPLEMENTED; }
     }
@@ -375,6 +419,28 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   { std::vector<int> cursor(pic->level_start.begin(), pic->level_start.end() - 1);
     for (size_t i = 0; i < tasks.size(); i++) sorted[cursor[levels[i]]++] = tasks[i]; }
   pic->n_tus = (int)sorted.size();
+
+  // ---- runs in dependency (ticket) order: producers first
+  std::vector<RunTask> runs; std::vector<uint32_t> run_deps; std::vector<TuTask> run_tus;
+  int max_rl = 0;
+  {
+    for (auto& R : rb) { int l = 0; for (int dp : R.deps) l = std::max(l, rb[dp].level); R.level = l + 1; max_rl = std::max(max_rl, R.level); }
+    std::vector<int> count(max_rl + 2, 0), order(rb.size()), newidx(rb.size());
+    for (auto& R : rb) count[R.level + 1]++;
+    for (int l = 0; l <= max_rl; l++) count[l + 1] += count[l];
+    for (size_t i = 0; i < rb.size(); i++) { int k = count[rb[i].level]++; order[k] = (int)i; newidx[i] = k; }
+    runs.resize(rb.size());
+    for (size_t k = 0; k < rb.size(); k++) {
+      const RunBuild& R = rb[order[k]];
+      RunTask& o = runs[k]; memset(&o, 0, sizeof(o));
+      o.x0 = (uint16_t)R.x0; o.y0 = (uint16_t)R.y0; o.x1 = (uint16_t)R.x1; o.y1 = (uint16_t)R.y1;
+      o.c_idx = (uint8_t)R.c; o.n_tus = (uint16_t)R.tus.size();
+      o.first_tu = (uint32_t)run_tus.size(); o.dep_offset = (uint32_t)run_deps.size(); o.n_deps = (uint16_t)R.deps.size();
+      run_tus.insert(run_tus.end(), R.tus.begin(), R.tus.end());
+      for (int dp : R.deps) run_deps.push_back((uint32_t)newidx[dp]);
+    }
+  }
+  pic->n_runs = (int)runs.size();
 
   // ---- MC tasks: resolve references, bi->uni shortcut, split into <=16x16 tiles
   std::vector<McTask> mcs;
@@ -452,6 +518,10 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   const size_t o_tile = L.add((size_t)d->n_ctbs * 2);
   const size_t o_flags = L.add(nblk), o_qp = L.add(nblk), o_mot = L.add(nblk * sizeof(de265hip_motion));
   const size_t o_bs = L.add(nblk);
+  const size_t o_runs = L.add(runs.size() * sizeof(RunTask)), o_rdeps = L.add(run_deps.size() * 4);
+  const size_t o_rtus = L.add(run_tus.size() * sizeof(TuTask));
+  pic->sync_bytes = (2 + runs.size()) * 4;
+  const size_t o_sync = L.add(pic->sync_bytes);
   std::vector<uint8_t> host(L.total, 0);
   auto put = [&](size_t off, const void* src, size_t bytes) { if (bytes && src) memcpy(host.data() + off, src, bytes); };
   put(o_tus, sorted.data(), sorted.size() * sizeof(TuTask));
@@ -462,6 +532,8 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   put(o_sl, d->slices, (size_t)d->n_slices * sizeof(de265hip_slice_params));
   put(o_ctb, d->ctbs, (size_t)d->n_ctbs * sizeof(de265hip_ctb_info));
   put(o_tile, g.tile_id.data(), (size_t)d->n_ctbs * 2);
+  put(o_runs, runs.data(), runs.size() * sizeof(RunTask)); put(o_rdeps, run_deps.data(), run_deps.size() * 4);
+  put(o_rtus, run_tus.data(), run_tus.size() * sizeof(TuTask));
   put(o_flags, d->blk_flags, nblk); put(o_qp, d->blk_qp_y, nblk);
   if (d->blk_motion) put(o_mot, d->blk_motion, nblk * sizeof(de265hip_motion));
   else memset(host.data() + o_mot, 0xFF, nblk * sizeof(de265hip_motion));       // ref_slot = -1 everywhere
@@ -483,10 +555,13 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   pic->d_flags = base + o_flags; pic->d_qp = (int8_t*)(base + o_qp);
   pic->d_motion = (de265hip_motion*)(base + o_mot);
   pic->d_bs = base + o_bs;
+  pic->d_runs = (RunTask*)(base + o_runs); pic->d_deps = (uint32_t*)(base + o_rdeps);
+  pic->d_run_tus = (TuTask*)(base + o_rtus); pic->d_sync = (uint32_t*)(base + o_sync);
 
   const int64_t Pbytes = (int64_t)p.width * p.height * 3 / 2 * px_bytes(p.bit_depth_luma);
   pic->stats.n_levels = max_level + (pic->level_start[1] > 0 ? 1 : 0);
   pic->stats.n_tu_tasks = pic->n_tus; pic->stats.n_mc_tasks = pic->n_mc;
+  pic->stats.n_runs = pic->n_runs; pic->stats.n_run_levels = max_rl;
   pic->stats.device_bytes = (int64_t)L.total;
   pic->stats.alg_bytes_mc = alg_mc; pic->stats.alg_bytes_resid = alg_resid; pic->stats.alg_bytes_intra = alg_intra;
   pic->stats.alg_bytes_deblock = pic->any_edges ? 2 * Pbytes : 0;       // one read + one write
@@ -542,7 +617,12 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
     hipLaunchKernelGGL(k_tu<PX>, dim3(pic->level_start[1] - pic->level_start[0]), dim3(64), 0, st, P, d0, d1, d2,
                        pic->d_tus, pic->level_start[0], pic->d_cval, pic->d_cpos, pic->d_scaling);
   }
-  if (nlev > 1) {
+  if (pic->n_runs > 0 && !dec->intra_levels) {
+    KTimer t(dec, DE265HIP_K_INTRA, 1);
+    (void)hipMemsetAsync(pic->d_sync, 0, pic->sync_bytes, st);
+    hipLaunchKernelGGL(k_run<PX>, dim3(pic->n_runs), dim3(64), 0, st, P, d0, d1, d2, pic->d_runs, pic->d_deps,
+                       pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_cval, pic->d_cpos, pic->d_scaling, dec->dbg);
+  } else if (nlev > 1) {
     KTimer t(dec, DE265HIP_K_INTRA, nlev - 1);
     for (int l = 1; l < nlev; l++) {
       int cnt = pic->level_start[l + 1] - pic->level_start[l];
@@ -595,6 +675,17 @@ int de265hip_decoder_sync(de265hip_decoder* dec)
 {
   if (!dec) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   HIPCHK(hipStreamSynchronize(dec->stream), DE265HIP_ERROR_DECODING);
+  uint32_t err = 0;                     // a dependency wait that expired (k_run): results are not trustworthy
+  HIPCHK(hipMemcpy(&err, dec->d_err, 4, hipMemcpyDeviceToHost), DE265HIP_ERROR_DECODING);
+  if (dec->dbg & 16) {                  // diagnostic build switch: dump and clear the phase stamps
+    uint32_t st[16];
+    HIPCHK(hipMemcpy(st, dec->d_err + 8, sizeof(st), hipMemcpyDeviceToHost), DE265HIP_ERROR_DECODING);
+    fprintf(stderr, "de265hip stamps: tus=%u cycles/TU: setup=%.0f border=%.0f filter=%.0f predict=%.0f coeff=%.0f resid=%.0f writeback=%.0f\n",
+            st[7], st[0] / (double)st[7], st[1] / (double)st[7], st[2] / (double)st[7], st[3] / (double)st[7],
+            st[4] / (double)st[7], st[5] / (double)st[7], st[6] / (double)st[7]);
+    (void)hipMemset(dec->d_err + 8, 0, sizeof(st));
+  }
+  if (err) { (void)hipMemset(dec->d_err, 0, 4); return DE265HIP_ERROR_DECODING; }
   return 0;
 }
 

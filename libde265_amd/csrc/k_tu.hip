@@ -16,7 +16,7 @@ namespace d265 {
 __device__ __constant__ int8_t c_dct_mat[32 * 32] = {
 #include "dct_table.inc"
 };
-__device__ __constant__ int8_t c_dst_mat[16] = { 29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29 };
+__device__ __constant__ __attribute__((aligned(4))) int8_t c_dst_mat[16] = { 29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29 };
 __device__ __constant__ int8_t c_level_scale[6] = { 40, 45, 51, 57, 64, 72 };
 __device__ __constant__ int8_t c_intra_angle[35] = {
   0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26,
@@ -26,9 +26,30 @@ __device__ __constant__ int16_t c_inv_angle[15] = {
 
 __device__ __forceinline__ int clip3(int lo, int hi, int v) { return min(max(v, lo), hi); }
 
+// All kernels in this file run ONE wavefront per workgroup, so the phases of a TU only
+// need LDS ordering inside the wave.  __syncthreads() would also drain vmcnt (global
+// stores of the previous TU, ~1 us each); this waits for LDS only and is a compiler barrier.
+#define LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+// Diagnostic cycle stamps (DE265HIP_DEBUG bit 16): per-phase s_memtime deltas summed into a
+// debug buffer that nothing else reads.  stamp == nullptr in normal runs.
+struct Stamper {
+  uint32_t* buf; long long t0; int lane;
+  __device__ __forceinline__ void mark(int phase)
+  {
+    if (buf) {
+      LDS_SYNC();
+      long long t = clock64();
+      if (lane == 0) atomicAdd(&buf[phase], (uint32_t)(t - t0));
+      t0 = clock64();
+    }
+  }
+};
+
 template <typename PX>
 struct TuShared {
   int8_t  mat[32 * 32];        // DCT matrix
+  int8_t  dstm[16];            // DST matrix
   int16_t coeff[32 * 32];      // dequantised coefficients
   int16_t g[32 * 32];          // first-stage output
   uint16_t pred[32 * 32];      // intra prediction
@@ -47,7 +68,7 @@ __device__ __forceinline__ int wave_sum(int v)
 
 template <typename PX>
 __device__ void intra_predict(const PicDev& P, const TuTask& t, const PX* plane, int stride,
-                              TuShared<PX>& S, int lane)
+                              TuShared<PX>& S, int lane, Stamper& st)
 {
   const int nT = 1 << t.log2_size;
   const int cIdx = t.c_idx;
@@ -86,7 +107,8 @@ __device__ void intra_predict(const PicDev& P, const TuTask& t, const PX* plane,
     }
     border[i] = val;
   }
-  __syncthreads();
+  LDS_SYNC();
+  st.mark(1);
 
   // ---- smoothing (intra_prediction_sample_filtering), luma only in 4:2:0
   const int mode = t.intra_mode >= 35 ? 1 : t.intra_mode;
@@ -113,11 +135,12 @@ __device__ void intra_predict(const PicDev& P, const TuTask& t, const PX* plane,
       } else v = (border[i + 1] + 2 * border[i] + border[i - 1] + 2) >> 2;
       bf[i] = v;
     }
-    __syncthreads();
+    LDS_SYNC();
     for (int p = lane; p <= 4 * nT; p += 64) border[p - 2 * nT] = bf[p - 2 * nT];
-    __syncthreads();
+    LDS_SYNC();
   }
 
+  st.mark(2);
   const int log2 = t.log2_size;
   const int nS = nT * nT;
   if (mode == 0) {                           // planar
@@ -157,7 +180,7 @@ __device__ void intra_predict(const PicDev& P, const TuTask& t, const PX* plane,
           bf[x] = vert ? border[-k] : border[k];
         }
     }
-    __syncthreads();
+    LDS_SYNC();
     for (int s = lane; s < nS; s += 64) {
       int y = s >> log2, x = s & (nT - 1);
       int a = vert ? y : x, b = vert ? x : y;      // a: along prediction direction
@@ -173,7 +196,8 @@ __device__ void intra_predict(const PicDev& P, const TuTask& t, const PX* plane,
       S.pred[s] = (uint16_t)o;
     }
   }
-  __syncthreads();
+  LDS_SYNC();
+  st.mark(3);
 }
 
 // Residual reconstruction from the dense coefficient block in S.coeff.
@@ -204,15 +228,15 @@ __device__ void tu_residual_add(TuShared<PX>& S, int lane, PX* dst, int stride, 
       int i = lane >> 2, c = lane & 3;
       int sum = 0;
 #pragma unroll
-      for (int j = 0; j < 4; j++) sum += c_dst_mat[j * 4 + i] * S.coeff[c + j * 4];
+      for (int j = 0; j < 4; j++) sum += S.dstm[j * 4 + i] * S.coeff[c + j * 4];
       S.g[i * 4 + c] = (int16_t)clip3(-32768, 32767, (sum + 64) >> 7);
     }
-    __syncthreads();
+    LDS_SYNC();
     if (lane < 16) {
       int y = lane >> 2, i = lane & 3;
       int sum = 0;
 #pragma unroll
-      for (int j = 0; j < 4; j++) sum += c_dst_mat[j * 4 + i] * S.g[y * 4 + j];
+      for (int j = 0; j < 4; j++) sum += S.dstm[j * 4 + i] * S.g[y * 4 + j];
       int out = clip3(-32768, 32767, (sum + rnd2) >> post);
       int p = has_pred ? (int)S.pred[lane] : (int)dst[i + y * stride];
       dst[i + y * stride] = (PX)clip3(0, maxv, p + out);
@@ -229,7 +253,7 @@ __device__ void tu_residual_add(TuShared<PX>& S, int lane, PX* dst, int stride, 
     for (int j = 0; j <= lastRow; j++) sum += S.mat[fact * j * 32 + i] * S.coeff[c + j * nT];
     S.g[i * nT + c] = (int16_t)clip3(-32768, 32767, (sum + 64) >> 7);
   }
-  __syncthreads();
+  LDS_SYNC();
   for (int s = lane; s < nS; s += 64) {
     int y = s >> log2, i = s & (nT - 1);
     int sum = 0;
@@ -240,19 +264,16 @@ __device__ void tu_residual_add(TuShared<PX>& S, int lane, PX* dst, int stride, 
   }
 }
 
+// One TU on `plane` (a global picture plane or an LDS pixel window; t.x0/t.y0 are
+// coordinates in that plane): intra prediction, coefficient scatter + dequantisation,
+// residual add.  load_mat: copy the DCT matrix into LDS first (skip when already there).
 template <typename PX>
-__global__ __launch_bounds__(64)
-void k_tu(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const TuTask* __restrict__ tasks,
-          int first, const int16_t* __restrict__ coeff_val, const uint16_t* __restrict__ coeff_pos,
-          const uint8_t* __restrict__ scaling)
+__device__ void tu_reconstruct(const PicDev& P, const TuTask& t, PX* plane, int stride, TuShared<PX>& S,
+                               int lane, const int16_t* __restrict__ coeff_val,
+                               const uint16_t* __restrict__ coeff_pos, const uint8_t* __restrict__ scaling,
+                               bool load_mat, Stamper& st)
 {
-  __shared__ TuShared<PX> S;
-  const int lane = threadIdx.x;
-  const TuTask t = tasks[first + blockIdx.x];
   const int cIdx = t.c_idx;
-  const PlaneRef pr = cIdx == 0 ? pl0 : (cIdx == 1 ? pl1 : pl2);
-  PX* plane = (PX*)pr.ptr;
-  const int stride = pr.stride;
   const int log2 = t.log2_size;
   const int nT = 1 << log2, nS = nT * nT;
   const int bd = cIdx ? P.bd_chroma : P.bd_luma;
@@ -260,7 +281,7 @@ void k_tu(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const TuTask* __re
   const bool cbf = t.flags & DE265HIP_TU_CBF;
   PX* dst = plane + t.x0 + t.y0 * stride;
 
-  if (intra) intra_predict<PX>(P, t, plane, stride, S, lane);
+  if (intra) intra_predict<PX>(P, t, plane, stride, S, lane, st);
 
   if (!cbf) {
     if (intra)
@@ -274,9 +295,11 @@ void k_tu(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const TuTask* __re
   const bool is_dst = (nT == 4 && cIdx == 0 && intra);
   for (int s = lane; s < nS; s += 64) S.coeff[s] = 0;
   if (lane == 0) { S.last_row = 0; S.last_col = 0; }
-  if (!bypass && !tskip && !is_dst)
-    for (int s = lane; s < 256; s += 64) ((int32_t*)S.mat)[s] = ((const int32_t*)c_dct_mat)[s];
-  __syncthreads();
+  if (load_mat && !bypass && !tskip) {
+    if (is_dst) { if (lane < 4) ((int32_t*)S.dstm)[lane] = ((const int32_t*)c_dst_mat)[lane]; }
+    else for (int s = lane; s < 256; s += 64) ((int32_t*)S.mat)[s] = ((const int32_t*)c_dct_mat)[s];
+  }
+  LDS_SYNC();
   {
     const int16_t* vals = coeff_val + t.coeff_offset;
     const uint16_t* pos = coeff_pos + t.coeff_offset;
@@ -312,10 +335,161 @@ void k_tu(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const TuTask* __re
     if (lr) atomicMax(&S.last_row, lr);
     if (lc) atomicMax(&S.last_col, lc);
   }
-  __syncthreads();
+  LDS_SYNC();
+  st.mark(4);
 
   const int kind = bypass ? 3 : (tskip ? 2 : (is_dst ? 1 : 0));
   tu_residual_add<PX>(S, lane, dst, stride, log2, bd, kind, intra, S.last_row, S.last_col);
+  st.mark(5);
+}
+
+// One workgroup (one wavefront) per TU of a dependency level.
+template <typename PX>
+__global__ __launch_bounds__(64)
+void k_tu(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const TuTask* __restrict__ tasks,
+          int first, const int16_t* __restrict__ coeff_val, const uint16_t* __restrict__ coeff_pos,
+          const uint8_t* __restrict__ scaling)
+{
+  __shared__ TuShared<PX> S;
+  const TuTask t = tasks[first + blockIdx.x];
+  const PlaneRef pr = t.c_idx == 0 ? pl0 : (t.c_idx == 1 ? pl1 : pl2);
+  Stamper st{ nullptr, 0, (int)threadIdx.x };
+  tu_reconstruct<PX>(P, t, (PX*)pr.ptr, pr.stride, S, threadIdx.x, coeff_val, coeff_pos, scaling, true, st);
+}
+
+// ---------------------------------------------------------------- run kernel
+// All intra TUs of a picture in ONE launch.  Each wavefront takes a ticket (runs are
+// stored in dependency order, producers first), waits for the runs it reads from
+// (agent-scope flag + acquire), loads the pixel window of its run into LDS, reconstructs
+// the run's TUs serially inside LDS (the z-scan dependency chain never leaves the CU),
+// writes every finished TU back and publishes its flag (agent-scope release).
+// Deadlock-free for any dispatch order: a run only waits on smaller tickets, and a
+// ticket is only taken by a wavefront that is already running.  Spins are bounded.
+#define RUN_TILE_H 97                 // 1 + 64 + 32 rows
+#define RUN_TILE_P 104                // 7 (alignment slack) + 1 + 64 + 32 columns; 16-byte aligned rows
+#define RUN_SPIN_LIMIT (1 << 19)      // x ~2 us per poll: about 1 s
+
+// 8 consecutive samples <-> 8 x uint16 in LDS
+__device__ __forceinline__ uint4 load8_as_u16(const uint16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ uint4 load8_as_u16(const uint8_t* p)
+{
+  uint2 r = *reinterpret_cast<const uint2*>(p);
+  uint4 o;
+  o.x = (r.x & 0xFF) | ((r.x & 0xFF00) << 8);           o.y = ((r.x >> 16) & 0xFF) | ((r.x >> 24) << 16);
+  o.z = (r.y & 0xFF) | ((r.y & 0xFF00) << 8);           o.w = ((r.y >> 16) & 0xFF) | ((r.y >> 24) << 16);
+  return o;
+}
+__device__ __forceinline__ void store4_from_u16(uint16_t* g, uint2 v) { *reinterpret_cast<uint2*>(g) = v; }
+__device__ __forceinline__ void store4_from_u16(uint8_t* g, uint2 v)
+{
+  *reinterpret_cast<uint32_t*>(g) = (v.x & 0xFF) | ((v.x >> 8) & 0xFF00) | ((v.y & 0xFF) << 16) | ((v.y >> 16) << 24);
+}
+
+template <typename PX>
+__global__ __launch_bounds__(64)
+void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __restrict__ runs,
+           const uint32_t* __restrict__ deps, uint32_t* sync, uint32_t* err, const TuTask* __restrict__ tasks,
+           const int16_t* __restrict__ coeff_val, const uint16_t* __restrict__ coeff_pos,
+           const uint8_t* __restrict__ scaling, int dbg)
+{
+  __shared__ TuShared<uint16_t> S;
+  __shared__ __attribute__((aligned(16))) uint16_t tile[RUN_TILE_H * RUN_TILE_P];
+  __shared__ TuTask s_tasks[64];
+  __shared__ uint32_t s_ticket;
+  const int lane = threadIdx.x;
+  if (lane == 0) s_ticket = atomicAdd(&sync[0], 1u);
+  for (int s = lane; s < 256; s += 64) ((int32_t*)S.mat)[s] = ((const int32_t*)c_dct_mat)[s];
+  if (lane < 4) ((int32_t*)S.dstm)[lane] = ((const int32_t*)c_dst_mat)[lane];
+  __syncthreads();
+  const uint32_t ticket = __builtin_amdgcn_readfirstlane(s_ticket);    // wave-uniform: scalar loads/branches below
+  const RunTask run = runs[ticket];
+  Stamper st{ (dbg & 16) ? err + 8 : nullptr, clock64(), lane };
+
+  if (run.n_deps) {
+    for (int i = lane; i < run.n_deps; i += 64) {
+      const uint32_t* flag = &sync[2 + deps[run.dep_offset + i]];
+      int spins = 0;
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        // back off quickly: hundreds of waiting wavefronts polling at full rate starve the fabric
+        if (spins < 4) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(64);
+        if (++spins > RUN_SPIN_LIMIT) { atomicExch(err, 1u); break; }           // never hang the grid
+      }
+    }
+    __syncthreads();
+    if (!(dbg & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+
+  const int c = run.c_idx;
+  const PlaneRef pr = c == 0 ? pl0 : (c == 1 ? pl1 : pl2);
+  PX* plane = (PX*)pr.ptr;
+  const int stride = pr.stride;
+  const int cw = c ? P.width >> 1 : P.width, ch = c ? P.height >> 1 : P.height;
+  // pixel window: bbox + 1 left/top + 32 right/bottom (everything a TU of the run can read),
+  // fetched in aligned 8-sample chunks, several loads in flight per lane
+  const int wx0 = (int)run.x0 - 1, wy0 = (int)run.y0 - 1;
+  const int wx1 = min((int)run.x1 + 32, cw), wy1 = min((int)run.y1 + 32, ch);
+  const int ax0 = wx0 & ~7;                                  // -8 when the run touches the left picture edge
+  const int nchx = (wx1 - ax0 + 7) >> 3, nrows = wy1 - wy0;
+  const int nchunks = nchx * nrows;
+  if (!(dbg & 8))
+  for (int base = 0; base < nchunks; base += 256) {
+    uint4 v[4]; int off[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      int idx = base + u * 64 + lane;
+      off[u] = -1;
+      if (idx < nchunks) {
+        int r = idx / nchx, cx = idx - r * nchx;
+        int gx = ax0 + 8 * cx, gy = wy0 + r;
+        // the bottom-right 32x32 corner of the window is never read
+        if (gx >= 0 && gy >= 0 && !(gx >= (int)run.x1 && gy >= (int)run.y1)) {
+          v[u] = load8_as_u16(plane + gx + gy * stride);
+          off[u] = r * RUN_TILE_P + 8 * cx;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (off[u] >= 0) *reinterpret_cast<uint4*>(&tile[off[u]]) = v[u];
+  }
+  LDS_SYNC();
+
+  if (!(dbg & 4))
+  for (int base = 0; base < run.n_tus; base += 64) {
+    const int nb = min(64, (int)run.n_tus - base);
+    if (lane < nb) s_tasks[lane] = tasks[run.first_tu + base + lane];
+    LDS_SYNC();
+    for (int k = 0; k < nb; k++) {
+      // wave-uniform copy of the task (SGPRs): every branch and table index below is scalar
+      TuTask t;
+      {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(&s_tasks[k]);
+        uint32_t* o = reinterpret_cast<uint32_t*>(&t);
+#pragma unroll
+        for (int q = 0; q < 6; q++) o[q] = __builtin_amdgcn_readfirstlane(w[q]);
+      }
+      const int gx0 = t.x0, gy0 = t.y0;
+      t.x0 = (uint16_t)(gx0 - ax0); t.y0 = (uint16_t)(gy0 - wy0);       // window coordinates
+      st.mark(0);
+      tu_reconstruct<uint16_t>(P, t, tile, RUN_TILE_P, S, lane, coeff_val, coeff_pos, scaling, false, st);
+      LDS_SYNC();
+      // write the finished TU back, 4 samples per lane (only the run's own samples ever leave the window)
+      const int log2 = t.log2_size, nT = 1 << log2, l4 = log2 - 2;
+      for (int s = lane; s < (nT * nT) >> 2; s += 64) {
+        int y = s >> l4, x = (s & ((1 << l4) - 1)) << 2;
+        uint2 v = *reinterpret_cast<const uint2*>(&tile[(t.y0 + y) * RUN_TILE_P + t.x0 + x]);
+        store4_from_u16(plane + (gx0 + x) + (gy0 + y) * stride, v);
+      }
+      st.mark(6);
+      if (st.buf && lane == 0) atomicAdd(&st.buf[7], 1u);
+    }
+    LDS_SYNC();
+  }
+
+  // publish: all stores of this wavefront -> agent-scope release -> flag
+  if (!(dbg & 1)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) __hip_atomic_store(&sync[2 + ticket], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Function-level form (acceleration.h:143-178 slot semantics): dense coefficient
@@ -331,6 +505,7 @@ void k_fn_residual(int kind, int log2_size, int bit_depth, PX* plane, int stride
   const int16_t* c = coeffs + (size_t)blockIdx.x * nS;
   for (int s = lane; s < nS; s += 64) S.coeff[s] = c[s];
   for (int s = lane; s < 256; s += 64) ((int32_t*)S.mat)[s] = ((const int32_t*)c_dct_mat)[s];
+  if (lane < 4) ((int32_t*)S.dstm)[lane] = ((const int32_t*)c_dst_mat)[lane];
   __syncthreads();
   PX* dst = plane + xy[2 * blockIdx.x] + xy[2 * blockIdx.x + 1] * stride;
   tu_residual_add<PX>(S, lane, dst, stride, log2_size, bit_depth, kind, false, nT - 1, nT - 1);
@@ -340,6 +515,10 @@ template __global__ void k_tu<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, con
                                        const int16_t*, const uint16_t*, const uint8_t*);
 template __global__ void k_tu<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int,
                                         const int16_t*, const uint16_t*, const uint8_t*);
+template __global__ void k_run<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*,
+                                        const TuTask*, const int16_t*, const uint16_t*, const uint8_t*, int);
+template __global__ void k_run<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*,
+                                         const TuTask*, const int16_t*, const uint16_t*, const uint8_t*, int);
 template __global__ void k_fn_residual<uint8_t>(int, int, int, uint8_t*, int, const int32_t*, const int16_t*);
 template __global__ void k_fn_residual<uint16_t>(int, int, int, uint16_t*, int, const int32_t*, const int16_t*);
 

@@ -22,6 +22,9 @@ template <typename PX>
 __global__ void k_tu(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int,
                      const int16_t*, const uint16_t*, const uint8_t*);
 template <typename PX>
+__global__ void k_run(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*,
+                      const TuTask*, const int16_t*, const uint16_t*, const uint8_t*, int);
+template <typename PX>
 __global__ void k_mc(PicDev, DpbTable, PlaneRef, PlaneRef, PlaneRef, const McTask*,
                      const de265hip_slice_params*);
 template <typename PX>

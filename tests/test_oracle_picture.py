@@ -42,8 +42,8 @@ def test_phase_order_equals_decode_order(bd, st):
 
 
 def test_generator_is_deterministic_and_covers_features():
-    a, _ = make(352, 288, 8, 0, 9, pcm_pct=10, tskip_pct=30, bypass_pct=10)
-    b, _ = make(352, 288, 8, 0, 9, pcm_pct=10, tskip_pct=30, bypass_pct=10)
+    a, _ = make(352, 288, 8, 0, 9, pcm_pct=40, tskip_pct=30, bypass_pct=10)
+    b, _ = make(352, 288, 8, 0, 9, pcm_pct=40, tskip_pct=30, bypass_pct=10)
     da, db = a.d, b.d
     assert da.n_tus == db.n_tus and da.n_pus == db.n_pus and da.n_coeffs == db.n_coeffs
     ta = np.ctypeslib.as_array(C.cast(da.tus, C.POINTER(C.c_uint8)), shape=(da.n_tus * C.sizeof(_abi.TU),))

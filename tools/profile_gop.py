@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Per-picture device-time breakdown of the bench GOP (hipEvent timers of the library).
+    python tools/profile_gop.py [--pictures 4] [--reps 5]"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
+    sys.path.insert(0, p)
+import pysynth  # noqa: E402
+from libde265_amd import backend, farm, _abi  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--pictures", type=int, default=4)
+ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--width", type=int, default=3840)
+ap.add_argument("--height", type=int, default=2160)
+ap.add_argument("--bit-depth", type=int, default=10)
+ap.add_argument("--over", default="", help="synth overrides, e.g. cbf_pct=0,split_bias=100")
+a = ap.parse_args()
+W, H, BD = a.width, a.height, a.bit_depth
+dec = backend.Decoder()
+pics = []
+for k, (st, refs) in enumerate(farm.gop_plan(a.pictures)):
+    over = dict(ref_slots=refs) if refs else {}
+    over.update({kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.over.split(",") if kv})
+    sp = pysynth.SynthPicture(pysynth.default_config(W, H, BD, st, seed=farm.gop_seed(4, 0) + k, **over))
+    dec.dpb_alloc(k, W, H, BD)
+    pics.append((sp, dec.build(k, sp.desc)))
+for sp, p in pics:
+    dec.run(p, 2)
+dec.sync()
+dec.set_profiling(True)
+for k, (sp, p) in enumerate(pics):
+    dec.kernel_times(reset=True)
+    for _ in range(a.reps):
+        dec.run(p, 2)
+    kt = dec.kernel_times(reset=True)
+    s = p.stats()
+    print("pic %d type %s tus %d mc %d levels %d runs %d runlevels %d | " % (
+        k, "I" if k == 0 else "B", s.n_tu_tasks, s.n_mc_tasks, s.n_levels, s.n_runs, s.n_run_levels) +
+          " ".join("%s=%.1fus" % (n, 1e3 * v[0] / a.reps) for n, v in kt.items() if v[1]))

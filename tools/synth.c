@@ -388,7 +388,7 @@ synth_picture* synth_generate(const synth_config* cfg)
   synth_picture* s = calloc(1, sizeof(*s));
   s->cfg = *cfg;
   const synth_config* g = &s->cfg;
-  s->rng.s = cfg->seed * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+  { rng_t h; h.s = cfg->seed ^ 0x5DEECE66Dull; (void)rnd64(&h); s->rng.s = rnd64(&h); }   /* hashed: nearby seeds give unrelated streams */
   rng_t* r = &s->rng;
   de265hip_pic_params* P = &s->desc.params;
   P->width = g->width; P->height = g->height;
@@ -538,7 +538,7 @@ const uint8_t* synth_blk_flags_noedge(const synth_picture* s) { return s->blk_fl
 
 void synth_fill_plane(void* plane, int stride, int w, int h, int bd, uint64_t seed)
 {
-  rng_t r; r.s = seed * 0xD1342543DE82EF95ull + 77;
+  rng_t r; { rng_t h; h.s = seed ^ 0xA5A5A5A5ull; (void)rnd64(&h); r.s = rnd64(&h); }
   int maxv = (1 << bd) - 1;
   double amp = maxv * 0.35, mid = maxv * 0.5;
   double fx = 1.0 / (17.0 + (double)(seed % 13)), fy = 1.0 / (29.0 + (double)(seed % 7));
