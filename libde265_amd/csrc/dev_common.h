@@ -42,8 +42,12 @@ struct TuTask {
   uint16_t n_coeff;
   uint32_t coeff_offset;
   uint64_t avail;
+  uint32_t resid_offset;   // run mode: where the precomputed int16 residual block of an intra TU lives
+  uint32_t pad2;
 };
-static_assert(sizeof(TuTask) == 24, "TuTask layout");
+static_assert(sizeof(TuTask) == 32, "TuTask layout");
+// internal TuTask flag: compute the residual only (into the residual buffer), no prediction, no picture access
+#define D265_TU_RESID_ONLY 0x80
 
 // MC task: a <=16x16 luma tile of one PU (plus its two 4:2:0 chroma tiles).
 struct McTask {
@@ -66,8 +70,10 @@ struct RunTask {
   uint32_t first_tu;         // into the run-ordered TuTask array
   uint32_t dep_offset;       // into the producer-run id array
   uint16_t n_deps, pad1;
+  uint32_t res_offset;       // the run's residual blocks: one contiguous int16 range (multiple of 8 long)
+  uint32_t res_len;
 };
-static_assert(sizeof(RunTask) == 24, "RunTask layout");
+static_assert(sizeof(RunTask) == 32, "RunTask layout");
 
 struct PcmTask {
   uint16_t x0, y0;

@@ -72,7 +72,9 @@ struct de265hip_picture {
   uint8_t* d_bs = nullptr;
   RunTask* d_runs = nullptr; uint32_t* d_deps = nullptr; uint32_t* d_sync = nullptr;
   TuTask* d_run_tus = nullptr;
-  int n_runs = 0; size_t sync_bytes = 0;
+  TuTask* d_l0 = nullptr; int n_l0 = 0;       // run mode: inter residual TUs + residual-only copies of intra TUs
+  int16_t* d_resid = nullptr;                 // precomputed residual blocks of intra TUs
+  int n_runs = 0, n_workers = 0; size_t sync_bytes = 0;
   std::vector<int> level_start;       // level_start[l] .. level_start[l+1] in d_tus
   int n_mc = 0, n_pcm = 0, n_tus = 0;
   bool any_edges = false;
@@ -421,7 +423,8 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   pic->n_tus = (int)sorted.size();
 
   // ---- runs in dependency (ticket) order: producers first
-  std::vector<RunTask> runs; std::vector<uint32_t> run_deps; std::vector<TuTask> run_tus;
+  std::vector<RunTask> runs; std::vector<uint32_t> run_deps; std::vector<TuTask> run_tus, resid_only;
+  size_t n_resid = 0;
   int max_rl = 0;
   {
     for (auto& R : rb) { int l = 0; for (int dp : R.deps) l = std::max(l, rb[dp].level); R.level = l + 1; max_rl = std::max(max_rl, R.level); }
@@ -436,11 +439,34 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       o.x0 = (uint16_t)R.x0; o.y0 = (uint16_t)R.y0; o.x1 = (uint16_t)R.x1; o.y1 = (uint16_t)R.y1;
       o.c_idx = (uint8_t)R.c; o.n_tus = (uint16_t)R.tus.size();
       o.first_tu = (uint32_t)run_tus.size(); o.dep_offset = (uint32_t)run_deps.size(); o.n_deps = (uint16_t)R.deps.size();
-      run_tus.insert(run_tus.end(), R.tus.begin(), R.tus.end());
+      o.res_offset = (uint32_t)n_resid;
+      for (TuTask tt : R.tus) {
+        if (tt.flags & DE265HIP_TU_CBF) {
+          tt.resid_offset = (uint32_t)n_resid;
+          n_resid += (size_t)1 << (2 * tt.log2_size);
+          TuTask ro = tt; ro.flags |= D265_TU_RESID_ONLY;
+          resid_only.push_back(ro);
+        }
+        run_tus.push_back(tt);
+      }
+      o.res_len = (uint32_t)(n_resid - o.res_offset);
       for (int dp : R.deps) run_deps.push_back((uint32_t)newidx[dp]);
     }
   }
   pic->n_runs = (int)runs.size();
+  {
+    // worker count = widest dependency level (more workers would only wait), within [64, 4 per CU]
+    std::vector<int> width(max_rl + 2, 0);
+    for (auto& R : rb) width[R.level]++;
+    int widest = 0; for (int wv : width) widest = std::max(widest, wv);
+    const char* wenv = getenv("DE265HIP_RUN_WORKERS");
+    int cap = wenv ? atoi(wenv) : 1024;
+    pic->n_workers = std::min(pic->n_runs, std::max(64, std::min(cap, widest + widest / 4)));
+  }
+  // level-0 launch of run mode: inter TUs with residual, then the residual-only intra TUs
+  std::vector<TuTask> l0(sorted.begin() + pic->level_start[0], sorted.begin() + pic->level_start[1]);
+  l0.insert(l0.end(), resid_only.begin(), resid_only.end());
+  pic->n_l0 = (int)l0.size();
 
   // ---- MC tasks: resolve references, bi->uni shortcut, split into <=16x16 tiles
   std::vector<McTask> mcs;
@@ -520,6 +546,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   const size_t o_bs = L.add(nblk);
   const size_t o_runs = L.add(runs.size() * sizeof(RunTask)), o_rdeps = L.add(run_deps.size() * 4);
   const size_t o_rtus = L.add(run_tus.size() * sizeof(TuTask));
+  const size_t o_l0 = L.add(l0.size() * sizeof(TuTask)), o_resid = L.add(n_resid * 2 + 64);
   pic->sync_bytes = (2 + runs.size()) * 4;
   const size_t o_sync = L.add(pic->sync_bytes);
   std::vector<uint8_t> host(L.total, 0);
@@ -534,6 +561,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   put(o_tile, g.tile_id.data(), (size_t)d->n_ctbs * 2);
   put(o_runs, runs.data(), runs.size() * sizeof(RunTask)); put(o_rdeps, run_deps.data(), run_deps.size() * 4);
   put(o_rtus, run_tus.data(), run_tus.size() * sizeof(TuTask));
+  put(o_l0, l0.data(), l0.size() * sizeof(TuTask));
   put(o_flags, d->blk_flags, nblk); put(o_qp, d->blk_qp_y, nblk);
   if (d->blk_motion) put(o_mot, d->blk_motion, nblk * sizeof(de265hip_motion));
   else memset(host.data() + o_mot, 0xFF, nblk * sizeof(de265hip_motion));       // ref_slot = -1 everywhere
@@ -557,6 +585,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   pic->d_bs = base + o_bs;
   pic->d_runs = (RunTask*)(base + o_runs); pic->d_deps = (uint32_t*)(base + o_rdeps);
   pic->d_run_tus = (TuTask*)(base + o_rtus); pic->d_sync = (uint32_t*)(base + o_sync);
+  pic->d_l0 = (TuTask*)(base + o_l0); pic->d_resid = (int16_t*)(base + o_resid);
 
   const int64_t Pbytes = (int64_t)p.width * p.height * 3 / 2 * px_bytes(p.bit_depth_luma);
   pic->stats.n_levels = max_level + (pic->level_start[1] > 0 ? 1 : 0);
@@ -612,23 +641,34 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
     hipLaunchKernelGGL(k_pcm<PX>, dim3(pic->n_pcm), dim3(256), 0, st, d0, d1, d2, pic->d_pcm, pic->d_pcm_samples);
   }
   const int nlev = (int)pic->level_start.size() - 1;
-  if (nlev > 0 && pic->level_start[1] > pic->level_start[0]) {
-    KTimer t(dec, DE265HIP_K_RESID, 1);
-    hipLaunchKernelGGL(k_tu<PX>, dim3(pic->level_start[1] - pic->level_start[0]), dim3(64), 0, st, P, d0, d1, d2,
-                       pic->d_tus, pic->level_start[0], pic->d_cval, pic->d_cpos, pic->d_scaling);
-  }
-  if (pic->n_runs > 0 && !dec->intra_levels) {
-    KTimer t(dec, DE265HIP_K_INTRA, 1);
-    (void)hipMemsetAsync(pic->d_sync, 0, pic->sync_bytes, st);
-    hipLaunchKernelGGL(k_run<PX>, dim3(pic->n_runs), dim3(64), 0, st, P, d0, d1, d2, pic->d_runs, pic->d_deps,
-                       pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_cval, pic->d_cpos, pic->d_scaling, dec->dbg);
-  } else if (nlev > 1) {
-    KTimer t(dec, DE265HIP_K_INTRA, nlev - 1);
-    for (int l = 1; l < nlev; l++) {
-      int cnt = pic->level_start[l + 1] - pic->level_start[l];
-      if (cnt <= 0) continue;
-      hipLaunchKernelGGL(k_tu<PX>, dim3(cnt), dim3(64), 0, st, P, d0, d1, d2, pic->d_tus, pic->level_start[l],
-                         pic->d_cval, pic->d_cpos, pic->d_scaling);
+  if (!dec->intra_levels) {
+    // run mode: one launch for every residual (inter TUs add into the picture, intra TUs fill the
+    // residual buffer), then one launch for the whole intra dependency graph
+    if (pic->n_l0 > 0) {
+      KTimer t(dec, DE265HIP_K_RESID, 1);
+      hipLaunchKernelGGL(k_tu<PX>, dim3(pic->n_l0), dim3(64), 0, st, P, d0, d1, d2, pic->d_l0, 0, pic->d_cval,
+                         pic->d_cpos, pic->d_scaling, pic->d_resid);
+    }
+    if (pic->n_runs > 0) {
+      KTimer t(dec, DE265HIP_K_INTRA, 1);
+      (void)hipMemsetAsync(pic->d_sync, 0, pic->sync_bytes, st);
+      hipLaunchKernelGGL(k_run<PX>, dim3(pic->n_workers), dim3(64), 0, st, P, d0, d1, d2, pic->d_runs, pic->d_deps,
+                         pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->n_runs, dec->dbg);
+    }
+  } else {
+    if (nlev > 0 && pic->level_start[1] > pic->level_start[0]) {
+      KTimer t(dec, DE265HIP_K_RESID, 1);
+      hipLaunchKernelGGL(k_tu<PX>, dim3(pic->level_start[1] - pic->level_start[0]), dim3(64), 0, st, P, d0, d1, d2,
+                         pic->d_tus, pic->level_start[0], pic->d_cval, pic->d_cpos, pic->d_scaling, (int16_t*)nullptr);
+    }
+    if (nlev > 1) {
+      KTimer t(dec, DE265HIP_K_INTRA, nlev - 1);
+      for (int l = 1; l < nlev; l++) {
+        int cnt = pic->level_start[l + 1] - pic->level_start[l];
+        if (cnt <= 0) continue;
+        hipLaunchKernelGGL(k_tu<PX>, dim3(cnt), dim3(64), 0, st, P, d0, d1, d2, pic->d_tus, pic->level_start[l],
+                           pic->d_cval, pic->d_cpos, pic->d_scaling, (int16_t*)nullptr);
+      }
     }
   }
   if (last_stage >= DE265HIP_STAGE_DEBLOCKED && !pic->params.disable_deblocking && pic->any_edges) {

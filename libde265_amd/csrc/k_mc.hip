@@ -115,76 +115,255 @@ __device__ __forceinline__ PX mc_combine(int mode, int a, int b, int bd, int w0,
   return (PX)mc_clip3(0, maxv, v);
 }
 
+// ---------------------------------------------------------------- picture-level MC kernel
+// One wavefront per MC task.  All reference fetches of the task (2 lists x 3 planes) are
+// issued back to back as aligned 4-sample vector loads into LDS (one exposed HBM/L2 latency
+// instead of six); tasks that touch the picture border use per-sample clamped loads into the
+// same LDS layout.  Each lane then produces 4 horizontally adjacent luma samples (2 chroma)
+// so that filters slide over registers and the final store is one 8-byte access per lane.
+#define MCL_P 36                       // luma input pitch: 28 used; 72-byte rows are 8-byte aligned and spread over banks
+#define MCC_P 20                       // chroma input pitch: 16 used
+#define MCT_P 20                       // pitch of the horizontal-pass buffer (16 used)
+
+template <typename PX> __device__ __forceinline__ uint2 ld4_u16(const PX* p);
+template <> __device__ __forceinline__ uint2 ld4_u16<uint16_t>(const uint16_t* p) { return *reinterpret_cast<const uint2*>(p); }
+template <> __device__ __forceinline__ uint2 ld4_u16<uint8_t>(const uint8_t* p)
+{
+  uint32_t r = *reinterpret_cast<const uint32_t*>(p);
+  return make_uint2((r & 0xFF) | ((r & 0xFF00) << 8), ((r >> 16) & 0xFF) | ((r >> 24) << 16));
+}
+template <typename PX> __device__ __forceinline__ void st4_px(PX* p, const int v[4]);
+template <> __device__ __forceinline__ void st4_px<uint16_t>(uint16_t* p, const int v[4])
+{ *reinterpret_cast<uint2*>(p) = make_uint2((uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16)); }
+template <> __device__ __forceinline__ void st4_px<uint8_t>(uint8_t* p, const int v[4])
+{ *reinterpret_cast<uint32_t*>(p) = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24); }
+template <typename PX> __device__ __forceinline__ void st2_px(PX* p, int a, int b);
+template <> __device__ __forceinline__ void st2_px<uint16_t>(uint16_t* p, int a, int b)
+{ *reinterpret_cast<uint32_t*>(p) = (uint32_t)a | ((uint32_t)b << 16); }
+template <> __device__ __forceinline__ void st2_px<uint8_t>(uint8_t* p, int a, int b)
+{ *reinterpret_cast<uint16_t*>(p) = (uint16_t)(a | (b << 8)); }
+
+#define MC_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")   // one wave per workgroup
+
 template <typename PX>
 __global__ __launch_bounds__(64)
 void k_mc(PicDev P, DpbTable dpb, PlaneRef d0, PlaneRef d1, PlaneRef d2,
           const McTask* __restrict__ tasks, const de265hip_slice_params* __restrict__ slices)
 {
-  __shared__ uint16_t s_in[23 * MC_IWP];
-  __shared__ int16_t s_tmp[23 * 16];
+  __shared__ __attribute__((aligned(16))) uint16_t s_inL[2][23 * MCL_P];
+  __shared__ __attribute__((aligned(16))) uint16_t s_inC[2][2][11 * MCC_P];
+  __shared__ __attribute__((aligned(16))) int16_t s_tmp[23 * MCT_P];
   const int lane = threadIdx.x;
   const McTask t = tasks[blockIdx.x];
   const de265hip_slice_params* sh = &slices[t.slice_idx];
   const bool use0 = t.slot[0] >= 0, use1 = t.slot[1] >= 0;
   const bool bi = use0 && use1;
   const int l_uni = use0 ? 0 : 1;
+  const int w = t.w, h = t.h, wc = w >> 1, hc = h >> 1;
+  const int cW = P.width >> 1, cH = P.height >> 1;
 
-  // prediction mode (motion.cc:440-620)
-  int mode;
+  int mode;                                         // motion.cc:440-620
   if (sh->slice_type == 1) mode = P.weighted_pred ? 1 : 0;
   else if (bi) mode = P.weighted_bipred ? 3 : 2;
   else mode = P.weighted_bipred ? 1 : 0;
 
-  const PlaneRef dsts[3] = { d0, d1, d2 };
+  // ---------------- fetch (all lists and planes, then one wait)
+  int oxL[2] = { 0, 0 }, oxC[2] = { 0, 0 };
 #pragma unroll
-  for (int comp = 0; comp < 3; comp++) {
-    const int bd = comp ? P.bd_chroma : P.bd_luma;
-    const int w = comp ? t.w >> 1 : t.w, h = comp ? t.h >> 1 : t.h;
-    const int x0 = comp ? t.x >> 1 : t.x, y0 = comp ? t.y >> 1 : t.y;
-    const int picW = comp ? P.width >> 1 : P.width, picH = comp ? P.height >> 1 : P.height;
-    int16_t pr[2][4];
+  for (int l = 0; l < 2; l++) {
+    if (t.slot[l] < 0) continue;
+    const int mvx = t.mv[l][0], mvy = t.mv[l][1];
+    {   // luma: rows yI-3 .. yI+h+3, columns xI-3 .. xI+w+3
+      const PlaneRef r = dpb.p[t.slot[l]][0];
+      const PX* ref = (const PX*)r.ptr;
+      const int xs = t.x + (mvx >> 2) - 3, ys = t.y + (mvy >> 2) - 3;
+      const int nrow = h + 7, ncol = w + 7;
+      const bool inside = xs >= 0 && ys >= 0 && xs + ncol <= P.width && ys + nrow <= P.height;
+      if (inside) {
+        const int ax = xs & ~3;
+        oxL[l] = xs & 3;
 #pragma unroll
-    for (int l = 0; l < 2; l++) {
-      if (t.slot[l] < 0) continue;
-      const PlaneRef r = dpb.p[t.slot[l]][comp];
-      const int mvx = t.mv[l][0], mvy = t.mv[l][1];
-      if (comp == 0)
-        mc_block<PX, 8>((const PX*)r.ptr, r.stride, picW, picH, x0 + (mvx >> 2), y0 + (mvy >> 2),
-                        mvx & 3, mvy & 3, w, h, bd, s_in, s_tmp, lane, pr[l]);
-      else
-        mc_block<PX, 4>((const PX*)r.ptr, r.stride, picW, picH, x0 + (mvx >> 3), y0 + (mvy >> 3),
-                        mvx & 7, mvy & 7, w, h, bd, s_in, s_tmp, lane, pr[l]);
-    }
-    // weights (motion.cc:403-406, :464-473, :522-540)
-    int w0 = 0, o0 = 0, w1 = 0, o1 = 0, log2WD = 1;
-    if (mode == 1 || mode == 3) {
-      const int shift1 = max(2, 14 - bd);
-      const int offsh = bd - 8;                              // WpOffsetBdShift (sps.cc:554-563)
-      const int la = (mode == 3) ? 0 : l_uni;
-      const int ra = t.ref_idx[la];
-      if (comp == 0) {
-        log2WD = sh->luma_log2_weight_denom + shift1;
-        w0 = sh->luma_weight[la][ra]; o0 = sh->luma_offset[la][ra] * (1 << offsh);
-        if (mode == 3) { int rb = t.ref_idx[1]; w1 = sh->luma_weight[1][rb]; o1 = sh->luma_offset[1][rb] * (1 << offsh); }
+        for (int i = 0; i < 3; i++) {
+          int slot = lane + 64 * i, rr = slot >> 3, ch = slot & 7;
+          if (rr < nrow && ch < 7)
+            *reinterpret_cast<uint2*>(&s_inL[l][rr * MCL_P + 4 * ch]) = ld4_u16<PX>(ref + ax + 4 * ch + (ys + rr) * r.stride);
+        }
       } else {
-        log2WD = sh->chroma_log2_weight_denom + shift1;
-        w0 = sh->chroma_weight[la][ra][comp - 1]; o0 = sh->chroma_offset[la][ra][comp - 1] * (1 << offsh);
-        if (mode == 3) { int rb = t.ref_idx[1]; w1 = sh->chroma_weight[1][rb][comp - 1]; o1 = sh->chroma_offset[1][rb][comp - 1] * (1 << offsh); }
+        for (int idx = lane; idx < nrow * 32; idx += 64) {
+          int rr = idx >> 5, c = idx & 31;   // 32 > w + 7
+          if (c < ncol) {
+            int xA = mc_clip3(0, P.width - 1, xs + c), yA = mc_clip3(0, P.height - 1, ys + rr);
+            s_inL[l][rr * MCL_P + c] = ref[xA + yA * r.stride];
+          }
+        }
       }
     }
-    PX* dst = (PX*)dsts[comp].ptr;
-    const int dstride = dsts[comp].stride;
-    const int nOut = w * h;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      int s = lane + 64 * k;
-      if (s < nOut) {
-        int y = s / w, x = s - y * w;
-        int a = bi ? pr[0][k] : (use0 ? pr[0][k] : pr[1][k]);
-        int b = pr[1][k];
-        dst[(x0 + x) + (y0 + y) * dstride] = mc_combine<PX>(mode, a, b, bd, w0, o0, w1, o1, log2WD);
+    for (int cp = 0; cp < 2; cp++) {   // chroma: rows yI-1 .. yI+hc+1, columns xI-1 .. xI+wc+1
+      const PlaneRef r = dpb.p[t.slot[l]][cp + 1];
+      const PX* ref = (const PX*)r.ptr;
+      const int xs = (t.x >> 1) + (mvx >> 3) - 1, ys = (t.y >> 1) + (mvy >> 3) - 1;
+      const int nrow = hc + 3, ncol = wc + 3;
+      const bool inside = xs >= 0 && ys >= 0 && xs + ncol <= cW && ys + nrow <= cH;
+      if (inside) {
+        const int ax = xs & ~3;
+        oxC[l] = xs & 3;
+        int rr = lane >> 2, ch = lane & 3;
+        if (rr < nrow)
+          *reinterpret_cast<uint2*>(&s_inC[l][cp][rr * MCC_P + 4 * ch]) = ld4_u16<PX>(ref + ax + 4 * ch + (ys + rr) * r.stride);
+      } else {
+        oxC[l] = 0;
+        for (int idx = lane; idx < nrow * 16; idx += 64) {
+          int rr = idx >> 4, c = idx & 15;
+          if (c < ncol) {
+            int xA = mc_clip3(0, cW - 1, xs + c), yA = mc_clip3(0, cH - 1, ys + rr);
+            s_inC[l][cp][rr * MCC_P + c] = ref[xA + yA * r.stride];
+          }
+        }
       }
     }
+  }
+  MC_LDS_SYNC();
+
+  // ---------------- luma: lane -> row (lane>>2), 4 adjacent columns
+  const int ly = lane >> 2, lx4 = (lane & 3) * 4;
+  int prL[2][4];
+#pragma unroll
+  for (int l = 0; l < 2; l++) {
+    if (t.slot[l] < 0) continue;
+    const int xF = t.mv[l][0] & 3, yF = t.mv[l][1] & 3;
+    const int bd = P.bd_luma, shift1 = bd - 8;
+    const uint16_t* in = &s_inL[l][oxL[l]];
+    if (xF == 0 && yF == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) prL[l][j] = (int16_t)(in[(ly + 3) * MCL_P + lx4 + j + 3] << (14 - bd));
+      continue;
+    }
+    const int nrow = h + 7;
+#pragma unroll
+    for (int it = 0; it < 2; it++) {               // horizontal pass -> s_tmp[row][16]
+      const int rr = ly + 16 * it;
+      if (rr < nrow) {
+        int o[4];
+        if (xF == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) o[j] = in[rr * MCL_P + lx4 + j + 3];
+        } else {
+          int sv[11];
+#pragma unroll
+          for (int k = 0; k < 11; k++) sv[k] = in[rr * MCL_P + lx4 + k];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            int sum = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) sum += __mul24((int)c_qpel_filt[xF][k], sv[j + k]);
+            o[j] = (int16_t)(sum >> shift1);
+          }
+        }
+        *reinterpret_cast<uint2*>(&s_tmp[rr * MCT_P + lx4]) =
+          make_uint2((uint32_t)(uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16), (uint32_t)(uint16_t)o[2] | ((uint32_t)(uint16_t)o[3] << 16));
+      }
+    }
+    MC_LDS_SYNC();
+    if (yF == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) prL[l][j] = s_tmp[(ly + 3) * MCT_P + lx4 + j];
+    } else {
+      const int vshift = (xF == 0) ? shift1 : 6;
+      int acc[4] = { 0, 0, 0, 0 };
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const uint2 rv = *reinterpret_cast<const uint2*>(&s_tmp[(ly + k) * MCT_P + lx4]);
+        const int tap = c_qpel_filt[yF][k];
+        acc[0] += __mul24(tap, (int)(int16_t)(rv.x & 0xFFFF)); acc[1] += __mul24(tap, (int)(int16_t)(rv.x >> 16));
+        acc[2] += __mul24(tap, (int)(int16_t)(rv.y & 0xFFFF)); acc[3] += __mul24(tap, (int)(int16_t)(rv.y >> 16));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) prL[l][j] = (int16_t)(acc[j] >> vshift);
+    }
+    MC_LDS_SYNC();                                 // s_tmp is reused by the next list / chroma
+  }
+
+  // weights (motion.cc:403-406, :464-473, :522-540)
+  const int la = (mode == 3) ? 0 : l_uni;
+  int w0 = 0, o0 = 0, w1 = 0, o1 = 0, log2WD = 1;
+  if (mode == 1 || mode == 3) {
+    const int bd = P.bd_luma;
+    log2WD = sh->luma_log2_weight_denom + max(2, 14 - bd);
+    w0 = sh->luma_weight[la][t.ref_idx[la]]; o0 = sh->luma_offset[la][t.ref_idx[la]] * (1 << (bd - 8));
+    if (mode == 3) { w1 = sh->luma_weight[1][t.ref_idx[1]]; o1 = sh->luma_offset[1][t.ref_idx[1]] * (1 << (bd - 8)); }
+  }
+  if (ly < h && lx4 < w) {
+    int o[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      o[j] = mc_combine<PX>(mode, bi ? prL[0][j] : (use0 ? prL[0][j] : prL[1][j]), prL[1][j], P.bd_luma, w0, o0, w1, o1, log2WD);
+    st4_px<PX>((PX*)d0.ptr + t.x + lx4 + (t.y + ly) * d0.stride, o);
+  }
+
+  // ---------------- chroma: both planes at once, lane -> plane (lane>>5), row, 2 adjacent columns
+  const int cp = lane >> 5, cy = (lane & 31) >> 2, cx2 = (lane & 3) * 2;
+  int prC[2][2];
+#pragma unroll
+  for (int l = 0; l < 2; l++) {
+    if (t.slot[l] < 0) continue;
+    const int xF = t.mv[l][0] & 7, yF = t.mv[l][1] & 7;
+    const int bd = P.bd_chroma, shift1 = bd - 8;
+    if (xF == 0 && yF == 0) {
+      const uint16_t* in = &s_inC[l][cp][oxC[l]];
+      prC[l][0] = (int16_t)(in[(cy + 1) * MCC_P + cx2 + 1] << (14 - bd));
+      prC[l][1] = (int16_t)(in[(cy + 1) * MCC_P + cx2 + 2] << (14 - bd));
+      continue;
+    }
+    const int nrow = hc + 3;
+    // horizontal pass, plane by plane: lane -> row (lane>>2, 11 rows), 2 columns -> s_tmp[plane*176 + row*16 + x]
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const uint16_t* in = &s_inC[l][q][oxC[l]];
+      const int rr = lane >> 2, x2 = (lane & 3) * 2;
+      if (rr < nrow) {
+        int o0v, o1v;
+        if (xF == 0) { o0v = in[rr * MCC_P + x2 + 1]; o1v = in[rr * MCC_P + x2 + 2]; }
+        else {
+          int sv[5];
+#pragma unroll
+          for (int k = 0; k < 5; k++) sv[k] = in[rr * MCC_P + x2 + k];
+          int s0 = 0, s1 = 0;
+#pragma unroll
+          for (int k = 0; k < 4; k++) { const int tap = c_epel_filt[xF][k]; s0 += __mul24(tap, sv[k]); s1 += __mul24(tap, sv[k + 1]); }
+          o0v = (int16_t)(s0 >> shift1); o1v = (int16_t)(s1 >> shift1);
+        }
+        *reinterpret_cast<uint32_t*>(&s_tmp[q * (11 * MCT_P) + rr * MCT_P + x2]) = (uint32_t)(uint16_t)o0v | ((uint32_t)(uint16_t)o1v << 16);
+      }
+    }
+    MC_LDS_SYNC();
+    const int16_t* tp = &s_tmp[cp * (11 * MCT_P)];
+    if (yF == 0) { prC[l][0] = tp[(cy + 1) * MCT_P + cx2]; prC[l][1] = tp[(cy + 1) * MCT_P + cx2 + 1]; }
+    else {
+      const int vshift = (xF == 0) ? shift1 : 6;
+      int a0 = 0, a1 = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t rv = *reinterpret_cast<const uint32_t*>(&tp[(cy + k) * MCT_P + cx2]);
+        const int tap = c_epel_filt[yF][k];
+        a0 += __mul24(tap, (int)(int16_t)(rv & 0xFFFF)); a1 += __mul24(tap, (int)(int16_t)(rv >> 16));
+      }
+      prC[l][0] = (int16_t)(a0 >> vshift); prC[l][1] = (int16_t)(a1 >> vshift);
+    }
+    MC_LDS_SYNC();
+  }
+  if (mode == 1 || mode == 3) {
+    const int bd = P.bd_chroma;
+    log2WD = sh->chroma_log2_weight_denom + max(2, 14 - bd);
+    w0 = sh->chroma_weight[la][t.ref_idx[la]][cp]; o0 = sh->chroma_offset[la][t.ref_idx[la]][cp] * (1 << (bd - 8));
+    if (mode == 3) { w1 = sh->chroma_weight[1][t.ref_idx[1]][cp]; o1 = sh->chroma_offset[1][t.ref_idx[1]][cp] * (1 << (bd - 8)); }
+  }
+  if (cy < hc && cx2 < wc) {
+    const PlaneRef dc = cp ? d2 : d1;
+    const int a0 = bi ? prC[0][0] : (use0 ? prC[0][0] : prC[1][0]), a1 = bi ? prC[0][1] : (use0 ? prC[0][1] : prC[1][1]);
+    const int r0 = mc_combine<PX>(mode, a0, prC[1][0], P.bd_chroma, w0, o0, w1, o1, log2WD);
+    const int r1 = mc_combine<PX>(mode, a1, prC[1][1], P.bd_chroma, w0, o0, w1, o1, log2WD);
+    st2_px<PX>((PX*)dc.ptr + (t.x >> 1) + cx2 + ((t.y >> 1) + cy) * dc.stride, r0, r1);
   }
 }
 

@@ -66,9 +66,9 @@ __device__ __forceinline__ int wave_sum(int v)
   return v;
 }
 
-template <typename PX>
+template <typename PX, typename SH>
 __device__ void intra_predict(const PicDev& P, const TuTask& t, const PX* plane, int stride,
-                              TuShared<PX>& S, int lane, Stamper& st)
+                              SH& S, int lane, Stamper& st)
 {
   const int nT = 1 << t.log2_size;
   const int cIdx = t.c_idx;
@@ -205,7 +205,7 @@ __device__ void intra_predict(const PicDev& P, const TuTask& t, const PX* plane,
 // has_pred: prediction comes from S.pred (intra) instead of the picture.
 template <typename PX>
 __device__ void tu_residual_add(TuShared<PX>& S, int lane, PX* dst, int stride, int log2, int bd,
-                                int kind, bool has_pred, int lastRow, int lastCol)
+                                int kind, bool has_pred, int lastRow, int lastCol, int16_t* res_out = nullptr)
 {
   const int nT = 1 << log2, nS = nT * nT;
   const int maxv = (1 << bd) - 1;
@@ -216,6 +216,7 @@ __device__ void tu_residual_add(TuShared<PX>& S, int lane, PX* dst, int stride, 
       int x = s & (nT - 1), y = s >> log2;
       int r = bypass ? (int)S.coeff[s]
                      : (((int32_t)((uint32_t)(int32_t)S.coeff[s] << tsShift) + rnd) >> bdShift);
+      if (res_out) { res_out[s] = (int16_t)clip3(-32768, 32767, r); continue; }
       int p = has_pred ? (int)S.pred[s] : (int)dst[x + y * stride];
       dst[x + y * stride] = (PX)clip3(0, maxv, p + r);
     }
@@ -238,8 +239,11 @@ __device__ void tu_residual_add(TuShared<PX>& S, int lane, PX* dst, int stride, 
 #pragma unroll
       for (int j = 0; j < 4; j++) sum += S.dstm[j * 4 + i] * S.g[y * 4 + j];
       int out = clip3(-32768, 32767, (sum + rnd2) >> post);
-      int p = has_pred ? (int)S.pred[lane] : (int)dst[i + y * stride];
-      dst[i + y * stride] = (PX)clip3(0, maxv, p + out);
+      if (res_out) res_out[lane] = (int16_t)out;
+      else {
+        int p = has_pred ? (int)S.pred[lane] : (int)dst[i + y * stride];
+        dst[i + y * stride] = (PX)clip3(0, maxv, p + out);
+      }
     }
     return;
   }
@@ -259,6 +263,8 @@ __device__ void tu_residual_add(TuShared<PX>& S, int lane, PX* dst, int stride, 
     int sum = 0;
     for (int j = 0; j <= lastCol; j++) sum += S.mat[fact * j * 32 + i] * S.g[y * nT + j];
     int out = (sum + rnd2) >> post;            // second stage is not clipped (fallback-dct.cc:682)
+    // a residual beyond int16 saturates the pixel clip either way, so the stored form may saturate
+    if (res_out) { res_out[s] = (int16_t)clip3(-32768, 32767, out); continue; }
     int p = has_pred ? (int)S.pred[s] : (int)dst[i + y * stride];
     dst[i + y * stride] = (PX)clip3(0, maxv, p + out);
   }
@@ -271,7 +277,7 @@ template <typename PX>
 __device__ void tu_reconstruct(const PicDev& P, const TuTask& t, PX* plane, int stride, TuShared<PX>& S,
                                int lane, const int16_t* __restrict__ coeff_val,
                                const uint16_t* __restrict__ coeff_pos, const uint8_t* __restrict__ scaling,
-                               bool load_mat, Stamper& st)
+                               bool load_mat, Stamper& st, int16_t* resid = nullptr)
 {
   const int cIdx = t.c_idx;
   const int log2 = t.log2_size;
@@ -281,7 +287,8 @@ __device__ void tu_reconstruct(const PicDev& P, const TuTask& t, PX* plane, int 
   const bool cbf = t.flags & DE265HIP_TU_CBF;
   PX* dst = plane + t.x0 + t.y0 * stride;
 
-  if (intra) intra_predict<PX>(P, t, plane, stride, S, lane, st);
+  const bool resid_only = t.flags & D265_TU_RESID_ONLY;
+  if (intra && !resid_only) intra_predict<PX, TuShared<PX>>(P, t, plane, stride, S, lane, st);
 
   if (!cbf) {
     if (intra)
@@ -339,7 +346,8 @@ __device__ void tu_reconstruct(const PicDev& P, const TuTask& t, PX* plane, int 
   st.mark(4);
 
   const int kind = bypass ? 3 : (tskip ? 2 : (is_dst ? 1 : 0));
-  tu_residual_add<PX>(S, lane, dst, stride, log2, bd, kind, intra, S.last_row, S.last_col);
+  tu_residual_add<PX>(S, lane, dst, stride, log2, bd, kind, intra, S.last_row, S.last_col,
+                      resid_only ? resid + t.resid_offset : nullptr);
   st.mark(5);
 }
 
@@ -348,13 +356,13 @@ template <typename PX>
 __global__ __launch_bounds__(64)
 void k_tu(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const TuTask* __restrict__ tasks,
           int first, const int16_t* __restrict__ coeff_val, const uint16_t* __restrict__ coeff_pos,
-          const uint8_t* __restrict__ scaling)
+          const uint8_t* __restrict__ scaling, int16_t* resid)
 {
   __shared__ TuShared<PX> S;
   const TuTask t = tasks[first + blockIdx.x];
   const PlaneRef pr = t.c_idx == 0 ? pl0 : (t.c_idx == 1 ? pl1 : pl2);
   Stamper st{ nullptr, 0, (int)threadIdx.x };
-  tu_reconstruct<PX>(P, t, (PX*)pr.ptr, pr.stride, S, threadIdx.x, coeff_val, coeff_pos, scaling, true, st);
+  tu_reconstruct<PX>(P, t, (PX*)pr.ptr, pr.stride, S, threadIdx.x, coeff_val, coeff_pos, scaling, true, st, resid);
 }
 
 // ---------------------------------------------------------------- run kernel
@@ -379,31 +387,55 @@ __device__ __forceinline__ uint4 load8_as_u16(const uint8_t* p)
   o.z = (r.y & 0xFF) | ((r.y & 0xFF00) << 8);           o.w = ((r.y >> 16) & 0xFF) | ((r.y >> 24) << 16);
   return o;
 }
-__device__ __forceinline__ void store4_from_u16(uint16_t* g, uint2 v) { *reinterpret_cast<uint2*>(g) = v; }
+// Write-through (sc1) stores: the run kernel hands these bytes to other CUs without an L2
+// write-back fence (relaxed agent-scope atomic store == global_store ... sc1).
+__device__ __forceinline__ void store4_from_u16(uint16_t* g, uint2 v)
+{
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(g), (unsigned long long)v.x | ((unsigned long long)v.y << 32),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void store4_from_u16(uint8_t* g, uint2 v)
 {
-  *reinterpret_cast<uint32_t*>(g) = (v.x & 0xFF) | ((v.x >> 8) & 0xFF00) | ((v.y & 0xFF) << 16) | ((v.y >> 16) << 24);
+  __hip_atomic_store(reinterpret_cast<uint32_t*>(g),
+                     (v.x & 0xFF) | ((v.x >> 8) & 0xFF00) | ((v.y & 0xFF) << 16) | ((v.y >> 16) << 24),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+// Intra-only scratch of the run kernel (the residuals were computed beforehand).
+struct RunShared {
+  uint16_t pred[32 * 32];
+  int32_t border[4 * 32 + 4];
+  int32_t bfilt[4 * 32 + 4];
+};
 
 template <typename PX>
 __global__ __launch_bounds__(64)
 void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __restrict__ runs,
            const uint32_t* __restrict__ deps, uint32_t* sync, uint32_t* err, const TuTask* __restrict__ tasks,
-           const int16_t* __restrict__ coeff_val, const uint16_t* __restrict__ coeff_pos,
-           const uint8_t* __restrict__ scaling, int dbg)
+           const int16_t* __restrict__ resid, int n_runs, int dbg)
 {
-  __shared__ TuShared<uint16_t> S;
+  __shared__ RunShared S;
   __shared__ __attribute__((aligned(16))) uint16_t tile[RUN_TILE_H * RUN_TILE_P];
+  __shared__ __attribute__((aligned(16))) int16_t s_res[64 * 64];
   __shared__ TuTask s_tasks[64];
   __shared__ uint32_t s_ticket;
   const int lane = threadIdx.x;
+  // persistent worker: the grid is only as wide as the picture's widest dependency level
+  // (waiting wavefronts would just occupy LDS), every worker pulls tickets until none are left
+  for (;;) {
   if (lane == 0) s_ticket = atomicAdd(&sync[0], 1u);
-  for (int s = lane; s < 256; s += 64) ((int32_t*)S.mat)[s] = ((const int32_t*)c_dct_mat)[s];
-  if (lane < 4) ((int32_t*)S.dstm)[lane] = ((const int32_t*)c_dst_mat)[lane];
   __syncthreads();
   const uint32_t ticket = __builtin_amdgcn_readfirstlane(s_ticket);    // wave-uniform: scalar loads/branches below
+  __syncthreads();
+  if (ticket >= (uint32_t)n_runs) break;
   const RunTask run = runs[ticket];
   Stamper st{ (dbg & 16) ? err + 8 : nullptr, clock64(), lane };
+
+  // residuals of the whole run: one contiguous range, independent of the producers -> fetch before waiting
+  const uint32_t res_base = run.res_offset;
+  if (!(dbg & 8))
+  for (int i = lane * 8; i < (int)run.res_len; i += 512)
+    *reinterpret_cast<uint4*>(&s_res[i]) = *reinterpret_cast<const uint4*>(&resid[res_base + i]);
 
   if (run.n_deps) {
     for (int i = lane; i < run.n_deps; i += 64) {
@@ -424,6 +456,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   PX* plane = (PX*)pr.ptr;
   const int stride = pr.stride;
   const int cw = c ? P.width >> 1 : P.width, ch = c ? P.height >> 1 : P.height;
+  const int bd = c ? P.bd_chroma : P.bd_luma, maxv = (1 << bd) - 1;
   // pixel window: bbox + 1 left/top + 32 right/bottom (everything a TU of the run can read),
   // fetched in aligned 8-sample chunks, several loads in flight per lane
   const int wx0 = (int)run.x0 - 1, wy0 = (int)run.y0 - 1;
@@ -454,6 +487,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   }
   LDS_SYNC();
 
+  // ---- the dependency chain: border -> (filter) -> predict -> + residual, all inside LDS
   if (!(dbg & 4))
   for (int base = 0; base < run.n_tus; base += 64) {
     const int nb = min(64, (int)run.n_tus - base);
@@ -466,30 +500,47 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
         const uint32_t* w = reinterpret_cast<const uint32_t*>(&s_tasks[k]);
         uint32_t* o = reinterpret_cast<uint32_t*>(&t);
 #pragma unroll
-        for (int q = 0; q < 6; q++) o[q] = __builtin_amdgcn_readfirstlane(w[q]);
+        for (int q = 0; q < 8; q++) o[q] = __builtin_amdgcn_readfirstlane(w[q]);
       }
-      const int gx0 = t.x0, gy0 = t.y0;
-      t.x0 = (uint16_t)(gx0 - ax0); t.y0 = (uint16_t)(gy0 - wy0);       // window coordinates
+      t.x0 = (uint16_t)((int)t.x0 - ax0); t.y0 = (uint16_t)((int)t.y0 - wy0);      // window coordinates
       st.mark(0);
-      tu_reconstruct<uint16_t>(P, t, tile, RUN_TILE_P, S, lane, coeff_val, coeff_pos, scaling, false, st);
-      LDS_SYNC();
-      // write the finished TU back, 4 samples per lane (only the run's own samples ever leave the window)
-      const int log2 = t.log2_size, nT = 1 << log2, l4 = log2 - 2;
-      for (int s = lane; s < (nT * nT) >> 2; s += 64) {
-        int y = s >> l4, x = (s & ((1 << l4) - 1)) << 2;
-        uint2 v = *reinterpret_cast<const uint2*>(&tile[(t.y0 + y) * RUN_TILE_P + t.x0 + x]);
-        store4_from_u16(plane + (gx0 + x) + (gy0 + y) * stride, v);
+      intra_predict<uint16_t, RunShared>(P, t, tile, RUN_TILE_P, S, lane, st);
+      const int log2 = t.log2_size, nT = 1 << log2, nS = nT * nT;
+      uint16_t* dst = tile + t.x0 + t.y0 * RUN_TILE_P;
+      if (t.flags & DE265HIP_TU_CBF) {
+        const int16_t* r = &s_res[t.resid_offset - res_base];
+        for (int s = lane; s < nS; s += 64)
+          dst[(s & (nT - 1)) + (s >> log2) * RUN_TILE_P] = (uint16_t)clip3(0, maxv, (int)S.pred[s] + (int)r[s]);
+      } else {
+        for (int s = lane; s < nS; s += 64) dst[(s & (nT - 1)) + (s >> log2) * RUN_TILE_P] = S.pred[s];
       }
-      st.mark(6);
+      LDS_SYNC();
+      st.mark(5);
       if (st.buf && lane == 0) atomicAdd(&st.buf[7], 1u);
     }
+    // write the finished TUs of this batch back, 4 samples per lane; stores are independent of the
+    // chain, so they are issued back to back (only the run's own samples ever leave the window)
+    for (int k = 0; k < nb; k++) {
+      const uint32_t* w = reinterpret_cast<const uint32_t*>(&s_tasks[k]);
+      const uint32_t w0 = __builtin_amdgcn_readfirstlane(w[0]), w1 = __builtin_amdgcn_readfirstlane(w[1]);
+      const int gx0 = w0 & 0xFFFF, gy0 = w0 >> 16, log2 = w1 & 0xFF, nT = 1 << log2, l4 = log2 - 2;
+      const int tx = gx0 - ax0, ty = gy0 - wy0;
+      for (int s = lane; s < (nT * nT) >> 2; s += 64) {
+        int y = s >> l4, x = (s & ((1 << l4) - 1)) << 2;
+        uint2 v = *reinterpret_cast<const uint2*>(&tile[(ty + y) * RUN_TILE_P + tx + x]);
+        store4_from_u16(plane + (gx0 + x) + (gy0 + y) * stride, v);
+      }
+    }
+    st.mark(6);
     LDS_SYNC();
   }
 
-  // publish: all stores of this wavefront -> agent-scope release -> flag
-  if (!(dbg & 1)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  // publish: every handed-off byte was stored write-through (sc1); drain them, then raise the flag.
+  // (MI355X_MICROARCH.md, valid forms: sc1 payload stores + vmcnt(0) + flag on the producer,
+  //  poll + agent acquire + plain loads on the consumer; no L2 write-back fence needed.)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (lane == 0) __hip_atomic_store(&sync[2 + ticket], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // Function-level form (acceleration.h:143-178 slot semantics): dense coefficient
@@ -512,13 +563,13 @@ void k_fn_residual(int kind, int log2_size, int bit_depth, PX* plane, int stride
 }
 
 template __global__ void k_tu<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int,
-                                       const int16_t*, const uint16_t*, const uint8_t*);
+                                       const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
 template __global__ void k_tu<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int,
-                                        const int16_t*, const uint16_t*, const uint8_t*);
+                                        const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
 template __global__ void k_run<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*,
-                                        const TuTask*, const int16_t*, const uint16_t*, const uint8_t*, int);
+                                        const TuTask*, const int16_t*, int, int);
 template __global__ void k_run<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*,
-                                         const TuTask*, const int16_t*, const uint16_t*, const uint8_t*, int);
+                                         const TuTask*, const int16_t*, int, int);
 template __global__ void k_fn_residual<uint8_t>(int, int, int, uint8_t*, int, const int32_t*, const int16_t*);
 template __global__ void k_fn_residual<uint16_t>(int, int, int, uint16_t*, int, const int32_t*, const int16_t*);
 

@@ -20,10 +20,10 @@ struct SaoMeta {
 
 template <typename PX>
 __global__ void k_tu(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int,
-                     const int16_t*, const uint16_t*, const uint8_t*);
+                     const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
 template <typename PX>
 __global__ void k_run(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*,
-                      const TuTask*, const int16_t*, const uint16_t*, const uint8_t*, int);
+                      const TuTask*, const int16_t*, int, int);
 template <typename PX>
 __global__ void k_mc(PicDev, DpbTable, PlaneRef, PlaneRef, PlaneRef, const McTask*,
                      const de265hip_slice_params*);
