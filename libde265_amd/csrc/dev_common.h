@@ -29,6 +29,8 @@ struct PicDev {
   int32_t cb_qp_offset, cr_qp_offset;
   int32_t lf_across_tiles;
   int32_t scaling_list;
+  int32_t dbg;                      // DE265HIP_DEBUG ablation bits (timing only)
+  int32_t has_exempt;               // some 4x4 unit is pcm (with pcm_loop_filter_disable) or transquant-bypass
 };
 
 // TU task: de265hip_tu plus the host-derived neighbour availability.

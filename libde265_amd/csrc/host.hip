@@ -531,6 +531,10 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
 
   const size_t nblk = (size_t)g.w4 * g.h4;
   for (size_t i = 0; i < nblk && !pic->any_edges; i++) pic->any_edges = (d->blk_flags[i] & 0xF0) != 0;
+  P.has_exempt = 0;
+  for (size_t i = 0; i < nblk && !P.has_exempt; i++)
+    P.has_exempt = ((d->blk_flags[i] & DE265HIP_BLK_BYPASS) ||
+                    ((d->blk_flags[i] & DE265HIP_BLK_PCM) && p.pcm_loop_filter_disable_flag)) ? 1 : 0;
 
   // ---- one arena, one upload
   ArenaLayout L;
@@ -626,7 +630,8 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
   Slot& dst = dec->slots[pic->dst_slot];
   if (!dst.valid) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   hipStream_t st = dec->stream;
-  const PicDev& P = pic->P;
+  PicDev P = pic->P;
+  P.dbg = dec->dbg;
   const PlaneRef d0 = dst.pl[0], d1 = dst.pl[1], d2 = dst.pl[2];
 
   if (pic->n_mc) {
@@ -691,7 +696,7 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
     SaoMeta M{ pic->d_flags, pic->d_ctbs, pic->d_slices, pic->d_tile_id };
     {
       KTimer t(dec, DE265HIP_K_SAO, 1);
-      hipLaunchKernelGGL(k_sao<PX>, dim3((P.width / 8 + 255) / 256, P.height, 3), dim3(256), 0, st, P, d0, d1, d2,
+      hipLaunchKernelGGL(k_sao<PX>, dim3((P.width / 8 + 4 * 62 - 1) / (4 * 62), (P.height + 7) / 8, 3), dim3(256), 0, st, P, d0, d1, d2,
                          sp.pl[0], sp.pl[1], sp.pl[2], M);
     }
     for (int c = 0; c < 3; c++) std::swap(dst.pl[c], sp.pl[c]);      // output picture now lives in the slot

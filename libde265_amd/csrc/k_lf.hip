@@ -271,6 +271,43 @@ template __global__ void k_deblock<uint16_t, false>(PicDev, PlaneRef, PlaneRef, 
 // ---------------------------------------------------------------- SAO
 // Out of place: src = deblocked picture, dst = output picture (every sample is
 // written, so dst needs no initialisation).  One lane per 8 samples of a row.
+#define SAO_ROWS 8                      // rows per lane: never crosses a CTB (chroma CTB height >= 8)
+#define SAO_LANES 62                    // output lanes per wavefront; lanes 0 and 63 are halo lanes
+
+template <typename PX> __device__ __forceinline__ void load8i(const PX* p, int v[8]);
+template <> __device__ __forceinline__ void load8i<uint16_t>(const uint16_t* p, int v[8])
+{
+  const uint4 r = *reinterpret_cast<const uint4*>(p);
+  v[0] = r.x & 0xFFFF; v[1] = r.x >> 16; v[2] = r.y & 0xFFFF; v[3] = r.y >> 16;
+  v[4] = r.z & 0xFFFF; v[5] = r.z >> 16; v[6] = r.w & 0xFFFF; v[7] = r.w >> 16;
+}
+template <> __device__ __forceinline__ void load8i<uint8_t>(const uint8_t* p, int v[8])
+{
+  const uint2 r = *reinterpret_cast<const uint2*>(p);
+  v[0] = r.x & 0xFF; v[1] = (r.x >> 8) & 0xFF; v[2] = (r.x >> 16) & 0xFF; v[3] = r.x >> 24;
+  v[4] = r.y & 0xFF; v[5] = (r.y >> 8) & 0xFF; v[6] = (r.y >> 16) & 0xFF; v[7] = r.y >> 24;
+}
+template <typename PX> __device__ __forceinline__ void store8i(PX* p, const int v[8]);
+template <> __device__ __forceinline__ void store8i<uint16_t>(uint16_t* p, const int v[8])
+{
+  uint4 r;
+  r.x = (uint32_t)v[0] | ((uint32_t)v[1] << 16); r.y = (uint32_t)v[2] | ((uint32_t)v[3] << 16);
+  r.z = (uint32_t)v[4] | ((uint32_t)v[5] << 16); r.w = (uint32_t)v[6] | ((uint32_t)v[7] << 16);
+  *reinterpret_cast<uint4*>(p) = r;
+}
+template <> __device__ __forceinline__ void store8i<uint8_t>(uint8_t* p, const int v[8])
+{
+  uint2 r;
+  r.x = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+  r.y = (uint32_t)v[4] | ((uint32_t)v[5] << 8) | ((uint32_t)v[6] << 16) | ((uint32_t)v[7] << 24);
+  *reinterpret_cast<uint2*>(p) = r;
+}
+
+// One lane filters an 8 (wide) x 8 (high) strip.  All ten rows it needs are requested up
+// front as 16-byte loads (ten loads in flight per lane), the left/right neighbours come from the
+// adjacent lanes through DPP wave shifts (lanes 0 and 63 of every wavefront only supply them),
+// the CTB parameters and the slice/tile permissions of the 3x3 CTB neighbourhood are evaluated
+// once per strip, and every output row is one 16-byte store.
 template <typename PX>
 __global__ __launch_bounds__(256)
 void k_sao(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, PlaneRef d1, PlaneRef d2,
@@ -279,16 +316,43 @@ void k_sao(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, PlaneRe
   const int comp = blockIdx.z;
   const int cs = comp ? 1 : 0;
   const int width = P.width >> cs, height = P.height >> cs;
-  const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
-  const int y = blockIdx.y;
-  if (x0 >= width || y >= height) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x0 = ((blockIdx.x * 4 + wave) * SAO_LANES + lane - 1) * 8;
+  const int y0 = blockIdx.y * SAO_ROWS;
+  if (y0 >= height) return;                                   // uniform per workgroup
   const PlaneRef sp = comp == 0 ? s0 : (comp == 1 ? s1 : s2);
   const PlaneRef dp = comp == 0 ? d0 : (comp == 1 ? d1 : d2);
   const PX* src = (const PX*)sp.ptr;
   PX* dst = (PX*)dp.ptr;
   const int sstride = sp.stride, dstride = dp.stride;
+  const bool inpic = x0 >= 0 && x0 < width;
+
+  int v[SAO_ROWS + 2][8];
+#pragma unroll
+  for (int j = 0; j < SAO_ROWS + 2; j++) {
+    const int y = y0 - 1 + j;
+    if (inpic && y >= 0 && y < height) load8i<PX>(src + x0 + y * sstride, v[j]);
+    else {
+#pragma unroll
+      for (int i = 0; i < 8; i++) v[j][i] = 0;
+    }
+  }
+  int nl[SAO_ROWS + 2], nr[SAO_ROWS + 2];                     // left / right neighbour of the strip, per row
+#pragma unroll
+  for (int j = 0; j < SAO_ROWS + 2; j++) {
+    nl[j] = __builtin_amdgcn_update_dpp(0, v[j][7], 0x138, 0xf, 0xf, false);   // wave_shr:1 -> lane-1's last sample
+    nr[j] = __builtin_amdgcn_update_dpp(0, v[j][0], 0x130, 0xf, 0xf, false);   // wave_shl:1 -> lane+1's first sample
+  }
+  if (!inpic || lane == 0 || lane == 63) return;
+  if (P.dbg & 32) {                                           // ablation: pure copy
+#pragma unroll
+    for (int r = 0; r < SAO_ROWS; r++)
+      if (y0 + r < height) store8i<PX>(dst + x0 + (y0 + r) * dstride, v[r + 1]);
+    return;
+  }
+
   const int ctbshift = P.log2_ctb - cs;
-  const int ctbX = x0 >> ctbshift, ctbY = y >> ctbshift;
+  const int ctbX = x0 >> ctbshift, ctbY = y0 >> ctbshift;
   const int ctbAddr = ctbX + ctbY * P.ctbs_w;
   const de265hip_ctb_info ci = M.ctbs[ctbAddr];
   const de265hip_slice_params* sh = &M.slices[ci.slice_idx];
@@ -296,64 +360,122 @@ void k_sao(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, PlaneRe
   const int maxv = (1 << bd) - 1;
   int type = (ci.sao_type_idx >> (2 * comp)) & 3;
   if (comp == 0 ? !sh->slice_sao_luma_flag : !sh->slice_sao_chroma_flag) type = 0;
+  const int nrows = min(SAO_ROWS, height - y0);
 
-  int cur[8];
-  load4<PX>(src + x0 + y * sstride, cur);
-  load4<PX>(src + x0 + 4 + y * sstride, cur + 4);
-  int out[8];
+  if (type == 0) {                                            // plain copy of the deblocked samples
 #pragma unroll
-  for (int i = 0; i < 8; i++) out[i] = cur[i];
+    for (int r = 0; r < SAO_ROWS; r++)
+      if (r < nrows) store8i<PX>(dst + x0 + (y0 + r) * dstride, v[r + 1]);
+    return;
+  }
 
-  if (type == 1) {
-    const int bandShift = bd - 5;
-    const int left = ci.sao_band_position[comp];
+  int o4[4];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      int xs = x0 + i;
-      if (xs >= width) break;
-      int f = M.flags[((xs << cs) >> 2) + ((y << cs) >> 2) * P.w4];
-      if (lf_exempt(P, f)) continue;
-      int k = ((cur[i] >> bandShift) - left) & 31;         // bandTable[(k+left)&31] = k+1
-      if (k < 4) out[i] = lf_clip3(0, maxv, cur[i] + ci.sao_offset_val[comp][k]);
+  for (int k = 0; k < 4; k++) o4[k] = ci.sao_offset_val[comp][k];
+  if (P.dbg & 64) type = 1;                                   // ablation: band offset everywhere
+
+  // pcm / transquant-bypass exemptions of the 4x4 units under the strip (only when the picture has any)
+  // luma: 2 units x 2 unit rows; chroma: 4 units x 4 unit rows; bit (unit_row*4 + unit)
+  unsigned exm = 0;
+  if (P.has_exempt) {
+    const int urows = cs ? 4 : 2, ucols = cs ? 4 : 2;
+    for (int ur = 0; ur < urows; ur++)
+      for (int uc = 0; uc < ucols; uc++) {
+        const int lx = ((x0 << cs) >> 2) + uc, ly = ((y0 << cs) >> 2) + ur;
+        if (lx < P.w4 && ly < P.h4 && lf_exempt(P, M.flags[lx + ly * P.w4])) exm |= 1u << (ur * 4 + uc);
+      }
+  }
+
+  if (type == 1) {                                            // band offset (sao.cc:182-251)
+    const int bandShift = bd - 5, left = ci.sao_band_position[comp];
+#pragma unroll
+    for (int r = 0; r < SAO_ROWS; r++) {
+      if (r >= nrows) break;
+      int out[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int c = v[r + 1][i];
+        const int k = ((c >> bandShift) - left) & 31;         // bandTable[(k+left)&31] = k+1
+        const bool ex = (exm >> ((cs ? r >> 1 : r >> 2) * 4 + (cs ? i >> 1 : i >> 2))) & 1;
+        const int off = k == 0 ? o4[0] : (k == 1 ? o4[1] : (k == 2 ? o4[2] : o4[3]));   // no dynamic register indexing
+        out[i] = (!ex && k < 4) ? lf_clip3(0, maxv, c + off) : c;
+      }
+      store8i<PX>(dst + x0 + (y0 + r) * dstride, out);
     }
-  } else if (type == 2) {
-    const int eo = (ci.sao_eo_class >> (2 * comp)) & 3;
-    const int hx0 = (eo == 1) ? 0 : (eo == 3 ? 1 : -1), hy0 = (eo == 0) ? 0 : -1;
-    const int hx1 = -hx0, hy1 = -hy0;
+    return;
+  }
+
+  // ---- edge offset (sao.cc:75-178)
+  const int eo = (ci.sao_eo_class >> (2 * comp)) & 3;
+  const int hx = (eo == 1) ? 0 : (eo == 3 ? 1 : -1), hy = (eo == 0) ? 0 : -1;   // first neighbour; second is the mirror
+  // permissions of the 3x3 CTB neighbourhood: bit (dy+1)*3+(dx+1); evaluated only on the CTB outline
+  const int mask = (1 << ctbshift) - 1;
+  unsigned perm = 0x1FF;
+  if ((x0 & mask) == 0 || ((x0 + 7) & mask) == mask || (y0 & mask) == 0 || ((y0 + SAO_ROWS - 1) & mask) == mask) {
     const int ctbSlice = ci.slice_addr_rs;
     const int tileCur = M.tile_id[ctbAddr];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      int xs = x0 + i;
-      if (xs >= width) break;
-      int f = M.flags[((xs << cs) >> 2) + ((y << cs) >> 2) * P.w4];
-      if (lf_exempt(P, f)) continue;
-      bool ok = true;
-      int nb[2];
-#pragma unroll
-      for (int k = 0; k < 2; k++) {
-        int xS = xs + (k ? hx1 : hx0), yS = y + (k ? hy1 : hy0);
-        if (xS < 0 || yS < 0 || xS >= width || yS >= height) { ok = false; nb[k] = 0; continue; }
-        int nAddr = (xS >> ctbshift) + (yS >> ctbshift) * P.ctbs_w;
-        if (nAddr != ctbAddr) {
+    const int nCtbX = (width + mask) >> ctbshift, nCtbY = (height + mask) >> ctbshift;
+    perm = 0x10;
+    for (int dy = -1; dy <= 1; dy++)
+      for (int dx = -1; dx <= 1; dx++) {
+        if (!dx && !dy) continue;
+        const int nx = ctbX + dx, ny = ctbY + dy;
+        bool ok = nx >= 0 && ny >= 0 && nx < nCtbX && ny < nCtbY;
+        if (ok) {
+          const int nAddr = nx + ny * P.ctbs_w;
           const de265hip_ctb_info* nci = &M.ctbs[nAddr];
-          int ns = nci->slice_addr_rs;
+          const int ns = nci->slice_addr_rs;
           if (ns < ctbSlice && !sh->slice_loop_filter_across_slices_enabled_flag) ok = false;
           if (ns > ctbSlice && !M.slices[nci->slice_idx].slice_loop_filter_across_slices_enabled_flag) ok = false;
           if (!P.lf_across_tiles && M.tile_id[nAddr] != tileCur) ok = false;
         }
-        nb[k] = src[xS + yS * sstride];
+        if (ok) perm |= 1u << ((dy + 1) * 3 + dx + 1);
       }
-      if (!ok) continue;
-      int c = cur[i];
-      int e = (c > nb[0]) - (c < nb[0]) + (c > nb[1]) - (c < nb[1]);
-      // offsets {o1,o2,0,o3,o4} indexed by e+2 (sao.cc:95-100)
-      int off = e == 0 ? 0 : ci.sao_offset_val[comp][e < 0 ? e + 2 : e + 1];
-      out[i] = lf_clip3(0, maxv, c + off);
-    }
   }
-  store4<PX>(dst + x0 + y * dstride, out);
-  store4<PX>(dst + x0 + 4 + y * dstride, out + 4);
+
+  // offsets {o1,o2,0,o3,o4} indexed by edgeIdx+2 (sao.cc:95-100): four of them packed into one register
+  const unsigned otab = (unsigned)(uint8_t)o4[0] | ((unsigned)(uint8_t)o4[1] << 8) | ((unsigned)(uint8_t)o4[2] << 24);
+  const bool e0 = eo == 0, e1 = eo == 1, e2 = eo == 2;
+  const bool touchL = (x0 & mask) == 0, touchR = ((x0 + 7) & mask) == mask;
+#pragma unroll
+  for (int r = 0; r < SAO_ROWS; r++) {
+    if (r >= nrows) break;
+    const int y = y0 + r;
+    const bool okRows = hy ? (y > 0 && y + 1 < height) : true;
+    const int dyA = hy ? (((y - 1) >> ctbshift) - ctbY) : 0, dyB = hy ? (((y + 1) >> ctbshift) - ctbY) : 0;
+    int out[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int c = v[r + 1][i];
+      // the eight neighbours with compile-time register indices, then a select by edge class
+      // (a runtime index into v[][] would push the whole window into scratch memory)
+      const int nL = i > 0 ? v[r + 1][i > 0 ? i - 1 : 0] : nl[r + 1], nR = i < 7 ? v[r + 1][i < 7 ? i + 1 : 7] : nr[r + 1];
+      const int nU = v[r][i], nD = v[r + 2][i];
+      const int nUL = i > 0 ? v[r][i > 0 ? i - 1 : 0] : nl[r], nUR = i < 7 ? v[r][i < 7 ? i + 1 : 7] : nr[r];
+      const int nDL = i > 0 ? v[r + 2][i > 0 ? i - 1 : 0] : nl[r + 2], nDR = i < 7 ? v[r + 2][i < 7 ? i + 1 : 7] : nr[r + 2];
+      const int na = e0 ? nL : (e1 ? nU : (e2 ? nUL : nUR));
+      const int nb = e0 ? nR : (e1 ? nD : (e2 ? nDR : nDL));
+      // branch-free predicates (bitwise, not short-circuit: no exec-mask juggling per sample)
+      unsigned ok = ~(exm >> ((cs ? r >> 1 : r >> 2) * 4 + (cs ? i >> 1 : i >> 2))) & 1u;
+      // only samples on the outline of the strip can have a neighbour in another CTB / outside the picture
+      // (i and r are compile-time constants here: interior samples carry none of this code)
+      if (i == 0 || i == 7 || r == 0 || r == SAO_ROWS - 1) {
+        const int xs = x0 + i, xa = xs + hx, xb = xs - hx;
+        ok &= (unsigned)okRows & (unsigned)(xs < width) & (unsigned)(xa >= 0) & (unsigned)(xa < width) &
+              (unsigned)(xb >= 0) & (unsigned)(xb < width);
+        const int dxA = (i == 0 && touchL && hx < 0) ? -1 : ((i == 7 && touchR && hx > 0) ? 1 : 0);
+        const int dxB = (i == 0 && touchL && hx > 0) ? -1 : ((i == 7 && touchR && hx < 0) ? 1 : 0);
+        ok &= (perm >> ((dyA + 1) * 3 + dxA + 1)) & (perm >> ((dyB + 1) * 3 + dxB + 1));
+      } else {
+        // a partial last strip ends inside the 8 rows / 8 columns: the picture edge can cut through it
+        ok &= (unsigned)okRows & (unsigned)(x0 + i + (hx ? 1 : 0) < width);
+      }
+      const int ee = min(max(c - na, -1), 1) + min(max(c - nb, -1), 1) + 2;      // 0..4
+      const int off = ee == 4 ? o4[3] : (int)(int8_t)((otab >> (8 * ee)) & 0xFF);
+      out[i] = ok ? lf_clip3(0, maxv, c + off) : c;
+    }
+    store8i<PX>(dst + x0 + y * dstride, out);
+  }
 }
 
 template __global__ void k_sao<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, SaoMeta);

@@ -403,10 +403,139 @@ __device__ __forceinline__ void store4_from_u16(uint8_t* g, uint2 v)
 
 // Intra-only scratch of the run kernel (the residuals were computed beforehand).
 struct RunShared {
-  uint16_t pred[32 * 32];
-  int32_t border[4 * 32 + 4];
-  int32_t bfilt[4 * 32 + 4];
+  int32_t b0[4 * 32 + 4];      // neighbours as fetched (+ substitution), centre at [64]
+  int32_t b1[4 * 32 + 4];      // smoothed neighbours
 };
+
+// wave64 sum with DPP row shifts (no LDS traffic); the total is returned to every lane
+__device__ __forceinline__ int wave_sum_dpp(int v)
+{
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8  -> lane 15 of each row = row sum
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);   // row_bcast:15 into rows 1,3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);   // row_bcast:31 into rows 2,3 -> lane 63 = total
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// One intra TU of a run, entirely inside LDS: gather the neighbours from the pixel window
+// (availability mask + substitution, intrapred.cc:395-431,:577-688), smooth them when the
+// mode asks for it (:816-889), predict (:903-1069), add the precomputed residual and write the
+// reconstructed samples into the window.  t is wave-uniform and in window coordinates.
+// Three dependent LDS round trips per TU (gather, [smooth], predict) instead of ten.
+__device__ __forceinline__ void run_intra_tu(const PicDev& P, const TuTask& t, uint16_t* tile, RunShared& S,
+                                             int lane, const int16_t* res, int bd)
+{
+  const int log2 = t.log2_size, nT = 1 << log2, nS = nT * nT;
+  const int cIdx = t.c_idx;
+  const int xB = t.x0, yB = t.y0;
+  const uint64_t avail = t.avail;
+  const int cornerUnit = nT >> 1;
+  int* A = &S.b0[64];
+  int* Bf = &S.b1[64];
+
+  for (int p = lane; p <= 4 * nT; p += 64) {
+    const int i = p - 2 * nT;
+    const int u = (i < 0) ? (p >> 2) : (i == 0 ? cornerUnit : cornerUnit + 1 + ((i - 1) >> 2));
+    int val = 1 << (bd - 1);
+    if (avail != 0) {
+      int src = i;
+      if (!((avail >> u) & 1)) {
+        const uint64_t below = avail & ((2ull << u) - 1ull);
+        if (below) {
+          const int su = 63 - __clzll((long long)below);
+          src = (su < cornerUnit) ? (-2 * nT + 4 * su + 3) : (su == cornerUnit ? 0 : 4 * (su - cornerUnit));
+        } else {
+          const int su = __ffsll((long long)avail) - 1;
+          src = (su < cornerUnit) ? (-2 * nT + 4 * su) : (su == cornerUnit ? 0 : 4 * (su - cornerUnit - 1) + 1);
+        }
+      }
+      const int sx = src <= 0 ? xB - 1 : xB + src - 1;
+      const int sy = src < 0 ? yB - src - 1 : yB - 1;
+      val = tile[sx + sy * RUN_TILE_P];
+    }
+    A[i] = val;
+  }
+  LDS_SYNC();
+
+  const int mode = t.intra_mode >= 35 ? 1 : t.intra_mode;
+  const int* bord = A;
+  if (cIdx == 0 && mode != 1 && nT != 4) {
+    const int minDist = min(abs(mode - 26), abs(mode - 10));
+    const bool filt = (nT == 8) ? (minDist > 7) : (nT == 16 ? (minDist > 1) : (minDist > 0));
+    if (filt) {
+      bool biInt = false;
+      if (P.strong_intra && nT == 32) {
+        const int th = 1 << (P.bd_luma - 5);
+        biInt = abs(A[0] + A[64] - 2 * A[32]) < th && abs(A[0] + A[-64] - 2 * A[-32]) < th;
+      }
+      for (int p = lane; p <= 4 * nT; p += 64) {
+        const int i = p - 2 * nT;
+        int v;
+        if (i == -2 * nT || i == 2 * nT) v = A[i];
+        else if (biInt) v = (i == 0) ? A[0] : (i < 0 ? A[0] + (((-i) * (A[-64] - A[0]) + 32) >> 6)
+                                                       : A[0] + ((i * (A[64] - A[0]) + 32) >> 6));
+        else v = (A[i + 1] + 2 * A[i] + A[i - 1] + 2) >> 2;
+        Bf[i] = v;
+      }
+      LDS_SYNC();
+      bord = Bf;
+    }
+  }
+
+  const int maxv = (1 << bd) - 1;
+  uint16_t* dst = tile + xB + yB * RUN_TILE_P;
+  if (mode == 0) {                                   // planar
+    const int tr = bord[1 + nT], bl = bord[-1 - nT];
+    for (int s = lane; s < nS; s += 64) {
+      const int y = s >> log2, x = s & (nT - 1);
+      int pv = ((nT - 1 - x) * bord[-1 - y] + (x + 1) * tr + (nT - 1 - y) * bord[1 + x] + (y + 1) * bl + nT) >> (log2 + 1);
+      if (res) pv = clip3(0, maxv, pv + res[s]);
+      dst[x + y * RUN_TILE_P] = (uint16_t)pv;
+    }
+  } else if (mode == 1) {                            // DC
+    int v = 0;
+    if (lane < nT) v = bord[lane + 1] + bord[-lane - 1];
+    const int dc = (wave_sum_dpp(v) + nT) >> (log2 + 1);
+    const bool edge = (cIdx == 0 && nT < 32);
+    for (int s = lane; s < nS; s += 64) {
+      const int y = s >> log2, x = s & (nT - 1);
+      int pv = dc;
+      if (edge) {
+        if (x == 0 && y == 0) pv = (bord[-1] + 2 * dc + bord[1] + 2) >> 2;
+        else if (y == 0) pv = (bord[x + 1] + 3 * dc + 2) >> 2;
+        else if (x == 0) pv = (bord[-y - 1] + 3 * dc + 2) >> 2;
+      }
+      if (res) pv = clip3(0, maxv, pv + res[s]);
+      dst[x + y * RUN_TILE_P] = (uint16_t)pv;
+    }
+  } else {                                           // angular, reference array evaluated in place
+    const int angle = c_intra_angle[mode];
+    const bool vert = mode >= 18;
+    const int inv = angle < 0 ? (int)c_inv_angle[mode - 11] : 0;
+    const bool edge = (cIdx == 0 && nT < 32) && (mode == 26 || mode == 10);
+    for (int s = lane; s < nS; s += 64) {
+      const int y = s >> log2, x = s & (nT - 1);
+      const int a = vert ? y : x, b = vert ? x : y;
+      const int iIdx = ((a + 1) * angle) >> 5, iFact = ((a + 1) * angle) & 31;
+      const int i0 = b + iIdx + 1, i1 = i0 + 1;
+      // ref[i] = border[+-i] for i >= 0, border[-+((i*invAngle+128)>>8)] for the projected part (i < 0)
+      const int k0 = i0 >= 0 ? i0 : -((i0 * inv + 128) >> 8);
+      const int k1 = i1 >= 0 ? i1 : -((i1 * inv + 128) >> 8);
+      const int r0 = bord[vert ? k0 : -k0];
+      int pv = r0;
+      if (iFact) pv = ((32 - iFact) * r0 + iFact * bord[vert ? k1 : -k1] + 16) >> 5;
+      if (edge) {
+        if (mode == 26 && x == 0) pv = clip3(0, maxv, bord[1] + ((bord[-1 - y] - bord[0]) >> 1));
+        if (mode == 10 && y == 0) pv = clip3(0, maxv, bord[-1] + ((bord[1 + x] - bord[0]) >> 1));
+      }
+      if (res) pv = clip3(0, maxv, pv + res[s]);
+      dst[x + y * RUN_TILE_P] = (uint16_t)pv;
+    }
+  }
+  LDS_SYNC();
+}
 
 template <typename PX>
 __global__ __launch_bounds__(64)
@@ -456,7 +585,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   PX* plane = (PX*)pr.ptr;
   const int stride = pr.stride;
   const int cw = c ? P.width >> 1 : P.width, ch = c ? P.height >> 1 : P.height;
-  const int bd = c ? P.bd_chroma : P.bd_luma, maxv = (1 << bd) - 1;
+  const int bd = c ? P.bd_chroma : P.bd_luma;
   // pixel window: bbox + 1 left/top + 32 right/bottom (everything a TU of the run can read),
   // fetched in aligned 8-sample chunks, several loads in flight per lane
   const int wx0 = (int)run.x0 - 1, wy0 = (int)run.y0 - 1;
@@ -504,17 +633,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
       }
       t.x0 = (uint16_t)((int)t.x0 - ax0); t.y0 = (uint16_t)((int)t.y0 - wy0);      // window coordinates
       st.mark(0);
-      intra_predict<uint16_t, RunShared>(P, t, tile, RUN_TILE_P, S, lane, st);
-      const int log2 = t.log2_size, nT = 1 << log2, nS = nT * nT;
-      uint16_t* dst = tile + t.x0 + t.y0 * RUN_TILE_P;
-      if (t.flags & DE265HIP_TU_CBF) {
-        const int16_t* r = &s_res[t.resid_offset - res_base];
-        for (int s = lane; s < nS; s += 64)
-          dst[(s & (nT - 1)) + (s >> log2) * RUN_TILE_P] = (uint16_t)clip3(0, maxv, (int)S.pred[s] + (int)r[s]);
-      } else {
-        for (int s = lane; s < nS; s += 64) dst[(s & (nT - 1)) + (s >> log2) * RUN_TILE_P] = S.pred[s];
-      }
-      LDS_SYNC();
+      run_intra_tu(P, t, tile, S, lane, (t.flags & DE265HIP_TU_CBF) ? &s_res[t.resid_offset - res_base] : nullptr, bd);
       st.mark(5);
       if (st.buf && lane == 0) atomicAdd(&st.buf[7], 1u);
     }
