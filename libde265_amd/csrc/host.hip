@@ -72,6 +72,7 @@ struct de265hip_picture {
   uint8_t* d_bs = nullptr;
   RunTask* d_runs = nullptr; uint32_t* d_deps = nullptr; uint32_t* d_sync = nullptr;
   TuTask* d_run_tus = nullptr;
+  int n_l0_size[4] = { 0, 0, 0, 0 };          // TU count per size in d_l0 (sorted 32,16,8,4)
   TuTask* d_l0 = nullptr; int n_l0 = 0;       // run mode: inter residual TUs + residual-only copies of intra TUs
   int16_t* d_resid = nullptr;                 // precomputed residual blocks of intra TUs
   int n_runs = 0, n_workers = 0; size_t sync_bytes = 0;
@@ -466,7 +467,11 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   // level-0 launch of run mode: inter TUs with residual, then the residual-only intra TUs
   std::vector<TuTask> l0(sorted.begin() + pic->level_start[0], sorted.begin() + pic->level_start[1]);
   l0.insert(l0.end(), resid_only.begin(), resid_only.end());
+  // largest first: [32x32 | 16x16 | 8x8 | 4x4]; the two small sizes get their own packed kernel
+  std::stable_sort(l0.begin(), l0.end(), [](const TuTask& a, const TuTask& b) { return a.log2_size > b.log2_size; });
   pic->n_l0 = (int)l0.size();
+  for (int k = 0; k < 4; k++) pic->n_l0_size[k] = 0;
+  for (const TuTask& tt : l0) pic->n_l0_size[tt.log2_size - 2]++;
 
   // ---- MC tasks: resolve references, bi->uni shortcut, split into <=16x16 tiles
   std::vector<McTask> mcs;
@@ -650,9 +655,17 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
     // run mode: one launch for every residual (inter TUs add into the picture, intra TUs fill the
     // residual buffer), then one launch for the whole intra dependency graph
     if (pic->n_l0 > 0) {
-      KTimer t(dec, DE265HIP_K_RESID, 1);
-      hipLaunchKernelGGL(k_tu<PX>, dim3(pic->n_l0), dim3(64), 0, st, P, d0, d1, d2, pic->d_l0, 0, pic->d_cval,
-                         pic->d_cpos, pic->d_scaling, pic->d_resid);
+      const int nbig = pic->n_l0_size[3] + pic->n_l0_size[2], n8 = pic->n_l0_size[1], n4 = pic->n_l0_size[0];
+      KTimer t(dec, DE265HIP_K_RESID, (nbig > 0) + (n8 > 0) + (n4 > 0));
+      if (nbig > 0)
+        hipLaunchKernelGGL(k_tu<PX>, dim3(nbig), dim3(64), 0, st, P, d0, d1, d2, pic->d_l0, 0, pic->d_cval,
+                           pic->d_cpos, pic->d_scaling, pic->d_resid);
+      if (n8 > 0)
+        hipLaunchKernelGGL((k_resid_small<PX, 3>), dim3(n8), dim3(64), 0, st, P, d0, d1, d2, pic->d_l0, nbig, n8,
+                           pic->d_cval, pic->d_cpos, pic->d_scaling, pic->d_resid);
+      if (n4 > 0)
+        hipLaunchKernelGGL((k_resid_small<PX, 2>), dim3((n4 + 3) / 4), dim3(64), 0, st, P, d0, d1, d2, pic->d_l0,
+                           nbig + n8, n4, pic->d_cval, pic->d_cpos, pic->d_scaling, pic->d_resid);
     }
     if (pic->n_runs > 0) {
       KTimer t(dec, DE265HIP_K_INTRA, 1);

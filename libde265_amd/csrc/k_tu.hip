@@ -351,6 +351,92 @@ __device__ void tu_reconstruct(const PicDev& P, const TuTask& t, PX* plane, int 
   st.mark(5);
 }
 
+// ---------------------------------------------------------------- small-TU residual kernel
+// 4x4 and 8x8 TUs are ~95 % of all TUs.  One wavefront handles four 4x4 TUs (16 lanes each) or
+// one 8x8 TU: every lane owns one coefficient in the scatter and one sample in both transform
+// stages, the 4/8-point matrices sit in LDS (64 bytes), nothing else is staged.  Handles the
+// level-0 work of run mode: inter TUs (residual added into the picture) and the residual-only
+// copies of intra TUs (int16 block into the residual buffer).
+template <typename PX, int LOG2>
+__global__ __launch_bounds__(64)
+void k_resid_small(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const TuTask* __restrict__ tasks,
+                   int first, int count, const int16_t* __restrict__ coeff_val,
+                   const uint16_t* __restrict__ coeff_pos, const uint8_t* __restrict__ scaling,
+                   int16_t* __restrict__ resid)
+{
+  constexpr int nT = 1 << LOG2, nS = nT * nT, TPW = 64 / nS;      // TUs per wavefront: 4 or 1
+  __shared__ int16_t s_c[TPW][nS];
+  __shared__ int16_t s_g[TPW][nS];
+  __shared__ int8_t s_dct[nS];          // M[j][i] = mat_dct[(32/nT)*j][i]
+  __shared__ int8_t s_dst[16];
+  const int lane = threadIdx.x;
+  const int sub = lane / nS, s = lane % nS;
+  const int tix = blockIdx.x * TPW + sub;
+  const bool live = tix < count;
+  if (lane < nS) s_dct[lane] = c_dct_mat[(32 / nT) * (lane / nT) * 32 + (lane % nT)];
+  if (LOG2 == 2 && lane < 16) s_dst[lane] = c_dst_mat[lane];
+  s_c[sub][s] = 0;
+  TuTask t;
+  if (live) t = tasks[first + tix];
+  LDS_SYNC();
+  const int cIdx = live ? t.c_idx : 0;
+  const int bd = cIdx ? P.bd_chroma : P.bd_luma;
+  const bool intra = live && (t.flags & DE265HIP_TU_INTRA);
+  const bool bypass = live && (t.flags & DE265HIP_TU_BYPASS);
+  const bool tskip = live && (t.flags & DE265HIP_TU_TSKIP);
+  if (live && s < (int)t.n_coeff) {
+    const int p = coeff_pos[t.coeff_offset + s];
+    const int v = coeff_val[t.coeff_offset + s];
+    int out;
+    if (bypass) out = v;
+    else if (!P.scaling_list) {
+      const int bdShift = bd + LOG2 - 9;
+      const int32_t fact = (int32_t)c_level_scale[t.qp % 6] << (t.qp / 6);
+      const int32_t cc = (int32_t)((uint32_t)v * (uint32_t)fact + (uint32_t)(1 << (bdShift - 1)));   // 32-bit wrap
+      out = clip3(-32768, 32767, cc >> bdShift);
+    } else {
+      const int bdShift = bd + LOG2 - 5;
+      const int matrixID = cIdx + (intra ? 0 : 3);
+      const int m = scaling[(LOG2 == 2 ? 0 : 96) + matrixID * nS + p];
+      const int fact = (m * c_level_scale[t.qp % 6]) << (t.qp / 6);
+      long long cc = ((long long)v * fact + (1ll << (bdShift - 1))) >> bdShift;
+      out = (int)(cc < -32768 ? -32768 : (cc > 32767 ? 32767 : cc));
+    }
+    s_c[sub][p] = (int16_t)out;
+  }
+  LDS_SYNC();
+  if (!live) return;
+  int r;
+  if (bypass) r = s_c[sub][s];
+  else if (tskip) r = ((int32_t)((uint32_t)(int32_t)s_c[sub][s] << (5 + LOG2)) + (1 << (19 - bd))) >> (20 - bd);
+  else {
+    const bool is_dst = LOG2 == 2 && cIdx == 0 && intra;
+    const int8_t* M = is_dst ? s_dst : s_dct;
+    {                                   // first stage: lane -> (row i, column c)
+      const int i = s / nT, c = s % nT;
+      int sum = 0;
+#pragma unroll
+      for (int j = 0; j < nT; j++) sum += M[j * nT + i] * s_c[sub][c + j * nT];
+      s_g[sub][i * nT + c] = (int16_t)clip3(-32768, 32767, (sum + 64) >> 7);
+    }
+    LDS_SYNC();
+    const int y = s / nT, i = s % nT;
+    int sum = 0;
+#pragma unroll
+    for (int j = 0; j < nT; j++) sum += M[j * nT + i] * s_g[sub][y * nT + j];
+    r = (sum + (1 << (19 - bd))) >> (20 - bd);
+    if (is_dst) r = clip3(-32768, 32767, r);                   // DST clips its second stage, the DCT does not
+  }
+  if (t.flags & D265_TU_RESID_ONLY) { resid[t.resid_offset + s] = (int16_t)clip3(-32768, 32767, r); return; }
+  const PlaneRef pr = cIdx == 0 ? pl0 : (cIdx == 1 ? pl1 : pl2);
+  PX* d = (PX*)pr.ptr + t.x0 + (s % nT) + (t.y0 + s / nT) * pr.stride;
+  *d = (PX)clip3(0, (1 << bd) - 1, (int)*d + r);
+}
+template __global__ void k_resid_small<uint8_t, 2>(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int, int, const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
+template __global__ void k_resid_small<uint8_t, 3>(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int, int, const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
+template __global__ void k_resid_small<uint16_t, 2>(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int, int, const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
+template __global__ void k_resid_small<uint16_t, 3>(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int, int, const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
+
 // One workgroup (one wavefront) per TU of a dependency level.
 template <typename PX>
 __global__ __launch_bounds__(64)
