@@ -53,6 +53,9 @@ def main():
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DE265HIP_BENCH_STREAMS", "1")),
                     help="independent closed GOPs decoded concurrently per GPU (one decoder/HIP stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm; gloo for rehearsals)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal only: every rank uses GPU 0 (a 1-GPU box cannot give each rank its own GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -65,11 +68,17 @@ def main():
 
     if not torch.cuda.is_available() or backend.device_count() == 0:
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
+    red_dev = "cuda" if args.backend == "nccl" else "cpu"
 
     W, H, BD, GOP, S = args.width, args.height, args.bit_depth, args.gop, max(1, args.streams)
     gops, decs, pics = [], [], []
@@ -99,7 +108,7 @@ def main():
     for d in decs:
         d.set_profiling(True)
         d.kernel_times(reset=True)
-    timer = farm.RankTimer(dist, sync, device="cuda")
+    timer = farm.RankTimer(dist, sync, device=red_dev)
     timer.start()                       # barrier + synchronize
     for _ in range(args.steps):
         step()

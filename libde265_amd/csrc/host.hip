@@ -644,7 +644,8 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
     for (int s = 0; s < DE265HIP_MAX_DPB_SLOTS; s++)
       if (dec->slots[s].valid) for (int c = 0; c < 3; c++) tab.p[s][c] = dec->slots[s].pl[c];
     KTimer t(dec, DE265HIP_K_MC, 1);
-    hipLaunchKernelGGL(k_mc<PX>, dim3(pic->n_mc), dim3(64), 0, st, P, tab, d0, d1, d2, pic->d_mc, pic->d_slices);
+    hipLaunchKernelGGL(k_mc<PX>, dim3(((pic->n_mc + 7) / 8) * 8), dim3(64), 0, st, P, tab, d0, d1, d2, pic->d_mc, pic->d_slices,
+                       pic->n_mc);
   }
   if (pic->n_pcm) {
     KTimer t(dec, DE265HIP_K_PCM, 1);

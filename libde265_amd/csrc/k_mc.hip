@@ -148,13 +148,19 @@ template <> __device__ __forceinline__ void st2_px<uint8_t>(uint8_t* p, int a, i
 template <typename PX>
 __global__ __launch_bounds__(64)
 void k_mc(PicDev P, DpbTable dpb, PlaneRef d0, PlaneRef d1, PlaneRef d2,
-          const McTask* __restrict__ tasks, const de265hip_slice_params* __restrict__ slices)
+          const McTask* __restrict__ tasks, const de265hip_slice_params* __restrict__ slices, int n_tasks)
 {
   __shared__ __attribute__((aligned(16))) uint16_t s_inL[2][23 * MCL_P];
   __shared__ __attribute__((aligned(16))) uint16_t s_inC[2][2][11 * MCC_P];
   __shared__ __attribute__((aligned(16))) int16_t s_tmp[23 * MCT_P];
   const int lane = threadIdx.x;
-  const McTask t = tasks[blockIdx.x];
+  // XCD-aware mapping: workgroups b and b+8 share an XCD (and its L2); give every XCD one contiguous
+  // eighth of the task list (tasks are in decode order, i.e. spatial neighbours) so that the
+  // overlapping filter margins of neighbouring tiles hit in the same L2.  Speed only, never correctness.
+  const int per = (n_tasks + 7) >> 3;
+  const int tix = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (tix >= n_tasks) return;
+  const McTask t = tasks[tix];
   const de265hip_slice_params* sh = &slices[t.slice_idx];
   const bool use0 = t.slot[0] >= 0, use1 = t.slot[1] >= 0;
   const bool bi = use0 && use1;
@@ -368,9 +374,9 @@ void k_mc(PicDev P, DpbTable dpb, PlaneRef d0, PlaneRef d1, PlaneRef d2,
 }
 
 template __global__ void k_mc<uint8_t>(PicDev, DpbTable, PlaneRef, PlaneRef, PlaneRef, const McTask*,
-                                       const de265hip_slice_params*);
+                                       const de265hip_slice_params*, int);
 template __global__ void k_mc<uint16_t>(PicDev, DpbTable, PlaneRef, PlaneRef, PlaneRef, const McTask*,
-                                        const de265hip_slice_params*);
+                                        const de265hip_slice_params*, int);
 
 // ---- PCM sample copy (slice.cc:4143-4183), one workgroup per PCM CU
 template <typename PX>

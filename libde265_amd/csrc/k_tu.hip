@@ -511,7 +511,7 @@ __device__ __forceinline__ int wave_sum_dpp(int v)
 // reconstructed samples into the window.  t is wave-uniform and in window coordinates.
 // Three dependent LDS round trips per TU (gather, [smooth], predict) instead of ten.
 __device__ __forceinline__ void run_intra_tu(const PicDev& P, const TuTask& t, uint16_t* tile, RunShared& S,
-                                             int lane, const int16_t* res, int bd)
+                                             int lane, const int16_t* res, int bd, Stamper& st)
 {
   const int log2 = t.log2_size, nT = 1 << log2, nS = nT * nT;
   const int cIdx = t.c_idx;
@@ -521,6 +521,7 @@ __device__ __forceinline__ void run_intra_tu(const PicDev& P, const TuTask& t, u
   int* A = &S.b0[64];
   int* Bf = &S.b1[64];
 
+  if (!(P.dbg & 256))                                // ablation: no neighbour gather
   for (int p = lane; p <= 4 * nT; p += 64) {
     const int i = p - 2 * nT;
     const int u = (i < 0) ? (p >> 2) : (i == 0 ? cornerUnit : cornerUnit + 1 + ((i - 1) >> 2));
@@ -544,6 +545,7 @@ __device__ __forceinline__ void run_intra_tu(const PicDev& P, const TuTask& t, u
     A[i] = val;
   }
   LDS_SYNC();
+  st.mark(1);
 
   const int mode = t.intra_mode >= 35 ? 1 : t.intra_mode;
   const int* bord = A;
@@ -570,37 +572,41 @@ __device__ __forceinline__ void run_intra_tu(const PicDev& P, const TuTask& t, u
     }
   }
 
+  st.mark(2);
   const int maxv = (1 << bd) - 1;
   uint16_t* dst = tile + xB + yB * RUN_TILE_P;
+  // All three predictors are written branch-free: every LDS operand of a sample is requested
+  // unconditionally and together (one round trip), special cases are selects.
+  const bool has_res = res != nullptr;                // wave-uniform
+  if (P.dbg & 128) { LDS_SYNC(); return; }           // ablation: no prediction
   if (mode == 0) {                                   // planar
     const int tr = bord[1 + nT], bl = bord[-1 - nT];
     for (int s = lane; s < nS; s += 64) {
       const int y = s >> log2, x = s & (nT - 1);
-      int pv = ((nT - 1 - x) * bord[-1 - y] + (x + 1) * tr + (nT - 1 - y) * bord[1 + x] + (y + 1) * bl + nT) >> (log2 + 1);
-      if (res) pv = clip3(0, maxv, pv + res[s]);
-      dst[x + y * RUN_TILE_P] = (uint16_t)pv;
+      const int l = bord[-1 - y], tp = bord[1 + x];
+      const int rs = has_res ? (int)res[s] : 0;
+      const int pv = ((nT - 1 - x) * l + (x + 1) * tr + (nT - 1 - y) * tp + (y + 1) * bl + nT) >> (log2 + 1);
+      dst[x + y * RUN_TILE_P] = (uint16_t)clip3(0, maxv, pv + rs);
     }
   } else if (mode == 1) {                            // DC
-    int v = 0;
-    if (lane < nT) v = bord[lane + 1] + bord[-lane - 1];
+    const int v = (lane < nT) ? bord[lane + 1] + bord[-lane - 1] : 0;
     const int dc = (wave_sum_dpp(v) + nT) >> (log2 + 1);
     const bool edge = (cIdx == 0 && nT < 32);
+    const int corner = (bord[-1] + 2 * dc + bord[1] + 2) >> 2;
     for (int s = lane; s < nS; s += 64) {
       const int y = s >> log2, x = s & (nT - 1);
+      const int tp = bord[x + 1], l = bord[-y - 1];
+      const int rs = has_res ? (int)res[s] : 0;
       int pv = dc;
-      if (edge) {
-        if (x == 0 && y == 0) pv = (bord[-1] + 2 * dc + bord[1] + 2) >> 2;
-        else if (y == 0) pv = (bord[x + 1] + 3 * dc + 2) >> 2;
-        else if (x == 0) pv = (bord[-y - 1] + 3 * dc + 2) >> 2;
-      }
-      if (res) pv = clip3(0, maxv, pv + res[s]);
-      dst[x + y * RUN_TILE_P] = (uint16_t)pv;
+      if (edge) pv = (x | y) == 0 ? corner : (y == 0 ? (tp + 3 * dc + 2) >> 2 : (x == 0 ? (l + 3 * dc + 2) >> 2 : dc));
+      dst[x + y * RUN_TILE_P] = (uint16_t)clip3(0, maxv, pv + rs);
     }
   } else {                                           // angular, reference array evaluated in place
     const int angle = c_intra_angle[mode];
     const bool vert = mode >= 18;
     const int inv = angle < 0 ? (int)c_inv_angle[mode - 11] : 0;
     const bool edge = (cIdx == 0 && nT < 32) && (mode == 26 || mode == 10);
+    const int b0 = bord[0], bp1 = bord[1], bm1 = bord[-1];
     for (int s = lane; s < nS; s += 64) {
       const int y = s >> log2, x = s & (nT - 1);
       const int a = vert ? y : x, b = vert ? x : y;
@@ -609,15 +615,15 @@ __device__ __forceinline__ void run_intra_tu(const PicDev& P, const TuTask& t, u
       // ref[i] = border[+-i] for i >= 0, border[-+((i*invAngle+128)>>8)] for the projected part (i < 0)
       const int k0 = i0 >= 0 ? i0 : -((i0 * inv + 128) >> 8);
       const int k1 = i1 >= 0 ? i1 : -((i1 * inv + 128) >> 8);
-      const int r0 = bord[vert ? k0 : -k0];
-      int pv = r0;
-      if (iFact) pv = ((32 - iFact) * r0 + iFact * bord[vert ? k1 : -k1] + 16) >> 5;
+      const int r0 = bord[vert ? k0 : -k0], r1 = bord[vert ? k1 : -k1];
+      const int ev = vert ? bord[-1 - y] : bord[1 + x];         // operand of the mode 26 / 10 edge filter
+      const int rs = has_res ? (int)res[s] : 0;
+      int pv = ((32 - iFact) * r0 + iFact * r1 + 16) >> 5;     // == r0 when iFact == 0
       if (edge) {
-        if (mode == 26 && x == 0) pv = clip3(0, maxv, bord[1] + ((bord[-1 - y] - bord[0]) >> 1));
-        if (mode == 10 && y == 0) pv = clip3(0, maxv, bord[-1] + ((bord[1 + x] - bord[0]) >> 1));
+        const int e = clip3(0, maxv, (vert ? bp1 : bm1) + ((ev - b0) >> 1));
+        pv = (vert ? x == 0 : y == 0) ? e : pv;
       }
-      if (res) pv = clip3(0, maxv, pv + res[s]);
-      dst[x + y * RUN_TILE_P] = (uint16_t)pv;
+      dst[x + y * RUN_TILE_P] = (uint16_t)clip3(0, maxv, pv + rs);
     }
   }
   LDS_SYNC();
@@ -719,8 +725,8 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
       }
       t.x0 = (uint16_t)((int)t.x0 - ax0); t.y0 = (uint16_t)((int)t.y0 - wy0);      // window coordinates
       st.mark(0);
-      run_intra_tu(P, t, tile, S, lane, (t.flags & DE265HIP_TU_CBF) ? &s_res[t.resid_offset - res_base] : nullptr, bd);
-      st.mark(5);
+      run_intra_tu(P, t, tile, S, lane, (t.flags & DE265HIP_TU_CBF) ? &s_res[t.resid_offset - res_base] : nullptr, bd, st);
+      st.mark(3);
       if (st.buf && lane == 0) atomicAdd(&st.buf[7], 1u);
     }
     // write the finished TUs of this batch back, 4 samples per lane; stores are independent of the

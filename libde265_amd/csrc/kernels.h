@@ -29,7 +29,7 @@ __global__ void k_run(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, cons
                       const TuTask*, const int16_t*, int, int);
 template <typename PX>
 __global__ void k_mc(PicDev, DpbTable, PlaneRef, PlaneRef, PlaneRef, const McTask*,
-                     const de265hip_slice_params*);
+                     const de265hip_slice_params*, int);
 template <typename PX>
 __global__ void k_pcm(PlaneRef, PlaneRef, PlaneRef, const PcmTask*, const uint16_t*);
 __global__ void k_bs(PicDev, const uint8_t*, const de265hip_motion*, uint8_t*);

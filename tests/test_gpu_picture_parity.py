@@ -166,3 +166,62 @@ def test_4k_main10_full_size(dec):
     dec.run(pic, 2); dec.sync()
     assert all(np.array_equal(g, e) for g, e in zip(dec.download(2, w, h, bd), exp_b))
     pic.free()
+
+
+def test_intra_run_kernel_equals_level_launches(dec):
+    """The single-launch run kernel (default) and the one-launch-per-dependency-level path
+    (DE265HIP_INTRA_MODE=levels) are two schedules of the same work: identical pictures."""
+    import os
+    from libde265_amd import backend
+    w, h, bd = 416, 240, 10
+    refs = {0: pysynth.fill_planes(w, h, bd, 5), 1: pysynth.fill_planes(w, h, bd, 6)}
+    outs = []
+    for mode in ("levels", None):
+        if mode:
+            os.environ["DE265HIP_INTRA_MODE"] = mode
+        else:
+            os.environ.pop("DE265HIP_INTRA_MODE", None)
+        d2 = backend.Decoder()
+        try:
+            for s, pl in refs.items():
+                d2.dpb_alloc(s, w, h, bd); d2.upload(s, pl)
+            res = []
+            for st, seed in ((2, 71), (0, 72)):
+                sp = pysynth.SynthPicture(pysynth.default_config(w, h, bd, st, seed=seed, tskip_pct=20, pcm_pct=10,
+                                                                 scaling_list=1, n_slices=2))
+                d2.dpb_alloc(2, w, h, bd); d2.upload(2, pysynth.fill_planes(w, h, bd, 9))
+                pic = d2.build(2, sp.desc); d2.run(pic, 2); d2.sync()
+                res.append(d2.download(2, w, h, bd))
+                stats = pic.stats()
+                assert stats.n_runs > 0 and stats.n_levels > 1
+                pic.free()
+            outs.append(res)
+        finally:
+            d2.close()
+    os.environ.pop("DE265HIP_INTRA_MODE", None)
+    for a, b in zip(outs[0], outs[1]):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_concurrent_decoders_do_not_interfere(dec):
+    """Several decoders (HIP streams) in flight at once, as bench.py --streams does."""
+    from libde265_amd import backend
+    w, h, bd = 352, 288, 8
+    decs, pics, exps = [], [], []
+    for s in range(3):
+        d = backend.Decoder()
+        sp_i = pysynth.SynthPicture(pysynth.default_config(w, h, bd, 2, seed=300 + s))
+        sp_b = pysynth.SynthPicture(pysynth.default_config(w, h, bd, 0, seed=400 + s, ref_slots=[0, 0]))
+        e_i = pyoracle.alloc_planes(w, h, bd); pyoracle.reconstruct(sp_i.desc, sp_i.order, {}, e_i)
+        e_b = pyoracle.alloc_planes(w, h, bd); pyoracle.reconstruct(sp_b.desc, sp_b.order, {0: e_i}, e_b)
+        d.dpb_alloc(0, w, h, bd); d.dpb_alloc(1, w, h, bd)
+        decs.append(d); pics.append((d.build(0, sp_i.desc), d.build(1, sp_b.desc), sp_i, sp_b)); exps.append(e_b)
+    for rep in range(3):
+        for k in range(2):
+            for s in range(3):
+                decs[s].run(pics[s][k], 2)
+    for s in range(3):
+        decs[s].sync()
+        got = decs[s].download(1, w, h, bd)
+        assert all(np.array_equal(g, e) for g, e in zip(got, exps[s])), s
+        pics[s][0].free(); pics[s][1].free(); decs[s].close()
