@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """bench.py -- decoded frames/s of the MI355X HEVC reconstruction back end.
 
-Workload (BASELINE.json configs[3] / SURVEY.md 8d config 4): one closed GOP of
+Workload (BASELINE.json configs[3] / SURVEY.md 8d config 4): closed GOPs of
 3840x2160 10-bit 4:2:0 pictures (1 I + 15 B, each B referencing the two
 previously decoded pictures), synthetic command buffers (seed 0xDE265000+4),
 all stages on the device: MC -> residual -> intra -> deblock -> SAO.
-One "step" = one pass over the GOP; all command buffers and reference pictures
-are resident in HBM before the timed region starts.  value = pictures/s over
-all ranks (weak scaling: every rank decodes its own independent GOP, no
-data-path collective).
+One "step" = one pass over --streams independent GOPs per GPU (default 3, each
+on its own decoder / HIP stream: the intra dependency chain of one GOP's I
+picture is latency-bound, so independent GOPs are kept in flight to fill the
+GPU); all command buffers and reference pictures are resident in HBM before
+the timed region starts.  value = pictures/s over all ranks (weak scaling:
+every rank decodes its own independent GOPs, no data-path collective).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -24,6 +26,10 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_b_pmc_traffic.json")
+PMC_KERNEL = {"intra": ["k_run<unsigned short>"], "mc": ["k_mc<unsigned short>"], "sao": ["k_sao<unsigned short>"],
+              "deblock_v": ["k_deblock<unsigned short, true>"], "deblock_h": ["k_deblock<unsigned short, false>"],
+              "resid": ["k_tu<unsigned short>", "k_resid_small<unsigned short, 3>", "k_resid_small<unsigned short, 2>"]}
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 CONFIG_ID = 4                  # SURVEY 8d config 4 -> seed 0xDE265000 + 4
 
@@ -50,7 +56,7 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--bit-depth", type=int, default=10)
     ap.add_argument("--gop", type=int, default=16)
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("DE265HIP_BENCH_STREAMS", "1")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("DE265HIP_BENCH_STREAMS", "3")),
                     help="independent closed GOPs decoded concurrently per GPU (one decoder/HIP stream each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm; gloo for rehearsals)")
@@ -130,8 +136,19 @@ def main():
         if dom in ("deblock_v", "deblock_h"):
             alg_total //= 2                       # SURVEY 8d counts 2P for the two passes together
         achieved = (alg_total / 1e9) / (dom_ms / 1e3) if dom_ms > 0 else 0.0
+        # HBM-side traffic of that kernel: rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) committed under
+        # profiles/ (bench.py cannot run the profiler on itself); FETCH_SIZE doubled as the guide prescribes
+        # for gfx950 (MI355X_MICROARCH.md, HBM).  Only valid for the default 4K 10-bit workload.
+        traffic = None
+        try:
+            if (W, H, BD, GOP) == (3840, 2160, 10, 16) and dom in PMC_KERNEL:
+                pk = json.load(open(PMC_FILE))["kernels"]
+                traffic = int(sum((2 * pk[k]["fetch_kb_per_launch"] + pk[k]["write_kb_per_launch"]) * 1024
+                                  for k in PMC_KERNEL[dom]))
+        except Exception:
+            traffic = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "launches": int(dom_launches), "avg_launch_us": round(1e3 * dom_ms / max(dom_launches, 1), 3),
                     "alg_bytes_per_launch": int(alg_total / max(dom_launches, 1))}
         kernels = {k: {"ms_per_step": round(v[0] / args.steps, 4), "launches_per_step": v[1] // args.steps,

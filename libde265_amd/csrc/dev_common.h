@@ -67,6 +67,7 @@ static_assert(sizeof(McTask) == 20, "McTask layout");
 // Runs are ordered so that every producer run has a smaller index (ticket).
 struct RunTask {
   uint16_t x0, y0, x1, y1;   // bounding box of the run's TUs, component samples, x1/y1 exclusive
+  uint16_t wx1, wy1;         // end of the pixel window: furthest neighbour any TU of the run may read
   uint8_t  c_idx, pad0;
   uint16_t n_tus;
   uint32_t first_tu;         // into the run-ordered TuTask array
@@ -74,8 +75,9 @@ struct RunTask {
   uint16_t n_deps, pad1;
   uint32_t res_offset;       // the run's residual blocks: one contiguous int16 range (multiple of 8 long)
   uint32_t res_len;
+  uint32_t pad2;
 };
-static_assert(sizeof(RunTask) == 32, "RunTask layout");
+static_assert(sizeof(RunTask) == 40, "RunTask layout");
 
 struct PcmTask {
   uint16_t x0, y0;

@@ -75,7 +75,7 @@ struct de265hip_picture {
   int n_l0_size[4] = { 0, 0, 0, 0 };          // TU count per size in d_l0 (sorted 32,16,8,4)
   TuTask* d_l0 = nullptr; int n_l0 = 0;       // run mode: inter residual TUs + residual-only copies of intra TUs
   int16_t* d_resid = nullptr;                 // precomputed residual blocks of intra TUs
-  int n_runs = 0, n_workers = 0; size_t sync_bytes = 0;
+  int n_runs = 0, n_workers = 0, run_box = 64, ticket_batch = 1; size_t sync_bytes = 0;
   std::vector<int> level_start;       // level_start[l] .. level_start[l+1] in d_tus
   int n_mc = 0, n_pcm = 0, n_tus = 0;
   bool any_edges = false;
@@ -357,12 +357,18 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   int64_t alg_resid = 0, alg_intra = 0;
   // runs: maximal intervals of the per-component intra TU sequence inside one CTB in which
   // every TU reads from the run so far (see k_run); independent TUs start a new run
-  struct RunBuild { int c, ctu, x0, y0, x1, y1, level; std::vector<TuTask> tus; std::vector<int> deps; };
+  struct RunBuild { int c, ctu, x0, y0, x1, y1, level, wx1, wy1; std::vector<TuTask> tus; std::vector<int> deps; };
   std::vector<RunBuild> rb;
   std::vector<int32_t> runmap[3];
   for (int c = 0; c < 3; c++) runmap[c].assign((size_t)map_w[c] * map_h[c], -1);
   int cur_run[3] = { -1, -1, -1 };
   std::vector<int> producers;
+  // dense intra (no inter PUs at all): one run per CTB and component, fewest hand-offs on the z-scan chain.
+  // sparse intra: small runs (<= 32x32) need a quarter of the LDS, so ~3x more of them are in flight.
+  // (measured: with <= 32x32 runs and 2816 workers a 4K B picture got slower, 231 -> 273 us: the longer
+  //  producer chains cost more than the extra residency buys, so every picture uses 64x64 runs for now)
+  const int run_box = 64;
+  pic->run_box = run_box;
   for (int i = 0; i < d->n_tus; i++) {
     const de265hip_tu& tu = d->tus[i];
     const int nT = 1 << tu.log2_size;
@@ -388,16 +394,22 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       t.avail = intra_availability(*d, g, tu, lvl[c], map_w[c], &level, runmap[c], producers);
       const int ctu = ((tu.x0 * sub) >> p.log2_ctb_size) + ((tu.y0 * sub) >> p.log2_ctb_size) * g.ctbs_w;
       int r = cur_run[c];
-      const bool extends = r >= 0 && rb[r].ctu == ctu && rb[r].tus.size() < 60000 &&
-                           std::find(producers.begin(), producers.end(), r) != producers.end();
+      bool extends = r >= 0 && rb[r].ctu == ctu && rb[r].tus.size() < 60000 &&
+                     std::find(producers.begin(), producers.end(), r) != producers.end();
+      if (extends && run_box < 64) {       // sparse-intra pictures: keep every run inside a run_box^2 bounding box
+        const int bw = std::max(rb[r].x1, tu.x0 + nT) - std::min(rb[r].x0, (int)tu.x0);
+        const int bh = std::max(rb[r].y1, tu.y0 + nT) - std::min(rb[r].y0, (int)tu.y0);
+        extends = bw <= run_box && bh <= run_box;
+      }
       if (!extends) {
         r = (int)rb.size();
-        rb.push_back(RunBuild{ c, ctu, tu.x0, tu.y0, tu.x0 + nT, tu.y0 + nT, 0, {}, {} });
+        rb.push_back(RunBuild{ c, ctu, tu.x0, tu.y0, tu.x0 + nT, tu.y0 + nT, 0, 0, 0, {}, {} });
         cur_run[c] = r;
       }
       RunBuild& R = rb[r];
       R.x0 = std::min(R.x0, (int)tu.x0); R.y0 = std::min(R.y0, (int)tu.y0);
       R.x1 = std::max(R.x1, tu.x0 + nT); R.y1 = std::max(R.y1, tu.y0 + nT);
+      R.wx1 = std::max(R.wx1, tu.x0 + 2 * nT); R.wy1 = std::max(R.wy1, tu.y0 + 2 * nT);    // top-right / bottom-left reach
       for (int pr : producers)
         if (pr != r && std::find(R.deps.begin(), R.deps.end(), pr) == R.deps.end()) R.deps.push_back(pr);
       R.tus.push_back(t);
@@ -438,6 +450,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       const RunBuild& R = rb[order[k]];
       RunTask& o = runs[k]; memset(&o, 0, sizeof(o));
       o.x0 = (uint16_t)R.x0; o.y0 = (uint16_t)R.y0; o.x1 = (uint16_t)R.x1; o.y1 = (uint16_t)R.y1;
+      o.wx1 = (uint16_t)std::min(R.wx1, R.x1 + 32); o.wy1 = (uint16_t)std::min(R.wy1, R.y1 + 32);
       o.c_idx = (uint8_t)R.c; o.n_tus = (uint16_t)R.tus.size();
       o.first_tu = (uint32_t)run_tus.size(); o.dep_offset = (uint32_t)run_deps.size(); o.n_deps = (uint16_t)R.deps.size();
       o.res_offset = (uint32_t)n_resid;
@@ -461,8 +474,10 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     for (auto& R : rb) width[R.level]++;
     int widest = 0; for (int wv : width) widest = std::max(widest, wv);
     const char* wenv = getenv("DE265HIP_RUN_WORKERS");
-    int cap = wenv ? atoi(wenv) : 1024;
+    int cap = wenv ? atoi(wenv) : (run_box == 64 ? 1024 : 2816);      // LDS-limited residency: 4 resp. 11 per CU
     pic->n_workers = std::min(pic->n_runs, std::max(64, std::min(cap, widest + widest / 4)));
+    const char* benv = getenv("DE265HIP_TICKET_BATCH");
+    pic->ticket_batch = benv ? std::max(1, atoi(benv)) : 1;   // measured: drawing 4/8 tickets per atomic costs 46 % / 100 % on a 4K B picture (serialises dependants)
   }
   // level-0 launch of run mode: inter TUs with residual, then the residual-only intra TUs
   std::vector<TuTask> l0(sorted.begin() + pic->level_start[0], sorted.begin() + pic->level_start[1]);
@@ -671,8 +686,12 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
     if (pic->n_runs > 0) {
       KTimer t(dec, DE265HIP_K_INTRA, 1);
       (void)hipMemsetAsync(pic->d_sync, 0, pic->sync_bytes, st);
-      hipLaunchKernelGGL(k_run<PX>, dim3(pic->n_workers), dim3(64), 0, st, P, d0, d1, d2, pic->d_runs, pic->d_deps,
-                         pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->n_runs, dec->dbg);
+      if (pic->run_box == 64)
+        hipLaunchKernelGGL((k_run<PX, 64>), dim3(pic->n_workers), dim3(64), 0, st, P, d0, d1, d2, pic->d_runs, pic->d_deps,
+                           pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->n_runs, pic->ticket_batch, dec->dbg);
+      else
+        hipLaunchKernelGGL((k_run<PX, 32>), dim3(pic->n_workers), dim3(64), 0, st, P, d0, d1, d2, pic->d_runs, pic->d_deps,
+                           pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->n_runs, pic->ticket_batch, dec->dbg);
     }
   } else {
     if (nlev > 0 && pic->level_start[1] > pic->level_start[0]) {

@@ -459,8 +459,11 @@ void k_tu(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const TuTask* __re
 // writes every finished TU back and publishes its flag (agent-scope release).
 // Deadlock-free for any dispatch order: a run only waits on smaller tickets, and a
 // ticket is only taken by a wavefront that is already running.  Spins are bounded.
-#define RUN_TILE_H 97                 // 1 + 64 + 32 rows
-#define RUN_TILE_P 104                // 7 (alignment slack) + 1 + 64 + 32 columns; 16-byte aligned rows
+// Pixel window of a run with a bbox of at most B x B samples: 1 + B + 32 rows, and
+// 7 (alignment slack) + 1 + B + 32 columns rounded to 8 (16-byte aligned rows).
+#define RUN_TILE_H_OF(B) ((B) + 33)
+#define RUN_TILE_P_OF(B) ((((B) + 40) + 7) & ~7)
+#define RUN_TILE_P_MAX RUN_TILE_P_OF(64)
 #define RUN_SPIN_LIMIT (1 << 19)      // x ~2 us per poll: about 1 s
 
 // 8 consecutive samples <-> 8 x uint16 in LDS
@@ -510,6 +513,7 @@ __device__ __forceinline__ int wave_sum_dpp(int v)
 // mode asks for it (:816-889), predict (:903-1069), add the precomputed residual and write the
 // reconstructed samples into the window.  t is wave-uniform and in window coordinates.
 // Three dependent LDS round trips per TU (gather, [smooth], predict) instead of ten.
+template <int RUN_TILE_P>
 __device__ __forceinline__ void run_intra_tu(const PicDev& P, const TuTask& t, uint16_t* tile, RunShared& S,
                                              int lane, const int16_t* res, int bd, Stamper& st)
 {
@@ -629,25 +633,34 @@ __device__ __forceinline__ void run_intra_tu(const PicDev& P, const TuTask& t, u
   LDS_SYNC();
 }
 
-template <typename PX>
+template <typename PX, int BOX>
 __global__ __launch_bounds__(64)
 void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __restrict__ runs,
            const uint32_t* __restrict__ deps, uint32_t* sync, uint32_t* err, const TuTask* __restrict__ tasks,
-           const int16_t* __restrict__ resid, int n_runs, int dbg)
+           const int16_t* __restrict__ resid, int n_runs, int batch, int dbg)
 {
+  constexpr int RUN_TILE_H = RUN_TILE_H_OF(BOX), RUN_TILE_P = RUN_TILE_P_OF(BOX);
   __shared__ RunShared S;
   __shared__ __attribute__((aligned(16))) uint16_t tile[RUN_TILE_H * RUN_TILE_P];
-  __shared__ __attribute__((aligned(16))) int16_t s_res[64 * 64];
+  __shared__ __attribute__((aligned(16))) int16_t s_res[BOX * BOX];
   __shared__ TuTask s_tasks[64];
   __shared__ uint32_t s_ticket;
   const int lane = threadIdx.x;
   // persistent worker: the grid is only as wide as the picture's widest dependency level
   // (waiting wavefronts would just occupy LDS), every worker pulls tickets until none are left
+  // tickets are drawn `batch` at a time (one atomic per batch) and processed in increasing order,
+  // which keeps the no-deadlock argument: the smallest unfinished ticket is always owned by a
+  // running wavefront that is not waiting on anything larger.
+  uint32_t next_ticket = 0, batch_end = 0;
   for (;;) {
-  if (lane == 0) s_ticket = atomicAdd(&sync[0], 1u);
-  __syncthreads();
-  const uint32_t ticket = __builtin_amdgcn_readfirstlane(s_ticket);    // wave-uniform: scalar loads/branches below
-  __syncthreads();
+  if (next_ticket == batch_end) {
+    if (lane == 0) s_ticket = atomicAdd(&sync[0], (uint32_t)batch);
+    __syncthreads();
+    next_ticket = __builtin_amdgcn_readfirstlane(s_ticket);
+    batch_end = next_ticket + batch;
+    __syncthreads();
+  }
+  const uint32_t ticket = next_ticket++;                               // wave-uniform: scalar loads/branches below
   if (ticket >= (uint32_t)n_runs) break;
   const RunTask run = runs[ticket];
   Stamper st{ (dbg & 16) ? err + 8 : nullptr, clock64(), lane };
@@ -678,10 +691,10 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   const int stride = pr.stride;
   const int cw = c ? P.width >> 1 : P.width, ch = c ? P.height >> 1 : P.height;
   const int bd = c ? P.bd_chroma : P.bd_luma;
-  // pixel window: bbox + 1 left/top + 32 right/bottom (everything a TU of the run can read),
+  // pixel window: bbox + 1 left/top + the top-right / bottom-left reach of its TUs (host-computed),
   // fetched in aligned 8-sample chunks, several loads in flight per lane
   const int wx0 = (int)run.x0 - 1, wy0 = (int)run.y0 - 1;
-  const int wx1 = min((int)run.x1 + 32, cw), wy1 = min((int)run.y1 + 32, ch);
+  const int wx1 = min((int)run.wx1, cw), wy1 = min((int)run.wy1, ch);
   const int ax0 = wx0 & ~7;                                  // -8 when the run touches the left picture edge
   const int nchx = (wx1 - ax0 + 7) >> 3, nrows = wy1 - wy0;
   const int nchunks = nchx * nrows;
@@ -725,7 +738,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
       }
       t.x0 = (uint16_t)((int)t.x0 - ax0); t.y0 = (uint16_t)((int)t.y0 - wy0);      // window coordinates
       st.mark(0);
-      run_intra_tu(P, t, tile, S, lane, (t.flags & DE265HIP_TU_CBF) ? &s_res[t.resid_offset - res_base] : nullptr, bd, st);
+      run_intra_tu<RUN_TILE_P>(P, t, tile, S, lane, (t.flags & DE265HIP_TU_CBF) ? &s_res[t.resid_offset - res_base] : nullptr, bd, st);
       st.mark(3);
       if (st.buf && lane == 0) atomicAdd(&st.buf[7], 1u);
     }
@@ -777,10 +790,10 @@ template __global__ void k_tu<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, con
                                        const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
 template __global__ void k_tu<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int,
                                         const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
-template __global__ void k_run<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*,
-                                        const TuTask*, const int16_t*, int, int);
-template __global__ void k_run<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*,
-                                         const TuTask*, const int16_t*, int, int);
+template __global__ void k_run<uint8_t, 64>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, int, int, int);
+template __global__ void k_run<uint16_t, 64>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, int, int, int);
+template __global__ void k_run<uint8_t, 32>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, int, int, int);
+template __global__ void k_run<uint16_t, 32>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, int, int, int);
 template __global__ void k_fn_residual<uint8_t>(int, int, int, uint8_t*, int, const int32_t*, const int16_t*);
 template __global__ void k_fn_residual<uint16_t>(int, int, int, uint16_t*, int, const int32_t*, const int16_t*);
 
