@@ -633,6 +633,106 @@ __device__ __forceinline__ void run_intra_tu(const PicDev& P, const TuTask& t, u
   LDS_SYNC();
 }
 
+// ---- register-resident fast path for 4x4 and 8x8 intra TUs (about 95 % of all TUs) ----
+// The 4nT+1 <= 33 neighbours live one per lane in a VGPR: smoothing is two DPP wave shifts,
+// the DC sum a DPP reduction, and the predictors fetch their operands with ds_bpermute (the LDS
+// crossbar, no LDS memory, no write/wait).  Two LDS latencies on the chain per TU: the gather
+// from the pixel window and the bpermute; the write into the window needs no wait (LDS executes
+// a wavefront's operations in order).
+#define WAVE_BARRIER_ONLY() asm volatile("" ::: "memory")
+
+template <typename PX> __device__ __forceinline__ void store4_packed(PX* g, int v0123_lo, int v0123_hi);
+template <> __device__ __forceinline__ void store4_packed<uint16_t>(uint16_t* g, int lo, int hi)
+{ store4_from_u16(g, make_uint2((uint32_t)lo, (uint32_t)hi)); }
+template <> __device__ __forceinline__ void store4_packed<uint8_t>(uint8_t* g, int lo, int hi)
+{ store4_from_u16(g, make_uint2((uint32_t)lo, (uint32_t)hi)); }
+
+template <int LOG2, int RUN_TILE_P, typename PX>
+__device__ __forceinline__ void run_intra_small(const PicDev& P, const TuTask& t, uint16_t* tile, int lane,
+                                                const int16_t* res, int bd, PX* gdst, int gstride)
+{
+  constexpr int nT = 1 << LOG2, nS = nT * nT, NB = 4 * nT + 1, C = 2 * nT;       // C: lane of border[0]
+  const int xB = t.x0, yB = t.y0, cIdx = t.c_idx;
+  const uint64_t avail = t.avail;
+  const int maxv = (1 << bd) - 1;
+  const int rs = (res != nullptr && lane < nS) ? (int)res[lane] : 0;              // independent of the chain: issued first
+
+  // neighbour p = lane (border index i = p - 2nT), with substitution (intrapred.cc:395-431)
+  int bv = 1 << (bd - 1);
+  if (avail != 0) {
+    const int p = min(lane, NB - 1), i = p - C;
+    int src = i;
+    if (avail != ((2ull << nT) - 1ull)) {             // not every unit available: nearest available one before
+      constexpr int cornerUnit = nT >> 1;
+      const int u = (i < 0) ? (p >> 2) : (i == 0 ? cornerUnit : cornerUnit + 1 + ((i - 1) >> 2));
+      if (!((avail >> u) & 1)) {
+        const uint64_t below = avail & ((2ull << u) - 1ull);
+        if (below) {
+          const int su = 63 - __clzll((long long)below);
+          src = (su < cornerUnit) ? (-C + 4 * su + 3) : (su == cornerUnit ? 0 : 4 * (su - cornerUnit));
+        } else {
+          const int su = __ffsll((long long)avail) - 1;
+          src = (su < cornerUnit) ? (-C + 4 * su) : (su == cornerUnit ? 0 : 4 * (su - cornerUnit - 1) + 1);
+        }
+      }
+    }
+    const int sx = src <= 0 ? xB - 1 : xB + src - 1;
+    const int sy = src < 0 ? yB - src - 1 : yB - 1;
+    bv = tile[sx + sy * RUN_TILE_P];
+  }
+
+  const int mode = t.intra_mode >= 35 ? 1 : t.intra_mode;
+  if (LOG2 == 3 && cIdx == 0 && mode != 1 && min(abs(mode - 26), abs(mode - 10)) > 7) {
+    // [1 2 1] smoothing (intrapred.cc:816-889); both ends keep their value
+    const int prev = __builtin_amdgcn_update_dpp(bv, bv, 0x138, 0xf, 0xf, false);   // wave_shr:1 -> lane-1
+    const int next = __builtin_amdgcn_update_dpp(bv, bv, 0x130, 0xf, 0xf, false);   // wave_shl:1 -> lane+1
+    const int f = (prev + 2 * bv + next + 2) >> 2;
+    bv = (lane == 0 || lane >= NB - 1) ? bv : f;
+  }
+#define BORD(idx) __builtin_amdgcn_ds_bpermute(((idx) + C) << 2, bv)
+  const int y = (lane >> LOG2) & (nT - 1), x = lane & (nT - 1);
+  int pv;
+  if (mode == 0) {
+    const int l = BORD(-1 - y), tp = BORD(1 + x);
+    const int tr = __builtin_amdgcn_readlane(bv, C + 1 + nT), bl = __builtin_amdgcn_readlane(bv, C - 1 - nT);
+    pv = ((nT - 1 - x) * l + (x + 1) * tr + (nT - 1 - y) * tp + (y + 1) * bl + nT) >> (LOG2 + 1);
+  } else if (mode == 1) {
+    const int tp = BORD(1 + x), l = BORD(-1 - y);
+    const int v = (lane >= nT && lane <= 3 * nT && lane != C) ? bv : 0;
+    const int dc = (wave_sum_dpp(v) + nT) >> (LOG2 + 1);
+    const int corner = (__builtin_amdgcn_readlane(bv, C - 1) + 2 * dc + __builtin_amdgcn_readlane(bv, C + 1) + 2) >> 2;
+    pv = dc;
+    if (cIdx == 0) pv = (x | y) == 0 ? corner : (y == 0 ? (tp + 3 * dc + 2) >> 2 : (x == 0 ? (l + 3 * dc + 2) >> 2 : dc));
+  } else {
+    const int angle = c_intra_angle[mode];
+    const bool vert = mode >= 18;
+    const int inv = angle < 0 ? (int)c_inv_angle[mode - 11] : 0;
+    const int a = vert ? y : x, b = vert ? x : y;
+    const int iIdx = ((a + 1) * angle) >> 5, iFact = ((a + 1) * angle) & 31;
+    const int i0 = b + iIdx + 1, i1 = i0 + 1;
+    const int k0 = i0 >= 0 ? i0 : -((i0 * inv + 128) >> 8);
+    const int k1 = i1 >= 0 ? i1 : -((i1 * inv + 128) >> 8);
+    const int r0 = BORD(vert ? k0 : -k0), r1 = BORD(vert ? min(k1, C) : -min(k1, C));
+    const int ev = BORD(vert ? -1 - y : 1 + x);
+    pv = ((32 - iFact) * r0 + iFact * r1 + 16) >> 5;
+    if (cIdx == 0 && (mode == 26 || mode == 10)) {
+      const int b0 = __builtin_amdgcn_readlane(bv, C);
+      const int b1 = vert ? __builtin_amdgcn_readlane(bv, C + 1) : __builtin_amdgcn_readlane(bv, C - 1);
+      const int e = clip3(0, maxv, b1 + ((ev - b0) >> 1));
+      pv = (vert ? x == 0 : y == 0) ? e : pv;
+    }
+  }
+#undef BORD
+  const int outv = clip3(0, maxv, pv + rs);
+  if (lane < nS) tile[xB + x + (yB + y) * RUN_TILE_P] = (uint16_t)outv;
+  // write-back straight from the registers: four adjacent lanes are packed with two DPP row shifts and
+  // every fourth lane issues one 8-byte (4-byte for 8-bit pictures) write-through store
+  const int w01 = outv | (__builtin_amdgcn_update_dpp(0, outv, 0x101, 0xf, 0xf, true) << 16);   // row_shl:1
+  const int w23 = __builtin_amdgcn_update_dpp(0, w01, 0x102, 0xf, 0xf, true);                   // row_shl:2
+  if (lane < nS && (x & 3) == 0) store4_packed<PX>(gdst + x + y * gstride, w01, w23);
+  WAVE_BARRIER_ONLY();
+}
+
 template <typename PX, int BOX>
 __global__ __launch_bounds__(64)
 void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __restrict__ runs,
@@ -643,7 +743,6 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   __shared__ RunShared S;
   __shared__ __attribute__((aligned(16))) uint16_t tile[RUN_TILE_H * RUN_TILE_P];
   __shared__ __attribute__((aligned(16))) int16_t s_res[BOX * BOX];
-  __shared__ TuTask s_tasks[64];
   __shared__ uint32_t s_ticket;
   const int lane = threadIdx.x;
   // persistent worker: the grid is only as wide as the picture's widest dependency level
@@ -721,42 +820,35 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   }
   LDS_SYNC();
 
-  // ---- the dependency chain: border -> (filter) -> predict -> + residual, all inside LDS
-  if (!(dbg & 4))
-  for (int base = 0; base < run.n_tus; base += 64) {
-    const int nb = min(64, (int)run.n_tus - base);
-    if (lane < nb) s_tasks[lane] = tasks[run.first_tu + base + lane];
-    LDS_SYNC();
-    for (int k = 0; k < nb; k++) {
-      // wave-uniform copy of the task (SGPRs): every branch and table index below is scalar
-      TuTask t;
-      {
-        const uint32_t* w = reinterpret_cast<const uint32_t*>(&s_tasks[k]);
-        uint32_t* o = reinterpret_cast<uint32_t*>(&t);
-#pragma unroll
-        for (int q = 0; q < 8; q++) o[q] = __builtin_amdgcn_readfirstlane(w[q]);
-      }
-      t.x0 = (uint16_t)((int)t.x0 - ax0); t.y0 = (uint16_t)((int)t.y0 - wy0);      // window coordinates
+  // ---- the dependency chain: gather -> (smooth) -> predict -> + residual, all inside LDS / registers.
+  // Tasks come through the scalar cache (uniform address), the next one is requested a TU ahead.
+  if (!(dbg & 4)) {
+    const TuTask* tp = tasks + run.first_tu;
+    TuTask cur = tp[0];
+    for (int k = 0; k < (int)run.n_tus; k++) {
+      const TuTask nxt = tp[min(k + 1, (int)run.n_tus - 1)];
+      TuTask t = cur;
+      const int gx0 = t.x0, gy0 = t.y0;
+      t.x0 = (uint16_t)(gx0 - ax0); t.y0 = (uint16_t)(gy0 - wy0);      // window coordinates
       st.mark(0);
-      run_intra_tu<RUN_TILE_P>(P, t, tile, S, lane, (t.flags & DE265HIP_TU_CBF) ? &s_res[t.resid_offset - res_base] : nullptr, bd, st);
+      const int16_t* rp = (t.flags & DE265HIP_TU_CBF) ? &s_res[t.resid_offset - res_base] : nullptr;
+      PX* gdst = plane + gx0 + gy0 * stride;
+      if (t.log2_size == 2 && !(dbg & 512)) run_intra_small<2, RUN_TILE_P, PX>(P, t, tile, lane, rp, bd, gdst, stride);
+      else if (t.log2_size == 3 && !(dbg & 512)) run_intra_small<3, RUN_TILE_P, PX>(P, t, tile, lane, rp, bd, gdst, stride);
+      else {
+        run_intra_tu<RUN_TILE_P>(P, t, tile, S, lane, rp, bd, st);
+        // write the finished TU back, 4 samples per lane (only the run's own samples ever leave the window)
+        const int log2 = t.log2_size, nT = 1 << log2, l4 = log2 - 2;
+        for (int s = lane; s < (nT * nT) >> 2; s += 64) {
+          const int y = s >> l4, x = (s & ((1 << l4) - 1)) << 2;
+          const uint2 v = *reinterpret_cast<const uint2*>(&tile[(t.y0 + y) * RUN_TILE_P + t.x0 + x]);
+          store4_from_u16(gdst + x + y * stride, v);
+        }
+      }
       st.mark(3);
       if (st.buf && lane == 0) atomicAdd(&st.buf[7], 1u);
+      cur = nxt;
     }
-    // write the finished TUs of this batch back, 4 samples per lane; stores are independent of the
-    // chain, so they are issued back to back (only the run's own samples ever leave the window)
-    for (int k = 0; k < nb; k++) {
-      const uint32_t* w = reinterpret_cast<const uint32_t*>(&s_tasks[k]);
-      const uint32_t w0 = __builtin_amdgcn_readfirstlane(w[0]), w1 = __builtin_amdgcn_readfirstlane(w[1]);
-      const int gx0 = w0 & 0xFFFF, gy0 = w0 >> 16, log2 = w1 & 0xFF, nT = 1 << log2, l4 = log2 - 2;
-      const int tx = gx0 - ax0, ty = gy0 - wy0;
-      for (int s = lane; s < (nT * nT) >> 2; s += 64) {
-        int y = s >> l4, x = (s & ((1 << l4) - 1)) << 2;
-        uint2 v = *reinterpret_cast<const uint2*>(&tile[(ty + y) * RUN_TILE_P + tx + x]);
-        store4_from_u16(plane + (gx0 + x) + (gy0 + y) * stride, v);
-      }
-    }
-    st.mark(6);
-    LDS_SYNC();
   }
 
   // publish: every handed-off byte was stored write-through (sc1); drain them, then raise the flag.
