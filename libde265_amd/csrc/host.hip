@@ -567,17 +567,21 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   const size_t o_ctb = L.add((size_t)d->n_ctbs * sizeof(de265hip_ctb_info));
   const size_t o_tile = L.add((size_t)d->n_ctbs * 2);
   const size_t o_flags = L.add(nblk), o_qp = L.add(nblk), o_mot = L.add(nblk * sizeof(de265hip_motion));
-  const size_t o_bs = L.add(nblk);
   const size_t o_runs = L.add(runs.size() * sizeof(RunTask)), o_rdeps = L.add(run_deps.size() * 4);
   const size_t o_rtus = L.add(run_tus.size() * sizeof(TuTask));
-  const size_t o_l0 = L.add(l0.size() * sizeof(TuTask)), o_resid = L.add(n_resid * 2 + 64);
+  const size_t o_l0 = L.add(l0.size() * sizeof(TuTask));
+  const size_t upload_bytes = L.total;                 // everything above is written by the host
+  // device-only scratch: boundary strengths, residual blocks, run flags (no staging, no upload)
+  const size_t o_bs = L.add(nblk);
+  const size_t o_resid = L.add(n_resid * 2 + 64);
   pic->sync_bytes = (2 + runs.size()) * 4;
   const size_t o_sync = L.add(pic->sync_bytes);
-  std::vector<uint8_t> host(L.total, 0);
+  std::vector<uint8_t> host(upload_bytes);
   auto put = [&](size_t off, const void* src, size_t bytes) { if (bytes && src) memcpy(host.data() + off, src, bytes); };
   put(o_tus, sorted.data(), sorted.size() * sizeof(TuTask));
   put(o_cval, d->coeff_val, (size_t)d->n_coeffs * 2); put(o_cpos, d->coeff_pos, (size_t)d->n_coeffs * 2);
   if (p.scaling_list_enable_flag) put(o_scal, d->scaling_factors, DE265HIP_SCALING_BLOB_BYTES);
+  else memset(host.data() + o_scal, 0, DE265HIP_SCALING_BLOB_BYTES);
   put(o_mc, mcs.data(), mcs.size() * sizeof(McTask));
   put(o_pcm, pcms.data(), pcms.size() * sizeof(PcmTask)); put(o_pcms, d->pcm_samples, (size_t)d->n_pcm_samples * 2);
   put(o_sl, d->slices, (size_t)d->n_slices * sizeof(de265hip_slice_params));
@@ -592,7 +596,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
 
   if (hipMalloc(&pic->arena, L.total) != hipSuccess) { delete pic; return DE265HIP_ERROR_OUT_OF_MEMORY; }
   pic->arena_bytes = L.total;
-  if (hipMemcpy(pic->arena, host.data(), L.total, hipMemcpyHostToDevice) != hipSuccess) {
+  if (hipMemcpy(pic->arena, host.data(), upload_bytes, hipMemcpyHostToDevice) != hipSuccess) {
     (void)hipFree(pic->arena); delete pic; return DE265HIP_ERROR_DECODING;
   }
   uint8_t* base = (uint8_t*)pic->arena;
