@@ -79,6 +79,18 @@ struct RunTask {
 };
 static_assert(sizeof(RunTask) == 40, "RunTask layout");
 
+// Per-CTB SAO record, fully resolved on the host (slice flags applied, slice/tile permissions of the
+// 3x3 CTB neighbourhood evaluated): one 24-byte load per lane instead of a chain of dependent loads.
+struct __attribute__((aligned(8))) SaoCtb {
+  uint8_t type[3];          // 0 off, 1 band, 2 edge (0 when the slice's sao flag for that component is off)
+  uint8_t eo[3];
+  uint8_t band[3];
+  int8_t  off[3][4];
+  uint8_t pad;
+  uint16_t perm;            // bit (dy+1)*3+(dx+1): samples of this CTB may use neighbours in CTB (x+dx, y+dy)
+};
+static_assert(sizeof(SaoCtb) == 24, "SaoCtb layout");
+
 struct PcmTask {
   uint16_t x0, y0;
   uint32_t log2_cb_size;

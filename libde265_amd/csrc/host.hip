@@ -70,6 +70,7 @@ struct de265hip_picture {
   uint16_t* d_tile_id = nullptr;
   uint8_t* d_flags = nullptr; int8_t* d_qp = nullptr; de265hip_motion* d_motion = nullptr;
   uint8_t* d_bs = nullptr;
+  SaoCtb* d_sao = nullptr;
   RunTask* d_runs = nullptr; uint32_t* d_deps = nullptr; uint32_t* d_sync = nullptr;
   TuTask* d_run_tus = nullptr;
   int n_l0_size[4] = { 0, 0, 0, 0 };          // TU count per size in d_l0 (sorted 32,16,8,4)
@@ -430,10 +431,14 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   pic->level_start.assign(max_level + 2, 0);
   for (int l : levels) pic->level_start[l + 1]++;
   for (int l = 0; l <= max_level; l++) pic->level_start[l + 1] += pic->level_start[l];
-  std::vector<TuTask> sorted(tasks.size());
-  { std::vector<int> cursor(pic->level_start.begin(), pic->level_start.end() - 1);
-    for (size_t i = 0; i < tasks.size(); i++) sorted[cursor[levels[i]]++] = tasks[i]; }
-  pic->n_tus = (int)sorted.size();
+  // the level-sorted task array is only needed by the level-launch schedule (DE265HIP_INTRA_MODE=levels)
+  std::vector<TuTask> sorted;
+  if (dec->intra_levels) {
+    sorted.resize(tasks.size());
+    std::vector<int> cursor(pic->level_start.begin(), pic->level_start.end() - 1);
+    for (size_t i = 0; i < tasks.size(); i++) sorted[cursor[levels[i]]++] = tasks[i];
+  }
+  pic->n_tus = (int)tasks.size();
 
   // ---- runs in dependency (ticket) order: producers first
   std::vector<RunTask> runs; std::vector<uint32_t> run_deps; std::vector<TuTask> run_tus, resid_only;
@@ -480,13 +485,18 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     pic->ticket_batch = benv ? std::max(1, atoi(benv)) : 1;   // measured: drawing 4/8 tickets per atomic costs 46 % / 100 % on a 4K B picture (serialises dependants)
   }
   // level-0 launch of run mode: inter TUs with residual, then the residual-only intra TUs
-  std::vector<TuTask> l0(sorted.begin() + pic->level_start[0], sorted.begin() + pic->level_start[1]);
-  l0.insert(l0.end(), resid_only.begin(), resid_only.end());
-  // largest first: [32x32 | 16x16 | 8x8 | 4x4]; the two small sizes get their own packed kernel
-  std::stable_sort(l0.begin(), l0.end(), [](const TuTask& a, const TuTask& b) { return a.log2_size > b.log2_size; });
+  // largest first: [32x32 | 16x16 | 8x8 | 4x4] (counting sort); the two small sizes get their own packed kernel
+  std::vector<TuTask> l0;
+  {
+    for (int k = 0; k < 4; k++) pic->n_l0_size[k] = 0;
+    for (size_t i = 0; i < tasks.size(); i++) if (levels[i] == 0) pic->n_l0_size[tasks[i].log2_size - 2]++;
+    for (const TuTask& tt : resid_only) pic->n_l0_size[tt.log2_size - 2]++;
+    size_t cur[4]; cur[3] = 0; cur[2] = pic->n_l0_size[3]; cur[1] = cur[2] + pic->n_l0_size[2]; cur[0] = cur[1] + pic->n_l0_size[1];
+    l0.resize(cur[0] + pic->n_l0_size[0]);
+    for (size_t i = 0; i < tasks.size(); i++) if (levels[i] == 0) l0[cur[tasks[i].log2_size - 2]++] = tasks[i];
+    for (const TuTask& tt : resid_only) l0[cur[tt.log2_size - 2]++] = tt;
+  }
   pic->n_l0 = (int)l0.size();
-  for (int k = 0; k < 4; k++) pic->n_l0_size[k] = 0;
-  for (const TuTask& tt : l0) pic->n_l0_size[tt.log2_size - 2]++;
 
   // ---- MC tasks: resolve references, bi->uni shortcut, split into <=16x16 tiles
   std::vector<McTask> mcs;
@@ -556,6 +566,41 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     P.has_exempt = ((d->blk_flags[i] & DE265HIP_BLK_BYPASS) ||
                     ((d->blk_flags[i] & DE265HIP_BLK_PCM) && p.pcm_loop_filter_disable_flag)) ? 1 : 0;
 
+  // ---- per-CTB SAO records: slice flags applied, slice / tile permissions of the 3x3 neighbourhood
+  // (sao.cc:127-163) evaluated once here instead of per sample on the device
+  std::vector<SaoCtb> saos((size_t)d->n_ctbs);
+  for (int cy = 0; cy < g.ctbs_h; cy++)
+    for (int cx = 0; cx < g.ctbs_w; cx++) {
+      const int a = cx + cy * g.ctbs_w;
+      const de265hip_ctb_info& ci = d->ctbs[a];
+      const de265hip_slice_params& sh = d->slices[ci.slice_idx];
+      SaoCtb& o = saos[a]; memset(&o, 0, sizeof(o));
+      for (int c = 0; c < 3; c++) {
+        const bool on = c == 0 ? sh.slice_sao_luma_flag != 0 : sh.slice_sao_chroma_flag != 0;
+        o.type[c] = on ? (ci.sao_type_idx >> (2 * c)) & 3 : 0;
+        o.eo[c] = (ci.sao_eo_class >> (2 * c)) & 3;
+        o.band[c] = ci.sao_band_position[c];
+        for (int k = 0; k < 4; k++) o.off[c][k] = ci.sao_offset_val[c][k];
+      }
+      unsigned perm = 0x10;
+      for (int dy = -1; dy <= 1; dy++)
+        for (int dx = -1; dx <= 1; dx++) {
+          if (!dx && !dy) continue;
+          const int nx = cx + dx, ny = cy + dy;
+          bool ok = nx >= 0 && ny >= 0 && nx < g.ctbs_w && ny < g.ctbs_h;
+          if (ok) {
+            const int nb = nx + ny * g.ctbs_w;
+            const de265hip_ctb_info& ni = d->ctbs[nb];
+            if (ni.slice_addr_rs < ci.slice_addr_rs && !sh.slice_loop_filter_across_slices_enabled_flag) ok = false;
+            if (ni.slice_addr_rs > ci.slice_addr_rs &&
+                !d->slices[ni.slice_idx].slice_loop_filter_across_slices_enabled_flag) ok = false;
+            if (!p.loop_filter_across_tiles_enabled_flag && g.tile_id[nb] != g.tile_id[a]) ok = false;
+          }
+          if (ok) perm |= 1u << ((dy + 1) * 3 + dx + 1);
+        }
+      o.perm = (uint16_t)perm;
+    }
+
   // ---- one arena, one upload
   ArenaLayout L;
   const size_t o_tus = L.add(sorted.size() * sizeof(TuTask));
@@ -566,6 +611,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   const size_t o_sl = L.add((size_t)d->n_slices * sizeof(de265hip_slice_params));
   const size_t o_ctb = L.add((size_t)d->n_ctbs * sizeof(de265hip_ctb_info));
   const size_t o_tile = L.add((size_t)d->n_ctbs * 2);
+  const size_t o_sao = L.add((size_t)d->n_ctbs * sizeof(SaoCtb));
   const size_t o_flags = L.add(nblk), o_qp = L.add(nblk), o_mot = L.add(nblk * sizeof(de265hip_motion));
   const size_t o_runs = L.add(runs.size() * sizeof(RunTask)), o_rdeps = L.add(run_deps.size() * 4);
   const size_t o_rtus = L.add(run_tus.size() * sizeof(TuTask));
@@ -587,6 +633,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   put(o_sl, d->slices, (size_t)d->n_slices * sizeof(de265hip_slice_params));
   put(o_ctb, d->ctbs, (size_t)d->n_ctbs * sizeof(de265hip_ctb_info));
   put(o_tile, g.tile_id.data(), (size_t)d->n_ctbs * 2);
+  put(o_sao, saos.data(), saos.size() * sizeof(SaoCtb));
   put(o_runs, runs.data(), runs.size() * sizeof(RunTask)); put(o_rdeps, run_deps.data(), run_deps.size() * 4);
   put(o_rtus, run_tus.data(), run_tus.size() * sizeof(TuTask));
   put(o_l0, l0.data(), l0.size() * sizeof(TuTask));
@@ -608,6 +655,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   pic->d_slices = (de265hip_slice_params*)(base + o_sl);
   pic->d_ctbs = (de265hip_ctb_info*)(base + o_ctb);
   pic->d_tile_id = (uint16_t*)(base + o_tile);
+  pic->d_sao = (SaoCtb*)(base + o_sao);
   pic->d_flags = base + o_flags; pic->d_qp = (int8_t*)(base + o_qp);
   pic->d_motion = (de265hip_motion*)(base + o_mot);
   pic->d_bs = base + o_bs;
@@ -730,10 +778,10 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
   }
   if (last_stage >= DE265HIP_STAGE_FINAL && !pic->params.disable_sao && pic->params.sample_adaptive_offset_enabled_flag) {
     Slot& sp = dec->spare;
-    SaoMeta M{ pic->d_flags, pic->d_ctbs, pic->d_slices, pic->d_tile_id };
+    SaoMeta M{ pic->d_flags, pic->d_sao };
     {
       KTimer t(dec, DE265HIP_K_SAO, 1);
-      hipLaunchKernelGGL(k_sao<PX>, dim3((P.width / 8 + 4 * 62 - 1) / (4 * 62), (P.height + 7) / 8, 3), dim3(256), 0, st, P, d0, d1, d2,
+      hipLaunchKernelGGL(k_sao<PX>, dim3((P.width / 8 + 4 * 62 - 1) / (4 * 62), (P.height + SAO_ROWS - 1) / SAO_ROWS, 3), dim3(256), 0, st, P, d0, d1, d2,
                          sp.pl[0], sp.pl[1], sp.pl[2], M);
     }
     for (int c = 0; c < 3; c++) std::swap(dst.pl[c], sp.pl[c]);      // output picture now lives in the slot

@@ -271,7 +271,6 @@ template __global__ void k_deblock<uint16_t, false>(PicDev, PlaneRef, PlaneRef, 
 // ---------------------------------------------------------------- SAO
 // Out of place: src = deblocked picture, dst = output picture (every sample is
 // written, so dst needs no initialisation).  One lane per 8 samples of a row.
-#define SAO_ROWS 8                      // rows per lane: never crosses a CTB (chroma CTB height >= 8)
 #define SAO_LANES 62                    // output lanes per wavefront; lanes 0 and 63 are halo lanes
 
 template <typename PX> __device__ __forceinline__ void load8i(const PX* p, int v[8]);
@@ -326,6 +325,10 @@ void k_sao(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, PlaneRe
   PX* dst = (PX*)dp.ptr;
   const int sstride = sp.stride, dstride = dp.stride;
   const bool inpic = x0 >= 0 && x0 < width;
+  const int ctbshift = P.log2_ctb - cs;
+  const int ctbX = max(x0, 0) >> ctbshift, ctbY = y0 >> ctbshift;
+  // the CTB record is requested together with the pixels (one latency, not two)
+  const SaoCtb sc = M.sao[min(ctbX, P.ctbs_w - 1) + ctbY * P.ctbs_w];
 
   int v[SAO_ROWS + 2][8];
 #pragma unroll
@@ -351,15 +354,9 @@ void k_sao(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, PlaneRe
     return;
   }
 
-  const int ctbshift = P.log2_ctb - cs;
-  const int ctbX = x0 >> ctbshift, ctbY = y0 >> ctbshift;
-  const int ctbAddr = ctbX + ctbY * P.ctbs_w;
-  const de265hip_ctb_info ci = M.ctbs[ctbAddr];
-  const de265hip_slice_params* sh = &M.slices[ci.slice_idx];
   const int bd = comp ? P.bd_chroma : P.bd_luma;
   const int maxv = (1 << bd) - 1;
-  int type = (ci.sao_type_idx >> (2 * comp)) & 3;
-  if (comp == 0 ? !sh->slice_sao_luma_flag : !sh->slice_sao_chroma_flag) type = 0;
+  int type = sc.type[comp];
   const int nrows = min(SAO_ROWS, height - y0);
 
   if (type == 0) {                                            // plain copy of the deblocked samples
@@ -371,14 +368,14 @@ void k_sao(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, PlaneRe
 
   int o4[4];
 #pragma unroll
-  for (int k = 0; k < 4; k++) o4[k] = ci.sao_offset_val[comp][k];
+  for (int k = 0; k < 4; k++) o4[k] = sc.off[comp][k];
   if (P.dbg & 64) type = 1;                                   // ablation: band offset everywhere
 
   // pcm / transquant-bypass exemptions of the 4x4 units under the strip (only when the picture has any)
   // luma: 2 units x 2 unit rows; chroma: 4 units x 4 unit rows; bit (unit_row*4 + unit)
   unsigned exm = 0;
   if (P.has_exempt) {
-    const int urows = cs ? 4 : 2, ucols = cs ? 4 : 2;
+    const int urows = cs ? SAO_ROWS / 2 : (SAO_ROWS + 3) / 4, ucols = cs ? 4 : 2;
     for (int ur = 0; ur < urows; ur++)
       for (int uc = 0; uc < ucols; uc++) {
         const int lx = ((x0 << cs) >> 2) + uc, ly = ((y0 << cs) >> 2) + ur;
@@ -387,7 +384,7 @@ void k_sao(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, PlaneRe
   }
 
   if (type == 1) {                                            // band offset (sao.cc:182-251)
-    const int bandShift = bd - 5, left = ci.sao_band_position[comp];
+    const int bandShift = bd - 5, left = sc.band[comp];
 #pragma unroll
     for (int r = 0; r < SAO_ROWS; r++) {
       if (r >= nrows) break;
@@ -406,43 +403,53 @@ void k_sao(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, PlaneRe
   }
 
   // ---- edge offset (sao.cc:75-178)
-  const int eo = (ci.sao_eo_class >> (2 * comp)) & 3;
+  const int eo = sc.eo[comp];
   const int hx = (eo == 1) ? 0 : (eo == 3 ? 1 : -1), hy = (eo == 0) ? 0 : -1;   // first neighbour; second is the mirror
-  // permissions of the 3x3 CTB neighbourhood: bit (dy+1)*3+(dx+1); evaluated only on the CTB outline
+  // permissions of the 3x3 CTB neighbourhood, resolved on the host: bit (dy+1)*3+(dx+1)
   const int mask = (1 << ctbshift) - 1;
-  unsigned perm = 0x1FF;
-  if ((x0 & mask) == 0 || ((x0 + 7) & mask) == mask || (y0 & mask) == 0 || ((y0 + SAO_ROWS - 1) & mask) == mask) {
-    const int ctbSlice = ci.slice_addr_rs;
-    const int tileCur = M.tile_id[ctbAddr];
-    const int nCtbX = (width + mask) >> ctbshift, nCtbY = (height + mask) >> ctbshift;
-    perm = 0x10;
-    for (int dy = -1; dy <= 1; dy++)
-      for (int dx = -1; dx <= 1; dx++) {
-        if (!dx && !dy) continue;
-        const int nx = ctbX + dx, ny = ctbY + dy;
-        bool ok = nx >= 0 && ny >= 0 && nx < nCtbX && ny < nCtbY;
-        if (ok) {
-          const int nAddr = nx + ny * P.ctbs_w;
-          const de265hip_ctb_info* nci = &M.ctbs[nAddr];
-          const int ns = nci->slice_addr_rs;
-          if (ns < ctbSlice && !sh->slice_loop_filter_across_slices_enabled_flag) ok = false;
-          if (ns > ctbSlice && !M.slices[nci->slice_idx].slice_loop_filter_across_slices_enabled_flag) ok = false;
-          if (!P.lf_across_tiles && M.tile_id[nAddr] != tileCur) ok = false;
-        }
-        if (ok) perm |= 1u << ((dy + 1) * 3 + dx + 1);
-      }
-  }
+  const unsigned perm = sc.perm;
 
   // offsets {o1,o2,0,o3,o4} indexed by edgeIdx+2 (sao.cc:95-100): four of them packed into one register
   const unsigned otab = (unsigned)(uint8_t)o4[0] | ((unsigned)(uint8_t)o4[1] << 8) | ((unsigned)(uint8_t)o4[2] << 24);
   const bool e0 = eo == 0, e1 = eo == 1, e2 = eo == 2;
-  const bool touchL = (x0 & mask) == 0, touchR = ((x0 + 7) & mask) == mask;
+
+  // ---- which of the 64 samples may be modified: one 64-bit mask per strip (bit r*8+i) instead of
+  // per-sample boundary logic.  A sample is blocked when one of its two neighbours lies outside the
+  // picture, or in another CTB whose slice/tile rules forbid filtering across (perm), or when it is
+  // pcm/bypass-exempt, or outside the picture itself.
+  const int ncols = min(8, width - x0);
+  const unsigned long long COL0 = 0x0101010101010101ull, ROW0 = 0xFFull;
+  const unsigned long long colL = COL0, colR = COL0 << (ncols - 1);
+  const unsigned long long rowT = ROW0, rowB = ROW0 << (8 * (nrows - 1));
+  const bool touchL = (x0 & mask) == 0, touchR = ((x0 + ncols - 1) & mask) == mask || x0 + ncols >= width;
+  const bool touchT = (y0 & mask) == 0, touchB = ((y0 + nrows - 1) & mask) == mask || y0 + nrows >= height;
+  // permission of the CTB at offset (dx,dy) (0 = this CTB); out-of-picture CTBs have their bit cleared in perm
+  auto permitted = [&](int dx, int dy) -> bool { return (perm >> ((dy + 1) * 3 + dx + 1)) & 1; };
+  auto blocked = [&](int sx, int sy) -> unsigned long long {   // samples whose neighbour in direction (sx,sy) is not usable
+    const unsigned long long X = sx < 0 ? colL : (sx > 0 ? colR : 0ull);
+    const unsigned long long Y = sy < 0 ? rowT : (sy > 0 ? rowB : 0ull);
+    const int dx = sx < 0 ? (touchL ? -1 : 0) : (sx > 0 ? (touchR ? 1 : 0) : 0);
+    const int dy = sy < 0 ? (touchT ? -1 : 0) : (sy > 0 ? (touchB ? 1 : 0) : 0);
+    unsigned long long bad = 0;
+    if (!permitted(dx, 0)) bad |= X & ~Y;
+    if (!permitted(0, dy)) bad |= Y & ~X;
+    if (!permitted(dx, dy)) bad |= X & Y;
+    return bad;
+  };
+  unsigned long long okmask = ~(blocked(hx, hy) | blocked(-hx, -hy));
+  okmask &= (COL0 * ((1ull << ncols) - 1ull)) & (nrows >= 8 ? ~0ull : ((1ull << (8 * nrows)) - 1ull));
+  if (exm) {
+#pragma unroll
+    for (int r = 0; r < SAO_ROWS; r++)
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        if ((exm >> ((cs ? r >> 1 : r >> 2) * 4 + (cs ? i >> 1 : i >> 2))) & 1) okmask &= ~(1ull << (r * 8 + i));
+  }
+  const unsigned ok_lo = (unsigned)okmask, ok_hi = (unsigned)(okmask >> 32);
+
 #pragma unroll
   for (int r = 0; r < SAO_ROWS; r++) {
     if (r >= nrows) break;
-    const int y = y0 + r;
-    const bool okRows = hy ? (y > 0 && y + 1 < height) : true;
-    const int dyA = hy ? (((y - 1) >> ctbshift) - ctbY) : 0, dyB = hy ? (((y + 1) >> ctbshift) - ctbY) : 0;
     int out[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -455,26 +462,12 @@ void k_sao(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, PlaneRe
       const int nDL = i > 0 ? v[r + 2][i > 0 ? i - 1 : 0] : nl[r + 2], nDR = i < 7 ? v[r + 2][i < 7 ? i + 1 : 7] : nr[r + 2];
       const int na = e0 ? nL : (e1 ? nU : (e2 ? nUL : nUR));
       const int nb = e0 ? nR : (e1 ? nD : (e2 ? nDR : nDL));
-      // branch-free predicates (bitwise, not short-circuit: no exec-mask juggling per sample)
-      unsigned ok = ~(exm >> ((cs ? r >> 1 : r >> 2) * 4 + (cs ? i >> 1 : i >> 2))) & 1u;
-      // only samples on the outline of the strip can have a neighbour in another CTB / outside the picture
-      // (i and r are compile-time constants here: interior samples carry none of this code)
-      if (i == 0 || i == 7 || r == 0 || r == SAO_ROWS - 1) {
-        const int xs = x0 + i, xa = xs + hx, xb = xs - hx;
-        ok &= (unsigned)okRows & (unsigned)(xs < width) & (unsigned)(xa >= 0) & (unsigned)(xa < width) &
-              (unsigned)(xb >= 0) & (unsigned)(xb < width);
-        const int dxA = (i == 0 && touchL && hx < 0) ? -1 : ((i == 7 && touchR && hx > 0) ? 1 : 0);
-        const int dxB = (i == 0 && touchL && hx > 0) ? -1 : ((i == 7 && touchR && hx < 0) ? 1 : 0);
-        ok &= (perm >> ((dyA + 1) * 3 + dxA + 1)) & (perm >> ((dyB + 1) * 3 + dxB + 1));
-      } else {
-        // a partial last strip ends inside the 8 rows / 8 columns: the picture edge can cut through it
-        ok &= (unsigned)okRows & (unsigned)(x0 + i + (hx ? 1 : 0) < width);
-      }
+      const bool ok = ((r < 4 ? ok_lo : ok_hi) >> ((r & 3) * 8 + i)) & 1u;
       const int ee = min(max(c - na, -1), 1) + min(max(c - nb, -1), 1) + 2;      // 0..4
       const int off = ee == 4 ? o4[3] : (int)(int8_t)((otab >> (8 * ee)) & 0xFF);
       out[i] = ok ? lf_clip3(0, maxv, c + off) : c;
     }
-    store8i<PX>(dst + x0 + y * dstride, out);
+    store8i<PX>(dst + x0 + (y0 + r) * dstride, out);
   }
 }
 
