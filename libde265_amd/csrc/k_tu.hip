@@ -351,6 +351,95 @@ __device__ void tu_reconstruct(const PicDev& P, const TuTask& t, PX* plane, int 
   st.mark(5);
 }
 
+// ---------------------------------------------------------------- large-TU residual kernel
+// 16x16 and 32x32 TUs are few (~4 % of the TUs) but long: four wavefronts share one TU so that the
+// two transform stages (up to 32 k multiply-adds each) finish in a quarter of the time.  Same
+// arithmetic as tu_reconstruct's residual path; level-0 work only (inter add / intra residual-only).
+template <typename PX>
+__global__ __launch_bounds__(256)
+void k_resid_big(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const TuTask* __restrict__ tasks,
+                 const int16_t* __restrict__ coeff_val, const uint16_t* __restrict__ coeff_pos,
+                 const uint8_t* __restrict__ scaling, int16_t* __restrict__ resid)
+{
+  __shared__ int8_t s_mat[32 * 32];
+  __shared__ int16_t s_c[32 * 32];
+  __shared__ int16_t s_g[32 * 32];
+  __shared__ int s_last_row, s_last_col;
+  const int tid = threadIdx.x;
+  const TuTask t = tasks[blockIdx.x];
+  const int cIdx = t.c_idx, log2 = t.log2_size, nT = 1 << log2, nS = nT * nT;
+  const int bd = cIdx ? P.bd_chroma : P.bd_luma, maxv = (1 << bd) - 1;
+  const bool intra = t.flags & DE265HIP_TU_INTRA;
+  const bool bypass = t.flags & DE265HIP_TU_BYPASS;
+  for (int s = tid; s < nS; s += 256) s_c[s] = 0;
+  ((int32_t*)s_mat)[tid] = ((const int32_t*)c_dct_mat)[tid];
+  if (tid == 0) { s_last_row = 0; s_last_col = 0; }
+  __syncthreads();
+  {
+    const int16_t* vals = coeff_val + t.coeff_offset;
+    const uint16_t* pos = coeff_pos + t.coeff_offset;
+    int lr = 0, lc = 0;
+    if (bypass) {
+      for (int i = tid; i < t.n_coeff; i += 256) s_c[pos[i]] = vals[i];
+    } else if (!P.scaling_list) {
+      const int bdShift = bd + log2 - 9;
+      const int32_t fact = (int32_t)c_level_scale[t.qp % 6] << (t.qp / 6);
+      for (int i = tid; i < t.n_coeff; i += 256) {
+        const int p = pos[i];
+        const int32_t cc = (int32_t)((uint32_t)(int32_t)vals[i] * (uint32_t)fact + (uint32_t)(1 << (bdShift - 1)));
+        s_c[p] = (int16_t)clip3(-32768, 32767, cc >> bdShift);
+        lr = max(lr, p >> log2); lc = max(lc, p & (nT - 1));
+      }
+    } else {
+      const int bdShift = bd + log2 - 5;
+      int matrixID = cIdx;
+      if (!intra) matrixID += (nT < 32) ? 3 : 1;
+      const uint8_t* scl = scaling + (log2 == 4 ? 96 + 384 : 96 + 384 + 1536) + matrixID * nS;
+      for (int i = tid; i < t.n_coeff; i += 256) {
+        const int p = pos[i];
+        const int fact = ((int)scl[p] * c_level_scale[t.qp % 6]) << (t.qp / 6);
+        long long cc = ((long long)vals[i] * fact + (1ll << (bdShift - 1))) >> bdShift;
+        s_c[p] = (int16_t)(cc < -32768 ? -32768 : (cc > 32767 ? 32767 : cc));
+        lr = max(lr, p >> log2); lc = max(lc, p & (nT - 1));
+      }
+    }
+    if (lr) atomicMax(&s_last_row, lr);
+    if (lc) atomicMax(&s_last_col, lc);
+  }
+  __syncthreads();
+  const bool resid_only = t.flags & D265_TU_RESID_ONLY;
+  const PlaneRef pr = cIdx == 0 ? pl0 : (cIdx == 1 ? pl1 : pl2);
+  PX* dst = (PX*)pr.ptr + t.x0 + t.y0 * pr.stride;
+  int16_t* ro = resid + t.resid_offset;
+  if (bypass) {
+    for (int s = tid; s < nS; s += 256) {
+      const int r = s_c[s];
+      if (resid_only) ro[s] = (int16_t)r;
+      else { PX* d = dst + (s & (nT - 1)) + (s >> log2) * pr.stride; *d = (PX)clip3(0, maxv, (int)*d + r); }
+    }
+    return;
+  }
+  const int fact = 32 >> log2, lastRow = s_last_row, lastCol = s_last_col, ncols = lastCol + 1;
+  for (int tix = tid; tix < nT * ncols; tix += 256) {
+    const int c = tix % ncols, i = tix / ncols;
+    int sum = 0;
+    for (int j = 0; j <= lastRow; j++) sum += s_mat[fact * j * 32 + i] * s_c[c + j * nT];
+    s_g[i * nT + c] = (int16_t)clip3(-32768, 32767, (sum + 64) >> 7);
+  }
+  __syncthreads();
+  const int post = 20 - bd, rnd2 = 1 << (post - 1);
+  for (int s = tid; s < nS; s += 256) {
+    const int y = s >> log2, i = s & (nT - 1);
+    int sum = 0;
+    for (int j = 0; j <= lastCol; j++) sum += s_mat[fact * j * 32 + i] * s_g[y * nT + j];
+    const int out = (sum + rnd2) >> post;
+    if (resid_only) ro[s] = (int16_t)clip3(-32768, 32767, out);
+    else { PX* d = dst + i + y * pr.stride; *d = (PX)clip3(0, maxv, (int)*d + out); }
+  }
+}
+template __global__ void k_resid_big<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
+template __global__ void k_resid_big<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
+
 // ---------------------------------------------------------------- small-TU residual kernel
 // 4x4 and 8x8 TUs are ~95 % of all TUs.  One wavefront handles four 4x4 TUs (16 lanes each) or
 // one 8x8 TU: every lane owns one coefficient in the scatter and one sample in both transform

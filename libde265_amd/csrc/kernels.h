@@ -22,6 +22,9 @@ struct SaoMeta {
 template <typename PX>
 __global__ void k_tu(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int,
                      const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
+template <typename PX>
+__global__ void k_resid_big(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, const int16_t*, const uint16_t*,
+                            const uint8_t*, int16_t*);
 template <typename PX, int LOG2>
 __global__ void k_resid_small(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int, int, const int16_t*,
                               const uint16_t*, const uint8_t*, int16_t*);
