@@ -246,6 +246,28 @@ void de265hip_picture_free(de265hip_picture*);
 int  de265hip_decode_picture(de265hip_decoder*, int dst_slot,
                              const de265hip_picture_desc*);
 
+/* ---- recorder: the same interface as incremental calls, for a host parser that produces TUs,
+ * PUs and PCM blocks one at a time (what decode_TU / generate_inter_prediction_samples /
+ * read_pcm_samples receive, slice.cc:3424, motion.cc:279, slice.cc:4185).  The recorder only
+ * accumulates a de265hip_picture_desc on the host; de265hip_recorder_submit == picture_build. ---- */
+typedef struct de265hip_recorder de265hip_recorder;
+int  de265hip_recorder_new(de265hip_recorder** out, const de265hip_pic_params* params,
+                           const uint8_t* scaling_factors /* NULL unless scaling lists are on */);
+void de265hip_recorder_free(de265hip_recorder*);
+/* TU in decode order; vals/pos hold tu->n_coeff entries (coeff_offset is filled in here) */
+int  de265hip_record_tu(de265hip_recorder*, const de265hip_tu* tu, const int16_t* vals, const uint16_t* pos);
+int  de265hip_record_pu(de265hip_recorder*, const de265hip_pu* pu);
+/* samples: Y (size^2) then Cb, Cr ((size/2)^2 each), already << (bitDepth - pcmBits) */
+int  de265hip_record_pcm(de265hip_recorder*, int x0, int y0, int log2_cb_size, const uint16_t* samples);
+int  de265hip_record_slice(de265hip_recorder*, const de265hip_slice_params* slice);      /* returns its index via n_slices-1 */
+int  de265hip_record_ctb(de265hip_recorder*, int ctb_addr_rs, const de265hip_ctb_info* info);
+/* metadata planes (ceil(W/4) x ceil(H/4)); copied */
+int  de265hip_record_blk_planes(de265hip_recorder*, const uint8_t* blk_flags, const int8_t* blk_qp_y,
+                                const de265hip_motion* blk_motion /* may be NULL */);
+/* the accumulated description (valid until the recorder is modified or freed) */
+const de265hip_picture_desc* de265hip_recorder_desc(de265hip_recorder*);
+int  de265hip_recorder_submit(de265hip_decoder*, int dst_slot, de265hip_recorder*, de265hip_picture** out);
+
 /* Introspection used by bench/tests */
 typedef struct de265hip_picture_stats {
   int32_t n_levels;          /* intra dependency levels at TU granularity */

@@ -22,6 +22,9 @@ EXPORTS = [
     "de265hip_picture_build", "de265hip_picture_run", "de265hip_decoder_sync", "de265hip_picture_free",
     "de265hip_decode_picture", "de265hip_picture_get_stats",
     "de265hip_set_profiling", "de265hip_get_kernel_times", "de265hip_derive_edge_flags",
+    "de265hip_recorder_new", "de265hip_recorder_free", "de265hip_record_tu", "de265hip_record_pu",
+    "de265hip_record_pcm", "de265hip_record_slice", "de265hip_record_ctb", "de265hip_record_blk_planes",
+    "de265hip_recorder_desc", "de265hip_recorder_submit",
     "de265hip_fn_transform_add", "de265hip_fn_transform_skip_add", "de265hip_fn_transform_bypass_add",
     "de265hip_fn_put_qpel", "de265hip_fn_put_epel", "de265hip_fn_put_pred",
 ]
@@ -65,6 +68,18 @@ def lib():
     L.de265hip_get_kernel_times.argtypes = [vp, pp(C.c_double), pp(C.c_int64), i32]
     L.de265hip_derive_edge_flags.argtypes = [pp(_abi.PicParams), pp(_abi.SliceParams), i32, pp(_abi.CtbInfo),
                                              vp, vp, vp, vp]
+    L.de265hip_recorder_new.argtypes = [pp(vp), pp(_abi.PicParams), vp]
+    L.de265hip_recorder_free.argtypes = [vp]
+    L.de265hip_recorder_free.restype = None
+    L.de265hip_record_tu.argtypes = [vp, pp(_abi.TU), vp, vp]
+    L.de265hip_record_pu.argtypes = [vp, pp(_abi.PU)]
+    L.de265hip_record_pcm.argtypes = [vp, i32, i32, i32, vp]
+    L.de265hip_record_slice.argtypes = [vp, pp(_abi.SliceParams)]
+    L.de265hip_record_ctb.argtypes = [vp, i32, pp(_abi.CtbInfo)]
+    L.de265hip_record_blk_planes.argtypes = [vp, vp, vp, vp]
+    L.de265hip_recorder_desc.argtypes = [vp]
+    L.de265hip_recorder_desc.restype = pp(_abi.PictureDesc)
+    L.de265hip_recorder_submit.argtypes = [vp, i32, vp, pp(vp)]
     for n in ("de265hip_fn_transform_add",):
         getattr(L, n).argtypes = [i32, i32, i32, vp, C.c_ssize_t, i32, i32, vp, vp]
     for n in ("de265hip_fn_transform_skip_add", "de265hip_fn_transform_bypass_add"):
@@ -177,6 +192,58 @@ class Decoder:
         n = (C.c_int64 * len(_abi.K_NAMES))()
         _chk(lib().de265hip_get_kernel_times(self._h, ms, n, int(reset)), "get_kernel_times")
         return {k: (ms[i], n[i]) for i, k in enumerate(_abi.K_NAMES)}
+
+
+class Recorder:
+    """Incremental form of the frame-level interface (de265hip_recorder_*): what a host parser calls
+    per TU / PU / PCM block; submit() == Decoder.build() on the accumulated description."""
+
+    def __init__(self, params, scaling_factors=None):
+        h = C.c_void_p()
+        sf = scaling_factors.ctypes.data if scaling_factors is not None else None
+        _chk(lib().de265hip_recorder_new(C.byref(h), C.byref(params), sf), "recorder_new")
+        self._h = h
+
+    def record_desc(self, d):
+        """Replays an existing description call by call (used by tests)."""
+        L = lib()
+        cv = C.cast(d.coeff_val, C.c_void_p).value or 0
+        cp = C.cast(d.coeff_pos, C.c_void_p).value or 0
+        for i in range(d.n_slices):
+            _chk(L.de265hip_record_slice(self._h, C.byref(d.slices[i])), "record_slice")
+        for i in range(d.n_ctbs):
+            _chk(L.de265hip_record_ctb(self._h, i, C.byref(d.ctbs[i])), "record_ctb")
+        for i in range(d.n_tus):
+            t = d.tus[i]
+            _chk(L.de265hip_record_tu(self._h, C.byref(t), cv + 2 * t.coeff_offset, cp + 2 * t.coeff_offset), "record_tu")
+        for i in range(d.n_pus):
+            _chk(L.de265hip_record_pu(self._h, C.byref(d.pus[i])), "record_pu")
+        ps = C.cast(d.pcm_samples, C.c_void_p).value or 0
+        for i in range(d.n_pcms):
+            p = d.pcms[i]
+            _chk(L.de265hip_record_pcm(self._h, p.x0, p.y0, p.log2_cb_size, ps + 2 * p.sample_offset), "record_pcm")
+        _chk(L.de265hip_record_blk_planes(self._h, C.cast(d.blk_flags, C.c_void_p), C.cast(d.blk_qp_y, C.c_void_p),
+                                          C.cast(d.blk_motion, C.c_void_p)), "record_blk_planes")
+
+    @property
+    def desc(self):
+        return lib().de265hip_recorder_desc(self._h)
+
+    def submit(self, dec, dst_slot):
+        h = C.c_void_p()
+        _chk(lib().de265hip_recorder_submit(dec._h, dst_slot, self._h, C.byref(h)), "recorder_submit")
+        return Picture(dec, h)
+
+    def free(self):
+        if self._h:
+            lib().de265hip_recorder_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def derive_edge_flags(params, slices, n_slices, ctbs, cb_log2_size, cb_part_mode, tu_split, blk_flags):

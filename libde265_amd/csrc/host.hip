@@ -934,6 +934,120 @@ int de265hip_derive_edge_flags(const de265hip_pic_params* pp, const de265hip_sli
   return 0;
 }
 
+// ------------------------------------------------------------------ recorder (host only)
+struct de265hip_recorder {
+  de265hip_picture_desc d;
+  std::vector<uint8_t> scaling;
+  std::vector<de265hip_slice_params> slices;
+  std::vector<de265hip_ctb_info> ctbs;
+  std::vector<de265hip_tu> tus;
+  std::vector<int16_t> cval; std::vector<uint16_t> cpos;
+  std::vector<de265hip_pu> pus;
+  std::vector<de265hip_pcm> pcms; std::vector<uint16_t> pcm_samples;
+  std::vector<uint8_t> flags; std::vector<int8_t> qp; std::vector<de265hip_motion> motion;
+  bool have_motion = false;
+};
+
+int de265hip_recorder_new(de265hip_recorder** out, const de265hip_pic_params* params, const uint8_t* scaling_factors)
+{
+  if (!out || !params) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  *out = nullptr;
+  if (params->width <= 0 || params->height <= 0 || params->log2_ctb_size < 4 || params->log2_ctb_size > 6)
+    return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  if (params->scaling_list_enable_flag && !scaling_factors) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  de265hip_recorder* r = new (std::nothrow) de265hip_recorder();
+  if (!r) return DE265HIP_ERROR_OUT_OF_MEMORY;
+  memset(&r->d, 0, sizeof(r->d));
+  r->d.params = *params;
+  if (scaling_factors) r->scaling.assign(scaling_factors, scaling_factors + DE265HIP_SCALING_BLOB_BYTES);
+  const int ctb = 1 << params->log2_ctb_size;
+  const int nctb = ((params->width + ctb - 1) / ctb) * ((params->height + ctb - 1) / ctb);
+  r->ctbs.assign((size_t)nctb, de265hip_ctb_info{});
+  const size_t nblk = (size_t)((params->width + 3) / 4) * ((params->height + 3) / 4);
+  r->flags.assign(nblk, 0); r->qp.assign(nblk, 0);
+  *out = r;
+  return DE265HIP_OK;
+}
+
+void de265hip_recorder_free(de265hip_recorder* r) { delete r; }
+
+int de265hip_record_tu(de265hip_recorder* r, const de265hip_tu* tu, const int16_t* vals, const uint16_t* pos)
+{
+  if (!r || !tu || (tu->n_coeff && (!vals || !pos))) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  de265hip_tu t = *tu;
+  t.coeff_offset = (uint32_t)r->cval.size();
+  r->cval.insert(r->cval.end(), vals, vals + t.n_coeff);
+  r->cpos.insert(r->cpos.end(), pos, pos + t.n_coeff);
+  r->tus.push_back(t);
+  return DE265HIP_OK;
+}
+
+int de265hip_record_pu(de265hip_recorder* r, const de265hip_pu* pu)
+{
+  if (!r || !pu) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  r->pus.push_back(*pu);
+  return DE265HIP_OK;
+}
+
+int de265hip_record_pcm(de265hip_recorder* r, int x0, int y0, int log2_cb_size, const uint16_t* samples)
+{
+  if (!r || !samples || log2_cb_size < 3 || log2_cb_size > 5 || x0 < 0 || y0 < 0) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  de265hip_pcm p; memset(&p, 0, sizeof(p));
+  p.x0 = (uint16_t)x0; p.y0 = (uint16_t)y0; p.log2_cb_size = (uint8_t)log2_cb_size;
+  p.sample_offset = (uint32_t)r->pcm_samples.size();
+  const int n = 1 << log2_cb_size;
+  r->pcm_samples.insert(r->pcm_samples.end(), samples, samples + n * n * 3 / 2);
+  r->pcms.push_back(p);
+  return DE265HIP_OK;
+}
+
+int de265hip_record_slice(de265hip_recorder* r, const de265hip_slice_params* s)
+{
+  if (!r || !s) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  r->slices.push_back(*s);
+  return DE265HIP_OK;
+}
+
+int de265hip_record_ctb(de265hip_recorder* r, int addr, const de265hip_ctb_info* info)
+{
+  if (!r || !info || addr < 0 || addr >= (int)r->ctbs.size()) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  r->ctbs[addr] = *info;
+  return DE265HIP_OK;
+}
+
+int de265hip_record_blk_planes(de265hip_recorder* r, const uint8_t* f, const int8_t* q, const de265hip_motion* m)
+{
+  if (!r || !f || !q) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  memcpy(r->flags.data(), f, r->flags.size());
+  memcpy(r->qp.data(), q, r->qp.size());
+  r->have_motion = m != nullptr;
+  if (m) r->motion.assign(m, m + r->flags.size());
+  return DE265HIP_OK;
+}
+
+const de265hip_picture_desc* de265hip_recorder_desc(de265hip_recorder* r)
+{
+  if (!r) return nullptr;
+  de265hip_picture_desc& d = r->d;
+  d.scaling_factors = r->scaling.empty() ? nullptr : r->scaling.data();
+  d.n_slices = (int32_t)r->slices.size(); d.slices = r->slices.data();
+  d.n_ctbs = (int32_t)r->ctbs.size(); d.ctbs = r->ctbs.data();
+  d.n_tus = (int32_t)r->tus.size(); d.tus = r->tus.data();
+  d.n_coeffs = (int32_t)r->cval.size(); d.coeff_val = r->cval.data(); d.coeff_pos = r->cpos.data();
+  d.n_pus = (int32_t)r->pus.size(); d.pus = r->pus.data();
+  d.n_pcms = (int32_t)r->pcms.size(); d.pcms = r->pcms.data();
+  d.n_pcm_samples = (int32_t)r->pcm_samples.size(); d.pcm_samples = r->pcm_samples.data();
+  d.blk_flags = r->flags.data(); d.blk_qp_y = r->qp.data();
+  d.blk_motion = r->have_motion ? r->motion.data() : nullptr;
+  return &d;
+}
+
+int de265hip_recorder_submit(de265hip_decoder* dec, int dst_slot, de265hip_recorder* r, de265hip_picture** out)
+{
+  if (!r) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  return de265hip_picture_build(dec, dst_slot, de265hip_recorder_desc(r), out);
+}
+
 // ------------------------------------------------------------------ Part B
 namespace {
 struct DevBuf {

@@ -225,3 +225,62 @@ def test_concurrent_decoders_do_not_interfere(dec):
         got = decs[s].download(1, w, h, bd)
         assert all(np.array_equal(g, e) for g, e in zip(got, exps[s])), s
         pics[s][0].free(); pics[s][1].free(); decs[s].close()
+
+
+def test_randomized_small_pictures(dec):
+    """Many small random configurations (sizes down to one CTB, every feature switch drawn at random):
+    shakes out corner cases of availability, window clipping and partial strips."""
+    rng = np.random.default_rng(20260104)
+    for it in range(60):
+        log2_ctb = int(rng.choice([4, 5, 6]))
+        w = int(rng.integers(1, 26)) * 8
+        h = int(rng.integers(1, 18)) * 8
+        bd = int(rng.choice([8, 9, 10, 12]))
+        st = int(rng.choice([0, 1, 2]))
+        cols = int(rng.integers(1, 3)) if w >= 128 else 1
+        rows = int(rng.integers(1, 3)) if h >= 128 else 1
+        ctbs_w = -(-w // (1 << log2_ctb))
+        ctbs_h = -(-h // (1 << log2_ctb))
+        cols, rows = min(cols, ctbs_w), min(rows, ctbs_h)
+        over = dict(log2_ctb_size=log2_ctb, log2_max_tb_size=min(5, log2_ctb),
+                    log2_min_tb_size=int(rng.choice([2, 2, 3])),
+                    intra_pct=int(rng.choice([0, 15, 50, 100])), tskip_pct=int(rng.choice([0, 30])),
+                    bypass_pct=int(rng.choice([0, 10])), pcm_pct=int(rng.choice([0, 20])),
+                    pcm_loop_filter_disable=int(rng.integers(0, 2)), scaling_list=int(rng.integers(0, 2)),
+                    constrained_intra_pred=int(rng.integers(0, 2)), strong_intra_smoothing=int(rng.integers(0, 2)),
+                    weighted_pred=int(rng.integers(0, 2)), n_slices=int(rng.integers(1, 4)),
+                    tile_cols=cols, tile_rows=rows, slice_per_tile=int(rng.integers(0, 2)),
+                    lf_across_tiles=int(rng.integers(0, 2)), lf_across_slices_pct=int(rng.choice([0, 50, 100])),
+                    deblocking=int(rng.integers(0, 4) > 0), sao=int(rng.integers(0, 4) > 0),
+                    big_coeff_pct=int(rng.choice([0, 5])), mv_sigma_qpel=int(rng.choice([4, 12, 60])),
+                    split_bias=int(rng.choice([0, 50, 100])), cbf_pct=int(rng.choice([0, 60, 100])))
+        try:
+            run_case(dec, w, h, bd, st, seed=5000 + it, stages=(2,), **over)
+        except AssertionError as e:
+            raise AssertionError("config %d: %dx%d bd=%d st=%d %r: %s" % (it, w, h, bd, st, over, e))
+
+
+def test_recorder_submit_matches_oracle(dec):
+    """Incremental interface (de265hip_record_* + recorder_submit) on the GPU: same picture as the oracle."""
+    w, h, bd = 352, 288, 10
+    cfg = pysynth.default_config(w, h, bd, 0, seed=77, pcm_pct=10, tskip_pct=20, n_slices=2, scaling_list=1)
+    sp = pysynth.SynthPicture(cfg)
+    refs = {0: pysynth.fill_planes(w, h, bd, 177), 1: pysynth.fill_planes(w, h, bd, 277)}
+    for slot, pl in refs.items():
+        dec.dpb_alloc(slot, w, h, bd)
+        dec.upload(slot, pl)
+    sf = np.ctypeslib.as_array(sp.d.scaling_factors, shape=(_abi.SCALING_BLOB_BYTES,)).copy()
+    rec = backend.Recorder(sp.d.params, sf)
+    rec.record_desc(sp.d)
+    init = pysynth.fill_planes(w, h, bd, 999)
+    exp = [p.copy() for p in init]
+    pyoracle.reconstruct(sp.desc, sp.order, refs, exp)
+    dec.upload(2, init)
+    pic = rec.submit(dec, 2)
+    dec.run(pic)
+    dec.sync()
+    got = dec.download(2, w, h, bd)
+    pic.free()
+    rec.free()
+    for c in range(3):
+        assert np.array_equal(got[c], exp[c])

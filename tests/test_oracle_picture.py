@@ -163,3 +163,25 @@ def test_bs_values_and_intra_rule():
         intra = ((flags[ys, xs] | nb) & _abi.BLK_INTRA) != 0
         assert (bs[ys, xs][intra] == 2).all() and (bs[ys, xs][~intra] < 2).all()
     del d
+
+
+def test_recorder_accumulates_the_same_description():
+    """de265hip_recorder_*: replaying a description call by call (TU / PU / PCM / slice / CTB / planes)
+    yields a description the oracle reconstructs to the identical picture (host logic, no GPU)."""
+    sp, refs = make(352, 288, 10, 0, 33, pcm_pct=15, tskip_pct=20, n_slices=2, scaling_list=1)
+    d = sp.d
+    sf = np.ctypeslib.as_array(d.scaling_factors, shape=(_abi.SCALING_BLOB_BYTES,)).copy()
+    rec = backend.Recorder(d.params, sf)
+    rec.record_desc(d)
+    rd = rec.desc.contents
+    assert (rd.n_tus, rd.n_pus, rd.n_pcms, rd.n_coeffs, rd.n_slices, rd.n_ctbs) == \
+           (d.n_tus, d.n_pus, d.n_pcms, d.n_coeffs, d.n_slices, d.n_ctbs)
+    P = d.params
+    a = pysynth.fill_planes(P.width, P.height, P.bit_depth_luma, 3)
+    b = [p.copy() for p in a]
+    pyoracle.reconstruct(sp.desc, None, refs, a)
+    pyoracle.reconstruct(rec.desc, None, refs, b)
+    assert digest(a) == digest(b)
+    with pytest.raises(backend.De265HipError):
+        backend._chk(backend.lib().de265hip_record_ctb(rec._h, 10 ** 6, C.byref(d.ctbs[0])), "record_ctb")
+    rec.free()
