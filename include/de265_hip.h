@@ -275,7 +275,7 @@ typedef struct de265hip_picture_stats {
   int32_t n_mc_tasks;
   int32_t n_runs;            /* intra runs (wavefront tasks of the single-launch run kernel) */
   int32_t n_run_levels;      /* longest producer->consumer chain of runs */
-  int32_t pad;
+  int32_t n_in_run_levels;   /* sum over runs of their in-run dependency levels (barrier steps of the run kernel) */
   int64_t device_bytes;      /* command-buffer bytes resident in HBM */
   int64_t alg_bytes_mc;      /* algorithmic bytes, SURVEY 8d definitions */
   int64_t alg_bytes_resid;

@@ -121,7 +121,7 @@ class PictureDesc(C.Structure):
 class PictureStats(C.Structure):
     _fields_ = [
         ("n_levels", C.c_int32), ("n_tu_tasks", C.c_int32), ("n_mc_tasks", C.c_int32),
-        ("n_runs", C.c_int32), ("n_run_levels", C.c_int32), ("pad", C.c_int32),
+        ("n_runs", C.c_int32), ("n_run_levels", C.c_int32), ("n_in_run_levels", C.c_int32),
         ("device_bytes", C.c_int64),
         ("alg_bytes_mc", C.c_int64), ("alg_bytes_resid", C.c_int64),
         ("alg_bytes_intra", C.c_int64), ("alg_bytes_deblock", C.c_int64),

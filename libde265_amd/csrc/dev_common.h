@@ -45,7 +45,9 @@ struct TuTask {
   uint32_t coeff_offset;
   uint64_t avail;
   uint32_t resid_offset;   // run mode: where the precomputed int16 residual block of an intra TU lives
-  uint32_t pad2;
+  int8_t   angle;          // run mode: intraPredAngle of the mode (intrapred.cc:742-760), host-resolved so that
+  uint8_t  pad3;           //           no table load sits on the z-scan chain
+  int16_t  inv_angle;      //           invAngle for the negative angles, else 0
 };
 static_assert(sizeof(TuTask) == 32, "TuTask layout");
 // internal TuTask flag: compute the residual only (into the residual buffer), no prediction, no picture access
@@ -72,10 +74,10 @@ struct RunTask {
   uint16_t n_tus;
   uint32_t first_tu;         // into the run-ordered TuTask array
   uint32_t dep_offset;       // into the producer-run id array
-  uint16_t n_deps, pad1;
+  uint16_t n_deps, n_lvls;  // n_lvls: in-run dependency levels (TUs of one level are independent of each other)
   uint32_t res_offset;       // the run's residual blocks: one contiguous int16 range (multiple of 8 long)
   uint32_t res_len;
-  uint32_t pad2;
+  uint32_t lvl_offset;       // into the uint16 level table: n_lvls + 1 TU indices (relative to first_tu)
 };
 static_assert(sizeof(RunTask) == 40, "RunTask layout");
 

@@ -44,6 +44,7 @@ struct de265hip_decoder {
   Slot slots[DE265HIP_MAX_DPB_SLOTS];
   Slot spare;                         // SAO output target, swapped with the decoded slot
   uint32_t* d_err = nullptr;          // set by a kernel whose bounded spin expired
+  int run_waves = RUN_WAVES;          // DE265HIP_RUN_WAVES: wavefronts per run workgroup (experiments)
   int dbg = 0;                        // DE265HIP_DEBUG: timing-only ablations of k_run (results invalid)
   bool intra_levels = false;          // DE265HIP_INTRA_MODE=levels: one launch per dependency level
   bool profiling = false;
@@ -71,6 +72,7 @@ struct de265hip_picture {
   uint8_t* d_flags = nullptr; int8_t* d_qp = nullptr; de265hip_motion* d_motion = nullptr;
   uint8_t* d_bs = nullptr;
   SaoCtb* d_sao = nullptr;
+  uint16_t* d_run_lv = nullptr;
   RunTask* d_runs = nullptr; uint32_t* d_deps = nullptr; uint32_t* d_sync = nullptr;
   TuTask* d_run_tus = nullptr;
   int n_l0_size[4] = { 0, 0, 0, 0 };          // TU count per size in d_l0 (sorted 32,16,8,4)
@@ -155,7 +157,8 @@ int make_geometry(const de265hip_pic_params& p, Geometry& g)
 // :577-688 fill_from_image) as a unit bitmask, and the TU's dependency level.
 uint64_t intra_availability(const de265hip_picture_desc& d, const Geometry& g, const de265hip_tu& tu,
                             const std::vector<uint16_t>& lvl, int map_w, int* level_out,
-                            const std::vector<int32_t>& runmap, std::vector<int>& producers)
+                            const std::vector<int32_t>& runmap, std::vector<int>& producers,
+                            const std::vector<uint16_t>& llvl, int cur_run, int* local_level_out)
 {
   producers.clear();
   const de265hip_pic_params& p = d.params;
@@ -183,12 +186,13 @@ uint64_t intra_availability(const de265hip_picture_desc& d, const Geometry& g, c
     if (p.constrained_intra_pred_flag && !(d.blk_flags[(nx >> 2) + (ny >> 2) * g.w4] & DE265HIP_BLK_INTRA)) return false;
     return true;
   };
-  uint64_t mask = 0; int lev = 0;
+  uint64_t mask = 0; int lev = 0, llev = 0;
   const int corner = nT >> 1;
   auto take = [&](int u, int xs, int ys) {
     mask |= 1ull << u;
     lev = std::max(lev, (int)lvl[(xs >> 2) + (ys >> 2) * map_w]);
     const int r = runmap[(xs >> 2) + (ys >> 2) * map_w];
+    if (r >= 0 && r == cur_run) llev = std::max(llev, (int)llvl[(xs >> 2) + (ys >> 2) * map_w]);
     if (r >= 0 && std::find(producers.begin(), producers.end(), r) == producers.end()) producers.push_back(r);
   };
   if (aL)
@@ -198,6 +202,7 @@ uint64_t intra_availability(const de265hip_picture_desc& d, const Geometry& g, c
   for (int x = 0; x < nRight; x += 4)
     if ((x < nT ? aT : aTR) && usable(xB + x, yB - 1)) take(corner + 1 + (x >> 2), xB + x, yB - 1);
   *level_out = lev + 1;
+  *local_level_out = llev + 1;      // only meaningful when the TU ends up extending cur_run
   return mask;
 }
 
@@ -236,6 +241,7 @@ int de265hip_decoder_new(de265hip_decoder** out, int device)
   const char* mode = getenv("DE265HIP_INTRA_MODE");
   d->intra_levels = mode && !strcmp(mode, "levels");
   if (const char* dbg = getenv("DE265HIP_DEBUG")) d->dbg = atoi(dbg);
+  if (const char* rw = getenv("DE265HIP_RUN_WAVES")) d->run_waves = std::min(RUN_WAVES, std::max(1, atoi(rw)));
   *out = d;
   return DE265HIP_OK;
 }
@@ -358,10 +364,13 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   int64_t alg_resid = 0, alg_intra = 0;
   // runs: maximal intervals of the per-component intra TU sequence inside one CTB in which
   // every TU reads from the run so far (see k_run); independent TUs start a new run
-  struct RunBuild { int c, ctu, x0, y0, x1, y1, level, wx1, wy1; std::vector<TuTask> tus; std::vector<int> deps; };
+  struct RunBuild { int c, ctu, x0, y0, x1, y1, level, wx1, wy1; std::vector<TuTask> tus; std::vector<int> deps;
+                    std::vector<uint16_t> llev; };
   std::vector<RunBuild> rb;
   std::vector<int32_t> runmap[3];
   for (int c = 0; c < 3; c++) runmap[c].assign((size_t)map_w[c] * map_h[c], -1);
+  std::vector<uint16_t> llvl[3];                 // in-run dependency level of the TU covering a 4x4 unit
+  for (int c = 0; c < 3; c++) llvl[c].assign((size_t)map_w[c] * map_h[c], 0);
   int cur_run[3] = { -1, -1, -1 };
   std::vector<int> producers;
   // dense intra (no inter PUs at all): one run per CTB and component, fewest hand-offs on the z-scan chain.
@@ -392,10 +401,20 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     const size_t bpp = px_bytes(tu.c_idx ? p.bit_depth_chroma : p.bit_depth_luma);
     if (tu.flags & DE265HIP_TU_INTRA) {
       const int c = tu.c_idx, sub = c ? 2 : 1;
-      t.avail = intra_availability(*d, g, tu, lvl[c], map_w[c], &level, runmap[c], producers);
+      {
+        static const int8_t k_angle[35] = { 0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26,
+                                            -32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };
+        static const int16_t k_inv[15] = { -4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630,
+                                           -910, -1638, -4096 };
+        const int m = tu.intra_mode < 35 ? tu.intra_mode : 1;
+        t.angle = k_angle[m];
+        t.inv_angle = (m >= 11 && m <= 25 && k_angle[m] < 0) ? k_inv[m - 11] : 0;
+      }
+      int llev = 1;
+      t.avail = intra_availability(*d, g, tu, lvl[c], map_w[c], &level, runmap[c], producers, llvl[c], cur_run[c], &llev);
       const int ctu = ((tu.x0 * sub) >> p.log2_ctb_size) + ((tu.y0 * sub) >> p.log2_ctb_size) * g.ctbs_w;
       int r = cur_run[c];
-      bool extends = r >= 0 && rb[r].ctu == ctu && rb[r].tus.size() < 60000 &&
+      bool extends = r >= 0 && rb[r].ctu == ctu && rb[r].tus.size() < 256 &&        /* RUN_MAX_LVLS of k_run */
                      std::find(producers.begin(), producers.end(), r) != producers.end();
       if (extends && run_box < 64) {       // sparse-intra pictures: keep every run inside a run_box^2 bounding box
         const int bw = std::max(rb[r].x1, tu.x0 + nT) - std::min(rb[r].x0, (int)tu.x0);
@@ -406,6 +425,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
         r = (int)rb.size();
         rb.push_back(RunBuild{ c, ctu, tu.x0, tu.y0, tu.x0 + nT, tu.y0 + nT, 0, 0, 0, {}, {} });
         cur_run[c] = r;
+        llev = 1;
       }
       RunBuild& R = rb[r];
       R.x0 = std::min(R.x0, (int)tu.x0); R.y0 = std::min(R.y0, (int)tu.y0);
@@ -413,10 +433,11 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       R.wx1 = std::max(R.wx1, tu.x0 + 2 * nT); R.wy1 = std::max(R.wy1, tu.y0 + 2 * nT);    // top-right / bottom-left reach
       for (int pr : producers)
         if (pr != r && std::find(R.deps.begin(), R.deps.end(), pr) == R.deps.end()) R.deps.push_back(pr);
-      R.tus.push_back(t);
+      R.tus.push_back(t); R.llev.push_back((uint16_t)llev);
       for (int y = tu.y0 >> 2; y < (tu.y0 + nT) >> 2; y++)
         for (int x = tu.x0 >> 2; x < (tu.x0 + nT) >> 2; x++) {
           lvl[c][x + (size_t)y * map_w[c]] = (uint16_t)level;
+          llvl[c][x + (size_t)y * map_w[c]] = (uint16_t)llev;
           runmap[c][x + (size_t)y * map_w[c]] = r;
         }
       alg_intra += (int64_t)bpp * (4 * nT + 1) + (int64_t)bpp * nT * nT;
@@ -442,6 +463,8 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
 
   // ---- runs in dependency (ticket) order: producers first
   std::vector<RunTask> runs; std::vector<uint32_t> run_deps; std::vector<TuTask> run_tus, resid_only;
+  std::vector<uint16_t> run_lv;                  // per run: n_lvls + 1 TU indices (level boundaries)
+  int64_t sum_lvls = 0;
   size_t n_resid = 0;
   int max_rl = 0;
   {
@@ -459,7 +482,19 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       o.c_idx = (uint8_t)R.c; o.n_tus = (uint16_t)R.tus.size();
       o.first_tu = (uint32_t)run_tus.size(); o.dep_offset = (uint32_t)run_deps.size(); o.n_deps = (uint16_t)R.deps.size();
       o.res_offset = (uint32_t)n_resid;
-      for (TuTask tt : R.tus) {
+      // TUs of the run, stable-sorted by in-run level: a level's TUs only read earlier levels (or other runs)
+      int nl = 0; for (uint16_t l : R.llev) nl = std::max(nl, (int)l);
+      std::vector<uint16_t> lstart(nl + 2, 0);
+      for (uint16_t l : R.llev) lstart[l + 1]++;
+      for (int l = 0; l <= nl; l++) lstart[l + 1] += lstart[l];
+      if (nl > 256) { delete pic; return DE265HIP_ERROR_NOT_IMPLEMENTED; }      // RUN_MAX_LVLS of k_run
+      o.n_lvls = (uint16_t)nl; o.lvl_offset = (uint32_t)run_lv.size();
+      for (int l = 1; l <= nl + 1; l++) run_lv.push_back(lstart[l]);
+      sum_lvls += nl;
+      std::vector<TuTask> ordered(R.tus.size());
+      { std::vector<uint16_t> cur(lstart.begin(), lstart.end());
+        for (size_t i = 0; i < R.tus.size(); i++) ordered[cur[R.llev[i]]++] = R.tus[i]; }
+      for (TuTask tt : ordered) {
         if (tt.flags & DE265HIP_TU_CBF) {
           tt.resid_offset = (uint32_t)n_resid;
           n_resid += (size_t)1 << (2 * tt.log2_size);
@@ -615,6 +650,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   const size_t o_flags = L.add(nblk), o_qp = L.add(nblk), o_mot = L.add(nblk * sizeof(de265hip_motion));
   const size_t o_runs = L.add(runs.size() * sizeof(RunTask)), o_rdeps = L.add(run_deps.size() * 4);
   const size_t o_rtus = L.add(run_tus.size() * sizeof(TuTask));
+  const size_t o_rlv = L.add(run_lv.size() * 2);
   const size_t o_l0 = L.add(l0.size() * sizeof(TuTask));
   const size_t upload_bytes = L.total;                 // everything above is written by the host
   // device-only scratch: boundary strengths, residual blocks, run flags (no staging, no upload)
@@ -636,6 +672,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   put(o_sao, saos.data(), saos.size() * sizeof(SaoCtb));
   put(o_runs, runs.data(), runs.size() * sizeof(RunTask)); put(o_rdeps, run_deps.data(), run_deps.size() * 4);
   put(o_rtus, run_tus.data(), run_tus.size() * sizeof(TuTask));
+  put(o_rlv, run_lv.data(), run_lv.size() * 2);
   put(o_l0, l0.data(), l0.size() * sizeof(TuTask));
   put(o_flags, d->blk_flags, nblk); put(o_qp, d->blk_qp_y, nblk);
   if (d->blk_motion) put(o_mot, d->blk_motion, nblk * sizeof(de265hip_motion));
@@ -660,13 +697,14 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   pic->d_motion = (de265hip_motion*)(base + o_mot);
   pic->d_bs = base + o_bs;
   pic->d_runs = (RunTask*)(base + o_runs); pic->d_deps = (uint32_t*)(base + o_rdeps);
-  pic->d_run_tus = (TuTask*)(base + o_rtus); pic->d_sync = (uint32_t*)(base + o_sync);
+  pic->d_run_tus = (TuTask*)(base + o_rtus); pic->d_run_lv = (uint16_t*)(base + o_rlv); pic->d_sync = (uint32_t*)(base + o_sync);
   pic->d_l0 = (TuTask*)(base + o_l0); pic->d_resid = (int16_t*)(base + o_resid);
 
   const int64_t Pbytes = (int64_t)p.width * p.height * 3 / 2 * px_bytes(p.bit_depth_luma);
   pic->stats.n_levels = max_level + (pic->level_start[1] > 0 ? 1 : 0);
   pic->stats.n_tu_tasks = pic->n_tus; pic->stats.n_mc_tasks = pic->n_mc;
   pic->stats.n_runs = pic->n_runs; pic->stats.n_run_levels = max_rl;
+  pic->stats.n_in_run_levels = (int32_t)sum_lvls;
   pic->stats.device_bytes = (int64_t)L.total;
   pic->stats.alg_bytes_mc = alg_mc; pic->stats.alg_bytes_resid = alg_resid; pic->stats.alg_bytes_intra = alg_intra;
   pic->stats.alg_bytes_deblock = pic->any_edges ? 2 * Pbytes : 0;       // one read + one write
@@ -739,11 +777,11 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
       KTimer t(dec, DE265HIP_K_INTRA, 1);
       (void)hipMemsetAsync(pic->d_sync, 0, pic->sync_bytes, st);
       if (pic->run_box == 64)
-        hipLaunchKernelGGL((k_run<PX, 64>), dim3(pic->n_workers), dim3(64), 0, st, P, d0, d1, d2, pic->d_runs, pic->d_deps,
-                           pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->n_runs, pic->ticket_batch, dec->dbg);
+        hipLaunchKernelGGL((k_run<PX, 64>), dim3(pic->n_workers), dim3(64 * dec->run_waves), 0, st, P, d0, d1, d2, pic->d_runs, pic->d_deps,
+                           pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->d_run_lv, pic->n_runs, pic->ticket_batch, dec->dbg);
       else
-        hipLaunchKernelGGL((k_run<PX, 32>), dim3(pic->n_workers), dim3(64), 0, st, P, d0, d1, d2, pic->d_runs, pic->d_deps,
-                           pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->n_runs, pic->ticket_batch, dec->dbg);
+        hipLaunchKernelGGL((k_run<PX, 32>), dim3(pic->n_workers), dim3(64 * dec->run_waves), 0, st, P, d0, d1, d2, pic->d_runs, pic->d_deps,
+                           pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->d_run_lv, pic->n_runs, pic->ticket_batch, dec->dbg);
     }
   } else {
     if (nlev > 0 && pic->level_start[1] > pic->level_start[0]) {
@@ -810,9 +848,9 @@ int de265hip_decoder_sync(de265hip_decoder* dec)
   if (dec->dbg & 16) {                  // diagnostic build switch: dump and clear the phase stamps
     uint32_t st[16];
     HIPCHK(hipMemcpy(st, dec->d_err + 8, sizeof(st), hipMemcpyDeviceToHost), DE265HIP_ERROR_DECODING);
-    fprintf(stderr, "de265hip stamps: tus=%u cycles/TU: setup=%.0f border=%.0f filter=%.0f predict=%.0f coeff=%.0f resid=%.0f writeback=%.0f\n",
+    fprintf(stderr, "de265hip stamps: tus=%u cycles/TU: loop=%.0f gather=%.0f predict=%.0f finish=%.0f | run setup (per TU)=%.0f\n",
             st[7], st[0] / (double)st[7], st[1] / (double)st[7], st[2] / (double)st[7], st[3] / (double)st[7],
-            st[4] / (double)st[7], st[5] / (double)st[7], st[6] / (double)st[7]);
+            st[4] / (double)st[7]);
     (void)hipMemset(dec->d_err + 8, 0, sizeof(st));
   }
   if (err) { (void)hipMemset(dec->d_err, 0, 4); return DE265HIP_ERROR_DECODING; }

@@ -579,6 +579,44 @@ __device__ __forceinline__ void store4_from_u16(uint8_t* g, uint2 v)
                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// A TuTask as the run kernel holds it: every field in a scalar register.  The 32-byte record is fetched with
+// two 16-byte scalar loads (field-wise access makes the compiler fetch the byte fields with vector loads,
+// each followed by a vmcnt(0) that also waits for the previous TU's write-through stores).
+struct RunTu {
+  int x0, y0, log2_size, c_idx, flags, intra_mode, angle, inv_angle;
+  uint32_t resid_offset;
+  uint64_t avail;
+};
+// Staged form in LDS (16 bytes, written once per run by run_tu_pack, read back with one ds_read_b128):
+//   x: window x | window y << 8 | log2 << 16 | cbf << 19 | mode << 20      (mode >= 35 folded into DC)
+//   y: (uint8)angle | inv_angle << 16      z: avail bits 0-31      w: avail bit 32 | (resid offset in the run) << 1
+__device__ __forceinline__ uint4 run_tu_pack(const TuTask* __restrict__ tp, int k, int ax0, int wy0, uint32_t res_base)
+{
+  const uint4* q = reinterpret_cast<const uint4*>(tp + k);
+  const uint4 a = q[0], b = q[1];
+  const uint32_t x0 = a.x & 0xFFFF, y0 = a.x >> 16;
+  const uint32_t log2 = a.y & 0xFF, flags = (a.y >> 16) & 0xFF;
+  uint32_t mode = a.y >> 24; if (mode >= 35) mode = 1;
+  uint4 o;
+  o.x = (x0 - ax0) | ((y0 - wy0) << 8) | (log2 << 16) | ((flags & DE265HIP_TU_CBF) ? 1u << 19 : 0u) | (mode << 20);
+  o.y = (b.w & 0xFF) | (b.w & 0xFFFF0000u);
+  o.z = b.x;
+  o.w = (b.y & 1u) | ((b.z - res_base) << 1);
+  return o;
+}
+__device__ __forceinline__ RunTu run_tu_decode(const uint4& r, int c_idx)
+{
+  RunTu t;
+  const uint32_t w0 = __builtin_amdgcn_readfirstlane(r.x), w1 = __builtin_amdgcn_readfirstlane(r.y);
+  const uint32_t w2 = __builtin_amdgcn_readfirstlane(r.z), w3 = __builtin_amdgcn_readfirstlane(r.w);
+  t.x0 = w0 & 0xFF; t.y0 = (w0 >> 8) & 0xFF;
+  t.log2_size = (w0 >> 16) & 7; t.c_idx = c_idx; t.flags = (w0 >> 19) & 1; t.intra_mode = (w0 >> 20) & 63;
+  t.angle = (int)(int8_t)(w1 & 0xFF); t.inv_angle = (int)(int16_t)(w1 >> 16);
+  t.avail = (uint64_t)w2 | ((uint64_t)(w3 & 1) << 32);
+  t.resid_offset = w3 >> 1;
+  return t;
+}
+
 // Intra-only scratch of the run kernel (the residuals were computed beforehand).
 struct RunShared {
   int32_t b0[4 * 32 + 4];      // neighbours as fetched (+ substitution), centre at [64]
@@ -603,7 +641,7 @@ __device__ __forceinline__ int wave_sum_dpp(int v)
 // reconstructed samples into the window.  t is wave-uniform and in window coordinates.
 // Three dependent LDS round trips per TU (gather, [smooth], predict) instead of ten.
 template <int RUN_TILE_P>
-__device__ __forceinline__ void run_intra_tu(const PicDev& P, const TuTask& t, uint16_t* tile, RunShared& S,
+__device__ __forceinline__ void run_intra_tu(const PicDev& P, const RunTu& t, uint16_t* tile, RunShared& S,
                                              int lane, const int16_t* res, int bd, Stamper& st)
 {
   const int log2 = t.log2_size, nT = 1 << log2, nS = nT * nT;
@@ -695,9 +733,9 @@ __device__ __forceinline__ void run_intra_tu(const PicDev& P, const TuTask& t, u
       dst[x + y * RUN_TILE_P] = (uint16_t)clip3(0, maxv, pv + rs);
     }
   } else {                                           // angular, reference array evaluated in place
-    const int angle = c_intra_angle[mode];
+    const int angle = t.angle;
     const bool vert = mode >= 18;
-    const int inv = angle < 0 ? (int)c_inv_angle[mode - 11] : 0;
+    const int inv = t.inv_angle;
     const bool edge = (cIdx == 0 && nT < 32) && (mode == 26 || mode == 10);
     const int b0 = bord[0], bp1 = bord[1], bm1 = bord[-1];
     for (int s = lane; s < nS; s += 64) {
@@ -737,12 +775,12 @@ template <> __device__ __forceinline__ void store4_packed<uint8_t>(uint8_t* g, i
 { store4_from_u16(g, make_uint2((uint32_t)lo, (uint32_t)hi)); }
 
 template <int LOG2, int RUN_TILE_P, typename PX>
-__device__ __forceinline__ void run_intra_small(const PicDev& P, const TuTask& t, uint16_t* tile, int lane,
-                                                const int16_t* res, int bd, PX* gdst, int gstride)
+__device__ __forceinline__ void run_intra_small(const PicDev& P, const RunTu& t, uint16_t* tile, int lane,
+                                                const int16_t* res, int bd, PX* gdst, int gstride, Stamper& st)
 {
   constexpr int nT = 1 << LOG2, nS = nT * nT, NB = 4 * nT + 1, C = 2 * nT;       // C: lane of border[0]
   const int xB = t.x0, yB = t.y0, cIdx = t.c_idx;
-  const uint64_t avail = t.avail;
+  const uint32_t avail = (uint32_t)t.avail;          // 2nT/4*2 + 1 <= 9 units
   const int maxv = (1 << bd) - 1;
   const int rs = (res != nullptr && lane < nS) ? (int)res[lane] : 0;              // independent of the chain: issued first
 
@@ -751,16 +789,16 @@ __device__ __forceinline__ void run_intra_small(const PicDev& P, const TuTask& t
   if (avail != 0) {
     const int p = min(lane, NB - 1), i = p - C;
     int src = i;
-    if (avail != ((2ull << nT) - 1ull)) {             // not every unit available: nearest available one before
+    if (avail != ((2u << nT) - 1u)) {                 // not every unit available: nearest available one before
       constexpr int cornerUnit = nT >> 1;
       const int u = (i < 0) ? (p >> 2) : (i == 0 ? cornerUnit : cornerUnit + 1 + ((i - 1) >> 2));
       if (!((avail >> u) & 1)) {
-        const uint64_t below = avail & ((2ull << u) - 1ull);
+        const uint32_t below = avail & ((2u << u) - 1u);
         if (below) {
-          const int su = 63 - __clzll((long long)below);
+          const int su = 31 - __clz((int)below);
           src = (su < cornerUnit) ? (-C + 4 * su + 3) : (su == cornerUnit ? 0 : 4 * (su - cornerUnit));
         } else {
-          const int su = __ffsll((long long)avail) - 1;
+          const int su = __ffs((int)avail) - 1;
           src = (su < cornerUnit) ? (-C + 4 * su) : (su == cornerUnit ? 0 : 4 * (su - cornerUnit - 1) + 1);
         }
       }
@@ -769,6 +807,7 @@ __device__ __forceinline__ void run_intra_small(const PicDev& P, const TuTask& t
     const int sy = src < 0 ? yB - src - 1 : yB - 1;
     bv = tile[sx + sy * RUN_TILE_P];
   }
+  st.mark(1);
 
   const int mode = t.intra_mode >= 35 ? 1 : t.intra_mode;
   if (LOG2 == 3 && cIdx == 0 && mode != 1 && min(abs(mode - 26), abs(mode - 10)) > 7) {
@@ -793,9 +832,9 @@ __device__ __forceinline__ void run_intra_small(const PicDev& P, const TuTask& t
     pv = dc;
     if (cIdx == 0) pv = (x | y) == 0 ? corner : (y == 0 ? (tp + 3 * dc + 2) >> 2 : (x == 0 ? (l + 3 * dc + 2) >> 2 : dc));
   } else {
-    const int angle = c_intra_angle[mode];
+    const int angle = t.angle;
     const bool vert = mode >= 18;
-    const int inv = angle < 0 ? (int)c_inv_angle[mode - 11] : 0;
+    const int inv = t.inv_angle;
     const int a = vert ? y : x, b = vert ? x : y;
     const int iIdx = ((a + 1) * angle) >> 5, iFact = ((a + 1) * angle) & 31;
     const int i0 = b + iIdx + 1, i1 = i0 + 1;
@@ -812,6 +851,7 @@ __device__ __forceinline__ void run_intra_small(const PicDev& P, const TuTask& t
     }
   }
 #undef BORD
+  st.mark(2);
   const int outv = clip3(0, maxv, pv + rs);
   if (lane < nS) tile[xB + x + (yB + y) * RUN_TILE_P] = (uint16_t)outv;
   // write-back straight from the registers: four adjacent lanes are packed with two DPP row shifts and
@@ -822,45 +862,53 @@ __device__ __forceinline__ void run_intra_small(const PicDev& P, const TuTask& t
   WAVE_BARRIER_ONLY();
 }
 
+#define RUN_MAX_LVLS 256                // a run has at most 256 TUs (64x64 luma of 4x4s), hence at most 256 levels
+
 template <typename PX, int BOX>
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(64 * RUN_WAVES)
 void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __restrict__ runs,
            const uint32_t* __restrict__ deps, uint32_t* sync, uint32_t* err, const TuTask* __restrict__ tasks,
-           const int16_t* __restrict__ resid, int n_runs, int batch, int dbg)
+           const int16_t* __restrict__ resid, const uint16_t* __restrict__ lvtab, int n_runs, int batch, int dbg)
 {
   constexpr int RUN_TILE_H = RUN_TILE_H_OF(BOX), RUN_TILE_P = RUN_TILE_P_OF(BOX);
-  __shared__ RunShared S;
+  __shared__ RunShared S[RUN_WAVES];
   __shared__ __attribute__((aligned(16))) uint16_t tile[RUN_TILE_H * RUN_TILE_P];
   __shared__ __attribute__((aligned(16))) int16_t s_res[BOX * BOX];
+  __shared__ uint16_t s_lv[RUN_MAX_LVLS + 2];
+  __shared__ uint4 s_task[RUN_MAX_LVLS];          // the run's TUs, packed (run_tu_pack)
   __shared__ uint32_t s_ticket;
-  const int lane = threadIdx.x;
-  // persistent worker: the grid is only as wide as the picture's widest dependency level
-  // (waiting wavefronts would just occupy LDS), every worker pulls tickets until none are left
-  // tickets are drawn `batch` at a time (one atomic per batch) and processed in increasing order,
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nthr = blockDim.x, nw = nthr >> 6;
+  // persistent workgroup: the grid is only as wide as the picture's widest dependency level
+  // (waiting workgroups would just occupy LDS), every one pulls tickets until none are left.
+  // Tickets are drawn `batch` at a time (one atomic per batch) and processed in increasing order,
   // which keeps the no-deadlock argument: the smallest unfinished ticket is always owned by a
-  // running wavefront that is not waiting on anything larger.
+  // running workgroup that is not waiting on anything larger.
   uint32_t next_ticket = 0, batch_end = 0;
   for (;;) {
   if (next_ticket == batch_end) {
-    if (lane == 0) s_ticket = atomicAdd(&sync[0], (uint32_t)batch);
+    if (tid == 0) s_ticket = atomicAdd(&sync[0], (uint32_t)batch);
     __syncthreads();
     next_ticket = __builtin_amdgcn_readfirstlane(s_ticket);
     batch_end = next_ticket + batch;
-    __syncthreads();
   }
-  const uint32_t ticket = next_ticket++;                               // wave-uniform: scalar loads/branches below
+  __syncthreads();                                                     // the previous run's LDS is free
+  const uint32_t ticket = next_ticket++;                               // uniform: scalar loads/branches below
   if (ticket >= (uint32_t)n_runs) break;
   const RunTask run = runs[ticket];
-  Stamper st{ (dbg & 16) ? err + 8 : nullptr, clock64(), lane };
+  Stamper st{ ((dbg & 16) && wave == 0) ? err + 8 : nullptr, clock64(), lane };
 
-  // residuals of the whole run: one contiguous range, independent of the producers -> fetch before waiting
+  // residuals and level table of the whole run: contiguous, independent of the producers -> fetch before waiting
   const uint32_t res_base = run.res_offset;
   if (!(dbg & 8))
-  for (int i = lane * 8; i < (int)run.res_len; i += 512)
+  for (int i = tid * 8; i < (int)run.res_len; i += nthr * 8)
     *reinterpret_cast<uint4*>(&s_res[i]) = *reinterpret_cast<const uint4*>(&resid[res_base + i]);
+  const int n_lvls = min((int)run.n_lvls, RUN_MAX_LVLS);
+  for (int i = tid; i <= n_lvls; i += nthr) s_lv[i] = lvtab[run.lvl_offset + i];
 
   if (run.n_deps) {
-    for (int i = lane; i < run.n_deps; i += 64) {
+    for (int i = tid; i < run.n_deps; i += nthr) {
       const uint32_t* flag = &sync[2 + deps[run.dep_offset + i]];
       int spins = 0;
       while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
@@ -886,12 +934,14 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   const int ax0 = wx0 & ~7;                                  // -8 when the run touches the left picture edge
   const int nchx = (wx1 - ax0 + 7) >> 3, nrows = wy1 - wy0;
   const int nchunks = nchx * nrows;
+  const int n_tus = min((int)run.n_tus, RUN_MAX_LVLS);
+  for (int i = tid; i < n_tus; i += nthr) s_task[i] = run_tu_pack(tasks + run.first_tu, i, ax0, wy0, res_base);
   if (!(dbg & 8))
-  for (int base = 0; base < nchunks; base += 256) {
+  for (int base = 0; base < nchunks; base += 4 * nthr) {
     uint4 v[4]; int off[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      int idx = base + u * 64 + lane;
+      int idx = base + u * nthr + tid;
       off[u] = -1;
       if (idx < nchunks) {
         int r = idx / nchx, cx = idx - r * nchx;
@@ -907,36 +957,47 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
     for (int u = 0; u < 4; u++)
       if (off[u] >= 0) *reinterpret_cast<uint4*>(&tile[off[u]]) = v[u];
   }
-  LDS_SYNC();
+  __syncthreads();
 
   // ---- the dependency chain: gather -> (smooth) -> predict -> + residual, all inside LDS / registers.
+  // The run's TUs are sorted by in-run dependency level; the TUs of one level are independent, so the
+  // workgroup's wavefronts take them round-robin and meet at a barrier before the next level.
   // Tasks come through the scalar cache (uniform address), the next one is requested a TU ahead.
+  st.mark(4);
   if (!(dbg & 4)) {
-    const TuTask* tp = tasks + run.first_tu;
-    TuTask cur = tp[0];
-    for (int k = 0; k < (int)run.n_tus; k++) {
-      const TuTask nxt = tp[min(k + 1, (int)run.n_tus - 1)];
-      TuTask t = cur;
-      const int gx0 = t.x0, gy0 = t.y0;
-      t.x0 = (uint16_t)(gx0 - ax0); t.y0 = (uint16_t)(gy0 - wy0);      // window coordinates
-      st.mark(0);
-      const int16_t* rp = (t.flags & DE265HIP_TU_CBF) ? &s_res[t.resid_offset - res_base] : nullptr;
-      PX* gdst = plane + gx0 + gy0 * stride;
-      if (t.log2_size == 2 && !(dbg & 512)) run_intra_small<2, RUN_TILE_P, PX>(P, t, tile, lane, rp, bd, gdst, stride);
-      else if (t.log2_size == 3 && !(dbg & 512)) run_intra_small<3, RUN_TILE_P, PX>(P, t, tile, lane, rp, bd, gdst, stride);
-      else {
-        run_intra_tu<RUN_TILE_P>(P, t, tile, S, lane, rp, bd, st);
-        // write the finished TU back, 4 samples per lane (only the run's own samples ever leave the window)
-        const int log2 = t.log2_size, nT = 1 << log2, l4 = log2 - 2;
-        for (int s = lane; s < (nT * nT) >> 2; s += 64) {
-          const int y = s >> l4, x = (s & ((1 << l4) - 1)) << 2;
-          const uint2 v = *reinterpret_cast<const uint2*>(&tile[(t.y0 + y) * RUN_TILE_P + t.x0 + x]);
-          store4_from_u16(gdst + x + y * stride, v);
+    const int last = n_tus - 1;
+    int pre_k = min(wave, last);
+    uint4 pre = s_task[pre_k];
+    int lv_b = 0;
+    int lv_e = __builtin_amdgcn_readfirstlane((int)s_lv[1]);
+    int lv_n = __builtin_amdgcn_readfirstlane((int)s_lv[min(2, n_lvls)]);
+    for (int l = 0; l < n_lvls; l++) {
+      const int lv_nn = s_lv[min(l + 3, n_lvls)];                       // level bounds are read two levels ahead
+      for (int k = lv_b + wave; k < lv_e; k += nw) {
+        RunTu t = run_tu_decode((k == pre_k) ? pre : s_task[k], c);
+        pre_k = min((k + nw < lv_e) ? k + nw : ((lv_e + wave < lv_n) ? lv_e + wave : last), last);
+        pre = s_task[pre_k];                                            // LDS returns in order: no extra wait later
+        const int gx0 = t.x0 + ax0, gy0 = t.y0 + wy0;
+        st.mark(0);
+        const int16_t* rp = t.flags ? &s_res[t.resid_offset] : nullptr;
+        PX* gdst = plane + gx0 + gy0 * stride;
+        if (t.log2_size == 2 && !(dbg & 512)) run_intra_small<2, RUN_TILE_P, PX>(P, t, tile, lane, rp, bd, gdst, stride, st);
+        else if (t.log2_size == 3 && !(dbg & 512)) run_intra_small<3, RUN_TILE_P, PX>(P, t, tile, lane, rp, bd, gdst, stride, st);
+        else {
+          run_intra_tu<RUN_TILE_P>(P, t, tile, S[wave], lane, rp, bd, st);
+          // write the finished TU back, 4 samples per lane (only the run's own samples ever leave the window)
+          const int log2 = t.log2_size, nT = 1 << log2, l4 = log2 - 2;
+          for (int s = lane; s < (nT * nT) >> 2; s += 64) {
+            const int y = s >> l4, x = (s & ((1 << l4) - 1)) << 2;
+            const uint2 v = *reinterpret_cast<const uint2*>(&tile[(t.y0 + y) * RUN_TILE_P + t.x0 + x]);
+            store4_from_u16(gdst + x + y * stride, v);
+          }
         }
+        st.mark(3);
+        if (st.buf && lane == 0) atomicAdd(&st.buf[7], 1u);
       }
-      st.mark(3);
-      if (st.buf && lane == 0) atomicAdd(&st.buf[7], 1u);
-      cur = nxt;
+      lv_b = lv_e; lv_e = lv_n; lv_n = __builtin_amdgcn_readfirstlane(lv_nn);
+      if (l + 1 < n_lvls) __syncthreads();
     }
   }
 
@@ -944,7 +1005,8 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   // (MI355X_MICROARCH.md, valid forms: sc1 payload stores + vmcnt(0) + flag on the producer,
   //  poll + agent acquire + plain loads on the consumer; no L2 write-back fence needed.)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (lane == 0) __hip_atomic_store(&sync[2 + ticket], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(&sync[2 + ticket], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -971,10 +1033,10 @@ template __global__ void k_tu<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, con
                                        const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
 template __global__ void k_tu<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int,
                                         const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
-template __global__ void k_run<uint8_t, 64>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, int, int, int);
-template __global__ void k_run<uint16_t, 64>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, int, int, int);
-template __global__ void k_run<uint8_t, 32>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, int, int, int);
-template __global__ void k_run<uint16_t, 32>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, int, int, int);
+template __global__ void k_run<uint8_t, 64>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, const uint16_t*, int, int, int);
+template __global__ void k_run<uint16_t, 64>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, const uint16_t*, int, int, int);
+template __global__ void k_run<uint8_t, 32>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, const uint16_t*, int, int, int);
+template __global__ void k_run<uint16_t, 32>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, const uint16_t*, int, int, int);
 template __global__ void k_fn_residual<uint8_t>(int, int, int, uint8_t*, int, const int32_t*, const int16_t*);
 template __global__ void k_fn_residual<uint16_t>(int, int, int, uint16_t*, int, const int32_t*, const int16_t*);
 

@@ -6,7 +6,7 @@ import pytest
 
 import pyoracle
 import pysynth
-from libde265_amd import _abi
+from libde265_amd import _abi, backend
 
 pytestmark = pytest.mark.gpu
 

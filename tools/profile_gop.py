@@ -38,6 +38,6 @@ for k, (sp, p) in enumerate(pics):
         dec.run(p, 2)
     kt = dec.kernel_times(reset=True)
     s = p.stats()
-    print("pic %d type %s tus %d mc %d levels %d runs %d runlevels %d | " % (
-        k, "I" if k == 0 else "B", s.n_tu_tasks, s.n_mc_tasks, s.n_levels, s.n_runs, s.n_run_levels) +
+    print("pic %d type %s tus %d mc %d levels %d runs %d runlevels %d inrunlevels %d | " % (
+        k, "I" if k == 0 else "B", s.n_tu_tasks, s.n_mc_tasks, s.n_levels, s.n_runs, s.n_run_levels, s.n_in_run_levels) +
           " ".join("%s=%.1fus" % (n, 1e3 * v[0] / a.reps) for n, v in kt.items() if v[1]))
