@@ -40,9 +40,9 @@ struct TuTask {
   uint16_t x0, y0;
   uint8_t  log2_size, c_idx, flags, intra_mode;
   int8_t   qp;
-  uint8_t  pad;
+  uint8_t  run_level;      // run mode: in-run dependency level of the TU (0-based)
   uint16_t n_coeff;
-  uint32_t coeff_offset;
+  uint32_t coeff_offset;   // run mode (run-ordered array only): sample offset of the TU inside its run
   uint64_t avail;
   uint32_t resid_offset;   // run mode: where the precomputed int16 residual block of an intra TU lives
   int8_t   angle;          // run mode: intraPredAngle of the mode (intrapred.cc:742-760), host-resolved so that
@@ -75,11 +75,12 @@ struct RunTask {
   uint32_t first_tu;         // into the run-ordered TuTask array
   uint32_t dep_offset;       // into the producer-run id array
   uint16_t n_deps, n_lvls;  // n_lvls: in-run dependency levels (TUs of one level are independent of each other)
-  uint32_t res_offset;       // the run's residual blocks: one contiguous int16 range (multiple of 8 long)
-  uint32_t res_len;
-  uint32_t lvl_offset;       // into the uint16 level table: n_lvls + 1 TU indices (relative to first_tu)
+  uint32_t res_offset;       // the run's residual blocks (TUs with coefficients only): one contiguous int16 range
+  uint32_t n_samples;        // samples of all TUs of the run
+  uint16_t wave_end[4];      // the run's TUs are stored as one list per wavefront of the workgroup (each list in
+                             // level order): list w is [wave_end[w-1], wave_end[w]) relative to first_tu
 };
-static_assert(sizeof(RunTask) == 40, "RunTask layout");
+static_assert(sizeof(RunTask) == 44, "RunTask layout");
 
 // Per-CTB SAO record, fully resolved on the host (slice flags applied, slice/tile permissions of the
 // 3x3 CTB neighbourhood evaluated): one 24-byte load per lane instead of a chain of dependent loads.

@@ -72,7 +72,6 @@ struct de265hip_picture {
   uint8_t* d_flags = nullptr; int8_t* d_qp = nullptr; de265hip_motion* d_motion = nullptr;
   uint8_t* d_bs = nullptr;
   SaoCtb* d_sao = nullptr;
-  uint16_t* d_run_lv = nullptr;
   RunTask* d_runs = nullptr; uint32_t* d_deps = nullptr; uint32_t* d_sync = nullptr;
   TuTask* d_run_tus = nullptr;
   int n_l0_size[4] = { 0, 0, 0, 0 };          // TU count per size in d_l0 (sorted 32,16,8,4)
@@ -377,7 +376,9 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   // sparse intra: small runs (<= 32x32) need a quarter of the LDS, so ~3x more of them are in flight.
   // (measured: with <= 32x32 runs and 2816 workers a 4K B picture got slower, 231 -> 273 us: the longer
   //  producer chains cost more than the extra residency buys, so every picture uses 64x64 runs for now)
-  const int run_box = 64;
+  // DE265HIP_RUN_BOX_B: run bounding box for pictures with inter PUs (experiment)
+  const char* rbenv = getenv("DE265HIP_RUN_BOX_B");
+  const int run_box = (d->n_pus > 0 && rbenv && atoi(rbenv) == 32) ? 32 : 64;
   pic->run_box = run_box;
   for (int i = 0; i < d->n_tus; i++) {
     const de265hip_tu& tu = d->tus[i];
@@ -463,7 +464,6 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
 
   // ---- runs in dependency (ticket) order: producers first
   std::vector<RunTask> runs; std::vector<uint32_t> run_deps; std::vector<TuTask> run_tus, resid_only;
-  std::vector<uint16_t> run_lv;                  // per run: n_lvls + 1 TU indices (level boundaries)
   int64_t sum_lvls = 0;
   size_t n_resid = 0;
   int max_rl = 0;
@@ -482,28 +482,44 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       o.c_idx = (uint8_t)R.c; o.n_tus = (uint16_t)R.tus.size();
       o.first_tu = (uint32_t)run_tus.size(); o.dep_offset = (uint32_t)run_deps.size(); o.n_deps = (uint16_t)R.deps.size();
       o.res_offset = (uint32_t)n_resid;
-      // TUs of the run, stable-sorted by in-run level: a level's TUs only read earlier levels (or other runs)
+      // TUs of the run: the TUs of one in-run level are independent of each other and are dealt round-robin to
+      // the wavefronts of the workgroup; stored as one list per wavefront, each in level order, level in the record
       int nl = 0; for (uint16_t l : R.llev) nl = std::max(nl, (int)l);
-      std::vector<uint16_t> lstart(nl + 2, 0);
-      for (uint16_t l : R.llev) lstart[l + 1]++;
-      for (int l = 0; l <= nl; l++) lstart[l + 1] += lstart[l];
-      if (nl > 256) { delete pic; return DE265HIP_ERROR_NOT_IMPLEMENTED; }      // RUN_MAX_LVLS of k_run
-      o.n_lvls = (uint16_t)nl; o.lvl_offset = (uint32_t)run_lv.size();
-      for (int l = 1; l <= nl + 1; l++) run_lv.push_back(lstart[l]);
+      if (nl > 256) { delete pic; return DE265HIP_ERROR_NOT_IMPLEMENTED; }      // RUN_MAX_TUS of k_run
+      o.n_lvls = (uint16_t)nl;
       sum_lvls += nl;
-      std::vector<TuTask> ordered(R.tus.size());
-      { std::vector<uint16_t> cur(lstart.begin(), lstart.end());
-        for (size_t i = 0; i < R.tus.size(); i++) ordered[cur[R.llev[i]]++] = R.tus[i]; }
+      std::vector<TuTask> ordered; ordered.reserve(R.tus.size());
+      {
+        const int nwv = dec->run_waves;
+        std::vector<int> rank(nl + 1, 0);
+        std::vector<std::vector<TuTask>> lists(nwv);
+        for (size_t i = 0; i < R.tus.size(); i++) {
+          TuTask tt = R.tus[i];
+          tt.run_level = (uint8_t)(R.llev[i] - 1);
+          lists[rank[R.llev[i]]++ % nwv].push_back(tt);
+        }
+        for (int w = 0; w < 4; w++) {
+          if (w < nwv) {
+            std::stable_sort(lists[w].begin(), lists[w].end(),
+                             [](const TuTask& a, const TuTask& b) { return a.run_level < b.run_level; });
+            ordered.insert(ordered.end(), lists[w].begin(), lists[w].end());
+          }
+          o.wave_end[w] = (uint16_t)ordered.size();
+        }
+      }
+      uint32_t samp = 0;
       for (TuTask tt : ordered) {
+        const uint32_t coeff_offset = tt.coeff_offset;
+        tt.coeff_offset = samp; samp += 1u << (2 * tt.log2_size);
         if (tt.flags & DE265HIP_TU_CBF) {
           tt.resid_offset = (uint32_t)n_resid;
           n_resid += (size_t)1 << (2 * tt.log2_size);
-          TuTask ro = tt; ro.flags |= D265_TU_RESID_ONLY;
+          TuTask ro = tt; ro.flags |= D265_TU_RESID_ONLY; ro.coeff_offset = coeff_offset;
           resid_only.push_back(ro);
         }
         run_tus.push_back(tt);
       }
-      o.res_len = (uint32_t)(n_resid - o.res_offset);
+      o.n_samples = samp;
       for (int dp : R.deps) run_deps.push_back((uint32_t)newidx[dp]);
     }
   }
@@ -514,7 +530,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     for (auto& R : rb) width[R.level]++;
     int widest = 0; for (int wv : width) widest = std::max(widest, wv);
     const char* wenv = getenv("DE265HIP_RUN_WORKERS");
-    int cap = wenv ? atoi(wenv) : (run_box == 64 ? 1024 : 2816);      // LDS-limited residency: 4 resp. 11 per CU
+    int cap = wenv ? atoi(wenv) : (run_box == 64 ? 768 : 2048);      // LDS-limited residency: 3 resp. 8 workgroups per CU
     pic->n_workers = std::min(pic->n_runs, std::max(64, std::min(cap, widest + widest / 4)));
     const char* benv = getenv("DE265HIP_TICKET_BATCH");
     pic->ticket_batch = benv ? std::max(1, atoi(benv)) : 1;   // measured: drawing 4/8 tickets per atomic costs 46 % / 100 % on a 4K B picture (serialises dependants)
@@ -650,7 +666,6 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   const size_t o_flags = L.add(nblk), o_qp = L.add(nblk), o_mot = L.add(nblk * sizeof(de265hip_motion));
   const size_t o_runs = L.add(runs.size() * sizeof(RunTask)), o_rdeps = L.add(run_deps.size() * 4);
   const size_t o_rtus = L.add(run_tus.size() * sizeof(TuTask));
-  const size_t o_rlv = L.add(run_lv.size() * 2);
   const size_t o_l0 = L.add(l0.size() * sizeof(TuTask));
   const size_t upload_bytes = L.total;                 // everything above is written by the host
   // device-only scratch: boundary strengths, residual blocks, run flags (no staging, no upload)
@@ -672,7 +687,6 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   put(o_sao, saos.data(), saos.size() * sizeof(SaoCtb));
   put(o_runs, runs.data(), runs.size() * sizeof(RunTask)); put(o_rdeps, run_deps.data(), run_deps.size() * 4);
   put(o_rtus, run_tus.data(), run_tus.size() * sizeof(TuTask));
-  put(o_rlv, run_lv.data(), run_lv.size() * 2);
   put(o_l0, l0.data(), l0.size() * sizeof(TuTask));
   put(o_flags, d->blk_flags, nblk); put(o_qp, d->blk_qp_y, nblk);
   if (d->blk_motion) put(o_mot, d->blk_motion, nblk * sizeof(de265hip_motion));
@@ -697,7 +711,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   pic->d_motion = (de265hip_motion*)(base + o_mot);
   pic->d_bs = base + o_bs;
   pic->d_runs = (RunTask*)(base + o_runs); pic->d_deps = (uint32_t*)(base + o_rdeps);
-  pic->d_run_tus = (TuTask*)(base + o_rtus); pic->d_run_lv = (uint16_t*)(base + o_rlv); pic->d_sync = (uint32_t*)(base + o_sync);
+  pic->d_run_tus = (TuTask*)(base + o_rtus); pic->d_sync = (uint32_t*)(base + o_sync);
   pic->d_l0 = (TuTask*)(base + o_l0); pic->d_resid = (int16_t*)(base + o_resid);
 
   const int64_t Pbytes = (int64_t)p.width * p.height * 3 / 2 * px_bytes(p.bit_depth_luma);
@@ -778,10 +792,10 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
       (void)hipMemsetAsync(pic->d_sync, 0, pic->sync_bytes, st);
       if (pic->run_box == 64)
         hipLaunchKernelGGL((k_run<PX, 64>), dim3(pic->n_workers), dim3(64 * dec->run_waves), 0, st, P, d0, d1, d2, pic->d_runs, pic->d_deps,
-                           pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->d_run_lv, pic->n_runs, pic->ticket_batch, dec->dbg);
+                           pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->n_runs, pic->ticket_batch, dec->dbg);
       else
         hipLaunchKernelGGL((k_run<PX, 32>), dim3(pic->n_workers), dim3(64 * dec->run_waves), 0, st, P, d0, d1, d2, pic->d_runs, pic->d_deps,
-                           pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->d_run_lv, pic->n_runs, pic->ticket_batch, dec->dbg);
+                           pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->n_runs, pic->ticket_batch, dec->dbg);
     }
   } else {
     if (nlev > 0 && pic->level_start[1] > pic->level_start[0]) {
@@ -848,9 +862,9 @@ int de265hip_decoder_sync(de265hip_decoder* dec)
   if (dec->dbg & 16) {                  // diagnostic build switch: dump and clear the phase stamps
     uint32_t st[16];
     HIPCHK(hipMemcpy(st, dec->d_err + 8, sizeof(st), hipMemcpyDeviceToHost), DE265HIP_ERROR_DECODING);
-    fprintf(stderr, "de265hip stamps: tus=%u cycles/TU: loop=%.0f gather=%.0f predict=%.0f finish=%.0f | run setup (per TU)=%.0f\n",
-            st[7], st[0] / (double)st[7], st[1] / (double)st[7], st[2] / (double)st[7], st[3] / (double)st[7],
-            st[4] / (double)st[7]);
+    const double n = st[7] ? (double)st[7] : 1.0;
+    fprintf(stderr, "de265hip stamps: runs=%u cycles/run: record=%.0f tasks=%.0f prepare=%.0f wait=%.0f window=%.0f chain=%.0f drain=%.0f\n",
+            st[7], st[0] / n, st[1] / n, st[2] / n, st[3] / n, st[4] / n, st[5] / n, st[6] / n);
     (void)hipMemset(dec->d_err + 8, 0, sizeof(st));
   }
   if (err) { (void)hipMemset(dec->d_err, 0, 4); return DE265HIP_ERROR_DECODING; }

@@ -33,18 +33,37 @@ __device__ __forceinline__ int clip3(int lo, int hi, int v) { return min(max(v, 
 
 // Diagnostic cycle stamps (DE265HIP_DEBUG bit 16): per-phase s_memtime deltas summed into a
 // debug buffer that nothing else reads.  stamp == nullptr in normal runs.
+// Cycle stamps of the run kernel's phases: a diagnostic that is compiled in only with -DD265_STAMPS
+// (DE265HIP_EXTRA_CXXFLAGS) and switched on with DE265HIP_DEBUG=16; otherwise every call is empty.
+#ifdef D265_STAMPS
 struct Stamper {
   uint32_t* buf; long long t0; int lane;
+  uint32_t acc[8];                    // per-phase cycle sums, kept in registers (phase numbers are literals)
   __device__ __forceinline__ void mark(int phase)
   {
     if (buf) {
       LDS_SYNC();
       long long t = clock64();
-      if (lane == 0) atomicAdd(&buf[phase], (uint32_t)(t - t0));
+      acc[phase] += (uint32_t)(t - t0);
       t0 = clock64();
     }
   }
+  __device__ __forceinline__ void count() { if (buf) acc[7]++; }
+  __device__ __forceinline__ void flush()        // one atomic per phase and run: the stamps must not load the fabric
+  {
+    if (buf && lane == 0)
+      for (int i = 0; i < 8; i++) if (acc[i]) atomicAdd(&buf[i], acc[i]);
+  }
 };
+#else
+struct Stamper {
+  uint32_t* buf; long long t0; int lane;
+  uint32_t acc[8];
+  __device__ __forceinline__ void mark(int) {}
+  __device__ __forceinline__ void count() {}
+  __device__ __forceinline__ void flush() {}
+};
+#endif
 
 template <typename PX>
 struct TuShared {
@@ -536,7 +555,7 @@ void k_tu(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const TuTask* __re
   __shared__ TuShared<PX> S;
   const TuTask t = tasks[first + blockIdx.x];
   const PlaneRef pr = t.c_idx == 0 ? pl0 : (t.c_idx == 1 ? pl1 : pl2);
-  Stamper st{ nullptr, 0, (int)threadIdx.x };
+  Stamper st{ nullptr, 0, (int)threadIdx.x, {} };
   tu_reconstruct<PX>(P, t, (PX*)pr.ptr, pr.stride, S, threadIdx.x, coeff_val, coeff_pos, scaling, true, st, resid);
 }
 
@@ -588,39 +607,46 @@ struct RunTu {
   uint64_t avail;
 };
 // Staged form in LDS (16 bytes, written once per run by run_tu_pack, read back with one ds_read_b128):
-//   x: window x | window y << 8 | log2 << 16 | cbf << 19 | mode << 20      (mode >= 35 folded into DC)
-//   y: (uint8)angle | inv_angle << 16      z: avail bits 0-31      w: avail bit 32 | (resid offset in the run) << 1
-__device__ __forceinline__ uint4 run_tu_pack(const TuTask* __restrict__ tp, int k, int ax0, int wy0, uint32_t res_base)
+//   x: window x | window y << 8 | log2 << 16 | cbf << 19 | mode << 20 | smooth << 26 | kind << 27 | vertical << 29
+//      (mode >= 35 folded into DC; kind 0 planar, 1 DC, 2 angular, 3 angular with the mode 10/26 edge filter)
+//   y: (uint8)angle | in-run level << 8 | inv_angle << 16
+//   z: avail bits 0-31
+//   w: avail bit 32 | (offset in the run's residual range) << 1 | (sample offset in the run) << 16
+#define RTU_SMOOTH (1u << 26)
+__device__ __forceinline__ uint4 run_tu_pack(const TuTask* __restrict__ tp, int k, int ax0, int wy0, uint32_t res_base, int c)
 {
   const uint4* q = reinterpret_cast<const uint4*>(tp + k);
   const uint4 a = q[0], b = q[1];
   const uint32_t x0 = a.x & 0xFFFF, y0 = a.x >> 16;
   const uint32_t log2 = a.y & 0xFF, flags = (a.y >> 16) & 0xFF;
   uint32_t mode = a.y >> 24; if (mode >= 35) mode = 1;
+  const uint32_t level = (a.z >> 8) & 0xFF, samp = a.w;
+  const int md = min(abs((int)mode - 26), abs((int)mode - 10));
+  const uint32_t kind = mode == 0 ? 0u : (mode == 1 ? 1u : ((c == 0 && md == 0 && log2 < 5) ? 3u : 2u));
+  const uint32_t smooth = (c == 0 && log2 == 3 && mode != 1 && md > 7) ? RTU_SMOOTH : 0u;
   uint4 o;
-  o.x = (x0 - ax0) | ((y0 - wy0) << 8) | (log2 << 16) | ((flags & DE265HIP_TU_CBF) ? 1u << 19 : 0u) | (mode << 20);
-  o.y = (b.w & 0xFF) | (b.w & 0xFFFF0000u);
+  o.x = (x0 - ax0) | ((y0 - wy0) << 8) | (log2 << 16) | ((flags & DE265HIP_TU_CBF) ? 1u << 19 : 0u) | (mode << 20) |
+        smooth | (kind << 27) | (mode >= 18 ? 1u << 29 : 0u);
+  o.y = (b.w & 0xFF) | (level << 8) | (b.w & 0xFFFF0000u);
   o.z = b.x;
-  o.w = (b.y & 1u) | ((b.z - res_base) << 1);
+  o.w = (b.y & 1u) | (((b.z - res_base) & 0x1FFFu) << 1) | (samp << 16);
   return o;
 }
-__device__ __forceinline__ RunTu run_tu_decode(const uint4& r, int c_idx)
+__device__ __forceinline__ RunTu run_tu_unpack(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, int c_idx)
 {
   RunTu t;
-  const uint32_t w0 = __builtin_amdgcn_readfirstlane(r.x), w1 = __builtin_amdgcn_readfirstlane(r.y);
-  const uint32_t w2 = __builtin_amdgcn_readfirstlane(r.z), w3 = __builtin_amdgcn_readfirstlane(r.w);
   t.x0 = w0 & 0xFF; t.y0 = (w0 >> 8) & 0xFF;
   t.log2_size = (w0 >> 16) & 7; t.c_idx = c_idx; t.flags = (w0 >> 19) & 1; t.intra_mode = (w0 >> 20) & 63;
   t.angle = (int)(int8_t)(w1 & 0xFF); t.inv_angle = (int)(int16_t)(w1 >> 16);
   t.avail = (uint64_t)w2 | ((uint64_t)(w3 & 1) << 32);
-  t.resid_offset = w3 >> 1;
+  t.resid_offset = (w3 >> 1) & 0x1FFF;
   return t;
 }
 
 // Intra-only scratch of the run kernel (the residuals were computed beforehand).
 struct RunShared {
-  int32_t b0[4 * 32 + 4];      // neighbours as fetched (+ substitution), centre at [64]
-  int32_t b1[4 * 32 + 4];      // smoothed neighbours
+  uint16_t b0[4 * 32 + 4];     // neighbours as fetched (+ substitution), centre at [64]
+  uint16_t b1[4 * 32 + 4];     // smoothed neighbours
 };
 
 // wave64 sum with DPP row shifts (no LDS traffic); the total is returned to every lane
@@ -649,8 +675,8 @@ __device__ __forceinline__ void run_intra_tu(const PicDev& P, const RunTu& t, ui
   const int xB = t.x0, yB = t.y0;
   const uint64_t avail = t.avail;
   const int cornerUnit = nT >> 1;
-  int* A = &S.b0[64];
-  int* Bf = &S.b1[64];
+  uint16_t* A = &S.b0[64];
+  uint16_t* Bf = &S.b1[64];
 
   if (!(P.dbg & 256))                                // ablation: no neighbour gather
   for (int p = lane; p <= 4 * nT; p += 64) {
@@ -676,10 +702,9 @@ __device__ __forceinline__ void run_intra_tu(const PicDev& P, const RunTu& t, ui
     A[i] = val;
   }
   LDS_SYNC();
-  st.mark(1);
 
   const int mode = t.intra_mode >= 35 ? 1 : t.intra_mode;
-  const int* bord = A;
+  const uint16_t* bord = A;
   if (cIdx == 0 && mode != 1 && nT != 4) {
     const int minDist = min(abs(mode - 26), abs(mode - 10));
     const bool filt = (nT == 8) ? (minDist > 7) : (nT == 16 ? (minDist > 1) : (minDist > 0));
@@ -703,7 +728,6 @@ __device__ __forceinline__ void run_intra_tu(const PicDev& P, const RunTu& t, ui
     }
   }
 
-  st.mark(2);
   const int maxv = (1 << bd) - 1;
   uint16_t* dst = tile + xB + yB * RUN_TILE_P;
   // All three predictors are written branch-free: every LDS operand of a sample is requested
@@ -761,12 +785,17 @@ __device__ __forceinline__ void run_intra_tu(const PicDev& P, const RunTu& t, ui
 }
 
 // ---- register-resident fast path for 4x4 and 8x8 intra TUs (about 95 % of all TUs) ----
-// The 4nT+1 <= 33 neighbours live one per lane in a VGPR: smoothing is two DPP wave shifts,
-// the DC sum a DPP reduction, and the predictors fetch their operands with ds_bpermute (the LDS
-// crossbar, no LDS memory, no write/wait).  Two LDS latencies on the chain per TU: the gather
-// from the pixel window and the bpermute; the write into the window needs no wait (LDS executes
-// a wavefront's operations in order).
+// A run is bound by the latency of its TU chain, and a lone wavefront issues one instruction every ~4 cycles,
+// so the chain carries only what depends on pixel values.  Everything that depends on the TU records alone is
+// computed beforehand by all threads of the workgroup (run_prepare_sample, typically while the run still waits
+// for its producers) and left in LDS per border lane / per sample:
+//   s_gat  LDS byte address of the window sample each border lane reads (substitution of unavailable
+//          neighbours, intrapred.cc:395-431, already resolved; a constant cell when nothing is available)
+//   s_ctl  per sample: the border lanes of its two predictor operands (byte 0: A*4, byte 1: B*4)
+//   s_res  per sample: residual (0 for TUs without coefficients)
+// On the chain: one ds_read (gather) -> [DPP smoothing] -> two ds_bpermute -> ~10 VALU -> ds_write + store.
 #define WAVE_BARRIER_ONLY() asm volatile("" ::: "memory")
+#define RUN_MAX_TUS 256                 // a run lies inside one 64x64 CTB: at most 256 TUs / levels
 
 template <typename PX> __device__ __forceinline__ void store4_packed(PX* g, int v0123_lo, int v0123_hi);
 template <> __device__ __forceinline__ void store4_packed<uint16_t>(uint16_t* g, int lo, int hi)
@@ -774,152 +803,163 @@ template <> __device__ __forceinline__ void store4_packed<uint16_t>(uint16_t* g,
 template <> __device__ __forceinline__ void store4_packed<uint8_t>(uint8_t* g, int lo, int hi)
 { store4_from_u16(g, make_uint2((uint32_t)lo, (uint32_t)hi)); }
 
-template <int LOG2, int RUN_TILE_P, typename PX>
-__device__ __forceinline__ void run_intra_small(const PicDev& P, const RunTu& t, uint16_t* tile, int lane,
-                                                const int16_t* res, int bd, PX* gdst, int gstride, Stamper& st)
+// LDS byte address (inside the pixel window) that border entry p of a TU reads; const_addr when no
+// neighbour is available at all.  Border order as intrapred.cc:577-688: p = 0 bottom-left ... 2nT corner ... 4nT.
+template <int RUN_TILE_P>
+__device__ __forceinline__ int run_gather_addr(int p, int nT, int xB, int yB, uint64_t avail, int const_addr)
 {
-  constexpr int nT = 1 << LOG2, nS = nT * nT, NB = 4 * nT + 1, C = 2 * nT;       // C: lane of border[0]
-  const int xB = t.x0, yB = t.y0, cIdx = t.c_idx;
-  const uint32_t avail = (uint32_t)t.avail;          // 2nT/4*2 + 1 <= 9 units
-  const int maxv = (1 << bd) - 1;
-  const int rs = (res != nullptr && lane < nS) ? (int)res[lane] : 0;              // independent of the chain: issued first
-
-  // neighbour p = lane (border index i = p - 2nT), with substitution (intrapred.cc:395-431)
-  int bv = 1 << (bd - 1);
-  if (avail != 0) {
-    const int p = min(lane, NB - 1), i = p - C;
-    int src = i;
-    if (avail != ((2u << nT) - 1u)) {                 // not every unit available: nearest available one before
-      constexpr int cornerUnit = nT >> 1;
-      const int u = (i < 0) ? (p >> 2) : (i == 0 ? cornerUnit : cornerUnit + 1 + ((i - 1) >> 2));
-      if (!((avail >> u) & 1)) {
-        const uint32_t below = avail & ((2u << u) - 1u);
-        if (below) {
-          const int su = 31 - __clz((int)below);
-          src = (su < cornerUnit) ? (-C + 4 * su + 3) : (su == cornerUnit ? 0 : 4 * (su - cornerUnit));
-        } else {
-          const int su = __ffs((int)avail) - 1;
-          src = (su < cornerUnit) ? (-C + 4 * su) : (su == cornerUnit ? 0 : 4 * (su - cornerUnit - 1) + 1);
-        }
-      }
+  if (avail == 0) return const_addr;
+  const int C = 2 * nT, i = p - C, cornerUnit = nT >> 1;
+  int src = i;
+  const int u = (i < 0) ? (p >> 2) : (i == 0 ? cornerUnit : cornerUnit + 1 + ((i - 1) >> 2));
+  if (!((avail >> u) & 1)) {                          // nearest available unit before, else the first available one
+    const uint64_t below = avail & ((2ull << u) - 1ull);
+    if (below) {
+      const int su = 63 - __clzll((long long)below);
+      src = (su < cornerUnit) ? (-C + 4 * su + 3) : (su == cornerUnit ? 0 : 4 * (su - cornerUnit));
+    } else {
+      const int su = __ffsll((long long)avail) - 1;
+      src = (su < cornerUnit) ? (-C + 4 * su) : (su == cornerUnit ? 0 : 4 * (su - cornerUnit - 1) + 1);
     }
-    const int sx = src <= 0 ? xB - 1 : xB + src - 1;
-    const int sy = src < 0 ? yB - src - 1 : yB - 1;
-    bv = tile[sx + sy * RUN_TILE_P];
   }
-  st.mark(1);
+  const int sx = src <= 0 ? xB - 1 : xB + src - 1;
+  const int sy = src < 0 ? yB - src - 1 : yB - 1;
+  return (sx + sy * RUN_TILE_P) * 2;
+}
 
-  const int mode = t.intra_mode >= 35 ? 1 : t.intra_mode;
-  if (LOG2 == 3 && cIdx == 0 && mode != 1 && min(abs(mode - 26), abs(mode - 10)) > 7) {
+// Off-chain preparation of sample s of the run (one thread per sample).
+template <int RUN_TILE_P>
+__device__ __forceinline__ void run_prepare_sample(int s, const uint4* s_task, const uint8_t* s_own, int16_t* s_res,
+                                                   uint16_t* s_ctl, uint16_t* s_gat, const int16_t* __restrict__ resid,
+                                                   uint32_t res_base, int const_addr)
+{
+  const int k = s_own[s >> 4];
+  const uint4 r = s_task[k];
+  const int log2 = (r.x >> 16) & 7, nT = 1 << log2;
+  const int samp = r.w >> 16, local = s - samp;
+  const int x = local & (nT - 1), y = local >> log2;
+  s_res[s] = (r.x & (1u << 19)) ? resid[res_base + ((r.w >> 1) & 0x1FFF) + local] : (int16_t)0;
+  if (log2 > 3) return;                               // 16x16 / 32x32 TUs take the LDS path (run_intra_tu)
+  const int xB = r.x & 0xFF, yB = (r.x >> 8) & 0xFF;
+  const int kind = (r.x >> 27) & 3;
+  const bool vert = (r.x >> 29) & 1;
+  const int C = 2 * nT;
+  int A = C - 1 - y, B = C + 1 + x;                   // planar / DC: A = left[y], B = top[x]
+  if (kind >= 2) {                                    // angular (intrapred.cc:903-1069), reference array evaluated in place
+    const int angle = (int)(int8_t)(r.y & 0xFF), inv = (int)(int16_t)(r.y >> 16);
+    const int a = vert ? y : x, b = vert ? x : y;
+    const int iIdx = ((a + 1) * angle) >> 5;
+    const int i0 = b + iIdx + 1, i1 = i0 + 1;
+    const int k0 = i0 >= 0 ? i0 : -((i0 * inv + 128) >> 8);
+    const int k1 = min(i1 >= 0 ? i1 : -((i1 * inv + 128) >> 8), C);
+    A = vert ? C + k0 : C - k0;
+    B = (kind == 3) ? (vert ? C - 1 - y : C + 1 + x)  // operand of the mode 26 / 10 edge filter (iFact == 0: B unused)
+                    : (vert ? C + k1 : C - k1);
+  }
+  s_ctl[s] = (uint16_t)((A << 2) | (B << 10));
+  const uint64_t avail = (uint64_t)r.z | ((uint64_t)(r.w & 1) << 32);
+  if (local < 4 * nT) s_gat[samp + k + local] = (uint16_t)run_gather_addr<RUN_TILE_P>(local, nT, xB, yB, avail, const_addr);
+  if (local == 0) s_gat[samp + k + 4 * nT] = (uint16_t)run_gather_addr<RUN_TILE_P>(4 * nT, nT, xB, yB, avail, const_addr);
+}
+
+struct RunLane { int x, y, toff2; };                  // per-lane constants of one TU size: sample position, byte offset in the window
+
+// The chain step of a 4x4 / 8x8 TU.  w0: packed record word 0 (uniform), bv: this lane's neighbour sample,
+// ctl / rs: this lane's operands and residual, tb: LDS byte address of the TU origin in the window.
+template <int LOG2, typename PX>
+__device__ __forceinline__ void run_chain_small(uint32_t w0, int angle, int c, int maxv, int lane, const RunLane& L,
+                                                int bv, int ctl, int rs, char* tile_b, int tb, PX* gdst, uint32_t goff, Stamper& st)
+{
+  constexpr int nT = 1 << LOG2, nS = nT * nT, NB = 4 * nT + 1, C = 2 * nT;
+  if (LOG2 == 3 && (w0 & RTU_SMOOTH)) {
     // [1 2 1] smoothing (intrapred.cc:816-889); both ends keep their value
     const int prev = __builtin_amdgcn_update_dpp(bv, bv, 0x138, 0xf, 0xf, false);   // wave_shr:1 -> lane-1
     const int next = __builtin_amdgcn_update_dpp(bv, bv, 0x130, 0xf, 0xf, false);   // wave_shl:1 -> lane+1
     const int f = (prev + 2 * bv + next + 2) >> 2;
     bv = (lane == 0 || lane >= NB - 1) ? bv : f;
   }
-#define BORD(idx) __builtin_amdgcn_ds_bpermute(((idx) + C) << 2, bv)
-  const int y = (lane >> LOG2) & (nT - 1), x = lane & (nT - 1);
+  const int A = __builtin_amdgcn_ds_bpermute(ctl & 0xFF, bv);
+  const int B = __builtin_amdgcn_ds_bpermute(ctl >> 8, bv);
+  const int kind = (w0 >> 27) & 3;
+  const bool vert = (w0 >> 29) & 1;
   int pv;
-  if (mode == 0) {
-    const int l = BORD(-1 - y), tp = BORD(1 + x);
+  if (kind == 2) {
+    const int f = __mul24(vert ? L.y + 1 : L.x + 1, angle) & 31;
+    pv = __mul24(A, 32 - f) + __mul24(B, f) + 16;
+    pv >>= 5;
+  } else if (kind == 3) {
+    const int b0 = __builtin_amdgcn_readlane(bv, C);
+    const int e = clip3(0, maxv, A + ((B - b0) >> 1));
+    pv = ((vert ? L.x : L.y) == 0) ? e : A;
+  } else if (kind == 0) {
     const int tr = __builtin_amdgcn_readlane(bv, C + 1 + nT), bl = __builtin_amdgcn_readlane(bv, C - 1 - nT);
-    pv = ((nT - 1 - x) * l + (x + 1) * tr + (nT - 1 - y) * tp + (y + 1) * bl + nT) >> (LOG2 + 1);
-  } else if (mode == 1) {
-    const int tp = BORD(1 + x), l = BORD(-1 - y);
+    pv = ((nT - 1 - L.x) * A + (L.x + 1) * tr + (nT - 1 - L.y) * B + (L.y + 1) * bl + nT) >> (LOG2 + 1);
+  } else {
     const int v = (lane >= nT && lane <= 3 * nT && lane != C) ? bv : 0;
     const int dc = (wave_sum_dpp(v) + nT) >> (LOG2 + 1);
-    const int corner = (__builtin_amdgcn_readlane(bv, C - 1) + 2 * dc + __builtin_amdgcn_readlane(bv, C + 1) + 2) >> 2;
     pv = dc;
-    if (cIdx == 0) pv = (x | y) == 0 ? corner : (y == 0 ? (tp + 3 * dc + 2) >> 2 : (x == 0 ? (l + 3 * dc + 2) >> 2 : dc));
-  } else {
-    const int angle = t.angle;
-    const bool vert = mode >= 18;
-    const int inv = t.inv_angle;
-    const int a = vert ? y : x, b = vert ? x : y;
-    const int iIdx = ((a + 1) * angle) >> 5, iFact = ((a + 1) * angle) & 31;
-    const int i0 = b + iIdx + 1, i1 = i0 + 1;
-    const int k0 = i0 >= 0 ? i0 : -((i0 * inv + 128) >> 8);
-    const int k1 = i1 >= 0 ? i1 : -((i1 * inv + 128) >> 8);
-    const int r0 = BORD(vert ? k0 : -k0), r1 = BORD(vert ? min(k1, C) : -min(k1, C));
-    const int ev = BORD(vert ? -1 - y : 1 + x);
-    pv = ((32 - iFact) * r0 + iFact * r1 + 16) >> 5;
-    if (cIdx == 0 && (mode == 26 || mode == 10)) {
-      const int b0 = __builtin_amdgcn_readlane(bv, C);
-      const int b1 = vert ? __builtin_amdgcn_readlane(bv, C + 1) : __builtin_amdgcn_readlane(bv, C - 1);
-      const int e = clip3(0, maxv, b1 + ((ev - b0) >> 1));
-      pv = (vert ? x == 0 : y == 0) ? e : pv;
-    }
+    if (c == 0) pv = (L.x | L.y) == 0 ? (A + 2 * dc + B + 2) >> 2
+                                      : (L.y == 0 ? (B + 3 * dc + 2) >> 2 : (L.x == 0 ? (A + 3 * dc + 2) >> 2 : dc));
   }
-#undef BORD
-  st.mark(2);
   const int outv = clip3(0, maxv, pv + rs);
-  if (lane < nS) tile[xB + x + (yB + y) * RUN_TILE_P] = (uint16_t)outv;
   // write-back straight from the registers: four adjacent lanes are packed with two DPP row shifts and
   // every fourth lane issues one 8-byte (4-byte for 8-bit pictures) write-through store
   const int w01 = outv | (__builtin_amdgcn_update_dpp(0, outv, 0x101, 0xf, 0xf, true) << 16);   // row_shl:1
   const int w23 = __builtin_amdgcn_update_dpp(0, w01, 0x102, 0xf, 0xf, true);                   // row_shl:2
-  if (lane < nS && (x & 3) == 0) store4_packed<PX>(gdst + x + y * gstride, w01, w23);
+  if (lane < nS) {
+    *reinterpret_cast<uint16_t*>(tile_b + tb + L.toff2) = (uint16_t)outv;
+    if ((lane & 3) == 0) store4_packed<PX>(gdst + goff, w01, w23);
+  }
   WAVE_BARRIER_ONLY();
 }
 
-#define RUN_MAX_LVLS 256                // a run has at most 256 TUs (64x64 luma of 4x4s), hence at most 256 levels
+#define RUN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 template <typename PX, int BOX>
 __global__ __launch_bounds__(64 * RUN_WAVES)
 void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __restrict__ runs,
            const uint32_t* __restrict__ deps, uint32_t* sync, uint32_t* err, const TuTask* __restrict__ tasks,
-           const int16_t* __restrict__ resid, const uint16_t* __restrict__ lvtab, int n_runs, int batch, int dbg)
+           const int16_t* __restrict__ resid, int n_runs, int batch, int dbg)
 {
   constexpr int RUN_TILE_H = RUN_TILE_H_OF(BOX), RUN_TILE_P = RUN_TILE_P_OF(BOX);
+  constexpr int MAX_TUS = BOX * BOX / 16;
+  constexpr int CONST_ADDR = RUN_TILE_H * RUN_TILE_P * 2;               // the "nothing available" cell behind the window
   __shared__ RunShared S[RUN_WAVES];
-  __shared__ __attribute__((aligned(16))) uint16_t tile[RUN_TILE_H * RUN_TILE_P];
-  __shared__ __attribute__((aligned(16))) int16_t s_res[BOX * BOX];
-  __shared__ uint16_t s_lv[RUN_MAX_LVLS + 2];
-  __shared__ uint4 s_task[RUN_MAX_LVLS];          // the run's TUs, packed (run_tu_pack)
+  __shared__ __attribute__((aligned(16))) uint16_t tile[RUN_TILE_H * RUN_TILE_P + 8];
+  __shared__ __attribute__((aligned(16))) int16_t s_res[BOX * BOX + 64];
+  __shared__ uint16_t s_ctl[BOX * BOX + 64];
+  __shared__ uint16_t s_gat[BOX * BOX + MAX_TUS + 64];
+  __shared__ uint4 s_task[MAX_TUS];           // the run's TUs, packed (run_tu_pack)
+  __shared__ uint8_t s_own[BOX * BOX / 16];       // TU that owns each group of 16 samples of the run
   __shared__ uint32_t s_ticket;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nthr = blockDim.x, nw = nthr >> 6;
+  const int nthr = blockDim.x;
+  char* tile_b = reinterpret_cast<char*>(tile);
+  const RunLane L4{ lane & 3, (lane >> 2) & 3, (((lane >> 2) & 3) * RUN_TILE_P + (lane & 3)) * 2 };
+  const RunLane L8{ lane & 7, (lane >> 3) & 7, (((lane >> 3) & 7) * RUN_TILE_P + (lane & 7)) * 2 };
+  const int bl4 = min(lane, 16) * 2, bl8 = min(lane, 32) * 2;          // border lane -> byte offset in s_gat
+  const int sl4 = (lane & 15) * 2, sl8 = lane * 2;                     // sample lane -> byte offset in s_ctl / s_res
   // persistent workgroup: the grid is only as wide as the picture's widest dependency level
   // (waiting workgroups would just occupy LDS), every one pulls tickets until none are left.
-  // Tickets are drawn `batch` at a time (one atomic per batch) and processed in increasing order,
-  // which keeps the no-deadlock argument: the smallest unfinished ticket is always owned by a
-  // running workgroup that is not waiting on anything larger.
-  uint32_t next_ticket = 0, batch_end = 0;
+  // No deadlock for any dispatch order: a run only waits on smaller tickets, and a ticket is only ever
+  // held by a running workgroup, which works through its tickets in increasing order (the next ticket is
+  // drawn while the current run's stores drain, so it is held for about a memory round trip at most).
+  // Memory round trips on a run's path: run record -> {TU records, producer ids} -> {residuals, producer flags}
+  // -> window -> chain -> {store drain, next ticket}; everything inside braces is in flight together.
+  Stamper st{ ((dbg & 16) && wave == 0) ? err + 8 : nullptr, 0, lane, {} };
+  if (tid == 0) s_ticket = atomicAdd(&sync[0], 1u);
+  __syncthreads();
+  uint32_t ticket = __builtin_amdgcn_readfirstlane(s_ticket);          // uniform: scalar loads/branches below
   for (;;) {
-  if (next_ticket == batch_end) {
-    if (tid == 0) s_ticket = atomicAdd(&sync[0], (uint32_t)batch);
-    __syncthreads();
-    next_ticket = __builtin_amdgcn_readfirstlane(s_ticket);
-    batch_end = next_ticket + batch;
-  }
   __syncthreads();                                                     // the previous run's LDS is free
-  const uint32_t ticket = next_ticket++;                               // uniform: scalar loads/branches below
   if (ticket >= (uint32_t)n_runs) break;
+  st.t0 = clock64();
   const RunTask run = runs[ticket];
-  Stamper st{ ((dbg & 16) && wave == 0) ? err + 8 : nullptr, clock64(), lane };
-
-  // residuals and level table of the whole run: contiguous, independent of the producers -> fetch before waiting
-  const uint32_t res_base = run.res_offset;
-  if (!(dbg & 8))
-  for (int i = tid * 8; i < (int)run.res_len; i += nthr * 8)
-    *reinterpret_cast<uint4*>(&s_res[i]) = *reinterpret_cast<const uint4*>(&resid[res_base + i]);
-  const int n_lvls = min((int)run.n_lvls, RUN_MAX_LVLS);
-  for (int i = tid; i <= n_lvls; i += nthr) s_lv[i] = lvtab[run.lvl_offset + i];
-
-  if (run.n_deps) {
-    for (int i = tid; i < run.n_deps; i += nthr) {
-      const uint32_t* flag = &sync[2 + deps[run.dep_offset + i]];
-      int spins = 0;
-      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-        // back off quickly: hundreds of waiting wavefronts polling at full rate starve the fabric
-        if (spins < 4) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(64);
-        if (++spins > RUN_SPIN_LIMIT) { atomicExch(err, 1u); break; }           // never hang the grid
-      }
-    }
-    __syncthreads();
-    if (!(dbg & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
+  st.mark(0);
+  const bool has_dep = tid < (int)run.n_deps;
+  uint32_t dep_id = 0;
+  if (has_dep) dep_id = deps[run.dep_offset + tid];
 
   const int c = run.c_idx;
   const PlaneRef pr = c == 0 ? pl0 : (c == 1 ? pl1 : pl2);
@@ -927,15 +967,51 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   const int stride = pr.stride;
   const int cw = c ? P.width >> 1 : P.width, ch = c ? P.height >> 1 : P.height;
   const int bd = c ? P.bd_chroma : P.bd_luma;
-  // pixel window: bbox + 1 left/top + the top-right / bottom-left reach of its TUs (host-computed),
-  // fetched in aligned 8-sample chunks, several loads in flight per lane
+  const int maxv = (1 << bd) - 1;
+  // pixel window: bbox + 1 left/top + the top-right / bottom-left reach of its TUs (host-computed)
   const int wx0 = (int)run.x0 - 1, wy0 = (int)run.y0 - 1;
   const int wx1 = min((int)run.wx1, cw), wy1 = min((int)run.wy1, ch);
   const int ax0 = wx0 & ~7;                                  // -8 when the run touches the left picture edge
+  const int n_tus = min((int)run.n_tus, MAX_TUS), n_samples = min((int)run.n_samples, BOX * BOX);
+  const uint32_t res_base = run.res_offset;
+
+  // ---- preparation, independent of the producers: pack the TU records, then one thread per sample
+  for (int i = tid; i < n_tus; i += nthr) {
+    const uint4 r = run_tu_pack(tasks + run.first_tu, i, ax0, wy0, res_base, c);
+    s_task[i] = r;
+    const int samp = r.w >> 16, cells = 1 << (2 * ((r.x >> 16) & 7) - 4);
+    for (int q = 0; q < cells; q++) s_own[(samp >> 4) + q] = (uint8_t)i;
+  }
+  // first look at the producers' flags: in flight while the samples are prepared
+  uint32_t flag0 = 1;
+  if (has_dep) flag0 = __hip_atomic_load(&sync[2 + dep_id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) tile[RUN_TILE_H * RUN_TILE_P] = (uint16_t)(1 << (bd - 1));
+  __syncthreads();
+  st.mark(1);
+  for (int s = tid; s < n_samples; s += nthr)
+    run_prepare_sample<RUN_TILE_P>(s, s_task, s_own, s_res, s_ctl, s_gat, resid, res_base, CONST_ADDR);
+
+  st.mark(2);
+  if (run.n_deps) {
+    for (int i = tid; i < run.n_deps; i += nthr) {
+      const uint32_t* flag = &sync[2 + (i == tid ? dep_id : deps[run.dep_offset + i])];
+      int spins = 0;
+      uint32_t f = (i == tid) ? flag0 : 0u;
+      while (f == 0) {
+        // back off quickly: hundreds of waiting wavefronts polling at full rate starve the fabric
+        if (spins) { if (spins < 4) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(64); }
+        if (++spins > RUN_SPIN_LIMIT) { atomicExch(err, 1u); break; }           // never hang the grid
+        f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();
+    if (!(dbg & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+
+  st.mark(3);
+  // the window, fetched in aligned 8-sample chunks, several loads in flight per lane
   const int nchx = (wx1 - ax0 + 7) >> 3, nrows = wy1 - wy0;
   const int nchunks = nchx * nrows;
-  const int n_tus = min((int)run.n_tus, RUN_MAX_LVLS);
-  for (int i = tid; i < n_tus; i += nthr) s_task[i] = run_tu_pack(tasks + run.first_tu, i, ax0, wy0, res_base);
   if (!(dbg & 8))
   for (int base = 0; base < nchunks; base += 4 * nthr) {
     uint4 v[4]; int off[4];
@@ -958,56 +1034,82 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
       if (off[u] >= 0) *reinterpret_cast<uint4*>(&tile[off[u]]) = v[u];
   }
   __syncthreads();
-
-  // ---- the dependency chain: gather -> (smooth) -> predict -> + residual, all inside LDS / registers.
-  // The run's TUs are sorted by in-run dependency level; the TUs of one level are independent, so the
-  // workgroup's wavefronts take them round-robin and meet at a barrier before the next level.
-  // Tasks come through the scalar cache (uniform address), the next one is requested a TU ahead.
   st.mark(4);
+
+  // ---- the dependency chain.  Each wavefront walks its own list of the run's TUs (level order); before a TU
+  // of level l it passes barriers until the workgroup has finished level l-1.  Records are read two TUs ahead
+  // and per-lane operands one TU ahead (LDS returns in order, so none of this is waited for on the chain).
   if (!(dbg & 4)) {
-    const int last = n_tus - 1;
-    int pre_k = min(wave, last);
-    uint4 pre = s_task[pre_k];
-    int lv_b = 0;
-    int lv_e = __builtin_amdgcn_readfirstlane((int)s_lv[1]);
-    int lv_n = __builtin_amdgcn_readfirstlane((int)s_lv[min(2, n_lvls)]);
-    for (int l = 0; l < n_lvls; l++) {
-      const int lv_nn = s_lv[min(l + 3, n_lvls)];                       // level bounds are read two levels ahead
-      for (int k = lv_b + wave; k < lv_e; k += nw) {
-        RunTu t = run_tu_decode((k == pre_k) ? pre : s_task[k], c);
-        pre_k = min((k + nw < lv_e) ? k + nw : ((lv_e + wave < lv_n) ? lv_e + wave : last), last);
-        pre = s_task[pre_k];                                            // LDS returns in order: no extra wait later
-        const int gx0 = t.x0 + ax0, gy0 = t.y0 + wy0;
-        st.mark(0);
-        const int16_t* rp = t.flags ? &s_res[t.resid_offset] : nullptr;
-        PX* gdst = plane + gx0 + gy0 * stride;
-        if (t.log2_size == 2 && !(dbg & 512)) run_intra_small<2, RUN_TILE_P, PX>(P, t, tile, lane, rp, bd, gdst, stride, st);
-        else if (t.log2_size == 3 && !(dbg & 512)) run_intra_small<3, RUN_TILE_P, PX>(P, t, tile, lane, rp, bd, gdst, stride, st);
+    const uint16_t* we = runs[ticket].wave_end;                          // (indexed in memory: no register array)
+    const int j0 = wave == 0 ? 0 : (int)we[wave - 1], j1 = (int)we[wave];
+    const int n_lvls = run.n_lvls;
+    const uint32_t goff4 = L4.x + L4.y * stride, goff8 = L8.x + L8.y * stride;
+    PX* wplane = plane + ax0 + wy0 * stride;                             // picture address of window sample (0, 0)
+    int level = 0;
+    if (j0 < j1) {
+      uint4 rr = s_task[j0];
+      uint32_t w0 = __builtin_amdgcn_readfirstlane(rr.x), w1 = __builtin_amdgcn_readfirstlane(rr.y);
+      uint32_t w2 = __builtin_amdgcn_readfirstlane(rr.z), w3 = __builtin_amdgcn_readfirstlane(rr.w);
+      uint4 r_nxt = s_task[min(j0 + 1, j1 - 1)];
+      char* res_b = reinterpret_cast<char*>(s_res); char* ctl_b = reinterpret_cast<char*>(s_ctl);
+      char* gat_b = reinterpret_cast<char*>(s_gat);
+      int samp2 = (w3 >> 16) * 2;
+      const bool is4 = ((w0 >> 16) & 7) == 2;
+      int gaddr = *reinterpret_cast<uint16_t*>(gat_b + samp2 + 2 * j0 + (is4 ? bl4 : bl8));
+      int ctl = *reinterpret_cast<uint16_t*>(ctl_b + samp2 + (is4 ? sl4 : sl8));
+      int rs = *reinterpret_cast<int16_t*>(res_b + samp2 + (is4 ? sl4 : sl8));
+      for (int j = j0; j < j1; j++) {
+        const int lev = (w1 >> 8) & 0xFF;
+        while (level < lev) { RUN_LDS_BARRIER(); level++; }
+        const int log2 = (w0 >> 16) & 7;
+        const int bv = *reinterpret_cast<uint16_t*>(tile_b + gaddr);            // the chain's first LDS round trip
+        // off the chain, in the shadow of that read: next TU's record -> its per-lane operands; record after next
+        const uint32_t n0 = __builtin_amdgcn_readfirstlane(r_nxt.x), n1 = __builtin_amdgcn_readfirstlane(r_nxt.y);
+        const uint32_t n2 = __builtin_amdgcn_readfirstlane(r_nxt.z), n3 = __builtin_amdgcn_readfirstlane(r_nxt.w);
+        const int nsamp2 = (n3 >> 16) * 2;
+        const bool n4 = ((n0 >> 16) & 7) == 2;
+        const int jn = min(j + 1, j1 - 1);
+        const int ngaddr = *reinterpret_cast<uint16_t*>(gat_b + nsamp2 + 2 * jn + (n4 ? bl4 : bl8));
+        const int nctl = *reinterpret_cast<uint16_t*>(ctl_b + nsamp2 + (n4 ? sl4 : sl8));
+        const int nrs = *reinterpret_cast<int16_t*>(res_b + nsamp2 + (n4 ? sl4 : sl8));
+        r_nxt = s_task[min(j + 2, j1 - 1)];
+
+        const int xw = w0 & 0xFF, yw = (w0 >> 8) & 0xFF;
+        PX* gdst = wplane + (uint32_t)(xw + yw * stride);               // window origin + 32-bit offset
+        const int tb = (yw * RUN_TILE_P + xw) * 2;
+        const int angle = (int)(int8_t)(w1 & 0xFF);
+        if (log2 == 2) run_chain_small<2, PX>(w0, angle, c, maxv, lane, L4, bv, ctl, rs, tile_b, tb, gdst, goff4, st);
+        else if (log2 == 3) run_chain_small<3, PX>(w0, angle, c, maxv, lane, L8, bv, ctl, rs, tile_b, tb, gdst, goff8, st);
         else {
-          run_intra_tu<RUN_TILE_P>(P, t, tile, S[wave], lane, rp, bd, st);
+          const RunTu t = run_tu_unpack(w0, w1, w2, w3, c);
+          run_intra_tu<RUN_TILE_P>(P, t, tile, S[wave], lane, &s_res[samp2 >> 1], bd, st);
           // write the finished TU back, 4 samples per lane (only the run's own samples ever leave the window)
-          const int log2 = t.log2_size, nT = 1 << log2, l4 = log2 - 2;
+          const int nT = 1 << log2, l4 = log2 - 2;
           for (int s = lane; s < (nT * nT) >> 2; s += 64) {
             const int y = s >> l4, x = (s & ((1 << l4) - 1)) << 2;
-            const uint2 v = *reinterpret_cast<const uint2*>(&tile[(t.y0 + y) * RUN_TILE_P + t.x0 + x]);
+            const uint2 v = *reinterpret_cast<const uint2*>(&tile[(yw + y) * RUN_TILE_P + xw + x]);
             store4_from_u16(gdst + x + y * stride, v);
           }
         }
-        st.mark(3);
-        if (st.buf && lane == 0) atomicAdd(&st.buf[7], 1u);
+        w0 = n0; w1 = n1; w2 = n2; w3 = n3; samp2 = nsamp2; gaddr = ngaddr; ctl = nctl; rs = nrs;
       }
-      lv_b = lv_e; lv_e = lv_n; lv_n = __builtin_amdgcn_readfirstlane(lv_nn);
-      if (l + 1 < n_lvls) __syncthreads();
     }
+    while (level < n_lvls - 1) { RUN_LDS_BARRIER(); level++; }
   }
 
   // publish: every handed-off byte was stored write-through (sc1); drain them, then raise the flag.
   // (MI355X_MICROARCH.md, valid forms: sc1 payload stores + vmcnt(0) + flag on the producer,
   //  poll + agent acquire + plain loads on the consumer; no L2 write-back fence needed.)
+  st.mark(5);
+  if (tid == 0) s_ticket = atomicAdd(&sync[0], 1u);                    // next ticket: returns while the stores drain
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  st.mark(6);
+  st.count();
   if (tid == 0) __hip_atomic_store(&sync[2 + ticket], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ticket = __builtin_amdgcn_readfirstlane(s_ticket);
   }
+  st.flush();
 }
 
 // Function-level form (acceleration.h:143-178 slot semantics): dense coefficient
@@ -1033,10 +1135,10 @@ template __global__ void k_tu<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, con
                                        const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
 template __global__ void k_tu<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int,
                                         const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
-template __global__ void k_run<uint8_t, 64>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, const uint16_t*, int, int, int);
-template __global__ void k_run<uint16_t, 64>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, const uint16_t*, int, int, int);
-template __global__ void k_run<uint8_t, 32>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, const uint16_t*, int, int, int);
-template __global__ void k_run<uint16_t, 32>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, const uint16_t*, int, int, int);
+template __global__ void k_run<uint8_t, 64>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, int, int, int);
+template __global__ void k_run<uint16_t, 64>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, int, int, int);
+template __global__ void k_run<uint8_t, 32>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, int, int, int);
+template __global__ void k_run<uint16_t, 32>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, int, int, int);
 template __global__ void k_fn_residual<uint8_t>(int, int, int, uint8_t*, int, const int32_t*, const int16_t*);
 template __global__ void k_fn_residual<uint16_t>(int, int, int, uint16_t*, int, const int32_t*, const int16_t*);
 

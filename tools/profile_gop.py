@@ -17,6 +17,7 @@ ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--width", type=int, default=3840)
 ap.add_argument("--height", type=int, default=2160)
 ap.add_argument("--bit-depth", type=int, default=10)
+ap.add_argument("--only", type=int, default=-1, help="time only this picture of the GOP")
 ap.add_argument("--over", default="", help="synth overrides, e.g. cbf_pct=0,split_bias=100")
 a = ap.parse_args()
 W, H, BD = a.width, a.height, a.bit_depth
@@ -32,10 +33,14 @@ for sp, p in pics:
     dec.run(p, 2)
 dec.sync()
 dec.set_profiling(True)
+dec.sync()
 for k, (sp, p) in enumerate(pics):
+    if a.only >= 0 and k != a.only:
+        continue
     dec.kernel_times(reset=True)
     for _ in range(a.reps):
         dec.run(p, 2)
+    dec.sync()
     kt = dec.kernel_times(reset=True)
     s = p.stats()
     print("pic %d type %s tus %d mc %d levels %d runs %d runlevels %d inrunlevels %d | " % (
