@@ -123,8 +123,10 @@ def main():
         d.kernel_times(reset=True)
     timer = farm.RankTimer(dist, sync, device=red_dev)
     timer.start()                       # barrier + synchronize
+    t_host = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_host = time.perf_counter() - t_host   # host time spent enqueueing (the device runs behind it)
     elapsed = timer.stop()              # synchronize + barrier, MAX over ranks
     ktimes = {}
     for d in decs:
@@ -213,6 +215,7 @@ def main():
                                    "%d independent GOP(s) in flight per GPU, all stages on device"
                                    % (W, H, BD, GOP, GOP - 1, S),
                        "gop": GOP, "streams_per_gpu": S, "pictures_per_step": GOP * S,
+                       "host_enqueue_ms_per_step": round(1e3 * t_host / args.steps, 3),
                        "parallelism": "%d gop stream(s) x %d gpu(s)" % (S, world)},
             "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity, "kernels": kernels,
             "kernels_isolated": kernels_iso,

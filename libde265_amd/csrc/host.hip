@@ -77,7 +77,7 @@ struct de265hip_picture {
   int n_l0_size[4] = { 0, 0, 0, 0 };          // TU count per size in d_l0 (sorted 32,16,8,4)
   TuTask* d_l0 = nullptr; int n_l0 = 0;       // run mode: inter residual TUs + residual-only copies of intra TUs
   int16_t* d_resid = nullptr;                 // precomputed residual blocks of intra TUs
-  int n_runs = 0, n_workers = 0, run_box = 64, ticket_batch = 1; size_t sync_bytes = 0;
+  int n_runs = 0, n_workers = 0, run_box = 64, late_publish = 0; size_t sync_bytes = 0;
   std::vector<int> level_start;       // level_start[l] .. level_start[l+1] in d_tus
   int n_mc = 0, n_pcm = 0, n_tus = 0;
   bool any_edges = false;
@@ -532,8 +532,27 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     const char* wenv = getenv("DE265HIP_RUN_WORKERS");
     int cap = wenv ? atoi(wenv) : (run_box == 64 ? 768 : 2048);      // LDS-limited residency: 3 resp. 8 workgroups per CU
     pic->n_workers = std::min(pic->n_runs, std::max(64, std::min(cap, widest + widest / 4)));
+    // pictures with inter PUs have thousands of small runs in few levels (bound by run throughput): raise flags late;
+    // all-intra pictures are bound by the producer->consumer chain: raise them first thing (DE265HIP_LATE_PUBLISH: 0/1)
+    const char* lenv = getenv("DE265HIP_LATE_PUBLISH");
+    pic->late_publish = lenv ? atoi(lenv) : 0;
+    if (getenv("DE265HIP_PRINT_CRIT")) {               // diagnostic: longest path through the run DAG
+      std::vector<double> fin(rb.size(), 0.0); double worst = 0, worst_l = 0; int worst_n = 0;
+      std::vector<int> nl_of(rb.size(), 0), cnt(rb.size(), 0); std::vector<double> lv(rb.size(), 0.0);
+      for (size_t i = 0; i < rb.size(); i++) {           // rb is in decode order: producers precede consumers
+        int nl = 0; for (uint16_t l : rb[i].llev) nl = std::max(nl, (int)l);
+        double st = 0, sl = 0; int sn = 0;
+        for (int dp : rb[i].deps) if (fin[dp] > st) { st = fin[dp]; sl = lv[dp]; sn = cnt[dp]; }
+        fin[i] = st + 8.0 + 0.45 * nl; lv[i] = sl + nl; cnt[i] = sn + 1;
+        if (fin[i] > worst) { worst = fin[i]; worst_l = lv[i]; worst_n = cnt[i]; }
+      }
+      fprintf(stderr, "de265hip crit: est %.0f us, %d runs and %.0f in-run levels on the longest path\n", worst, worst_n, worst_l);
+    }
+    // tickets per draw (bits 8.. of the kernel's mode word): 1 for chain-bound pictures, several where the draw
+    // rate of the single device-scope counter would be the limit (DE265HIP_TICKET_BATCH)
     const char* benv = getenv("DE265HIP_TICKET_BATCH");
-    pic->ticket_batch = benv ? std::max(1, atoi(benv)) : 1;   // measured: drawing 4/8 tickets per atomic costs 46 % / 100 % on a 4K B picture (serialises dependants)
+    const int tb = benv ? std::max(1, std::min(64, atoi(benv))) : 1;
+    pic->late_publish |= tb << 8;
   }
   // level-0 launch of run mode: inter TUs with residual, then the residual-only intra TUs
   // largest first: [32x32 | 16x16 | 8x8 | 4x4] (counting sort); the two small sizes get their own packed kernel
@@ -792,10 +811,10 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
       (void)hipMemsetAsync(pic->d_sync, 0, pic->sync_bytes, st);
       if (pic->run_box == 64)
         hipLaunchKernelGGL((k_run<PX, 64>), dim3(pic->n_workers), dim3(64 * dec->run_waves), 0, st, P, d0, d1, d2, pic->d_runs, pic->d_deps,
-                           pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->n_runs, pic->ticket_batch, dec->dbg);
+                           pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->n_runs, pic->late_publish, dec->dbg);
       else
         hipLaunchKernelGGL((k_run<PX, 32>), dim3(pic->n_workers), dim3(64 * dec->run_waves), 0, st, P, d0, d1, d2, pic->d_runs, pic->d_deps,
-                           pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->n_runs, pic->ticket_batch, dec->dbg);
+                           pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->n_runs, pic->late_publish, dec->dbg);
     }
   } else {
     if (nlev > 0 && pic->level_start[1] > pic->level_start[0]) {
@@ -863,8 +882,8 @@ int de265hip_decoder_sync(de265hip_decoder* dec)
     uint32_t st[16];
     HIPCHK(hipMemcpy(st, dec->d_err + 8, sizeof(st), hipMemcpyDeviceToHost), DE265HIP_ERROR_DECODING);
     const double n = st[7] ? (double)st[7] : 1.0;
-    fprintf(stderr, "de265hip stamps: runs=%u cycles/run: record=%.0f tasks=%.0f prepare=%.0f wait=%.0f window=%.0f chain=%.0f drain=%.0f\n",
-            st[7], st[0] / n, st[1] / n, st[2] / n, st[3] / n, st[4] / n, st[5] / n, st[6] / n);
+    fprintf(stderr, "de265hip stamps: runs=%u cycles/run: ticket=%.0f record=%.0f tasks=%.0f prepare(+early window)=%.0f wait=%.0f window=%.0f chain=%.0f\n",
+            st[7], st[6] / n, st[0] / n, st[1] / n, st[2] / n, st[3] / n, st[4] / n, st[5] / n);
     (void)hipMemset(dec->d_err + 8, 0, sizeof(st));
   }
   if (err) { (void)hipMemset(dec->d_err, 0, 4); return DE265HIP_ERROR_DECODING; }

@@ -598,6 +598,21 @@ __device__ __forceinline__ void store4_from_u16(uint8_t* g, uint2 v)
                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// 8 / 4 consecutive window samples (uint16 in LDS) -> picture, one write-through store
+typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store8_from_u16(uint16_t* g, uint4 v)
+{
+  v4u32 d = { v.x, v.y, v.z, v.w };
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(g), "v"(d) : "memory");   // 16-B write-through store
+}
+__device__ __forceinline__ void store8_from_u16(uint8_t* g, uint4 v)
+{
+  const uint32_t lo = (v.x & 0xFF) | ((v.x >> 8) & 0xFF00) | ((v.y & 0xFF) << 16) | ((v.y >> 16) << 24);
+  const uint32_t hi = (v.z & 0xFF) | ((v.z >> 8) & 0xFF00) | ((v.w & 0xFF) << 16) | ((v.w >> 16) << 24);
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(g), (unsigned long long)lo | ((unsigned long long)hi << 32),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // A TuTask as the run kernel holds it: every field in a scalar register.  The 32-byte record is fetched with
 // two 16-byte scalar loads (field-wise access makes the compiler fetch the byte fields with vector loads,
 // each followed by a vmcnt(0) that also waits for the previous TU's write-through stores).
@@ -830,8 +845,8 @@ __device__ __forceinline__ int run_gather_addr(int p, int nT, int xB, int yB, ui
 // Off-chain preparation of sample s of the run (one thread per sample).
 template <int RUN_TILE_P>
 __device__ __forceinline__ void run_prepare_sample(int s, const uint4* s_task, const uint8_t* s_own, int16_t* s_res,
-                                                   uint16_t* s_ctl, uint16_t* s_gat, const int16_t* __restrict__ resid,
-                                                   uint32_t res_base, int const_addr)
+                                                   uint16_t* s_ctl, uint16_t* s_gat, uint32_t* s_mine,
+                                                   const int16_t* __restrict__ resid, uint32_t res_base, int const_addr)
 {
   const int k = s_own[s >> 4];
   const uint4 r = s_task[k];
@@ -839,6 +854,7 @@ __device__ __forceinline__ void run_prepare_sample(int s, const uint4* s_task, c
   const int samp = r.w >> 16, local = s - samp;
   const int x = local & (nT - 1), y = local >> log2;
   s_res[s] = (r.x & (1u << 19)) ? resid[res_base + ((r.w >> 1) & 0x1FFF) + local] : (int16_t)0;
+  if ((x & 3) == 0) atomicOr(&s_mine[(int)((r.x >> 8) & 0xFF) + y], 1u << (((int)(r.x & 0xFF) + x) >> 2));
   if (log2 > 3) return;                               // 16x16 / 32x32 TUs take the LDS path (run_intra_tu)
   const int xB = r.x & 0xFF, yB = (r.x >> 8) & 0xFF;
   const int kind = (r.x >> 27) & 3;
@@ -866,11 +882,11 @@ struct RunLane { int x, y, toff2; };                  // per-lane constants of o
 
 // The chain step of a 4x4 / 8x8 TU.  w0: packed record word 0 (uniform), bv: this lane's neighbour sample,
 // ctl / rs: this lane's operands and residual, tb: LDS byte address of the TU origin in the window.
-template <int LOG2, typename PX>
+template <int LOG2>
 __device__ __forceinline__ void run_chain_small(uint32_t w0, int angle, int c, int maxv, int lane, const RunLane& L,
-                                                int bv, int ctl, int rs, char* tile_b, int tb, PX* gdst, uint32_t goff, Stamper& st)
+                                                int bv, int ctl, int rs, char* tile_b, int tb)
 {
-  constexpr int nT = 1 << LOG2, nS = nT * nT, NB = 4 * nT + 1, C = 2 * nT;
+  constexpr int nT = 1 << LOG2, NB = 4 * nT + 1, C = 2 * nT;
   if (LOG2 == 3 && (w0 & RTU_SMOOTH)) {
     // [1 2 1] smoothing (intrapred.cc:816-889); both ends keep their value
     const int prev = __builtin_amdgcn_update_dpp(bv, bv, 0x138, 0xf, 0xf, false);   // wave_shr:1 -> lane-1
@@ -902,24 +918,29 @@ __device__ __forceinline__ void run_chain_small(uint32_t w0, int angle, int c, i
                                       : (L.y == 0 ? (B + 3 * dc + 2) >> 2 : (L.x == 0 ? (A + 3 * dc + 2) >> 2 : dc));
   }
   const int outv = clip3(0, maxv, pv + rs);
-  // write-back straight from the registers: four adjacent lanes are packed with two DPP row shifts and
-  // every fourth lane issues one 8-byte (4-byte for 8-bit pictures) write-through store
-  const int w01 = outv | (__builtin_amdgcn_update_dpp(0, outv, 0x101, 0xf, 0xf, true) << 16);   // row_shl:1
-  const int w23 = __builtin_amdgcn_update_dpp(0, w01, 0x102, 0xf, 0xf, true);                   // row_shl:2
-  if (lane < nS) {
-    *reinterpret_cast<uint16_t*>(tile_b + tb + L.toff2) = (uint16_t)outv;
-    if ((lane & 3) == 0) store4_packed<PX>(gdst + goff, w01, w23);
-  }
+  // into the window only (lanes beyond the TU mirror lanes of it: same value, same address); the picture is
+  // written once, at the end of the run, in whole 16-byte chunks
+  *reinterpret_cast<uint16_t*>(tile_b + tb + L.toff2) = (uint16_t)outv;
   WAVE_BARRIER_ONLY();
 }
 
 #define RUN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// Ticket draw on the scalar unit (s_atomic_add ... glc returns the old value through lgkmcnt): unlike a vector
+// atomic it does not queue behind the wavefront's outstanding write-through stores (vmcnt).
+__device__ __forceinline__ uint32_t run_draw_ticket(uint32_t* counter, uint32_t n)
+{
+  uint32_t v = n;
+  asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(v) : "s"(counter) : "memory");
+  return v;
+}
+#define RUN_NO_TICKET 0xFFFFFFFFu
+
 template <typename PX, int BOX>
 __global__ __launch_bounds__(64 * RUN_WAVES)
 void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __restrict__ runs,
            const uint32_t* __restrict__ deps, uint32_t* sync, uint32_t* err, const TuTask* __restrict__ tasks,
-           const int16_t* __restrict__ resid, int n_runs, int batch, int dbg)
+           const int16_t* __restrict__ resid, int n_runs, int late_publish, int dbg)
 {
   constexpr int RUN_TILE_H = RUN_TILE_H_OF(BOX), RUN_TILE_P = RUN_TILE_P_OF(BOX);
   constexpr int MAX_TUS = BOX * BOX / 16;
@@ -931,6 +952,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   __shared__ uint16_t s_gat[BOX * BOX + MAX_TUS + 64];
   __shared__ uint4 s_task[MAX_TUS];           // the run's TUs, packed (run_tu_pack)
   __shared__ uint8_t s_own[BOX * BOX / 16];       // TU that owns each group of 16 samples of the run
+  __shared__ uint32_t s_mine[RUN_TILE_H];         // per window row: bit g = the 4 samples at columns 4g.. are the run's
   __shared__ uint32_t s_ticket;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -942,19 +964,39 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   const int sl4 = (lane & 15) * 2, sl8 = lane * 2;                     // sample lane -> byte offset in s_ctl / s_res
   // persistent workgroup: the grid is only as wide as the picture's widest dependency level
   // (waiting workgroups would just occupy LDS), every one pulls tickets until none are left.
-  // No deadlock for any dispatch order: a run only waits on smaller tickets, and a ticket is only ever
-  // held by a running workgroup, which works through its tickets in increasing order (the next ticket is
-  // drawn while the current run's stores drain, so it is held for about a memory round trip at most).
-  // Memory round trips on a run's path: run record -> {TU records, producer ids} -> {residuals, producer flags}
-  // -> window -> chain -> {store drain, next ticket}; everything inside braces is in flight together.
+  // No deadlock for any dispatch order: a run only waits on smaller tickets, a ticket is only ever held by a
+  // running workgroup, and a finished run's flag is published without waiting on any other run.
+  // Memory round trips on a run's path: ticket -> run record -> {TU records, producer ids, drain of the previous
+  // run's stores} -> producer flags -> {window, residuals} -> chain; what is inside braces is in flight together.
+  // late_publish (pictures bound by run throughput, i.e. with inter PUs): the flag of a finished run is raised one
+  // step late, after the next run's first round trip has drained the write-through stores, instead of a wait of
+  // its own.  Otherwise (all-intra pictures, bound by the producer->consumer chain) it is raised first thing.
   Stamper st{ ((dbg & 16) && wave == 0) ? err + 8 : nullptr, 0, lane, {} };
-  if (tid == 0) s_ticket = atomicAdd(&sync[0], 1u);
-  __syncthreads();
-  uint32_t ticket = __builtin_amdgcn_readfirstlane(s_ticket);          // uniform: scalar loads/branches below
+  uint32_t prev = RUN_NO_TICKET;                                       // finished run whose flag is not raised yet
+  const int batch = max(1, late_publish >> 8);
+  late_publish &= 1;
+  uint32_t next_ticket = 0, batch_end = 0;
   for (;;) {
+  if (!late_publish) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                                     // the previous run's LDS is free
+  if (!late_publish && prev != RUN_NO_TICKET) {
+    if (tid == 0) __hip_atomic_store(&sync[2 + prev], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    prev = RUN_NO_TICKET;
+  }
+  if (prev == RUN_NO_TICKET) st.t0 = clock64();                        // (stamps: the first run of the workgroup)
+  // Tickets are drawn `batch` at a time and worked off in increasing order (the no-deadlock argument holds: the
+  // smallest unfinished ticket is held by a running workgroup that waits on nothing larger).  One device-scope
+  // counter serves about one add per 12 ns: with thousands of small runs the draw rate itself is the limit,
+  // so throughput-bound pictures draw several at once.
+  if (next_ticket == batch_end) {
+    if (wave == 0) { const uint32_t t = run_draw_ticket(sync, (uint32_t)batch); if (lane == 0) s_ticket = t; }
+    __syncthreads();
+    next_ticket = __builtin_amdgcn_readfirstlane(s_ticket);
+    batch_end = next_ticket + batch;
+  }
+  st.mark(6);
+  const uint32_t ticket = next_ticket++;                               // uniform: scalar loads/branches below
   if (ticket >= (uint32_t)n_runs) break;
-  st.t0 = clock64();
   const RunTask run = runs[ticket];
   st.mark(0);
   const bool has_dep = tid < (int)run.n_deps;
@@ -976,28 +1018,75 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   const uint32_t res_base = run.res_offset;
 
   // ---- preparation, independent of the producers: pack the TU records, then one thread per sample
+  for (int i = tid; i < RUN_TILE_H; i += nthr) s_mine[i] = 0;
   for (int i = tid; i < n_tus; i += nthr) {
     const uint4 r = run_tu_pack(tasks + run.first_tu, i, ax0, wy0, res_base, c);
     s_task[i] = r;
     const int samp = r.w >> 16, cells = 1 << (2 * ((r.x >> 16) & 7) - 4);
     for (int q = 0; q < cells; q++) s_own[(samp >> 4) + q] = (uint8_t)i;
   }
-  // first look at the producers' flags: in flight while the samples are prepared
-  uint32_t flag0 = 1;
+  // the TU records are here, so every earlier store of this wavefront has drained too (made explicit)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  uint32_t flag0 = 1;                                                   // first look at the producers' flags
   if (has_dep) flag0 = __hip_atomic_load(&sync[2 + dep_id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (tid == 0) tile[RUN_TILE_H * RUN_TILE_P] = (uint16_t)(1 << (bd - 1));
   __syncthreads();
+  // publish the previous run: its payload was stored write-through (sc1) and has drained in every wavefront.
+  // (MI355X_MICROARCH.md, valid forms: sc1 payload stores + vmcnt(0) + flag on the producer,
+  //  poll + agent acquire + plain loads on the consumer; no L2 write-back fence needed.)
+  if (tid == 0 && prev != RUN_NO_TICKET)
+    __hip_atomic_store(&sync[2 + prev], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  prev = ticket;
   st.mark(1);
-  for (int s = tid; s < n_samples; s += nthr)
-    run_prepare_sample<RUN_TILE_P>(s, s_task, s_own, s_res, s_ctl, s_gat, resid, res_base, CONST_ADDR);
 
+  // the window, fetched in aligned 8-sample chunks, up to four loads in flight per lane
+  const int nchx = (wx1 - ax0 + 7) >> 3, nrows = wy1 - wy0;
+  const int nchunks = nchx * nrows;
+  uint4 wv[4]; int woff[4];
+  auto window_issue = [&](int base) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int idx = base + u * nthr + tid;
+      woff[u] = -1;
+      if (idx < nchunks) {
+        const int r = idx / nchx, cx = idx - r * nchx;
+        const int gx = ax0 + 8 * cx, gy = wy0 + r;
+        // the bottom-right 32x32 corner of the window is never read
+        if (gx >= 0 && gy >= 0 && !(gx >= (int)run.x1 && gy >= (int)run.y1)) {
+          wv[u] = load8_as_u16(plane + gx + gy * stride);
+          woff[u] = r * RUN_TILE_P + 8 * cx;
+        }
+      }
+    }
+  };
+  auto window_commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (woff[u] >= 0) *reinterpret_cast<uint4*>(&tile[woff[u]]) = wv[u];
+  };
+  // producers already finished (the usual case when the picture is throughput-bound): fetch the window now,
+  // under the preparation of the samples, instead of after it
+  const bool early = !(dbg & 8) && (run.n_deps == 0 || __syncthreads_and(flag0 != 0));
+  if (early) {
+    if (run.n_deps && !(dbg & 2)) {
+      // one acquire per workgroup (the L1 belongs to the CU): wavefront 0 invalidates and waits for it,
+      // the others load behind the barrier
+      if (wave == 0) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+      __syncthreads();
+    }
+    window_issue(0);
+  }
+  for (int s = tid; s < n_samples; s += nthr)
+    run_prepare_sample<RUN_TILE_P>(s, s_task, s_own, s_res, s_ctl, s_gat, s_mine, resid, res_base, CONST_ADDR);
   st.mark(2);
-  if (run.n_deps) {
+  int wbase = 0;
+  if (early) { window_commit(); wbase = 4 * nthr; }
+  else if (run.n_deps) {
     for (int i = tid; i < run.n_deps; i += nthr) {
       const uint32_t* flag = &sync[2 + (i == tid ? dep_id : deps[run.dep_offset + i])];
       int spins = 0;
       uint32_t f = (i == tid) ? flag0 : 0u;
-      while (f == 0) {
+      while (f == 0 && !(dbg & 32)) {                                  // (dbg 32: timing-only ablation, ignores producers)
         // back off quickly: hundreds of waiting wavefronts polling at full rate starve the fabric
         if (spins) { if (spins < 4) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(64); }
         if (++spins > RUN_SPIN_LIMIT) { atomicExch(err, 1u); break; }           // never hang the grid
@@ -1005,34 +1094,14 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
       }
     }
     __syncthreads();
-    if (!(dbg & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-
-  st.mark(3);
-  // the window, fetched in aligned 8-sample chunks, several loads in flight per lane
-  const int nchx = (wx1 - ax0 + 7) >> 3, nrows = wy1 - wy0;
-  const int nchunks = nchx * nrows;
-  if (!(dbg & 8))
-  for (int base = 0; base < nchunks; base += 4 * nthr) {
-    uint4 v[4]; int off[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      int idx = base + u * nthr + tid;
-      off[u] = -1;
-      if (idx < nchunks) {
-        int r = idx / nchx, cx = idx - r * nchx;
-        int gx = ax0 + 8 * cx, gy = wy0 + r;
-        // the bottom-right 32x32 corner of the window is never read
-        if (gx >= 0 && gy >= 0 && !(gx >= (int)run.x1 && gy >= (int)run.y1)) {
-          v[u] = load8_as_u16(plane + gx + gy * stride);
-          off[u] = r * RUN_TILE_P + 8 * cx;
-        }
-      }
+    if (!(dbg & 2)) {
+      if (wave == 0) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+      __syncthreads();
     }
-#pragma unroll
-    for (int u = 0; u < 4; u++)
-      if (off[u] >= 0) *reinterpret_cast<uint4*>(&tile[off[u]]) = v[u];
   }
+  st.mark(3);
+  if (!(dbg & 8))
+  for (int base = wbase; base < nchunks; base += 4 * nthr) { window_issue(base); window_commit(); }
   __syncthreads();
   st.mark(4);
 
@@ -1043,8 +1112,6 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
     const uint16_t* we = runs[ticket].wave_end;                          // (indexed in memory: no register array)
     const int j0 = wave == 0 ? 0 : (int)we[wave - 1], j1 = (int)we[wave];
     const int n_lvls = run.n_lvls;
-    const uint32_t goff4 = L4.x + L4.y * stride, goff8 = L8.x + L8.y * stride;
-    PX* wplane = plane + ax0 + wy0 * stride;                             // picture address of window sample (0, 0)
     int level = 0;
     if (j0 < j1) {
       uint4 rr = s_task[j0];
@@ -1075,40 +1142,47 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
         r_nxt = s_task[min(j + 2, j1 - 1)];
 
         const int xw = w0 & 0xFF, yw = (w0 >> 8) & 0xFF;
-        PX* gdst = wplane + (uint32_t)(xw + yw * stride);               // window origin + 32-bit offset
         const int tb = (yw * RUN_TILE_P + xw) * 2;
         const int angle = (int)(int8_t)(w1 & 0xFF);
-        if (log2 == 2) run_chain_small<2, PX>(w0, angle, c, maxv, lane, L4, bv, ctl, rs, tile_b, tb, gdst, goff4, st);
-        else if (log2 == 3) run_chain_small<3, PX>(w0, angle, c, maxv, lane, L8, bv, ctl, rs, tile_b, tb, gdst, goff8, st);
+        if (log2 == 2) run_chain_small<2>(w0, angle, c, maxv, lane, L4, bv, ctl, rs, tile_b, tb);
+        else if (log2 == 3) run_chain_small<3>(w0, angle, c, maxv, lane, L8, bv, ctl, rs, tile_b, tb);
         else {
           const RunTu t = run_tu_unpack(w0, w1, w2, w3, c);
           run_intra_tu<RUN_TILE_P>(P, t, tile, S[wave], lane, &s_res[samp2 >> 1], bd, st);
-          // write the finished TU back, 4 samples per lane (only the run's own samples ever leave the window)
-          const int nT = 1 << log2, l4 = log2 - 2;
-          for (int s = lane; s < (nT * nT) >> 2; s += 64) {
-            const int y = s >> l4, x = (s & ((1 << l4) - 1)) << 2;
-            const uint2 v = *reinterpret_cast<const uint2*>(&tile[(yw + y) * RUN_TILE_P + xw + x]);
-            store4_from_u16(gdst + x + y * stride, v);
-          }
         }
         w0 = n0; w1 = n1; w2 = n2; w3 = n3; samp2 = nsamp2; gaddr = ngaddr; ctl = nctl; rs = nrs;
       }
     }
     while (level < n_lvls - 1) { RUN_LDS_BARRIER(); level++; }
   }
+  // ---- write the run's samples to the picture: whole 8-sample chunks where both halves are the run's (one
+  // 16-byte write-through store), half chunks otherwise; nothing outside the run's own TUs is ever written.
+  // The flag is only raised after the run, so nothing is lost by storing here instead of per TU, and a
+  // write-through store costs one fabric write whatever its size.
+  __syncthreads();
+  {
+    PX* wplane = plane + ax0 + wy0 * stride;                             // picture address of window sample (0, 0)
+    const int rows = (int)run.y1 - (int)run.y0, nch = ((int)run.x1 - ax0 + 7) >> 3;
+    for (int idx = tid; idx < rows * nch; idx += nthr) {
+      const int r = 1 + idx / nch, cx = idx - (r - 1) * nch;
+      const uint32_t m = (s_mine[r] >> (2 * cx)) & 3u;
+      if (m == 0) continue;
+      const uint4 v = *reinterpret_cast<const uint4*>(&tile[r * RUN_TILE_P + 8 * cx]);
+      PX* g = wplane + r * stride + 8 * cx;
+      if (m == 3) store8_from_u16(g, v);
+      else if (m == 1) store4_from_u16(g, make_uint2(v.x, v.y));
+      else store4_from_u16(g + 4, make_uint2(v.z, v.w));
+    }
+  }
 
-  // publish: every handed-off byte was stored write-through (sc1); drain them, then raise the flag.
-  // (MI355X_MICROARCH.md, valid forms: sc1 payload stores + vmcnt(0) + flag on the producer,
-  //  poll + agent acquire + plain loads on the consumer; no L2 write-back fence needed.)
   st.mark(5);
-  if (tid == 0) s_ticket = atomicAdd(&sync[0], 1u);                    // next ticket: returns while the stores drain
+  st.count();
+  }
+  // the last run of this workgroup: drain, then raise its flag
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  st.mark(6);
-  st.count();
-  if (tid == 0) __hip_atomic_store(&sync[2 + ticket], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  ticket = __builtin_amdgcn_readfirstlane(s_ticket);
-  }
+  if (tid == 0 && prev != RUN_NO_TICKET)
+    __hip_atomic_store(&sync[2 + prev], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   st.flush();
 }
 
