@@ -77,7 +77,8 @@ struct de265hip_picture {
   int n_l0_size[4] = { 0, 0, 0, 0 };          // TU count per size in d_l0 (sorted 32,16,8,4)
   TuTask* d_l0 = nullptr; int n_l0 = 0;       // run mode: inter residual TUs + residual-only copies of intra TUs
   int16_t* d_resid = nullptr;                 // precomputed residual blocks of intra TUs
-  int n_runs = 0, n_workers = 0, run_box = 64, late_publish = 0; size_t sync_bytes = 0;
+  int n_runs = 0, n_batches = 0, n_workers = 0, run_box = 64, late_publish = 0; size_t sync_bytes = 0;
+  uint32_t* d_slots = nullptr;
   std::vector<int> level_start;       // level_start[l] .. level_start[l+1] in d_tus
   int n_mc = 0, n_pcm = 0, n_tus = 0;
   bool any_edges = false;
@@ -463,7 +464,9 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   pic->n_tus = (int)tasks.size();
 
   // ---- runs in dependency (ticket) order: producers first
-  std::vector<RunTask> runs; std::vector<uint32_t> run_deps; std::vector<TuTask> run_tus, resid_only;
+  std::vector<RunTask> runs; std::vector<uint32_t> run_deps, slots; std::vector<TuTask> run_tus, resid_only;
+  const bool micro_off = getenv("DE265HIP_NO_MICRO") != nullptr;
+  const int micro_tus = getenv("DE265HIP_MICRO_TUS") ? std::min(16, atoi(getenv("DE265HIP_MICRO_TUS"))) : 16;   // MICRO_TUS of k_run
   int64_t sum_lvls = 0;
   size_t n_resid = 0;
   int max_rl = 0;
@@ -472,14 +475,36 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     std::vector<int> count(max_rl + 2, 0), order(rb.size()), newidx(rb.size());
     for (auto& R : rb) count[R.level + 1]++;
     for (int l = 0; l <= max_rl; l++) count[l + 1] += count[l];
-    for (size_t i = 0; i < rb.size(); i++) { int k = count[rb[i].level]++; order[k] = (int)i; newidx[i] = k; }
+    // micro runs (<= 16 TUs of <= 8x8 inside a 32x32 box: most runs of a picture with inter PUs) are reconstructed by
+    // one wavefront each, four per workgroup and ticket; inside a level they come first (same-level runs are independent)
+    auto is_micro = [&](const RunBuild& R) {
+      if (micro_off || (int)R.tus.size() > micro_tus || R.x1 - R.x0 > 32 || R.y1 - R.y0 > 32) return false;
+      for (const TuTask& t : R.tus) if (t.log2_size > 3) return false;
+      return true;
+    };
+    std::vector<uint8_t> micro(rb.size(), 0);
+    for (size_t i = 0; i < rb.size(); i++) micro[i] = is_micro(rb[i]);
+    std::vector<int> count2(2 * (max_rl + 2) + 1, 0);
+    for (size_t i = 0; i < rb.size(); i++) count2[2 * rb[i].level + (micro[i] ? 0 : 1) + 1]++;
+    for (size_t l = 0; l + 1 < count2.size(); l++) count2[l + 1] += count2[l];
+    for (size_t i = 0; i < rb.size(); i++) { int k = count2[2 * rb[i].level + (micro[i] ? 0 : 1)]++; order[k] = (int)i; newidx[i] = k; }
     runs.resize(rb.size());
+    // ticket slots: a ticket is a batch of four slots: four micro runs, or one ordinary run (+ three empty slots)
+    for (size_t k = 0; k < rb.size(); k++) {
+      if (micro[order[k]]) slots.push_back((uint32_t)k | 0x80000000u);
+      else {
+        while (slots.size() & 3) slots.push_back(0xFFFFFFFFu);
+        slots.push_back((uint32_t)k);
+        for (int q = 0; q < 3; q++) slots.push_back(0xFFFFFFFFu);
+      }
+    }
+    while (slots.size() & 3) slots.push_back(0xFFFFFFFFu);
     for (size_t k = 0; k < rb.size(); k++) {
       const RunBuild& R = rb[order[k]];
       RunTask& o = runs[k]; memset(&o, 0, sizeof(o));
       o.x0 = (uint16_t)R.x0; o.y0 = (uint16_t)R.y0; o.x1 = (uint16_t)R.x1; o.y1 = (uint16_t)R.y1;
       o.wx1 = (uint16_t)std::min(R.wx1, R.x1 + 32); o.wy1 = (uint16_t)std::min(R.wy1, R.y1 + 32);
-      o.c_idx = (uint8_t)R.c; o.n_tus = (uint16_t)R.tus.size();
+      o.c_idx = (uint8_t)R.c; o.micro = micro[order[k]]; o.n_tus = (uint16_t)R.tus.size();
       o.first_tu = (uint32_t)run_tus.size(); o.dep_offset = (uint32_t)run_deps.size(); o.n_deps = (uint16_t)R.deps.size();
       o.res_offset = (uint32_t)n_resid;
       // TUs of the run: the TUs of one in-run level are independent of each other and are dealt round-robin to
@@ -490,7 +515,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       sum_lvls += nl;
       std::vector<TuTask> ordered; ordered.reserve(R.tus.size());
       {
-        const int nwv = dec->run_waves;
+        const int nwv = micro[order[k]] ? 1 : dec->run_waves;
         std::vector<int> rank(nl + 1, 0);
         std::vector<std::vector<TuTask>> lists(nwv);
         for (size_t i = 0; i < R.tus.size(); i++) {
@@ -531,7 +556,8 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     int widest = 0; for (int wv : width) widest = std::max(widest, wv);
     const char* wenv = getenv("DE265HIP_RUN_WORKERS");
     int cap = wenv ? atoi(wenv) : (run_box == 64 ? 768 : 2048);      // LDS-limited residency: 3 resp. 8 workgroups per CU
-    pic->n_workers = std::min(pic->n_runs, std::max(64, std::min(cap, widest + widest / 4)));
+    pic->n_batches = (int)(slots.size() / 4);
+    pic->n_workers = std::min(pic->n_batches, std::max(64, std::min(cap, widest + widest / 4)));
     // pictures with inter PUs have thousands of small runs in few levels (bound by run throughput): raise flags late;
     // all-intra pictures are bound by the producer->consumer chain: raise them first thing (DE265HIP_LATE_PUBLISH: 0/1)
     const char* lenv = getenv("DE265HIP_LATE_PUBLISH");
@@ -546,6 +572,16 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
         fin[i] = st + 8.0 + 0.45 * nl; lv[i] = sl + nl; cnt[i] = sn + 1;
         if (fin[i] > worst) { worst = fin[i]; worst_l = lv[i]; worst_n = cnt[i]; }
       }
+      int hist[8] = {0}, small32 = 0, nmicro = 0;
+      for (size_t i = 0; i < rb.size(); i++) {
+        const size_t n = rb[i].tus.size();
+        hist[n <= 1 ? 0 : n <= 2 ? 1 : n <= 4 ? 2 : n <= 8 ? 3 : n <= 16 ? 4 : n <= 32 ? 5 : n <= 64 ? 6 : 7]++;
+        bool ok = rb[i].x1 - rb[i].x0 <= 32 && rb[i].y1 - rb[i].y0 <= 32 && n <= 64;
+        for (const TuTask& t : rb[i].tus) if (t.log2_size > 3) ok = false;
+        small32 += ok; nmicro += ok && n <= 4 && rb[i].x1 - rb[i].x0 <= 16 && rb[i].y1 - rb[i].y0 <= 16;
+      }
+      fprintf(stderr, "de265hip runs: %zu, micro %d, <=8x8 TUs in 32x32 box %d; by TU count 1:%d 2:%d 3-4:%d 5-8:%d 9-16:%d 17-32:%d 33-64:%d >64:%d\n",
+              rb.size(), nmicro, small32, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7]);
       fprintf(stderr, "de265hip crit: est %.0f us, %d runs and %.0f in-run levels on the longest path\n", worst, worst_n, worst_l);
     }
     // tickets per draw (bits 8.. of the kernel's mode word): 1 for chain-bound pictures, several where the draw
@@ -685,6 +721,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   const size_t o_flags = L.add(nblk), o_qp = L.add(nblk), o_mot = L.add(nblk * sizeof(de265hip_motion));
   const size_t o_runs = L.add(runs.size() * sizeof(RunTask)), o_rdeps = L.add(run_deps.size() * 4);
   const size_t o_rtus = L.add(run_tus.size() * sizeof(TuTask));
+  const size_t o_slots = L.add(slots.size() * 4);
   const size_t o_l0 = L.add(l0.size() * sizeof(TuTask));
   const size_t upload_bytes = L.total;                 // everything above is written by the host
   // device-only scratch: boundary strengths, residual blocks, run flags (no staging, no upload)
@@ -706,6 +743,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   put(o_sao, saos.data(), saos.size() * sizeof(SaoCtb));
   put(o_runs, runs.data(), runs.size() * sizeof(RunTask)); put(o_rdeps, run_deps.data(), run_deps.size() * 4);
   put(o_rtus, run_tus.data(), run_tus.size() * sizeof(TuTask));
+  put(o_slots, slots.data(), slots.size() * 4);
   put(o_l0, l0.data(), l0.size() * sizeof(TuTask));
   put(o_flags, d->blk_flags, nblk); put(o_qp, d->blk_qp_y, nblk);
   if (d->blk_motion) put(o_mot, d->blk_motion, nblk * sizeof(de265hip_motion));
@@ -730,7 +768,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   pic->d_motion = (de265hip_motion*)(base + o_mot);
   pic->d_bs = base + o_bs;
   pic->d_runs = (RunTask*)(base + o_runs); pic->d_deps = (uint32_t*)(base + o_rdeps);
-  pic->d_run_tus = (TuTask*)(base + o_rtus); pic->d_sync = (uint32_t*)(base + o_sync);
+  pic->d_run_tus = (TuTask*)(base + o_rtus); pic->d_slots = (uint32_t*)(base + o_slots); pic->d_sync = (uint32_t*)(base + o_sync);
   pic->d_l0 = (TuTask*)(base + o_l0); pic->d_resid = (int16_t*)(base + o_resid);
 
   const int64_t Pbytes = (int64_t)p.width * p.height * 3 / 2 * px_bytes(p.bit_depth_luma);
@@ -811,10 +849,10 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
       (void)hipMemsetAsync(pic->d_sync, 0, pic->sync_bytes, st);
       if (pic->run_box == 64)
         hipLaunchKernelGGL((k_run<PX, 64>), dim3(pic->n_workers), dim3(64 * dec->run_waves), 0, st, P, d0, d1, d2, pic->d_runs, pic->d_deps,
-                           pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->n_runs, pic->late_publish, dec->dbg);
+                           pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->d_slots, pic->n_batches, pic->late_publish, dec->dbg);
       else
         hipLaunchKernelGGL((k_run<PX, 32>), dim3(pic->n_workers), dim3(64 * dec->run_waves), 0, st, P, d0, d1, d2, pic->d_runs, pic->d_deps,
-                           pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->n_runs, pic->late_publish, dec->dbg);
+                           pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->d_slots, pic->n_batches, pic->late_publish, dec->dbg);
     }
   } else {
     if (nlev > 0 && pic->level_start[1] > pic->level_start[0]) {

@@ -924,6 +924,193 @@ __device__ __forceinline__ void run_chain_small(uint32_t w0, int angle, int c, i
   WAVE_BARRIER_ONLY();
 }
 
+// ---- micro runs: <= 16 TUs of <= 8x8 inside a 32x32 box (most runs of a picture with inter PUs) ----
+// One wavefront reconstructs the whole run on its own: no workgroup barrier, no staging of operands; a workgroup
+// works on four of them at a time (one ticket).  The window is at most 41 rows x 48 columns.
+#define MICRO_P 56                       // window pitch (samples): 8 slack + 32 + 8 and a spare chunk, rows 16-byte aligned
+#define MICRO_H 41                       // 1 + 32 + 8 rows
+#define MICRO_BOX 32
+#define MICRO_TUS 16
+#define MICRO_SLICE 2520                 // uint16 per wavefront inside the workgroup's window array (>= MICRO_H * MICRO_P)
+#define MICRO_RES 1024                   // residual samples per wavefront (MICRO_TUS * 64)
+
+// one 4x4 / 8x8 TU, operands computed on the spot (intrapred.cc:395-431 substitution, :816-889 smoothing,
+// :903-1069 predictors); t in window coordinates; rs = this lane's residual
+template <int LOG2, typename PX>
+__device__ __forceinline__ void micro_intra_tu(const RunTu& t, uint16_t* tile, int lane, int rs, int bd, PX* gdst, int gstride)
+{
+  constexpr int nT = 1 << LOG2, nS = nT * nT, NB = 4 * nT + 1, C = 2 * nT;       // C: lane of border[0]
+  const int xB = t.x0, yB = t.y0, cIdx = t.c_idx;
+  const uint32_t avail = (uint32_t)t.avail;          // 2nT/4*2 + 1 <= 9 units
+  const int maxv = (1 << bd) - 1;
+  int bv = 1 << (bd - 1);
+  if (avail != 0) {
+    const int p = min(lane, NB - 1), i = p - C;
+    int src = i;
+    if (avail != ((2u << nT) - 1u)) {                 // not every unit available: nearest available one before
+      constexpr int cornerUnit = nT >> 1;
+      const int u = (i < 0) ? (p >> 2) : (i == 0 ? cornerUnit : cornerUnit + 1 + ((i - 1) >> 2));
+      if (!((avail >> u) & 1)) {
+        const uint32_t below = avail & ((2u << u) - 1u);
+        if (below) {
+          const int su = 31 - __clz((int)below);
+          src = (su < cornerUnit) ? (-C + 4 * su + 3) : (su == cornerUnit ? 0 : 4 * (su - cornerUnit));
+        } else {
+          const int su = __ffs((int)avail) - 1;
+          src = (su < cornerUnit) ? (-C + 4 * su) : (su == cornerUnit ? 0 : 4 * (su - cornerUnit - 1) + 1);
+        }
+      }
+    }
+    const int sx = src <= 0 ? xB - 1 : xB + src - 1;
+    const int sy = src < 0 ? yB - src - 1 : yB - 1;
+    bv = tile[sx + sy * MICRO_P];
+  }
+  const int mode = t.intra_mode >= 35 ? 1 : t.intra_mode;
+  if (LOG2 == 3 && cIdx == 0 && mode != 1 && min(abs(mode - 26), abs(mode - 10)) > 7) {
+    const int prev = __builtin_amdgcn_update_dpp(bv, bv, 0x138, 0xf, 0xf, false);   // wave_shr:1 -> lane-1
+    const int next = __builtin_amdgcn_update_dpp(bv, bv, 0x130, 0xf, 0xf, false);   // wave_shl:1 -> lane+1
+    const int f = (prev + 2 * bv + next + 2) >> 2;
+    bv = (lane == 0 || lane >= NB - 1) ? bv : f;
+  }
+#define BORD(idx) __builtin_amdgcn_ds_bpermute(((idx) + C) << 2, bv)
+  const int y = (lane >> LOG2) & (nT - 1), x = lane & (nT - 1);
+  int pv;
+  if (mode == 0) {
+    const int l = BORD(-1 - y), tp = BORD(1 + x);
+    const int tr = __builtin_amdgcn_readlane(bv, C + 1 + nT), bl = __builtin_amdgcn_readlane(bv, C - 1 - nT);
+    pv = ((nT - 1 - x) * l + (x + 1) * tr + (nT - 1 - y) * tp + (y + 1) * bl + nT) >> (LOG2 + 1);
+  } else if (mode == 1) {
+    const int tp = BORD(1 + x), l = BORD(-1 - y);
+    const int v = (lane >= nT && lane <= 3 * nT && lane != C) ? bv : 0;
+    const int dc = (wave_sum_dpp(v) + nT) >> (LOG2 + 1);
+    const int corner = (__builtin_amdgcn_readlane(bv, C - 1) + 2 * dc + __builtin_amdgcn_readlane(bv, C + 1) + 2) >> 2;
+    pv = dc;
+    if (cIdx == 0) pv = (x | y) == 0 ? corner : (y == 0 ? (tp + 3 * dc + 2) >> 2 : (x == 0 ? (l + 3 * dc + 2) >> 2 : dc));
+  } else {
+    const int angle = t.angle;
+    const bool vert = mode >= 18;
+    const int inv = t.inv_angle;
+    const int a = vert ? y : x, b = vert ? x : y;
+    const int iIdx = ((a + 1) * angle) >> 5, iFact = ((a + 1) * angle) & 31;
+    const int i0 = b + iIdx + 1, i1 = i0 + 1;
+    const int k0 = i0 >= 0 ? i0 : -((i0 * inv + 128) >> 8);
+    const int k1 = i1 >= 0 ? i1 : -((i1 * inv + 128) >> 8);
+    const int r0 = BORD(vert ? k0 : -k0), r1 = BORD(vert ? min(k1, C) : -min(k1, C));
+    const int ev = BORD(vert ? -1 - y : 1 + x);
+    pv = ((32 - iFact) * r0 + iFact * r1 + 16) >> 5;
+    if (cIdx == 0 && (mode == 26 || mode == 10)) {
+      const int b0 = __builtin_amdgcn_readlane(bv, C);
+      const int b1 = vert ? __builtin_amdgcn_readlane(bv, C + 1) : __builtin_amdgcn_readlane(bv, C - 1);
+      const int e = clip3(0, maxv, b1 + ((ev - b0) >> 1));
+      pv = (vert ? x == 0 : y == 0) ? e : pv;
+    }
+  }
+#undef BORD
+  const int outv = clip3(0, maxv, pv + rs);
+  if (lane < nS) tile[xB + x + (yB + y) * MICRO_P] = (uint16_t)outv;
+  // four adjacent lanes are packed with two DPP row shifts, every fourth lane issues one write-through store
+  const int w01 = outv | (__builtin_amdgcn_update_dpp(0, outv, 0x101, 0xf, 0xf, true) << 16);   // row_shl:1
+  const int w23 = __builtin_amdgcn_update_dpp(0, w01, 0x102, 0xf, 0xf, true);                   // row_shl:2
+  if (lane < nS && (x & 3) == 0) store4_packed<PX>(gdst + x + y * gstride, w01, w23);
+  WAVE_BARRIER_ONLY();
+}
+
+template <typename PX>
+__device__ __forceinline__ void micro_run(const PicDev& P, const PlaneRef& pl0, const PlaneRef& pl1, const PlaneRef& pl2,
+                                          const RunTask* __restrict__ runs, const uint32_t* __restrict__ deps,
+                                          uint32_t* sync, uint32_t* err, const TuTask* __restrict__ tasks,
+                                          const int16_t* __restrict__ resid, uint16_t* mt, int16_t* mres,
+                                          uint32_t r, int lane, int dbg)
+{
+  const RunTask run = runs[r];
+  const int n_tus = min((int)run.n_tus, MICRO_TUS);
+  // one round trip: producer ids (a lane each) and the TU records (a lane each, two 16-byte loads)
+  uint32_t dep_id = 0;
+  const bool has_dep = lane < (int)run.n_deps;
+  if (has_dep) dep_id = deps[run.dep_offset + lane];
+  uint4 ra = make_uint4(0, 0, 0, 0), rb = ra;
+  if (lane < n_tus) {
+    const uint4* q = reinterpret_cast<const uint4*>(tasks + run.first_tu + lane);
+    ra = q[0]; rb = q[1];
+  }
+  const int c = run.c_idx;
+  const PlaneRef pr = c == 0 ? pl0 : (c == 1 ? pl1 : pl2);
+  PX* plane = (PX*)pr.ptr;
+  const int stride = pr.stride;
+  const int cw = c ? P.width >> 1 : P.width, ch = c ? P.height >> 1 : P.height;
+  const int bd = c ? P.bd_chroma : P.bd_luma;
+  const int wx0 = (int)run.x0 - 1, wy0 = (int)run.y0 - 1;
+  const int wx1 = min(min((int)run.wx1, cw), wx0 + 1 + MICRO_BOX + 8), wy1 = min(min((int)run.wy1, ch), wy0 + MICRO_H);
+  const int ax0 = wx0 & ~7;
+  // second round trip: residuals (into this wavefront's LDS slice) and the first look at the producers' flags
+  uint32_t flag0 = 1;
+  if (has_dep) flag0 = __hip_atomic_load(&sync[2 + dep_id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int k0 = 0; k0 < n_tus; k0 += 4) {                              // four loads in flight
+    int16_t rv[4]; int ro[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int k = min(k0 + u, n_tus - 1);
+      const uint32_t w1 = __builtin_amdgcn_readlane(ra.y, k), samp = __builtin_amdgcn_readlane(ra.w, k) & (MICRO_RES - 1);
+      const uint32_t roff = __builtin_amdgcn_readlane(rb.z, k);
+      const int nS = 1 << (2 * (w1 & 0xFF));
+      ro[u] = (k0 + u < n_tus && lane < nS) ? (int)samp + lane : -1;
+      rv[u] = (ro[u] >= 0 && ((w1 >> 16) & DE265HIP_TU_CBF)) ? resid[roff + lane] : (int16_t)0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) if (ro[u] >= 0) mres[ro[u]] = rv[u];
+  }
+  // producers (bounded spin, as in the workgroup path)
+  for (int i = lane; i < (int)run.n_deps; i += 64) {
+    const uint32_t* flag = &sync[2 + (i == lane ? dep_id : deps[run.dep_offset + i])];
+    int spins = 0;
+    uint32_t f = (i == lane) ? flag0 : 0u;
+    while (f == 0 && !(dbg & 32)) {
+      if (spins) { if (spins < 4) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(64); }
+      if (++spins > RUN_SPIN_LIMIT) { atomicExch(err, 1u); break; }
+      f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (run.n_deps && !(dbg & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // this wavefront's own loads follow
+  // window: at most 41 rows x 6 chunks of 8 samples
+  const int nchx = (wx1 - ax0 + 7) >> 3, nrows = wy1 - wy0, nchunks = nchx * nrows;
+  {
+    uint4 v[4]; int off[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int idx = u * 64 + lane;
+      off[u] = -1;
+      if (idx < nchunks) {
+        const int rr = idx / nchx, cx = idx - rr * nchx;
+        const int gx = ax0 + 8 * cx, gy = wy0 + rr;
+        if (gx >= 0 && gy >= 0) { v[u] = load8_as_u16(plane + gx + gy * stride); off[u] = rr * MICRO_P + 8 * cx; }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (off[u] >= 0) *reinterpret_cast<uint4*>(&mt[off[u]]) = v[u];
+  }
+  LDS_SYNC();
+  // the chain
+  for (int k = 0; k < n_tus; k++) {
+    const uint32_t w0 = __builtin_amdgcn_readlane(ra.x, k), w1 = __builtin_amdgcn_readlane(ra.y, k);
+    const uint32_t w3 = __builtin_amdgcn_readlane(ra.w, k);
+    const uint32_t w4 = __builtin_amdgcn_readlane(rb.x, k), w7 = __builtin_amdgcn_readlane(rb.w, k);
+    RunTu t;
+    const int gx0 = w0 & 0xFFFF, gy0 = w0 >> 16;
+    t.x0 = gx0 - ax0; t.y0 = gy0 - wy0;
+    t.log2_size = w1 & 0xFF; t.c_idx = c; t.flags = (w1 >> 16) & 0xFF; t.intra_mode = w1 >> 24;
+    t.avail = w4; t.resid_offset = 0;
+    t.angle = (int)(int8_t)(w7 & 0xFF); t.inv_angle = (int)(int16_t)(w7 >> 16);
+    PX* gdst = plane + gx0 + gy0 * stride;
+    const int rs = mres[(w3 & (MICRO_RES - 1)) + (lane & ((1 << (2 * t.log2_size)) - 1))];
+    if (t.log2_size == 2) micro_intra_tu<2, PX>(t, mt, lane, rs, bd, gdst, stride);
+    else micro_intra_tu<3, PX>(t, mt, lane, rs, bd, gdst, stride);
+  }
+  // publish: write-through stores drained, then the flag
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) __hip_atomic_store(&sync[2 + r], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 #define RUN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // Ticket draw on the scalar unit (s_atomic_add ... glc returns the old value through lgkmcnt): unlike a vector
@@ -940,7 +1127,7 @@ template <typename PX, int BOX>
 __global__ __launch_bounds__(64 * RUN_WAVES)
 void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __restrict__ runs,
            const uint32_t* __restrict__ deps, uint32_t* sync, uint32_t* err, const TuTask* __restrict__ tasks,
-           const int16_t* __restrict__ resid, int n_runs, int late_publish, int dbg)
+           const int16_t* __restrict__ resid, const uint32_t* __restrict__ slots, int n_batches, int late_publish, int dbg)
 {
   constexpr int RUN_TILE_H = RUN_TILE_H_OF(BOX), RUN_TILE_P = RUN_TILE_P_OF(BOX);
   constexpr int MAX_TUS = BOX * BOX / 16;
@@ -995,8 +1182,20 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
     batch_end = next_ticket + batch;
   }
   st.mark(6);
-  const uint32_t ticket = next_ticket++;                               // uniform: scalar loads/branches below
-  if (ticket >= (uint32_t)n_runs) break;
+  const uint32_t bticket = next_ticket++;                              // uniform: scalar loads/branches below
+  if (bticket >= (uint32_t)n_batches) break;
+  // a ticket is four slots: four micro runs (a wavefront each, no workgroup barrier), or one ordinary run
+  const uint4 sl = *reinterpret_cast<const uint4*>(slots + 4 * bticket);
+  if (sl.x & 0x80000000u) {
+    for (int q = wave; q < 4; q += (nthr >> 6)) {
+      const uint32_t mine = q == 0 ? sl.x : (q == 1 ? sl.y : (q == 2 ? sl.z : sl.w));
+      if (mine != 0xFFFFFFFFu)
+        micro_run<PX>(P, pl0, pl1, pl2, runs, deps, sync, err, tasks, resid, tile + q * MICRO_SLICE,
+                      s_res + q * MICRO_RES, mine & 0x7FFFFFFFu, lane, dbg);
+    }
+    continue;
+  }
+  const uint32_t ticket = sl.x;
   const RunTask run = runs[ticket];
   st.mark(0);
   const bool has_dep = tid < (int)run.n_deps;
@@ -1076,6 +1275,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
     }
     window_issue(0);
   }
+  if (!(dbg & 64))
   for (int s = tid; s < n_samples; s += nthr)
     run_prepare_sample<RUN_TILE_P>(s, s_task, s_own, s_res, s_ctl, s_gat, s_mine, resid, res_base, CONST_ADDR);
   st.mark(2);
@@ -1163,6 +1363,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   {
     PX* wplane = plane + ax0 + wy0 * stride;                             // picture address of window sample (0, 0)
     const int rows = (int)run.y1 - (int)run.y0, nch = ((int)run.x1 - ax0 + 7) >> 3;
+    if (!(dbg & 1024))
     for (int idx = tid; idx < rows * nch; idx += nthr) {
       const int r = 1 + idx / nch, cx = idx - (r - 1) * nch;
       const uint32_t m = (s_mine[r] >> (2 * cx)) & 3u;
@@ -1209,10 +1410,10 @@ template __global__ void k_tu<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, con
                                        const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
 template __global__ void k_tu<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int,
                                         const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
-template __global__ void k_run<uint8_t, 64>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, int, int, int);
-template __global__ void k_run<uint16_t, 64>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, int, int, int);
-template __global__ void k_run<uint8_t, 32>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, int, int, int);
-template __global__ void k_run<uint16_t, 32>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, int, int, int);
+template __global__ void k_run<uint8_t, 64>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, const uint32_t*, int, int, int);
+template __global__ void k_run<uint16_t, 64>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, const uint32_t*, int, int, int);
+template __global__ void k_run<uint8_t, 32>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, const uint32_t*, int, int, int);
+template __global__ void k_run<uint16_t, 32>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, const uint32_t*, int, int, int);
 template __global__ void k_fn_residual<uint8_t>(int, int, int, uint8_t*, int, const int32_t*, const int16_t*);
 template __global__ void k_fn_residual<uint16_t>(int, int, int, uint16_t*, int, const int32_t*, const int16_t*);
 
