@@ -40,7 +40,7 @@ struct TuTask {
   uint16_t x0, y0;
   uint8_t  log2_size, c_idx, flags, intra_mode;
   int8_t   qp;
-  uint8_t  run_level;      // run mode: in-run dependency level of the TU (0-based)
+  uint8_t  run_level;      // run mode (run-ordered array): workgroup barriers the TU's wavefront passes before it (k_run)
   uint16_t n_coeff;
   uint32_t coeff_offset;   // run mode (run-ordered array only): sample offset of the TU inside its run
   uint64_t avail;
@@ -74,7 +74,7 @@ struct RunTask {
   uint16_t n_tus;
   uint32_t first_tu;         // into the run-ordered TuTask array
   uint32_t dep_offset;       // into the producer-run id array
-  uint16_t n_deps, n_lvls;  // n_lvls: in-run dependency levels (TUs of one level are independent of each other)
+  uint16_t n_deps, n_lvls;  // n_lvls: workgroup barriers of the run's chain (barrier epochs, see host.hip)
   uint32_t res_offset;       // the run's residual blocks (TUs with coefficients only): one contiguous int16 range
   uint32_t n_samples;        // samples of all TUs of the run
   uint16_t wave_end[4];      // the run's TUs are stored as one list per wavefront of the workgroup (each list in

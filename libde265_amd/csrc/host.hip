@@ -158,8 +158,10 @@ int make_geometry(const de265hip_pic_params& p, Geometry& g)
 uint64_t intra_availability(const de265hip_picture_desc& d, const Geometry& g, const de265hip_tu& tu,
                             const std::vector<uint16_t>& lvl, int map_w, int* level_out,
                             const std::vector<int32_t>& runmap, std::vector<int>& producers,
-                            const std::vector<uint16_t>& llvl, int cur_run, int* local_level_out)
+                            const std::vector<uint16_t>& llvl, int cur_run, int* local_level_out,
+                            const std::vector<uint16_t>& tumap, std::vector<uint16_t>& prod_tus)
 {
+  prod_tus.clear();
   producers.clear();
   const de265hip_pic_params& p = d.params;
   const int nT = 1 << tu.log2_size, sub = tu.c_idx ? 2 : 1;
@@ -192,7 +194,11 @@ uint64_t intra_availability(const de265hip_picture_desc& d, const Geometry& g, c
     mask |= 1ull << u;
     lev = std::max(lev, (int)lvl[(xs >> 2) + (ys >> 2) * map_w]);
     const int r = runmap[(xs >> 2) + (ys >> 2) * map_w];
-    if (r >= 0 && r == cur_run) llev = std::max(llev, (int)llvl[(xs >> 2) + (ys >> 2) * map_w]);
+    if (r >= 0 && r == cur_run) {
+      llev = std::max(llev, (int)llvl[(xs >> 2) + (ys >> 2) * map_w]);
+      const uint16_t pt = tumap[(xs >> 2) + (ys >> 2) * map_w];          // producing TU inside the current run
+      if (std::find(prod_tus.begin(), prod_tus.end(), pt) == prod_tus.end()) prod_tus.push_back(pt);
+    }
     if (r >= 0 && std::find(producers.begin(), producers.end(), r) == producers.end()) producers.push_back(r);
   };
   if (aL)
@@ -365,12 +371,15 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   // runs: maximal intervals of the per-component intra TU sequence inside one CTB in which
   // every TU reads from the run so far (see k_run); independent TUs start a new run
   struct RunBuild { int c, ctu, x0, y0, x1, y1, level, wx1, wy1; std::vector<TuTask> tus; std::vector<int> deps;
-                    std::vector<uint16_t> llev; };
+                    std::vector<uint16_t> llev; std::vector<std::vector<uint16_t>> prods; };
   std::vector<RunBuild> rb;
   std::vector<int32_t> runmap[3];
   for (int c = 0; c < 3; c++) runmap[c].assign((size_t)map_w[c] * map_h[c], -1);
   std::vector<uint16_t> llvl[3];                 // in-run dependency level of the TU covering a 4x4 unit
   for (int c = 0; c < 3; c++) llvl[c].assign((size_t)map_w[c] * map_h[c], 0);
+  std::vector<uint16_t> tumap[3];                // index (inside its run) of the TU covering a 4x4 unit
+  for (int c = 0; c < 3; c++) tumap[c].assign((size_t)map_w[c] * map_h[c], 0);
+  std::vector<uint16_t> prod_tus;
   int cur_run[3] = { -1, -1, -1 };
   std::vector<int> producers;
   // dense intra (no inter PUs at all): one run per CTB and component, fewest hand-offs on the z-scan chain.
@@ -413,10 +422,11 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
         t.inv_angle = (m >= 11 && m <= 25 && k_angle[m] < 0) ? k_inv[m - 11] : 0;
       }
       int llev = 1;
-      t.avail = intra_availability(*d, g, tu, lvl[c], map_w[c], &level, runmap[c], producers, llvl[c], cur_run[c], &llev);
+      t.avail = intra_availability(*d, g, tu, lvl[c], map_w[c], &level, runmap[c], producers, llvl[c], cur_run[c], &llev,
+                                   tumap[c], prod_tus);
       const int ctu = ((tu.x0 * sub) >> p.log2_ctb_size) + ((tu.y0 * sub) >> p.log2_ctb_size) * g.ctbs_w;
       int r = cur_run[c];
-      bool extends = r >= 0 && rb[r].ctu == ctu && rb[r].tus.size() < 256 &&        /* RUN_MAX_LVLS of k_run */
+      bool extends = r >= 0 && rb[r].ctu == ctu && rb[r].tus.size() < 255 &&        /* RUN_MAX_TUS of k_run; positions + 1 fit a byte */
                      std::find(producers.begin(), producers.end(), r) != producers.end();
       if (extends && run_box < 64) {       // sparse-intra pictures: keep every run inside a run_box^2 bounding box
         const int bw = std::max(rb[r].x1, tu.x0 + nT) - std::min(rb[r].x0, (int)tu.x0);
@@ -428,6 +438,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
         rb.push_back(RunBuild{ c, ctu, tu.x0, tu.y0, tu.x0 + nT, tu.y0 + nT, 0, 0, 0, {}, {} });
         cur_run[c] = r;
         llev = 1;
+        prod_tus.clear();
       }
       RunBuild& R = rb[r];
       R.x0 = std::min(R.x0, (int)tu.x0); R.y0 = std::min(R.y0, (int)tu.y0);
@@ -435,11 +446,13 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       R.wx1 = std::max(R.wx1, tu.x0 + 2 * nT); R.wy1 = std::max(R.wy1, tu.y0 + 2 * nT);    // top-right / bottom-left reach
       for (int pr : producers)
         if (pr != r && std::find(R.deps.begin(), R.deps.end(), pr) == R.deps.end()) R.deps.push_back(pr);
-      R.tus.push_back(t); R.llev.push_back((uint16_t)llev);
+      const uint16_t tu_in_run = (uint16_t)R.tus.size();
+      R.tus.push_back(t); R.llev.push_back((uint16_t)llev); R.prods.push_back(prod_tus);
       for (int y = tu.y0 >> 2; y < (tu.y0 + nT) >> 2; y++)
         for (int x = tu.x0 >> 2; x < (tu.x0 + nT) >> 2; x++) {
           lvl[c][x + (size_t)y * map_w[c]] = (uint16_t)level;
           llvl[c][x + (size_t)y * map_w[c]] = (uint16_t)llev;
+          tumap[c][x + (size_t)y * map_w[c]] = tu_in_run;
           runmap[c][x + (size_t)y * map_w[c]] = r;
         }
       alg_intra += (int64_t)bpp * (4 * nT + 1) + (int64_t)bpp * nT * nT;
@@ -467,7 +480,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   std::vector<RunTask> runs; std::vector<uint32_t> run_deps, slots; std::vector<TuTask> run_tus, resid_only;
   const bool micro_off = getenv("DE265HIP_NO_MICRO") != nullptr;
   const int micro_tus = getenv("DE265HIP_MICRO_TUS") ? std::min(16, atoi(getenv("DE265HIP_MICRO_TUS"))) : 16;   // MICRO_TUS of k_run
-  int64_t sum_lvls = 0;
+  int64_t sum_lvls = 0, dbg_foreign = 0, dbg_w[4] = { 0, 0, 0, 0 };
   size_t n_resid = 0;
   int max_rl = 0;
   {
@@ -514,26 +527,41 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       o.n_lvls = (uint16_t)nl;
       sum_lvls += nl;
       std::vector<TuTask> ordered; ordered.reserve(R.tus.size());
+      std::vector<uint32_t> ordered_req; ordered_req.reserve(R.tus.size());
       {
         const int nwv = micro[order[k]] ? 1 : dec->run_waves;
-        std::vector<int> rank(nl + 1, 0);
-        std::vector<std::vector<TuTask>> lists(nwv);
-        for (size_t i = 0; i < R.tus.size(); i++) {
-          TuTask tt = R.tus[i];
-          tt.run_level = (uint8_t)(R.llev[i] - 1);
-          lists[rank[R.llev[i]]++ % nwv].push_back(tt);
+        // the TUs of one in-run level are independent of each other: dealt round-robin to the wavefronts of the
+        // workgroup, every list in level order; the chain passes one workgroup barrier per level.
+        // (measured on a 4K all-intra picture: this 3.46 ms; list scheduling that keeps z-scan chains on one wavefront,
+        //  with barriers only where a producer sits on another wavefront, 4.0-4.2 ms: a wavefront that runs ahead
+        //  arrives late at the barrier the others need; progress counters in LDS polled by the waiting wavefronts
+        //  3.9 ms: the pollers take issue slots from the working wavefronts of the other workgroups on their SIMDs)
+        std::vector<std::vector<int>> lists(nwv);             // TU indices (decode order inside the run)
+        std::vector<uint16_t> epoch(R.tus.size(), 0);
+        int n_epochs = nl > 0 ? nl - 1 : 0;
+        {
+          std::vector<int> rank(nl + 1, 0);
+          for (size_t i = 0; i < R.tus.size(); i++) { lists[rank[R.llev[i]]++ % nwv].push_back((int)i); epoch[i] = (uint16_t)(R.llev[i] - 1); }
+          for (int w = 0; w < nwv; w++)
+            std::stable_sort(lists[w].begin(), lists[w].end(), [&](int a, int b) { return R.llev[a] < R.llev[b]; });
         }
         for (int w = 0; w < 4; w++) {
-          if (w < nwv) {
-            std::stable_sort(lists[w].begin(), lists[w].end(),
-                             [](const TuTask& a, const TuTask& b) { return a.run_level < b.run_level; });
-            ordered.insert(ordered.end(), lists[w].begin(), lists[w].end());
-          }
+          if (w < nwv)
+            for (int i : lists[w]) {
+              TuTask tt = R.tus[i];
+              ordered.push_back(tt);
+              ordered_req.push_back(epoch[i]);
+              dbg_w[w]++;
+            }
           o.wave_end[w] = (uint16_t)ordered.size();
         }
+        if (n_epochs > 255) { delete pic; return DE265HIP_ERROR_NOT_IMPLEMENTED; }
+        o.n_lvls = (uint16_t)n_epochs;                   // workgroup barriers of the run's chain
+        dbg_foreign += n_epochs;
       }
       uint32_t samp = 0;
-      for (TuTask tt : ordered) {
+      for (size_t oi = 0; oi < ordered.size(); oi++) {
+        TuTask tt = ordered[oi];
         const uint32_t coeff_offset = tt.coeff_offset;
         tt.coeff_offset = samp; samp += 1u << (2 * tt.log2_size);
         if (tt.flags & DE265HIP_TU_CBF) {
@@ -542,6 +570,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
           TuTask ro = tt; ro.flags |= D265_TU_RESID_ONLY; ro.coeff_offset = coeff_offset;
           resid_only.push_back(ro);
         }
+        tt.run_level = (uint8_t)ordered_req[oi];         // the run-ordered copy carries the TU's barrier epoch
         run_tus.push_back(tt);
       }
       o.n_samples = samp;
@@ -582,6 +611,8 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       }
       fprintf(stderr, "de265hip runs: %zu, micro %d, <=8x8 TUs in 32x32 box %d; by TU count 1:%d 2:%d 3-4:%d 5-8:%d 9-16:%d 17-32:%d 33-64:%d >64:%d\n",
               rb.size(), nmicro, small32, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7]);
+      fprintf(stderr, "de265hip chain: %lld barrier epochs in all runs; TUs per wavefront %lld %lld %lld %lld\n",
+              (long long)dbg_foreign, (long long)dbg_w[0], (long long)dbg_w[1], (long long)dbg_w[2], (long long)dbg_w[3]);
       fprintf(stderr, "de265hip crit: est %.0f us, %d runs and %.0f in-run levels on the longest path\n", worst, worst_n, worst_l);
     }
     // tickets per draw (bits 8.. of the kernel's mode word): 1 for chain-bound pictures, several where the draw

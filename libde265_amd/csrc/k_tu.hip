@@ -621,40 +621,47 @@ struct RunTu {
   uint32_t resid_offset;
   uint64_t avail;
 };
-// Staged form in LDS (16 bytes, written once per run by run_tu_pack, read back with one ds_read_b128):
-//   x: window x | window y << 8 | log2 << 16 | cbf << 19 | mode << 20 | smooth << 26 | kind << 27 | vertical << 29
-//      (mode >= 35 folded into DC; kind 0 planar, 1 DC, 2 angular, 3 angular with the mode 10/26 edge filter)
-//   y: (uint8)angle | in-run level << 8 | inv_angle << 16
+// Staged form in LDS (16 bytes per TU, written once per run by run_tu_pack).  The chain reads x and y only:
+//   x: tb (LDS byte address of the TU origin in the window, 15 bits) | is4x4 << 15 | in-run level << 16 | kind << 24 |
+//      vertical << 26 | smooth << 27 | big (16x16, 32x32) << 28 | cbf << 29
+//      (kind 0 planar, 1 DC, 2 angular, 3 angular with the mode 10/26 edge filter; mode >= 35 folded into DC)
+//   y: 4 * (sample offset in the run) (14 bits) | mode << 14 | (uint8)angle << 24
 //   z: avail bits 0-31
-//   w: avail bit 32 | (offset in the run's residual range) << 1 | (sample offset in the run) << 16
-#define RTU_SMOOTH (1u << 26)
+//   w: avail bit 32 | (offset in the run's residual range) << 1 | window x << 13 | window y << 20 | log2 << 27
+#define RTU_IS4 (1u << 15)
+#define RTU_VERT (1u << 26)
+#define RTU_SMOOTH (1u << 27)
+#define RTU_BIG (1u << 28)
+#define RTU_CBF (1u << 29)
+template <int RUN_TILE_P>
 __device__ __forceinline__ uint4 run_tu_pack(const TuTask* __restrict__ tp, int k, int ax0, int wy0, uint32_t res_base, int c)
 {
   const uint4* q = reinterpret_cast<const uint4*>(tp + k);
   const uint4 a = q[0], b = q[1];
-  const uint32_t x0 = a.x & 0xFFFF, y0 = a.x >> 16;
+  const uint32_t xw = (a.x & 0xFFFF) - ax0, yw = (a.x >> 16) - wy0;
   const uint32_t log2 = a.y & 0xFF, flags = (a.y >> 16) & 0xFF;
   uint32_t mode = a.y >> 24; if (mode >= 35) mode = 1;
   const uint32_t level = (a.z >> 8) & 0xFF, samp = a.w;
   const int md = min(abs((int)mode - 26), abs((int)mode - 10));
   const uint32_t kind = mode == 0 ? 0u : (mode == 1 ? 1u : ((c == 0 && md == 0 && log2 < 5) ? 3u : 2u));
-  const uint32_t smooth = (c == 0 && log2 == 3 && mode != 1 && md > 7) ? RTU_SMOOTH : 0u;
   uint4 o;
-  o.x = (x0 - ax0) | ((y0 - wy0) << 8) | (log2 << 16) | ((flags & DE265HIP_TU_CBF) ? 1u << 19 : 0u) | (mode << 20) |
-        smooth | (kind << 27) | (mode >= 18 ? 1u << 29 : 0u);
-  o.y = (b.w & 0xFF) | (level << 8) | (b.w & 0xFFFF0000u);
+  o.x = ((yw * RUN_TILE_P + xw) * 2) | (log2 == 2 ? RTU_IS4 : 0u) | (level << 16) | (kind << 24) |
+        (mode >= 18 ? RTU_VERT : 0u) | ((c == 0 && log2 == 3 && mode != 1 && md > 7) ? RTU_SMOOTH : 0u) |
+        (log2 > 3 ? RTU_BIG : 0u) | ((flags & DE265HIP_TU_CBF) ? RTU_CBF : 0u);
+  o.y = (samp << 2) | (mode << 14) | ((b.w & 0xFF) << 24);
   o.z = b.x;
-  o.w = (b.y & 1u) | (((b.z - res_base) & 0x1FFFu) << 1) | (samp << 16);
+  o.w = (b.y & 1u) | (((b.z - res_base) & 0xFFFu) << 1) | (xw << 13) | (yw << 20) | (log2 << 27);
   return o;
 }
-__device__ __forceinline__ RunTu run_tu_unpack(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, int c_idx)
+__device__ __forceinline__ RunTu run_tu_unpack(const uint4& r, int c_idx)
 {
   RunTu t;
-  t.x0 = w0 & 0xFF; t.y0 = (w0 >> 8) & 0xFF;
-  t.log2_size = (w0 >> 16) & 7; t.c_idx = c_idx; t.flags = (w0 >> 19) & 1; t.intra_mode = (w0 >> 20) & 63;
-  t.angle = (int)(int8_t)(w1 & 0xFF); t.inv_angle = (int)(int16_t)(w1 >> 16);
-  t.avail = (uint64_t)w2 | ((uint64_t)(w3 & 1) << 32);
-  t.resid_offset = (w3 >> 1) & 0x1FFF;
+  t.x0 = (r.w >> 13) & 0x7F; t.y0 = (r.w >> 20) & 0x7F;
+  t.log2_size = (r.w >> 27) & 7; t.c_idx = c_idx; t.flags = (r.x & RTU_CBF) ? 1 : 0; t.intra_mode = (r.y >> 14) & 63;
+  t.angle = (int)(int8_t)(r.y >> 24);
+  t.inv_angle = (t.intra_mode >= 11 && t.intra_mode <= 25 && t.angle < 0) ? (int)c_inv_angle[t.intra_mode - 11] : 0;
+  t.avail = (uint64_t)r.z | ((uint64_t)(r.w & 1) << 32);
+  t.resid_offset = (r.w >> 1) & 0xFFF;
   return t;
 }
 
@@ -799,16 +806,20 @@ __device__ __forceinline__ void run_intra_tu(const PicDev& P, const RunTu& t, ui
   LDS_SYNC();
 }
 
-// ---- register-resident fast path for 4x4 and 8x8 intra TUs (about 95 % of all TUs) ----
+// ---- fast path for 4x4 and 8x8 intra TUs (about 95 % of all TUs) ----
 // A run is bound by the latency of its TU chain, and a lone wavefront issues one instruction every ~4 cycles,
 // so the chain carries only what depends on pixel values.  Everything that depends on the TU records alone is
 // computed beforehand by all threads of the workgroup (run_prepare_sample, typically while the run still waits
-// for its producers) and left in LDS per border lane / per sample:
-//   s_gat  LDS byte address of the window sample each border lane reads (substitution of unavailable
-//          neighbours, intrapred.cc:395-431, already resolved; a constant cell when nothing is available)
-//   s_ctl  per sample: the border lanes of its two predictor operands (byte 0: A*4, byte 1: B*4)
+// for its producers) and left in LDS per sample:
+//   s_ctl  32 bits per sample.  TUs without smoothing: the LDS byte addresses (in the pixel window) of the sample's
+//          two predictor operands, substitution of unavailable neighbours (intrapred.cc:395-431) already resolved
+//          (a constant cell when nothing is available).  Smoothed TUs (8x8 luma): bits 0-15 the border lanes of the
+//          two operands (A*4 | B*4 << 8), bits 16-31 the window address border lane `local` gathers from.
+//   s_ex   per TU: the window addresses of the two TU-wide operands (planar: top-right | bottom-left << 16; edge
+//          filter: corner)
 //   s_res  per sample: residual (0 for TUs without coefficients)
-// On the chain: one ds_read (gather) -> [DPP smoothing] -> two ds_bpermute -> ~10 VALU -> ds_write + store.
+// On the chain, TU without smoothing: two ds_read (operands) -> ~10 VALU -> ds_write: ONE LDS round trip.
+// Smoothed TU: ds_read (gather) -> DPP [1 2 1] -> two ds_bpermute -> ~10 VALU -> ds_write.
 #define WAVE_BARRIER_ONLY() asm volatile("" ::: "memory")
 #define RUN_MAX_TUS 256                 // a run lies inside one 64x64 CTB: at most 256 TUs / levels
 
@@ -845,24 +856,26 @@ __device__ __forceinline__ int run_gather_addr(int p, int nT, int xB, int yB, ui
 // Off-chain preparation of sample s of the run (one thread per sample).
 template <int RUN_TILE_P>
 __device__ __forceinline__ void run_prepare_sample(int s, const uint4* s_task, const uint8_t* s_own, int16_t* s_res,
-                                                   uint16_t* s_ctl, uint16_t* s_gat, uint32_t* s_mine,
+                                                   uint32_t* s_ctl, uint32_t* s_ex, uint32_t* s_mine,
                                                    const int16_t* __restrict__ resid, uint32_t res_base, int const_addr)
 {
   const int k = s_own[s >> 4];
   const uint4 r = s_task[k];
-  const int log2 = (r.x >> 16) & 7, nT = 1 << log2;
-  const int samp = r.w >> 16, local = s - samp;
+  const int log2 = (r.w >> 27) & 7, nT = 1 << log2;
+  const int samp = (r.y & 0x3FFF) >> 2, local = s - samp;
   const int x = local & (nT - 1), y = local >> log2;
-  s_res[s] = (r.x & (1u << 19)) ? resid[res_base + ((r.w >> 1) & 0x1FFF) + local] : (int16_t)0;
-  if ((x & 3) == 0) atomicOr(&s_mine[(int)((r.x >> 8) & 0xFF) + y], 1u << (((int)(r.x & 0xFF) + x) >> 2));
+  const int xB = (r.w >> 13) & 0x7F, yB = (r.w >> 20) & 0x7F;
+  s_res[s] = (r.x & RTU_CBF) ? resid[res_base + ((r.w >> 1) & 0xFFF) + local] : (int16_t)0;
+  if ((x & 3) == 0) atomicOr(&s_mine[yB + y], 1u << ((xB + x) >> 2));
   if (log2 > 3) return;                               // 16x16 / 32x32 TUs take the LDS path (run_intra_tu)
-  const int xB = r.x & 0xFF, yB = (r.x >> 8) & 0xFF;
-  const int kind = (r.x >> 27) & 3;
-  const bool vert = (r.x >> 29) & 1;
+  const int kind = (r.x >> 24) & 3;
+  const bool vert = r.x & RTU_VERT;
   const int C = 2 * nT;
   int A = C - 1 - y, B = C + 1 + x;                   // planar / DC: A = left[y], B = top[x]
   if (kind >= 2) {                                    // angular (intrapred.cc:903-1069), reference array evaluated in place
-    const int angle = (int)(int8_t)(r.y & 0xFF), inv = (int)(int16_t)(r.y >> 16);
+    const int mode = (r.y >> 14) & 63;
+    const int angle = (int)(int8_t)(r.y >> 24);
+    const int inv = (mode >= 11 && mode <= 25 && angle < 0) ? (int)c_inv_angle[mode - 11] : 0;
     const int a = vert ? y : x, b = vert ? x : y;
     const int iIdx = ((a + 1) * angle) >> 5;
     const int i0 = b + iIdx + 1, i1 = i0 + 1;
@@ -872,46 +885,68 @@ __device__ __forceinline__ void run_prepare_sample(int s, const uint4* s_task, c
     B = (kind == 3) ? (vert ? C - 1 - y : C + 1 + x)  // operand of the mode 26 / 10 edge filter (iFact == 0: B unused)
                     : (vert ? C + k1 : C - k1);
   }
-  s_ctl[s] = (uint16_t)((A << 2) | (B << 10));
   const uint64_t avail = (uint64_t)r.z | ((uint64_t)(r.w & 1) << 32);
-  if (local < 4 * nT) s_gat[samp + k + local] = (uint16_t)run_gather_addr<RUN_TILE_P>(local, nT, xB, yB, avail, const_addr);
-  if (local == 0) s_gat[samp + k + 4 * nT] = (uint16_t)run_gather_addr<RUN_TILE_P>(4 * nT, nT, xB, yB, avail, const_addr);
+  if (r.x & RTU_SMOOTH) {
+    const uint32_t g = local <= 4 * nT ? (uint32_t)run_gather_addr<RUN_TILE_P>(local, nT, xB, yB, avail, const_addr) : 0u;
+    s_ctl[s] = (uint32_t)((A << 2) | (B << 10)) | (g << 16);
+  } else {
+    const uint32_t aA = (uint32_t)run_gather_addr<RUN_TILE_P>(A, nT, xB, yB, avail, const_addr);
+    const uint32_t aB = (uint32_t)run_gather_addr<RUN_TILE_P>(B, nT, xB, yB, avail, const_addr);
+    s_ctl[s] = aA | (aB << 16);
+    if (local == 0 && (kind == 0 || kind == 3)) {
+      const uint32_t e0 = (uint32_t)run_gather_addr<RUN_TILE_P>(kind == 0 ? C + 1 + nT : C, nT, xB, yB, avail, const_addr);
+      const uint32_t e1 = (uint32_t)run_gather_addr<RUN_TILE_P>(C - 1 - nT, nT, xB, yB, avail, const_addr);
+      s_ex[k] = e0 | (e1 << 16);
+    }
+  }
 }
 
 struct RunLane { int x, y, toff2; };                  // per-lane constants of one TU size: sample position, byte offset in the window
 
-// The chain step of a 4x4 / 8x8 TU.  w0: packed record word 0 (uniform), bv: this lane's neighbour sample,
-// ctl / rs: this lane's operands and residual, tb: LDS byte address of the TU origin in the window.
+// The chain step of a 4x4 / 8x8 TU.  w0: packed record word x (uniform), ctl / rs: this lane's operand word and
+// residual, tb: LDS byte address of the TU origin in the window.
 template <int LOG2>
 __device__ __forceinline__ void run_chain_small(uint32_t w0, int angle, int c, int maxv, int lane, const RunLane& L,
-                                                int bv, int ctl, int rs, char* tile_b, int tb)
+                                                uint32_t ctl, int rs, char* tile_b, int tb, const uint32_t* s_ex, int k)
 {
-  constexpr int nT = 1 << LOG2, NB = 4 * nT + 1, C = 2 * nT;
-  if (LOG2 == 3 && (w0 & RTU_SMOOTH)) {
+  constexpr int nT = 1 << LOG2, nS = nT * nT, NB = 4 * nT + 1, C = 2 * nT;
+  const int kind = (w0 >> 24) & 3;
+  const bool vert = w0 & RTU_VERT;
+  int A, B, bv = 0;
+  const bool smooth = LOG2 == 3 && (w0 & RTU_SMOOTH);
+  if (smooth) {
+    bv = *reinterpret_cast<uint16_t*>(tile_b + (ctl >> 16));
     // [1 2 1] smoothing (intrapred.cc:816-889); both ends keep their value
     const int prev = __builtin_amdgcn_update_dpp(bv, bv, 0x138, 0xf, 0xf, false);   // wave_shr:1 -> lane-1
     const int next = __builtin_amdgcn_update_dpp(bv, bv, 0x130, 0xf, 0xf, false);   // wave_shl:1 -> lane+1
     const int f = (prev + 2 * bv + next + 2) >> 2;
     bv = (lane == 0 || lane >= NB - 1) ? bv : f;
+    A = __builtin_amdgcn_ds_bpermute(ctl & 0xFF, bv);
+    B = __builtin_amdgcn_ds_bpermute((ctl >> 8) & 0xFF, bv);
+  } else {
+    A = *reinterpret_cast<uint16_t*>(tile_b + (ctl & 0xFFFF));
+    B = *reinterpret_cast<uint16_t*>(tile_b + (ctl >> 16));
   }
-  const int A = __builtin_amdgcn_ds_bpermute(ctl & 0xFF, bv);
-  const int B = __builtin_amdgcn_ds_bpermute(ctl >> 8, bv);
-  const int kind = (w0 >> 27) & 3;
-  const bool vert = (w0 >> 29) & 1;
   int pv;
-  if (kind == 2) {
+  if (__builtin_expect(kind == 2, 1)) {
     const int f = __mul24(vert ? L.y + 1 : L.x + 1, angle) & 31;
-    pv = __mul24(A, 32 - f) + __mul24(B, f) + 16;
-    pv >>= 5;
+    pv = (__mul24(A, 32 - f) + __mul24(B, f) + 16) >> 5;
   } else if (kind == 3) {
-    const int b0 = __builtin_amdgcn_readlane(bv, C);
+    const int b0 = smooth ? __builtin_amdgcn_readlane(bv, C)
+                          : (int)*reinterpret_cast<uint16_t*>(tile_b + (s_ex[k] & 0xFFFF));
     const int e = clip3(0, maxv, A + ((B - b0) >> 1));
     pv = ((vert ? L.x : L.y) == 0) ? e : A;
   } else if (kind == 0) {
-    const int tr = __builtin_amdgcn_readlane(bv, C + 1 + nT), bl = __builtin_amdgcn_readlane(bv, C - 1 - nT);
+    int tr, bl;
+    if (smooth) { tr = __builtin_amdgcn_readlane(bv, C + 1 + nT); bl = __builtin_amdgcn_readlane(bv, C - 1 - nT); }
+    else {
+      const uint32_t e = s_ex[k];
+      tr = *reinterpret_cast<uint16_t*>(tile_b + (e & 0xFFFF)); bl = *reinterpret_cast<uint16_t*>(tile_b + (e >> 16));
+    }
     pv = ((nT - 1 - L.x) * A + (L.x + 1) * tr + (nT - 1 - L.y) * B + (L.y + 1) * bl + nT) >> (LOG2 + 1);
   } else {
-    const int v = (lane >= nT && lane <= 3 * nT && lane != C) ? bv : 0;
+    // DC: the 2nT neighbours are the A operands of column 0 and the B operands of row 0 (never smoothed)
+    const int v = (lane < nS) ? ((L.x == 0 ? A : 0) + (L.y == 0 ? B : 0)) : 0;
     const int dc = (wave_sum_dpp(v) + nT) >> (LOG2 + 1);
     pv = dc;
     if (c == 0) pv = (L.x | L.y) == 0 ? (A + 2 * dc + B + 2) >> 2
@@ -1135,9 +1170,9 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   __shared__ RunShared S[RUN_WAVES];
   __shared__ __attribute__((aligned(16))) uint16_t tile[RUN_TILE_H * RUN_TILE_P + 8];
   __shared__ __attribute__((aligned(16))) int16_t s_res[BOX * BOX + 64];
-  __shared__ uint16_t s_ctl[BOX * BOX + 64];
-  __shared__ uint16_t s_gat[BOX * BOX + MAX_TUS + 64];
-  __shared__ uint4 s_task[MAX_TUS];           // the run's TUs, packed (run_tu_pack)
+  __shared__ uint32_t s_ctl[BOX * BOX + 64];      // per sample: operand addresses / border lanes (run_prepare_sample)
+  __shared__ uint32_t s_ex[MAX_TUS];              // per TU: window addresses of the TU-wide operands (planar, edge filter)
+  __shared__ uint4 s_task[MAX_TUS];               // the run's TUs, packed (run_tu_pack)
   __shared__ uint8_t s_own[BOX * BOX / 16];       // TU that owns each group of 16 samples of the run
   __shared__ uint32_t s_mine[RUN_TILE_H];         // per window row: bit g = the 4 samples at columns 4g.. are the run's
   __shared__ uint32_t s_ticket;
@@ -1147,8 +1182,6 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   char* tile_b = reinterpret_cast<char*>(tile);
   const RunLane L4{ lane & 3, (lane >> 2) & 3, (((lane >> 2) & 3) * RUN_TILE_P + (lane & 3)) * 2 };
   const RunLane L8{ lane & 7, (lane >> 3) & 7, (((lane >> 3) & 7) * RUN_TILE_P + (lane & 7)) * 2 };
-  const int bl4 = min(lane, 16) * 2, bl8 = min(lane, 32) * 2;          // border lane -> byte offset in s_gat
-  const int sl4 = (lane & 15) * 2, sl8 = lane * 2;                     // sample lane -> byte offset in s_ctl / s_res
   // persistent workgroup: the grid is only as wide as the picture's widest dependency level
   // (waiting workgroups would just occupy LDS), every one pulls tickets until none are left.
   // No deadlock for any dispatch order: a run only waits on smaller tickets, a ticket is only ever held by a
@@ -1219,9 +1252,9 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   // ---- preparation, independent of the producers: pack the TU records, then one thread per sample
   for (int i = tid; i < RUN_TILE_H; i += nthr) s_mine[i] = 0;
   for (int i = tid; i < n_tus; i += nthr) {
-    const uint4 r = run_tu_pack(tasks + run.first_tu, i, ax0, wy0, res_base, c);
+    const uint4 r = run_tu_pack<RUN_TILE_P>(tasks + run.first_tu, i, ax0, wy0, res_base, c);
     s_task[i] = r;
-    const int samp = r.w >> 16, cells = 1 << (2 * ((r.x >> 16) & 7) - 4);
+    const int samp = (r.y & 0x3FFF) >> 2, cells = 1 << (2 * ((r.w >> 27) & 7) - 4);
     for (int q = 0; q < cells; q++) s_own[(samp >> 4) + q] = (uint8_t)i;
   }
   // the TU records are here, so every earlier store of this wavefront has drained too (made explicit)
@@ -1277,7 +1310,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   }
   if (!(dbg & 64))
   for (int s = tid; s < n_samples; s += nthr)
-    run_prepare_sample<RUN_TILE_P>(s, s_task, s_own, s_res, s_ctl, s_gat, s_mine, resid, res_base, CONST_ADDR);
+    run_prepare_sample<RUN_TILE_P>(s, s_task, s_own, s_res, s_ctl, s_ex, s_mine, resid, res_base, CONST_ADDR);
   st.mark(2);
   int wbase = 0;
   if (early) { window_commit(); wbase = 4 * nthr; }
@@ -1305,55 +1338,51 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   __syncthreads();
   st.mark(4);
 
-  // ---- the dependency chain.  Each wavefront walks its own list of the run's TUs (level order); before a TU
-  // of level l it passes barriers until the workgroup has finished level l-1.  Records are read two TUs ahead
-  // and per-lane operands one TU ahead (LDS returns in order, so none of this is waited for on the chain).
+  // ---- the dependency chain.  Each wavefront walks its own list of the run's TUs (the host's list schedule keeps
+  // a z-scan chain on one wavefront and moves independent branches to the others).  A TU whose producers all come
+  // earlier in the own list starts at once (LDS executes a wavefront's operations in order); producers on another
+  // wavefront lie a barrier epoch earlier: before a TU of epoch e its wavefront has passed e workgroup barriers.
+  // Records are read two TUs ahead and per-lane operands one TU ahead (none of this is waited for on the chain).
   if (!(dbg & 4)) {
     const uint16_t* we = runs[ticket].wave_end;                          // (indexed in memory: no register array)
     const int j0 = wave == 0 ? 0 : (int)we[wave - 1], j1 = (int)we[wave];
-    const int n_lvls = run.n_lvls;
-    int level = 0;
+    const int n_epochs = run.n_lvls;
+    int epoch = 0;
     if (j0 < j1) {
-      uint4 rr = s_task[j0];
-      uint32_t w0 = __builtin_amdgcn_readfirstlane(rr.x), w1 = __builtin_amdgcn_readfirstlane(rr.y);
-      uint32_t w2 = __builtin_amdgcn_readfirstlane(rr.z), w3 = __builtin_amdgcn_readfirstlane(rr.w);
-      uint4 r_nxt = s_task[min(j0 + 1, j1 - 1)];
-      char* res_b = reinterpret_cast<char*>(s_res); char* ctl_b = reinterpret_cast<char*>(s_ctl);
-      char* gat_b = reinterpret_cast<char*>(s_gat);
-      int samp2 = (w3 >> 16) * 2;
-      const bool is4 = ((w0 >> 16) & 7) == 2;
-      int gaddr = *reinterpret_cast<uint16_t*>(gat_b + samp2 + 2 * j0 + (is4 ? bl4 : bl8));
-      int ctl = *reinterpret_cast<uint16_t*>(ctl_b + samp2 + (is4 ? sl4 : sl8));
-      int rs = *reinterpret_cast<int16_t*>(res_b + samp2 + (is4 ? sl4 : sl8));
+      const char* task_b = reinterpret_cast<const char*>(s_task);
+      const char* res_b = reinterpret_cast<const char*>(s_res); const char* ctl_b = reinterpret_cast<const char*>(s_ctl);
+      const uint2 r0 = *reinterpret_cast<const uint2*>(task_b + 16 * j0);
+      uint32_t w0 = __builtin_amdgcn_readfirstlane(r0.x), w1 = __builtin_amdgcn_readfirstlane(r0.y);
+      uint2 r_nxt = *reinterpret_cast<const uint2*>(task_b + 16 * min(j0 + 1, j1 - 1));
+      int sl = lane & ((w0 & RTU_IS4) ? 15 : 63);
+      uint32_t ctl = *reinterpret_cast<const uint32_t*>(ctl_b + (w1 & 0x3FFF) + 4 * sl);
+      int rs = *reinterpret_cast<const int16_t*>(res_b + ((w1 & 0x3FFF) >> 1) + 2 * sl);
       for (int j = j0; j < j1; j++) {
-        const int lev = (w1 >> 8) & 0xFF;
-        while (level < lev) { RUN_LDS_BARRIER(); level++; }
-        const int log2 = (w0 >> 16) & 7;
-        const int bv = *reinterpret_cast<uint16_t*>(tile_b + gaddr);            // the chain's first LDS round trip
-        // off the chain, in the shadow of that read: next TU's record -> its per-lane operands; record after next
+        const int ep = (w0 >> 16) & 0xFF;
+        while (epoch < ep) { RUN_LDS_BARRIER(); epoch++; }
+        // off the chain: next TU's record -> its per-lane operands; the record after next
         const uint32_t n0 = __builtin_amdgcn_readfirstlane(r_nxt.x), n1 = __builtin_amdgcn_readfirstlane(r_nxt.y);
-        const uint32_t n2 = __builtin_amdgcn_readfirstlane(r_nxt.z), n3 = __builtin_amdgcn_readfirstlane(r_nxt.w);
-        const int nsamp2 = (n3 >> 16) * 2;
-        const bool n4 = ((n0 >> 16) & 7) == 2;
-        const int jn = min(j + 1, j1 - 1);
-        const int ngaddr = *reinterpret_cast<uint16_t*>(gat_b + nsamp2 + 2 * jn + (n4 ? bl4 : bl8));
-        const int nctl = *reinterpret_cast<uint16_t*>(ctl_b + nsamp2 + (n4 ? sl4 : sl8));
-        const int nrs = *reinterpret_cast<int16_t*>(res_b + nsamp2 + (n4 ? sl4 : sl8));
-        r_nxt = s_task[min(j + 2, j1 - 1)];
+        const int nsl = lane & ((n0 & RTU_IS4) ? 15 : 63);
+        const uint32_t nctl = *reinterpret_cast<const uint32_t*>(ctl_b + (n1 & 0x3FFF) + 4 * nsl);
+        const int nrs = *reinterpret_cast<const int16_t*>(res_b + ((n1 & 0x3FFF) >> 1) + 2 * nsl);
+        r_nxt = *reinterpret_cast<const uint2*>(task_b + 16 * min(j + 2, j1 - 1));
 
-        const int xw = w0 & 0xFF, yw = (w0 >> 8) & 0xFF;
-        const int tb = (yw * RUN_TILE_P + xw) * 2;
-        const int angle = (int)(int8_t)(w1 & 0xFF);
-        if (log2 == 2) run_chain_small<2>(w0, angle, c, maxv, lane, L4, bv, ctl, rs, tile_b, tb);
-        else if (log2 == 3) run_chain_small<3>(w0, angle, c, maxv, lane, L8, bv, ctl, rs, tile_b, tb);
-        else {
-          const RunTu t = run_tu_unpack(w0, w1, w2, w3, c);
-          run_intra_tu<RUN_TILE_P>(P, t, tile, S[wave], lane, &s_res[samp2 >> 1], bd, st);
+        const int tb = w0 & 0x7FFF;
+        const int angle = (int)(int8_t)(w1 >> 24);
+        if (__builtin_expect(!(w0 & RTU_BIG), 1)) {
+          if (w0 & RTU_IS4) run_chain_small<2>(w0, angle, c, maxv, lane, L4, ctl, rs, tile_b, tb, s_ex, j);
+          else run_chain_small<3>(w0, angle, c, maxv, lane, L8, ctl, rs, tile_b, tb, s_ex, j);
+        } else {
+          uint4 rr = s_task[j];
+          rr.x = __builtin_amdgcn_readfirstlane(rr.x); rr.y = __builtin_amdgcn_readfirstlane(rr.y);
+          rr.z = __builtin_amdgcn_readfirstlane(rr.z); rr.w = __builtin_amdgcn_readfirstlane(rr.w);
+          const RunTu t = run_tu_unpack(rr, c);
+          run_intra_tu<RUN_TILE_P>(P, t, tile, S[wave], lane, &s_res[(w1 & 0x3FFF) >> 2], bd, st);
         }
-        w0 = n0; w1 = n1; w2 = n2; w3 = n3; samp2 = nsamp2; gaddr = ngaddr; ctl = nctl; rs = nrs;
+        w0 = n0; w1 = n1; ctl = nctl; rs = nrs;
       }
     }
-    while (level < n_lvls - 1) { RUN_LDS_BARRIER(); level++; }
+    while (epoch < n_epochs) { RUN_LDS_BARRIER(); epoch++; }
   }
   // ---- write the run's samples to the picture: whole 8-sample chunks where both halves are the run's (one
   // 16-byte write-through store), half chunks otherwise; nothing outside the run's own TUs is ever written.
