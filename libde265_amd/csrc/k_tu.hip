@@ -646,7 +646,8 @@ __device__ __forceinline__ uint4 run_tu_pack(const TuTask* __restrict__ tp, int 
   const uint32_t kind = mode == 0 ? 0u : (mode == 1 ? 1u : ((c == 0 && md == 0 && log2 < 5) ? 3u : 2u));
   uint4 o;
   o.x = ((yw * RUN_TILE_P + xw) * 2) | (log2 == 2 ? RTU_IS4 : 0u) | (level << 16) | (kind << 24) |
-        (mode >= 18 ? RTU_VERT : 0u) | ((c == 0 && log2 == 3 && mode != 1 && md > 7) ? RTU_SMOOTH : 0u) |
+        (mode >= 18 ? RTU_VERT : 0u) |
+        ((c == 0 && mode != 1 && (log2 == 3 ? md > 7 : (log2 == 4 ? md > 1 : (log2 == 5 && md > 0)))) ? RTU_SMOOTH : 0u) |
         (log2 > 3 ? RTU_BIG : 0u) | ((flags & DE265HIP_TU_CBF) ? RTU_CBF : 0u);
   o.y = (samp << 2) | (mode << 14) | ((b.w & 0xFF) << 24);
   o.z = b.x;
@@ -867,7 +868,6 @@ __device__ __forceinline__ void run_prepare_sample(int s, const uint4* s_task, c
   const int xB = (r.w >> 13) & 0x7F, yB = (r.w >> 20) & 0x7F;
   s_res[s] = (r.x & RTU_CBF) ? resid[res_base + ((r.w >> 1) & 0xFFF) + local] : (int16_t)0;
   if ((x & 3) == 0) atomicOr(&s_mine[yB + y], 1u << ((xB + x) >> 2));
-  if (log2 > 3) return;                               // 16x16 / 32x32 TUs take the LDS path (run_intra_tu)
   const int kind = (r.x >> 24) & 3;
   const bool vert = r.x & RTU_VERT;
   const int C = 2 * nT;
@@ -888,7 +888,8 @@ __device__ __forceinline__ void run_prepare_sample(int s, const uint4* s_task, c
   const uint64_t avail = (uint64_t)r.z | ((uint64_t)(r.w & 1) << 32);
   if (r.x & RTU_SMOOTH) {
     const uint32_t g = local <= 4 * nT ? (uint32_t)run_gather_addr<RUN_TILE_P>(local, nT, xB, yB, avail, const_addr) : 0u;
-    s_ctl[s] = (uint32_t)((A << 2) | (B << 10)) | (g << 16);
+    // 4x4 / 8x8: border lanes for ds_bpermute (byte offsets); 16x16 / 32x32: indices into the border array in LDS
+    s_ctl[s] = (log2 <= 3 ? (uint32_t)((A << 2) | (B << 10)) : (uint32_t)(A | (B << 8))) | (g << 16);
   } else {
     const uint32_t aA = (uint32_t)run_gather_addr<RUN_TILE_P>(A, nT, xB, yB, avail, const_addr);
     const uint32_t aB = (uint32_t)run_gather_addr<RUN_TILE_P>(B, nT, xB, yB, avail, const_addr);
@@ -957,6 +958,81 @@ __device__ __forceinline__ void run_chain_small(uint32_t w0, int angle, int c, i
   // written once, at the end of the run, in whole 16-byte chunks
   *reinterpret_cast<uint16_t*>(tile_b + tb + L.toff2) = (uint16_t)outv;
   WAVE_BARRIER_ONLY();
+}
+
+// The chain step of a 16x16 / 32x32 TU: nS / 64 samples per lane.  Same prepared operands as the small TUs; a
+// smoothed TU goes through a border array in LDS (gather -> [1 2 1] or the 32x32 bilinear filter, intrapred.cc:816-889
+// -> operands by index), the others read their operands straight from the window.
+template <int RUN_TILE_P>
+__device__ __forceinline__ void run_chain_big(const PicDev& P, uint32_t w0, int angle, int c, int maxv, int lane, int log2,
+                                              const uint32_t* ctl, const int16_t* res, char* tile_b, int tb,
+                                              const uint32_t* s_ex, int k, RunShared& S)
+{
+  const int nT = 1 << log2, nS = nT * nT, NB = 4 * nT + 1, C = 2 * nT;
+  const int kind = (w0 >> 24) & 3;
+  const bool vert = w0 & RTU_VERT;
+  const bool smooth = w0 & RTU_SMOOTH;
+  const uint16_t* bord = S.b1;
+  if (smooth) {
+    for (int p = lane; p < NB; p += 64) S.b0[p] = *reinterpret_cast<uint16_t*>(tile_b + (ctl[p] >> 16));
+    LDS_SYNC();
+    bool biInt = false;
+    if (P.strong_intra && nT == 32) {
+      const int th = 1 << (P.bd_luma - 5);
+      biInt = abs((int)S.b0[C] + S.b0[4 * nT] - 2 * S.b0[3 * nT]) < th && abs((int)S.b0[C] + S.b0[0] - 2 * S.b0[nT]) < th;
+    }
+    for (int p = lane; p < NB; p += 64) {
+      int v;
+      if (p == 0 || p == NB - 1) v = S.b0[p];
+      else if (biInt) v = (p == C) ? S.b0[C] : (p < C ? S.b0[C] + (((C - p) * (S.b0[0] - S.b0[C]) + 32) >> 6)
+                                                       : S.b0[C] + (((p - C) * (S.b0[4 * nT] - S.b0[C]) + 32) >> 6));
+      else v = (S.b0[p + 1] + 2 * S.b0[p] + S.b0[p - 1] + 2) >> 2;
+      S.b1[p] = (uint16_t)v;
+    }
+    LDS_SYNC();
+  }
+  int tr = 0, bl = 0, b0 = 0, dc = 0;
+  if (kind == 0) {
+    if (smooth) { tr = bord[C + 1 + nT]; bl = bord[C - 1 - nT]; }
+    else { const uint32_t e = s_ex[k]; tr = *reinterpret_cast<uint16_t*>(tile_b + (e & 0xFFFF)); bl = *reinterpret_cast<uint16_t*>(tile_b + (e >> 16)); }
+  } else if (kind == 3) {
+    b0 = *reinterpret_cast<uint16_t*>(tile_b + (s_ex[k] & 0xFFFF));
+  } else if (kind == 1) {                               // DC (never smoothed): column 0 holds left[y] in A, row 0 top[x] in B
+    int v = 0;
+    for (int s = lane; s < nS; s += 64) {
+      const int x = s & (nT - 1), y = s >> log2;
+      const uint32_t cw = ctl[s];
+      if (x == 0) v += *reinterpret_cast<uint16_t*>(tile_b + (cw & 0xFFFF));
+      if (y == 0) v += *reinterpret_cast<uint16_t*>(tile_b + (cw >> 16));
+    }
+    dc = (wave_sum_dpp(v) + nT) >> (log2 + 1);
+  }
+  const bool dc_edge = c == 0 && nT < 32;
+#pragma unroll 4
+  for (int s = lane; s < nS; s += 64) {
+    const int x = s & (nT - 1), y = s >> log2;
+    const uint32_t cw = ctl[s];
+    const int rs = res[s];
+    int A, B;
+    if (smooth) { A = bord[cw & 0xFF]; B = bord[(cw >> 8) & 0xFF]; }
+    else { A = *reinterpret_cast<uint16_t*>(tile_b + (cw & 0xFFFF)); B = *reinterpret_cast<uint16_t*>(tile_b + (cw >> 16)); }
+    int pv;
+    if (kind == 2) {
+      const int f = __mul24(vert ? y + 1 : x + 1, angle) & 31;
+      pv = (__mul24(A, 32 - f) + __mul24(B, f) + 16) >> 5;
+    } else if (kind == 3) {
+      const int e = clip3(0, maxv, A + ((B - b0) >> 1));
+      pv = ((vert ? x : y) == 0) ? e : A;
+    } else if (kind == 0) {
+      pv = ((nT - 1 - x) * A + (x + 1) * tr + (nT - 1 - y) * B + (y + 1) * bl + nT) >> (log2 + 1);
+    } else {
+      pv = dc;
+      if (dc_edge) pv = (x | y) == 0 ? (A + 2 * dc + B + 2) >> 2
+                                     : (y == 0 ? (B + 3 * dc + 2) >> 2 : (x == 0 ? (A + 3 * dc + 2) >> 2 : dc));
+    }
+    *reinterpret_cast<uint16_t*>(tile_b + tb + (y * RUN_TILE_P + x) * 2) = (uint16_t)clip3(0, maxv, pv + rs);
+  }
+  LDS_SYNC();
 }
 
 // ---- micro runs: <= 16 TUs of <= 8x8 inside a 32x32 box (most runs of a picture with inter PUs) ----
@@ -1373,11 +1449,9 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
           if (w0 & RTU_IS4) run_chain_small<2>(w0, angle, c, maxv, lane, L4, ctl, rs, tile_b, tb, s_ex, j);
           else run_chain_small<3>(w0, angle, c, maxv, lane, L8, ctl, rs, tile_b, tb, s_ex, j);
         } else {
-          uint4 rr = s_task[j];
-          rr.x = __builtin_amdgcn_readfirstlane(rr.x); rr.y = __builtin_amdgcn_readfirstlane(rr.y);
-          rr.z = __builtin_amdgcn_readfirstlane(rr.z); rr.w = __builtin_amdgcn_readfirstlane(rr.w);
-          const RunTu t = run_tu_unpack(rr, c);
-          run_intra_tu<RUN_TILE_P>(P, t, tile, S[wave], lane, &s_res[(w1 & 0x3FFF) >> 2], bd, st);
+          const int samp = (w1 & 0x3FFF) >> 2;
+          const int log2 = __builtin_amdgcn_readfirstlane((int)((s_task[j].w >> 27) & 7));
+          run_chain_big<RUN_TILE_P>(P, w0, angle, c, maxv, lane, log2, s_ctl + samp, s_res + samp, tile_b, tb, s_ex, j, S[wave]);
         }
         w0 = n0; w1 = n1; ctl = nctl; rs = nrs;
       }
