@@ -77,7 +77,7 @@ struct de265hip_picture {
   int n_l0_size[4] = { 0, 0, 0, 0 };          // TU count per size in d_l0 (sorted 32,16,8,4)
   TuTask* d_l0 = nullptr; int n_l0 = 0;       // run mode: inter residual TUs + residual-only copies of intra TUs
   int16_t* d_resid = nullptr;                 // precomputed residual blocks of intra TUs
-  int n_runs = 0, n_batches = 0, n_workers = 0, run_box = 64, late_publish = 0; size_t sync_bytes = 0;
+  int n_runs = 0, n_batches = 0, n_workers = 0, run_box = 64, ticket_batch = 1; size_t sync_bytes = 0;
   uint32_t* d_slots = nullptr;
   std::vector<int> level_start;       // level_start[l] .. level_start[l+1] in d_tus
   int n_mc = 0, n_pcm = 0, n_tus = 0;
@@ -377,9 +377,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   // sparse intra: small runs (<= 32x32) need a quarter of the LDS, so ~3x more of them are in flight.
   // (measured: with <= 32x32 runs and 2816 workers a 4K B picture got slower, 231 -> 273 us: the longer
   //  producer chains cost more than the extra residency buys, so every picture uses 64x64 runs for now)
-  // DE265HIP_RUN_BOX_B: run bounding box for pictures with inter PUs (experiment)
-  const char* rbenv = getenv("DE265HIP_RUN_BOX_B");
-  const int run_box = (d->n_pus > 0 && rbenv && atoi(rbenv) == 32) ? 32 : 64;
+  const int run_box = 64;      // (32x32 boxes: more runs in flight but 13-15 instead of 8 run levels on a 4K B picture: slower)
   pic->run_box = run_box;
   for (int i = 0; i < d->n_tus; i++) {
     const de265hip_tu& tu = d->tus[i];
@@ -571,13 +569,9 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     for (auto& R : rb) width[R.level]++;
     int widest = 0; for (int wv : width) widest = std::max(widest, wv);
     const char* wenv = getenv("DE265HIP_RUN_WORKERS");
-    int cap = wenv ? atoi(wenv) : (run_box == 64 ? 768 : 2048);      // LDS-limited residency: 3 resp. 8 workgroups per CU
+    int cap = wenv ? atoi(wenv) : 768;      // LDS-limited residency: 3 workgroups per CU
     pic->n_batches = (int)(slots.size() / 4);
     pic->n_workers = std::min(pic->n_batches, std::max(64, std::min(cap, widest + widest / 4)));
-    // pictures with inter PUs have thousands of small runs in few levels (bound by run throughput): raise flags late;
-    // all-intra pictures are bound by the producer->consumer chain: raise them first thing (DE265HIP_LATE_PUBLISH: 0/1)
-    const char* lenv = getenv("DE265HIP_LATE_PUBLISH");
-    pic->late_publish = lenv ? atoi(lenv) : 0;
     if (getenv("DE265HIP_PRINT_CRIT")) {               // diagnostic: longest path through the run DAG
       std::vector<double> fin(rb.size(), 0.0); double worst = 0, worst_l = 0; int worst_n = 0;
       std::vector<int> nl_of(rb.size(), 0), cnt(rb.size(), 0); std::vector<double> lv(rb.size(), 0.0);
@@ -602,11 +596,10 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
               (long long)dbg_foreign, (long long)dbg_w[0], (long long)dbg_w[1], (long long)dbg_w[2], (long long)dbg_w[3]);
       fprintf(stderr, "de265hip crit: est %.0f us, %d runs and %.0f in-run levels on the longest path\n", worst, worst_n, worst_l);
     }
-    // tickets per draw (bits 8.. of the kernel's mode word): 1 for chain-bound pictures, several where the draw
-    // rate of the single device-scope counter would be the limit (DE265HIP_TICKET_BATCH)
+    // tickets per draw: 1 (DE265HIP_TICKET_BATCH for experiments: several per draw relieve the single device-scope
+    // counter, ~12 ns per add, but serialise dependants: +46 % at 4 on a 4K B picture)
     const char* benv = getenv("DE265HIP_TICKET_BATCH");
-    const int tb = benv ? std::max(1, std::min(64, atoi(benv))) : 1;
-    pic->late_publish |= tb << 8;
+    pic->ticket_batch = benv ? std::max(1, std::min(64, atoi(benv))) : 1;
   }
   // level-0 launch of run mode: inter TUs with residual, then the residual-only intra TUs
   // largest first: [32x32 | 16x16 | 8x8 | 4x4] (counting sort); the two small sizes get their own packed kernel
@@ -865,12 +858,8 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
     if (pic->n_runs > 0) {
       KTimer t(dec, DE265HIP_K_INTRA, 1);
       (void)hipMemsetAsync(pic->d_sync, 0, pic->sync_bytes, st);
-      if (pic->run_box == 64)
-        hipLaunchKernelGGL((k_run<PX, 64>), dim3(pic->n_workers), dim3(64 * dec->run_waves), 0, st, P, d0, d1, d2, pic->d_runs, pic->d_deps,
-                           pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->d_slots, pic->n_batches, pic->late_publish, dec->dbg);
-      else
-        hipLaunchKernelGGL((k_run<PX, 32>), dim3(pic->n_workers), dim3(64 * dec->run_waves), 0, st, P, d0, d1, d2, pic->d_runs, pic->d_deps,
-                           pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->d_slots, pic->n_batches, pic->late_publish, dec->dbg);
+      hipLaunchKernelGGL((k_run<PX, 64>), dim3(pic->n_workers), dim3(64 * dec->run_waves), 0, st, P, d0, d1, d2, pic->d_runs, pic->d_deps,
+                         pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->d_slots, pic->n_batches, pic->ticket_batch, dec->dbg);
     }
   } else {
     if (nlev > 0 && pic->level_start[1] > pic->level_start[0]) {

@@ -1238,7 +1238,7 @@ template <typename PX, int BOX>
 __global__ __launch_bounds__(64 * RUN_WAVES)
 void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __restrict__ runs,
            const uint32_t* __restrict__ deps, uint32_t* sync, uint32_t* err, const TuTask* __restrict__ tasks,
-           const int16_t* __restrict__ resid, const uint32_t* __restrict__ slots, int n_batches, int late_publish, int dbg)
+           const int16_t* __restrict__ resid, const uint32_t* __restrict__ slots, int n_batches, int batch, int dbg)
 {
   constexpr int RUN_TILE_H = RUN_TILE_H_OF(BOX), RUN_TILE_P = RUN_TILE_P_OF(BOX);
   constexpr int MAX_TUS = BOX * BOX / 16;
@@ -1262,24 +1262,24 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   // (waiting workgroups would just occupy LDS), every one pulls tickets until none are left.
   // No deadlock for any dispatch order: a run only waits on smaller tickets, a ticket is only ever held by a
   // running workgroup, and a finished run's flag is published without waiting on any other run.
-  // Memory round trips on a run's path: ticket -> run record -> {TU records, producer ids, drain of the previous
-  // run's stores} -> producer flags -> {window, residuals} -> chain; what is inside braces is in flight together.
-  // late_publish (pictures bound by run throughput, i.e. with inter PUs): the flag of a finished run is raised one
-  // step late, after the next run's first round trip has drained the write-through stores, instead of a wait of
-  // its own.  Otherwise (all-intra pictures, bound by the producer->consumer chain) it is raised first thing.
+  // Memory round trips on a run's path: ticket -> run record -> {TU records, producer ids} -> producer flags ->
+  // {window, residuals} -> chain -> store drain; what is inside braces is in flight together.
+  // (Raising a finished run's flag one step late, after the next run's first round trip had drained the stores,
+  //  gained nothing and can deadlock: the workgroup may itself wait on the flag it still holds.)
   Stamper st{ ((dbg & 16) && wave == 0) ? err + 8 : nullptr, 0, lane, {} };
   uint32_t prev = RUN_NO_TICKET;                                       // finished run whose flag is not raised yet
-  const int batch = max(1, late_publish >> 8);
-  late_publish &= 1;
   uint32_t next_ticket = 0, batch_end = 0;
+  st.t0 = clock64();
   for (;;) {
-  if (!late_publish) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();                                                     // the previous run's LDS is free
-  if (!late_publish && prev != RUN_NO_TICKET) {
+  // publish the previous run: its payload was stored write-through (sc1); drained in every wavefront, then the flag.
+  // (MI355X_MICROARCH.md, valid forms: sc1 payload stores + vmcnt(0) + flag on the producer,
+  //  poll + agent acquire + plain loads on the consumer; no L2 write-back fence needed.)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                                     // also: the previous run's LDS is free
+  if (prev != RUN_NO_TICKET) {
     if (tid == 0) __hip_atomic_store(&sync[2 + prev], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     prev = RUN_NO_TICKET;
   }
-  if (prev == RUN_NO_TICKET) st.t0 = clock64();                        // (stamps: the first run of the workgroup)
   // Tickets are drawn `batch` at a time and worked off in increasing order (the no-deadlock argument holds: the
   // smallest unfinished ticket is held by a running workgroup that waits on nothing larger).  One device-scope
   // counter serves about one add per 12 ns: with thousands of small runs the draw rate itself is the limit,
@@ -1333,17 +1333,10 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
     const int samp = (r.y & 0x3FFF) >> 2, cells = 1 << (2 * ((r.w >> 27) & 7) - 4);
     for (int q = 0; q < cells; q++) s_own[(samp >> 4) + q] = (uint8_t)i;
   }
-  // the TU records are here, so every earlier store of this wavefront has drained too (made explicit)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   uint32_t flag0 = 1;                                                   // first look at the producers' flags
   if (has_dep) flag0 = __hip_atomic_load(&sync[2 + dep_id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (tid == 0) tile[RUN_TILE_H * RUN_TILE_P] = (uint16_t)(1 << (bd - 1));
   __syncthreads();
-  // publish the previous run: its payload was stored write-through (sc1) and has drained in every wavefront.
-  // (MI355X_MICROARCH.md, valid forms: sc1 payload stores + vmcnt(0) + flag on the producer,
-  //  poll + agent acquire + plain loads on the consumer; no L2 write-back fence needed.)
-  if (tid == 0 && prev != RUN_NO_TICKET)
-    __hip_atomic_store(&sync[2 + prev], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   prev = ticket;
   st.mark(1);
 
@@ -1515,8 +1508,6 @@ template __global__ void k_tu<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, co
                                         const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
 template __global__ void k_run<uint8_t, 64>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, const uint32_t*, int, int, int);
 template __global__ void k_run<uint16_t, 64>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, const uint32_t*, int, int, int);
-template __global__ void k_run<uint8_t, 32>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, const uint32_t*, int, int, int);
-template __global__ void k_run<uint16_t, 32>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, const uint32_t*, int, int, int);
 template __global__ void k_fn_residual<uint8_t>(int, int, int, uint8_t*, int, const int32_t*, const int16_t*);
 template __global__ void k_fn_residual<uint16_t>(int, int, int, uint16_t*, int, const int32_t*, const int16_t*);
 

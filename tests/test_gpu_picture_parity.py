@@ -284,3 +284,25 @@ def test_recorder_submit_matches_oracle(dec):
     rec.free()
     for c in range(3):
         assert np.array_equal(got[c], exp[c])
+
+
+@pytest.mark.parametrize("env", [{"DE265HIP_RUN_WAVES": "1"}, {"DE265HIP_RUN_WAVES": "2"}, {"DE265HIP_NO_MICRO": "1"},
+                                 {"DE265HIP_MICRO_TUS": "4"}, {"DE265HIP_TICKET_BATCH": "4"}])
+def test_run_kernel_schedule_variants(env):
+    """k_run's schedule knobs (wavefronts per workgroup, micro runs on/off, tickets per draw) only change who does what when: every variant is bit-exact against the oracle."""
+    import os
+    from libde265_amd import backend
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    d2 = backend.Decoder()
+    try:
+        run_case(d2, 416, 240, 10, 2, seed=91, stages=(2,), tskip_pct=20, pcm_pct=8, n_slices=2)
+        run_case(d2, 352, 288, 8, 0, seed=92, stages=(2,), tskip_pct=10, scaling_list=1, constrained_intra_pred=1)
+        run_case(d2, 512, 320, 10, 0, seed=93, stages=(2,), intra_pct=60, split_bias=80)
+    finally:
+        d2.close()
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
