@@ -79,6 +79,7 @@ struct de265hip_picture {
   int16_t* d_resid = nullptr;                 // precomputed residual blocks of intra TUs
   int n_runs = 0, n_batches = 0, n_workers = 0, run_box = 64, ticket_batch = 1; size_t sync_bytes = 0;
   uint32_t* d_slots = nullptr;
+  uint32_t gen = 0;                           // runs of this picture so far (k_run flag generation)
   std::vector<int> level_start;       // level_start[l] .. level_start[l+1] in d_tus
   int n_mc = 0, n_pcm = 0, n_tus = 0;
   bool any_edges = false;
@@ -780,6 +781,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   pic->d_bs = base + o_bs;
   pic->d_runs = (RunTask*)(base + o_runs); pic->d_deps = (uint32_t*)(base + o_rdeps);
   pic->d_run_tus = (TuTask*)(base + o_rtus); pic->d_slots = (uint32_t*)(base + o_slots); pic->d_sync = (uint32_t*)(base + o_sync);
+  if (hipMemset(pic->d_sync, 0, pic->sync_bytes) != hipSuccess) { (void)hipFree(pic->arena); delete pic; return DE265HIP_ERROR_DECODING; }
   pic->d_l0 = (TuTask*)(base + o_l0); pic->d_resid = (int16_t*)(base + o_resid);
 
   const int64_t Pbytes = (int64_t)p.width * p.height * 3 / 2 * px_bytes(p.bit_depth_luma);
@@ -857,9 +859,15 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
     }
     if (pic->n_runs > 0) {
       KTimer t(dec, DE265HIP_K_INTRA, 1);
-      (void)hipMemsetAsync(pic->d_sync, 0, pic->sync_bytes, st);
+      // ticket counter and run flags are not cleared between runs of a picture: every workgroup draws exactly one
+      // ticket beyond the last batch, so run g starts at ticket g * (n_batches + n_workers), and a flag is "raised"
+      // when it holds the run's generation number (cleared once, at build).  Several tickets per draw (experiment)
+      // make the count depend on the schedule: clear instead.
+      uint32_t base = 0, gen = 1;
+      if (pic->ticket_batch == 1) { gen = ++pic->gen; base = (gen - 1u) * (uint32_t)(pic->n_batches + pic->n_workers); }
+      else { (void)hipMemsetAsync(pic->d_sync, 0, pic->sync_bytes, st); pic->gen = 0; }
       hipLaunchKernelGGL((k_run<PX, 64>), dim3(pic->n_workers), dim3(64 * dec->run_waves), 0, st, P, d0, d1, d2, pic->d_runs, pic->d_deps,
-                         pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->d_slots, pic->n_batches, pic->ticket_batch, dec->dbg);
+                         pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->d_slots, pic->n_batches, pic->ticket_batch, base, gen, dec->dbg);
     }
   } else {
     if (nlev > 0 && pic->level_start[1] > pic->level_start[0]) {

@@ -1131,7 +1131,7 @@ __device__ __forceinline__ void micro_run(const PicDev& P, const PlaneRef& pl0, 
                                           const RunTask* __restrict__ runs, const uint32_t* __restrict__ deps,
                                           uint32_t* sync, uint32_t* err, const TuTask* __restrict__ tasks,
                                           const int16_t* __restrict__ resid, uint16_t* mt, int16_t* mres,
-                                          uint32_t r, int lane, int dbg)
+                                          uint32_t r, int lane, uint32_t gen, int dbg)
 {
   const RunTask run = runs[r];
   const int n_tus = min((int)run.n_tus, MICRO_TUS);
@@ -1154,7 +1154,7 @@ __device__ __forceinline__ void micro_run(const PicDev& P, const PlaneRef& pl0, 
   const int wx1 = min(min((int)run.wx1, cw), wx0 + 1 + MICRO_BOX + 8), wy1 = min(min((int)run.wy1, ch), wy0 + MICRO_H);
   const int ax0 = wx0 & ~7;
   // second round trip: residuals (into this wavefront's LDS slice) and the first look at the producers' flags
-  uint32_t flag0 = 1;
+  uint32_t flag0 = gen;
   if (has_dep) flag0 = __hip_atomic_load(&sync[2 + dep_id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   for (int k0 = 0; k0 < n_tus; k0 += 4) {                              // four loads in flight
     int16_t rv[4]; int ro[4];
@@ -1174,8 +1174,8 @@ __device__ __forceinline__ void micro_run(const PicDev& P, const PlaneRef& pl0, 
   for (int i = lane; i < (int)run.n_deps; i += 64) {
     const uint32_t* flag = &sync[2 + (i == lane ? dep_id : deps[run.dep_offset + i])];
     int spins = 0;
-    uint32_t f = (i == lane) ? flag0 : 0u;
-    while (f == 0 && !(dbg & 32)) {
+    uint32_t f = (i == lane) ? flag0 : gen - 1u;
+    while (f != gen && !(dbg & 32)) {
       if (spins) { if (spins < 4) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(64); }
       if (++spins > RUN_SPIN_LIMIT) { atomicExch(err, 1u); break; }
       f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1219,7 +1219,7 @@ __device__ __forceinline__ void micro_run(const PicDev& P, const PlaneRef& pl0, 
   }
   // publish: write-through stores drained, then the flag
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (lane == 0) __hip_atomic_store(&sync[2 + r], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == 0) __hip_atomic_store(&sync[2 + r], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 #define RUN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -1238,7 +1238,8 @@ template <typename PX, int BOX>
 __global__ __launch_bounds__(64 * RUN_WAVES)
 void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __restrict__ runs,
            const uint32_t* __restrict__ deps, uint32_t* sync, uint32_t* err, const TuTask* __restrict__ tasks,
-           const int16_t* __restrict__ resid, const uint32_t* __restrict__ slots, int n_batches, int batch, int dbg)
+           const int16_t* __restrict__ resid, const uint32_t* __restrict__ slots, int n_batches, int batch, uint32_t ticket_base,
+           uint32_t gen, int dbg)
 {
   constexpr int RUN_TILE_H = RUN_TILE_H_OF(BOX), RUN_TILE_P = RUN_TILE_P_OF(BOX);
   constexpr int MAX_TUS = BOX * BOX / 16;
@@ -1277,7 +1278,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                                     // also: the previous run's LDS is free
   if (prev != RUN_NO_TICKET) {
-    if (tid == 0) __hip_atomic_store(&sync[2 + prev], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(&sync[2 + prev], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     prev = RUN_NO_TICKET;
   }
   // Tickets are drawn `batch` at a time and worked off in increasing order (the no-deadlock argument holds: the
@@ -1285,7 +1286,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   // counter serves about one add per 12 ns: with thousands of small runs the draw rate itself is the limit,
   // so throughput-bound pictures draw several at once.
   if (next_ticket == batch_end) {
-    if (wave == 0) { const uint32_t t = run_draw_ticket(sync, (uint32_t)batch); if (lane == 0) s_ticket = t; }
+    if (wave == 0) { const uint32_t t = run_draw_ticket(sync, (uint32_t)batch) - ticket_base; if (lane == 0) s_ticket = t; }
     __syncthreads();
     next_ticket = __builtin_amdgcn_readfirstlane(s_ticket);
     batch_end = next_ticket + batch;
@@ -1300,7 +1301,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
       const uint32_t mine = q == 0 ? sl.x : (q == 1 ? sl.y : (q == 2 ? sl.z : sl.w));
       if (mine != 0xFFFFFFFFu)
         micro_run<PX>(P, pl0, pl1, pl2, runs, deps, sync, err, tasks, resid, tile + q * MICRO_SLICE,
-                      s_res + q * MICRO_RES, mine & 0x7FFFFFFFu, lane, dbg);
+                      s_res + q * MICRO_RES, mine & 0x7FFFFFFFu, lane, gen, dbg);
     }
     continue;
   }
@@ -1333,7 +1334,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
     const int samp = (r.y & 0x3FFF) >> 2, cells = 1 << (2 * ((r.w >> 27) & 7) - 4);
     for (int q = 0; q < cells; q++) s_own[(samp >> 4) + q] = (uint8_t)i;
   }
-  uint32_t flag0 = 1;                                                   // first look at the producers' flags
+  uint32_t flag0 = gen;                                                 // first look at the producers' flags
   if (has_dep) flag0 = __hip_atomic_load(&sync[2 + dep_id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (tid == 0) tile[RUN_TILE_H * RUN_TILE_P] = (uint16_t)(1 << (bd - 1));
   __syncthreads();
@@ -1367,7 +1368,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   };
   // producers already finished (the usual case when the picture is throughput-bound): fetch the window now,
   // under the preparation of the samples, instead of after it
-  const bool early = !(dbg & 8) && (run.n_deps == 0 || __syncthreads_and(flag0 != 0));
+  const bool early = !(dbg & 8) && (run.n_deps == 0 || __syncthreads_and(flag0 == gen));
   if (early) {
     if (run.n_deps && !(dbg & 2)) {
       // one acquire per workgroup (the L1 belongs to the CU): wavefront 0 invalidates and waits for it,
@@ -1387,8 +1388,8 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
     for (int i = tid; i < run.n_deps; i += nthr) {
       const uint32_t* flag = &sync[2 + (i == tid ? dep_id : deps[run.dep_offset + i])];
       int spins = 0;
-      uint32_t f = (i == tid) ? flag0 : 0u;
-      while (f == 0 && !(dbg & 32)) {                                  // (dbg 32: timing-only ablation, ignores producers)
+      uint32_t f = (i == tid) ? flag0 : gen - 1u;
+      while (f != gen && !(dbg & 32)) {                                  // (dbg 32: timing-only ablation, ignores producers)
         // back off quickly: hundreds of waiting wavefronts polling at full rate starve the fabric
         if (spins) { if (spins < 4) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(64); }
         if (++spins > RUN_SPIN_LIMIT) { atomicExch(err, 1u); break; }           // never hang the grid
@@ -1479,7 +1480,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0 && prev != RUN_NO_TICKET)
-    __hip_atomic_store(&sync[2 + prev], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&sync[2 + prev], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   st.flush();
 }
 
@@ -1506,8 +1507,8 @@ template __global__ void k_tu<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, con
                                        const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
 template __global__ void k_tu<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int,
                                         const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
-template __global__ void k_run<uint8_t, 64>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, const uint32_t*, int, int, int);
-template __global__ void k_run<uint16_t, 64>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, const uint32_t*, int, int, int);
+template __global__ void k_run<uint8_t, 64>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, const uint32_t*, int, int, uint32_t, uint32_t, int);
+template __global__ void k_run<uint16_t, 64>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, const uint32_t*, int, int, uint32_t, uint32_t, int);
 template __global__ void k_fn_residual<uint8_t>(int, int, int, uint8_t*, int, const int32_t*, const int16_t*);
 template __global__ void k_fn_residual<uint16_t>(int, int, int, uint16_t*, int, const int32_t*, const int16_t*);
 
