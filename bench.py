@@ -29,7 +29,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
 PMC_FILE = os.path.join(ROOT, "profiles", "r01_e_pmc_traffic.json")
 PMC_KERNEL = {"intra": ["k_run<unsigned short, 64>"], "mc": ["k_mc<unsigned short>"], "sao": ["k_sao<unsigned short>"],
               "deblock_v": ["k_deblock<unsigned short, true>"], "deblock_h": ["k_deblock<unsigned short, false>"],
-              "resid": ["k_resid_big<unsigned short>", "k_resid_small<unsigned short, 3>", "k_resid_small<unsigned short, 2>"]}
+              "resid": ["k_resid_big<unsigned short>", "k_resid_small<unsigned short>"]}
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 CONFIG_ID = 4                  # SURVEY 8d config 4 -> seed 0xDE265000 + 4
 

@@ -846,16 +846,13 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
     // residual buffer), then one launch for the whole intra dependency graph
     if (pic->n_l0 > 0) {
       const int nbig = pic->n_l0_size[3] + pic->n_l0_size[2], n8 = pic->n_l0_size[1], n4 = pic->n_l0_size[0];
-      KTimer t(dec, DE265HIP_K_RESID, (nbig > 0) + (n8 > 0) + (n4 > 0));
+      KTimer t(dec, DE265HIP_K_RESID, (nbig > 0) + (n8 + n4 > 0));
       if (nbig > 0)
         hipLaunchKernelGGL(k_resid_big<PX>, dim3(nbig), dim3(256), 0, st, P, d0, d1, d2, pic->d_l0, pic->d_cval,
                            pic->d_cpos, pic->d_scaling, pic->d_resid);
-      if (n8 > 0)
-        hipLaunchKernelGGL((k_resid_small<PX, 3>), dim3(n8), dim3(64), 0, st, P, d0, d1, d2, pic->d_l0, nbig, n8,
+      if (n8 + n4 > 0)
+        hipLaunchKernelGGL(k_resid_small<PX>, dim3(n8 + ((n4 + 3) >> 2)), dim3(64), 0, st, P, d0, d1, d2, pic->d_l0, nbig, n8, n4,
                            pic->d_cval, pic->d_cpos, pic->d_scaling, pic->d_resid);
-      if (n4 > 0)
-        hipLaunchKernelGGL((k_resid_small<PX, 2>), dim3((n4 + 3) / 4), dim3(64), 0, st, P, d0, d1, d2, pic->d_l0,
-                           nbig + n8, n4, pic->d_cval, pic->d_cpos, pic->d_scaling, pic->d_resid);
     }
     if (pic->n_runs > 0) {
       KTimer t(dec, DE265HIP_K_INTRA, 1);

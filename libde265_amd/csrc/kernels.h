@@ -25,8 +25,8 @@ __global__ void k_tu(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int,
 template <typename PX>
 __global__ void k_resid_big(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, const int16_t*, const uint16_t*,
                             const uint8_t*, int16_t*);
-template <typename PX, int LOG2>
-__global__ void k_resid_small(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int, int, const int16_t*,
+template <typename PX>
+__global__ void k_resid_small(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int, int, int, const int16_t*,
                               const uint16_t*, const uint8_t*, int16_t*);
 #define RUN_WAVES 4          // wavefronts per run workgroup (one per SIMD of a CU); blockDim.x = 64..64*RUN_WAVES
 template <typename PX, int BOX>
