@@ -70,7 +70,7 @@ static_assert(sizeof(McTask) == 20, "McTask layout");
 struct RunTask {
   uint16_t x0, y0, x1, y1;   // bounding box of the run's TUs, component samples, x1/y1 exclusive
   uint16_t wx1, wy1;         // end of the pixel window: furthest neighbour any TU of the run may read
-  uint8_t  c_idx, micro;     // micro: <= 16 TUs of <= 8x8 in a <= 32x32 box: reconstructed by ONE wavefront (k_run)
+  uint8_t  c_idx, micro;     // bit 1: dense (the run's TUs cover its whole bounding box); bit 0 micro: <= 16 TUs of <= 8x8 in a <= 32x32 box: reconstructed by ONE wavefront (k_run)
   uint16_t n_tus;
   uint32_t first_tu;         // into the run-ordered TuTask array
   uint32_t dep_offset;       // into the producer-run id array

@@ -503,7 +503,22 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       RunTask& o = runs[k]; memset(&o, 0, sizeof(o));
       o.x0 = (uint16_t)R.x0; o.y0 = (uint16_t)R.y0; o.x1 = (uint16_t)R.x1; o.y1 = (uint16_t)R.y1;
       o.wx1 = (uint16_t)std::min(R.wx1, R.x1 + 32); o.wy1 = (uint16_t)std::min(R.wy1, R.y1 + 32);
-      o.c_idx = (uint8_t)R.c; o.micro = micro[order[k]]; o.n_tus = (uint16_t)R.tus.size();
+      int own_samples = 0; for (const TuTask& tt : R.tus) own_samples += 1 << (2 * tt.log2_size);
+      // dense: the run's TUs cover its whole bounding box AND every available neighbour outside the box lies on the row
+      // above it or the column left of it (two stacked CUs with an inter CU beside the upper one do not qualify: the
+      // lower CU reads above-right samples from inside the box's row range)
+      bool dense = own_samples == (R.x1 - R.x0) * (R.y1 - R.y0) && !getenv("DE265HIP_NO_DENSE");
+      for (size_t i = 0; dense && i < R.tus.size(); i++) {
+        const TuTask& tt = R.tus[i];
+        const int nT = 1 << tt.log2_size, xB = tt.x0, yB = tt.y0, corner = nT >> 1;
+        auto ok = [&](int x, int y) { return (x >= R.x0 && x < R.x1 && y >= R.y0 && y < R.y1) || y == R.y0 - 1 || x == R.x0 - 1; };
+        for (int u = 0; u < corner && dense; u++)                               // left column, bottom -> top
+          if ((tt.avail >> u) & 1) dense = ok(xB - 1, yB + 2 * nT - 4 * u - 4) && ok(xB - 1, yB + 2 * nT - 4 * u - 1);
+        if (dense && ((tt.avail >> corner) & 1)) dense = ok(xB - 1, yB - 1);
+        for (int k = 0; k < corner && dense; k++)                               // top row, left -> right
+          if ((tt.avail >> (corner + 1 + k)) & 1) dense = ok(xB + 4 * k, yB - 1) && ok(xB + 4 * k + 3, yB - 1);
+      }
+      o.c_idx = (uint8_t)R.c; o.micro = (uint8_t)(micro[order[k]] | (dense ? 2 : 0)); o.n_tus = (uint16_t)R.tus.size();
       o.first_tu = (uint32_t)run_tus.size(); o.dep_offset = (uint32_t)run_deps.size(); o.n_deps = (uint16_t)R.deps.size();
       o.res_offset = (uint32_t)n_resid;
       // TUs of the run: the TUs of one in-run level are independent of each other and are dealt round-robin to

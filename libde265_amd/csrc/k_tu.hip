@@ -1371,7 +1371,10 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
 
   // the window, fetched in aligned 8-sample chunks, up to four loads in flight per lane
   const int nchx = (wx1 - ax0 + 7) >> 3, nrows = wy1 - wy0;
-  const int nchunks = nchx * nrows;
+  // a dense run (its TUs cover its whole bounding box, e.g. an all-intra CTB) writes every sample of the box before it
+  // reads it: only row 0 and the first chunk of the other rows (left column, below-left reach) are fetched
+  const bool dense = run.micro & 2;
+  const int nchunks = dense ? nchx + nrows - 1 : nchx * nrows;
   uint4 wv[4]; int woff[4];
   auto window_issue = [&](int base) {
 #pragma unroll
@@ -1379,7 +1382,9 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
       const int idx = base + u * nthr + tid;
       woff[u] = -1;
       if (idx < nchunks) {
-        const int r = idx / nchx, cx = idx - r * nchx;
+        int r, cx;
+        if (dense) { r = idx < nchx ? 0 : idx - nchx + 1; cx = idx < nchx ? idx : 0; }
+        else { r = idx / nchx; cx = idx - r * nchx; }
         const int gx = ax0 + 8 * cx, gy = wy0 + r;
         // the bottom-right 32x32 corner of the window is never read
         if (gx >= 0 && gy >= 0 && !(gx >= (int)run.x1 && gy >= (int)run.y1)) {
