@@ -12,7 +12,7 @@ import numpy as np
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libde265_hip.so")
+SO_PATH = os.environ.get("DE265HIP_SO") or os.path.join(_HERE, "libde265_hip.so")   # (override: A/B of builds)
 
 # every symbol include/de265_hip.h declares (tests/test_abi.py checks the .so exports them all)
 EXPORTS = [

@@ -533,12 +533,15 @@ __device__ __forceinline__ void resid_small_body(const PicDev& P, const PlaneRef
   *d = (PX)clip3(0, (1 << bd) - 1, (int)*d + r);
 }
 
+#ifndef RESID_BIG_WAVES
+#define RESID_BIG_WAVES 8         // wavefronts per SIMD the register allocation of k_resid_big aims at (4: 112 VGPRs, 58 us per 4K B picture; 8: 64 VGPRs + 148 B scratch, 48 us)
+#endif
 // The residuals of a picture in two launches.  k_resid_big: one 4-wavefront workgroup per 16x16/32x32 TU.
 // k_resid_small: one wavefront per workgroup, workgroups [0, n8) an 8x8 TU each, the rest four 4x4 TUs each (one launch
 // for both small sizes; a single launch for all three made every workgroup pay the big path's 112 VGPRs and 5 KB of LDS:
 // 7.0 instead of 5.3 ms per 48 pictures with three GOP streams in flight).  tasks[] is sorted [32x32 | 16x16 | 8x8 | 4x4].
 template <typename PX>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, RESID_BIG_WAVES)
 void k_resid_big(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const TuTask* __restrict__ tasks,
                  const int16_t* __restrict__ coeff_val, const uint16_t* __restrict__ coeff_pos,
                  const uint8_t* __restrict__ scaling, int16_t* __restrict__ resid)
