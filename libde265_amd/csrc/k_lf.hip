@@ -10,6 +10,16 @@
 //   sao.cc:29-254       apply_sao_internal
 #include "kernels.h"
 
+// wavefronts per SIMD the register allocation aims at (A/B with -DDEBLOCK_WAVES=.. / -DSAO_WAVES=..; measured on a
+// 4K Main10 B picture: deblock V 13.5 us at 4 (79 VGPRs) vs 16.7 at 8; SAO 42.7 at 4 (83 VGPRs), 48.4 at 6, 56.7 at 8:
+// the spills cost more than the extra wavefronts hide, unlike k_resid_big)
+#ifndef DEBLOCK_WAVES
+#define DEBLOCK_WAVES 4
+#endif
+#ifndef SAO_WAVES
+#define SAO_WAVES 4
+#endif
+
 namespace d265 {
 
 __device__ __constant__ uint8_t c_beta[52] = {
@@ -157,7 +167,7 @@ __device__ __forceinline__ bool luma_filter_segment(int p[4][4], int q[4][4], in
 // ---------------------------------------------------------------- deblock
 // blockIdx.z: 0 luma, 1 Cb, 2 Cr.  VERT: vertical edges (filtering across x).
 template <typename PX, bool VERT>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, DEBLOCK_WAVES)
 void k_deblock(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, LfMeta M)
 {
   const int comp = blockIdx.z;
@@ -308,7 +318,7 @@ template <> __device__ __forceinline__ void store8i<uint8_t>(uint8_t* p, const i
 // the CTB parameters and the slice/tile permissions of the 3x3 CTB neighbourhood are evaluated
 // once per strip, and every output row is one 16-byte store.
 template <typename PX>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, SAO_WAVES)
 void k_sao(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, PlaneRef d1, PlaneRef d2,
            SaoMeta M)
 {
