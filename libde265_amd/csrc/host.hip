@@ -857,8 +857,10 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
   }
   const int nlev = (int)pic->level_start.size() - 1;
   if (!dec->intra_levels) {
-    // run mode: one launch for every residual (inter TUs add into the picture, intra TUs fill the
-    // residual buffer), then one launch for the whole intra dependency graph
+    // run mode: the residuals (inter TUs add into the picture, intra TUs fill the residual buffer), then one launch for
+    // the whole intra dependency graph.  (Tried: the intra TUs' residuals and the bS derivation, which depend on nothing
+    // before them, on a second HIP stream per decoder: +1 % with one GOP stream, -8 % with three (six streams on four
+    // hardware queues; -20 % with GPU_MAX_HW_QUEUES=8), so everything stays on the decoder's one stream.)
     if (pic->n_l0 > 0) {
       const int nbig = pic->n_l0_size[3] + pic->n_l0_size[2], n8 = pic->n_l0_size[1], n4 = pic->n_l0_size[0];
       KTimer t(dec, DE265HIP_K_RESID, (nbig > 0) + (n8 + n4 > 0));
