@@ -115,6 +115,10 @@ __device__ __forceinline__ PX mc_combine(int mode, int a, int b, int bd, int w0,
   return (PX)mc_clip3(0, maxv, v);
 }
 
+// (Tried: a second kernel for tiles of at most 8x8 -- 42 % of the tasks, 12 % of the samples of the synthetic B
+//  pictures -- with four tasks per wavefront, one per 16-lane group, every task quantity per lane and both filter passes
+//  always run (fraction-0 taps {0,0,0,64,..} are bit-exact).  Bit-exact, but 71-79 us instead of 62 us per 4K B picture:
+//  without the scalar registers and wave-uniform shortcuts a packed wavefront costs about twice a plain one.)
 // ---------------------------------------------------------------- picture-level MC kernel
 // One wavefront per MC task.  All reference fetches of the task (2 lists x 3 planes) are
 // issued back to back as aligned 4-sample vector loads into LDS (one exposed HBM/L2 latency
