@@ -685,18 +685,6 @@ __device__ __forceinline__ uint4 run_tu_pack(const TuTask* __restrict__ tp, int 
   o.w = (b.y & 1u) | (((b.z - res_base) & 0xFFFu) << 1) | (xw << 13) | (yw << 20) | (log2 << 27);
   return o;
 }
-__device__ __forceinline__ RunTu run_tu_unpack(const uint4& r, int c_idx)
-{
-  RunTu t;
-  t.x0 = (r.w >> 13) & 0x7F; t.y0 = (r.w >> 20) & 0x7F;
-  t.log2_size = (r.w >> 27) & 7; t.c_idx = c_idx; t.flags = (r.x & RTU_CBF) ? 1 : 0; t.intra_mode = (r.y >> 14) & 63;
-  t.angle = (int)(int8_t)(r.y >> 24);
-  t.inv_angle = (t.intra_mode >= 11 && t.intra_mode <= 25 && t.angle < 0) ? (int)c_inv_angle[t.intra_mode - 11] : 0;
-  t.avail = (uint64_t)r.z | ((uint64_t)(r.w & 1) << 32);
-  t.resid_offset = (r.w >> 1) & 0xFFF;
-  return t;
-}
-
 // Intra-only scratch of the run kernel (the residuals were computed beforehand).
 struct RunShared {
   uint16_t b0[4 * 32 + 4];     // neighbours as fetched (+ substitution), centre at [64]
@@ -713,129 +701,6 @@ __device__ __forceinline__ int wave_sum_dpp(int v)
   v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);   // row_bcast:15 into rows 1,3
   v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);   // row_bcast:31 into rows 2,3 -> lane 63 = total
   return __builtin_amdgcn_readlane(v, 63);
-}
-
-// One intra TU of a run, entirely inside LDS: gather the neighbours from the pixel window
-// (availability mask + substitution, intrapred.cc:395-431,:577-688), smooth them when the
-// mode asks for it (:816-889), predict (:903-1069), add the precomputed residual and write the
-// reconstructed samples into the window.  t is wave-uniform and in window coordinates.
-// Three dependent LDS round trips per TU (gather, [smooth], predict) instead of ten.
-template <int RUN_TILE_P>
-__device__ __forceinline__ void run_intra_tu(const PicDev& P, const RunTu& t, uint16_t* tile, RunShared& S,
-                                             int lane, const int16_t* res, int bd, Stamper& st)
-{
-  const int log2 = t.log2_size, nT = 1 << log2, nS = nT * nT;
-  const int cIdx = t.c_idx;
-  const int xB = t.x0, yB = t.y0;
-  const uint64_t avail = t.avail;
-  const int cornerUnit = nT >> 1;
-  uint16_t* A = &S.b0[64];
-  uint16_t* Bf = &S.b1[64];
-
-  if (!(P.dbg & 256))                                // ablation: no neighbour gather
-  for (int p = lane; p <= 4 * nT; p += 64) {
-    const int i = p - 2 * nT;
-    const int u = (i < 0) ? (p >> 2) : (i == 0 ? cornerUnit : cornerUnit + 1 + ((i - 1) >> 2));
-    int val = 1 << (bd - 1);
-    if (avail != 0) {
-      int src = i;
-      if (!((avail >> u) & 1)) {
-        const uint64_t below = avail & ((2ull << u) - 1ull);
-        if (below) {
-          const int su = 63 - __clzll((long long)below);
-          src = (su < cornerUnit) ? (-2 * nT + 4 * su + 3) : (su == cornerUnit ? 0 : 4 * (su - cornerUnit));
-        } else {
-          const int su = __ffsll((long long)avail) - 1;
-          src = (su < cornerUnit) ? (-2 * nT + 4 * su) : (su == cornerUnit ? 0 : 4 * (su - cornerUnit - 1) + 1);
-        }
-      }
-      const int sx = src <= 0 ? xB - 1 : xB + src - 1;
-      const int sy = src < 0 ? yB - src - 1 : yB - 1;
-      val = tile[sx + sy * RUN_TILE_P];
-    }
-    A[i] = val;
-  }
-  LDS_SYNC();
-
-  const int mode = t.intra_mode >= 35 ? 1 : t.intra_mode;
-  const uint16_t* bord = A;
-  if (cIdx == 0 && mode != 1 && nT != 4) {
-    const int minDist = min(abs(mode - 26), abs(mode - 10));
-    const bool filt = (nT == 8) ? (minDist > 7) : (nT == 16 ? (minDist > 1) : (minDist > 0));
-    if (filt) {
-      bool biInt = false;
-      if (P.strong_intra && nT == 32) {
-        const int th = 1 << (P.bd_luma - 5);
-        biInt = abs(A[0] + A[64] - 2 * A[32]) < th && abs(A[0] + A[-64] - 2 * A[-32]) < th;
-      }
-      for (int p = lane; p <= 4 * nT; p += 64) {
-        const int i = p - 2 * nT;
-        int v;
-        if (i == -2 * nT || i == 2 * nT) v = A[i];
-        else if (biInt) v = (i == 0) ? A[0] : (i < 0 ? A[0] + (((-i) * (A[-64] - A[0]) + 32) >> 6)
-                                                       : A[0] + ((i * (A[64] - A[0]) + 32) >> 6));
-        else v = (A[i + 1] + 2 * A[i] + A[i - 1] + 2) >> 2;
-        Bf[i] = v;
-      }
-      LDS_SYNC();
-      bord = Bf;
-    }
-  }
-
-  const int maxv = (1 << bd) - 1;
-  uint16_t* dst = tile + xB + yB * RUN_TILE_P;
-  // All three predictors are written branch-free: every LDS operand of a sample is requested
-  // unconditionally and together (one round trip), special cases are selects.
-  const bool has_res = res != nullptr;                // wave-uniform
-  if (P.dbg & 128) { LDS_SYNC(); return; }           // ablation: no prediction
-  if (mode == 0) {                                   // planar
-    const int tr = bord[1 + nT], bl = bord[-1 - nT];
-    for (int s = lane; s < nS; s += 64) {
-      const int y = s >> log2, x = s & (nT - 1);
-      const int l = bord[-1 - y], tp = bord[1 + x];
-      const int rs = has_res ? (int)res[s] : 0;
-      const int pv = ((nT - 1 - x) * l + (x + 1) * tr + (nT - 1 - y) * tp + (y + 1) * bl + nT) >> (log2 + 1);
-      dst[x + y * RUN_TILE_P] = (uint16_t)clip3(0, maxv, pv + rs);
-    }
-  } else if (mode == 1) {                            // DC
-    const int v = (lane < nT) ? bord[lane + 1] + bord[-lane - 1] : 0;
-    const int dc = (wave_sum_dpp(v) + nT) >> (log2 + 1);
-    const bool edge = (cIdx == 0 && nT < 32);
-    const int corner = (bord[-1] + 2 * dc + bord[1] + 2) >> 2;
-    for (int s = lane; s < nS; s += 64) {
-      const int y = s >> log2, x = s & (nT - 1);
-      const int tp = bord[x + 1], l = bord[-y - 1];
-      const int rs = has_res ? (int)res[s] : 0;
-      int pv = dc;
-      if (edge) pv = (x | y) == 0 ? corner : (y == 0 ? (tp + 3 * dc + 2) >> 2 : (x == 0 ? (l + 3 * dc + 2) >> 2 : dc));
-      dst[x + y * RUN_TILE_P] = (uint16_t)clip3(0, maxv, pv + rs);
-    }
-  } else {                                           // angular, reference array evaluated in place
-    const int angle = t.angle;
-    const bool vert = mode >= 18;
-    const int inv = t.inv_angle;
-    const bool edge = (cIdx == 0 && nT < 32) && (mode == 26 || mode == 10);
-    const int b0 = bord[0], bp1 = bord[1], bm1 = bord[-1];
-    for (int s = lane; s < nS; s += 64) {
-      const int y = s >> log2, x = s & (nT - 1);
-      const int a = vert ? y : x, b = vert ? x : y;
-      const int iIdx = ((a + 1) * angle) >> 5, iFact = ((a + 1) * angle) & 31;
-      const int i0 = b + iIdx + 1, i1 = i0 + 1;
-      // ref[i] = border[+-i] for i >= 0, border[-+((i*invAngle+128)>>8)] for the projected part (i < 0)
-      const int k0 = i0 >= 0 ? i0 : -((i0 * inv + 128) >> 8);
-      const int k1 = i1 >= 0 ? i1 : -((i1 * inv + 128) >> 8);
-      const int r0 = bord[vert ? k0 : -k0], r1 = bord[vert ? k1 : -k1];
-      const int ev = vert ? bord[-1 - y] : bord[1 + x];         // operand of the mode 26 / 10 edge filter
-      const int rs = has_res ? (int)res[s] : 0;
-      int pv = ((32 - iFact) * r0 + iFact * r1 + 16) >> 5;     // == r0 when iFact == 0
-      if (edge) {
-        const int e = clip3(0, maxv, (vert ? bp1 : bm1) + ((ev - b0) >> 1));
-        pv = (vert ? x == 0 : y == 0) ? e : pv;
-      }
-      dst[x + y * RUN_TILE_P] = (uint16_t)clip3(0, maxv, pv + rs);
-    }
-  }
-  LDS_SYNC();
 }
 
 // ---- fast path for 4x4 and 8x8 intra TUs (about 95 % of all TUs) ----
