@@ -1022,6 +1022,13 @@ __device__ __forceinline__ void micro_intra_tu(const RunTu& t, uint16_t* tile, i
   WAVE_BARRIER_ONLY();
 }
 
+// Timing-only ablation switches of the run kernel (DE265HIP_DEBUG bits 2, 4, 8, 32, 64, 1024) exist only in builds with
+// -DD265_ABLATE: in the shipped kernel every one of them is a branch and code the chain has to step over.
+#ifdef D265_ABLATE
+#define RUN_DBG dbg
+#else
+#define RUN_DBG 0
+#endif
 template <typename PX>
 __device__ __forceinline__ void micro_run(const PicDev& P, const PlaneRef& pl0, const PlaneRef& pl1, const PlaneRef& pl2,
                                           const RunTask* __restrict__ runs, const uint32_t* __restrict__ deps,
@@ -1071,13 +1078,13 @@ __device__ __forceinline__ void micro_run(const PicDev& P, const PlaneRef& pl0, 
     const uint32_t* flag = &sync[2 + (i == lane ? dep_id : deps[run.dep_offset + i])];
     int spins = 0;
     uint32_t f = (i == lane) ? flag0 : gen - 1u;
-    while (f != gen && !(dbg & 32)) {
+    while (f != gen && !(RUN_DBG & 32)) {
       if (spins) { if (spins < 4) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(64); }
       if (++spins > RUN_SPIN_LIMIT) { atomicExch(err, 1u); break; }
       f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  if (run.n_deps && !(dbg & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // this wavefront's own loads follow
+  if (run.n_deps && !(RUN_DBG & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // this wavefront's own loads follow
   // window: at most 41 rows x 6 chunks of 8 samples
   const int nchx = (wx1 - ax0 + 7) >> 3, nrows = wy1 - wy0, nchunks = nchx * nrows;
   {
@@ -1269,9 +1276,9 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   };
   // producers already finished (the usual case when the picture is throughput-bound): fetch the window now,
   // under the preparation of the samples, instead of after it
-  const bool early = !(dbg & 8) && (run.n_deps == 0 || __syncthreads_and(flag0 == gen));
+  const bool early = !(RUN_DBG & 8) && (run.n_deps == 0 || __syncthreads_and(flag0 == gen));
   if (early) {
-    if (run.n_deps && !(dbg & 2)) {
+    if (run.n_deps && !(RUN_DBG & 2)) {
       // one acquire per workgroup (the L1 belongs to the CU): wavefront 0 invalidates and waits for it,
       // the others load behind the barrier
       if (wave == 0) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -1279,7 +1286,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
     }
     window_issue(0);
   }
-  if (!(dbg & 64))
+  if (!(RUN_DBG & 64))
   for (int s = tid; s < n_samples; s += nthr)
     run_prepare_sample<RUN_TILE_P>(s, s_task, s_own, s_res, s_ctl, s_ex, s_mine, resid, res_base, CONST_ADDR);
   st.mark(2);
@@ -1290,7 +1297,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
       const uint32_t* flag = &sync[2 + (i == tid ? dep_id : deps[run.dep_offset + i])];
       int spins = 0;
       uint32_t f = (i == tid) ? flag0 : gen - 1u;
-      while (f != gen && !(dbg & 32)) {                                  // (dbg 32: timing-only ablation, ignores producers)
+      while (f != gen && !(RUN_DBG & 32)) {                                  // (dbg 32: timing-only ablation, ignores producers)
         // back off quickly: hundreds of waiting wavefronts polling at full rate starve the fabric
         if (spins) { if (spins < 4) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(64); }
         if (++spins > RUN_SPIN_LIMIT) { atomicExch(err, 1u); break; }           // never hang the grid
@@ -1298,13 +1305,13 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
       }
     }
     __syncthreads();
-    if (!(dbg & 2)) {
+    if (!(RUN_DBG & 2)) {
       if (wave == 0) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
       __syncthreads();
     }
   }
   st.mark(3);
-  if (!(dbg & 8))
+  if (!(RUN_DBG & 8))
   for (int base = wbase; base < nchunks; base += 4 * nthr) { window_issue(base); window_commit(); }
   __syncthreads();
   st.mark(4);
@@ -1314,7 +1321,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   // earlier in the own list starts at once (LDS executes a wavefront's operations in order); producers on another
   // wavefront lie a barrier epoch earlier: before a TU of epoch e its wavefront has passed e workgroup barriers.
   // Records are read two TUs ahead and per-lane operands one TU ahead (none of this is waited for on the chain).
-  if (!(dbg & 4)) {
+  if (!(RUN_DBG & 4)) {
     const uint16_t* we = runs[ticket].wave_end;                          // (indexed in memory: no register array)
     const int j0 = wave == 0 ? 0 : (int)we[wave - 1], j1 = (int)we[wave];
     const int n_epochs = run.n_lvls;
@@ -1361,7 +1368,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   {
     PX* wplane = plane + ax0 + wy0 * stride;                             // picture address of window sample (0, 0)
     const int rows = (int)run.y1 - (int)run.y0, nch = ((int)run.x1 - ax0 + 7) >> 3;
-    if (!(dbg & 1024))
+    if (!(RUN_DBG & 1024))
     for (int idx = tid; idx < rows * nch; idx += nthr) {
       const int r = 1 + idx / nch, cx = idx - (r - 1) * nch;
       const uint32_t m = (s_mine[r] >> (2 * cx)) & 3u;
