@@ -159,10 +159,8 @@ int make_geometry(const de265hip_pic_params& p, Geometry& g)
 uint64_t intra_availability(const de265hip_picture_desc& d, const Geometry& g, const de265hip_tu& tu,
                             const std::vector<uint16_t>& lvl, int map_w, int* level_out,
                             const std::vector<int32_t>& runmap, std::vector<int>& producers,
-                            const std::vector<uint16_t>& llvl, int cur_run, int* local_level_out,
-                            const std::vector<uint16_t>& tumap, std::vector<uint16_t>& prod_tus)
+                            const std::vector<uint16_t>& llvl, int cur_run, int* local_level_out)
 {
-  prod_tus.clear();
   producers.clear();
   const de265hip_pic_params& p = d.params;
   const int nT = 1 << tu.log2_size, sub = tu.c_idx ? 2 : 1;
@@ -195,11 +193,7 @@ uint64_t intra_availability(const de265hip_picture_desc& d, const Geometry& g, c
     mask |= 1ull << u;
     lev = std::max(lev, (int)lvl[(xs >> 2) + (ys >> 2) * map_w]);
     const int r = runmap[(xs >> 2) + (ys >> 2) * map_w];
-    if (r >= 0 && r == cur_run) {
-      llev = std::max(llev, (int)llvl[(xs >> 2) + (ys >> 2) * map_w]);
-      const uint16_t pt = tumap[(xs >> 2) + (ys >> 2) * map_w];          // producing TU inside the current run
-      if (std::find(prod_tus.begin(), prod_tus.end(), pt) == prod_tus.end()) prod_tus.push_back(pt);
-    }
+    if (r >= 0 && r == cur_run) llev = std::max(llev, (int)llvl[(xs >> 2) + (ys >> 2) * map_w]);
     if (r >= 0 && std::find(producers.begin(), producers.end(), r) == producers.end()) producers.push_back(r);
   };
   if (aL)
@@ -372,15 +366,12 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   // runs: maximal intervals of the per-component intra TU sequence inside one CTB in which
   // every TU reads from the run so far (see k_run); independent TUs start a new run
   struct RunBuild { int c, ctu, x0, y0, x1, y1, level, wx1, wy1; std::vector<TuTask> tus; std::vector<int> deps;
-                    std::vector<uint16_t> llev; std::vector<std::vector<uint16_t>> prods; };
+                    std::vector<uint16_t> llev; };
   std::vector<RunBuild> rb;
   std::vector<int32_t> runmap[3];
   for (int c = 0; c < 3; c++) runmap[c].assign((size_t)map_w[c] * map_h[c], -1);
   std::vector<uint16_t> llvl[3];                 // in-run dependency level of the TU covering a 4x4 unit
   for (int c = 0; c < 3; c++) llvl[c].assign((size_t)map_w[c] * map_h[c], 0);
-  std::vector<uint16_t> tumap[3];                // index (inside its run) of the TU covering a 4x4 unit
-  for (int c = 0; c < 3; c++) tumap[c].assign((size_t)map_w[c] * map_h[c], 0);
-  std::vector<uint16_t> prod_tus;
   int cur_run[3] = { -1, -1, -1 };
   std::vector<int> producers;
   // dense intra (no inter PUs at all): one run per CTB and component, fewest hand-offs on the z-scan chain.
@@ -421,8 +412,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
         t.inv_angle = (m >= 11 && m <= 25 && k_angle[m] < 0) ? k_inv[m - 11] : 0;
       }
       int llev = 1;
-      t.avail = intra_availability(*d, g, tu, lvl[c], map_w[c], &level, runmap[c], producers, llvl[c], cur_run[c], &llev,
-                                   tumap[c], prod_tus);
+      t.avail = intra_availability(*d, g, tu, lvl[c], map_w[c], &level, runmap[c], producers, llvl[c], cur_run[c], &llev);
       const int ctu = ((tu.x0 * sub) >> p.log2_ctb_size) + ((tu.y0 * sub) >> p.log2_ctb_size) * g.ctbs_w;
       int r = cur_run[c];
       bool extends = r >= 0 && rb[r].ctu == ctu && rb[r].tus.size() < 255 &&        /* RUN_MAX_TUS of k_run; positions + 1 fit a byte */
@@ -437,7 +427,6 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
         rb.push_back(RunBuild{ c, ctu, tu.x0, tu.y0, tu.x0 + nT, tu.y0 + nT, 0, 0, 0, {}, {} });
         cur_run[c] = r;
         llev = 1;
-        prod_tus.clear();
       }
       RunBuild& R = rb[r];
       R.x0 = std::min(R.x0, (int)tu.x0); R.y0 = std::min(R.y0, (int)tu.y0);
@@ -445,13 +434,11 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       R.wx1 = std::max(R.wx1, tu.x0 + 2 * nT); R.wy1 = std::max(R.wy1, tu.y0 + 2 * nT);    // top-right / bottom-left reach
       for (int pr : producers)
         if (pr != r && std::find(R.deps.begin(), R.deps.end(), pr) == R.deps.end()) R.deps.push_back(pr);
-      const uint16_t tu_in_run = (uint16_t)R.tus.size();
-      R.tus.push_back(t); R.llev.push_back((uint16_t)llev); R.prods.push_back(prod_tus);
+      R.tus.push_back(t); R.llev.push_back((uint16_t)llev);
       for (int y = tu.y0 >> 2; y < (tu.y0 + nT) >> 2; y++)
         for (int x = tu.x0 >> 2; x < (tu.x0 + nT) >> 2; x++) {
           lvl[c][x + (size_t)y * map_w[c]] = (uint16_t)level;
           llvl[c][x + (size_t)y * map_w[c]] = (uint16_t)llev;
-          tumap[c][x + (size_t)y * map_w[c]] = tu_in_run;
           runmap[c][x + (size_t)y * map_w[c]] = r;
         }
       alg_intra += (int64_t)bpp * (4 * nT + 1) + (int64_t)bpp * nT * nT;
