@@ -230,11 +230,12 @@ def test_concurrent_decoders_do_not_interfere(dec):
 def test_randomized_small_pictures(dec):
     """Many small random configurations (sizes down to one CTB, every feature switch drawn at random):
     shakes out corner cases of availability, window clipping and partial strips."""
-    rng = np.random.default_rng(20260104)
-    for it in range(60):
+    import os
+    rng = np.random.default_rng(int(os.environ.get("DE265HIP_TEST_SEED", "20260104")))
+    for it in range(int(os.environ.get("DE265HIP_TEST_RANDOM", "60"))):       # a longer sweep: DE265HIP_TEST_RANDOM=1000
         log2_ctb = int(rng.choice([4, 5, 6]))
-        w = int(rng.integers(1, 26)) * 8
-        h = int(rng.integers(1, 18)) * 8
+        w = int(rng.integers(1, 26)) * 8 if it % 7 else int(rng.integers(26, 80)) * 8
+        h = int(rng.integers(1, 18)) * 8 if it % 7 else int(rng.integers(18, 48)) * 8
         bd = int(rng.choice([8, 9, 10, 12]))
         st = int(rng.choice([0, 1, 2]))
         cols = int(rng.integers(1, 3)) if w >= 128 else 1
