@@ -1329,6 +1329,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
     const int n_epochs = run.n_lvls;
     int epoch = 0;
     if (j0 < j1) {
+      __builtin_amdgcn_s_setprio(3);                                     // the chain is latency-bound: issue it first
       const char* task_b = reinterpret_cast<const char*>(s_task);
       const char* res_b = reinterpret_cast<const char*>(s_res); const char* ctl_b = reinterpret_cast<const char*>(s_ctl);
       const uint2 r0 = *reinterpret_cast<const uint2*>(task_b + 16 * j0);
@@ -1337,21 +1338,26 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
       int sl = lane & ((w0 & RTU_IS4) ? 15 : 63);
       uint32_t ctl = *reinterpret_cast<const uint32_t*>(ctl_b + (w1 & 0x3FFF) + 4 * sl);
       int rs = *reinterpret_cast<const int16_t*>(res_b + ((w1 & 0x3FFF) >> 1) + 2 * sl);
-      for (int j = j0; j < j1; j++) {
-        const int ep = (w0 >> 16) & 0xFF;
-        while (epoch < ep) { RUN_LDS_BARRIER(); epoch++; }
-        // off the chain: next TU's record -> its per-lane operands; the record after next
-        const uint32_t n0 = __builtin_amdgcn_readfirstlane(r_nxt.x), n1 = __builtin_amdgcn_readfirstlane(r_nxt.y);
-        const int nsl = lane & ((n0 & RTU_IS4) ? 15 : 63);
-        const uint32_t nctl = *reinterpret_cast<const uint32_t*>(ctl_b + (n1 & 0x3FFF) + 4 * nsl);
-        const int nrs = *reinterpret_cast<const int16_t*>(res_b + ((n1 & 0x3FFF) >> 1) + 2 * nsl);
-        r_nxt = *reinterpret_cast<const uint2*>(task_b + 16 * min(j + 2, j1 - 1));
-
-        const int tb = w0 & 0x7FFF;
-        const int angle = (int)(int8_t)(w1 >> 24);
-        if (__builtin_expect((w0 & (RTU_BIG | RTU_SMOOTH | (3u << 24))) == (2u << 24), 1)) {
-          // the common case by far, spelled out with as few instructions as possible (the chain costs about a dozen
-          // cycles per instruction): 4x4 / 8x8 angular TU without smoothing, operands straight from the window
+      // The loop is written as a tight inner loop over the common TU kind (angular, not smoothed, 4x4 / 8x8: spelled out
+      // with as few instructions as possible, the chain costs about a dozen cycles per instruction) that drops out to the
+      // general code for one TU of any other kind: the compiler then lays the common path out contiguously.
+#define RUN_CHAIN_HEAD()                                                                                                   \
+      { const int ep = (w0 >> 16) & 0xFF;                                                                                 \
+        while (epoch < ep) { RUN_LDS_BARRIER(); epoch++; } }                                                              \
+      /* off the chain: next TU's record -> its per-lane operands; the record after next */                               \
+      const uint32_t n0 = __builtin_amdgcn_readfirstlane(r_nxt.x), n1 = __builtin_amdgcn_readfirstlane(r_nxt.y);          \
+      const int nsl = lane & ((n0 & RTU_IS4) ? 15 : 63);                                                                   \
+      const uint32_t nctl = *reinterpret_cast<const uint32_t*>(ctl_b + (n1 & 0x3FFF) + 4 * nsl);                           \
+      const int nrs = *reinterpret_cast<const int16_t*>(res_b + ((n1 & 0x3FFF) >> 1) + 2 * nsl);                          \
+      r_nxt = *reinterpret_cast<const uint2*>(task_b + 16 * min(j + 2, j1 - 1));                                           \
+      const int tb = w0 & 0x7FFF;                                                                                          \
+      const int angle = (int)(int8_t)(w1 >> 24);
+#define RUN_CHAIN_NEXT() w0 = n0; w1 = n1; ctl = nctl; rs = nrs; j++;
+#define RUN_IS_FAST(w) (((w) & (RTU_BIG | RTU_SMOOTH | (3u << 24))) == (2u << 24))
+      int j = j0;
+      while (j < j1) {
+        while (j < j1 && RUN_IS_FAST(w0)) {
+          RUN_CHAIN_HEAD()
           const int A = *reinterpret_cast<uint16_t*>(tile_b + (ctl & 0xFFFF));
           const int B = *reinterpret_cast<uint16_t*>(tile_b + (ctl >> 16));
           // per-lane constants of both TU sizes live in one register each: byte 0/1 = x+1 / y+1 of the 4x4 position,
@@ -1362,7 +1368,11 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
           const int pv = (__mul24(f, B - A) + (A << 5) + 16) >> 5;
           *reinterpret_cast<uint16_t*>(tile_b + tb + toff2) = (uint16_t)clip3(0, maxv, pv + rs);
           WAVE_BARRIER_ONLY();
-        } else if (!(w0 & RTU_BIG)) {
+          RUN_CHAIN_NEXT()
+        }
+        if (j >= j1) break;
+        RUN_CHAIN_HEAD()
+        if (!(w0 & RTU_BIG)) {
           if (w0 & RTU_IS4) run_chain_small<2>(w0, angle, c, maxv, lane, L4, ctl, rs, tile_b, tb, s_ex, j);
           else run_chain_small<3>(w0, angle, c, maxv, lane, L8, ctl, rs, tile_b, tb, s_ex, j);
         } else {
@@ -1370,8 +1380,12 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
           const int log2 = __builtin_amdgcn_readfirstlane((int)((s_task[j].w >> 27) & 7));
           run_chain_big<RUN_TILE_P>(P, w0, angle, c, maxv, lane, log2, s_ctl + samp, s_res + samp, tile_b, tb, s_ex, j, S[wave]);
         }
-        w0 = n0; w1 = n1; ctl = nctl; rs = nrs;
+        RUN_CHAIN_NEXT()
       }
+#undef RUN_CHAIN_HEAD
+#undef RUN_CHAIN_NEXT
+#undef RUN_IS_FAST
+      __builtin_amdgcn_s_setprio(0);
     }
     while (epoch < n_epochs) { RUN_LDS_BARRIER(); epoch++; }
   }
