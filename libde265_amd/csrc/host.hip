@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <vector>
+#include <mutex>
 
 #include "kernels.h"
 
@@ -154,12 +155,80 @@ int make_geometry(const de265hip_pic_params& p, Geometry& g)
   return 0;
 }
 
+// Which neighbour units a TU's prediction actually reads, by size, mode and luma/chroma: the border is fetched as a whole
+// (intrapred.cc:532-542) but a vertical mode never looks at the left column, a mode-2 TU never at the top row, planar only
+// at the first sample beyond each side.  Bit u as in the availability mask.  Built once by running the very index
+// arithmetic of the predictors (intrapred.cc:903-1069; the same code as run_prepare_sample in k_tu.hip) over every
+// sample, plus the [1 2 1] / bilinear smoothing (:816-889) and the mode 10/26 and DC edge filters where they apply.
+// Dependencies derived from it (instead of from every available unit) shorten the intra dependency chains.
+static uint64_t g_used_units[4][35][2];
+static void build_used_units()
+{
+  static const int8_t k_angle[35] = { 0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26,
+                                      -32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };
+  static const int16_t k_inv[15] = { -4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096 };
+  for (int l2 = 2; l2 <= 5; l2++)
+    for (int mode = 0; mode < 35; mode++)
+      for (int luma = 0; luma < 2; luma++) {
+        const int nT = 1 << l2, C = 2 * nT, NB = 4 * nT + 1;
+        std::vector<uint8_t> e(NB, 0);                    // border entries read
+        if (mode == 0) {
+          for (int i = 0; i < nT; i++) { e[C - 1 - i] = 1; e[C + 1 + i] = 1; }
+          e[C + 1 + nT] = 1; e[C - 1 - nT] = 1;
+        } else if (mode == 1) {
+          for (int i = 0; i < nT; i++) { e[C - 1 - i] = 1; e[C + 1 + i] = 1; }
+        } else {
+          const int angle = k_angle[mode], inv = (mode >= 11 && mode <= 25 && angle < 0) ? k_inv[mode - 11] : 0;
+          const bool vert = mode >= 18;
+          for (int y = 0; y < nT; y++)
+            for (int x = 0; x < nT; x++) {
+              const int a = vert ? y : x, b = vert ? x : y;
+              const int iIdx = ((a + 1) * angle) >> 5;
+              const int i0 = b + iIdx + 1, i1 = i0 + 1;
+              const int k0 = i0 >= 0 ? i0 : -((i0 * inv + 128) >> 8);
+              const int k1 = std::min(i1 >= 0 ? i1 : -((i1 * inv + 128) >> 8), C);
+              e[vert ? C + k0 : C - k0] = 1; e[vert ? C + k1 : C - k1] = 1;
+            }
+          if (luma && nT < 32 && (mode == 26 || mode == 10)) {          // edge filter: the other side and the corner
+            for (int i = 0; i < nT; i++) e[mode == 26 ? C - 1 - i : C + 1 + i] = 1;
+            e[C] = 1;
+          }
+        }
+        const int md = std::min(std::abs(mode - 26), std::abs(mode - 10));
+        const bool smooth = luma && mode != 1 && (l2 == 3 ? md > 7 : (l2 == 4 ? md > 1 : (l2 == 5 && md > 0)));
+        if (smooth) {
+          std::vector<uint8_t> f(e);
+          for (int q = 0; q < NB; q++) if (e[q]) { if (q > 0) f[q - 1] = 1; if (q + 1 < NB) f[q + 1] = 1; }
+          if (l2 == 5) { f[0] = 1; f[C] = 1; f[4 * nT] = 1; }             // bilinear variant
+          e.swap(f);
+        }
+        uint64_t u = 0;
+        const int corner = nT >> 1;
+        for (int q = 0; q < NB; q++) if (e[q]) u |= 1ull << (q < C ? (q >> 2) : (q == C ? corner : corner + 1 + ((q - C - 1) >> 2)));
+        g_used_units[l2 - 2][mode][luma] = u;
+      }
+}
+// the units whose samples a TU with availability `avail` really reads: the used ones that are available, plus, for
+// every used but unavailable one, the unit its samples are substituted from (intrapred.cc:395-431)
+static uint64_t needed_units(uint64_t used, uint64_t avail)
+{
+  if (avail == 0) return 0;
+  uint64_t need = used & avail, miss = used & ~avail;
+  while (miss) {
+    const int u = __builtin_ctzll(miss); miss &= miss - 1;
+    const uint64_t below = avail & ((2ull << u) - 1ull);
+    need |= below ? 1ull << (63 - __builtin_clzll(below)) : avail & (~avail + 1ull);
+  }
+  return need;
+}
+
 // Neighbour availability of one intra TU (8.4.4.2.2; intrapred.cc:437-527 preproc,
 // :577-688 fill_from_image) as a unit bitmask, and the TU's dependency level.
 uint64_t intra_availability(const de265hip_picture_desc& d, const Geometry& g, const de265hip_tu& tu,
                             const std::vector<uint16_t>& lvl, int map_w, int* level_out,
                             const std::vector<int32_t>& runmap, std::vector<int>& producers,
-                            const std::vector<uint16_t>& llvl, int cur_run, int* local_level_out)
+                            const std::vector<uint16_t>& llvl, int cur_run, int* local_level_out,
+                            bool mode_deps, bool* in_cur_run)
 {
   producers.clear();
   const de265hip_pic_params& p = d.params;
@@ -189,12 +258,10 @@ uint64_t intra_availability(const de265hip_picture_desc& d, const Geometry& g, c
   };
   uint64_t mask = 0; int lev = 0, llev = 0;
   const int corner = nT >> 1;
+  int32_t cell[33];                                       // 4x4 map cell of every available unit
   auto take = [&](int u, int xs, int ys) {
     mask |= 1ull << u;
-    lev = std::max(lev, (int)lvl[(xs >> 2) + (ys >> 2) * map_w]);
-    const int r = runmap[(xs >> 2) + (ys >> 2) * map_w];
-    if (r >= 0 && r == cur_run) llev = std::max(llev, (int)llvl[(xs >> 2) + (ys >> 2) * map_w]);
-    if (r >= 0 && std::find(producers.begin(), producers.end(), r) == producers.end()) producers.push_back(r);
+    cell[u] = (xs >> 2) + (ys >> 2) * map_w;
   };
   if (aL)
     for (int y = nBottom - 1; y >= 0; y -= 4)
@@ -202,6 +269,21 @@ uint64_t intra_availability(const de265hip_picture_desc& d, const Geometry& g, c
   if (aTL && usable(xB - 1, yB - 1)) take(corner, xB - 1, yB - 1);
   for (int x = 0; x < nRight; x += 4)
     if ((x < nT ? aT : aTR) && usable(xB + x, yB - 1)) take(corner + 1 + (x >> 2), xB + x, yB - 1);
+  // dependencies: only the units the mode reads (mode_deps), or every available unit
+  const int mode = tu.intra_mode < 35 ? tu.intra_mode : 1;
+  uint64_t need = mode_deps ? needed_units(g_used_units[tu.log2_size - 2][mode][tu.c_idx == 0], mask) : mask;
+  *in_cur_run = false;
+  for (uint64_t m = mask; m; m &= m - 1) {
+    const int r = runmap[cell[__builtin_ctzll(m)]];
+    if (r >= 0 && r == cur_run) *in_cur_run = true;       // (the run structure is decided on the full neighbourhood)
+  }
+  for (; need; need &= need - 1) {
+    const int c4 = cell[__builtin_ctzll(need)];
+    lev = std::max(lev, (int)lvl[c4]);
+    const int r = runmap[c4];
+    if (r >= 0 && r == cur_run) llev = std::max(llev, (int)llvl[c4]);
+    if (r >= 0 && std::find(producers.begin(), producers.end(), r) == producers.end()) producers.push_back(r);
+  }
   *level_out = lev + 1;
   *local_level_out = llev + 1;      // only meaningful when the TU ends up extending cur_run
   return mask;
@@ -354,6 +436,9 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   P.cb_qp_offset = p.pic_cb_qp_offset; P.cr_qp_offset = p.pic_cr_qp_offset;
   P.lf_across_tiles = p.loop_filter_across_tiles_enabled_flag; P.scaling_list = p.scaling_list_enable_flag;
 
+  // dependencies between intra TUs from the units each mode reads (DE265HIP_NO_MODE_DEPS: from every available unit)
+  const bool mode_deps = getenv("DE265HIP_NO_MODE_DEPS") == nullptr;
+  { static std::once_flag once; std::call_once(once, build_used_units); }
   // ---- TU tasks: availability, dependency level, stable sort by level
   std::vector<TuTask> tasks; tasks.reserve(d->n_tus);
   std::vector<int> levels; levels.reserve(d->n_tus);
@@ -412,11 +497,13 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
         t.inv_angle = (m >= 11 && m <= 25 && k_angle[m] < 0) ? k_inv[m - 11] : 0;
       }
       int llev = 1;
-      t.avail = intra_availability(*d, g, tu, lvl[c], map_w[c], &level, runmap[c], producers, llvl[c], cur_run[c], &llev);
+      bool in_cur_run = false;
+      t.avail = intra_availability(*d, g, tu, lvl[c], map_w[c], &level, runmap[c], producers, llvl[c], cur_run[c], &llev,
+                                   mode_deps, &in_cur_run);
       const int ctu = ((tu.x0 * sub) >> p.log2_ctb_size) + ((tu.y0 * sub) >> p.log2_ctb_size) * g.ctbs_w;
       int r = cur_run[c];
       bool extends = r >= 0 && rb[r].ctu == ctu && rb[r].tus.size() < 255 &&        /* RUN_MAX_TUS of k_run; positions + 1 fit a byte */
-                     std::find(producers.begin(), producers.end(), r) != producers.end();
+                     in_cur_run;
       if (extends && run_box < 64) {       // sparse-intra pictures: keep every run inside a run_box^2 bounding box
         const int bw = std::max(rb[r].x1, tu.x0 + nT) - std::min(rb[r].x0, (int)tu.x0);
         const int bh = std::max(rb[r].y1, tu.y0 + nT) - std::min(rb[r].y0, (int)tu.y0);
