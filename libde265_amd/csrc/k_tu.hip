@@ -1253,10 +1253,10 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   const bool dense = run.micro & 2;
   const int nchunks = dense ? nchx + nrows - 1 : nchx * nrows;
   uint4 wv[4]; int woff[4];
-  auto window_issue = [&](int base) {
+  auto window_issue = [&](int base, int nth, int id) {
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      const int idx = base + u * nthr + tid;
+      const int idx = base + u * nth + id;
       woff[u] = -1;
       if (idx < nchunks) {
         int r, cx;
@@ -1286,7 +1286,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
       if (wave == 0) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
       __syncthreads();
     }
-    window_issue(0);
+    window_issue(0, nthr, tid);
   }
   if (!(RUN_DBG & 64))
   for (int s = tid; s < n_samples; s += nthr)
@@ -1308,14 +1308,22 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
       }
     }
     __syncthreads();
-    if (!(RUN_DBG & 2)) {
+    if (dense && nchunks <= 256 && !(RUN_DBG & 2)) {
+      // the few border chunks of a dense run: the acquiring wavefront fetches them itself, straight behind the invalidate
+      // (its own loads need neither the wait for it nor a barrier), instead of acquire -> wait -> barrier -> loads by all
+      if (wave == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        window_issue(0, 64, lane); window_commit();
+      }
+      wbase = nchunks;
+    } else if (!(RUN_DBG & 2)) {
       if (wave == 0) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
       __syncthreads();
     }
   }
   st.mark(3);
   if (!(RUN_DBG & 8))
-  for (int base = wbase; base < nchunks; base += 4 * nthr) { window_issue(base); window_commit(); }
+  for (int base = wbase; base < nchunks; base += 4 * nthr) { window_issue(base, nthr, tid); window_commit(); }
   __syncthreads();
   st.mark(4);
 
