@@ -627,13 +627,19 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
         //  round-robin lists with barriers only at cross-wavefront edges plus early arrival of the producing wavefront:
         //  54 % fewer barriers, 3.33 instead of 3.19 ms -- the workgroup barrier is not what the chain waits for)
         std::vector<std::vector<int>> lists(nwv);             // TU indices (decode order inside the run)
+        std::vector<int> collective;                          // the 16x16 / 32x32 TUs: a fifth list behind the wavefronts' lists
         std::vector<uint16_t> epoch(R.tus.size(), 0);
         int n_epochs = nl > 0 ? nl - 1 : 0;
         {
           std::vector<int> rank(nl + 1, 0);
-          for (size_t i = 0; i < R.tus.size(); i++) { lists[rank[R.llev[i]]++ % nwv].push_back((int)i); epoch[i] = (uint16_t)(R.llev[i] - 1); }
+          for (size_t i = 0; i < R.tus.size(); i++) {
+            epoch[i] = (uint16_t)(R.llev[i] - 1);
+            if (R.tus[i].log2_size > 3 && !micro[order[k]]) collective.push_back((int)i);   // reconstructed by all wavefronts together
+            else lists[rank[R.llev[i]]++ % nwv].push_back((int)i);
+          }
           for (int w = 0; w < nwv; w++)
             std::stable_sort(lists[w].begin(), lists[w].end(), [&](int a, int b) { return R.llev[a] < R.llev[b]; });
+          std::stable_sort(collective.begin(), collective.end(), [&](int a, int b) { return R.llev[a] < R.llev[b]; });
         }
         for (int w = 0; w < 4; w++) {
           if (w < nwv)
@@ -645,6 +651,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
             }
           o.wave_end[w] = (uint16_t)ordered.size();
         }
+        for (int i : collective) { ordered.push_back(R.tus[i]); ordered_req.push_back(epoch[i]); }
         if (n_epochs > 255) { delete pic; return DE265HIP_ERROR_NOT_IMPLEMENTED; }
         o.n_lvls = (uint16_t)n_epochs;                   // workgroup barriers of the run's chain
         dbg_foreign += n_epochs;
@@ -678,14 +685,24 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     pic->n_batches = (int)(slots.size() / 4);
     pic->n_workers = std::min(pic->n_batches, std::max(64, std::min(cap, widest + widest / 4)));
     if (getenv("DE265HIP_PRINT_CRIT")) {               // diagnostic: longest path through the run DAG
-      std::vector<double> fin(rb.size(), 0.0); double worst = 0, worst_l = 0; int worst_n = 0;
-      std::vector<int> nl_of(rb.size(), 0), cnt(rb.size(), 0); std::vector<double> lv(rb.size(), 0.0);
+      // cost model of one run (us; fitted to ablation timings): fixed + per barrier level + per TU a wavefront has to do
+      // in sequence inside a level + per 16x16 / 32x32 TU (collective)
+      struct Path { double t = 0, lv = 0, slots = 0, n16 = 0, n32 = 0; int runs = 0; };
+      std::vector<Path> fin(rb.size()); Path worst;
       for (size_t i = 0; i < rb.size(); i++) {           // rb is in decode order: producers precede consumers
         int nl = 0; for (uint16_t l : rb[i].llev) nl = std::max(nl, (int)l);
-        double st = 0, sl = 0; int sn = 0;
-        for (int dp : rb[i].deps) if (fin[dp] > st) { st = fin[dp]; sl = lv[dp]; sn = cnt[dp]; }
-        fin[i] = st + 8.0 + 0.45 * nl; lv[i] = sl + nl; cnt[i] = sn + 1;
-        if (fin[i] > worst) { worst = fin[i]; worst_l = lv[i]; worst_n = cnt[i]; }
+        std::vector<int> per(nl + 1, 0); int n16 = 0, n32 = 0;
+        for (size_t k = 0; k < rb[i].tus.size(); k++) {
+          const int l2 = rb[i].tus[k].log2_size;
+          if (l2 == 4) n16++; else if (l2 == 5) n32++; else per[rb[i].llev[k]]++;
+        }
+        int slots = 0; for (int l = 1; l <= nl; l++) slots += (per[l] + 3) / 4;
+        Path st;
+        for (int dp : rb[i].deps) if (fin[dp].t > st.t) st = fin[dp];
+        st.t += 4.5 + 0.13 * nl + 0.10 * slots + 0.55 * n16 + 0.65 * n32;
+        st.lv += nl; st.slots += slots; st.n16 += n16; st.n32 += n32; st.runs++;
+        fin[i] = st;
+        if (st.t > worst.t) worst = st;
       }
       int hist[8] = {0}, small32 = 0, nmicro = 0;
       for (size_t i = 0; i < rb.size(); i++) {
@@ -699,7 +716,8 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
               rb.size(), nmicro, small32, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7]);
       fprintf(stderr, "de265hip chain: %lld barrier epochs in all runs; TUs per wavefront %lld %lld %lld %lld\n",
               (long long)dbg_foreign, (long long)dbg_w[0], (long long)dbg_w[1], (long long)dbg_w[2], (long long)dbg_w[3]);
-      fprintf(stderr, "de265hip crit: est %.0f us, %d runs and %.0f in-run levels on the longest path\n", worst, worst_n, worst_l);
+      fprintf(stderr, "de265hip crit: est %.0f us; on the longest path %d runs, %.0f in-run levels, %.0f TU slots, %.0f 16x16 and %.0f 32x32 TUs\n",
+              worst.t, worst.runs, worst.lv, worst.slots, worst.n16, worst.n32);
     }
     // tickets per draw: 1 (DE265HIP_TICKET_BATCH for experiments: several per draw relieve the single device-scope
     // counter, ~12 ns per add, but serialise dependants: +46 % at 4 on a 4K B picture)

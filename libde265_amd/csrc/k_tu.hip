@@ -801,10 +801,12 @@ __device__ __forceinline__ void run_prepare_sample(int s, const uint4* s_task, c
 struct RunLane { int x, y, toff2; };                  // per-lane constants of one TU size: sample position, byte offset in the window
 
 // The chain step of a 4x4 / 8x8 TU.  w0: packed record word x (uniform), ctl / rs: this lane's operand word and
-// residual, tb: LDS byte address of the TU origin in the window.
+// residual, tb: LDS byte address of the TU origin in the window.  A0 / B0: the window samples at the two addresses of
+// ctl, read by the caller (the first thing behind the barrier, ahead of its read-ahead for the next TU).
 template <int LOG2>
 __device__ __forceinline__ void run_chain_small(uint32_t w0, int angle, int c, int maxv, int lane, const RunLane& L,
-                                                uint32_t ctl, int rs, char* tile_b, int tb, const uint32_t* s_ex, int k)
+                                                uint32_t ctl, int rs, char* tile_b, int tb, const uint32_t* s_ex, int k,
+                                                int A0, int B0)
 {
   constexpr int nT = 1 << LOG2, nS = nT * nT, NB = 4 * nT + 1, C = 2 * nT;
   const int kind = (w0 >> 24) & 3;
@@ -812,7 +814,7 @@ __device__ __forceinline__ void run_chain_small(uint32_t w0, int angle, int c, i
   int A, B, bv = 0;
   const bool smooth = LOG2 == 3 && (w0 & RTU_SMOOTH);
   if (smooth) {
-    bv = *reinterpret_cast<uint16_t*>(tile_b + (ctl >> 16));
+    bv = B0;
     // [1 2 1] smoothing (intrapred.cc:816-889); both ends keep their value
     const int prev = __builtin_amdgcn_update_dpp(bv, bv, 0x138, 0xf, 0xf, false);   // wave_shr:1 -> lane-1
     const int next = __builtin_amdgcn_update_dpp(bv, bv, 0x130, 0xf, 0xf, false);   // wave_shl:1 -> lane+1
@@ -821,8 +823,7 @@ __device__ __forceinline__ void run_chain_small(uint32_t w0, int angle, int c, i
     A = __builtin_amdgcn_ds_bpermute(ctl & 0xFF, bv);
     B = __builtin_amdgcn_ds_bpermute((ctl >> 8) & 0xFF, bv);
   } else {
-    A = *reinterpret_cast<uint16_t*>(tile_b + (ctl & 0xFFFF));
-    B = *reinterpret_cast<uint16_t*>(tile_b + (ctl >> 16));
+    A = A0; B = B0;
   }
   int pv;
   if (__builtin_expect(kind == 2, 1)) {
@@ -856,36 +857,88 @@ __device__ __forceinline__ void run_chain_small(uint32_t w0, int angle, int c, i
   WAVE_BARRIER_ONLY();
 }
 
-// The chain step of a 16x16 / 32x32 TU: nS / 64 samples per lane.  Same prepared operands as the small TUs; a
-// smoothed TU goes through a border array in LDS (gather -> [1 2 1] or the 32x32 bilinear filter, intrapred.cc:816-889
-// -> operands by index), the others read their operands straight from the window.
-template <int RUN_TILE_P>
-__device__ __forceinline__ void run_chain_big(const PicDev& P, uint32_t w0, int angle, int c, int maxv, int lane, int log2,
-                                              const uint32_t* ctl, const int16_t* res, char* tile_b, int tb,
-                                              const uint32_t* s_ex, int k, RunShared& S)
+// workgroup barrier that orders LDS traffic only (no vmcnt wait: the chain has no global traffic in flight to order)
+#ifndef RUN_READS_FIRST
+#define RUN_READS_FIRST 0   // (1: the two chain reads ahead of the read-ahead: measured 1.2 % slower)
+#endif
+#define RUN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// A 16x16 / 32x32 TU is reconstructed by ALL wavefronts of the workgroup together (measured: done by one wavefront,
+// these ~10 % of the TUs took half of an all-intra picture's chain): nS / (64 nw) samples per lane, workgroup barriers
+// between the phases.  Same prepared operands as the small TUs; a smoothed TU goes through a border array in LDS
+// ([1 2 1] or the 32x32 bilinear filter, intrapred.cc:816-889, straight from the window -> operands by index), the
+// others read their operands from the window.  Every wavefront calls this with the same (uniform) arguments.
+// All LDS reads of a phase are issued before the first is used: the chain pays one LDS latency per phase.
+// (A/B on an all-intra 4K picture: 16x16 and 32x32 together 2.07 ms, only 32x32 together 2.18 ms, none 2.38 ms.)
+template <int RUN_TILE_P, int CH>
+__device__ __forceinline__ void run_big_predict(uint32_t w0, int angle, int c, int maxv, int tid, int nthr, int log2,
+                                                const uint32_t* ctl, const int16_t* res, char* tile_b, int tb,
+                                                const uint16_t* bord, int tr, int bl, int b0, int dc)
 {
-  const int nT = 1 << log2, nS = nT * nT, NB = 4 * nT + 1, C = 2 * nT;
+  const int nT = 1 << log2, nS = nT * nT;
   const int kind = (w0 >> 24) & 3;
   const bool vert = w0 & RTU_VERT;
   const bool smooth = w0 & RTU_SMOOTH;
-  const uint16_t* bord = S.b1;
-  if (smooth) {
-    for (int p = lane; p < NB; p += 64) S.b0[p] = *reinterpret_cast<uint16_t*>(tile_b + (ctl[p] >> 16));
-    LDS_SYNC();
-    bool biInt = false;
-    if (P.strong_intra && nT == 32) {
-      const int th = 1 << (P.bd_luma - 5);
-      biInt = abs((int)S.b0[C] + S.b0[4 * nT] - 2 * S.b0[3 * nT]) < th && abs((int)S.b0[C] + S.b0[0] - 2 * S.b0[nT]) < th;
+  const bool dc_edge = c == 0 && nT < 32;
+  for (int base = tid; base < nS; base += CH * nthr) {
+    uint32_t cw[CH]; int rs[CH], A[CH], B[CH];
+#pragma unroll
+    for (int u = 0; u < CH; u++) { cw[u] = ctl[base + u * nthr]; rs[u] = res[base + u * nthr]; }
+#pragma unroll
+    for (int u = 0; u < CH; u++) {
+      if (smooth) { A[u] = bord[cw[u] & 0xFF]; B[u] = bord[(cw[u] >> 8) & 0xFF]; }
+      else { A[u] = *reinterpret_cast<uint16_t*>(tile_b + (cw[u] & 0xFFFF)); B[u] = *reinterpret_cast<uint16_t*>(tile_b + (cw[u] >> 16)); }
     }
-    for (int p = lane; p < NB; p += 64) {
-      int v;
-      if (p == 0 || p == NB - 1) v = S.b0[p];
-      else if (biInt) v = (p == C) ? S.b0[C] : (p < C ? S.b0[C] + (((C - p) * (S.b0[0] - S.b0[C]) + 32) >> 6)
-                                                       : S.b0[C] + (((p - C) * (S.b0[4 * nT] - S.b0[C]) + 32) >> 6));
-      else v = (S.b0[p + 1] + 2 * S.b0[p] + S.b0[p - 1] + 2) >> 2;
+#pragma unroll
+    for (int u = 0; u < CH; u++) {
+      const int s = base + u * nthr;
+      const int x = s & (nT - 1), y = s >> log2;
+      int pv;
+      if (kind == 2) {
+        const int f = __mul24(vert ? y + 1 : x + 1, angle) & 31;
+        pv = (__mul24(f, B[u] - A[u]) + (A[u] << 5) + 16) >> 5;
+      } else if (kind == 3) {
+        const int e = clip3(0, maxv, A[u] + ((B[u] - b0) >> 1));
+        pv = ((vert ? x : y) == 0) ? e : A[u];
+      } else if (kind == 0) {
+        pv = ((nT - 1 - x) * A[u] + (x + 1) * tr + (nT - 1 - y) * B[u] + (y + 1) * bl + nT) >> (log2 + 1);
+      } else {
+        pv = dc;
+        if (dc_edge) pv = (x | y) == 0 ? (A[u] + 2 * dc + B[u] + 2) >> 2
+                                       : (y == 0 ? (B[u] + 3 * dc + 2) >> 2 : (x == 0 ? (A[u] + 3 * dc + 2) >> 2 : dc));
+      }
+      *reinterpret_cast<uint16_t*>(tile_b + tb + (y * RUN_TILE_P + x) * 2) = (uint16_t)clip3(0, maxv, pv + rs[u]);
+    }
+  }
+}
+
+template <int RUN_TILE_P>
+__device__ __forceinline__ void run_chain_big(const PicDev& P, uint32_t w0, int angle, int c, int maxv, int tid, int nthr, int log2,
+                                              const uint32_t* ctl, const int16_t* res, char* tile_b, int tb,
+                                              const uint32_t* s_ex, int k, RunShared& S, int* s_dc)
+{
+  const int nT = 1 << log2, nS = nT * nT, NB = 4 * nT + 1, C = 2 * nT;
+  const int kind = (w0 >> 24) & 3;
+  const bool smooth = w0 & RTU_SMOOTH;
+  const uint16_t* bord = S.b1;
+  auto win = [&](uint32_t word) { return (int)*reinterpret_cast<uint16_t*>(tile_b + (word >> 16)); };   // border sample p <- ctl[p]
+  if (smooth) {
+    const bool strong = P.strong_intra && nT == 32;
+    for (int p = tid; p < NB; p += nthr) {
+      const uint32_t am = ctl[p ? p - 1 : 0], ac = ctl[p], ap = ctl[p < NB - 1 ? p + 1 : p];
+      uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+      if (strong) { a0 = ctl[0]; a1 = ctl[nT]; a2 = ctl[C]; a3 = ctl[3 * nT]; a4 = ctl[4 * nT]; }
+      const int vm = win(am), vc = win(ac), vp = win(ap);
+      int v = (p == 0 || p == NB - 1) ? vc : (vp + 2 * vc + vm + 2) >> 2;
+      if (strong) {
+        const int e0 = win(a0), e1 = win(a1), e2 = win(a2), e3 = win(a3), e4 = win(a4);
+        const int th = 1 << (P.bd_luma - 5);
+        if (abs(e2 + e4 - 2 * e3) < th && abs(e2 + e0 - 2 * e1) < th && p != 0 && p != NB - 1)
+          v = p < C ? e2 + (((C - p) * (e0 - e2) + 32) >> 6) : e2 + (((p - C) * (e4 - e2) + 32) >> 6);
+      }
       S.b1[p] = (uint16_t)v;
     }
-    LDS_SYNC();
+    RUN_LDS_BARRIER();
   }
   int tr = 0, bl = 0, b0 = 0, dc = 0;
   if (kind == 0) {
@@ -893,42 +946,24 @@ __device__ __forceinline__ void run_chain_big(const PicDev& P, uint32_t w0, int 
     else { const uint32_t e = s_ex[k]; tr = *reinterpret_cast<uint16_t*>(tile_b + (e & 0xFFFF)); bl = *reinterpret_cast<uint16_t*>(tile_b + (e >> 16)); }
   } else if (kind == 3) {
     b0 = *reinterpret_cast<uint16_t*>(tile_b + (s_ex[k] & 0xFFFF));
-  } else if (kind == 1) {                               // DC (never smoothed): column 0 holds left[y] in A, row 0 top[x] in B
-    int v = 0;
-    for (int s = lane; s < nS; s += 64) {
-      const int x = s & (nT - 1), y = s >> log2;
-      const uint32_t cw = ctl[s];
-      if (x == 0) v += *reinterpret_cast<uint16_t*>(tile_b + (cw & 0xFFFF));
-      if (y == 0) v += *reinterpret_cast<uint16_t*>(tile_b + (cw >> 16));
+  } else if (kind == 1) {
+    // DC (never smoothed): left[y] is the A operand of sample (0, y), top[x] the B operand of sample (x, 0); the first
+    // wavefront sums the 2 nT <= 64 of them (one per lane) and shares the mean
+    if (tid < 64) {
+      int v = 0;
+      if (tid < nT) v = *reinterpret_cast<uint16_t*>(tile_b + (ctl[tid << log2] & 0xFFFF));
+      else if (tid < 2 * nT) v = *reinterpret_cast<uint16_t*>(tile_b + (ctl[tid - nT] >> 16));
+      const int d = (wave_sum_dpp(v) + nT) >> (log2 + 1);
+      if (tid == 0) *s_dc = d;
     }
-    dc = (wave_sum_dpp(v) + nT) >> (log2 + 1);
+    RUN_LDS_BARRIER();
+    dc = *s_dc;
   }
-  const bool dc_edge = c == 0 && nT < 32;
-#pragma unroll 4
-  for (int s = lane; s < nS; s += 64) {
-    const int x = s & (nT - 1), y = s >> log2;
-    const uint32_t cw = ctl[s];
-    const int rs = res[s];
-    int A, B;
-    if (smooth) { A = bord[cw & 0xFF]; B = bord[(cw >> 8) & 0xFF]; }
-    else { A = *reinterpret_cast<uint16_t*>(tile_b + (cw & 0xFFFF)); B = *reinterpret_cast<uint16_t*>(tile_b + (cw >> 16)); }
-    int pv;
-    if (kind == 2) {
-      const int f = __mul24(vert ? y + 1 : x + 1, angle) & 31;
-      pv = (__mul24(A, 32 - f) + __mul24(B, f) + 16) >> 5;
-    } else if (kind == 3) {
-      const int e = clip3(0, maxv, A + ((B - b0) >> 1));
-      pv = ((vert ? x : y) == 0) ? e : A;
-    } else if (kind == 0) {
-      pv = ((nT - 1 - x) * A + (x + 1) * tr + (nT - 1 - y) * B + (y + 1) * bl + nT) >> (log2 + 1);
-    } else {
-      pv = dc;
-      if (dc_edge) pv = (x | y) == 0 ? (A + 2 * dc + B + 2) >> 2
-                                     : (y == 0 ? (B + 3 * dc + 2) >> 2 : (x == 0 ? (A + 3 * dc + 2) >> 2 : dc));
-    }
-    *reinterpret_cast<uint16_t*>(tile_b + tb + (y * RUN_TILE_P + x) * 2) = (uint16_t)clip3(0, maxv, pv + rs);
-  }
-  LDS_SYNC();
+  const int per = nS / nthr;                            // (uniform; a power of two >= 1)
+  if (per >= 4) run_big_predict<RUN_TILE_P, 4>(w0, angle, c, maxv, tid, nthr, log2, ctl, res, tile_b, tb, bord, tr, bl, b0, dc);
+  else if (per == 2) run_big_predict<RUN_TILE_P, 2>(w0, angle, c, maxv, tid, nthr, log2, ctl, res, tile_b, tb, bord, tr, bl, b0, dc);
+  else run_big_predict<RUN_TILE_P, 1>(w0, angle, c, maxv, tid, nthr, log2, ctl, res, tile_b, tb, bord, tr, bl, b0, dc);
+  RUN_LDS_BARRIER();                                    // (also: the border array and s_dc are free again)
 }
 
 // ---- micro runs: <= 16 TUs of <= 8x8 inside a 32x32 box (most runs of a picture with inter PUs) ----
@@ -1125,7 +1160,6 @@ __device__ __forceinline__ void micro_run(const PicDev& P, const PlaneRef& pl0, 
   if (lane == 0) __hip_atomic_store(&sync[2 + r], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-#define RUN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // Ticket draw on the scalar unit (s_atomic_add ... glc returns the old value through lgkmcnt): unlike a vector
 // atomic it does not queue behind the wavefront's outstanding write-through stores (vmcnt).
@@ -1147,7 +1181,8 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   constexpr int RUN_TILE_H = RUN_TILE_H_OF(BOX), RUN_TILE_P = RUN_TILE_P_OF(BOX);
   constexpr int MAX_TUS = BOX * BOX / 16;
   constexpr int CONST_ADDR = RUN_TILE_H * RUN_TILE_P * 2;               // the "nothing available" cell behind the window
-  __shared__ RunShared S[RUN_WAVES];
+  __shared__ RunShared S;                         // border arrays of the 16x16 / 32x32 TU being reconstructed
+  __shared__ int s_dc;
   __shared__ __attribute__((aligned(16))) uint16_t tile[RUN_TILE_H * RUN_TILE_P + 8];
   __shared__ __attribute__((aligned(16))) int16_t s_res[BOX * BOX + 64];
   __shared__ uint32_t s_ctl[BOX * BOX + 64];      // per sample: operand addresses / border lanes (run_prepare_sample)
@@ -1176,6 +1211,9 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   uint32_t prev = RUN_NO_TICKET;                                       // finished run whose flag is not raised yet
   uint32_t next_ticket = 0, batch_end = 0;
   st.t0 = clock64();
+  // (Experiment: only the workgroups of one XCD (s_getreg HW_REG_XCC_ID) take part and store without write-through, so
+  //  that every hand-over stays inside one L2: bit-exact, but an all-intra 4K picture is not faster (2.16 vs 2.13 ms) -
+  //  the hand-over between runs is not bound by the trip through the memory side.)
   for (;;) {
   // publish the previous run: its payload was stored write-through (sc1); drained in every wavefront, then the flag.
   // (MI355X_MICROARCH.md, valid forms: sc1 payload stores + vmcnt(0) + flag on the producer,
@@ -1333,42 +1371,75 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   // wavefront lie a barrier epoch earlier: before a TU of epoch e its wavefront has passed e workgroup barriers.
   // Records are read two TUs ahead and per-lane operands one TU ahead (none of this is waited for on the chain).
   if (!(RUN_DBG & 4)) {
-    const uint16_t* we = runs[ticket].wave_end;                          // (indexed in memory: no register array)
-    const int j0 = wave == 0 ? 0 : (int)we[wave - 1], j1 = (int)we[wave];
+    // this wavefront's list [j0, j1) of the run's TU array, from the four list ends (scalar shifts: no register array)
+    const uint64_t we = (uint64_t)run.wave_end[0] | ((uint64_t)run.wave_end[1] << 16) | ((uint64_t)run.wave_end[2] << 32) |
+                        ((uint64_t)run.wave_end[3] << 48);
+    const int j1 = (int)((we >> (16 * wave)) & 0xFFFF), j0 = wave ? (int)((we >> (16 * wave - 16)) & 0xFFFF) : 0;
     const int n_epochs = run.n_lvls;
-    int epoch = 0;
-    if (j0 < j1) {
-      __builtin_amdgcn_s_setprio(3);                                     // the chain is latency-bound: issue it first
-      const char* task_b = reinterpret_cast<const char*>(s_task);
-      const char* res_b = reinterpret_cast<const char*>(s_res); const char* ctl_b = reinterpret_cast<const char*>(s_ctl);
-      const uint2 r0 = *reinterpret_cast<const uint2*>(task_b + 16 * j0);
-      uint32_t w0 = __builtin_amdgcn_readfirstlane(r0.x), w1 = __builtin_amdgcn_readfirstlane(r0.y);
-      uint2 r_nxt = *reinterpret_cast<const uint2*>(task_b + 16 * min(j0 + 1, j1 - 1));
-      int sl = lane & ((w0 & RTU_IS4) ? 15 : 63);
-      uint32_t ctl = *reinterpret_cast<const uint32_t*>(ctl_b + (w1 & 0x3FFF) + 4 * sl);
-      int rs = *reinterpret_cast<const int16_t*>(res_b + ((w1 & 0x3FFF) >> 1) + 2 * sl);
-      // The loop is written as a tight inner loop over the common TU kind (angular, not smoothed, 4x4 / 8x8: spelled out
-      // with as few instructions as possible, the chain costs about a dozen cycles per instruction) that drops out to the
-      // general code for one TU of any other kind: the compiler then lays the common path out contiguously.
+    // the 16x16 / 32x32 TUs of the run form a fifth list (level order) that every wavefront walks in lockstep: after the
+    // barrier that opens level l, the workgroup reconstructs the level's big TUs together, then every wavefront its own
+    // small ones.  (The level of the list's head is kept in a scalar register: the test costs no LDS read.)
+    int jc = (int)run.wave_end[3];
+    const int jc1 = n_tus;
+    uint4 rc = s_task[jc < jc1 ? jc : 0];
+    int c_lvl = jc < jc1 ? (int)((__builtin_amdgcn_readfirstlane(rc.x) >> 16) & 0xFF) : -1;
+    __builtin_amdgcn_s_setprio(3);                                       // the chain is latency-bound: issue it first
+    const char* task_b = reinterpret_cast<const char*>(s_task);
+    const char* res_b = reinterpret_cast<const char*>(s_res); const char* ctl_b = reinterpret_cast<const char*>(s_ctl);
+    // The record of the wavefront's next TU (~0 behind the last: level 255 never comes), of the one after it, and the
+    // per-lane operands of the next one are read ahead (none of this is waited for on the chain).
+    const int jl = max(j1 - 1, 0);
+    const uint2 r0 = *reinterpret_cast<const uint2*>(task_b + 16 * min(j0, jl));
+    uint32_t w0 = j0 < j1 ? __builtin_amdgcn_readfirstlane(r0.x) : ~0u, w1 = __builtin_amdgcn_readfirstlane(r0.y);
+    uint2 r_nxt = *reinterpret_cast<const uint2*>(task_b + 16 * min(j0 + 1, jl));
+    int sl = lane & ((w0 & RTU_IS4) ? 15 : 63);
+    uint32_t ctl = *reinterpret_cast<const uint32_t*>(ctl_b + (w1 & 0x3FFF) + 4 * sl);
+    int rs = *reinterpret_cast<const int16_t*>(res_b + ((w1 & 0x3FFF) >> 1) + 2 * sl);
+    int j = j0;
 #define RUN_CHAIN_HEAD()                                                                                                   \
-      { const int ep = (w0 >> 16) & 0xFF;                                                                                 \
-        while (epoch < ep) { RUN_LDS_BARRIER(); epoch++; } }                                                              \
       /* off the chain: next TU's record -> its per-lane operands; the record after next */                               \
-      const uint32_t n0 = __builtin_amdgcn_readfirstlane(r_nxt.x), n1 = __builtin_amdgcn_readfirstlane(r_nxt.y);          \
+      const uint32_t n0 = j + 1 < j1 ? __builtin_amdgcn_readfirstlane(r_nxt.x) : ~0u, n1 = __builtin_amdgcn_readfirstlane(r_nxt.y); \
       const int nsl = lane & ((n0 & RTU_IS4) ? 15 : 63);                                                                   \
       const uint32_t nctl = *reinterpret_cast<const uint32_t*>(ctl_b + (n1 & 0x3FFF) + 4 * nsl);                           \
       const int nrs = *reinterpret_cast<const int16_t*>(res_b + ((n1 & 0x3FFF) >> 1) + 2 * nsl);                          \
-      r_nxt = *reinterpret_cast<const uint2*>(task_b + 16 * min(j + 2, j1 - 1));                                           \
+      r_nxt = *reinterpret_cast<const uint2*>(task_b + 16 * min(j + 2, jl));                                               \
       const int tb = w0 & 0x7FFF;                                                                                          \
       const int angle = (int)(int8_t)(w1 >> 24);
 #define RUN_CHAIN_NEXT() w0 = n0; w1 = n1; ctl = nctl; rs = nrs; j++;
-#define RUN_IS_FAST(w) (((w) & (RTU_BIG | RTU_SMOOTH | (3u << 24))) == (2u << 24))
-      int j = j0;
-      while (j < j1) {
-        while (j < j1 && RUN_IS_FAST(w0)) {
+    // One pass per level: the big TUs together, then the own list's TUs of the level, then the barrier that closes it.
+    // The own TUs are walked in a tight inner loop over the common kind (angular, not smoothed, 4x4 / 8x8: spelled out
+    // with as few instructions as possible, the chain costs about a dozen cycles per instruction) that drops out to the
+    // general code for one TU of any other kind: the compiler then lays the common path out contiguously.
+    for (int epoch = 0;; epoch++) {
+      while (c_lvl == epoch) {
+        const uint32_t c0 = __builtin_amdgcn_readfirstlane(rc.x), c1 = __builtin_amdgcn_readfirstlane(rc.y);
+        const int log2 = __builtin_amdgcn_readfirstlane((int)((rc.w >> 27) & 7));
+        const int k = jc++;
+        rc = s_task[jc < jc1 ? jc : 0];                                  // the next head, read under this TU's work
+        const int samp = (c1 & 0x3FFF) >> 2;
+        run_chain_big<RUN_TILE_P>(P, c0, (int)(int8_t)(c1 >> 24), c, maxv, tid, nthr, log2, s_ctl + samp, s_res + samp, tile_b,
+                                  (int)(c0 & 0x7FFF), s_ex, k, S, &s_dc);
+        if (RUN_DBG & 256)                                               // (timing-only ablation: the TU twice)
+          run_chain_big<RUN_TILE_P>(P, c0, (int)(int8_t)(c1 >> 24), c, maxv, tid, nthr, log2, s_ctl + samp, s_res + samp, tile_b,
+                                    (int)(c0 & 0x7FFF), s_ex, k, S, &s_dc);
+        c_lvl = jc < jc1 ? (int)((__builtin_amdgcn_readfirstlane(rc.x) >> 16) & 0xFF) : -1;
+      }
+      // (level and kind of a record in one compare)
+      const uint32_t lvl_key = (uint32_t)epoch << 16, fast_key = lvl_key | (2u << 24);
+      const uint32_t lvl_mask = 0xFFu << 16, fast_mask = lvl_mask | RTU_BIG | RTU_SMOOTH | (3u << 24);
+      while ((w0 & lvl_mask) == lvl_key) {
+        while ((w0 & fast_mask) == fast_key) {
+          // (the two reads the chain waits for go out first, the read-ahead behind them)
+#if RUN_READS_FIRST
+          const int A = *reinterpret_cast<uint16_t*>(tile_b + (ctl & 0xFFFF));
+          const int B = *reinterpret_cast<uint16_t*>(tile_b + (ctl >> 16));
+          RUN_CHAIN_HEAD()
+          __builtin_amdgcn_sched_barrier(0);           // (keep the read-ahead in front of the arithmetic that waits for A and B)
+#else
           RUN_CHAIN_HEAD()
           const int A = *reinterpret_cast<uint16_t*>(tile_b + (ctl & 0xFFFF));
           const int B = *reinterpret_cast<uint16_t*>(tile_b + (ctl >> 16));
+#endif
           // per-lane constants of both TU sizes live in one register each: byte 0/1 = x+1 / y+1 of the 4x4 position,
           // byte 2/3 the same for 8x8; the window offsets of the two sizes in the halves of lane_toff
           const int a1 = (lane_xy1 >> (((w0 & RTU_IS4) ? 0 : 16) + ((w0 & RTU_VERT) ? 8 : 0))) & 0xFF;
@@ -1379,24 +1450,28 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
           WAVE_BARRIER_ONLY();
           RUN_CHAIN_NEXT()
         }
-        if (j >= j1) break;
+        if ((w0 & lvl_mask) != lvl_key) break;
+#if RUN_READS_FIRST
+        const int B0 = *reinterpret_cast<uint16_t*>(tile_b + (ctl >> 16));
+        const int A0 = (w0 & RTU_SMOOTH) ? 0 : (int)*reinterpret_cast<uint16_t*>(tile_b + (ctl & 0xFFFF));   // (smoothed: indices, not an address)
         RUN_CHAIN_HEAD()
-        if (!(w0 & RTU_BIG)) {
-          if (w0 & RTU_IS4) run_chain_small<2>(w0, angle, c, maxv, lane, L4, ctl, rs, tile_b, tb, s_ex, j);
-          else run_chain_small<3>(w0, angle, c, maxv, lane, L8, ctl, rs, tile_b, tb, s_ex, j);
-        } else {
-          const int samp = (w1 & 0x3FFF) >> 2;
-          const int log2 = __builtin_amdgcn_readfirstlane((int)((s_task[j].w >> 27) & 7));
-          run_chain_big<RUN_TILE_P>(P, w0, angle, c, maxv, lane, log2, s_ctl + samp, s_res + samp, tile_b, tb, s_ex, j, S[wave]);
-        }
+        __builtin_amdgcn_sched_barrier(0);
+#else
+        RUN_CHAIN_HEAD()
+        const int B0 = *reinterpret_cast<uint16_t*>(tile_b + (ctl >> 16));
+        const int A0 = (w0 & RTU_SMOOTH) ? 0 : (int)*reinterpret_cast<uint16_t*>(tile_b + (ctl & 0xFFFF));   // (smoothed: indices, not an address)
+#endif
+        if (w0 & RTU_IS4) run_chain_small<2>(w0, angle, c, maxv, lane, L4, ctl, rs, tile_b, tb, s_ex, j, A0, B0);
+        else run_chain_small<3>(w0, angle, c, maxv, lane, L8, ctl, rs, tile_b, tb, s_ex, j, A0, B0);
         RUN_CHAIN_NEXT()
       }
+      if (epoch >= n_epochs) break;
+      RUN_LDS_BARRIER();
+      if (RUN_DBG & 128) RUN_LDS_BARRIER();
+    }
 #undef RUN_CHAIN_HEAD
 #undef RUN_CHAIN_NEXT
-#undef RUN_IS_FAST
-      __builtin_amdgcn_s_setprio(0);
-    }
-    while (epoch < n_epochs) { RUN_LDS_BARRIER(); epoch++; }
+    __builtin_amdgcn_s_setprio(0);
   }
   // ---- write the run's samples to the picture: whole 8-sample chunks where both halves are the run's (one
   // 16-byte write-through store), half chunks otherwise; nothing outside the run's own TUs is ever written.

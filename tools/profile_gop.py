@@ -19,6 +19,7 @@ ap.add_argument("--height", type=int, default=2160)
 ap.add_argument("--bit-depth", type=int, default=10)
 ap.add_argument("--only", type=int, default=-1, help="time only this picture of the GOP")
 ap.add_argument("--over", default="", help="synth overrides, e.g. cbf_pct=0,split_bias=100")
+ap.add_argument("--md5", action="store_true", help="print the md5 of every decoded picture (to compare library variants)")
 a = ap.parse_args()
 W, H, BD = a.width, a.height, a.bit_depth
 dec = backend.Decoder()
@@ -46,3 +47,9 @@ for k, (sp, p) in enumerate(pics):
     print("pic %d type %s tus %d mc %d levels %d runs %d runlevels %d inrunlevels %d | " % (
         k, "I" if k == 0 else "B", s.n_tu_tasks, s.n_mc_tasks, s.n_levels, s.n_runs, s.n_run_levels, s.n_in_run_levels) +
           " ".join("%s=%.1fus" % (n, 1e3 * v[0] / a.reps) for n, v in kt.items() if v[1]))
+    if a.md5:
+        import hashlib
+        h = hashlib.md5()
+        for pl in dec.download(k, W, H, BD):
+            h.update(pl.tobytes())
+        print("pic %d md5 %s" % (k, h.hexdigest()))
