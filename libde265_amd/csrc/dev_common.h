@@ -54,7 +54,7 @@ static_assert(sizeof(TuTask) == 32, "TuTask layout");
 #define D265_TU_RESID_ONLY 0x80
 
 // MC task: a <=16x16 luma tile of one PU (plus its two 4:2:0 chroma tiles).
-struct McTask {
+struct __attribute__((aligned(4))) McTask {   // (4-byte aligned: the kernel fetches its task with scalar loads)
   uint16_t x, y;          // luma position of the tile
   uint8_t  w, h;          // luma size (multiples of 4, <=16)
   int8_t   slot[2];       // DPB slot per list, -1 = list unused

@@ -337,18 +337,23 @@ void k_sao(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, PlaneRe
   const bool inpic = x0 >= 0 && x0 < width;
   const int ctbshift = P.log2_ctb - cs;
   const int ctbX = max(x0, 0) >> ctbshift, ctbY = y0 >> ctbshift;
-  // the CTB record is requested together with the pixels (one latency, not two)
-  const SaoCtb sc = M.sao[min(ctbX, P.ctbs_w - 1) + ctbY * P.ctbs_w];
+  // the CTB record is requested together with the pixels (one latency, not two), as three 8-byte words: its byte
+  // fields are picked out with shifts below (indexing the struct by component sent it through LDS)
+  uint32_t w[6];
+  {
+    const uint2* q = reinterpret_cast<const uint2*>(&M.sao[min(ctbX, P.ctbs_w - 1) + ctbY * P.ctbs_w]);
+    const uint2 q0 = q[0], q1 = q[1], q2 = q[2];
+    w[0] = q0.x; w[1] = q0.y; w[2] = q1.x; w[3] = q1.y; w[4] = q2.x; w[5] = q2.y;
+  }
 
+  // Every load is unconditional (the address is clamped into the picture instead): loads under a condition are
+  // compiled into one branch + wait each, i.e. one memory latency per row.  What a clamped load returns for a row or
+  // strip outside the picture is never used: such neighbours are masked out below (okmask), such strips return.
   int v[SAO_ROWS + 2][8];
+  {
+    const PX* col = src + min(max(x0, 0), (width - 1) & ~7);         // (the last strip may be partial: rows are padded)
 #pragma unroll
-  for (int j = 0; j < SAO_ROWS + 2; j++) {
-    const int y = y0 - 1 + j;
-    if (inpic && y >= 0 && y < height) load8i<PX>(src + x0 + y * sstride, v[j]);
-    else {
-#pragma unroll
-      for (int i = 0; i < 8; i++) v[j][i] = 0;
-    }
+    for (int j = 0; j < SAO_ROWS + 2; j++) load8i<PX>(col + min(max(y0 - 1 + j, 0), height - 1) * sstride, v[j]);
   }
   int nl[SAO_ROWS + 2], nr[SAO_ROWS + 2];                     // left / right neighbour of the strip, per row
 #pragma unroll
@@ -366,7 +371,20 @@ void k_sao(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, PlaneRe
 
   const int bd = comp ? P.bd_chroma : P.bd_luma;
   const int maxv = (1 << bd) - 1;
-  int type = sc.type[comp];
+#define SAO_BYTE(k) ((w[(k) >> 2] >> (((k) & 3) * 8)) & 0xFFu)        // byte k of the SaoCtb record (dev_common.h)
+  int type, eo, band_pos, o4[4];
+  if (comp == 0) {
+    type = SAO_BYTE(0); eo = SAO_BYTE(3); band_pos = SAO_BYTE(6);
+    o4[0] = (int8_t)SAO_BYTE(9); o4[1] = (int8_t)SAO_BYTE(10); o4[2] = (int8_t)SAO_BYTE(11); o4[3] = (int8_t)SAO_BYTE(12);
+  } else if (comp == 1) {
+    type = SAO_BYTE(1); eo = SAO_BYTE(4); band_pos = SAO_BYTE(7);
+    o4[0] = (int8_t)SAO_BYTE(13); o4[1] = (int8_t)SAO_BYTE(14); o4[2] = (int8_t)SAO_BYTE(15); o4[3] = (int8_t)SAO_BYTE(16);
+  } else {
+    type = SAO_BYTE(2); eo = SAO_BYTE(5); band_pos = SAO_BYTE(8);
+    o4[0] = (int8_t)SAO_BYTE(17); o4[1] = (int8_t)SAO_BYTE(18); o4[2] = (int8_t)SAO_BYTE(19); o4[3] = (int8_t)SAO_BYTE(20);
+  }
+#undef SAO_BYTE
+  const unsigned perm = w[5] >> 16;
   const int nrows = min(SAO_ROWS, height - y0);
 
   if (type == 0) {                                            // plain copy of the deblocked samples
@@ -376,9 +394,6 @@ void k_sao(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, PlaneRe
     return;
   }
 
-  int o4[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++) o4[k] = sc.off[comp][k];
   if (P.dbg & 64) type = 1;                                   // ablation: band offset everywhere
 
   // pcm / transquant-bypass exemptions of the 4x4 units under the strip (only when the picture has any)
@@ -394,7 +409,7 @@ void k_sao(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, PlaneRe
   }
 
   if (type == 1) {                                            // band offset (sao.cc:182-251)
-    const int bandShift = bd - 5, left = sc.band[comp];
+    const int bandShift = bd - 5, left = band_pos;
 #pragma unroll
     for (int r = 0; r < SAO_ROWS; r++) {
       if (r >= nrows) break;
@@ -413,11 +428,9 @@ void k_sao(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, PlaneRe
   }
 
   // ---- edge offset (sao.cc:75-178)
-  const int eo = sc.eo[comp];
   const int hx = (eo == 1) ? 0 : (eo == 3 ? 1 : -1), hy = (eo == 0) ? 0 : -1;   // first neighbour; second is the mirror
   // permissions of the 3x3 CTB neighbourhood, resolved on the host: bit (dy+1)*3+(dx+1)
   const int mask = (1 << ctbshift) - 1;
-  const unsigned perm = sc.perm;
 
   // offsets {o1,o2,0,o3,o4} indexed by edgeIdx+2 (sao.cc:95-100): four of them packed into one register
   const unsigned otab = (unsigned)(uint8_t)o4[0] | ((unsigned)(uint8_t)o4[1] << 8) | ((unsigned)(uint8_t)o4[2] << 24);

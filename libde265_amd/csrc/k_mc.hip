@@ -164,7 +164,14 @@ void k_mc(PicDev P, DpbTable dpb, PlaneRef d0, PlaneRef d1, PlaneRef d2,
   const int per = (n_tasks + 7) >> 3;
   const int tix = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   if (tix >= n_tasks) return;
-  const McTask t = tasks[tix];
+  McTask t;                                         // (five dwords at a uniform address: scalar loads)
+  {
+    const uint32_t* tq = reinterpret_cast<const uint32_t*>(tasks + tix);
+    uint32_t tw[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) tw[i] = __builtin_amdgcn_readfirstlane(tq[i]);
+    __builtin_memcpy(&t, tw, sizeof(t));
+  }
   const de265hip_slice_params* sh = &slices[t.slice_idx];
   const bool use0 = t.slot[0] >= 0, use1 = t.slot[1] >= 0;
   const bool bi = use0 && use1;
@@ -177,8 +184,13 @@ void k_mc(PicDev P, DpbTable dpb, PlaneRef d0, PlaneRef d1, PlaneRef d2,
   else if (bi) mode = P.weighted_bipred ? 3 : 2;
   else mode = P.weighted_bipred ? 1 : 0;
 
-  // ---------------- fetch (all lists and planes, then one wait)
+  // ---------------- fetch.  First every aligned vector load of both lists and all three planes is issued into
+  // registers, unconditionally (row / chunk clamped into the block: a load under a per-lane condition is compiled into
+  // its own branch + wait, i.e. one memory latency each - measured: the picture's MC pass 62 -> XX us); then they are
+  // stored to LDS.  Blocks that touch the picture border (few) are fetched sample by sample with clamped coordinates.
   int oxL[2] = { 0, 0 }, oxC[2] = { 0, 0 };
+  bool insL[2] = { false, false }, insC[2] = { false, false };
+  uint2 rl[2][3], rc[2][2];
 #pragma unroll
   for (int l = 0; l < 2; l++) {
     if (t.slot[l] < 0) continue;
@@ -188,17 +200,49 @@ void k_mc(PicDev P, DpbTable dpb, PlaneRef d0, PlaneRef d1, PlaneRef d2,
       const PX* ref = (const PX*)r.ptr;
       const int xs = t.x + (mvx >> 2) - 3, ys = t.y + (mvy >> 2) - 3;
       const int nrow = h + 7, ncol = w + 7;
-      const bool inside = xs >= 0 && ys >= 0 && xs + ncol <= P.width && ys + nrow <= P.height;
-      if (inside) {
+      insL[l] = xs >= 0 && ys >= 0 && xs + ncol <= P.width && ys + nrow <= P.height;
+      if (insL[l]) {
         const int ax = xs & ~3;
         oxL[l] = xs & 3;
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-          int slot = lane + 64 * i, rr = slot >> 3, ch = slot & 7;
-          if (rr < nrow && ch < 7)
-            *reinterpret_cast<uint2*>(&s_inL[l][rr * MCL_P + 4 * ch]) = ld4_u16<PX>(ref + ax + 4 * ch + (ys + rr) * r.stride);
+          const int slot = lane + 64 * i, rr = min(slot >> 3, nrow - 1), ch = min(slot & 7, 6);
+          rl[l][i] = ld4_u16<PX>(ref + ax + 4 * ch + (ys + rr) * r.stride);
+        }
+      }
+    }
+    {   // chroma: rows yI-1 .. yI+hc+1, columns xI-1 .. xI+wc+1
+      const int xs = (t.x >> 1) + (mvx >> 3) - 1, ys = (t.y >> 1) + (mvy >> 3) - 1;
+      const int nrow = hc + 3, ncol = wc + 3;
+      insC[l] = xs >= 0 && ys >= 0 && xs + ncol <= cW && ys + nrow <= cH;
+      if (insC[l]) {
+        const int ax = xs & ~3;
+        oxC[l] = xs & 3;
+        const int rr = min(lane >> 2, nrow - 1), ch = lane & 3;
+#pragma unroll
+        for (int cp = 0; cp < 2; cp++) {
+          const PlaneRef r = dpb.p[t.slot[l]][cp + 1];
+          rc[l][cp] = ld4_u16<PX>((const PX*)r.ptr + ax + 4 * ch + (ys + rr) * r.stride);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < 2; l++) {
+    if (t.slot[l] < 0) continue;
+    const int mvx = t.mv[l][0], mvy = t.mv[l][1];
+    {
+      const int nrow = h + 7, ncol = w + 7;
+      if (insL[l]) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          const int slot = lane + 64 * i, rr = slot >> 3, ch = slot & 7;
+          if (rr < nrow && ch < 7) *reinterpret_cast<uint2*>(&s_inL[l][rr * MCL_P + 4 * ch]) = rl[l][i];
         }
       } else {
+        const PlaneRef r = dpb.p[t.slot[l]][0];
+        const PX* ref = (const PX*)r.ptr;
+        const int xs = t.x + (mvx >> 2) - 3, ys = t.y + (mvy >> 2) - 3;
         for (int idx = lane; idx < nrow * 32; idx += 64) {
           int rr = idx >> 5, c = idx & 31;   // 32 > w + 7
           if (c < ncol) {
@@ -209,20 +253,15 @@ void k_mc(PicDev P, DpbTable dpb, PlaneRef d0, PlaneRef d1, PlaneRef d2,
       }
     }
 #pragma unroll
-    for (int cp = 0; cp < 2; cp++) {   // chroma: rows yI-1 .. yI+hc+1, columns xI-1 .. xI+wc+1
-      const PlaneRef r = dpb.p[t.slot[l]][cp + 1];
-      const PX* ref = (const PX*)r.ptr;
-      const int xs = (t.x >> 1) + (mvx >> 3) - 1, ys = (t.y >> 1) + (mvy >> 3) - 1;
+    for (int cp = 0; cp < 2; cp++) {
       const int nrow = hc + 3, ncol = wc + 3;
-      const bool inside = xs >= 0 && ys >= 0 && xs + ncol <= cW && ys + nrow <= cH;
-      if (inside) {
-        const int ax = xs & ~3;
-        oxC[l] = xs & 3;
-        int rr = lane >> 2, ch = lane & 3;
-        if (rr < nrow)
-          *reinterpret_cast<uint2*>(&s_inC[l][cp][rr * MCC_P + 4 * ch]) = ld4_u16<PX>(ref + ax + 4 * ch + (ys + rr) * r.stride);
+      if (insC[l]) {
+        const int rr = lane >> 2, ch = lane & 3;
+        if (rr < nrow) *reinterpret_cast<uint2*>(&s_inC[l][cp][rr * MCC_P + 4 * ch]) = rc[l][cp];
       } else {
-        oxC[l] = 0;
+        const PlaneRef r = dpb.p[t.slot[l]][cp + 1];
+        const PX* ref = (const PX*)r.ptr;
+        const int xs = (t.x >> 1) + (mvx >> 3) - 1, ys = (t.y >> 1) + (mvy >> 3) - 1;
         for (int idx = lane; idx < nrow * 16; idx += 64) {
           int rr = idx >> 4, c = idx & 15;
           if (c < ncol) {
