@@ -386,22 +386,37 @@ __device__ __forceinline__ void resid_big_body(const PicDev& P, const PlaneRef& 
   const int bd = cIdx ? P.bd_chroma : P.bd_luma, maxv = (1 << bd) - 1;
   const bool intra = t.flags & DE265HIP_TU_INTRA;
   const bool bypass = t.flags & DE265HIP_TU_BYPASS;
+  // every global read of the TU goes out first (one memory latency for coefficients and prediction together): the
+  // thread's coefficient entry (entries beyond 256 are rare and fetched in the loops below) and its <= 4 prediction samples
+  const int16_t* vals = coeff_val + t.coeff_offset;
+  const uint16_t* pos = coeff_pos + t.coeff_offset;
+  const bool resid_only = t.flags & D265_TU_RESID_ONLY;
+  const PlaneRef pr = cIdx == 0 ? pl0 : (cIdx == 1 ? pl1 : pl2);
+  PX* dst = (PX*)pr.ptr + t.x0 + t.y0 * pr.stride;
+  int v_first = 0, p_first = 0, pred[4] = { 0, 0, 0, 0 };
+  if (tid < (int)t.n_coeff) { v_first = vals[tid]; p_first = pos[tid]; }
+  if (!resid_only) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int s = tid + 256 * k;
+      if (s < nS) pred[k] = dst[(s & (nT - 1)) + (s >> log2) * pr.stride];     // (uniform condition: nS is 256 or 1024)
+    }
+  }
   for (int s = tid; s < nS; s += 256) s_c[s] = 0;
   ((int32_t*)s_mat)[tid] = ((const int32_t*)c_dct_mat)[tid];
   if (tid == 0) { s_last_row = 0; s_last_col = 0; }
   __syncthreads();
   {
-    const int16_t* vals = coeff_val + t.coeff_offset;
-    const uint16_t* pos = coeff_pos + t.coeff_offset;
     int lr = 0, lc = 0;
     if (bypass) {
-      for (int i = tid; i < t.n_coeff; i += 256) s_c[pos[i]] = vals[i];
+      for (int i = tid; i < t.n_coeff; i += 256) s_c[i == tid ? p_first : pos[i]] = (int16_t)(i == tid ? v_first : vals[i]);
     } else if (!P.scaling_list) {
       const int bdShift = bd + log2 - 9;
       const int32_t fact = (int32_t)c_level_scale[t.qp % 6] << (t.qp / 6);
       for (int i = tid; i < t.n_coeff; i += 256) {
-        const int p = pos[i];
-        const int32_t cc = (int32_t)((uint32_t)(int32_t)vals[i] * (uint32_t)fact + (uint32_t)(1 << (bdShift - 1)));
+        const int p = i == tid ? p_first : pos[i];
+        const int vi = i == tid ? v_first : vals[i];
+        const int32_t cc = (int32_t)((uint32_t)(int32_t)vi * (uint32_t)fact + (uint32_t)(1 << (bdShift - 1)));
         s_c[p] = (int16_t)clip3(-32768, 32767, cc >> bdShift);
         lr = max(lr, p >> log2); lc = max(lc, p & (nT - 1));
       }
@@ -411,9 +426,10 @@ __device__ __forceinline__ void resid_big_body(const PicDev& P, const PlaneRef& 
       if (!intra) matrixID += (nT < 32) ? 3 : 1;
       const uint8_t* scl = scaling + (log2 == 4 ? 96 + 384 : 96 + 384 + 1536) + matrixID * nS;
       for (int i = tid; i < t.n_coeff; i += 256) {
-        const int p = pos[i];
+        const int p = i == tid ? p_first : pos[i];
+        const int vi = i == tid ? v_first : vals[i];
         const int fact = ((int)scl[p] * c_level_scale[t.qp % 6]) << (t.qp / 6);
-        long long cc = ((long long)vals[i] * fact + (1ll << (bdShift - 1))) >> bdShift;
+        long long cc = ((long long)vi * fact + (1ll << (bdShift - 1))) >> bdShift;
         s_c[p] = (int16_t)(cc < -32768 ? -32768 : (cc > 32767 ? 32767 : cc));
         lr = max(lr, p >> log2); lc = max(lc, p & (nT - 1));
       }
@@ -422,15 +438,15 @@ __device__ __forceinline__ void resid_big_body(const PicDev& P, const PlaneRef& 
     if (lc) atomicMax(&s_last_col, lc);
   }
   __syncthreads();
-  const bool resid_only = t.flags & D265_TU_RESID_ONLY;
-  const PlaneRef pr = cIdx == 0 ? pl0 : (cIdx == 1 ? pl1 : pl2);
-  PX* dst = (PX*)pr.ptr + t.x0 + t.y0 * pr.stride;
   int16_t* ro = resid + t.resid_offset;
   if (bypass) {
-    for (int s = tid; s < nS; s += 256) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int s = tid + 256 * k;
+      if (s >= nS) break;
       const int r = s_c[s];
       if (resid_only) ro[s] = (int16_t)r;
-      else { PX* d = dst + (s & (nT - 1)) + (s >> log2) * pr.stride; *d = (PX)clip3(0, maxv, (int)*d + r); }
+      else dst[(s & (nT - 1)) + (s >> log2) * pr.stride] = (PX)clip3(0, maxv, pred[k] + r);
     }
     return;
   }
@@ -443,13 +459,16 @@ __device__ __forceinline__ void resid_big_body(const PicDev& P, const PlaneRef& 
   }
   __syncthreads();
   const int post = 20 - bd, rnd2 = 1 << (post - 1);
-  for (int s = tid; s < nS; s += 256) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int s = tid + 256 * k;
+    if (s >= nS) break;
     const int y = s >> log2, i = s & (nT - 1);
     int sum = 0;
     for (int j = 0; j <= lastCol; j++) sum += s_mat[fact * j * 32 + i] * s_g[y * nT + j];
     const int out = (sum + rnd2) >> post;
     if (resid_only) ro[s] = (int16_t)clip3(-32768, 32767, out);
-    else { PX* d = dst + i + y * pr.stride; *d = (PX)clip3(0, maxv, (int)*d + out); }
+    else dst[i + y * pr.stride] = (PX)clip3(0, maxv, pred[k] + out);
   }
 }
 
@@ -484,9 +503,18 @@ __device__ __forceinline__ void resid_small_body(const PicDev& P, const PlaneRef
   const bool intra = live && (t.flags & DE265HIP_TU_INTRA);
   const bool bypass = live && (t.flags & DE265HIP_TU_BYPASS);
   const bool tskip = live && (t.flags & DE265HIP_TU_TSKIP);
-  if (live && s < (int)t.n_coeff) {
-    const int p = coeff_pos[t.coeff_offset + s];
-    const int v = coeff_val[t.coeff_offset + s];
+  // every global read of the TU goes out as soon as its record is there (one memory latency for coefficients and
+  // prediction together, not two in sequence)
+  const bool has_c = live && s < (int)t.n_coeff;
+  int p = 0, v = 0, pred = 0;
+  PX* d = nullptr;
+  if (has_c) { p = coeff_pos[t.coeff_offset + s]; v = coeff_val[t.coeff_offset + s]; }
+  if (live && !(t.flags & D265_TU_RESID_ONLY)) {
+    const PlaneRef pr = cIdx == 0 ? pl0 : (cIdx == 1 ? pl1 : pl2);
+    d = (PX*)pr.ptr + t.x0 + (s % nT) + (t.y0 + s / nT) * pr.stride;
+    pred = *d;
+  }
+  if (has_c) {
     int out;
     if (bypass) out = v;
     else if (!P.scaling_list) {
@@ -528,9 +556,7 @@ __device__ __forceinline__ void resid_small_body(const PicDev& P, const PlaneRef
     if (is_dst) r = clip3(-32768, 32767, r);                   // DST clips its second stage, the DCT does not
   }
   if (t.flags & D265_TU_RESID_ONLY) { resid[t.resid_offset + s] = (int16_t)clip3(-32768, 32767, r); return; }
-  const PlaneRef pr = cIdx == 0 ? pl0 : (cIdx == 1 ? pl1 : pl2);
-  PX* d = (PX*)pr.ptr + t.x0 + (s % nT) + (t.y0 + s / nT) * pr.stride;
-  *d = (PX)clip3(0, (1 << bd) - 1, (int)*d + r);
+  *d = (PX)clip3(0, (1 << bd) - 1, pred + r);
 }
 
 #ifndef RESID_BIG_WAVES
