@@ -26,7 +26,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r01_g_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_h_pmc_traffic.json")
 PMC_KERNEL = {"intra": ["k_run<unsigned short, 64>"], "mc": ["k_mc<unsigned short>"], "sao": ["k_sao<unsigned short>"],
               "deblock_v": ["k_deblock<unsigned short, true>"], "deblock_h": ["k_deblock<unsigned short, false>"],
               "resid": ["k_resid_big<unsigned short>", "k_resid_small<unsigned short>"]}
