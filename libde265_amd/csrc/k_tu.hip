@@ -992,6 +992,20 @@ __device__ __forceinline__ void run_chain_big(const PicDev& P, uint32_t w0, int 
   RUN_LDS_BARRIER();                                    // (also: the border array and s_dc are free again)
 }
 
+// A run record at a wave-uniform index, as eleven dwords: scalar loads, one round trip (field-wise access makes the
+// compiler fetch the byte and short fields with vector loads, in several dependent steps).
+__device__ __forceinline__ RunTask load_run_task(const RunTask* __restrict__ runs, uint32_t r)
+{
+  static_assert(sizeof(RunTask) == 44, "RunTask layout");
+  const uint32_t* q = reinterpret_cast<const uint32_t*>(runs + r);
+  uint32_t w[11];
+#pragma unroll
+  for (int i = 0; i < 11; i++) w[i] = __builtin_amdgcn_readfirstlane(q[i]);
+  RunTask t;
+  __builtin_memcpy(&t, w, sizeof(t));
+  return t;
+}
+
 // ---- micro runs: <= 16 TUs of <= 8x8 inside a 32x32 box (most runs of a picture with inter PUs) ----
 // One wavefront reconstructs the whole run on its own: no workgroup barrier, no staging of operands; a workgroup
 // works on four of them at a time (one ticket).  The window is at most 41 rows x 48 columns.
@@ -1097,7 +1111,7 @@ __device__ __forceinline__ void micro_run(const PicDev& P, const PlaneRef& pl0, 
                                           const int16_t* __restrict__ resid, uint16_t* mt, int16_t* mres,
                                           uint32_t r, int lane, uint32_t gen, int dbg)
 {
-  const RunTask run = runs[r];
+  const RunTask run = load_run_task(runs, r);
   const int n_tus = min((int)run.n_tus, MICRO_TUS);
   // one round trip: producer ids (a lane each) and the TU records (a lane each, two 16-byte loads)
   uint32_t dep_id = 0;
@@ -1279,7 +1293,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
     continue;
   }
   const uint32_t ticket = sl.x;
-  const RunTask run = runs[ticket];
+  const RunTask run = load_run_task(runs, ticket);
   st.mark(0);
   const bool has_dep = tid < (int)run.n_deps;
   uint32_t dep_id = 0;
