@@ -199,7 +199,9 @@ static void build_used_units()
         if (smooth) {
           std::vector<uint8_t> f(e);
           for (int q = 0; q < NB; q++) if (e[q]) { if (q > 0) f[q - 1] = 1; if (q + 1 < NB) f[q + 1] = 1; }
-          if (l2 == 5) { f[0] = 1; f[C] = 1; f[4 * nT] = 1; }             // bilinear variant
+          // bilinear variant (strong_intra_smoothing): every filtered sample is made from p[0] and p[+-64], and the
+          // decision for the variant also reads p[+-32] (intrapred.cc:847-852)
+          if (l2 == 5) { f[0] = 1; f[nT] = 1; f[C] = 1; f[3 * nT] = 1; f[4 * nT] = 1; }
           e.swap(f);
         }
         uint64_t u = 0;

@@ -71,6 +71,16 @@ def test_ctb16_and_32(dec):
     run_case(dec, 264, 136, 10, 0, seed=6, log2_ctb_size=5)
 
 
+def test_strong_smoothing_decision_samples_are_dependencies(dec):
+    """Regression (found by tools/exp/sweep.py 31 60, iteration 45): a 32x32 luma TU whose border is flat enough for the
+    bilinear smoothing variant (here: weighted prediction with negative weights saturates whole regions to 0) reads
+    p[+-32] for the decision (intrapred.cc:847-852) whatever its mode reads; the mode-aware dependency sets missed
+    those two samples, so the TU could run before their producers."""
+    run_case(dec, 1416, 536, 10, 1, seed=9045, stages=(0,), log2_ctb_size=5, log2_max_tb_size=5, log2_min_tb_size=3,
+             intra_pct=40, tskip_pct=20, bypass_pct=0, pcm_pct=0, scaling_list=0, constrained_intra_pred=0,
+             strong_intra_smoothing=1, weighted_pred=1, n_slices=4, split_bias=0, cbf_pct=60, mv_sigma_qpel=12)
+
+
 def test_1080p_b_picture(dec):
     run_case(dec, 1920, 1080, 8, 0, seed=11, stages=(2,))
 
