@@ -227,6 +227,11 @@ int  de265hip_dpb_upload(de265hip_decoder*, int slot, int c_idx,
                          const void* src, ptrdiff_t stride_bytes);
 int  de265hip_dpb_download(de265hip_decoder*, int slot, int c_idx,
                            void* dst, ptrdiff_t stride_bytes);
+/* Geometry of the picture a DPB slot currently holds (what upload / download copy): the counterpart of
+ * de265_get_image_width / _height / de265_get_bits_per_pixel (de265.h:160-171) for a device-resident picture.
+ * DE265_ERROR_PARAMETER_OUT_OF_RANGE for an unallocated slot; any out pointer may be NULL. */
+int  de265hip_dpb_info(de265hip_decoder*, int slot, int* width, int* height,
+                       int* bit_depth_luma, int* bit_depth_chroma);
 /* Device pointer + stride (bytes) of a DPB plane (for zero-copy consumers). */
 int  de265hip_dpb_plane(de265hip_decoder*, int slot, int c_idx,
                         void** dev_ptr, ptrdiff_t* stride_bytes);

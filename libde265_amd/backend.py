@@ -18,7 +18,7 @@ SO_PATH = os.environ.get("DE265HIP_SO") or os.path.join(_HERE, "libde265_hip.so"
 EXPORTS = [
     "de265hip_version", "de265hip_device_count",
     "de265hip_decoder_new", "de265hip_decoder_free",
-    "de265hip_dpb_alloc", "de265hip_dpb_upload", "de265hip_dpb_download", "de265hip_dpb_plane",
+    "de265hip_dpb_alloc", "de265hip_dpb_upload", "de265hip_dpb_download", "de265hip_dpb_plane", "de265hip_dpb_info",
     "de265hip_picture_build", "de265hip_picture_run", "de265hip_decoder_sync", "de265hip_picture_free",
     "de265hip_decode_picture", "de265hip_picture_get_stats",
     "de265hip_set_profiling", "de265hip_get_kernel_times", "de265hip_derive_edge_flags",
@@ -57,6 +57,7 @@ def lib():
     L.de265hip_dpb_upload.argtypes = [vp, i32, i32, vp, C.c_ssize_t]
     L.de265hip_dpb_download.argtypes = [vp, i32, i32, vp, C.c_ssize_t]
     L.de265hip_dpb_plane.argtypes = [vp, i32, i32, pp(vp), pp(C.c_ssize_t)]
+    L.de265hip_dpb_info.argtypes = [vp, i32, pp(i32), pp(i32), pp(i32), pp(i32)]
     L.de265hip_picture_build.argtypes = [vp, i32, pp(_abi.PictureDesc), pp(vp)]
     L.de265hip_picture_run.argtypes = [vp, vp, i32]
     L.de265hip_decoder_sync.argtypes = [vp]
@@ -147,13 +148,30 @@ class Decoder:
         bdc = bit_depth_luma if bit_depth_chroma is None else bit_depth_chroma
         _chk(lib().de265hip_dpb_alloc(self._h, slot, width, height, bit_depth_luma, bdc), "dpb_alloc")
 
+    def dpb_info(self, slot):
+        """(width, height, bit_depth_luma, bit_depth_chroma) of the picture the slot holds."""
+        w, h, by, bc = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        _chk(lib().de265hip_dpb_info(self._h, slot, C.byref(w), C.byref(h), C.byref(by), C.byref(bc)), "dpb_info")
+        return w.value, h.value, by.value, bc.value
+
+    def _check_planes(self, slot, shapes_dtypes, what):
+        w, h, by, bc = self.dpb_info(slot)
+        for c, (shape, dt) in enumerate(shapes_dtypes):
+            want = (h, w) if c == 0 else (h // 2, w // 2)
+            wdt = np.uint16 if (by if c == 0 else bc) > 8 else np.uint8
+            if tuple(shape) != want or np.dtype(dt) != np.dtype(wdt):
+                raise ValueError("%s: plane %d is %s %s, DPB slot %d holds %s %s" % (what, c, tuple(shape), np.dtype(dt), slot, want, np.dtype(wdt)))
+
     def upload(self, slot, planes):
+        # the C entry point copies the slot's geometry from `src` (like memcpy, it trusts the caller): check here
+        self._check_planes(slot, [(p.shape, p.dtype) for p in planes], "upload")
         for c, p in enumerate(planes):
             p = np.ascontiguousarray(p)
             _chk(lib().de265hip_dpb_upload(self._h, slot, c, p.ctypes.data, p.strides[0]), "dpb_upload")
 
     def download(self, slot, width, height, bit_depth):
         dt = np.uint16 if bit_depth > 8 else np.uint8
+        self._check_planes(slot, [((height, width), dt), ((height // 2, width // 2), dt), ((height // 2, width // 2), dt)], "download")
         out = []
         for c, (w, h) in enumerate([(width, height), (width // 2, height // 2), (width // 2, height // 2)]):
             a = np.empty((h, w), dt)

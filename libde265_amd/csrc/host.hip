@@ -382,6 +382,17 @@ int de265hip_dpb_download(de265hip_decoder* d, int slot, int c, void* dst, ptrdi
   return 0;
 }
 
+int de265hip_dpb_info(de265hip_decoder* d, int slot, int* width, int* height, int* bit_depth_luma, int* bit_depth_chroma)
+{
+  if (!d || slot < 0 || slot >= DE265HIP_MAX_DPB_SLOTS || !d->slots[slot].valid) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  const Slot& s = d->slots[slot];
+  if (width) *width = s.w;
+  if (height) *height = s.h;
+  if (bit_depth_luma) *bit_depth_luma = s.bdY;
+  if (bit_depth_chroma) *bit_depth_chroma = s.bdC;
+  return 0;
+}
+
 int de265hip_dpb_plane(de265hip_decoder* d, int slot, int c, void** dev_ptr, ptrdiff_t* stride_bytes)
 {
   Slot* s; int w, h; size_t bpp;

@@ -114,6 +114,14 @@ def test_empty_picture_and_errors(dec):
     with pytest.raises(backend.De265HipError) as e:
         dec.build(2, sp.desc)
     assert e.value.code == _abi.ERROR_PARAMETER_OUT_OF_RANGE
+    # the host mirror refuses planes that do not match what the slot holds (the C entry point trusts its caller)
+    assert dec.dpb_info(2) == (w, h, bd, bd)
+    with pytest.raises(ValueError):
+        dec.upload(2, pysynth.fill_planes(w + 8, h, bd, 5))
+    with pytest.raises(ValueError):
+        dec.download(2, w, h, 10)
+    with pytest.raises(backend.De265HipError):
+        dec.dpb_info(15)                             # never allocated
     del n_pus, C
 
 
@@ -137,7 +145,7 @@ def test_mc_far_outside_picture_and_shortcuts(dec):
     init = pysynth.fill_planes(w, h, bd, 9)
     exp = [p.copy() for p in init]
     pyoracle.reconstruct(sp.desc, sp.order, refs, exp, last_stage=0)
-    dec.upload(2, init)
+    dec.dpb_alloc(2, w, h, bd); dec.upload(2, init)
     pic = dec.build(2, sp.desc); dec.run(pic, 0); dec.sync()
     got = dec.download(2, w, h, bd)
     assert all(np.array_equal(g, e) for g, e in zip(got, exp))
@@ -271,6 +279,40 @@ def test_randomized_small_pictures(dec):
             raise AssertionError("config %d: %dx%d bd=%d st=%d %r: %s" % (it, w, h, bd, st, over, e))
 
 
+def random_midsize_config(rng):
+    """One random mid-size configuration (320..1928 x 240..1088, every feature switch drawn at random); also used by
+    tools/exp/sweep.py for long sweeps."""
+    log2_ctb = int(rng.choice([4, 5, 6, 6]))
+    w = int(rng.integers(40, 241)) * 8; h = int(rng.integers(30, 137)) * 8
+    bd = int(rng.choice([8, 10, 10, 12])); st = int(rng.choice([0, 0, 1, 2]))
+    over = dict(log2_ctb_size=log2_ctb, log2_max_tb_size=min(5, log2_ctb), log2_min_tb_size=int(rng.choice([2, 2, 3])),
+                intra_pct=int(rng.choice([5, 15, 40, 100])), tskip_pct=int(rng.choice([0, 20])), bypass_pct=int(rng.choice([0, 5])),
+                pcm_pct=int(rng.choice([0, 10])), scaling_list=int(rng.integers(0, 2)), constrained_intra_pred=int(rng.integers(0, 2)),
+                strong_intra_smoothing=int(rng.integers(0, 2)), weighted_pred=int(rng.integers(0, 2)), n_slices=int(rng.integers(1, 5)),
+                split_bias=int(rng.choice([0, 30, 50, 80, 100])), cbf_pct=int(rng.choice([30, 60, 100])), mv_sigma_qpel=int(rng.choice([4, 12, 80])),
+                pcm_loop_filter_disable=int(rng.integers(0, 2)), lf_across_slices_pct=int(rng.choice([0, 50, 100])),
+                lf_across_tiles=int(rng.integers(0, 2)), big_coeff_pct=int(rng.choice([0, 0, 2])), bi_pct=int(rng.choice([0, 60, 100])),
+                amp=int(rng.integers(0, 2)), deblocking=int(rng.choice([1, 1, 1, 0])), sao=int(rng.choice([1, 1, 1, 0])))
+    if log2_ctb >= 5 and rng.integers(0, 3) == 0:        # tiles (the slice layout then follows the tiles)
+        over.update(tile_cols=int(rng.integers(1, 4)), tile_rows=int(rng.integers(1, 3)), slice_per_tile=int(rng.integers(0, 2)))
+    qlo = int(rng.integers(0, 40)); over.update(qp_min=qlo, qp_max=int(rng.integers(qlo, 52)))
+    return w, h, bd, st, over
+
+
+def test_randomized_midsize_pictures(dec):
+    """Random pictures of everyday sizes: long dependency chains, many runs per picture, partial CTBs at both edges
+    (a sweep of this kind found the missing dependency of test_strong_smoothing_decision_samples_are_dependencies).
+    Longer: DE265HIP_TEST_RANDOM_MID=500, or tools/exp/sweep.py <seed> <n>."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("DE265HIP_TEST_SEED", "20261004")))
+    for it in range(int(os.environ.get("DE265HIP_TEST_RANDOM_MID", "24"))):
+        w, h, bd, st, over = random_midsize_config(rng)
+        try:
+            run_case(dec, w, h, bd, st, seed=9000 + it, stages=(2,), **over)
+        except AssertionError as e:
+            raise AssertionError("config %d: %dx%d bd=%d st=%d %r: %s" % (it, w, h, bd, st, over, e))
+
+
 def test_recorder_submit_matches_oracle(dec):
     """Incremental interface (de265hip_record_* + recorder_submit) on the GPU: same picture as the oracle."""
     w, h, bd = 352, 288, 10
@@ -286,6 +328,7 @@ def test_recorder_submit_matches_oracle(dec):
     init = pysynth.fill_planes(w, h, bd, 999)
     exp = [p.copy() for p in init]
     pyoracle.reconstruct(sp.desc, sp.order, refs, exp)
+    dec.dpb_alloc(2, w, h, bd)                # (the slot may hold a picture of another size from an earlier test)
     dec.upload(2, init)
     pic = rec.submit(dec, 2)
     dec.run(pic)
