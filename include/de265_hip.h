@@ -301,6 +301,9 @@ int  de265hip_picture_get_stats(const de265hip_picture*, de265hip_picture_stats*
 #define DE265HIP_K_SAO       6
 #define DE265HIP_K_PCM       7
 #define DE265HIP_K_COUNT     8
+/* enable: 0 = off, 1 = every kernel, otherwise a mask with bit (id + 1) set for each kernel id to be timed
+ * (DE265HIP_PROFILE_ONLY(id)): every timed launch costs two event records on the stream. */
+#define DE265HIP_PROFILE_ONLY(id) (2 << (id))
 int  de265hip_set_profiling(de265hip_decoder*, int enable);
 /* Accumulated ms and launch counts since the last reset (sync first). */
 int  de265hip_get_kernel_times(de265hip_decoder*, double ms[DE265HIP_K_COUNT],

@@ -202,8 +202,15 @@ class Decoder:
         _chk(lib().de265hip_decode_picture(self._h, dst_slot, dptr), "decode_picture")
 
     # --- profiling ---
-    def set_profiling(self, on):
-        _chk(lib().de265hip_set_profiling(self._h, int(bool(on))), "set_profiling")
+    def set_profiling(self, on, only=None):
+        """on: time every kernel's launches with hipEvents; only=[kernel names]: just those (each timed launch costs
+        two event records on the stream)."""
+        v = int(bool(on))
+        if on and only is not None:
+            v = 0
+            for name in only:
+                v |= 2 << _abi.K_NAMES.index(name)
+        _chk(lib().de265hip_set_profiling(self._h, v), "set_profiling")
 
     def kernel_times(self, reset=True):
         ms = (C.c_double * len(_abi.K_NAMES))()

@@ -48,7 +48,7 @@ struct de265hip_decoder {
   int run_waves = RUN_WAVES;          // DE265HIP_RUN_WAVES: wavefronts per run workgroup (experiments)
   int dbg = 0;                        // DE265HIP_DEBUG: timing-only ablations of k_run (results invalid)
   bool intra_levels = false;          // DE265HIP_INTRA_MODE=levels: one launch per dependency level
-  bool profiling = false;
+  uint32_t profiling = 0;             // bit k: launches of kernel id k are bracketed by hipEvents
   std::vector<PendingEvent> pending;
   double ms[DE265HIP_K_COUNT] = {};
   int64_t launches[DE265HIP_K_COUNT] = {};
@@ -947,7 +947,7 @@ namespace {
 
 struct KTimer {
   de265hip_decoder* d; int kid; hipEvent_t a = nullptr, b = nullptr; bool on;
-  KTimer(de265hip_decoder* dec, int k, int n_launches) : d(dec), kid(k), on(dec->profiling)
+  KTimer(de265hip_decoder* dec, int k, int n_launches) : d(dec), kid(k), on((dec->profiling >> k) & 1u)
   {
     d->launches[kid] += n_launches;
     if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, d->stream); }
@@ -1093,7 +1093,7 @@ int de265hip_decode_picture(de265hip_decoder* dec, int dst_slot, const de265hip_
 int de265hip_set_profiling(de265hip_decoder* dec, int enable)
 {
   if (!dec) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
-  dec->profiling = enable != 0;
+  dec->profiling = enable == 1 ? 0xFFFFFFFFu : (uint32_t)enable >> 1;
   return 0;
 }
 
