@@ -46,6 +46,7 @@ struct de265hip_decoder {
   Slot spare;                         // SAO output target, swapped with the decoded slot
   uint32_t* d_err = nullptr;          // set by a kernel whose bounded spin expired
   int run_waves = RUN_WAVES;          // DE265HIP_RUN_WAVES: wavefronts per run workgroup (experiments)
+  bool separate_bs = false;           // DE265HIP_SEPARATE_BS: bS by its own kernel instead of inside the deblocking kernels
   int dbg = 0;                        // DE265HIP_DEBUG: timing-only ablations of k_run (results invalid)
   bool intra_levels = false;          // DE265HIP_INTRA_MODE=levels: one launch per dependency level
   uint32_t profiling = 0;             // bit k: launches of kernel id k are bracketed by hipEvents
@@ -326,6 +327,7 @@ int de265hip_decoder_new(de265hip_decoder** out, int device)
   const char* mode = getenv("DE265HIP_INTRA_MODE");
   d->intra_levels = mode && !strcmp(mode, "levels");
   if (const char* dbg = getenv("DE265HIP_DEBUG")) d->dbg = atoi(dbg);
+  if (const char* e = getenv("DE265HIP_SEPARATE_BS")) d->separate_bs = atoi(e) != 0;
   if (const char* rw = getenv("DE265HIP_RUN_WAVES")) d->run_waves = std::min(RUN_WAVES, std::max(1, atoi(rw)));
   *out = d;
   return DE265HIP_OK;
@@ -1022,11 +1024,13 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
     }
   }
   if (last_stage >= DE265HIP_STAGE_DEBLOCKED && !pic->params.disable_deblocking && pic->any_edges) {
-    {
+    // bS (a12) is derived inside the deblocking kernels (one launch and one pass over the unit grid less: 9 us of a 4K
+    // picture); DE265HIP_SEPARATE_BS=1 keeps the separate k_bs launch that writes the bS plane first
+    if (dec->separate_bs) {
       KTimer t(dec, DE265HIP_K_BS, 1);
       hipLaunchKernelGGL(k_bs, dim3((P.w4 + 255) / 256, P.h4), dim3(256), 0, st, P, pic->d_flags, pic->d_motion, pic->d_bs);
     }
-    LfMeta M{ pic->d_flags, pic->d_qp, pic->d_bs, pic->d_ctbs, pic->d_slices };
+    LfMeta M{ pic->d_flags, pic->d_qp, dec->separate_bs ? pic->d_bs : nullptr, pic->d_motion, pic->d_ctbs, pic->d_slices };
     {
       KTimer t(dec, DE265HIP_K_DEBLOCK_V, 1);
       hipLaunchKernelGGL((k_deblock<PX, true>), dim3(((P.w4 + 1) / 2 + 255) / 256, P.h4, 3), dim3(256), 0, st, P, d0, d1, d2, M);

@@ -51,6 +51,22 @@ __device__ __forceinline__ int bs_motion(const de265hip_motion& mP, const de265h
   return d00 && d01;
 }
 
+// bS of the edge on the left (VERT) / top side of unit idx (derive_boundaryStrength, deblock.cc:241-375), fused into
+// the deblocking kernels: the motion records are only fetched for inter/inter edges without coded residual.
+// chroma_only: only bS == 2 matters (deblock.cc:763), no motion needed.
+template <bool VERT>
+__device__ __forceinline__ int edge_bs(const uint8_t* __restrict__ flags, const de265hip_motion* __restrict__ motion,
+                                       int idx, int pidx, bool chroma_only)
+{
+  const int f = flags[idx];
+  if (!(f & (VERT ? (DE265HIP_BLK_EDGE_TU_V | DE265HIP_BLK_EDGE_PB_V) : (DE265HIP_BLK_EDGE_TU_H | DE265HIP_BLK_EDGE_PB_H)))) return 0;
+  const int fp = flags[pidx];
+  if ((f | fp) & DE265HIP_BLK_INTRA) return 2;
+  if (chroma_only) return 0;
+  if ((f & (VERT ? DE265HIP_BLK_EDGE_TU_V : DE265HIP_BLK_EDGE_TU_H)) && ((f | fp) & DE265HIP_BLK_NONZERO)) return 1;
+  return bs_motion(motion[pidx], motion[idx]);
+}
+
 __global__ __launch_bounds__(256)
 void k_bs(PicDev P, const uint8_t* __restrict__ flags, const de265hip_motion* __restrict__ motion,
           uint8_t* __restrict__ bs)
@@ -179,7 +195,9 @@ void k_deblock(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, LfMeta M)
     const int y = VERT ? ty : ty * 2;
     if (x >= P.w4 || y >= P.h4) return;
     const int idx = x + y * P.w4;
-    const int bS = VERT ? (M.bs[idx] & 3) : ((M.bs[idx] >> 2) & 3);
+    if ((VERT ? x : y) == 0) return;                                  // the picture border is no edge
+    const int bS = M.bs ? (VERT ? (M.bs[idx] & 3) : ((M.bs[idx] >> 2) & 3))
+                        : edge_bs<VERT>(M.flags, M.motion, idx, VERT ? idx - 1 : idx - P.w4, false);
     if (bS == 0) return;
     const int xDi = x << 2, yDi = y << 2;
     const int stride = pl0.stride;
@@ -237,7 +255,9 @@ void k_deblock(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, LfMeta M)
     const int y = VERT ? ty * 2 : ty * 4;
     if (x >= P.w4 || y >= P.h4) return;
     const int idx = x + y * P.w4;
-    const int bS = VERT ? (M.bs[idx] & 3) : ((M.bs[idx] >> 2) & 3);
+    if ((VERT ? x : y) == 0) return;
+    const int bS = M.bs ? (VERT ? (M.bs[idx] & 3) : ((M.bs[idx] >> 2) & 3))
+                        : edge_bs<VERT>(M.flags, M.motion, idx, VERT ? idx - 1 : idx - P.w4, true);
     if (bS < 2) return;
     const PlaneRef pl = comp == 1 ? pl1 : pl2;
     const int stride = pl.stride;

@@ -7,7 +7,8 @@ namespace d265 {
 struct LfMeta {
   const uint8_t* flags;
   const int8_t* qp;
-  const uint8_t* bs;
+  const uint8_t* bs;                    // from k_bs, or null: the deblocking kernels derive bS themselves (default)
+  const de265hip_motion* motion;
   const de265hip_ctb_info* ctbs;
   const de265hip_slice_params* slices;
 };
