@@ -46,6 +46,7 @@ struct de265hip_decoder {
   Slot spare;                         // SAO output target, swapped with the decoded slot
   uint32_t* d_err = nullptr;          // set by a kernel whose bounded spin expired
   int run_waves = RUN_WAVES;          // DE265HIP_RUN_WAVES: wavefronts per run workgroup (experiments)
+  bool two_pass_deblock = false;      // DE265HIP_TWO_PASS_DEBLOCK: k_deblock<V> then k_deblock<H> instead of k_deblock_fused
   bool separate_bs = false;           // DE265HIP_SEPARATE_BS: bS by its own kernel instead of inside the deblocking kernels
   int dbg = 0;                        // DE265HIP_DEBUG: timing-only ablations of k_run (results invalid)
   bool intra_levels = false;          // DE265HIP_INTRA_MODE=levels: one launch per dependency level
@@ -328,6 +329,7 @@ int de265hip_decoder_new(de265hip_decoder** out, int device)
   d->intra_levels = mode && !strcmp(mode, "levels");
   if (const char* dbg = getenv("DE265HIP_DEBUG")) d->dbg = atoi(dbg);
   if (const char* e = getenv("DE265HIP_SEPARATE_BS")) d->separate_bs = atoi(e) != 0;
+  if (const char* e = getenv("DE265HIP_TWO_PASS_DEBLOCK")) d->two_pass_deblock = atoi(e) != 0;
   if (const char* rw = getenv("DE265HIP_RUN_WAVES")) d->run_waves = std::min(RUN_WAVES, std::max(1, atoi(rw)));
   *out = d;
   return DE265HIP_OK;
@@ -1031,13 +1033,21 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
       hipLaunchKernelGGL(k_bs, dim3((P.w4 + 255) / 256, P.h4), dim3(256), 0, st, P, pic->d_flags, pic->d_motion, pic->d_bs);
     }
     LfMeta M{ pic->d_flags, pic->d_qp, dec->separate_bs ? pic->d_bs : nullptr, pic->d_motion, pic->d_ctbs, pic->d_slices };
-    {
+    if (!dec->two_pass_deblock && !dec->separate_bs) {
+      // both directions in one pass over 8x8 blocks centred on the edge crossings (k_deblock_fused); reported under
+      // the "deblock_v" kernel id
       KTimer t(dec, DE265HIP_K_DEBLOCK_V, 1);
-      hipLaunchKernelGGL((k_deblock<PX, true>), dim3(((P.w4 + 1) / 2 + 255) / 256, P.h4, 3), dim3(256), 0, st, P, d0, d1, d2, M);
-    }
-    {
-      KTimer t(dec, DE265HIP_K_DEBLOCK_H, 1);
-      hipLaunchKernelGGL((k_deblock<PX, false>), dim3((P.w4 + 255) / 256, (P.h4 + 1) / 2, 3), dim3(256), 0, st, P, d0, d1, d2, M);
+      const int nbx = (P.width + 3) / 8 + 1, nby = (P.height + 3) / 8 + 1;
+      hipLaunchKernelGGL((k_deblock_fused<PX>), dim3((nbx + 255) / 256, nby, 3), dim3(256), 0, st, P, d0, d1, d2, M);
+    } else {
+      {
+        KTimer t(dec, DE265HIP_K_DEBLOCK_V, 1);
+        hipLaunchKernelGGL((k_deblock<PX, true>), dim3(((P.w4 + 1) / 2 + 255) / 256, P.h4, 3), dim3(256), 0, st, P, d0, d1, d2, M);
+      }
+      {
+        KTimer t(dec, DE265HIP_K_DEBLOCK_H, 1);
+        hipLaunchKernelGGL((k_deblock<PX, false>), dim3((P.w4 + 255) / 256, (P.h4 + 1) / 2, 3), dim3(256), 0, st, P, d0, d1, d2, M);
+      }
     }
   }
   if (last_stage >= DE265HIP_STAGE_FINAL && !pic->params.disable_sao && pic->params.sample_adaptive_offset_enabled_flag) {

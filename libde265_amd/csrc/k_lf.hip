@@ -298,6 +298,166 @@ template __global__ void k_deblock<uint8_t, false>(PicDev, PlaneRef, PlaneRef, P
 template __global__ void k_deblock<uint16_t, true>(PicDev, PlaneRef, PlaneRef, PlaneRef, LfMeta);
 template __global__ void k_deblock<uint16_t, false>(PicDev, PlaneRef, PlaneRef, PlaneRef, LfMeta);
 
+// ---------------------------------------------------------------- deblock, both directions in one pass
+// Every sample of the picture belongs to exactly one 8x8 block centred on a crossing of the 8-sample edge grid
+// (block (bx, by) = columns 8bx-4 .. 8bx+3, rows 8by-4 .. 8by+3).  The vertical edge through the block's centre is the only
+// vertical edge whose filter reads or writes samples of the block (a filter reads 4 and writes 3 samples either side), the
+// same holds for the horizontal edge, and the horizontal filter's inputs - the vertically filtered samples of rows
+// 8by-4 .. 8by+3 - all lie in the block.  So one lane takes one block: load 8x8, filter the two vertical-edge segments,
+// then the two horizontal-edge segments on the result (deblock.cc:936-1020 filters all vertical edges of the picture
+// before any horizontal edge: same result), store what changed.  One read and one write of the picture instead of two
+// each, one launch instead of two.  Loads are unconditional (clamped addresses), see k_sao.
+template <typename PX>
+__global__ __launch_bounds__(256)
+void k_deblock_fused(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, LfMeta M)
+{
+  const int comp = blockIdx.z;
+  const bool chroma = comp != 0;
+  const int bx = blockIdx.x * blockDim.x + threadIdx.x, by = blockIdx.y;
+  const PlaneRef pl = comp == 0 ? pl0 : (comp == 1 ? pl1 : pl2);
+  const int W = chroma ? P.width >> 1 : P.width, H = chroma ? P.height >> 1 : P.height;
+  const int x0 = 8 * bx - 4, y0 = 8 * by - 4;
+  if (x0 >= W || y0 >= H) return;
+  const int stride = pl.stride;
+  PX* base = (PX*)pl.ptr;
+  const int ush = chroma ? 1 : 2;                      // a unit is 4 luma = 2 chroma samples
+  // ---- the four edge segments of the block: k = 0, 1: vertical edge, rows 4k..4k+3; k = 2, 3: horizontal edge, columns
+  // 4(k-2)..  Everything is fetched in two rounds for all four together (not one dependent chain per segment):
+  // round 1: flags and QP of both sides, the Q side's slice index; round 2: the slice's offsets, the motion records
+  // where bS depends on them, and the block's samples.
+  const bool hasV = bx > 0 && 8 * bx < W, hasH = by > 0 && 8 * by < H;
+  bool ex[4]; int idx[4], pidx[4], ux[4], uy[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const bool vert = k < 2; const int sgm = k & 1;
+    ux[k] = vert ? (8 * bx) >> ush : (x0 + 4 * sgm) >> ush;
+    uy[k] = vert ? (y0 + 4 * sgm) >> ush : (8 * by) >> ush;
+    ex[k] = vert ? (hasV && y0 + 4 * sgm >= 0 && y0 + 4 * sgm < H) : (hasH && x0 + 4 * sgm >= 0 && x0 + 4 * sgm < W);
+    // (clamped: the loads below are unconditional)
+    const int cx = min(max(ux[k], vert ? 1 : 0), P.w4 - 1), cy = min(max(uy[k], vert ? 0 : 1), P.h4 - 1);
+    idx[k] = cx + cy * P.w4; pidx[k] = vert ? idx[k] - 1 : idx[k] - P.w4;
+    ux[k] = cx; uy[k] = cy;
+  }
+  int f[4], fp[4], qq[4], qp_[4], sl[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    f[k] = M.flags[idx[k]]; fp[k] = M.flags[pidx[k]];
+    qq[k] = M.qp[idx[k]]; qp_[k] = M.qp[pidx[k]];
+    sl[k] = M.ctbs[((ux[k] << 2) >> P.log2_ctb) + ((uy[k] << 2) >> P.log2_ctb) * P.ctbs_w].slice_idx;
+  }
+  int bs[4]; bool need_m[4]; bool any = false, any_m = false;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const bool vert = k < 2;
+    const int e_any = vert ? (DE265HIP_BLK_EDGE_TU_V | DE265HIP_BLK_EDGE_PB_V) : (DE265HIP_BLK_EDGE_TU_H | DE265HIP_BLK_EDGE_PB_H);
+    const int e_tu = vert ? DE265HIP_BLK_EDGE_TU_V : DE265HIP_BLK_EDGE_TU_H;
+    bs[k] = 0; need_m[k] = false;
+    if (ex[k] && (f[k] & e_any)) {                     // derive_boundaryStrength (deblock.cc:241-375), as in edge_bs
+      if ((f[k] | fp[k]) & DE265HIP_BLK_INTRA) bs[k] = 2;
+      else if (chroma) bs[k] = 0;                      // chroma filters bS == 2 only (deblock.cc:763)
+      else if ((f[k] & e_tu) && ((f[k] | fp[k]) & DE265HIP_BLK_NONZERO)) bs[k] = 1;
+      else need_m[k] = true;
+    }
+    any = any || bs[k] != 0 || need_m[k]; any_m = any_m || need_m[k];
+  }
+  if (!any) return;
+  // round 2
+  int boff[4], toff[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { boff[k] = M.slices[sl[k]].slice_beta_offset; toff[k] = M.slices[sl[k]].slice_tc_offset; }
+  // (the motion records as raw dwords, fetched here and looked at behind the sample loads: one wait for all; a struct
+  //  copy unpacks the fields inside the branch and waits there)
+  static_assert(sizeof(de265hip_motion) == 12, "de265hip_motion layout");
+  uint32_t rp[4][3], rq[4][3];
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (need_m[k]) {
+      const uint32_t* a = reinterpret_cast<const uint32_t*>(M.motion + pidx[k]);
+      const uint32_t* b = reinterpret_cast<const uint32_t*>(M.motion + idx[k]);
+      rp[k][0] = a[0]; rp[k][1] = a[1]; rp[k][2] = a[2]; rq[k][0] = b[0]; rq[k][1] = b[1]; rq[k][2] = b[2];
+    }
+  const bool okx[2] = { x0 >= 0, x0 + 4 < W };
+  int px[8][8];
+  {
+    const int xa = okx[0] ? x0 : x0 + 4, xb = okx[1] ? x0 + 4 : x0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const PX* row = base + min(max(y0 + r, 0), H - 1) * stride;
+      load4<PX>(row + xa, &px[r][0]);
+      load4<PX>(row + xb, &px[r][4]);
+    }
+  }
+  if (any_m) {
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (need_m[k]) {
+        de265hip_motion mp, mq;
+        __builtin_memcpy(&mp, rp[k], 12); __builtin_memcpy(&mq, rq[k], 12);
+        bs[k] = bs_motion(mp, mq);
+      }
+  }
+  const int cQp = comp == 1 ? P.cb_qp_offset : P.cr_qp_offset;
+  const int bd = chroma ? P.bd_chroma : P.bd_luma, maxv = (1 << bd) - 1;
+  const int need = chroma ? 2 : 1;
+  unsigned mod_rows = 0, mod_cols = 0;                 // bit s: segment s of the vertical / horizontal edge changed samples
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (bs[k] < need) continue;
+    const bool vert = k < 2; const int sgm = k & 1;
+    // edge parameters (deblock.cc:497-528 luma, :809-832 chroma): offsets of the Q side's slice
+    const int qavg = (qq[k] + qp_[k] + 1) >> 1;
+    const int qp = chroma ? lf_qpc(qavg + cQp) : qavg;
+    const int beta = chroma ? 0 : c_beta[lf_clip3(0, 51, qp + boff[k])] * (1 << (bd - 8));
+    const int tc = c_tc[lf_clip3(0, 53, qp + 2 * (bs[k] - 1) + toff[k])] * (1 << (bd - 8));
+    const bool fP = !lf_exempt(P, fp[k]), fQ = !lf_exempt(P, f[k]);
+    if (!chroma) {
+      int p[4][4], q[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          p[j][i] = vert ? px[4 * sgm + j][3 - i] : px[3 - i][4 * sgm + j];
+          q[j][i] = vert ? px[4 * sgm + j][4 + i] : px[4 + i][4 * sgm + j];
+        }
+      if (luma_filter_segment(p, q, beta, tc, bd, fP, fQ)) {
+        if (vert) mod_rows |= 1u << sgm; else mod_cols |= 1u << sgm;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int i = 0; i < 3; i++) {
+            if (vert) { px[4 * sgm + j][3 - i] = p[j][i]; px[4 * sgm + j][4 + i] = q[j][i]; }
+            else { px[3 - i][4 * sgm + j] = p[j][i]; px[4 + i][4 * sgm + j] = q[j][i]; }
+          }
+      }
+    } else {
+      if (vert) mod_rows |= 1u << sgm; else mod_cols |= 1u << sgm;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int c = 4 * sgm + j;
+        int &p1 = vert ? px[c][2] : px[2][c], &p0 = vert ? px[c][3] : px[3][c];
+        int &q0 = vert ? px[c][4] : px[4][c], &q1 = vert ? px[c][5] : px[5][c];
+        const int delta = lf_clip3(-tc, tc, ((((q0 - p0) << 2) + p1 - q1 + 4) >> 3));
+        if (fP) p0 = lf_clip3(0, maxv, p0 + delta);
+        if (fQ) q0 = lf_clip3(0, maxv, q0 - delta);
+      }
+    }
+  }
+  // ---- store the halves of rows that a filter touched (vertical segment s: rows 4s..4s+3, both halves; horizontal
+  // segment s: rows 1..6 of half s)
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const int y = y0 + r;
+    if (y < 0 || y >= H) continue;
+    const bool rowV = (mod_rows >> (r >> 2)) & 1u;
+    const bool inH = r >= 1 && r <= 6;
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+      if (okx[h] && (rowV || (inH && ((mod_cols >> h) & 1u)))) store4<PX>(base + y * stride + x0 + 4 * h, &px[r][4 * h]);
+  }
+}
+template __global__ void k_deblock_fused<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, LfMeta);
+template __global__ void k_deblock_fused<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, LfMeta);
+
 // ---------------------------------------------------------------- SAO
 // Out of place: src = deblocked picture, dst = output picture (every sample is
 // written, so dst needs no initialisation).  One lane per 8 samples of a row.

@@ -42,6 +42,8 @@ __global__ void k_bs(PicDev, const uint8_t*, const de265hip_motion*, uint8_t*);
 template <typename PX, bool VERT>
 __global__ void k_deblock(PicDev, PlaneRef, PlaneRef, PlaneRef, LfMeta);
 template <typename PX>
+__global__ void k_deblock_fused(PicDev, PlaneRef, PlaneRef, PlaneRef, LfMeta);
+template <typename PX>
 __global__ void k_sao(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, SaoMeta);
 
 // function-level kernels (k_fn.hip)
