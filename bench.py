@@ -26,9 +26,9 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r01_h_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_i_pmc_traffic.json")
 PMC_KERNEL = {"intra": ["k_run<unsigned short, 64>"], "mc": ["k_mc<unsigned short>"], "sao": ["k_sao<unsigned short>"],
-              "deblock_v": ["k_deblock<unsigned short, true>"], "deblock_h": ["k_deblock<unsigned short, false>"],
+              "deblock_v": ["k_deblock_fused<unsigned short>"],   # both directions in one kernel, reported under deblock_v
               "resid": ["k_resid_big<unsigned short>", "k_resid_small<unsigned short>"]}
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 CONFIG_ID = 4                  # SURVEY 8d config 4 -> seed 0xDE265000 + 4
@@ -170,8 +170,9 @@ def main():
         # ---- roofline of the dominant kernel (device time from hipEvents on the decoder's stream)
         dom_ms, dom_launches = ktimes[dom]
         alg_total = sum(getattr(s, ALG_KEY[dom]) for s in stats) * args.steps if dom in ALG_KEY else 0
-        if dom in ("deblock_v", "deblock_h"):
-            alg_total //= 2                       # SURVEY 8d counts 2P for the two passes together
+        two_pass = ktimes_all.get("deblock_h", (0, 0))[1] > 0      # DE265HIP_TWO_PASS_DEBLOCK: SURVEY 8d's 2P is for both passes together
+        if dom in ("deblock_v", "deblock_h") and two_pass:
+            alg_total //= 2
         achieved = (alg_total / 1e9) / (dom_ms / 1e3) if dom_ms > 0 else 0.0
         # HBM-side traffic of that kernel: rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) committed under
         # profiles/ (bench.py cannot run the profiler on itself); FETCH_SIZE doubled as the guide prescribes
@@ -193,14 +194,14 @@ def main():
                     if dom == "intra" else ""}
         # per-kernel breakdown of one step with all streams in flight: the profiled pass ahead of the timed region
         kernels = {k: {"ms_per_step": round(v[0], 4), "launches_per_step": v[1],
-                       "alg_GBs": round((sum(getattr(s, ALG_KEY[k]) for s in stats) / (2 if k.startswith("deblock") else 1)
+                       "alg_GBs": round((sum(getattr(s, ALG_KEY[k]) for s in stats) / (2 if k.startswith("deblock") and two_pass else 1)
                                          / 1e9) / (v[0] / 1e3), 1) if k in ALG_KEY and v[0] > 0 else None}
                    for k, v in ktimes_all.items()}
 
         st0 = [p.stats() for p in pics[0]]
         kernels_iso = {k: {"us_per_picture": round(1e3 * v[0] / max(v[1], 1), 1) if k != "resid" else
                            round(1e3 * v[0] / (2 * GOP), 1),
-                           "alg_GBs": round((sum(getattr(x, ALG_KEY[k]) for x in st0) / (2 if k.startswith("deblock") else 1)
+                           "alg_GBs": round((sum(getattr(x, ALG_KEY[k]) for x in st0) / (2 if k.startswith("deblock") and two_pass else 1)
                                              / 1e9) / (v[0] / 2 / 1e3), 1) if k in ALG_KEY and v[0] > 0 else None}
                        for k, v in iso.items() if v[1]}
         cpu = None
