@@ -580,10 +580,19 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     for (int l = 0; l <= max_rl; l++) count[l + 1] += count[l];
     // micro runs (<= 16 TUs of <= 8x8 inside a 32x32 box: most runs of a picture with inter PUs) are reconstructed by
     // one wavefront each, four per workgroup and ticket; inside a level they come first (same-level runs are independent)
+    // micro runs: <= 16 TUs of <= 8x8 in a 32x32 box; 16x16 TUs too (DE265HIP_MICRO16=0: not) when the run's samples
+    // fit the wavefront's residual slice (1024) and its window the wavefront's slice of the window array (k_tu.hip:
+    // MICRO_P 56 columns from the 8-aligned left edge, MICRO_H 41 rows, 256 chunks of 8 samples)
+    static const bool micro16 = !getenv("DE265HIP_MICRO16") || atoi(getenv("DE265HIP_MICRO16")) != 0;
     auto is_micro = [&](const RunBuild& R) {
       if (micro_off || (int)R.tus.size() > micro_tus || R.x1 - R.x0 > 32 || R.y1 - R.y0 > 32) return false;
-      for (const TuTask& t : R.tus) if (t.log2_size > 3) return false;
-      return true;
+      int samples = 0; bool big = false;
+      for (const TuTask& t : R.tus) { if (t.log2_size > 4) return false; big = big || t.log2_size == 4; samples += 1 << (2 * t.log2_size); }
+      if (!big) return true;
+      if (!micro16 || samples > 1024) return false;
+      const int ax0 = (R.x0 - 1) & ~7, wx1 = std::min(R.wx1, R.x1 + 32), wy1 = std::min(R.wy1, R.y1 + 32);
+      const int cols = wx1 - ax0, rows = wy1 - (R.y0 - 1);
+      return cols <= 56 && rows <= 41 && ((cols + 7) >> 3) * rows <= 256;
     };
     std::vector<uint8_t> micro(rb.size(), 0);
     for (size_t i = 0; i < rb.size(); i++) micro[i] = is_micro(rb[i]);
@@ -723,9 +732,14 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
         fin[i] = st;
         if (st.t > worst.t) worst = st;
       }
-      int hist[8] = {0}, small32 = 0, nmicro = 0;
+      int hist[8] = {0}, small32 = 0, nmicro = 0, with16 = 0, single16 = 0, single32 = 0, only_big = 0;
       for (size_t i = 0; i < rb.size(); i++) {
         const size_t n = rb[i].tus.size();
+        {
+          int mx = 0, mn = 9; for (const TuTask& t : rb[i].tus) { mx = std::max(mx, (int)t.log2_size); mn = std::min(mn, (int)t.log2_size); }
+          const bool box32 = rb[i].x1 - rb[i].x0 <= 32 && rb[i].y1 - rb[i].y0 <= 32;
+          with16 += mx == 4 && n <= 16 && box32; single16 += n == 1 && mx == 4; single32 += n == 1 && mx == 5; only_big += mn >= 4;
+        }
         hist[n <= 1 ? 0 : n <= 2 ? 1 : n <= 4 ? 2 : n <= 8 ? 3 : n <= 16 ? 4 : n <= 32 ? 5 : n <= 64 ? 6 : 7]++;
         bool ok = rb[i].x1 - rb[i].x0 <= 32 && rb[i].y1 - rb[i].y0 <= 32 && n <= 64;
         for (const TuTask& t : rb[i].tus) if (t.log2_size > 3) ok = false;
@@ -733,6 +747,8 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       }
       fprintf(stderr, "de265hip runs: %zu, micro %d, <=8x8 TUs in 32x32 box %d; by TU count 1:%d 2:%d 3-4:%d 5-8:%d 9-16:%d 17-32:%d 33-64:%d >64:%d\n",
               rb.size(), nmicro, small32, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7]);
+      fprintf(stderr, "de265hip runs with 16x16 as largest TU, <= 16 TUs, 32x32 box: %d; a single 16x16 TU: %d; a single 32x32 TU: %d; only 16x16/32x32 TUs: %d\n",
+              with16, single16, single32, only_big);
       fprintf(stderr, "de265hip chain: %lld barrier epochs in all runs; TUs per wavefront %lld %lld %lld %lld\n",
               (long long)dbg_foreign, (long long)dbg_w[0], (long long)dbg_w[1], (long long)dbg_w[2], (long long)dbg_w[3]);
       fprintf(stderr, "de265hip crit: est %.0f us; on the longest path %d runs, %.0f in-run levels, %.0f TU slots, %.0f 16x16 and %.0f 32x32 TUs\n",

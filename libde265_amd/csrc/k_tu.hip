@@ -1097,6 +1097,100 @@ __device__ __forceinline__ void micro_intra_tu(const RunTu& t, uint16_t* tile, i
   WAVE_BARRIER_ONLY();
 }
 
+// A 16x16 TU inside a micro run (one wavefront): 65 border entries - lanes 0..63 hold border[-32..31] as in
+// micro_intra_tu, the top-right end border[32] lives in a register of its own (bx, the same in every lane) - and four
+// samples per lane (rows y, y+4, y+8, y+12 of column lane & 15).  Availability: 17 units.
+template <typename PX>
+__device__ __forceinline__ void micro_intra_tu16(const RunTu& t, uint16_t* tile, int lane, const int16_t* res, int bd, PX* gdst, int gstride)
+{
+  constexpr int nT = 16, NB = 65, C = 32, cornerUnit = 8;
+  const int xB = t.x0, yB = t.y0, cIdx = t.c_idx;
+  const uint32_t avail = (uint32_t)t.avail;
+  const int maxv = (1 << bd) - 1;
+  int bv = 1 << (bd - 1), bx = bv;
+  if (avail != 0) {
+    auto fetch = [&](int p) {
+      const int i = p - C;
+      int src = i;
+      if (avail != ((2u << nT) - 1u)) {               // not every unit available: nearest available one before
+        const int u = (i < 0) ? (p >> 2) : (i == 0 ? cornerUnit : cornerUnit + 1 + ((i - 1) >> 2));
+        if (!((avail >> u) & 1)) {
+          const uint32_t below = avail & ((2u << u) - 1u);
+          if (below) {
+            const int su = 31 - __clz((int)below);
+            src = (su < cornerUnit) ? (-C + 4 * su + 3) : (su == cornerUnit ? 0 : 4 * (su - cornerUnit));
+          } else {
+            const int su = __ffs((int)avail) - 1;
+            src = (su < cornerUnit) ? (-C + 4 * su) : (su == cornerUnit ? 0 : 4 * (su - cornerUnit - 1) + 1);
+          }
+        }
+      }
+      const int sx = src <= 0 ? xB - 1 : xB + src - 1;
+      const int sy = src < 0 ? yB - src - 1 : yB - 1;
+      return (int)tile[sx + sy * MICRO_P];
+    };
+    bv = fetch(lane);
+    bx = fetch(NB - 1);
+  }
+  const int mode = t.intra_mode >= 35 ? 1 : t.intra_mode;
+  if (cIdx == 0 && mode != 1 && min(abs(mode - 26), abs(mode - 10)) > 1) {           // [1 2 1], both ends keep their value
+    const int prev = __builtin_amdgcn_update_dpp(bv, bv, 0x138, 0xf, 0xf, false);   // wave_shr:1 -> lane-1
+    int next = __builtin_amdgcn_update_dpp(bv, bv, 0x130, 0xf, 0xf, false);         // wave_shl:1 -> lane+1
+    if (lane == 63) next = bx;
+    const int f = (prev + 2 * bv + next + 2) >> 2;
+    bv = lane == 0 ? bv : f;
+  }
+  auto bord = [&](int idx) {                           // border[idx], idx = -32 .. 32
+    const int v = __builtin_amdgcn_ds_bpermute((idx + C) << 2, bv);
+    return idx == 32 ? bx : v;
+  };
+  const int x = lane & 15, yq = lane >> 4;
+  int dc = 0;
+  if (mode == 1) {
+    const int v = (lane >= nT && lane <= 3 * nT && lane != C) ? bv : 0;
+    dc = (wave_sum_dpp(v) + nT) >> 5;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int y = yq + 4 * k;
+    int pv;
+    if (mode == 0) {
+      const int l = bord(-1 - y), tp = bord(1 + x);
+      const int tr = bord(1 + nT), bl = bord(-1 - nT);
+      pv = ((nT - 1 - x) * l + (x + 1) * tr + (nT - 1 - y) * tp + (y + 1) * bl + nT) >> 5;
+    } else if (mode == 1) {
+      const int tp = bord(1 + x), l = bord(-1 - y);
+      const int corner = (bord(-1) + 2 * dc + bord(1) + 2) >> 2;
+      pv = dc;
+      if (cIdx == 0) pv = (x | y) == 0 ? corner : (y == 0 ? (tp + 3 * dc + 2) >> 2 : (x == 0 ? (l + 3 * dc + 2) >> 2 : dc));
+    } else {
+      const int angle = t.angle;
+      const bool vert = mode >= 18;
+      const int inv = t.inv_angle;
+      const int a = vert ? y : x, b = vert ? x : y;
+      const int iIdx = ((a + 1) * angle) >> 5, iFact = ((a + 1) * angle) & 31;
+      const int i0 = b + iIdx + 1, i1 = i0 + 1;
+      const int k0 = i0 >= 0 ? i0 : -((i0 * inv + 128) >> 8);
+      const int k1 = i1 >= 0 ? i1 : -((i1 * inv + 128) >> 8);
+      const int r0 = bord(vert ? k0 : -k0), r1 = bord(vert ? min(k1, C) : -min(k1, C));
+      pv = ((32 - iFact) * r0 + iFact * r1 + 16) >> 5;
+      if (cIdx == 0 && (mode == 26 || mode == 10)) {
+        const int ev = bord(vert ? -1 - y : 1 + x);
+        const int b0 = bord(0), b1 = vert ? bord(1) : bord(-1);
+        const int e = clip3(0, maxv, b1 + ((ev - b0) >> 1));
+        pv = (vert ? x == 0 : y == 0) ? e : pv;
+      }
+    }
+    const int outv = clip3(0, maxv, pv + (int)res[lane + 64 * k]);
+    tile[xB + x + (yB + y) * MICRO_P] = (uint16_t)outv;
+    // four adjacent lanes are packed with two DPP row shifts, every fourth lane issues one write-through store
+    const int w01 = outv | (__builtin_amdgcn_update_dpp(0, outv, 0x101, 0xf, 0xf, true) << 16);   // row_shl:1
+    const int w23 = __builtin_amdgcn_update_dpp(0, w01, 0x102, 0xf, 0xf, true);                   // row_shl:2
+    if ((x & 3) == 0) store4_packed<PX>(gdst + x + y * gstride, w01, w23);
+  }
+  WAVE_BARRIER_ONLY();
+}
+
 // Timing-only ablation switches of the run kernel (DE265HIP_DEBUG bits 2, 4, 8, 32, 64, 1024) exist only in builds with
 // -DD265_ABLATE: in the shipped kernel every one of them is a branch and code the chain has to step over.
 #ifdef D265_ABLATE
@@ -1129,24 +1223,31 @@ __device__ __forceinline__ void micro_run(const PicDev& P, const PlaneRef& pl0, 
   const int cw = c ? P.width >> 1 : P.width, ch = c ? P.height >> 1 : P.height;
   const int bd = c ? P.bd_chroma : P.bd_luma;
   const int wx0 = (int)run.x0 - 1, wy0 = (int)run.y0 - 1;
-  const int wx1 = min(min((int)run.wx1, cw), wx0 + 1 + MICRO_BOX + 8), wy1 = min(min((int)run.wy1, ch), wy0 + MICRO_H);
   const int ax0 = wx0 & ~7;
+  const int wx1 = min(min((int)run.wx1, cw), ax0 + MICRO_P), wy1 = min(min((int)run.wy1, ch), wy0 + MICRO_H);
   // second round trip: residuals (into this wavefront's LDS slice) and the first look at the producers' flags
   uint32_t flag0 = gen;
   if (has_dep) flag0 = __hip_atomic_load(&sync[2 + dep_id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (int k0 = 0; k0 < n_tus; k0 += 4) {                              // four loads in flight
-    int16_t rv[4]; int ro[4];
+  // (in pieces of 64 samples - a 16x16 TU has four -, four loads in flight; the run holds at most MICRO_RES samples)
+  {
+    const int n_samp = min((int)run.n_samples, MICRO_RES);
+    // TU of this lane's sample in piece q: the TUs lie back to back in sample order, a lane finds its TU by its first sample
+    for (int q0 = 0; q0 < n_samp; q0 += 256) {
+      int16_t rv[4]; int ro[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int k = min(k0 + u, n_tus - 1);
-      const uint32_t w1 = __builtin_amdgcn_readlane(ra.y, k), samp = __builtin_amdgcn_readlane(ra.w, k) & (MICRO_RES - 1);
-      const uint32_t roff = __builtin_amdgcn_readlane(rb.z, k);
-      const int nS = 1 << (2 * (w1 & 0xFF));
-      ro[u] = (k0 + u < n_tus && lane < nS) ? (int)samp + lane : -1;
-      rv[u] = (ro[u] >= 0 && ((w1 >> 16) & DE265HIP_TU_CBF)) ? resid[roff + lane] : (int16_t)0;
+      for (int u = 0; u < 4; u++) {
+        const int sidx = q0 + 64 * u + lane;                             // sample of the run
+        ro[u] = sidx < n_samp ? sidx : -1;
+        // the TU that holds it: the last one whose first sample is <= sidx (<= 16 TUs: a short scan of scalars)
+        int kk = 0;
+        for (int k = 1; k < n_tus; k++) kk = ((int)(__builtin_amdgcn_readlane(ra.w, k) & (MICRO_RES - 1)) <= sidx) ? k : kk;
+        const uint32_t w1 = __builtin_amdgcn_ds_bpermute(kk << 2, (int)ra.y), first = __builtin_amdgcn_ds_bpermute(kk << 2, (int)ra.w) & (MICRO_RES - 1);
+        const uint32_t roff = __builtin_amdgcn_ds_bpermute(kk << 2, (int)rb.z);
+        rv[u] = (ro[u] >= 0 && ((w1 >> 16) & DE265HIP_TU_CBF)) ? resid[roff + (sidx - (int)first)] : (int16_t)0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) if (ro[u] >= 0) mres[ro[u]] = rv[u];
     }
-#pragma unroll
-    for (int u = 0; u < 4; u++) if (ro[u] >= 0) mres[ro[u]] = rv[u];
   }
   // producers (bounded spin, as in the workgroup path)
   for (int i = lane; i < (int)run.n_deps; i += 64) {
@@ -1191,6 +1292,7 @@ __device__ __forceinline__ void micro_run(const PicDev& P, const PlaneRef& pl0, 
     t.avail = w4; t.resid_offset = 0;
     t.angle = (int)(int8_t)(w7 & 0xFF); t.inv_angle = (int)(int16_t)(w7 >> 16);
     PX* gdst = plane + gx0 + gy0 * stride;
+    if (t.log2_size == 4) { micro_intra_tu16<PX>(t, mt, lane, mres + (w3 & (MICRO_RES - 1)), bd, gdst, stride); continue; }
     const int rs = mres[(w3 & (MICRO_RES - 1)) + (lane & ((1 << (2 * t.log2_size)) - 1))];
     if (t.log2_size == 2) micro_intra_tu<2, PX>(t, mt, lane, rs, bd, gdst, stride);
     else micro_intra_tu<3, PX>(t, mt, lane, rs, bd, gdst, stride);
