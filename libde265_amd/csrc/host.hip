@@ -571,6 +571,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   const bool micro_off = getenv("DE265HIP_NO_MICRO") != nullptr;
   const int micro_tus = getenv("DE265HIP_MICRO_TUS") ? std::min(16, atoi(getenv("DE265HIP_MICRO_TUS"))) : 16;   // MICRO_TUS of k_run
   int64_t sum_lvls = 0, dbg_foreign = 0, dbg_w[4] = { 0, 0, 0, 0 };
+  std::vector<uint8_t> dbg_micro;
   size_t n_resid = 0;
   int max_rl = 0;
   {
@@ -596,21 +597,22 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     };
     std::vector<uint8_t> micro(rb.size(), 0);
     for (size_t i = 0; i < rb.size(); i++) micro[i] = is_micro(rb[i]);
+    dbg_micro = micro;
     std::vector<int> count2(2 * (max_rl + 2) + 1, 0);
     for (size_t i = 0; i < rb.size(); i++) count2[2 * rb[i].level + (micro[i] ? 0 : 1) + 1]++;
     for (size_t l = 0; l + 1 < count2.size(); l++) count2[l + 1] += count2[l];
     for (size_t i = 0; i < rb.size(); i++) { int k = count2[2 * rb[i].level + (micro[i] ? 0 : 1)]++; order[k] = (int)i; newidx[i] = k; }
     runs.resize(rb.size());
-    // ticket slots: a ticket is a batch of four slots: four micro runs, or one ordinary run (+ three empty slots)
+    // ticket slots: a ticket is a batch of RUN_TICKET_SLOTS slots: that many micro runs, or one ordinary run (+ empty slots)
     for (size_t k = 0; k < rb.size(); k++) {
       if (micro[order[k]]) slots.push_back((uint32_t)k | 0x80000000u);
       else {
-        while (slots.size() & 3) slots.push_back(0xFFFFFFFFu);
+        while (slots.size() % RUN_TICKET_SLOTS) slots.push_back(0xFFFFFFFFu);
         slots.push_back((uint32_t)k);
-        for (int q = 0; q < 3; q++) slots.push_back(0xFFFFFFFFu);
+        for (int q = 1; q < RUN_TICKET_SLOTS; q++) slots.push_back(0xFFFFFFFFu);
       }
     }
-    while (slots.size() & 3) slots.push_back(0xFFFFFFFFu);
+    while (slots.size() % RUN_TICKET_SLOTS) slots.push_back(0xFFFFFFFFu);
     for (size_t k = 0; k < rb.size(); k++) {
       const RunBuild& R = rb[order[k]];
       RunTask& o = runs[k]; memset(&o, 0, sizeof(o));
@@ -710,7 +712,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     // LDS-limited residency is 3 workgroups per CU (768); 2 per CU leave LDS for the kernels of the other GOP streams:
     // bench with 3 streams 5304 vs 5173 frames/s, one stream alone 2317 vs 2353
     int cap = wenv ? atoi(wenv) : 512;
-    pic->n_batches = (int)(slots.size() / 4);
+    pic->n_batches = (int)(slots.size() / RUN_TICKET_SLOTS);
     pic->n_workers = std::min(pic->n_batches, std::max(64, std::min(cap, widest + widest / 4)));
     if (getenv("DE265HIP_PRINT_CRIT")) {               // diagnostic: longest path through the run DAG
       // cost model of one run (us; fitted to ablation timings): fixed + per barrier level + per TU a wavefront has to do
@@ -749,6 +751,18 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
               rb.size(), nmicro, small32, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7]);
       fprintf(stderr, "de265hip runs with 16x16 as largest TU, <= 16 TUs, 32x32 box: %d; a single 16x16 TU: %d; a single 32x32 TU: %d; only 16x16/32x32 TUs: %d\n",
               with16, single16, single32, only_big);
+      {
+        int n_mic = 0, r_tus = 0, r_box = 0, r_32 = 0, r_fit = 0, sparse_box = 0;
+        for (size_t i = 0; i < rb.size(); i++) {
+          if (dbg_micro[i]) { n_mic++; continue; }
+          const RunBuild& R = rb[i];
+          int mx = 0, own = 0; for (const TuTask& t : R.tus) { mx = std::max(mx, (int)t.log2_size); own += 1 << (2 * t.log2_size); }
+          const bool box = R.x1 - R.x0 > 32 || R.y1 - R.y0 > 32;
+          if (mx == 5) r_32++; else if (box) { r_box++; sparse_box += own < (R.x1 - R.x0) * (R.y1 - R.y0); } else if ((int)R.tus.size() > 16) r_tus++; else r_fit++;
+        }
+        fprintf(stderr, "de265hip micro runs %d; ordinary because of: a 32x32 TU %d, box > 32 %d (sparse %d), > 16 TUs %d, samples/window do not fit %d\n",
+                n_mic, r_32, r_box, sparse_box, r_tus, r_fit);
+      }
       fprintf(stderr, "de265hip chain: %lld barrier epochs in all runs; TUs per wavefront %lld %lld %lld %lld\n",
               (long long)dbg_foreign, (long long)dbg_w[0], (long long)dbg_w[1], (long long)dbg_w[2], (long long)dbg_w[3]);
       fprintf(stderr, "de265hip crit: est %.0f us; on the longest path %d runs, %.0f in-run levels, %.0f TU slots, %.0f 16x16 and %.0f 32x32 TUs\n",

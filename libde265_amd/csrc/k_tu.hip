@@ -1383,18 +1383,27 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   st.mark(6);
   const uint32_t bticket = next_ticket++;                              // uniform: scalar loads/branches below
   if (bticket >= (uint32_t)n_batches) break;
-  // a ticket is four slots: four micro runs (a wavefront each, no workgroup barrier), or one ordinary run
-  const uint4 sl = *reinterpret_cast<const uint4*>(slots + 4 * bticket);
-  if (sl.x & 0x80000000u) {
-    for (int q = wave; q < 4; q += (nthr >> 6)) {
-      const uint32_t mine = q == 0 ? sl.x : (q == 1 ? sl.y : (q == 2 ? sl.z : sl.w));
+  // a ticket is RUN_TICKET_SLOTS slots: that many micro runs (a wavefront each, no workgroup barrier; slots q, q+4, ..
+  // one after the other by the same wavefront: fewer draws per run; the runs of a ticket follow each other in the run
+  // order, so a slot never waits for a later one), or one ordinary run in slot 0
+  uint32_t slv[RUN_TICKET_SLOTS];
+#pragma unroll
+  for (int i = 0; i < RUN_TICKET_SLOTS / 4; i++) {
+    const uint4 v = *reinterpret_cast<const uint4*>(slots + RUN_TICKET_SLOTS * bticket + 4 * i);
+    slv[4 * i] = v.x; slv[4 * i + 1] = v.y; slv[4 * i + 2] = v.z; slv[4 * i + 3] = v.w;
+  }
+  if (slv[0] & 0x80000000u) {
+    for (int q = wave; q < RUN_TICKET_SLOTS; q += (nthr >> 6)) {
+      uint32_t mine = slv[0];
+#pragma unroll
+      for (int i = 1; i < RUN_TICKET_SLOTS; i++) mine = q == i ? slv[i] : mine;     // (scalar selects: no register array)
       if (mine != 0xFFFFFFFFu)
-        micro_run<PX>(P, pl0, pl1, pl2, runs, deps, sync, err, tasks, resid, tile + q * MICRO_SLICE,
-                      s_res + q * MICRO_RES, mine & 0x7FFFFFFFu, lane, gen, dbg);
+        micro_run<PX>(P, pl0, pl1, pl2, runs, deps, sync, err, tasks, resid, tile + (q & 3) * MICRO_SLICE,
+                      s_res + (q & 3) * MICRO_RES, mine & 0x7FFFFFFFu, lane, gen, dbg);
     }
     continue;
   }
-  const uint32_t ticket = sl.x;
+  const uint32_t ticket = slv[0];
   const RunTask run = load_run_task(runs, ticket);
   st.mark(0);
   const bool has_dep = tid < (int)run.n_deps;

@@ -29,6 +29,10 @@ __global__ void k_resid_big(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*,
 template <typename PX>
 __global__ void k_resid_small(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int, int, int, const int16_t*,
                               const uint16_t*, const uint8_t*, int16_t*);
+#ifndef RUN_TICKET_SLOTS
+#define RUN_TICKET_SLOTS 8   // slots of a k_run ticket: that many micro runs (slot q and q+4 .. by the same wavefront, one after
+                             // the other), or one ordinary run in slot 0
+#endif
 #define RUN_WAVES 4          // wavefronts per run workgroup (one per SIMD of a CU); blockDim.x = 64..64*RUN_WAVES
 template <typename PX, int BOX>
 __global__ void k_run(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*,
