@@ -581,6 +581,8 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     for (int l = 0; l <= max_rl; l++) count[l + 1] += count[l];
     // micro runs (<= 16 TUs of <= 8x8 inside a 32x32 box: most runs of a picture with inter PUs) are reconstructed by
     // one wavefront each, four per workgroup and ticket; inside a level they come first (same-level runs are independent)
+    // (up to 32 TUs per micro run instead of 16 - the records live one per lane - measured slower: a long run is better
+    //  off with four wavefronts and in-run levels; B picture 99 -> 109 us)
     // micro runs: <= 16 TUs of <= 8x8 in a 32x32 box; 16x16 TUs too (DE265HIP_MICRO16=0: not) when the run's samples
     // fit the wavefront's residual slice (1024) and its window the wavefront's slice of the window array (k_tu.hip:
     // MICRO_P 56 columns from the 8-aligned left edge, MICRO_H 41 rows, 256 chunks of 8 samples)
