@@ -307,8 +307,11 @@ template __global__ void k_deblock<uint16_t, false>(PicDev, PlaneRef, PlaneRef, 
 // then the two horizontal-edge segments on the result (deblock.cc:936-1020 filters all vertical edges of the picture
 // before any horizontal edge: same result), store what changed.  One read and one write of the picture instead of two
 // each, one launch instead of two.  Loads are unconditional (clamped addresses), see k_sao.
+#ifndef DEBLOCK_FUSED_WAVES
+#define DEBLOCK_FUSED_WAVES 4     // (114 VGPRs; 5/6/8 wavefronts per SIMD spill 84/164/264 B to scratch: 3-stream bench 5 820 -> 5 660/5 330/4 970 frames/s)
+#endif
 template <typename PX>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, DEBLOCK_FUSED_WAVES)
 void k_deblock_fused(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, LfMeta M)
 {
   const int comp = blockIdx.z;
