@@ -22,6 +22,18 @@ __device__ __constant__ int8_t c_epel_filt[8][4] = {
   { 0, 64, 0, 0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 },
   { -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
 
+// the luma taps as int16 pairs (tap[2m], tap[2m+1]) for v_dot2_i32_i16: two multiply-adds per instruction on sample pairs
+#define QPK(a, b) ((uint32_t)(uint16_t)(int16_t)(a) | ((uint32_t)(uint16_t)(int16_t)(b) << 16))
+__device__ __constant__ uint32_t c_qpel_pk[4][4] = {
+  { QPK(0, 0), QPK(0, 64), QPK(0, 0), QPK(0, 0) },
+  { QPK(-1, 4), QPK(-10, 58), QPK(17, -5), QPK(1, 0) },
+  { QPK(-1, 4), QPK(-11, 40), QPK(40, -11), QPK(4, -1) },
+  { QPK(0, 1), QPK(-5, 17), QPK(58, -10), QPK(4, -1) } };
+#undef QPK
+typedef short mc_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int mc_dot2(uint32_t a, uint32_t b, int acc)
+{ return __builtin_amdgcn_sdot2(__builtin_bit_cast(mc_s2, a), __builtin_bit_cast(mc_s2, b), acc, false); }
+
 #define MC_IWP 24          // LDS pitch of the staged input tile (>= 16+7)
 
 __device__ __forceinline__ int mc_clip3(int lo, int hi, int v) { return min(max(v, lo), hi); }
@@ -298,16 +310,31 @@ void k_mc(PicDev P, DpbTable dpb, PlaneRef d0, PlaneRef d1, PlaneRef d2,
 #pragma unroll
           for (int j = 0; j < 4; j++) o[j] = in[rr * MCL_P + lx4 + j + 3];
         } else {
-          int sv[11];
+          // the 11 samples sv[0..10] the four outputs need, as pairs: E[m] = (sv[2m], sv[2m+1]) read as dwords (from the
+          // even element below the row's start, shifted by one sample when the start is odd), O[m] = (sv[2m+1], sv[2m+2])
+          const int e0 = rr * MCL_P + lx4 + (oxL[l] & ~1);
+          const uint32_t* rowd = reinterpret_cast<const uint32_t*>(&s_inL[l][e0]);
+          uint32_t D[7], E[6], O[5];
 #pragma unroll
-          for (int k = 0; k < 11; k++) sv[k] = in[rr * MCL_P + lx4 + k];
+          for (int m = 0; m < 7; m++) D[m] = rowd[m];
+          if (oxL[l] & 1) {
 #pragma unroll
-          for (int j = 0; j < 4; j++) {
-            int sum = 0;
+            for (int m = 0; m < 6; m++) E[m] = __builtin_amdgcn_alignbit(D[m + 1], D[m], 16);
+          } else {
 #pragma unroll
-            for (int k = 0; k < 8; k++) sum += __mul24((int)c_qpel_filt[xF][k], sv[j + k]);
-            o[j] = (int16_t)(sum >> shift1);
+            for (int m = 0; m < 6; m++) E[m] = D[m];
           }
+#pragma unroll
+          for (int m = 0; m < 5; m++) O[m] = __builtin_amdgcn_alignbit(E[m + 1], E[m], 16);
+          int sum[4] = { 0, 0, 0, 0 };
+#pragma unroll
+          for (int m = 0; m < 4; m++) {
+            const uint32_t tp = c_qpel_pk[xF][m];
+            sum[0] = mc_dot2(E[m], tp, sum[0]); sum[1] = mc_dot2(O[m], tp, sum[1]);
+            sum[2] = mc_dot2(E[m + 1], tp, sum[2]); sum[3] = mc_dot2(O[m + 1], tp, sum[3]);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; j++) o[j] = (int16_t)(sum[j] >> shift1);
         }
         *reinterpret_cast<uint2*>(&s_tmp[rr * MCT_P + lx4]) =
           make_uint2((uint32_t)(uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16), (uint32_t)(uint16_t)o[2] | ((uint32_t)(uint16_t)o[3] << 16));
@@ -321,11 +348,14 @@ void k_mc(PicDev P, DpbTable dpb, PlaneRef d0, PlaneRef d1, PlaneRef d2,
       const int vshift = (xF == 0) ? shift1 : 6;
       int acc[4] = { 0, 0, 0, 0 };
 #pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const uint2 rv = *reinterpret_cast<const uint2*>(&s_tmp[(ly + k) * MCT_P + lx4]);
-        const int tap = c_qpel_filt[yF][k];
-        acc[0] += __mul24(tap, (int)(int16_t)(rv.x & 0xFFFF)); acc[1] += __mul24(tap, (int)(int16_t)(rv.x >> 16));
-        acc[2] += __mul24(tap, (int)(int16_t)(rv.y & 0xFFFF)); acc[3] += __mul24(tap, (int)(int16_t)(rv.y >> 16));
+      for (int k = 0; k < 8; k += 2) {                 // rows k, k+1: their samples of one column as a pair, one dot2 each
+        const uint2 r0 = *reinterpret_cast<const uint2*>(&s_tmp[(ly + k) * MCT_P + lx4]);
+        const uint2 r1 = *reinterpret_cast<const uint2*>(&s_tmp[(ly + k + 1) * MCT_P + lx4]);
+        const uint32_t tp = c_qpel_pk[yF][k >> 1];
+        acc[0] = mc_dot2(__builtin_amdgcn_perm(r1.x, r0.x, 0x05040100u), tp, acc[0]);
+        acc[1] = mc_dot2(__builtin_amdgcn_perm(r1.x, r0.x, 0x07060302u), tp, acc[1]);
+        acc[2] = mc_dot2(__builtin_amdgcn_perm(r1.y, r0.y, 0x05040100u), tp, acc[2]);
+        acc[3] = mc_dot2(__builtin_amdgcn_perm(r1.y, r0.y, 0x07060302u), tp, acc[3]);
       }
 #pragma unroll
       for (int j = 0; j < 4; j++) prL[l][j] = (int16_t)(acc[j] >> vshift);
