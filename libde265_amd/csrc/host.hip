@@ -1087,7 +1087,7 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
     SaoMeta M{ pic->d_flags, pic->d_sao };
     {
       KTimer t(dec, DE265HIP_K_SAO, 1);
-      hipLaunchKernelGGL(k_sao<PX>, dim3((P.width / 8 + 4 * 62 - 1) / (4 * 62), (P.height + SAO_ROWS - 1) / SAO_ROWS, 3), dim3(256), 0, st, P, d0, d1, d2,
+      hipLaunchKernelGGL(k_sao<PX>, dim3((P.width / 8 + 4 * SAO_GROUPS * 62 - 1) / (4 * SAO_GROUPS * 62), (P.height + SAO_ROWS - 1) / SAO_ROWS, 3), dim3(256), 0, st, P, d0, d1, d2,
                          sp.pl[0], sp.pl[1], sp.pl[2], M);
     }
     for (int c = 0; c < 3; c++) std::swap(dst.pl[c], sp.pl[c]);      // output picture now lives in the slot

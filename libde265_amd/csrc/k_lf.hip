@@ -495,63 +495,46 @@ template <> __device__ __forceinline__ void store8i<uint8_t>(uint8_t* p, const i
   *reinterpret_cast<uint2*>(p) = r;
 }
 
+template <bool WIDE> struct SaoMaskT { typedef unsigned long long T; };
+template <> struct SaoMaskT<false> { typedef uint32_t T; };
+
+// 8 samples as four dwords of two 16-bit samples each (8-bit samples are widened / narrowed)
+template <typename PX> __device__ __forceinline__ uint4 load8_pk(const PX* p);
+template <> __device__ __forceinline__ uint4 load8_pk<uint16_t>(const uint16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+template <> __device__ __forceinline__ uint4 load8_pk<uint8_t>(const uint8_t* p)
+{
+  const uint2 r = *reinterpret_cast<const uint2*>(p);
+  return make_uint4(__builtin_amdgcn_perm(0, r.x, 0x0C010C00u), __builtin_amdgcn_perm(0, r.x, 0x0C030C02u),
+                    __builtin_amdgcn_perm(0, r.y, 0x0C010C00u), __builtin_amdgcn_perm(0, r.y, 0x0C030C02u));
+}
+template <typename PX> __device__ __forceinline__ void store8_pk(PX* p, uint4 v);
+template <> __device__ __forceinline__ void store8_pk<uint16_t>(uint16_t* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
+template <> __device__ __forceinline__ void store8_pk<uint8_t>(uint8_t* p, uint4 v)
+{
+  uint2 r;
+  r.x = __builtin_amdgcn_perm(v.y, v.x, 0x06040200u);
+  r.y = __builtin_amdgcn_perm(v.w, v.z, 0x06040200u);
+  *reinterpret_cast<uint2*>(p) = r;
+}
+
 // One lane filters an 8 (wide) x 8 (high) strip.  All ten rows it needs are requested up
 // front as 16-byte loads (ten loads in flight per lane), the left/right neighbours come from the
 // adjacent lanes through DPP wave shifts (lanes 0 and 63 of every wavefront only supply them),
 // the CTB parameters and the slice/tile permissions of the 3x3 CTB neighbourhood are evaluated
 // once per strip, and every output row is one 16-byte store.
+struct SaoRec { uint32_t w[6]; };
+struct SaoRows { uint4 r[SAO_ROWS + 2]; };
+// The part of a strip behind its loads: w = the CTB's record, R = rows y0-1 .. y0+SAO_ROWS of the strip, packed.
 template <typename PX>
-__global__ __launch_bounds__(256, SAO_WAVES)
-void k_sao(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, PlaneRef d1, PlaneRef d2,
-           SaoMeta M)
+__device__ __forceinline__ void sao_strip(const PicDev& P, const SaoMeta& M, PX* dst, int dstride, int comp, int cs,
+                                          int width, int height, int lane, int x0, int y0, bool inpic, int ctbshift,
+                                          const SaoRec rec, const SaoRows rows)
 {
-  const int comp = blockIdx.z;
-  const int cs = comp ? 1 : 0;
-  const int width = P.width >> cs, height = P.height >> cs;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int x0 = ((blockIdx.x * 4 + wave) * SAO_LANES + lane - 1) * 8;
-  const int y0 = blockIdx.y * SAO_ROWS;
-  if (y0 >= height) return;                                   // uniform per workgroup
-  const PlaneRef sp = comp == 0 ? s0 : (comp == 1 ? s1 : s2);
-  const PlaneRef dp = comp == 0 ? d0 : (comp == 1 ? d1 : d2);
-  const PX* src = (const PX*)sp.ptr;
-  PX* dst = (PX*)dp.ptr;
-  const int sstride = sp.stride, dstride = dp.stride;
-  const bool inpic = x0 >= 0 && x0 < width;
-  const int ctbshift = P.log2_ctb - cs;
-  const int ctbX = max(x0, 0) >> ctbshift, ctbY = y0 >> ctbshift;
-  // the CTB record is requested together with the pixels (one latency, not two), as three 8-byte words: its byte
-  // fields are picked out with shifts below (indexing the struct by component sent it through LDS)
-  uint32_t w[6];
-  {
-    const uint2* q = reinterpret_cast<const uint2*>(&M.sao[min(ctbX, P.ctbs_w - 1) + ctbY * P.ctbs_w]);
-    const uint2 q0 = q[0], q1 = q[1], q2 = q[2];
-    w[0] = q0.x; w[1] = q0.y; w[2] = q1.x; w[3] = q1.y; w[4] = q2.x; w[5] = q2.y;
-  }
-
-  // Every load is unconditional (the address is clamped into the picture instead): loads under a condition are
-  // compiled into one branch + wait each, i.e. one memory latency per row.  What a clamped load returns for a row or
-  // strip outside the picture is never used: such neighbours are masked out below (okmask), such strips return.
-  int v[SAO_ROWS + 2][8];
-  {
-    const PX* col = src + min(max(x0, 0), (width - 1) & ~7);         // (the last strip may be partial: rows are padded)
-#pragma unroll
-    for (int j = 0; j < SAO_ROWS + 2; j++) load8i<PX>(col + min(max(y0 - 1 + j, 0), height - 1) * sstride, v[j]);
-  }
-  int nl[SAO_ROWS + 2], nr[SAO_ROWS + 2];                     // left / right neighbour of the strip, per row
-#pragma unroll
-  for (int j = 0; j < SAO_ROWS + 2; j++) {
-    nl[j] = __builtin_amdgcn_update_dpp(0, v[j][7], 0x138, 0xf, 0xf, false);   // wave_shr:1 -> lane-1's last sample
-    nr[j] = __builtin_amdgcn_update_dpp(0, v[j][0], 0x130, 0xf, 0xf, false);   // wave_shl:1 -> lane+1's first sample
-  }
-  if (!inpic || lane == 0 || lane == 63) return;
-  if (P.dbg & 32) {                                           // ablation: pure copy
-#pragma unroll
-    for (int r = 0; r < SAO_ROWS; r++)
-      if (y0 + r < height) store8i<PX>(dst + x0 + (y0 + r) * dstride, v[r + 1]);
-    return;
-  }
-
+  const uint32_t (&w)[6] = rec.w;
+  const uint4 (&R)[SAO_ROWS + 2] = rows.r;
+  // (the record's fields first: its loads were issued ahead of the rows', so waiting for them leaves the rows in flight;
+  //  behind the rows' first use the compiler would sink the loads themselves there - a second memory latency in sequence.
+  //  An empty asm statement that merely "uses" the six words does the same but broke component 2 after a refactoring.)
   const int bd = comp ? P.bd_chroma : P.bd_luma;
   const int maxv = (1 << bd) - 1;
 #define SAO_BYTE(k) ((w[(k) >> 2] >> (((k) & 3) * 8)) & 0xFFu)        // byte k of the SaoCtb record (dev_common.h)
@@ -568,12 +551,34 @@ void k_sao(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, PlaneRe
   }
 #undef SAO_BYTE
   const unsigned perm = w[5] >> 16;
+
+  // S[j][m], m = 0..4: the row shifted by one sample: (left neighbour, v0), (v1, v2), (v3, v4), (v5, v6), (v7, right
+  // neighbour); the neighbours come from the adjacent lanes (DPP wave shifts; lanes 0 and 63 only supply them)
+  uint32_t S[SAO_ROWS + 2][5];
+#pragma unroll
+  for (int j = 0; j < SAO_ROWS + 2; j++) {
+    const uint32_t pw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)R[j].w, 0x138, 0xf, 0xf, false);   // wave_shr:1 -> lane-1's (v6, v7)
+    const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)R[j].x, 0x130, 0xf, 0xf, false);   // wave_shl:1 -> lane+1's (v0, v1)
+    S[j][0] = __builtin_amdgcn_alignbit(R[j].x, pw, 16);
+    S[j][1] = __builtin_amdgcn_alignbit(R[j].y, R[j].x, 16);
+    S[j][2] = __builtin_amdgcn_alignbit(R[j].z, R[j].y, 16);
+    S[j][3] = __builtin_amdgcn_alignbit(R[j].w, R[j].z, 16);
+    S[j][4] = __builtin_amdgcn_alignbit(nx, R[j].w, 16);
+  }
+  if (!inpic || lane == 0 || lane == 63) return;
+  if (P.dbg & 32) {                                           // ablation: pure copy
+#pragma unroll
+    for (int r = 0; r < SAO_ROWS; r++)
+      if (y0 + r < height) store8_pk<PX>(dst + x0 + (y0 + r) * dstride, R[r + 1]);
+    return;
+  }
+
   const int nrows = min(SAO_ROWS, height - y0);
 
   if (type == 0) {                                            // plain copy of the deblocked samples
 #pragma unroll
     for (int r = 0; r < SAO_ROWS; r++)
-      if (r < nrows) store8i<PX>(dst + x0 + (y0 + r) * dstride, v[r + 1]);
+      if (r < nrows) store8_pk<PX>(dst + x0 + (y0 + r) * dstride, R[r + 1]);
     return;
   }
 
@@ -596,10 +601,11 @@ void k_sao(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, PlaneRe
 #pragma unroll
     for (int r = 0; r < SAO_ROWS; r++) {
       if (r >= nrows) break;
+      const uint32_t rw[4] = { R[r + 1].x, R[r + 1].y, R[r + 1].z, R[r + 1].w };
       int out[8];
 #pragma unroll
       for (int i = 0; i < 8; i++) {
-        const int c = v[r + 1][i];
+        const int c = (rw[i >> 1] >> (16 * (i & 1))) & 0xFFFF;
         const int k = ((c >> bandShift) - left) & 31;         // bandTable[(k+left)&31] = k+1
         const bool ex = (exm >> ((cs ? r >> 1 : r >> 2) * 4 + (cs ? i >> 1 : i >> 2))) & 1;
         const int off = k == 0 ? o4[0] : (k == 1 ? o4[1] : (k == 2 ? o4[2] : o4[3]));   // no dynamic register indexing
@@ -611,70 +617,132 @@ void k_sao(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, PlaneRe
   }
 
   // ---- edge offset (sao.cc:75-178)
-  const int hx = (eo == 1) ? 0 : (eo == 3 ? 1 : -1), hy = (eo == 0) ? 0 : -1;   // first neighbour; second is the mirror
-  // permissions of the 3x3 CTB neighbourhood, resolved on the host: bit (dy+1)*3+(dx+1)
   const int mask = (1 << ctbshift) - 1;
-
-  // offsets {o1,o2,0,o3,o4} indexed by edgeIdx+2 (sao.cc:95-100): four of them packed into one register
-  const unsigned otab = (unsigned)(uint8_t)o4[0] | ((unsigned)(uint8_t)o4[1] << 8) | ((unsigned)(uint8_t)o4[2] << 24);
   const bool e0 = eo == 0, e1 = eo == 1, e2 = eo == 2;
+  const int hx = (eo == 1) ? 0 : (eo == 3 ? 1 : -1), hy = (eo == 0) ? 0 : -1;   // first neighbour; second is the mirror
 
-  // ---- which of the 64 samples may be modified: one 64-bit mask per strip (bit r*8+i) instead of
+  // ---- which of the samples may be modified: one 64-bit mask per strip (bit r*8+i) instead of
   // per-sample boundary logic.  A sample is blocked when one of its two neighbours lies outside the
   // picture, or in another CTB whose slice/tile rules forbid filtering across (perm), or when it is
   // pcm/bypass-exempt, or outside the picture itself.
   const int ncols = min(8, width - x0);
-  const unsigned long long COL0 = 0x0101010101010101ull, ROW0 = 0xFFull;
-  const unsigned long long colL = COL0, colR = COL0 << (ncols - 1);
-  const unsigned long long rowT = ROW0, rowB = ROW0 << (8 * (nrows - 1));
+  // (SAO_ROWS <= 4: the whole mask is one 32-bit word)
+  typedef typename SaoMaskT<(SAO_ROWS > 4)>::T mask_t;
+  const mask_t COL0 = (mask_t)0x0101010101010101ull, ROW0 = (mask_t)0xFF;
+  const mask_t colL = COL0, colR = COL0 << (ncols - 1);
+  const mask_t rowT = ROW0, rowB = ROW0 << (8 * (nrows - 1));
   const bool touchL = (x0 & mask) == 0, touchR = ((x0 + ncols - 1) & mask) == mask || x0 + ncols >= width;
   const bool touchT = (y0 & mask) == 0, touchB = ((y0 + nrows - 1) & mask) == mask || y0 + nrows >= height;
   // permission of the CTB at offset (dx,dy) (0 = this CTB); out-of-picture CTBs have their bit cleared in perm
   auto permitted = [&](int dx, int dy) -> bool { return (perm >> ((dy + 1) * 3 + dx + 1)) & 1; };
-  auto blocked = [&](int sx, int sy) -> unsigned long long {   // samples whose neighbour in direction (sx,sy) is not usable
-    const unsigned long long X = sx < 0 ? colL : (sx > 0 ? colR : 0ull);
-    const unsigned long long Y = sy < 0 ? rowT : (sy > 0 ? rowB : 0ull);
+  auto blocked = [&](int sx, int sy) -> mask_t {              // samples whose neighbour in direction (sx,sy) is not usable
+    const mask_t X = sx < 0 ? colL : (sx > 0 ? colR : (mask_t)0);
+    const mask_t Y = sy < 0 ? rowT : (sy > 0 ? rowB : (mask_t)0);
     const int dx = sx < 0 ? (touchL ? -1 : 0) : (sx > 0 ? (touchR ? 1 : 0) : 0);
     const int dy = sy < 0 ? (touchT ? -1 : 0) : (sy > 0 ? (touchB ? 1 : 0) : 0);
-    unsigned long long bad = 0;
+    mask_t bad = 0;
     if (!permitted(dx, 0)) bad |= X & ~Y;
     if (!permitted(0, dy)) bad |= Y & ~X;
     if (!permitted(dx, dy)) bad |= X & Y;
     return bad;
   };
-  unsigned long long okmask = ~(blocked(hx, hy) | blocked(-hx, -hy));
-  okmask &= (COL0 * ((1ull << ncols) - 1ull)) & (nrows >= 8 ? ~0ull : ((1ull << (8 * nrows)) - 1ull));
+  mask_t okmask = ~(blocked(hx, hy) | blocked(-hx, -hy));
+  okmask &= (COL0 * (mask_t)((1u << ncols) - 1u)) & (nrows >= (int)sizeof(mask_t) ? ~(mask_t)0 : (((mask_t)1 << (8 * nrows)) - 1));
   if (exm) {
 #pragma unroll
     for (int r = 0; r < SAO_ROWS; r++)
 #pragma unroll
       for (int i = 0; i < 8; i++)
-        if ((exm >> ((cs ? r >> 1 : r >> 2) * 4 + (cs ? i >> 1 : i >> 2))) & 1) okmask &= ~(1ull << (r * 8 + i));
+        if ((exm >> ((cs ? r >> 1 : r >> 2) * 4 + (cs ? i >> 1 : i >> 2))) & 1) okmask &= ~((mask_t)1 << (r * 8 + i));
   }
-  const unsigned ok_lo = (unsigned)okmask, ok_hi = (unsigned)(okmask >> 32);
+  const unsigned ok_lo = (unsigned)okmask, ok_hi = (unsigned)((unsigned long long)okmask >> 32);
 
+  // offsets {o1, o2, 0, o3, o4} indexed by edgeIdx + 2 (sao.cc:95-100) as a byte table, biased by 128 (v_perm looks up
+  // unsigned bytes): bytes 0..3 in tab_lo, byte 4 in tab_hi
+  const uint32_t tab_lo = (uint32_t)(uint8_t)(o4[0] + 128) | ((uint32_t)(uint8_t)(o4[1] + 128) << 8) | (128u << 16) |
+                          ((uint32_t)(uint8_t)(o4[2] + 128) << 24);
+  const uint32_t tab_hi = (uint32_t)(uint8_t)(o4[3] + 128);
+  typedef short sao_s2 __attribute__((ext_vector_type(2)));
+  const sao_s2 one = { 1, 1 }, mone = { -1, -1 }, two = { 2, 2 }, zero = { 0, 0 }, bias = { 128, 128 };
+  const sao_s2 vmax = { (short)maxv, (short)maxv };
 #pragma unroll
   for (int r = 0; r < SAO_ROWS; r++) {
     if (r >= nrows) break;
-    int out[8];
+    const uint32_t cur[4] = { R[r + 1].x, R[r + 1].y, R[r + 1].z, R[r + 1].w };
+    const uint32_t up[4] = { R[r].x, R[r].y, R[r].z, R[r].w }, dn[4] = { R[r + 2].x, R[r + 2].y, R[r + 2].z, R[r + 2].w };
+    uint32_t outw[4];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const int c = v[r + 1][i];
-      // the eight neighbours with compile-time register indices, then a select by edge class
-      // (a runtime index into v[][] would push the whole window into scratch memory)
-      const int nL = i > 0 ? v[r + 1][i > 0 ? i - 1 : 0] : nl[r + 1], nR = i < 7 ? v[r + 1][i < 7 ? i + 1 : 7] : nr[r + 1];
-      const int nU = v[r][i], nD = v[r + 2][i];
-      const int nUL = i > 0 ? v[r][i > 0 ? i - 1 : 0] : nl[r], nUR = i < 7 ? v[r][i < 7 ? i + 1 : 7] : nr[r];
-      const int nDL = i > 0 ? v[r + 2][i > 0 ? i - 1 : 0] : nl[r + 2], nDR = i < 7 ? v[r + 2][i < 7 ? i + 1 : 7] : nr[r + 2];
-      const int na = e0 ? nL : (e1 ? nU : (e2 ? nUL : nUR));
-      const int nb = e0 ? nR : (e1 ? nD : (e2 ? nDR : nDL));
-      const bool ok = ((r < 4 ? ok_lo : ok_hi) >> ((r & 3) * 8 + i)) & 1u;
-      const int ee = min(max(c - na, -1), 1) + min(max(c - nb, -1), 1) + 2;      // 0..4
-      const int off = ee == 4 ? o4[3] : (int)(int8_t)((otab >> (8 * ee)) & 0xFF);
-      out[i] = ok ? lf_clip3(0, maxv, c + off) : c;
+    for (int m = 0; m < 4; m++) {
+      // the two neighbours of the sample pair (2m, 2m+1) by edge class: 0 left/right, 1 up/down, 2 up-left/down-right,
+      // 3 up-right/down-left
+      const uint32_t na = e0 ? S[r + 1][m] : (e1 ? up[m] : (e2 ? S[r][m] : S[r][m + 1]));
+      const uint32_t nb = e0 ? S[r + 1][m + 1] : (e1 ? dn[m] : (e2 ? S[r + 2][m + 1] : S[r + 2][m]));
+      const sao_s2 c = __builtin_bit_cast(sao_s2, cur[m]);
+      const sao_s2 sa = __builtin_elementwise_min(__builtin_elementwise_max(c - __builtin_bit_cast(sao_s2, na), mone), one);
+      const sao_s2 sb = __builtin_elementwise_min(__builtin_elementwise_max(c - __builtin_bit_cast(sao_s2, nb), mone), one);
+      const uint32_t ee = __builtin_bit_cast(uint32_t, (sao_s2)(sa + sb + two));       // 0..4 in each half
+      const uint32_t t = __builtin_amdgcn_perm(tab_hi, tab_lo, ee | 0x0C000C00u);      // biased offsets, zero-extended
+      sao_s2 o = c + __builtin_bit_cast(sao_s2, t) - bias;
+      o = __builtin_elementwise_min(__builtin_elementwise_max(o, zero), vmax);
+      const unsigned okw = r < 4 ? ok_lo : ok_hi;
+      const int pos = (r & 3) * 8 + 2 * m;
+      const uint32_t mlo = (uint32_t)(((int)(okw << (31 - pos))) >> 31), mhi = (uint32_t)(((int)(okw << (30 - pos))) >> 31);
+      const uint32_t msk = (mlo & 0xFFFFu) | (mhi & 0xFFFF0000u);
+      outw[m] = (__builtin_bit_cast(uint32_t, o) & msk) | (cur[m] & ~msk);
     }
-    store8i<PX>(dst + x0 + (y0 + r) * dstride, out);
+    store8_pk<PX>(dst + x0 + (y0 + r) * dstride, make_uint4(outw[0], outw[1], outw[2], outw[3]));
   }
+}
+
+template <typename PX>
+__global__ __launch_bounds__(256, SAO_WAVES)
+void k_sao(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, PlaneRef d1, PlaneRef d2,
+           SaoMeta M)
+{
+  const int comp = blockIdx.z;
+  const int cs = comp ? 1 : 0;
+  const int width = P.width >> cs, height = P.height >> cs;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int y0 = blockIdx.y * SAO_ROWS;
+  if (y0 >= height) return;                                   // uniform per workgroup
+  const PlaneRef sp = comp == 0 ? s0 : (comp == 1 ? s1 : s2);
+  const PlaneRef dp = comp == 0 ? d0 : (comp == 1 ? d1 : d2);
+  const PX* src = (const PX*)sp.ptr;
+  PX* dst = (PX*)dp.ptr;
+  const int sstride = sp.stride, dstride = dp.stride;
+  const int ctbshift = P.log2_ctb - cs;
+  const int ctbY = y0 >> ctbshift;
+  // A wavefront takes SAO_GROUPS groups of 62 strips one after the other, with the loads of all of them issued up front:
+  // the second group's rows arrive while the first is computed, the first group's stores drain while the second is
+  // computed (with one group per wavefront all wavefronts of the picture load, compute and store in step).
+  // Every load is unconditional (the address is clamped into the picture instead): loads under a condition are
+  // compiled into one branch + wait each, i.e. one memory latency per row.  What a clamped load returns for a row or
+  // strip outside the picture is never used: such neighbours are masked out (okmask), such strips return.
+  // The rows stay packed: 8 samples = four dwords of two 16-bit samples (8-bit pictures are widened on load).  The edge
+  // class arithmetic runs on sample pairs (v_pk_* 16-bit instructions, the offset table as a byte lookup with v_perm).
+  int x0[SAO_GROUPS]; bool inpic[SAO_GROUPS];
+  SaoRec w[SAO_GROUPS];
+  SaoRows R[SAO_GROUPS];
+#pragma unroll
+  for (int g = 0; g < SAO_GROUPS; g++) {
+    x0[g] = (((blockIdx.x * 4 + wave) * SAO_GROUPS + g) * SAO_LANES + lane - 1) * 8;
+    inpic[g] = x0[g] >= 0 && x0[g] < width;
+    // the CTB record is requested together with the samples (one latency, not two), as three 8-byte words: its byte
+    // fields are picked out with shifts (indexing the struct by component sent it through LDS)
+    const int ctbX = min(max(x0[g], 0) >> ctbshift, P.ctbs_w - 1);
+    const uint2* q = reinterpret_cast<const uint2*>(&M.sao[ctbX + ctbY * P.ctbs_w]);
+    const uint2 q0 = q[0], q1 = q[1], q2 = q[2];
+    w[g].w[0] = q0.x; w[g].w[1] = q0.y; w[g].w[2] = q1.x; w[g].w[3] = q1.y; w[g].w[4] = q2.x; w[g].w[5] = q2.y;
+  }
+#pragma unroll
+  for (int g = 0; g < SAO_GROUPS; g++) {
+    const PX* col = src + min(max(x0[g], 0), (width - 1) & ~7);      // (the last strip may be partial: rows are padded)
+#pragma unroll
+    for (int j = 0; j < SAO_ROWS + 2; j++) R[g].r[j] = load8_pk<PX>(col + min(max(y0 - 1 + j, 0), height - 1) * sstride);
+  }
+#pragma unroll
+  for (int g = 0; g < SAO_GROUPS; g++)
+    sao_strip<PX>(P, M, dst, dstride, comp, cs, width, height, lane, x0[g], y0, inpic[g], ctbshift, w[g], R[g]);
 }
 
 template __global__ void k_sao<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, SaoMeta);

@@ -13,7 +13,13 @@ struct LfMeta {
   const de265hip_slice_params* slices;
 };
 #ifndef SAO_ROWS
-#define SAO_ROWS 4                      // rows per lane of k_sao (never crosses a CTB); measured: 8 -> 57 us, 4 -> 40 us, 2 -> 48 us per 4K picture
+#define SAO_ROWS 2                      // rows per lane of k_sao (never crosses a CTB).  Per 4K picture, packed kernel: 8 -> 32.3 us, 4 -> 27.6 us,
+                                        // 2 -> 26.6 us (twice the wavefronts and 2x instead of 1.5x the rows read, but their load / arithmetic /
+                                        // store phases overlap better; 3-stream bench +1.1 %)
+#endif
+#ifndef SAO_GROUPS
+#define SAO_GROUPS 1                    // groups of 62 strips per wavefront of k_sao, loaded together and finished one after the other
+                                        // (2: the second group's rows arrive under the first's arithmetic, but 105 VGPRs + scratch: 34 vs 27.6 us)
 #endif
 struct SaoMeta {
   const uint8_t* flags;
