@@ -46,6 +46,7 @@ struct de265hip_decoder {
   Slot spare;                         // SAO output target, swapped with the decoded slot
   uint32_t* d_err = nullptr;          // set by a kernel whose bounded spin expired
   int run_waves = RUN_WAVES;          // DE265HIP_RUN_WAVES: wavefronts per run workgroup (experiments)
+  bool resid16_big = false;           // DE265HIP_RESID16_BIG: 16x16 residual TUs by 4-wavefront workgroups (k_resid_big) instead of one wavefront
   bool two_pass_deblock = false;      // DE265HIP_TWO_PASS_DEBLOCK: k_deblock<V> then k_deblock<H> instead of k_deblock_fused
   bool separate_bs = false;           // DE265HIP_SEPARATE_BS: bS by its own kernel instead of inside the deblocking kernels
   int dbg = 0;                        // DE265HIP_DEBUG: timing-only ablations of k_run (results invalid)
@@ -330,6 +331,7 @@ int de265hip_decoder_new(de265hip_decoder** out, int device)
   if (const char* dbg = getenv("DE265HIP_DEBUG")) d->dbg = atoi(dbg);
   if (const char* e = getenv("DE265HIP_SEPARATE_BS")) d->separate_bs = atoi(e) != 0;
   if (const char* e = getenv("DE265HIP_TWO_PASS_DEBLOCK")) d->two_pass_deblock = atoi(e) != 0;
+  if (const char* e = getenv("DE265HIP_RESID16_BIG")) d->resid16_big = atoi(e) != 0;
   if (const char* rw = getenv("DE265HIP_RUN_WAVES")) d->run_waves = std::min(RUN_WAVES, std::max(1, atoi(rw)));
   *out = d;
   return DE265HIP_OK;
@@ -1020,13 +1022,17 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
     // before them, on a second HIP stream per decoder: +1 % with one GOP stream, -8 % with three (six streams on four
     // hardware queues; -20 % with GPU_MAX_HW_QUEUES=8), so everything stays on the decoder's one stream.)
     if (pic->n_l0 > 0) {
-      const int nbig = pic->n_l0_size[3] + pic->n_l0_size[2], n8 = pic->n_l0_size[1], n4 = pic->n_l0_size[0];
-      KTimer t(dec, DE265HIP_K_RESID, (nbig > 0) + (n8 + n4 > 0));
-      if (nbig > 0)
-        hipLaunchKernelGGL(k_resid_big<PX>, dim3(nbig), dim3(256), 0, st, P, d0, d1, d2, pic->d_l0, pic->d_cval,
-                           pic->d_cpos, pic->d_scaling, pic->d_resid);
+      // k_resid_big: a 4-wavefront workgroup per 32x32 TU, then four 16x16 TUs per workgroup, a wavefront each (all of a
+      // picture's 16x16 TUs are then in flight at once; DE265HIP_RESID16_BIG=1: a workgroup per 16x16 TU as well);
+      // k_resid_small: a wavefront per 8x8 TU / per four 4x4 TUs
+      const int n32 = pic->n_l0_size[3], n16 = pic->n_l0_size[2], n8 = pic->n_l0_size[1], n4 = pic->n_l0_size[0];
+      const int n_wg = dec->resid16_big ? n32 + n16 : n32, n_wave = dec->resid16_big ? 0 : n16;
+      KTimer t(dec, DE265HIP_K_RESID, (n32 + n16 > 0) + (n8 + n4 > 0));
+      if (n32 + n16 > 0)
+        hipLaunchKernelGGL(k_resid_big<PX>, dim3(n_wg + ((n_wave + 3) >> 2)), dim3(256), 0, st, P, d0, d1, d2, pic->d_l0, n_wg, n_wave,
+                           pic->d_cval, pic->d_cpos, pic->d_scaling, pic->d_resid);
       if (n8 + n4 > 0)
-        hipLaunchKernelGGL(k_resid_small<PX>, dim3(n8 + ((n4 + 3) >> 2)), dim3(64), 0, st, P, d0, d1, d2, pic->d_l0, nbig, n8, n4,
+        hipLaunchKernelGGL(k_resid_small<PX>, dim3(n8 + ((n4 + 3) >> 2)), dim3(64), 0, st, P, d0, d1, d2, pic->d_l0, n32 + n16, n8, n4,
                            pic->d_cval, pic->d_cpos, pic->d_scaling, pic->d_resid);
     }
     if (pic->n_runs > 0) {

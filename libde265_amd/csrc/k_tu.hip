@@ -559,6 +559,102 @@ __device__ __forceinline__ void resid_small_body(const PicDev& P, const PlaneRef
   *d = (PX)clip3(0, (1 << bd) - 1, pred + r);
 }
 
+__device__ __forceinline__ int wave_max_dpp(int v);      // (defined with wave_sum_dpp below)
+
+// A 16x16 TU by ONE wavefront (four samples per lane): same arithmetic as resid_big_body, but a picture's ~6 000 TUs of
+// this size are all in flight at once as single wavefronts instead of queueing as 4-wavefront workgroups.
+// s_c / s_g: 256 int16 each, s_m: the 16x16 matrix M[j][i] = mat_dct[2j][i].
+template <typename PX>
+__device__ __forceinline__ void resid16_body(const PicDev& P, const PlaneRef& pl0, const PlaneRef& pl1, const PlaneRef& pl2,
+                                             const TuTask& t, int lane, const int16_t* __restrict__ coeff_val,
+                                             const uint16_t* __restrict__ coeff_pos, const uint8_t* __restrict__ scaling,
+                                             int16_t* __restrict__ resid, int16_t* s_c, int16_t* s_g, int8_t* s_m)
+{
+  constexpr int nT = 16, nS = 256, log2 = 4;
+  const int cIdx = t.c_idx;
+  const int bd = cIdx ? P.bd_chroma : P.bd_luma, maxv = (1 << bd) - 1;
+  const bool intra = t.flags & DE265HIP_TU_INTRA;
+  const bool bypass = t.flags & DE265HIP_TU_BYPASS;
+  const bool resid_only = t.flags & D265_TU_RESID_ONLY;
+  const int16_t* vals = coeff_val + t.coeff_offset;
+  const uint16_t* pos = coeff_pos + t.coeff_offset;
+  const PlaneRef pr = cIdx == 0 ? pl0 : (cIdx == 1 ? pl1 : pl2);
+  PX* dst = (PX*)pr.ptr + t.x0 + t.y0 * pr.stride;
+  // every global read first: the lane's first coefficient entry and its four prediction samples
+  const int n_coeff = t.n_coeff;
+  int v_first = 0, p_first = 0, pred[4] = { 0, 0, 0, 0 };
+  if (lane < n_coeff) { v_first = vals[lane]; p_first = pos[lane]; }
+  if (!resid_only) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int s = lane + 64 * k; pred[k] = dst[(s & 15) + (s >> 4) * pr.stride]; }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) s_c[lane + 64 * k] = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { const int e = lane + 64 * k; s_m[e] = c_dct_mat[2 * (e >> 4) * 32 + (e & 15)]; }
+  LDS_SYNC();
+  int lr = 0, lc = 0;
+  {
+    const int qp = t.qp;
+    if (bypass) {
+      for (int i = lane; i < n_coeff; i += 64) s_c[i == lane ? p_first : pos[i]] = (int16_t)(i == lane ? v_first : vals[i]);
+    } else if (!P.scaling_list) {
+      const int bdShift = bd + log2 - 9;
+      const int32_t fact = (int32_t)c_level_scale[qp % 6] << (qp / 6);
+      for (int i = lane; i < n_coeff; i += 64) {
+        const int p = i == lane ? p_first : pos[i];
+        const int vi = i == lane ? v_first : vals[i];
+        const int32_t cc = (int32_t)((uint32_t)(int32_t)vi * (uint32_t)fact + (uint32_t)(1 << (bdShift - 1)));
+        s_c[p] = (int16_t)clip3(-32768, 32767, cc >> bdShift);
+        lr = max(lr, p >> log2); lc = max(lc, p & (nT - 1));
+      }
+    } else {
+      const int bdShift = bd + log2 - 5;
+      const int matrixID = cIdx + (intra ? 0 : 3);
+      const uint8_t* scl = scaling + (96 + 384) + matrixID * nS;
+      for (int i = lane; i < n_coeff; i += 64) {
+        const int p = i == lane ? p_first : pos[i];
+        const int vi = i == lane ? v_first : vals[i];
+        const int fact = ((int)scl[p] * c_level_scale[qp % 6]) << (qp / 6);
+        long long cc = ((long long)vi * fact + (1ll << (bdShift - 1))) >> bdShift;
+        s_c[p] = (int16_t)(cc < -32768 ? -32768 : (cc > 32767 ? 32767 : cc));
+        lr = max(lr, p >> log2); lc = max(lc, p & (nT - 1));
+      }
+    }
+  }
+  LDS_SYNC();
+  int16_t* ro = resid + t.resid_offset;
+  if (bypass) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int s = lane + 64 * k, r = s_c[s];
+      if (resid_only) ro[s] = (int16_t)r;
+      else dst[(s & 15) + (s >> 4) * pr.stride] = (PX)clip3(0, maxv, pred[k] + r);
+    }
+    return;
+  }
+  // the largest row / column with a coefficient, over the wavefront (DPP row shifts + row broadcasts, as wave_sum_dpp)
+  const int lastRow = wave_max_dpp(lr), lastCol = wave_max_dpp(lc), ncols = lastCol + 1;
+  for (int tix = lane; tix < nT * ncols; tix += 64) {
+    const int c = tix % ncols, i = tix / ncols;
+    int sum = 0;
+    for (int j = 0; j <= lastRow; j++) sum += s_m[j * nT + i] * s_c[c + j * nT];
+    s_g[i * nT + c] = (int16_t)clip3(-32768, 32767, (sum + 64) >> 7);
+  }
+  LDS_SYNC();
+  const int post = 20 - bd, rnd2 = 1 << (post - 1);
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int s = lane + 64 * k;
+    const int y = s >> log2, i = s & (nT - 1);
+    int sum = 0;
+    for (int j = 0; j <= lastCol; j++) sum += s_m[j * nT + i] * s_g[y * nT + j];
+    const int out = (sum + rnd2) >> post;
+    if (resid_only) ro[s] = (int16_t)clip3(-32768, 32767, out);
+    else dst[i + y * pr.stride] = (PX)clip3(0, maxv, pred[k] + out);
+  }
+}
+
 #ifndef RESID_BIG_WAVES
 #define RESID_BIG_WAVES 8         // wavefronts per SIMD the register allocation of k_resid_big aims at (4: 112 VGPRs, 58 us per 4K B picture; 8: 64 VGPRs + 148 B scratch, 48 us)
 #endif
@@ -568,7 +664,7 @@ __device__ __forceinline__ void resid_small_body(const PicDev& P, const PlaneRef
 // 7.0 instead of 5.3 ms per 48 pictures with three GOP streams in flight).  tasks[] is sorted [32x32 | 16x16 | 8x8 | 4x4].
 template <typename PX>
 __global__ __launch_bounds__(256, RESID_BIG_WAVES)
-void k_resid_big(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const TuTask* __restrict__ tasks,
+void k_resid_big(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const TuTask* __restrict__ tasks, int n_wg, int n_wave,
                  const int16_t* __restrict__ coeff_val, const uint16_t* __restrict__ coeff_pos,
                  const uint8_t* __restrict__ scaling, int16_t* __restrict__ resid)
 {
@@ -576,11 +672,21 @@ void k_resid_big(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const TuTas
   __shared__ __attribute__((aligned(16))) int16_t s_c[32 * 32];
   __shared__ __attribute__((aligned(16))) int16_t s_g[32 * 32];
   __shared__ int s_last_row, s_last_col;
-  const TuTask t = tasks[blockIdx.x];
-  resid_big_body<PX>(P, pl0, pl1, pl2, t, coeff_val, coeff_pos, scaling, resid, s_mat, s_c, s_g, s_last_row, s_last_col);
+  // workgroups [0, n_wg): one TU by the whole workgroup (the 32x32 ones); the rest: four 16x16 TUs, one per wavefront
+  // (tasks [n_wg, n_wg + n_wave), no workgroup barrier on that path)
+  if ((int)blockIdx.x < n_wg) {
+    const TuTask t = tasks[blockIdx.x];
+    resid_big_body<PX>(P, pl0, pl1, pl2, t, coeff_val, coeff_pos, scaling, resid, s_mat, s_c, s_g, s_last_row, s_last_col);
+  } else {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int k = ((int)blockIdx.x - n_wg) * 4 + wave;
+    if (k >= n_wave) return;
+    const TuTask t = tasks[n_wg + k];
+    resid16_body<PX>(P, pl0, pl1, pl2, t, lane, coeff_val, coeff_pos, scaling, resid, s_c + 256 * wave, s_g + 256 * wave, s_mat + 256 * wave);
+  }
 }
-template __global__ void k_resid_big<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
-template __global__ void k_resid_big<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
+template __global__ void k_resid_big<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int, int, const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
+template __global__ void k_resid_big<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int, int, const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
 
 template <typename PX>
 __global__ __launch_bounds__(64)
@@ -726,6 +832,18 @@ __device__ __forceinline__ int wave_sum_dpp(int v)
   v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8  -> lane 15 of each row = row sum
   v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);   // row_bcast:15 into rows 1,3
   v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);   // row_bcast:31 into rows 2,3 -> lane 63 = total
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// wave64 maximum of non-negative values with the same DPP pattern; the result is returned to every lane
+__device__ __forceinline__ int wave_max_dpp(int v)
+{
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true));   // row_shr:1
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true));   // row_shr:2
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true));   // row_shr:4
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true));   // row_shr:8
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true));   // row_bcast:15
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true));   // row_bcast:31
   return __builtin_amdgcn_readlane(v, 63);
 }
 
