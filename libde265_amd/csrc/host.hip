@@ -1032,7 +1032,7 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
         hipLaunchKernelGGL(k_resid_big<PX>, dim3(n_wg + ((n_wave + 3) >> 2)), dim3(256), 0, st, P, d0, d1, d2, pic->d_l0, n_wg, n_wave,
                            pic->d_cval, pic->d_cpos, pic->d_scaling, pic->d_resid);
       if (n8 + n4 > 0)
-        hipLaunchKernelGGL(k_resid_small<PX>, dim3(n8 + ((n4 + 3) >> 2)), dim3(64), 0, st, P, d0, d1, d2, pic->d_l0, n32 + n16, n8, n4,
+        hipLaunchKernelGGL(k_resid_small<PX>, dim3((n8 + RESID_SPL - 1) / RESID_SPL + (n4 + 4 * RESID_SPL - 1) / (4 * RESID_SPL)), dim3(64), 0, st, P, d0, d1, d2, pic->d_l0, n32 + n16, n8, n4,
                            pic->d_cval, pic->d_cpos, pic->d_scaling, pic->d_resid);
     }
     if (pic->n_runs > 0) {

@@ -479,6 +479,11 @@ __device__ __forceinline__ void resid_big_body(const PicDev& P, const PlaneRef& 
 // level-0 work of run mode: inter TUs (residual added into the picture) and the residual-only
 // copies of intra TUs (int16 block into the residual buffer).
 // wave-level: `wblock` numbers the wavefronts of this TU size; all LDS pointers are this wavefront's own
+// RESID_SPL samples per lane: an 8x8 TU takes 16 lanes, a 4x4 TU 4 lanes, so a wavefront holds 4 / 16 TUs and all small
+// TUs of a picture are in flight at once (with one sample per lane a 4K B picture's ~30 000 wavefronts took several rounds).
+#ifndef RESID_SPL
+#define RESID_SPL 4
+#endif
 template <typename PX, int LOG2>
 __device__ __forceinline__ void resid_small_body(const PicDev& P, const PlaneRef& pl0, const PlaneRef& pl1, const PlaneRef& pl2,
                                                  const TuTask* __restrict__ tasks, int first, int count, int wblock, int lane,
@@ -486,15 +491,16 @@ __device__ __forceinline__ void resid_small_body(const PicDev& P, const PlaneRef
                                                  const uint8_t* __restrict__ scaling, int16_t* __restrict__ resid,
                                                  int16_t* s_c_w, int16_t* s_g_w, int8_t* s_dct, int8_t* s_dst)
 {
-  constexpr int nT = 1 << LOG2, nS = nT * nT, TPW = 64 / nS;      // TUs per wavefront: 4 or 1
+  constexpr int nT = 1 << LOG2, nS = nT * nT, SPL = RESID_SPL, LPT = nS / SPL, TPW = 64 / LPT;   // lanes per TU, TUs per wavefront
   int16_t (*s_c)[nS] = reinterpret_cast<int16_t (*)[nS]>(s_c_w);
   int16_t (*s_g)[nS] = reinterpret_cast<int16_t (*)[nS]>(s_g_w);
-  const int sub = lane / nS, s = lane % nS;
+  const int sub = lane / LPT, sl = lane % LPT;
   const int tix = wblock * TPW + sub;
   const bool live = tix < count;
   if (lane < nS) s_dct[lane] = c_dct_mat[(32 / nT) * (lane / nT) * 32 + (lane % nT)];
   if (LOG2 == 2 && lane < 16) s_dst[lane] = c_dst_mat[lane];
-  s_c[sub][s] = 0;
+#pragma unroll
+  for (int k = 0; k < SPL; k++) s_c[sub][sl + LPT * k] = 0;
   TuTask t;
   if (live) t = tasks[first + tix];
   LDS_SYNC();
@@ -503,60 +509,82 @@ __device__ __forceinline__ void resid_small_body(const PicDev& P, const PlaneRef
   const bool intra = live && (t.flags & DE265HIP_TU_INTRA);
   const bool bypass = live && (t.flags & DE265HIP_TU_BYPASS);
   const bool tskip = live && (t.flags & DE265HIP_TU_TSKIP);
+  const bool to_pic = live && !(t.flags & D265_TU_RESID_ONLY);
   // every global read of the TU goes out as soon as its record is there (one memory latency for coefficients and
   // prediction together, not two in sequence)
-  const bool has_c = live && s < (int)t.n_coeff;
-  int p = 0, v = 0, pred = 0;
-  PX* d = nullptr;
-  if (has_c) { p = coeff_pos[t.coeff_offset + s]; v = coeff_val[t.coeff_offset + s]; }
-  if (live && !(t.flags & D265_TU_RESID_ONLY)) {
+  int p[SPL], v[SPL], pred[SPL];
+  bool has_c[SPL];
+  PX* d = nullptr; int dstride = 0;
+  if (to_pic) {
     const PlaneRef pr = cIdx == 0 ? pl0 : (cIdx == 1 ? pl1 : pl2);
-    d = (PX*)pr.ptr + t.x0 + (s % nT) + (t.y0 + s / nT) * pr.stride;
-    pred = *d;
+    d = (PX*)pr.ptr + t.x0 + t.y0 * pr.stride; dstride = pr.stride;
   }
-  if (has_c) {
+#pragma unroll
+  for (int k = 0; k < SPL; k++) {
+    const int s = sl + LPT * k;
+    has_c[k] = live && s < (int)t.n_coeff;
+    p[k] = 0; v[k] = 0; pred[k] = 0;
+    if (has_c[k]) { p[k] = coeff_pos[t.coeff_offset + s]; v[k] = coeff_val[t.coeff_offset + s]; }
+    if (to_pic) pred[k] = d[(s % nT) + (s / nT) * dstride];
+  }
+#pragma unroll
+  for (int k = 0; k < SPL; k++) {
+    if (!has_c[k]) continue;
     int out;
-    if (bypass) out = v;
+    if (bypass) out = v[k];
     else if (!P.scaling_list) {
       const int bdShift = bd + LOG2 - 9;
       const int32_t fact = (int32_t)c_level_scale[t.qp % 6] << (t.qp / 6);
-      const int32_t cc = (int32_t)((uint32_t)v * (uint32_t)fact + (uint32_t)(1 << (bdShift - 1)));   // 32-bit wrap
+      const int32_t cc = (int32_t)((uint32_t)v[k] * (uint32_t)fact + (uint32_t)(1 << (bdShift - 1)));   // 32-bit wrap
       out = clip3(-32768, 32767, cc >> bdShift);
     } else {
       const int bdShift = bd + LOG2 - 5;
       const int matrixID = cIdx + (intra ? 0 : 3);
-      const int m = scaling[(LOG2 == 2 ? 0 : 96) + matrixID * nS + p];
+      const int m = scaling[(LOG2 == 2 ? 0 : 96) + matrixID * nS + p[k]];
       const int fact = (m * c_level_scale[t.qp % 6]) << (t.qp / 6);
-      long long cc = ((long long)v * fact + (1ll << (bdShift - 1))) >> bdShift;
+      long long cc = ((long long)v[k] * fact + (1ll << (bdShift - 1))) >> bdShift;
       out = (int)(cc < -32768 ? -32768 : (cc > 32767 ? 32767 : cc));
     }
-    s_c[sub][p] = (int16_t)out;
+    s_c[sub][p[k]] = (int16_t)out;
   }
   LDS_SYNC();
   if (!live) return;
-  int r;
-  if (bypass) r = s_c[sub][s];
-  else if (tskip) r = ((int32_t)((uint32_t)(int32_t)s_c[sub][s] << (5 + LOG2)) + (1 << (19 - bd))) >> (20 - bd);
-  else {
+  int r[SPL];
+  if (bypass) {
+#pragma unroll
+    for (int k = 0; k < SPL; k++) r[k] = s_c[sub][sl + LPT * k];
+  } else if (tskip) {
+#pragma unroll
+    for (int k = 0; k < SPL; k++)
+      r[k] = ((int32_t)((uint32_t)(int32_t)s_c[sub][sl + LPT * k] << (5 + LOG2)) + (1 << (19 - bd))) >> (20 - bd);
+  } else {
     const bool is_dst = LOG2 == 2 && cIdx == 0 && intra;
     const int8_t* M = is_dst ? s_dst : s_dct;
-    {                                   // first stage: lane -> (row i, column c)
-      const int i = s / nT, c = s % nT;
+#pragma unroll
+    for (int k = 0; k < SPL; k++) {     // first stage: sample -> (row i, column c)
+      const int s = sl + LPT * k, i = s / nT, c = s % nT;
       int sum = 0;
 #pragma unroll
       for (int j = 0; j < nT; j++) sum += M[j * nT + i] * s_c[sub][c + j * nT];
       s_g[sub][i * nT + c] = (int16_t)clip3(-32768, 32767, (sum + 64) >> 7);
     }
     LDS_SYNC();
-    const int y = s / nT, i = s % nT;
-    int sum = 0;
 #pragma unroll
-    for (int j = 0; j < nT; j++) sum += M[j * nT + i] * s_g[sub][y * nT + j];
-    r = (sum + (1 << (19 - bd))) >> (20 - bd);
-    if (is_dst) r = clip3(-32768, 32767, r);                   // DST clips its second stage, the DCT does not
+    for (int k = 0; k < SPL; k++) {
+      const int s = sl + LPT * k, y = s / nT, i = s % nT;
+      int sum = 0;
+#pragma unroll
+      for (int j = 0; j < nT; j++) sum += M[j * nT + i] * s_g[sub][y * nT + j];
+      r[k] = (sum + (1 << (19 - bd))) >> (20 - bd);
+      if (is_dst) r[k] = clip3(-32768, 32767, r[k]);             // DST clips its second stage, the DCT does not
+    }
   }
-  if (t.flags & D265_TU_RESID_ONLY) { resid[t.resid_offset + s] = (int16_t)clip3(-32768, 32767, r); return; }
-  *d = (PX)clip3(0, (1 << bd) - 1, pred + r);
+#pragma unroll
+  for (int k = 0; k < SPL; k++) {
+    const int s = sl + LPT * k;
+    if (!to_pic) resid[t.resid_offset + s] = (int16_t)clip3(-32768, 32767, r[k]);
+    else d[(s % nT) + (s / nT) * dstride] = (PX)clip3(0, (1 << bd) - 1, pred[k] + r[k]);
+  }
 }
 
 __device__ __forceinline__ int wave_max_dpp(int v);      // (defined with wave_sum_dpp below)
@@ -694,15 +722,16 @@ void k_resid_small(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const TuT
                    const int16_t* __restrict__ coeff_val, const uint16_t* __restrict__ coeff_pos,
                    const uint8_t* __restrict__ scaling, int16_t* __restrict__ resid)
 {
-  __shared__ int16_t s_c[64];
-  __shared__ int16_t s_g[64];
+  __shared__ int16_t s_c[64 * RESID_SPL];
+  __shared__ int16_t s_g[64 * RESID_SPL];
   __shared__ int8_t s_m[80];            // 64: M[j][i] = mat_dct[(32/nT)*j][i]; 16: the DST matrix
   const int lane = threadIdx.x;
-  if ((int)blockIdx.x < n8)
+  const int wg8 = (n8 + RESID_SPL - 1) / RESID_SPL;           // wavefronts of 8x8 TUs (RESID_SPL TUs each), then 4x4 (4 RESID_SPL each)
+  if ((int)blockIdx.x < wg8)
     resid_small_body<PX, 3>(P, pl0, pl1, pl2, tasks, nbig, n8, blockIdx.x, lane, coeff_val, coeff_pos, scaling, resid,
                             s_c, s_g, s_m, s_m + 64);
   else
-    resid_small_body<PX, 2>(P, pl0, pl1, pl2, tasks, nbig + n8, n4, (int)blockIdx.x - n8, lane, coeff_val, coeff_pos, scaling,
+    resid_small_body<PX, 2>(P, pl0, pl1, pl2, tasks, nbig + n8, n4, (int)blockIdx.x - wg8, lane, coeff_val, coeff_pos, scaling,
                             resid, s_c, s_g, s_m, s_m + 64);
 }
 template __global__ void k_resid_small<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int, int, int, const int16_t*, const uint16_t*, const uint8_t*, int16_t*);

@@ -39,6 +39,9 @@ __global__ void k_resid_small(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask
 #define RUN_TICKET_SLOTS 8   // slots of a k_run ticket: that many micro runs (slot q and q+4 .. by the same wavefront, one after
                              // the other), or one ordinary run in slot 0
 #endif
+#ifndef RESID_SPL
+#define RESID_SPL 4          // samples per lane of k_resid_small: RESID_SPL 8x8 TUs / 4 RESID_SPL 4x4 TUs per wavefront
+#endif
 #define RUN_WAVES 4          // wavefronts per run workgroup (one per SIMD of a CU); blockDim.x = 64..64*RUN_WAVES
 template <typename PX, int BOX>
 __global__ void k_run(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*,
