@@ -764,6 +764,11 @@ void k_tu(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const TuTask* __re
 #define RUN_TILE_H_OF(B) ((B) + 33)
 #define RUN_TILE_P_OF(B) ((((B) + 40) + 7) & ~7)
 #define RUN_TILE_P_MAX RUN_TILE_P_OF(64)
+#ifndef RUN_POLL_FAST
+#define RUN_POLL_FAST 8        // s_sleep units (64 cycles) between the first RUN_POLL_FAST_N polls of a producer's flag, then RUN_POLL_SLOW
+#define RUN_POLL_FAST_N 4
+#define RUN_POLL_SLOW 16
+#endif
 #define RUN_SPIN_LIMIT (1 << 21)      // x ~1 us per poll: a couple of seconds, then the picture fails instead of hanging
 
 // 8 consecutive samples <-> 8 x uint16 in LDS
@@ -1402,7 +1407,7 @@ __device__ __forceinline__ void micro_run(const PicDev& P, const PlaneRef& pl0, 
     int spins = 0;
     uint32_t f = (i == lane) ? flag0 : gen - 1u;
     while (f != gen && !(RUN_DBG & 32)) {
-      if (spins) { if (spins < 4) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(16); }
+      if (spins) { if (spins < RUN_POLL_FAST_N) __builtin_amdgcn_s_sleep(RUN_POLL_FAST); else __builtin_amdgcn_s_sleep(RUN_POLL_SLOW); }
       if (++spins > RUN_SPIN_LIMIT) { atomicExch(err, 1u); break; }
       f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1642,7 +1647,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
       while (f != gen && !(RUN_DBG & 32)) {                                  // (dbg 32: timing-only ablation, ignores producers)
         // back off: hundreds of waiting wavefronts polling at full rate starve the fabric (s_sleep 64 instead of 16 here
         // costs 3 % of an all-intra picture: the flag is seen up to 2 us late)
-        if (spins) { if (spins < 4) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(16); }
+        if (spins) { if (spins < RUN_POLL_FAST_N) __builtin_amdgcn_s_sleep(RUN_POLL_FAST); else __builtin_amdgcn_s_sleep(RUN_POLL_SLOW); }
         if (++spins > RUN_SPIN_LIMIT) { atomicExch(err, 1u); break; }           // never hang the grid
         f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
