@@ -309,6 +309,12 @@ int  de265hip_set_profiling(de265hip_decoder*, int enable);
 int  de265hip_get_kernel_times(de265hip_decoder*, double ms[DE265HIP_K_COUNT],
                                int64_t launches[DE265HIP_K_COUNT], int reset);
 
+/* Diagnostic: the neighbour units (bit u as in the availability masks of intrapred.cc:437-527: 4-sample units of the
+ * left column bottom-up, the corner, the top row left to right) whose samples an intra TU of this size and mode can
+ * read - prediction (intrapred.cc:903-1069), edge filters and smoothing incl. the strong-smoothing decision (:816-889).
+ * The build uses it to order intra TUs only behind the producers they really depend on. */
+int  de265hip_intra_used_units(int log2_size, int intra_mode, int luma, uint64_t* units);
+
 /* Host helper: edge-flag derivation (deblock.cc:31-225 derive_edgeFlags) from
  * CU/TU structure, for hosts that do not already run it.  cb_log2_size /
  * cb_part_mode are per MinCb unit (top-left only, 0 elsewhere), tu_split per

@@ -21,7 +21,7 @@ EXPORTS = [
     "de265hip_dpb_alloc", "de265hip_dpb_upload", "de265hip_dpb_download", "de265hip_dpb_plane", "de265hip_dpb_info",
     "de265hip_picture_build", "de265hip_picture_run", "de265hip_decoder_sync", "de265hip_picture_free",
     "de265hip_decode_picture", "de265hip_picture_get_stats",
-    "de265hip_set_profiling", "de265hip_get_kernel_times", "de265hip_derive_edge_flags",
+    "de265hip_set_profiling", "de265hip_get_kernel_times", "de265hip_derive_edge_flags", "de265hip_intra_used_units",
     "de265hip_recorder_new", "de265hip_recorder_free", "de265hip_record_tu", "de265hip_record_pu",
     "de265hip_record_pcm", "de265hip_record_slice", "de265hip_record_ctb", "de265hip_record_blk_planes",
     "de265hip_recorder_desc", "de265hip_recorder_submit",
@@ -67,6 +67,7 @@ def lib():
     L.de265hip_picture_get_stats.argtypes = [vp, pp(_abi.PictureStats)]
     L.de265hip_set_profiling.argtypes = [vp, i32]
     L.de265hip_get_kernel_times.argtypes = [vp, pp(C.c_double), pp(C.c_int64), i32]
+    L.de265hip_intra_used_units.argtypes = [i32, i32, i32, pp(C.c_uint64)]
     L.de265hip_derive_edge_flags.argtypes = [pp(_abi.PicParams), pp(_abi.SliceParams), i32, pp(_abi.CtbInfo),
                                              vp, vp, vp, vp]
     L.de265hip_recorder_new.argtypes = [pp(vp), pp(_abi.PicParams), vp]

@@ -213,6 +213,8 @@ static void build_used_units()
         g_used_units[l2 - 2][mode][luma] = u;
       }
 }
+static void ensure_used_units() { static std::once_flag once; std::call_once(once, build_used_units); }
+
 // the units whose samples a TU with availability `avail` really reads: the used ones that are available, plus, for
 // every used but unavailable one, the unit its samples are substituted from (intrapred.cc:395-431)
 static uint64_t needed_units(uint64_t used, uint64_t avail)
@@ -457,7 +459,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
 
   // dependencies between intra TUs from the units each mode reads (DE265HIP_NO_MODE_DEPS: from every available unit)
   const bool mode_deps = getenv("DE265HIP_NO_MODE_DEPS") == nullptr;
-  { static std::once_flag once; std::call_once(once, build_used_units); }
+  ensure_used_units();
   // ---- TU tasks: availability, dependency level, stable sort by level
   std::vector<TuTask> tasks; tasks.reserve(d->n_tus);
   std::vector<int> levels; levels.reserve(d->n_tus);
@@ -1165,6 +1167,16 @@ int de265hip_get_kernel_times(de265hip_decoder* dec, double ms[DE265HIP_K_COUNT]
     if (launches) launches[k] = dec->launches[k];
     if (reset) { dec->ms[k] = 0; dec->launches[k] = 0; }
   }
+  return 0;
+}
+
+// ---- diagnostic: the neighbour units an intra TU of this size and mode reads (the table behind the mode-aware
+// dependencies; tests check it against the oracle's predictors by perturbing border samples)
+int de265hip_intra_used_units(int log2_size, int intra_mode, int luma, uint64_t* units)
+{
+  if (log2_size < 2 || log2_size > 5 || intra_mode < 0 || intra_mode > 34 || !units) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  ensure_used_units();
+  *units = g_used_units[log2_size - 2][intra_mode][luma ? 1 : 0];
   return 0;
 }
 

@@ -185,3 +185,48 @@ def test_recorder_accumulates_the_same_description():
     with pytest.raises(backend.De265HipError):
         backend._chk(backend.lib().de265hip_record_ctb(rec._h, 10 ** 6, C.byref(d.ctbs[0])), "record_ctb")
     rec.free()
+
+
+def test_mode_aware_dependency_table_covers_every_sample_the_predictors_read():
+    """Host logic behind the run kernel's schedule (de265hip_intra_used_units): an intra TU only waits for the producers
+    of the neighbour units its mode can read.  Checked against the oracle's predictors by brute force: for every size,
+    mode and component type, a border sample whose change alters the prediction (random borders, and smooth ramps that
+    switch the strong bilinear smoothing on) must lie in a unit the table names.  This is the check that would have
+    caught the strong-smoothing decision samples p[+-32] missing from the table."""
+    import ctypes as C
+    from libde265_amd import backend
+    import pyoracle
+    L, O = backend.lib(), pyoracle.lib()
+    rng = np.random.default_rng(77)
+    bd = 10
+    for log2 in (2, 3, 4, 5):
+        nT = 1 << log2
+        NB, Cc, corner = 4 * nT + 1, 2 * nT, nT >> 1
+        unit_of = lambda q: (q >> 2) if q < Cc else (corner if q == Cc else corner + 1 + ((q - Cc - 1) >> 2))
+        bases = [rng.integers(0, 1 << bd, NB) for _ in range(3)]
+        bases.append(np.linspace(400, 460, NB).astype(np.int64))          # smooth: bilinear variant at 32x32 luma
+        bases.append(np.full(NB, 512, np.int64))                          # flat
+        for luma in (1, 0):
+            for mode in range(35):
+                u = C.c_uint64()
+                assert L.de265hip_intra_used_units(log2, mode, luma, C.byref(u)) == 0
+                used = u.value
+                for base in bases:
+                    border = base.astype(np.uint16)
+                    ref = np.zeros((nT, nT), np.uint16)
+                    O.oracle_intra_predict(bd, 1, ref.ctypes.data, nT, nT, 0 if luma else 1, mode,
+                                           border.ctypes.data + Cc * 2)
+                    for q in range(NB):
+                        if (used >> unit_of(q)) & 1:
+                            continue                                      # named by the table: nothing to prove
+                        for delta in (37, -41, 300):
+                            b2 = border.copy()
+                            b2[q] = np.uint16(min(max(int(b2[q]) + delta, 0), (1 << bd) - 1))
+                            out = np.zeros((nT, nT), np.uint16)
+                            O.oracle_intra_predict(bd, 1, out.ctypes.data, nT, nT, 0 if luma else 1, mode,
+                                                   b2.ctypes.data + Cc * 2)
+                            assert np.array_equal(out, ref), \
+                                "size %d mode %d luma %d: border entry %d (unit %d) changes the prediction but is not in the table %x" % (
+                                    nT, mode, luma, q, unit_of(q), used)
+    bad = C.c_uint64()
+    assert L.de265hip_intra_used_units(6, 0, 1, C.byref(bad)) != 0
