@@ -930,7 +930,7 @@ __device__ __forceinline__ int run_gather_addr(int p, int nT, int xB, int yB, ui
 
 // Off-chain preparation of sample s of the run (one thread per sample).
 template <int RUN_TILE_P>
-__device__ __forceinline__ void run_prepare_sample(int s, const uint4* s_task, const uint8_t* s_own, int16_t* s_res,
+__device__ __forceinline__ void run_prepare_sample(int s, const uint4* s_task, const uint8_t* s_own, int32_t* s_res,
                                                    uint32_t* s_ctl, uint32_t* s_ex, uint32_t* s_mine,
                                                    const int16_t* __restrict__ resid, uint32_t res_base, int const_addr)
 {
@@ -940,10 +940,13 @@ __device__ __forceinline__ void run_prepare_sample(int s, const uint4* s_task, c
   const int samp = (r.y & 0x3FFF) >> 2, local = s - samp;
   const int x = local & (nT - 1), y = local >> log2;
   const int xB = (r.w >> 13) & 0x7F, yB = (r.w >> 20) & 0x7F;
-  s_res[s] = (r.x & RTU_CBF) ? resid[res_base + ((r.w >> 1) & 0xFFF) + local] : (int16_t)0;
+  const int rs16 = (r.x & RTU_CBF) ? (int)resid[res_base + ((r.w >> 1) & 0xFFF) + local] : 0;
   if ((x & 3) == 0) atomicOr(&s_mine[yB + y], 1u << ((xB + x) >> 2));
   const int kind = (r.x >> 24) & 3;
   const bool vert = r.x & RTU_VERT;
+  // the sample's residual and, above it, its angular weight ((x+1) or (y+1)) * angle & 31: the chain's common path then
+  // needs neither the TU's angle nor the lane's position
+  s_res[s] = (rs16 & 0xFFFF) | ((__mul24(vert ? y + 1 : x + 1, (int)(int8_t)(r.y >> 24)) & 31) << 16);
   const int C = 2 * nT;
   int A = C - 1 - y, B = C + 1 + x;                   // planar / DC: A = left[y], B = top[x]
   if (kind >= 2) {                                    // angular (intrapred.cc:903-1069), reference array evaluated in place
@@ -1050,7 +1053,7 @@ __device__ __forceinline__ void run_chain_small(uint32_t w0, int angle, int c, i
 // (A/B on an all-intra 4K picture: 16x16 and 32x32 together 2.07 ms, only 32x32 together 2.18 ms, none 2.38 ms.)
 template <int RUN_TILE_P, int CH>
 __device__ __forceinline__ void run_big_predict(uint32_t w0, int angle, int c, int maxv, int tid, int nthr, int log2,
-                                                const uint32_t* ctl, const int16_t* res, char* tile_b, int tb,
+                                                const uint32_t* ctl, const int32_t* res, char* tile_b, int tb,
                                                 const uint16_t* bord, int tr, int bl, int b0, int dc)
 {
   const int nT = 1 << log2, nS = nT * nT;
@@ -1061,7 +1064,7 @@ __device__ __forceinline__ void run_big_predict(uint32_t w0, int angle, int c, i
   for (int base = tid; base < nS; base += CH * nthr) {
     uint32_t cw[CH]; int rs[CH], A[CH], B[CH];
 #pragma unroll
-    for (int u = 0; u < CH; u++) { cw[u] = ctl[base + u * nthr]; rs[u] = res[base + u * nthr]; }
+    for (int u = 0; u < CH; u++) { cw[u] = ctl[base + u * nthr]; rs[u] = (int)(int16_t)res[base + u * nthr]; }
 #pragma unroll
     for (int u = 0; u < CH; u++) {
       if (smooth) { A[u] = bord[cw[u] & 0xFF]; B[u] = bord[(cw[u] >> 8) & 0xFF]; }
@@ -1092,7 +1095,7 @@ __device__ __forceinline__ void run_big_predict(uint32_t w0, int angle, int c, i
 
 template <int RUN_TILE_P>
 __device__ __forceinline__ void run_chain_big(const PicDev& P, uint32_t w0, int angle, int c, int maxv, int tid, int nthr, int log2,
-                                              const uint32_t* ctl, const int16_t* res, char* tile_b, int tb,
+                                              const uint32_t* ctl, const int32_t* res, char* tile_b, int tb,
                                               const uint32_t* s_ex, int k, RunShared& S, int* s_dc)
 {
   const int nT = 1 << log2, nS = nT * nT, NB = 4 * nT + 1, C = 2 * nT;
@@ -1478,7 +1481,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   __shared__ RunShared S;                         // border arrays of the 16x16 / 32x32 TU being reconstructed
   __shared__ int s_dc;
   __shared__ __attribute__((aligned(16))) uint16_t tile[RUN_TILE_H * RUN_TILE_P + 8];
-  __shared__ __attribute__((aligned(16))) int16_t s_res[BOX * BOX + 64];
+  __shared__ __attribute__((aligned(16))) int32_t s_res[BOX * BOX + 64];   // residual | angular weight << 16 per sample (micro runs: int16 residual slices)
   __shared__ uint32_t s_ctl[BOX * BOX + 64];      // per sample: operand addresses / border lanes (run_prepare_sample)
   __shared__ uint32_t s_ex[MAX_TUS];              // per TU: window addresses of the TU-wide operands (planar, edge filter)
   __shared__ uint4 s_task[MAX_TUS];               // the run's TUs, packed (run_tu_pack)
@@ -1491,7 +1494,6 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   char* tile_b = reinterpret_cast<char*>(tile);
   const RunLane L4{ lane & 3, (lane >> 2) & 3, (((lane >> 2) & 3) * RUN_TILE_P + (lane & 3)) * 2 };
   const RunLane L8{ lane & 7, (lane >> 3) & 7, (((lane >> 3) & 7) * RUN_TILE_P + (lane & 7)) * 2 };
-  const uint32_t lane_xy1 = (uint32_t)(L4.x + 1) | ((uint32_t)(L4.y + 1) << 8) | ((uint32_t)(L8.x + 1) << 16) | ((uint32_t)(L8.y + 1) << 24);
   const uint32_t lane_toff = (uint32_t)L4.toff2 | ((uint32_t)L8.toff2 << 16);
   // persistent workgroup: the grid is only as wide as the picture's widest dependency level
   // (waiting workgroups would just occupy LDS), every one pulls tickets until none are left.
@@ -1551,7 +1553,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
       for (int i = 1; i < RUN_TICKET_SLOTS; i++) mine = q == i ? slv[i] : mine;     // (scalar selects: no register array)
       if (mine != 0xFFFFFFFFu)
         micro_run<PX>(P, pl0, pl1, pl2, runs, deps, sync, err, tasks, resid, tile + (q & 3) * MICRO_SLICE,
-                      s_res + (q & 3) * MICRO_RES, mine & 0x7FFFFFFFu, lane, gen, dbg);
+                      reinterpret_cast<int16_t*>(s_res) + (q & 3) * MICRO_RES, mine & 0x7FFFFFFFu, lane, gen, dbg);
     }
     continue;
   }
@@ -1701,17 +1703,16 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
     uint2 r_nxt = *reinterpret_cast<const uint2*>(task_b + 16 * min(j0 + 1, jl));
     int sl = lane & ((w0 & RTU_IS4) ? 15 : 63);
     uint32_t ctl = *reinterpret_cast<const uint32_t*>(ctl_b + (w1 & 0x3FFF) + 4 * sl);
-    int rs = *reinterpret_cast<const int16_t*>(res_b + ((w1 & 0x3FFF) >> 1) + 2 * sl);
+    int rs = *reinterpret_cast<const int32_t*>(res_b + (w1 & 0x3FFF) + 4 * sl);      // residual | angular weight << 16
     int j = j0;
 #define RUN_CHAIN_HEAD()                                                                                                   \
       /* off the chain: next TU's record -> its per-lane operands; the record after next */                               \
       const uint32_t n0 = j + 1 < j1 ? __builtin_amdgcn_readfirstlane(r_nxt.x) : ~0u, n1 = __builtin_amdgcn_readfirstlane(r_nxt.y); \
       const int nsl = lane & ((n0 & RTU_IS4) ? 15 : 63);                                                                   \
       const uint32_t nctl = *reinterpret_cast<const uint32_t*>(ctl_b + (n1 & 0x3FFF) + 4 * nsl);                           \
-      const int nrs = *reinterpret_cast<const int16_t*>(res_b + ((n1 & 0x3FFF) >> 1) + 2 * nsl);                          \
+      const int nrs = *reinterpret_cast<const int32_t*>(res_b + (n1 & 0x3FFF) + 4 * nsl);                                 \
       r_nxt = *reinterpret_cast<const uint2*>(task_b + 16 * min(j + 2, jl));                                               \
-      const int tb = w0 & 0x7FFF;                                                                                          \
-      const int angle = (int)(int8_t)(w1 >> 24);
+      const int tb = w0 & 0x7FFF;
 #define RUN_CHAIN_NEXT() w0 = n0; w1 = n1; ctl = nctl; rs = nrs; j++;
     // One pass per level: the big TUs together, then the own list's TUs of the level, then the barrier that closes it.
     // The own TUs are walked in a tight inner loop over the common kind (angular, not smoothed, 4x4 / 8x8: spelled out
@@ -1747,13 +1748,12 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
           const int A = *reinterpret_cast<uint16_t*>(tile_b + (ctl & 0xFFFF));
           const int B = *reinterpret_cast<uint16_t*>(tile_b + (ctl >> 16));
 #endif
-          // per-lane constants of both TU sizes live in one register each: byte 0/1 = x+1 / y+1 of the 4x4 position,
-          // byte 2/3 the same for 8x8; the window offsets of the two sizes in the halves of lane_toff
-          const int a1 = (lane_xy1 >> (((w0 & RTU_IS4) ? 0 : 16) + ((w0 & RTU_VERT) ? 8 : 0))) & 0xFF;
+          // the sample's angular weight comes prepared with its residual; the window offsets of the two TU sizes are the
+          // halves of the per-lane constant lane_toff
           const int toff2 = (w0 & RTU_IS4) ? (lane_toff & 0xFFFF) : (lane_toff >> 16);
-          const int f = __mul24(a1, angle) & 31;
+          const int f = (rs >> 16) & 31;
           const int pv = (__mul24(f, B - A) + (A << 5) + 16) >> 5;
-          *reinterpret_cast<uint16_t*>(tile_b + tb + toff2) = (uint16_t)clip3(0, maxv, pv + rs);
+          *reinterpret_cast<uint16_t*>(tile_b + tb + toff2) = (uint16_t)clip3(0, maxv, pv + (int)(int16_t)rs);
           WAVE_BARRIER_ONLY();
           RUN_CHAIN_NEXT()
         }
@@ -1768,8 +1768,9 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
         const int B0 = *reinterpret_cast<uint16_t*>(tile_b + (ctl >> 16));
         const int A0 = (w0 & RTU_SMOOTH) ? 0 : (int)*reinterpret_cast<uint16_t*>(tile_b + (ctl & 0xFFFF));   // (smoothed: indices, not an address)
 #endif
-        if (w0 & RTU_IS4) run_chain_small<2>(w0, angle, c, maxv, lane, L4, ctl, rs, tile_b, tb, s_ex, j, A0, B0);
-        else run_chain_small<3>(w0, angle, c, maxv, lane, L8, ctl, rs, tile_b, tb, s_ex, j, A0, B0);
+        const int angle = (int)(int8_t)(w1 >> 24);
+        if (w0 & RTU_IS4) run_chain_small<2>(w0, angle, c, maxv, lane, L4, ctl, (int)(int16_t)rs, tile_b, tb, s_ex, j, A0, B0);
+        else run_chain_small<3>(w0, angle, c, maxv, lane, L8, ctl, (int)(int16_t)rs, tile_b, tb, s_ex, j, A0, B0);
         RUN_CHAIN_NEXT()
       }
       if (epoch >= n_epochs) break;
