@@ -46,6 +46,7 @@ struct de265hip_decoder {
   Slot spare;                         // SAO output target, swapped with the decoded slot
   uint32_t* d_err = nullptr;          // set by a kernel whose bounded spin expired
   int run_waves = RUN_WAVES;          // DE265HIP_RUN_WAVES: wavefronts per run workgroup (experiments)
+  bool resid_one_launch = true;       // DE265HIP_RESID_ONE_LAUNCH=0: 8x8 / 4x4 residual TUs in their own launch (k_resid_small)
   bool resid16_big = false;           // DE265HIP_RESID16_BIG: 16x16 residual TUs by 4-wavefront workgroups (k_resid_big) instead of one wavefront
   bool two_pass_deblock = false;      // DE265HIP_TWO_PASS_DEBLOCK: k_deblock<V> then k_deblock<H> instead of k_deblock_fused
   bool separate_bs = false;           // DE265HIP_SEPARATE_BS: bS by its own kernel instead of inside the deblocking kernels
@@ -334,6 +335,7 @@ int de265hip_decoder_new(de265hip_decoder** out, int device)
   if (const char* e = getenv("DE265HIP_SEPARATE_BS")) d->separate_bs = atoi(e) != 0;
   if (const char* e = getenv("DE265HIP_TWO_PASS_DEBLOCK")) d->two_pass_deblock = atoi(e) != 0;
   if (const char* e = getenv("DE265HIP_RESID16_BIG")) d->resid16_big = atoi(e) != 0;
+  if (const char* e = getenv("DE265HIP_RESID_ONE_LAUNCH")) d->resid_one_launch = atoi(e) != 0;
   if (const char* rw = getenv("DE265HIP_RUN_WAVES")) d->run_waves = std::min(RUN_WAVES, std::max(1, atoi(rw)));
   *out = d;
   return DE265HIP_OK;
@@ -1029,13 +1031,22 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
       // k_resid_small: a wavefront per 8x8 TU / per four 4x4 TUs
       const int n32 = pic->n_l0_size[3], n16 = pic->n_l0_size[2], n8 = pic->n_l0_size[1], n4 = pic->n_l0_size[0];
       const int n_wg = dec->resid16_big ? n32 + n16 : n32, n_wave = dec->resid16_big ? 0 : n16;
-      KTimer t(dec, DE265HIP_K_RESID, (n32 + n16 > 0) + (n8 + n4 > 0));
-      if (n32 + n16 > 0)
-        hipLaunchKernelGGL(k_resid_big<PX>, dim3(n_wg + ((n_wave + 3) >> 2)), dim3(256), 0, st, P, d0, d1, d2, pic->d_l0, n_wg, n_wave,
-                           pic->d_cval, pic->d_cpos, pic->d_scaling, pic->d_resid);
-      if (n8 + n4 > 0)
-        hipLaunchKernelGGL(k_resid_small<PX>, dim3((n8 + RESID_SPL - 1) / RESID_SPL + (n4 + 4 * RESID_SPL - 1) / (4 * RESID_SPL)), dim3(64), 0, st, P, d0, d1, d2, pic->d_l0, n32 + n16, n8, n4,
-                           pic->d_cval, pic->d_cpos, pic->d_scaling, pic->d_resid);
+      // the small TUs ride in k_resid_big's launch too, as wavefront slots behind the 16x16 ones (one launch less per picture:
+      // one GOP stream 2 870 -> 2 950 frames/s, three streams unchanged; DE265HIP_RESID_ONE_LAUNCH=0: k_resid_small launch)
+      const bool one = dec->resid_one_launch && !dec->resid16_big;
+      const int w_small = (n8 + RESID_SPL - 1) / RESID_SPL + (n4 + 4 * RESID_SPL - 1) / (4 * RESID_SPL);
+      KTimer t(dec, DE265HIP_K_RESID, one ? 1 : (n32 + n16 > 0) + (n8 + n4 > 0));
+      if (one)
+        hipLaunchKernelGGL(k_resid_big<PX>, dim3(n_wg + ((n_wave + w_small + 3) >> 2)), dim3(256), 0, st, P, d0, d1, d2, pic->d_l0, n_wg, n_wave,
+                           n8, n4, pic->d_cval, pic->d_cpos, pic->d_scaling, pic->d_resid);
+      else {
+        if (n32 + n16 > 0)
+          hipLaunchKernelGGL(k_resid_big<PX>, dim3(n_wg + ((n_wave + 3) >> 2)), dim3(256), 0, st, P, d0, d1, d2, pic->d_l0, n_wg, n_wave,
+                             0, 0, pic->d_cval, pic->d_cpos, pic->d_scaling, pic->d_resid);
+        if (n8 + n4 > 0)
+          hipLaunchKernelGGL(k_resid_small<PX>, dim3(w_small), dim3(64), 0, st, P, d0, d1, d2, pic->d_l0, n32 + n16, n8, n4,
+                             pic->d_cval, pic->d_cpos, pic->d_scaling, pic->d_resid);
+      }
     }
     if (pic->n_runs > 0) {
       KTimer t(dec, DE265HIP_K_INTRA, 1);

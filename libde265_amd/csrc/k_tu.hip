@@ -693,7 +693,7 @@ __device__ __forceinline__ void resid16_body(const PicDev& P, const PlaneRef& pl
 template <typename PX>
 __global__ __launch_bounds__(256, RESID_BIG_WAVES)
 void k_resid_big(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const TuTask* __restrict__ tasks, int n_wg, int n_wave,
-                 const int16_t* __restrict__ coeff_val, const uint16_t* __restrict__ coeff_pos,
+                 int n8, int n4, const int16_t* __restrict__ coeff_val, const uint16_t* __restrict__ coeff_pos,
                  const uint8_t* __restrict__ scaling, int16_t* __restrict__ resid)
 {
   __shared__ __attribute__((aligned(16))) int8_t s_mat[32 * 32];
@@ -706,15 +706,25 @@ void k_resid_big(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const TuTas
     const TuTask t = tasks[blockIdx.x];
     resid_big_body<PX>(P, pl0, pl1, pl2, t, coeff_val, coeff_pos, scaling, resid, s_mat, s_c, s_g, s_last_row, s_last_col);
   } else {
+    // wavefront slots behind the workgroup TUs: [0, n_wave) a 16x16 TU each, then ceil(n8 / RESID_SPL) slots of 8x8 TUs and
+    // ceil(n4 / 4 RESID_SPL) slots of 4x4 TUs (n8 = n4 = 0: those have their own launch, k_resid_small)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int k = ((int)blockIdx.x - n_wg) * 4 + wave;
-    if (k >= n_wave) return;
-    const TuTask t = tasks[n_wg + k];
-    resid16_body<PX>(P, pl0, pl1, pl2, t, lane, coeff_val, coeff_pos, scaling, resid, s_c + 256 * wave, s_g + 256 * wave, s_mat + 256 * wave);
+    int16_t* wc = s_c + 256 * wave; int16_t* wg = s_g + 256 * wave; int8_t* wm = s_mat + 256 * wave;
+    const int w8 = (n8 + RESID_SPL - 1) / RESID_SPL;
+    if (k < n_wave) {
+      const TuTask t = tasks[n_wg + k];
+      resid16_body<PX>(P, pl0, pl1, pl2, t, lane, coeff_val, coeff_pos, scaling, resid, wc, wg, wm);
+    } else if (k < n_wave + w8)
+      resid_small_body<PX, 3>(P, pl0, pl1, pl2, tasks, n_wg + n_wave, n8, k - n_wave, lane, coeff_val, coeff_pos, scaling, resid,
+                              wc, wg, wm, wm + 64);
+    else if (k < n_wave + w8 + (n4 + 4 * RESID_SPL - 1) / (4 * RESID_SPL))
+      resid_small_body<PX, 2>(P, pl0, pl1, pl2, tasks, n_wg + n_wave + n8, n4, k - n_wave - w8, lane, coeff_val, coeff_pos, scaling,
+                              resid, wc, wg, wm, wm + 64);
   }
 }
-template __global__ void k_resid_big<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int, int, const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
-template __global__ void k_resid_big<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int, int, const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
+template __global__ void k_resid_big<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int, int, int, int, const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
+template __global__ void k_resid_big<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int, int, int, int, const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
 
 template <typename PX>
 __global__ __launch_bounds__(64)

@@ -30,7 +30,7 @@ template <typename PX>
 __global__ void k_tu(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int,
                      const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
 template <typename PX>
-__global__ void k_resid_big(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int, int, const int16_t*, const uint16_t*,
+__global__ void k_resid_big(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int, int, int, int, const int16_t*, const uint16_t*,
                             const uint8_t*, int16_t*);
 template <typename PX>
 __global__ void k_resid_small(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int, int, int, const int16_t*,
