@@ -26,10 +26,10 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r01_n_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_o_pmc_traffic.json")
 PMC_KERNEL = {"intra": ["k_run<unsigned short, 64>"], "mc": ["k_mc<unsigned short>"], "sao": ["k_sao<unsigned short>"],
               "deblock_v": ["k_deblock_fused<unsigned short>"],   # both directions in one kernel, reported under deblock_v
-              "resid": ["k_resid_big<unsigned short>", "k_resid_small<unsigned short>"]}
+              "resid": ["k_resid_big<unsigned short>"]}     # all sizes in one launch
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 CONFIG_ID = 4                  # SURVEY 8d config 4 -> seed 0xDE265000 + 4
 
