@@ -213,8 +213,21 @@ typedef struct de265hip_picture de265hip_picture;
 const char* de265hip_version(void);
 int  de265hip_device_count(void);
 
-/* Decoder context: owns a HIP stream and the device-resident DPB.
- * device < 0 selects the current device. */
+/* Decoder context: owns a HIP stream (kernels), a copy stream (command-buffer uploads), the device-resident
+ * DPB, and the device side of every picture built on it (pooled arenas + pinned staging buffers).
+ * device < 0 selects the current device.
+ *
+ * LIFETIME: a de265hip_picture belongs to the decoder it was built on.  The normal order is
+ * picture_free() for every picture, then decoder_free().  decoder_free() with pictures still alive is
+ * allowed: it waits for the decoder's streams, releases those pictures' device memory and ORPHANS their
+ * handles; an orphaned handle may only be passed to de265hip_picture_free() (which then just releases the
+ * handle) and to de265hip_picture_get_stats(); de265hip_picture_run() refuses it with
+ * DE265_ERROR_CODED_PARAMETER_OUT_OF_RANGE.  de265hip_picture_free() never touches a freed decoder.
+ *
+ * THREADS: de265hip_picture_build() and de265hip_picture_free() may be called from several host threads
+ * on the same decoder at once (the host stage of picture n+1 overlaps the device work of picture n:
+ * decctx.cc:976-1178 is the reference's parallel host side); de265hip_picture_run(), the dpb_* calls and
+ * decoder_sync() of one decoder belong to one thread at a time. */
 int  de265hip_decoder_new(de265hip_decoder** out, int device);
 void de265hip_decoder_free(de265hip_decoder*);
 /* Allocate (or re-use) DPB slot `slot` for a picture of this geometry. */
@@ -237,8 +250,10 @@ int  de265hip_dpb_plane(de265hip_decoder*, int slot, int c_idx,
                         void** dev_ptr, ptrdiff_t* stride_bytes);
 
 /* Build: host-side preprocessing (intra availability + dependency levels,
- * level sort, MC task split) and upload of the command buffers.  After this
- * call every input of the picture is resident in HBM. */
+ * level sort, MC task split) into a pinned staging buffer and ASYNCHRONOUS upload of the command
+ * buffers on the decoder's copy stream into a pooled device arena (no allocation and no host-side wait
+ * in the steady state).  The desc's arrays may be reused as soon as the call returns; the first
+ * de265hip_picture_run() of the picture waits for the upload on the device. */
 int  de265hip_picture_build(de265hip_decoder*, int dst_slot,
                             const de265hip_picture_desc*, de265hip_picture** out);
 /* Run: enqueue all reconstruction kernels of the picture on the decoder's

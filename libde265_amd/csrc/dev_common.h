@@ -89,8 +89,11 @@ struct __attribute__((aligned(8))) SaoCtb {
   uint8_t eo[3];
   uint8_t band[3];
   int8_t  off[3][4];
-  uint8_t pad;
-  uint16_t perm;            // bit (dy+1)*3+(dx+1): samples of this CTB may use neighbours in CTB (x+dx, y+dy)
+  uint8_t perm_c_hi;        // bits 7..8 of the chroma permissions
+  uint16_t perm;            // bits 0..8: luma, bit (dy+1)*3+(dx+1): samples of this CTB may use neighbours in CTB
+                            // (x+dx, y+dy); bits 9..15: bits 0..6 of the chroma permissions (same numbering).  Chroma has
+                            // its own set, and its bit 4 (the CTB itself) can be 0: sao.cc:55 compares against the slice
+                            // of CTB (x/2, y/2) for chroma (component coordinates passed as luma coordinates)
 };
 static_assert(sizeof(SaoCtb) == 24, "SaoCtb layout");
 

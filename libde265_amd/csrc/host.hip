@@ -37,11 +37,25 @@ struct Slot {
 
 struct PendingEvent { int kid; hipEvent_t a, b; };
 
+// Pooled device arena of one picture's command buffers.  last_use: recorded on the decoder's stream when the
+// picture that used the arena is freed; the next upload into it waits for that event on the copy stream (no
+// host-side synchronisation, no hipMalloc / hipFree per picture -- both stall every stream of the process).
+struct ArenaBuf { void* ptr = nullptr; size_t bytes = 0; hipEvent_t last_use = nullptr; bool used = false; };
+// Pinned staging buffer the host stage assembles the command buffers in.  copied: recorded on the copy stream
+// behind the upload; the buffer is handed out again once it has completed.
+struct StageBuf { void* ptr = nullptr; size_t bytes = 0; hipEvent_t copied = nullptr; int state = 0; };   // state: 0 idle, 1 being filled by a host thread, 2 upload in flight
+
 }  // namespace
 
 struct de265hip_decoder {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;  // uploads of command buffers (de265hip_picture_build), overlapping the kernels of earlier pictures
+  std::mutex mu;                      // guards live, the two pools and slot allocation: build()/free() may come from several host threads
+  std::vector<de265hip_picture*> live;        // pictures built on this decoder and not yet freed (decoder_free orphans them)
+  std::vector<ArenaBuf> free_arenas;
+  std::vector<StageBuf> stage_pool;
+  size_t pooled_bytes = 0;
   Slot slots[DE265HIP_MAX_DPB_SLOTS];
   Slot spare;                         // SAO output target, swapped with the decoded slot
   uint32_t* d_err = nullptr;          // set by a kernel whose bounded spin expired
@@ -63,8 +77,11 @@ struct de265hip_picture {
   int dst_slot = 0;
   de265hip_pic_params params;
   PicDev P;
-  void* arena = nullptr;              // one device allocation for all command buffers
+  void* arena = nullptr;              // one (pooled) device allocation for all command buffers
   size_t arena_bytes = 0;
+  ArenaBuf arena_buf;                 // the pool entry behind `arena`
+  hipEvent_t uploaded = nullptr;      // recorded on the copy stream behind the upload; the first run waits for it on the decoder's stream
+  bool upload_waited = false;
   // device pointers into the arena
   TuTask* d_tus = nullptr;
   int16_t* d_cval = nullptr; uint16_t* d_cpos = nullptr;
@@ -297,6 +314,75 @@ uint64_t intra_availability(const de265hip_picture_desc& d, const Geometry& g, c
   return mask;
 }
 
+// ---- pools (caller holds dec->mu)
+constexpr size_t kPoolLimitBytes = (size_t)24 << 30;      // free arenas kept for reuse (of 288 GB of HBM)
+
+int acquire_arena(de265hip_decoder* dec, size_t bytes, ArenaBuf* out)
+{
+  int best = -1;
+  for (size_t i = 0; i < dec->free_arenas.size(); i++) {
+    const ArenaBuf& a = dec->free_arenas[i];
+    if (a.bytes >= bytes && a.bytes <= 4 * bytes + ((size_t)8 << 20) && (best < 0 || a.bytes < dec->free_arenas[best].bytes)) best = (int)i;
+  }
+  if (best >= 0) {
+    *out = dec->free_arenas[best];
+    dec->free_arenas.erase(dec->free_arenas.begin() + best);
+    dec->pooled_bytes -= out->bytes;
+    return 0;
+  }
+  ArenaBuf a;
+  a.bytes = (bytes + ((size_t)4 << 20) - 1) & ~(((size_t)4 << 20) - 1);        // 4 MB size classes
+  HIPCHK(hipMalloc(&a.ptr, a.bytes), DE265HIP_ERROR_OUT_OF_MEMORY);
+  if (hipEventCreateWithFlags(&a.last_use, hipEventDisableTiming) != hipSuccess) { (void)hipFree(a.ptr); return DE265HIP_ERROR_OUT_OF_MEMORY; }
+  *out = a;
+  return 0;
+}
+
+void destroy_arena(ArenaBuf& a)
+{
+  if (a.ptr) (void)hipFree(a.ptr);                        // (synchronises with the device: whatever used it has finished)
+  if (a.last_use) (void)hipEventDestroy(a.last_use);
+  a = ArenaBuf();
+}
+
+// hand an arena back: reusable once everything enqueued on the decoder's stream so far has run
+void release_arena(de265hip_decoder* dec, ArenaBuf a)
+{
+  if (!a.ptr) return;
+  if (hipEventRecord(a.last_use, dec->stream) != hipSuccess || dec->pooled_bytes + a.bytes > kPoolLimitBytes) { destroy_arena(a); return; }
+  a.used = true;
+  dec->pooled_bytes += a.bytes;
+  dec->free_arenas.push_back(a);
+}
+
+int acquire_stage(de265hip_decoder* dec, size_t bytes, int* index)
+{
+  int best = -1;
+  for (size_t i = 0; i < dec->stage_pool.size(); i++) {
+    StageBuf& b = dec->stage_pool[i];
+    if (b.state == 2 && hipEventQuery(b.copied) == hipSuccess) b.state = 0;
+    if (b.state == 0 && b.bytes >= bytes && (best < 0 || b.bytes < dec->stage_pool[best].bytes)) best = (int)i;
+  }
+  if (best < 0) {
+    // recycle an idle buffer that is too small rather than growing without bound
+    for (size_t i = 0; i < dec->stage_pool.size(); i++)
+      if (dec->stage_pool[i].state == 0 && dec->stage_pool[i].ptr) {
+        (void)hipHostFree(dec->stage_pool[i].ptr); (void)hipEventDestroy(dec->stage_pool[i].copied);
+        dec->stage_pool.erase(dec->stage_pool.begin() + i);
+        break;
+      }
+    StageBuf b;
+    b.bytes = (bytes + ((size_t)4 << 20) - 1) & ~(((size_t)4 << 20) - 1);
+    HIPCHK(hipHostMalloc(&b.ptr, b.bytes, hipHostMallocDefault), DE265HIP_ERROR_OUT_OF_MEMORY);
+    if (hipEventCreateWithFlags(&b.copied, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(b.ptr); return DE265HIP_ERROR_OUT_OF_MEMORY; }
+    dec->stage_pool.push_back(b);
+    best = (int)dec->stage_pool.size() - 1;
+  }
+  dec->stage_pool[best].state = 1;
+  *index = best;
+  return 0;
+}
+
 struct ArenaLayout {
   size_t total = 0;
   size_t add(size_t bytes) { size_t o = total; total = (total + bytes + 255) & ~(size_t)255; return o; }
@@ -327,6 +413,7 @@ int de265hip_decoder_new(de265hip_decoder** out, int device)
   if (!d) return DE265HIP_ERROR_OUT_OF_MEMORY;
   HIPCHK(hipGetDevice(&d->device), DE265HIP_ERROR_INIT_FAILED);
   HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking), DE265HIP_ERROR_INIT_FAILED);
+  HIPCHK(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking), DE265HIP_ERROR_INIT_FAILED);
   HIPCHK(hipMalloc((void**)&d->d_err, 256), DE265HIP_ERROR_OUT_OF_MEMORY);
   HIPCHK(hipMemset(d->d_err, 0, 256), DE265HIP_ERROR_INIT_FAILED);
   const char* mode = getenv("DE265HIP_INTRA_MODE");
@@ -341,14 +428,33 @@ int de265hip_decoder_new(de265hip_decoder** out, int device)
   return DE265HIP_OK;
 }
 
+// Lifetime rule (include/de265_hip.h): the decoder owns the device side of its pictures.  Freeing the decoder first
+// releases their device memory and ORPHANS the handles (dec = nullptr): an orphan can only be freed; picture_free
+// never touches a dead decoder.
 void de265hip_decoder_free(de265hip_decoder* d)
 {
   if (!d) return;
+  (void)hipStreamSynchronize(d->copy_stream);
   (void)hipStreamSynchronize(d->stream);
+  {
+    std::lock_guard<std::mutex> lk(d->mu);
+    for (de265hip_picture* p : d->live) {
+      destroy_arena(p->arena_buf);
+      p->arena = nullptr;
+      if (p->uploaded) { (void)hipEventDestroy(p->uploaded); p->uploaded = nullptr; }
+      p->dec = nullptr;
+    }
+    d->live.clear();
+    for (auto& a : d->free_arenas) destroy_arena(a);
+    d->free_arenas.clear();
+    for (auto& b : d->stage_pool) { if (b.ptr) (void)hipHostFree(b.ptr); if (b.copied) (void)hipEventDestroy(b.copied); }
+    d->stage_pool.clear();
+  }
   for (auto& e : d->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& s : d->slots) free_slot(s);
   free_slot(d->spare);
   if (d->d_err) (void)hipFree(d->d_err);
+  (void)hipStreamDestroy(d->copy_stream);
   (void)hipStreamDestroy(d->stream);
   delete d;
 }
@@ -415,7 +521,14 @@ int de265hip_dpb_plane(de265hip_decoder* d, int slot, int c, void** dev_ptr, ptr
 void de265hip_picture_free(de265hip_picture* p)
 {
   if (!p) return;
-  if (p->arena) { (void)hipStreamSynchronize(p->dec->stream); (void)hipFree(p->arena); }
+  if (de265hip_decoder* dec = p->dec) {                   // (an orphan has no device side left: only the handle goes)
+    std::lock_guard<std::mutex> lk(dec->mu);
+    dec->live.erase(std::remove(dec->live.begin(), dec->live.end(), p), dec->live.end());
+    // no synchronisation: the arena goes back to the pool behind an event on the decoder's stream, and its next
+    // upload waits for that event on the copy stream
+    release_arena(dec, p->arena_buf);
+    if (p->uploaded) (void)hipEventDestroy(p->uploaded);
+  }
   delete p;
 }
 
@@ -436,9 +549,12 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   if (p.scaling_list_enable_flag && !d->scaling_factors) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   if (dst_slot < 0 || dst_slot >= DE265HIP_MAX_DPB_SLOTS) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
-  int rc = alloc_slot(dec->slots[dst_slot], p.width, p.height, p.bit_depth_luma, p.bit_depth_chroma);
-  if (rc) return rc;
-  rc = alloc_slot(dec->spare, p.width, p.height, p.bit_depth_luma, p.bit_depth_chroma);
+  int rc;
+  {
+    std::lock_guard<std::mutex> lk(dec->mu);
+    rc = alloc_slot(dec->slots[dst_slot], p.width, p.height, p.bit_depth_luma, p.bit_depth_chroma);
+    if (!rc) rc = alloc_slot(dec->spare, p.width, p.height, p.bit_depth_luma, p.bit_depth_chroma);
+  }
   if (rc) return rc;
 
   Geometry g;
@@ -879,23 +995,30 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
         o.band[c] = ci.sao_band_position[c];
         for (int k = 0; k < 4; k++) o.off[c][k] = ci.sao_offset_val[c][k];
       }
-      unsigned perm = 0x10;
-      for (int dy = -1; dy <= 1; dy++)
-        for (int dx = -1; dx <= 1; dx++) {
-          if (!dx && !dy) continue;
-          const int nx = cx + dx, ny = cy + dy;
-          bool ok = nx >= 0 && ny >= 0 && nx < g.ctbs_w && ny < g.ctbs_h;
-          if (ok) {
-            const int nb = nx + ny * g.ctbs_w;
-            const de265hip_ctb_info& ni = d->ctbs[nb];
-            if (ni.slice_addr_rs < ci.slice_addr_rs && !sh.slice_loop_filter_across_slices_enabled_flag) ok = false;
-            if (ni.slice_addr_rs > ci.slice_addr_rs &&
-                !d->slices[ni.slice_idx].slice_loop_filter_across_slices_enabled_flag) ok = false;
-            if (!p.loop_filter_across_tiles_enabled_flag && g.tile_id[nb] != g.tile_id[a]) ok = false;
+      // The reference looks the CTB's own slice address up with get_SliceHeader(xC,yC) where xC,yC are in samples of
+      // the component (sao.cc:55) although the accessor takes luma samples: for chroma the address every neighbour is
+      // compared with is that of CTB (cx/2, cy/2).  Reproduced (the oracle is pinned to the compiled reference on it):
+      // chroma gets its own permission set, in which even the CTB itself can be "another slice".
+      unsigned perm[2] = { 0, 0 };
+      for (int ch = 0; ch < 2; ch++) {
+        const int own_addr = ch ? d->ctbs[(cx >> 1) + (cy >> 1) * g.ctbs_w].slice_addr_rs : ci.slice_addr_rs;
+        for (int dy = -1; dy <= 1; dy++)
+          for (int dx = -1; dx <= 1; dx++) {
+            const int nx = cx + dx, ny = cy + dy;
+            bool ok = nx >= 0 && ny >= 0 && nx < g.ctbs_w && ny < g.ctbs_h;
+            if (ok) {
+              const int nb = nx + ny * g.ctbs_w;
+              const de265hip_ctb_info& ni = d->ctbs[nb];
+              if (ni.slice_addr_rs < own_addr && !sh.slice_loop_filter_across_slices_enabled_flag) ok = false;
+              if (ni.slice_addr_rs > own_addr &&
+                  !d->slices[ni.slice_idx].slice_loop_filter_across_slices_enabled_flag) ok = false;
+              if (!p.loop_filter_across_tiles_enabled_flag && g.tile_id[nb] != g.tile_id[a]) ok = false;
+            }
+            if (ok) perm[ch] |= 1u << ((dy + 1) * 3 + dx + 1);
           }
-          if (ok) perm |= 1u << ((dy + 1) * 3 + dx + 1);
-        }
-      o.perm = (uint16_t)perm;
+      }
+      o.perm = (uint16_t)(perm[0] | ((perm[1] & 0x7Fu) << 9));
+      o.perm_c_hi = (uint8_t)(perm[1] >> 7);
     }
 
   // ---- one arena, one upload
@@ -920,7 +1043,30 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   const size_t o_resid = L.add(n_resid * 2 + 64);
   pic->sync_bytes = (2 + runs.size()) * 4;
   const size_t o_sync = L.add(pic->sync_bytes);
-  std::vector<uint8_t> host(upload_bytes);
+  // pinned staging + pooled arena: no allocation, no host-side wait in the steady state
+  int stage_idx = -1;
+  uint8_t* host_base = nullptr;
+  hipEvent_t stage_event = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(dec->mu);
+    rc = acquire_stage(dec, upload_bytes, &stage_idx);
+    if (!rc) {
+      host_base = (uint8_t*)dec->stage_pool[stage_idx].ptr; stage_event = dec->stage_pool[stage_idx].copied;
+      rc = acquire_arena(dec, L.total, &pic->arena_buf);
+      if (rc) dec->stage_pool[stage_idx].state = 0;
+    }
+  }
+  if (rc) { delete pic; return rc; }
+  // (a failure below hands both back)
+  auto fail = [&](int code) {
+    std::lock_guard<std::mutex> lk(dec->mu);
+    for (auto& b : dec->stage_pool) if (b.ptr == host_base) b.state = 0;
+    release_arena(dec, pic->arena_buf);
+    if (pic->uploaded) (void)hipEventDestroy(pic->uploaded);
+    delete pic;
+    return code;
+  };
+  struct HostView { uint8_t* p; uint8_t* data() const { return p; } } host{ host_base };
   auto put = [&](size_t off, const void* src, size_t bytes) { if (bytes && src) memcpy(host.data() + off, src, bytes); };
   put(o_tus, sorted.data(), sorted.size() * sizeof(TuTask));
   put(o_cval, d->coeff_val, (size_t)d->n_coeffs * 2); put(o_cpos, d->coeff_pos, (size_t)d->n_coeffs * 2);
@@ -940,10 +1086,19 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   if (d->blk_motion) put(o_mot, d->blk_motion, nblk * sizeof(de265hip_motion));
   else memset(host.data() + o_mot, 0xFF, nblk * sizeof(de265hip_motion));       // ref_slot = -1 everywhere
 
-  if (hipMalloc(&pic->arena, L.total) != hipSuccess) { delete pic; return DE265HIP_ERROR_OUT_OF_MEMORY; }
+  pic->arena = pic->arena_buf.ptr;
   pic->arena_bytes = L.total;
-  if (hipMemcpy(pic->arena, host.data(), upload_bytes, hipMemcpyHostToDevice) != hipSuccess) {
-    (void)hipFree(pic->arena); delete pic; return DE265HIP_ERROR_DECODING;
+  {
+    hipStream_t cs = dec->copy_stream;
+    // a recycled arena may still be read by kernels of the picture that had it before
+    if (pic->arena_buf.used && hipStreamWaitEvent(cs, pic->arena_buf.last_use, 0) != hipSuccess) return fail(DE265HIP_ERROR_DECODING);
+    if (hipEventCreateWithFlags(&pic->uploaded, hipEventDisableTiming) != hipSuccess) return fail(DE265HIP_ERROR_OUT_OF_MEMORY);
+    if (hipMemcpyAsync(pic->arena, host.data(), upload_bytes, hipMemcpyHostToDevice, cs) != hipSuccess ||
+        hipMemsetAsync((uint8_t*)pic->arena + o_sync, 0, pic->sync_bytes, cs) != hipSuccess ||
+        hipEventRecord(stage_event, cs) != hipSuccess || hipEventRecord(pic->uploaded, cs) != hipSuccess)
+      return fail(DE265HIP_ERROR_DECODING);
+    std::lock_guard<std::mutex> lk(dec->mu);
+    for (auto& b : dec->stage_pool) if (b.ptr == host_base) b.state = 2;      // reusable once `copied` has completed
   }
   uint8_t* base = (uint8_t*)pic->arena;
   pic->d_tus = (TuTask*)(base + o_tus);
@@ -960,7 +1115,6 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   pic->d_bs = base + o_bs;
   pic->d_runs = (RunTask*)(base + o_runs); pic->d_deps = (uint32_t*)(base + o_rdeps);
   pic->d_run_tus = (TuTask*)(base + o_rtus); pic->d_slots = (uint32_t*)(base + o_slots); pic->d_sync = (uint32_t*)(base + o_sync);
-  if (hipMemset(pic->d_sync, 0, pic->sync_bytes) != hipSuccess) { (void)hipFree(pic->arena); delete pic; return DE265HIP_ERROR_DECODING; }
   pic->d_l0 = (TuTask*)(base + o_l0); pic->d_resid = (int16_t*)(base + o_resid);
 
   const int64_t Pbytes = (int64_t)p.width * p.height * 3 / 2 * px_bytes(p.bit_depth_luma);
@@ -972,6 +1126,10 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   pic->stats.alg_bytes_mc = alg_mc; pic->stats.alg_bytes_resid = alg_resid; pic->stats.alg_bytes_intra = alg_intra;
   pic->stats.alg_bytes_deblock = pic->any_edges ? 2 * Pbytes : 0;       // one read + one write
   pic->stats.alg_bytes_sao = p.sample_adaptive_offset_enabled_flag ? 2 * Pbytes + 16 * (int64_t)d->n_ctbs : 0;
+  {
+    std::lock_guard<std::mutex> lk(dec->mu);
+    dec->live.push_back(pic);
+  }
   *out = pic;
   return DE265HIP_OK;
 }
@@ -1003,6 +1161,10 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
   Slot& dst = dec->slots[pic->dst_slot];
   if (!dst.valid) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   hipStream_t st = dec->stream;
+  if (!pic->upload_waited) {            // the command buffers arrive on the copy stream
+    if (hipStreamWaitEvent(st, pic->uploaded, 0) != hipSuccess) return DE265HIP_ERROR_DECODING;
+    pic->upload_waited = true;
+  }
   PicDev P = pic->P;
   P.dbg = dec->dbg;
   const PlaneRef d0 = dst.pl[0], d1 = dst.pl[1], d2 = dst.pl[2];

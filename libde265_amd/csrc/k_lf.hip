@@ -550,7 +550,8 @@ __device__ __forceinline__ void sao_strip(const PicDev& P, const SaoMeta& M, PX*
     o4[0] = (int8_t)SAO_BYTE(17); o4[1] = (int8_t)SAO_BYTE(18); o4[2] = (int8_t)SAO_BYTE(19); o4[3] = (int8_t)SAO_BYTE(20);
   }
 #undef SAO_BYTE
-  const unsigned perm = w[5] >> 16;
+  // luma: bits 0..8 of SaoCtb::perm; chroma: its bits 9..15 + perm_c_hi (dev_common.h)
+  const unsigned perm = comp == 0 ? (w[5] >> 16) & 0x1FFu : ((w[5] >> 25) & 0x7Fu) | (((w[5] >> 8) & 3u) << 7);
 
   // S[j][m], m = 0..4: the row shifted by one sample: (left neighbour, v0), (v1, v2), (v3, v4), (v5, v6), (v7, right
   // neighbour); the neighbours come from the adjacent lanes (DPP wave shifts; lanes 0 and 63 only supply them)
@@ -635,15 +636,19 @@ __device__ __forceinline__ void sao_strip(const PicDev& P, const SaoMeta& M, PX*
   const bool touchT = (y0 & mask) == 0, touchB = ((y0 + nrows - 1) & mask) == mask || y0 + nrows >= height;
   // permission of the CTB at offset (dx,dy) (0 = this CTB); out-of-picture CTBs have their bit cleared in perm
   auto permitted = [&](int dx, int dy) -> bool { return (perm >> ((dy + 1) * 3 + dx + 1)) & 1; };
+  // the samples of the strip on the CTB's outline: only they are tested at all (sao.cc:120 testBoundary)
+  const mask_t onEdge = (touchL ? colL : (mask_t)0) | (touchR ? colR : (mask_t)0) | (touchT ? rowT : (mask_t)0) |
+                        (touchB ? rowB : (mask_t)0);
   auto blocked = [&](int sx, int sy) -> mask_t {              // samples whose neighbour in direction (sx,sy) is not usable
-    const mask_t X = sx < 0 ? colL : (sx > 0 ? colR : (mask_t)0);
-    const mask_t Y = sy < 0 ? rowT : (sy > 0 ? rowB : (mask_t)0);
     const int dx = sx < 0 ? (touchL ? -1 : 0) : (sx > 0 ? (touchR ? 1 : 0) : 0);
     const int dy = sy < 0 ? (touchT ? -1 : 0) : (sy > 0 ? (touchB ? 1 : 0) : 0);
+    const mask_t X = dx < 0 ? colL : (dx > 0 ? colR : (mask_t)0);     // samples whose neighbour lies in another CTB column
+    const mask_t Y = dy < 0 ? rowT : (dy > 0 ? rowB : (mask_t)0);     // ... row
     mask_t bad = 0;
     if (!permitted(dx, 0)) bad |= X & ~Y;
     if (!permitted(0, dy)) bad |= Y & ~X;
     if (!permitted(dx, dy)) bad |= X & Y;
+    if (!permitted(0, 0)) bad |= onEdge & ~(X | Y);           // (chroma only: the CTB itself as "another slice")
     return bad;
   };
   mask_t okmask = ~(blocked(hx, hy) | blocked(-hx, -hy));

@@ -361,3 +361,55 @@ def test_run_kernel_schedule_variants(env):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_decoder_freed_before_its_pictures():
+    """Lifetime rule of include/de265_hip.h: decoder_free() with pictures alive orphans them; an orphan can still
+    be asked for its stats and freed, never run.  (Round 1: picture_free dereferenced the dead decoder.)"""
+    from libde265_amd import backend
+    w, h, bd = 128, 64, 8
+    sp = pysynth.SynthPicture(pysynth.default_config(w, h, bd, 2, seed=5))
+    d1 = backend.Decoder()
+    d1.dpb_alloc(2, w, h, bd)
+    pics = [d1.build(2, sp.desc) for _ in range(3)]
+    d1.run(pics[0], 2)
+    pics[1].free()                                   # the normal order for one of them
+    d1.close()                                       # decoder first ...
+    assert pics[0].stats().n_tu_tasks > 0            # ... the handles stay valid
+    d2 = backend.Decoder()
+    try:
+        with pytest.raises(backend.De265HipError) as e:
+            d2.run(pics[0], 2)                       # neither on its dead decoder nor on another one
+        assert e.value.code == _abi.ERROR_PARAMETER_OUT_OF_RANGE
+    finally:
+        pics[0].free(); pics[2].free()               # ... pictures second
+        d2.close()
+
+
+def test_arena_pool_reuse_keeps_pictures_apart(dec):
+    """build -> run -> free in a loop recycles pooled device arenas and pinned staging buffers without any host-side
+    wait: every picture must still come out right although its arena belonged to another picture a moment ago."""
+    w, h, bd = 352, 288, 10
+    refs = {0: pysynth.fill_planes(w, h, bd, 1), 1: pysynth.fill_planes(w, h, bd, 2)}
+    for s, pl in refs.items():
+        dec.dpb_alloc(s, w, h, bd); dec.upload(s, pl)
+    dec.dpb_alloc(2, w, h, bd)
+    sps, exps = [], []
+    for k in range(6):
+        sp = pysynth.SynthPicture(pysynth.default_config(w, h, bd, k % 3, seed=700 + k, n_slices=1 + k % 2))
+        exp = pyoracle.alloc_planes(w, h, bd)
+        pyoracle.reconstruct(sp.desc, sp.order, refs, exp)
+        sps.append(sp); exps.append(exp)
+    for rep in range(3):
+        for k in range(6):
+            pic = dec.build(2, sps[k].desc)
+            try:
+                dec.upload(2, pyoracle.alloc_planes(w, h, bd))
+                dec.run(pic, 2)
+                if (rep + k) % 2:                    # sometimes free while the kernels are still queued
+                    pic.free()
+                dec.sync()
+                got = dec.download(2, w, h, bd)
+            finally:
+                pic.free()
+            assert all(np.array_equal(g, e) for g, e in zip(got, exps[k])), (rep, k)
