@@ -12,14 +12,24 @@ GPU); all command buffers and reference pictures are resident in HBM before
 the timed region starts.  value = pictures/s over all ranks (weak scaling:
 every rank decodes its own independent GOPs, no data-path collective).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+`value` is a DEVICE REPLAY rate (config.timed_region): the pictures' command buffers were built
+(de265hip_picture_build: host stage + upload) before the timed region and are re-run every step.
+`host_inclusive` next to it is the rate of the C ABI as a libde265 host would drive it: build -> run -> free
+of every picture inside the timed region, the host stage of later pictures on a pool of host threads while
+the device works on earlier ones (thread and core counts stated).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]         N > 1: starts N ranks itself (one per GPU)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
+import collections
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
@@ -47,6 +57,112 @@ def make_gop(pysynth, farm, width, height, bit_depth, gop, seed):
     return pics
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) BEFORE this process
+    touches the GPU, rank 0's stdout is ours (the one JSON line), exit with the worst return code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:           # a rank died: the others would wait in the barrier for ever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def host_inclusive_pass(decs, gops, pool, window, final_stage, stagger):
+    """build -> run -> free of every picture of every stream through the C ABI.  Builds (host stage + async upload) run
+    on `pool`, at most `window` ahead of the consumer; this thread enqueues the pictures in decode order per stream."""
+    S, GOP = len(decs), len(gops[0])
+    order = [(s_i, (j + s_i * (GOP // S)) % GOP if stagger else j) for j in range(GOP) for s_i in range(S)]
+    futs = collections.deque()
+    it = iter(order)
+
+    def submit():
+        nxt = next(it, None)
+        if nxt is not None:
+            s_i, k = nxt
+            futs.append((s_i, pool.submit(decs[s_i].build, k, gops[s_i][k].desc)))
+
+    for _ in range(window):
+        submit()
+    while futs:
+        s_i, f = futs.popleft()
+        pic = f.result()
+        submit()
+        decs[s_i].run(pic, final_stage)
+        pic.free()                          # no wait: the arena returns to the pool behind an event on the stream
+
+
+def cpu_baseline(gops, decs, W, H, BD, GOP):
+    """libde265's own pixel-reconstruction path on this box's host cores, next to the GPU number (a reported baseline, not
+    the target).  kind "reference": the compiled reference (oracle/_ref/libde265_ref.so: libde265's decoder sources built
+    with plain g++, scalar fallback DSP -- what the reference itself runs for 10-bit, x86/sse.cc:67-100 overrides 8-bit
+    slots only) reconstructs the same command buffers through oracle/ref_shim.cc; kind "port": the C restatement, only
+    where the compiled reference did not travel.  One GOP per host thread (the path shards by GOP; the reference's own
+    WPP/tile threads live in its CABAC front end, which is not on this path), the first GOP alone for the 1-core figure.
+    Doubles as the bit-exactness check of stream 0's last picture."""
+    import numpy as np
+    import pyoracle
+    import pyref
+    kind = "reference" if pyref.available() else "port"
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+    def decode_gop(g):
+        planes = {}
+        for k in range(GOP):
+            out = pyoracle.alloc_planes(W, H, BD)
+            if kind == "reference":
+                pyref.reconstruct(g[k].desc, g[k].order, planes, out, g[k].structure())
+            else:
+                pyoracle.reconstruct(g[k].desc, g[k].order, planes, out)
+            planes[k] = out
+            if k >= 2:
+                planes.pop(k - 3, None)
+        return planes[GOP - 1]
+
+    if kind == "reference":
+        pyref.lib()
+    t0 = time.perf_counter()
+    last = decode_gop(gops[0])
+    t1 = time.perf_counter()
+    one = GOP / (t1 - t0)
+    got = decs[0].download(GOP - 1, W, H, BD)
+    parity = "bit-exact" if all(np.array_equal(g, e) for g, e in zip(got, last)) else "MISMATCH"
+    # all cores: `cores` GOPs at once, one per thread (ctypes releases the GIL), cycling through the streams' GOPs
+    n = max(1, min(cores, 32))
+    with ThreadPoolExecutor(n) as pool:
+        t0 = time.perf_counter()
+        list(pool.map(decode_gop, [gops[i % len(gops)] for i in range(n)]))
+        t1 = time.perf_counter()
+    allc = n * GOP / (t1 - t0)
+    cpu = {"value": round(allc, 3), "unit": "frames/s", "cores": n, "kind": kind, "value_1_core": round(one, 3),
+           "sample": "%d GOP(s) of the same workload (1 I + %d B, %dx%d %d-bit each), one per host thread, one pass; "
+                     "1-core figure: the first GOP alone" % (n, GOP - 1, W, H, BD)}
+    return cpu, parity
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,11 +183,41 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm; gloo for rehearsals)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal only: every rank uses GPU 0 (a 1-GPU box cannot give each rank its own GPU)")
+    ap.add_argument("--host-threads", type=int, default=0,
+                    help="host threads building pictures in the host_inclusive leg (0: the cores this process may use, at most 16)")
+    ap.add_argument("--no-host-inclusive", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher rehearsal without a GPU (tests/test_bench_launcher.py): ranks rendezvous over gloo, time an empty "
+                         "region with the barrier + MAX-over-ranks timer, rank 0 prints the JSON line with value null")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    if args.dry_run:
+        if os.environ.get("DE265HIP_BENCH_FAIL_RANK") == str(rank):     # (launcher test: a rank that dies early)
+            raise SystemExit(3)
+        import torch.distributed as dist
+        from libde265_amd import farm
+        if world > 1:
+            dist.init_process_group("gloo")
+        timer = farm.RankTimer(dist if world > 1 else None)
+        timer.start()
+        time.sleep(0.01 * (rank + 1))
+        elapsed = timer.stop()
+        units = farm.total_units(dist if world > 1 else None, args.gop * max(1, args.streams) * args.steps)
+        if rank == 0:
+            print(json.dumps({"metric": "decoded frames/sec (4K Main10)", "value": None, "unit": "frames/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "dry_run": True, "units_all_ranks": units,
+                              "ms_per_step": round(1e3 * elapsed / max(1, args.steps), 3)}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     import torch
     import pysynth
@@ -152,6 +298,36 @@ def main():
     for d in decs:
         d.set_profiling(False)
 
+    # ---- host-inclusive leg: the same GOPs, every picture built, run and freed inside the timed region
+    host_incl = None
+    if not args.no_host_inclusive:
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        nthr = args.host_threads if args.host_threads > 0 else max(1, min(16, cores // max(1, world if args.single_device or world > 1 else 1)))
+        for ps in pics:                                 # the prebuilt pictures go back to the pools
+            for p_ in ps:
+                p_.free()
+        sync()
+        hi_steps = max(2, min(args.steps, 5))
+
+        def timed_passes(threads, passes):
+            with ThreadPoolExecutor(threads) as pool:
+                host_inclusive_pass(decs, gops, pool, 2 * threads + 2, _abi.STAGE_FINAL, args.stagger)   # warm-up: fills the pools
+                sync()
+                tm = farm.RankTimer(dist, sync, device=red_dev)
+                tm.start()
+                for _ in range(passes):
+                    host_inclusive_pass(decs, gops, pool, 2 * threads + 2, _abi.STAGE_FINAL, args.stagger)
+                return tm.stop()
+
+        t_n = timed_passes(nthr, hi_steps)
+        t_1 = timed_passes(1, 1)
+        host_incl = {"value": round(world * hi_steps * GOP * S / t_n, 2), "unit": "frames/s", "host_threads": nthr,
+                     "host_cores_available": cores, "steps": hi_steps,
+                     "value_1_host_thread": round(world * GOP * S / t_1, 2),
+                     "what": "de265hip_picture_build -> de265hip_picture_run -> de265hip_picture_free per picture through the C ABI "
+                             "(host stage + pinned async upload + all kernels), builds on a pool of host threads ahead of the device"}
+        pics = [[d.build(k, g[k].desc) for k in range(GOP)] for d, g in zip(decs, gops)]   # (for the isolated pass below)
+
     # one more, untimed, pass of stream 0 alone: per-kernel device times without the other streams'
     # kernels competing for the GPU (reported as kernels_isolated; value/roofline come from the timed region)
     iso = {}
@@ -207,22 +383,7 @@ def main():
         cpu = None
         parity = "not checked"
         if not args.no_cpu_baseline:
-            import numpy as np
-            import pyoracle
-            planes = {}
-            tc0 = time.perf_counter()
-            for k in range(GOP):
-                out = pyoracle.alloc_planes(W, H, BD)
-                pyoracle.reconstruct(gop[k].desc, gop[k].order, planes, out)
-                planes[k] = out
-                if k >= 2:
-                    planes.pop(k - 3, None)
-            tc1 = time.perf_counter()
-            cpu = {"value": round(GOP / (tc1 - tc0), 3), "unit": "frames/s", "cores": 1, "kind": "port",
-                   "sample": "the same %d-picture GOP (1 I + %d B, %dx%d %d-bit), one pass, scalar C oracle"
-                             % (GOP, GOP - 1, W, H, BD)}
-            got = dec.download(GOP - 1, W, H, BD)
-            parity = "bit-exact" if all(np.array_equal(g, e) for g, e in zip(got, planes[GOP - 1])) else "MISMATCH"
+            cpu, parity = cpu_baseline(gops, decs, W, H, BD, GOP)
 
         line = {
             "metric": "decoded frames/sec (4K Main10)", "value": round(fps, 2), "unit": "frames/s",
@@ -232,11 +393,13 @@ def main():
             "config": {"workload": "%dx%d %d-bit 4:2:0 random-access closed GOPs of %d pictures (1 I + %d B, 2 refs), "
                                    "%d independent GOP(s) in flight per GPU, all stages on device"
                                    % (W, H, BD, GOP, GOP - 1, S),
+                       "timed_region": "device replay of prebuilt pictures (command buffers built and uploaded before the timed "
+                                       "region; see host_inclusive for build -> run -> free)",
                        "gop": GOP, "streams_per_gpu": S, "pictures_per_step": GOP * S,
                        "host_enqueue_ms_per_step": round(1e3 * t_host / args.steps, 3),
                        "events_in_timed_region": "every kernel" if args.events == "all" else "dominant kernel (%s) only" % dom,
                        "parallelism": "%d gop stream(s) x %d gpu(s)" % (S, world)},
-            "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle": parity, "kernels": kernels,
+            "roofline": roofline, "cpu_baseline": cpu, "host_inclusive": host_incl, "parity_vs_reference": parity, "kernels": kernels,
             "kernels_isolated": kernels_iso,
         }
         print(json.dumps(line))

@@ -1,0 +1,51 @@
+"""bench.py --gpus N must be self-contained: without a launcher it starts N rank processes itself,
+with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, before touching the GPU; rank 0 prints the single JSON line with
+n_gpus == N; under an external launcher WORLD_SIZE must equal --gpus.  Rehearsed on the CPU with --dry-run (gloo)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env():
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    return e
+
+
+def test_gpus_n_starts_n_ranks_and_prints_one_line():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--dry-run"], env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]        # (gloo itself chats on stdout)
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dry_run"] is True
+    assert out["units_all_ranks"] == 2 * 16 * 3 * 3          # both ranks' pictures: world x GOP x streams x steps
+    assert out["ms_per_step"] >= 20.0 / 3 - 1e-6              # MAX over ranks: rank 1 slept 20 ms
+
+
+def test_single_rank_needs_no_launcher():
+    r = subprocess.run([sys.executable, BENCH, "--steps", "2", "--dry-run"], env=_env(), capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])["n_gpus"] == 1
+
+
+def test_world_size_must_match_gpus():
+    e = _env()
+    e.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run"], env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_a_failing_rank_fails_the_launch():
+    """A rank that dies must not leave the others waiting in a barrier: the launcher ends them and reports failure."""
+    e = _env()
+    e["DE265HIP_BENCH_FAIL_RANK"] = "1"
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run"], env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
