@@ -249,6 +249,14 @@ int  de265hip_dpb_info(de265hip_decoder*, int slot, int* width, int* height,
 int  de265hip_dpb_plane(de265hip_decoder*, int slot, int c_idx,
                         void** dev_ptr, ptrdiff_t* stride_bytes);
 
+/* Reference-picture exchange (open GOPs / inter-GOP references): copy the three planes of
+ * src_dec's slot src_slot into dst_dec's slot dst_slot, device to device (hipMemcpyPeerAsync when the
+ * decoders sit on different GPUs of this process, one xGMI hop; a plain device copy otherwise), ordered
+ * behind everything enqueued on src_dec's stream so far; dst_dec's stream waits for the copy.  The
+ * destination slot is (re)allocated to the source's geometry.  Between PROCESSES (one rank per GPU) the same
+ * planes are sent with RCCL on zero-copy tensor views of de265hip_dpb_plane (libde265_amd/farm.py). */
+int  de265hip_dpb_copy(de265hip_decoder* src_dec, int src_slot, de265hip_decoder* dst_dec, int dst_slot);
+
 /* Build: host-side preprocessing (intra availability + dependency levels,
  * level sort, MC task split) into a pinned staging buffer and ASYNCHRONOUS upload of the command
  * buffers on the decoder's copy stream into a pooled device arena (no allocation and no host-side wait

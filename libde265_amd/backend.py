@@ -19,6 +19,7 @@ EXPORTS = [
     "de265hip_version", "de265hip_device_count",
     "de265hip_decoder_new", "de265hip_decoder_free",
     "de265hip_dpb_alloc", "de265hip_dpb_upload", "de265hip_dpb_download", "de265hip_dpb_plane", "de265hip_dpb_info",
+    "de265hip_dpb_copy",
     "de265hip_picture_build", "de265hip_picture_run", "de265hip_decoder_sync", "de265hip_picture_free",
     "de265hip_decode_picture", "de265hip_picture_get_stats",
     "de265hip_set_profiling", "de265hip_get_kernel_times", "de265hip_derive_edge_flags", "de265hip_intra_used_units",
@@ -27,6 +28,7 @@ EXPORTS = [
     "de265hip_recorder_desc", "de265hip_recorder_submit",
     "de265hip_fn_transform_add", "de265hip_fn_transform_skip_add", "de265hip_fn_transform_bypass_add",
     "de265hip_fn_put_qpel", "de265hip_fn_put_epel", "de265hip_fn_put_pred",
+    "init_acceleration_functions_hip",                  # include/de265_hip_vtable.h
 ]
 
 
@@ -58,6 +60,7 @@ def lib():
     L.de265hip_dpb_download.argtypes = [vp, i32, i32, vp, C.c_ssize_t]
     L.de265hip_dpb_plane.argtypes = [vp, i32, i32, pp(vp), pp(C.c_ssize_t)]
     L.de265hip_dpb_info.argtypes = [vp, i32, pp(i32), pp(i32), pp(i32), pp(i32)]
+    L.de265hip_dpb_copy.argtypes = [vp, i32, vp, i32]
     L.de265hip_picture_build.argtypes = [vp, i32, pp(_abi.PictureDesc), pp(vp)]
     L.de265hip_picture_run.argtypes = [vp, vp, i32]
     L.de265hip_decoder_sync.argtypes = [vp]
@@ -184,6 +187,10 @@ class Decoder:
         p, s = C.c_void_p(), C.c_ssize_t()
         _chk(lib().de265hip_dpb_plane(self._h, slot, c_idx, C.byref(p), C.byref(s)), "dpb_plane")
         return p.value, s.value
+
+    def copy_slot_to(self, slot, other, other_slot):
+        """Device-to-device hand-over of a finished reference picture to another decoder."""
+        _chk(lib().de265hip_dpb_copy(self._h, slot, other._h, other_slot), "dpb_copy")
 
     # --- pictures ---
     def build(self, dst_slot, desc):

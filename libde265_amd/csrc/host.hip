@@ -518,6 +518,39 @@ int de265hip_dpb_plane(de265hip_decoder* d, int slot, int c, void** dev_ptr, ptr
   return 0;
 }
 
+int de265hip_dpb_copy(de265hip_decoder* sd, int ss, de265hip_decoder* dd, int ds)
+{
+  if (!sd || !dd || ss < 0 || ss >= DE265HIP_MAX_DPB_SLOTS || ds < 0 || ds >= DE265HIP_MAX_DPB_SLOTS || !sd->slots[ss].valid ||
+      (sd == dd && ss == ds))
+    return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  const Slot& S = sd->slots[ss];
+  {
+    std::lock_guard<std::mutex> lk(dd->mu);
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    if (hipSetDevice(dd->device) != hipSuccess) return DE265HIP_ERROR_DECODING;
+    int rc = alloc_slot(dd->slots[ds], S.w, S.h, S.bdY, S.bdC);
+    (void)hipSetDevice(prev);
+    if (rc) return rc;
+  }
+  Slot& D = dd->slots[ds];
+  hipEvent_t ev = nullptr;
+  HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming), DE265HIP_ERROR_OUT_OF_MEMORY);
+  int rc = 0;
+  for (int c = 0; c < 3 && !rc; c++) {
+    const int h = c ? S.h / 2 : S.h;
+    const size_t bytes = (size_t)S.pl[c].stride * h * px_bytes(c ? S.bdC : S.bdY);      // same pitch on both sides (alloc_slot)
+    hipError_t e = sd->device == dd->device
+      ? hipMemcpyAsync(D.pl[c].ptr, S.pl[c].ptr, bytes, hipMemcpyDeviceToDevice, sd->stream)
+      : hipMemcpyPeerAsync(D.pl[c].ptr, dd->device, S.pl[c].ptr, sd->device, bytes, sd->stream);
+    if (e != hipSuccess) rc = DE265HIP_ERROR_DECODING;
+  }
+  if (!rc && (hipEventRecord(ev, sd->stream) != hipSuccess || hipStreamWaitEvent(dd->stream, ev, 0) != hipSuccess))
+    rc = DE265HIP_ERROR_DECODING;
+  (void)hipEventDestroy(ev);            // (released once it has completed)
+  return rc;
+}
+
 void de265hip_picture_free(de265hip_picture* p)
 {
   if (!p) return;

@@ -77,3 +77,53 @@ def send_reference_picture(dist, planes, src, dst, rank, device="cpu"):
         for p in planes:
             dist.recv(p, src=src)
     return planes
+
+
+# ---- the same exchange on DEVICE-RESIDENT DPB planes (the product's picture store) -----------------------------
+class _DevPlane:
+    """__cuda_array_interface__ holder: lets torch view a DPB plane's device memory without copying."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def dpb_plane_tensors(dec, slot):
+    """Zero-copy torch uint8 views (pitch x rows, padding included) of the three planes of a decoder's DPB slot
+    (de265hip_dpb_plane).  The caller orders access: dec.sync() before another stream reads them, and
+    torch.cuda.synchronize() (or an event) before the decoder's kernels read what torch wrote."""
+    import torch
+    w, h, _, _ = dec.dpb_info(slot)
+    views = []
+    for c in range(3):
+        ptr, stride_bytes = dec.plane(slot, c)
+        rows = h // 2 if c else h
+        views.append(torch.as_tensor(_DevPlane(ptr, stride_bytes * rows), device="cuda"))
+    return views
+
+
+def send_reference_picture_dpb(dist, dec, slot, src, dst, rank):
+    """Open-GOP exchange between ranks on the planes where they live: rank `src` sends DPB slot `slot` of its decoder
+    to rank `dst` (RCCL point-to-point over xGMI, 24.9 MB per 4K Main10 picture), which receives into the same slot of
+    its own decoder (already dpb_alloc'ed to the same geometry).  No host staging, no collective for the other ranks."""
+    import torch
+    if rank not in (src, dst):
+        return
+    if rank == src:
+        dec.sync()                                   # the picture is finished before it leaves
+    for t in dpb_plane_tensors(dec, slot):
+        if rank == src:
+            dist.send(t, dst=dst)
+        else:
+            dist.recv(t, src=src)
+    torch.cuda.synchronize()                         # received planes are in place before the decoder's stream reads them
+
+
+def broadcast_reference_picture_dpb(dist, dec, slot, src, rank, group=None):
+    """The same for several consumers: RCCL broadcast of the three planes from rank `src` (per-link bound on xGMI:
+    prefer send_reference_picture_dpb to the actual consumers when they are few)."""
+    import torch
+    if rank == src:
+        dec.sync()
+    for t in dpb_plane_tensors(dec, slot):
+        dist.broadcast(t, src=src, group=group)
+    torch.cuda.synchronize()

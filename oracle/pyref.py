@@ -74,6 +74,8 @@ def lib():
         L.ref_put_pred.restype = None
         L.ref_put_pred.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_void_p,
                                    C.c_ssize_t] + [C.c_int] * 7
+        L.ref_vtable_compare.restype = C.c_int
+        L.ref_vtable_compare.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_int)]
         L.ref_intra_tu.restype = C.c_int
         L.ref_intra_tu.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_ssize_t,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]

@@ -536,6 +536,178 @@ void ref_put_pred(int mode, int bit_depth, void* dst, ptrdiff_t ds, const int16_
   }
 }
 
+/* ---- Interface 1 check: the product's init_acceleration_functions_hip (passed in as a pointer; this library never
+ * links the product) fills a REAL struct acceleration_functions after the fallback, as decctx.cc:430-449 would, and
+ * every decoder slot is then called through the reference's own struct type next to the fallback's slot on the same
+ * seeded inputs.  counts[k] receives the number of mismatching calls of family k:
+ *   0 put_*_pred (8 slots)  1 put_hevc_epel* (8)  2 put_hevc_qpel (32)  3 transform_add / dst_add (10)
+ *   4 transform_bypass*, transform_skip_residual, rdpcm_*, transform_id{c,s}t_* (11)  5 add_residual (2)
+ *   6 rotate_coefficients  7 transform_skip_rdpcm_{v,h}_8  8 slots that must keep the fallback's pointer
+ * Returns the number of slot calls made. */
+int ref_vtable_compare(void (*init_hip)(struct acceleration_functions*), uint64_t seed, int iters, int* counts)
+{
+  acceleration_functions R, H;
+  memset(&R,0,sizeof(R)); memset(&H,0,sizeof(H));
+  init_acceleration_functions_fallback(&R);
+  init_acceleration_functions_fallback(&H);
+  init_hip(&H);
+  for (int k=0;k<9;k++) counts[k]=0;
+  uint64_t st = seed*6364136223846793005ull + 1442695040888963407ull;
+  auto rnd = [&](int lo,int hi)->int { st = st*6364136223846793005ull + 1442695040888963407ull; return lo + (int)((st>>33) % (uint64_t)(hi-lo+1)); };
+  int calls = 0;
+  // encoder slots and the deprecated transform_skip_{8,16} stay with the fallback
+  if (H.fwd_transform_4x4_dst_8 != R.fwd_transform_4x4_dst_8 || H.transform_skip_8 != R.transform_skip_8 || H.transform_skip_16 != R.transform_skip_16) counts[8]++;
+  for (int k=0;k<4;k++) if (H.fwd_transform_8[k] != R.fwd_transform_8[k] || H.hadamard_transform_8[k] != R.hadamard_transform_8[k]) counts[8]++;
+  // and every decoder slot was replaced
+  if (H.put_weighted_pred_avg_8 == R.put_weighted_pred_avg_8 || H.transform_add_16[3] == R.transform_add_16[3] ||
+      H.put_hevc_qpel_16[3][3] == R.put_hevc_qpel_16[3][3] || H.transform_idct_32x32 == R.transform_idct_32x32 ||
+      H.add_residual_16 == R.add_residual_16 || H.rdpcm_h == R.rdpcm_h) counts[8]++;
+
+  static const int bds[4] = { 8, 9, 10, 12 };
+  for (int it=0; it<iters; it++) {
+    const int bd = bds[it & 3];
+    const int maxv = (1<<bd)-1;
+    const bool hi = bd > 8;
+    // ---- sample prediction writes
+    {
+      int w = 2*rnd(1,32), h = rnd(1,32)*2, ss = 64, ds = 80;
+      std::vector<int16_t> a(ss*64), b(ss*64);
+      for (auto& v : a) v = (int16_t)rnd(-9000,16383);
+      for (auto& v : b) v = (int16_t)rnd(-9000,16383);
+      std::vector<uint16_t> d0(ds*64), d1, d2;
+      for (auto& v : d0) v = (uint16_t)rnd(0,maxv);
+      int w0 = rnd(-128,127), w1 = rnd(-128,127), o0 = rnd(-128,127)*(1<<(bd-8)), o1 = rnd(-128,127)*(1<<(bd-8));
+      int wd = rnd(0,7) + (14-bd > 2 ? 14-bd : 2);
+      for (int mode=0; mode<4; mode++) {
+        if (!hi) {
+          std::vector<uint8_t> x(ds*64), y;
+          for (size_t i=0;i<x.size();i++) x[i] = (uint8_t)d0[i];
+          y = x;
+          switch (mode) {
+            case 0: R.put_unweighted_pred_8(x.data(),ds,a.data(),ss,w,h); H.put_unweighted_pred_8(y.data(),ds,a.data(),ss,w,h); break;
+            case 1: R.put_weighted_pred_8(x.data(),ds,a.data(),ss,w,h,w0,o0,wd); H.put_weighted_pred_8(y.data(),ds,a.data(),ss,w,h,w0,o0,wd); break;
+            case 2: R.put_weighted_pred_avg_8(x.data(),ds,a.data(),b.data(),ss,w,h); H.put_weighted_pred_avg_8(y.data(),ds,a.data(),b.data(),ss,w,h); break;
+            default: R.put_weighted_bipred_8(x.data(),ds,a.data(),b.data(),ss,w,h,w0,o0,w1,o1,wd); H.put_weighted_bipred_8(y.data(),ds,a.data(),b.data(),ss,w,h,w0,o0,w1,o1,wd); break;
+          }
+          if (x != y) counts[0]++;
+        } else {
+          d1 = d0; d2 = d0;
+          switch (mode) {
+            case 0: R.put_unweighted_pred_16(d1.data(),ds,a.data(),ss,w,h,bd); H.put_unweighted_pred_16(d2.data(),ds,a.data(),ss,w,h,bd); break;
+            case 1: R.put_weighted_pred_16(d1.data(),ds,a.data(),ss,w,h,w0,o0,wd,bd); H.put_weighted_pred_16(d2.data(),ds,a.data(),ss,w,h,w0,o0,wd,bd); break;
+            case 2: R.put_weighted_pred_avg_16(d1.data(),ds,a.data(),b.data(),ss,w,h,bd); H.put_weighted_pred_avg_16(d2.data(),ds,a.data(),b.data(),ss,w,h,bd); break;
+            default: R.put_weighted_bipred_16(d1.data(),ds,a.data(),b.data(),ss,w,h,w0,o0,w1,o1,wd,bd); H.put_weighted_bipred_16(d2.data(),ds,a.data(),b.data(),ss,w,h,w0,o0,w1,o1,wd,bd); break;
+          }
+          if (d1 != d2) counts[0]++;
+        }
+        calls++;
+      }
+    }
+    // ---- interpolation: the block sits in a plane with exactly the margins its fraction may read (guard cells differ
+    // between the two runs: a slot that reads beyond its margins shows up as a mismatch)
+    {
+      const int PW = 96, PH = 96;
+      std::vector<uint16_t> p16(PW*PH); std::vector<uint8_t> p8(PW*PH);
+      for (int i=0;i<PW*PH;i++) { p16[i] = (uint16_t)rnd(0,maxv); p8[i] = (uint8_t)p16[i]; }
+      ALIGNED_16(int16_t) mcb[64*72];
+      for (int k=0;k<2;k++) {
+        const bool luma = k==0;
+        int w = luma ? 4*rnd(1,16) : 2*rnd(1,16), h = luma ? 4*rnd(1,16) : 2*rnd(1,16);
+        int fx = rnd(0, luma?3:7), fy = rnd(0, luma?3:7);
+        int x0 = rnd(4, PW-w-5), y0 = rnd(4, PH-h-5);
+        std::vector<int16_t> o1(64*64, 0), o2(64*64, 0);
+        if (luma) {
+          if (hi) { R.put_hevc_qpel_16[fx][fy](o1.data(),64,&p16[x0+y0*PW],PW,w,h,mcb,bd); H.put_hevc_qpel_16[fx][fy](o2.data(),64,&p16[x0+y0*PW],PW,w,h,mcb,bd); }
+          else    { R.put_hevc_qpel_8[fx][fy](o1.data(),64,&p8[x0+y0*PW],PW,w,h,mcb);      H.put_hevc_qpel_8[fx][fy](o2.data(),64,&p8[x0+y0*PW],PW,w,h,mcb); }
+          if (o1 != o2) counts[2]++;
+        } else {
+          // slot choice of mc_chroma (motion.cc:206-267)
+          if (hi) {
+            auto fr = (fx==0&&fy==0) ? R.put_hevc_epel_16 : (fy==0 ? R.put_hevc_epel_h_16 : (fx==0 ? R.put_hevc_epel_v_16 : R.put_hevc_epel_hv_16));
+            auto fh = (fx==0&&fy==0) ? H.put_hevc_epel_16 : (fy==0 ? H.put_hevc_epel_h_16 : (fx==0 ? H.put_hevc_epel_v_16 : H.put_hevc_epel_hv_16));
+            fr(o1.data(),64,&p16[x0+y0*PW],PW,w,h,fx,fy,mcb,bd); fh(o2.data(),64,&p16[x0+y0*PW],PW,w,h,fx,fy,mcb,bd);
+          } else if (fx==0 && fy==0) {
+            R.put_hevc_epel_8(o1.data(),64,&p8[x0+y0*PW],PW,w,h,fx,fy,mcb); H.put_hevc_epel_8(o2.data(),64,&p8[x0+y0*PW],PW,w,h,fx,fy,mcb);
+          } else {
+            auto fr = fy==0 ? R.put_hevc_epel_h_8 : (fx==0 ? R.put_hevc_epel_v_8 : R.put_hevc_epel_hv_8);
+            auto fh = fy==0 ? H.put_hevc_epel_h_8 : (fx==0 ? H.put_hevc_epel_v_8 : H.put_hevc_epel_hv_8);
+            fr(o1.data(),64,&p8[x0+y0*PW],PW,w,h,fx,fy,mcb,8); fh(o2.data(),64,&p8[x0+y0*PW],PW,w,h,fx,fy,mcb,8);
+          }
+          if (o1 != o2) counts[1]++;
+        }
+        calls++;
+      }
+    }
+    // ---- transforms
+    {
+      const int log2 = 2 + (it>>2)%4, nT = 1<<log2, n = nT*nT, ds = 48;
+      std::vector<int16_t> c(n, 0);
+      const int kind = rnd(0,4);
+      for (int i=0;i<n;i++) {
+        if (kind==0) c[i] = (int16_t)((i%nT<4 && i/nT<4) ? rnd(-600,600) : 0);
+        else if (kind==1) c[i] = (int16_t)rnd(-300,300);
+        else if (kind==2) { int q = rnd(0,4); c[i] = q==0 ? -32768 : (q==1 ? 32767 : 0); }
+        else if (kind==3) c[i] = (int16_t)rnd(-32768,32767);
+      }
+      if (kind==4) c[rnd(0,n-1)] = (int16_t)rnd(-32768,32767);
+      std::vector<uint16_t> d0(ds*32);
+      for (auto& v : d0) v = (uint16_t)rnd(0,maxv);
+      for (int dst=0; dst < (log2==2 ? 2 : 1); dst++) {
+        if (hi) {
+          std::vector<uint16_t> x = d0, y = d0;
+          if (dst) { R.transform_4x4_dst_add_16(x.data(),c.data(),ds,bd); H.transform_4x4_dst_add_16(y.data(),c.data(),ds,bd); }
+          else     { R.transform_add_16[log2-2](x.data(),c.data(),ds,bd); H.transform_add_16[log2-2](y.data(),c.data(),ds,bd); }
+          if (x != y) counts[3]++;
+        } else {
+          std::vector<uint8_t> x(d0.size()), y;
+          for (size_t i=0;i<x.size();i++) x[i] = (uint8_t)d0[i];
+          y = x;
+          if (dst) { R.transform_4x4_dst_add_8(x.data(),c.data(),ds); H.transform_4x4_dst_add_8(y.data(),c.data(),ds); }
+          else     { R.transform_add_8[log2-2](x.data(),c.data(),ds); H.transform_add_8[log2-2](y.data(),c.data(),ds); }
+          if (x != y) counts[3]++;
+        }
+        calls++;
+      }
+      // int32-residual family
+      std::vector<int32_t> r1(n), r2(n);
+      const int bdShift = 20-bd, tsShift = 5+log2;
+      auto cmp4 = [&]() { if (r1 != r2) counts[4]++; calls++; };
+      R.transform_bypass(r1.data(),c.data(),nT); H.transform_bypass(r2.data(),c.data(),nT); cmp4();
+      R.transform_bypass_rdpcm_v(r1.data(),c.data(),nT); H.transform_bypass_rdpcm_v(r2.data(),c.data(),nT); cmp4();
+      R.transform_bypass_rdpcm_h(r1.data(),c.data(),nT); H.transform_bypass_rdpcm_h(r2.data(),c.data(),nT); cmp4();
+      R.transform_skip_residual(r1.data(),c.data(),nT,tsShift,bdShift); H.transform_skip_residual(r2.data(),c.data(),nT,tsShift,bdShift); cmp4();
+      R.rdpcm_v(r1.data(),c.data(),nT,tsShift,bdShift); H.rdpcm_v(r2.data(),c.data(),nT,tsShift,bdShift); cmp4();
+      R.rdpcm_h(r1.data(),c.data(),nT,tsShift,bdShift); H.rdpcm_h(r2.data(),c.data(),nT,tsShift,bdShift); cmp4();
+      switch (log2) {
+        case 2: R.transform_idct_4x4(r1.data(),c.data(),bdShift,15); H.transform_idct_4x4(r2.data(),c.data(),bdShift,15); cmp4();
+                R.transform_idst_4x4(r1.data(),c.data(),bdShift,15); H.transform_idst_4x4(r2.data(),c.data(),bdShift,15); cmp4(); break;
+        case 3: R.transform_idct_8x8(r1.data(),c.data(),bdShift,15); H.transform_idct_8x8(r2.data(),c.data(),bdShift,15); cmp4(); break;
+        case 4: R.transform_idct_16x16(r1.data(),c.data(),bdShift,15); H.transform_idct_16x16(r2.data(),c.data(),bdShift,15); cmp4(); break;
+        default: R.transform_idct_32x32(r1.data(),c.data(),bdShift,15); H.transform_idct_32x32(r2.data(),c.data(),bdShift,15); cmp4(); break;
+      }
+      // add_residual on whatever the last transform left in r1 (wide range incl. clipping)
+      for (auto& v : r1) v = v / (1 + rnd(0,3));
+      if (hi) { std::vector<uint16_t> x = d0, y = d0; R.add_residual_16(x.data(),ds,r1.data(),nT,bd); H.add_residual_16(y.data(),ds,r1.data(),nT,bd); if (x != y) counts[5]++; }
+      else { std::vector<uint8_t> x(d0.size()), y; for (size_t i=0;i<x.size();i++) x[i] = (uint8_t)d0[i]; y = x;
+             R.add_residual_8(x.data(),ds,r1.data(),nT,bd); H.add_residual_8(y.data(),ds,r1.data(),nT,bd); if (x != y) counts[5]++; }
+      calls++;
+      std::vector<int16_t> c1 = c, c2 = c;
+      R.rotate_coefficients(c1.data(),nT); H.rotate_coefficients(c2.data(),nT);
+      if (c1 != c2) counts[6]++;
+      calls++;
+      if (!hi) {
+        std::vector<uint8_t> x(d0.size()), y; for (size_t i=0;i<x.size();i++) x[i] = (uint8_t)d0[i]; y = x;
+        R.transform_skip_rdpcm_v_8(x.data(),c.data(),log2,ds); H.transform_skip_rdpcm_v_8(y.data(),c.data(),log2,ds);
+        if (x != y) counts[7]++;
+        R.transform_skip_rdpcm_h_8(x.data(),c.data(),log2,ds); H.transform_skip_rdpcm_h_8(y.data(),c.data(),log2,ds);
+        if (x != y) counts[7]++;
+        calls += 2;
+      }
+    }
+  }
+  return calls;
+}
+
 /* One intra TU on a small single-slice picture: decode_intra_prediction (intrapred.cc:1115) reads
  * its neighbours from `plane` (w x h luma samples of geometry, the component plane is passed) and
  * writes the nT x nT block at (x0,y0) (component samples).  All earlier z-order neighbours inside

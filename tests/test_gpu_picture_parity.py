@@ -413,3 +413,41 @@ def test_arena_pool_reuse_keeps_pictures_apart(dec):
             finally:
                 pic.free()
             assert all(np.array_equal(g, e) for g, e in zip(got, exps[k])), (rep, k)
+
+
+def test_reference_picture_exchange_on_dpb_planes(dec):
+    """SURVEY 8e on the product's own picture store: slot -> slot device copy between two decoders
+    (de265hip_dpb_copy), and the zero-copy torch views RCCL sends/receives on (farm.dpb_plane_tensors):
+    a B picture decoded by the second decoder from the handed-over references equals the reference's."""
+    import torch
+    from libde265_amd import backend, farm
+    w, h, bd = 352, 288, 10
+    refs = {0: pysynth.fill_planes(w, h, bd, 11), 1: pysynth.fill_planes(w, h, bd, 12)}
+    for s, pl in refs.items():
+        dec.dpb_alloc(s, w, h, bd); dec.upload(s, pl)
+    d2 = backend.Decoder()
+    try:
+        dec.copy_slot_to(0, d2, 0)                       # C ABI, device to device, stream-ordered
+        d2.dpb_alloc(1, w, h, bd)
+        src, dst = farm.dpb_plane_tensors(dec, 1), farm.dpb_plane_tensors(d2, 1)
+        dec.sync()
+        for a, b in zip(src, dst):                       # what dist.send / dist.recv do between ranks, on one GPU
+            assert a.is_cuda and a.dtype == torch.uint8 and a.numel() == b.numel()
+            b.copy_(a)
+        torch.cuda.synchronize()
+        for s in (0, 1):
+            got = d2.download(s, w, h, bd)
+            assert all(np.array_equal(g, e) for g, e in zip(got, refs[s]))
+        sp = pysynth.SynthPicture(pysynth.default_config(w, h, bd, 0, seed=4242))
+        exp = pyoracle.alloc_planes(w, h, bd)
+        pyoracle.reconstruct(sp.desc, sp.order, refs, exp)
+        d2.dpb_alloc(2, w, h, bd)
+        pic = d2.build(2, sp.desc)
+        try:
+            d2.run(pic, 2); d2.sync()
+            got = d2.download(2, w, h, bd)
+        finally:
+            pic.free()
+        assert all(np.array_equal(g, e) for g, e in zip(got, exp))
+    finally:
+        d2.close()
