@@ -17,9 +17,13 @@ HEADER = os.path.join(ROOT, "include", "de265_hip.h")
 
 
 def declared_functions():
+    """every function include/*.h declares: de265hip_* of de265_hip.h + the vtable entry point of de265_hip_vtable.h"""
     txt = open(HEADER).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(de265hip_\w+)\s*\(", txt)))
+    names = set(re.findall(r"\b(de265hip_\w+)\s*\(", txt))
+    vt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "de265_hip_vtable.h")).read(), flags=re.S)
+    names |= set(re.findall(r"\bvoid\s+(init_acceleration_functions_\w+)\s*\(", vt))
+    return sorted(names)
 
 
 def test_library_is_built_and_loads():
