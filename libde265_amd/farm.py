@@ -91,7 +91,7 @@ def dpb_plane_tensors(dec, slot):
     """Zero-copy torch uint8 views (pitch x rows, padding included) of the three planes of a decoder's DPB slot
     (de265hip_dpb_plane).  The caller orders access: dec.sync() before another stream reads them, and
     torch.cuda.synchronize() (or an event) before the decoder's kernels read what torch wrote."""
-    import torch
+    import torch          # (import torch before the first libde265_hip.so call in such a process: tests/conftest.py)
     w, h, _, _ = dec.dpb_info(slot)
     views = []
     for c in range(3):

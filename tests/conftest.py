@@ -7,5 +7,11 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
         sys.path.insert(0, p)
 
 
+# Processes that use both torch and libde265_hip.so must import torch FIRST: the torch wheel bundles its own ROCm
+# runtime under the same sonames as /opt/rocm's; whichever is loaded first serves both, and torch's device
+# enumeration only works on top of its own (observed: "No HIP GPUs are available" when libde265_hip.so came first).
+import torch  # noqa: E402,F401
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
