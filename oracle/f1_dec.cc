@@ -1,0 +1,47 @@
+/*
+ * f1_dec.cc -- minimal driver of the PATCHED reference (oracle/Makefile `make f1`): pushes a bitstream through
+ * libde265's public API (de265.h: de265_new_decoder, de265_push_data, de265_decode, de265_get_next_picture; scalar
+ * DSP path, no worker threads = decode_slice_unit_sequential + run_postprocessing_filters_sequential) so that the
+ * hooks of oracle/f1_recorder.cc see every picture.  usage: F1_OUT=dir f1_dec stream.bin
+ */
+#include "libde265/de265.h"
+#include <stdio.h>
+#include <stdlib.h>
+
+int main(int argc, char** argv)
+{
+  if (argc < 2) { fprintf(stderr, "usage: F1_OUT=dir %s stream.bin\n", argv[0]); return 2; }
+  FILE* f = fopen(argv[1], "rb");
+  if (!f) { perror(argv[1]); return 2; }
+  de265_decoder_context* ctx = de265_new_decoder();
+  de265_set_parameter_int(ctx, DE265_DECODER_PARAM_ACCELERATION_CODE, de265_acceleration_SCALAR);
+  de265_set_parameter_bool(ctx, DE265_DECODER_PARAM_BOOL_SEI_CHECK_HASH, 1);
+  unsigned char buf[65536];
+  int n_out = 0, more = 1;
+  size_t n;
+  while ((n = fread(buf, 1, sizeof(buf), f)) > 0) {
+    if (de265_push_data(ctx, buf, (int)n, 0, NULL) != DE265_OK) return 3;
+    for (;;) {
+      de265_error e = de265_decode(ctx, &more);
+      while (de265_get_next_picture(ctx)) n_out++;
+      if (e == DE265_ERROR_WAITING_FOR_INPUT_DATA || !more) break;
+      if (e != DE265_OK) { fprintf(stderr, "decode error: %s\n", de265_get_error_text(e)); return 4; }
+    }
+  }
+  de265_flush_data(ctx);
+  more = 1;
+  while (more) {
+    de265_error e = de265_decode(ctx, &more);
+    while (de265_get_next_picture(ctx)) n_out++;
+    if (e != DE265_OK && e != DE265_ERROR_WAITING_FOR_INPUT_DATA) break;
+  }
+  for (;;) {
+    de265_error w = de265_get_warning(ctx);
+    if (w == DE265_OK) break;
+    fprintf(stderr, "warning: %s\n", de265_get_error_text(w));
+  }
+  de265_free_decoder(ctx);
+  fclose(f);
+  printf("%d pictures\n", n_out);
+  return 0;
+}
