@@ -296,6 +296,12 @@ int  de265hip_record_blk_planes(de265hip_recorder*, const uint8_t* blk_flags, co
 const de265hip_picture_desc* de265hip_recorder_desc(de265hip_recorder*);
 int  de265hip_recorder_submit(de265hip_decoder*, int dst_slot, de265hip_recorder*, de265hip_picture** out);
 
+/* Profiling aid: the host stage of de265hip_picture_build `reps` times, without a GPU and without any HIP call. */
+int  de265hip_debug_build_host_only(const de265hip_picture_desc*, int reps);
+/* FNV-1a hash over everything the last de265hip_debug_build_host_only of this thread would have uploaded (regression
+ * net for changes to the host stage: tools/exp/build_hash.py). */
+uint64_t de265hip_debug_last_build_hash(void);
+
 /* Introspection used by bench/tests */
 typedef struct de265hip_picture_stats {
   int32_t n_levels;          /* intra dependency levels at TU granularity */

@@ -19,7 +19,7 @@ EXPORTS = [
     "de265hip_version", "de265hip_device_count",
     "de265hip_decoder_new", "de265hip_decoder_free",
     "de265hip_dpb_alloc", "de265hip_dpb_upload", "de265hip_dpb_download", "de265hip_dpb_plane", "de265hip_dpb_info",
-    "de265hip_dpb_copy",
+    "de265hip_dpb_copy", "de265hip_debug_build_host_only", "de265hip_debug_last_build_hash",
     "de265hip_picture_build", "de265hip_picture_run", "de265hip_decoder_sync", "de265hip_picture_free",
     "de265hip_decode_picture", "de265hip_picture_get_stats",
     "de265hip_set_profiling", "de265hip_get_kernel_times", "de265hip_derive_edge_flags", "de265hip_intra_used_units",
@@ -61,6 +61,9 @@ def lib():
     L.de265hip_dpb_plane.argtypes = [vp, i32, i32, pp(vp), pp(C.c_ssize_t)]
     L.de265hip_dpb_info.argtypes = [vp, i32, pp(i32), pp(i32), pp(i32), pp(i32)]
     L.de265hip_dpb_copy.argtypes = [vp, i32, vp, i32]
+    L.de265hip_debug_build_host_only.argtypes = [pp(_abi.PictureDesc), i32]
+    L.de265hip_debug_last_build_hash.restype = C.c_uint64
+    L.de265hip_debug_last_build_hash.argtypes = []
     L.de265hip_picture_build.argtypes = [vp, i32, pp(_abi.PictureDesc), pp(vp)]
     L.de265hip_picture_run.argtypes = [vp, vp, i32]
     L.de265hip_decoder_sync.argtypes = [vp]

@@ -13,6 +13,7 @@
 #include <new>
 #include <vector>
 #include <mutex>
+#include <chrono>
 
 #include "kernels.h"
 
@@ -49,6 +50,7 @@ struct StageBuf { void* ptr = nullptr; size_t bytes = 0; hipEvent_t copied = nul
 
 struct de265hip_decoder {
   int device = 0;
+  bool dry = false;                   // de265hip_debug_build_host_only: the host stage without any HIP call (profiling on a CPU box)
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;  // uploads of command buffers (de265hip_picture_build), overlapping the kernels of earlier pictures
   std::mutex mu;                      // guards live, the two pools and slot allocation: build()/free() may come from several host threads
@@ -100,6 +102,7 @@ struct de265hip_picture {
   TuTask* d_l0 = nullptr; int n_l0 = 0;       // run mode: inter residual TUs + residual-only copies of intra TUs
   int16_t* d_resid = nullptr;                 // precomputed residual blocks of intra TUs
   int n_runs = 0, n_batches = 0, n_workers = 0, run_box = 64, ticket_batch = 1; size_t sync_bytes = 0;
+  bool run_direct = false;                    // k_run with one workgroup per ticket instead of persistent workers (wide pictures)
   uint32_t* d_slots = nullptr;
   uint32_t gen = 0;                           // runs of this picture so far (k_run flag generation)
   std::vector<int> level_start;       // level_start[l] .. level_start[l+1] in d_tus
@@ -383,6 +386,19 @@ int acquire_stage(de265hip_decoder* dec, size_t bytes, int* index)
   return 0;
 }
 
+// DE265HIP_BUILD_TIMING=1: where the host stage of a picture goes (stderr, one line per build)
+struct PhaseTimer {
+  bool on; std::chrono::steady_clock::time_point t0; char buf[512]; int len = 0;
+  PhaseTimer() : on(getenv("DE265HIP_BUILD_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
+  void mark(const char* name) {
+    if (!on) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    len += snprintf(buf + len, sizeof(buf) - len, " %s=%.2fms", name, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+  void done() { if (on) fprintf(stderr, "de265hip build:%s\n", buf); }
+};
+
 struct ArenaLayout {
   size_t total = 0;
   size_t add(size_t bytes) { size_t o = total; total = (total + bytes + 255) & ~(size_t)255; return o; }
@@ -582,17 +598,31 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   if (p.scaling_list_enable_flag && !d->scaling_factors) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   if (dst_slot < 0 || dst_slot >= DE265HIP_MAX_DPB_SLOTS) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
-  int rc;
-  {
+  int rc = 0;
+  if (!dec->dry) {
     std::lock_guard<std::mutex> lk(dec->mu);
     rc = alloc_slot(dec->slots[dst_slot], p.width, p.height, p.bit_depth_luma, p.bit_depth_chroma);
     if (!rc) rc = alloc_slot(dec->spare, p.width, p.height, p.bit_depth_luma, p.bit_depth_chroma);
   }
   if (rc) return rc;
 
-  Geometry g;
-  rc = make_geometry(p, g);
-  if (rc) return rc;
+  PhaseTimer pt;
+  // CtbAddrRStoTS / TileIdRS / MinTbAddrZS depend on the picture size, CTB / min TB size and the tile grid only: the same for
+  // every picture of a sequence.  One cached copy per host thread (4K: 522 240 z-scan addresses, 4 ms to compute).
+  struct GeoKey { int32_t w, h, lc, lt, nc, nr; uint16_t cb[24], rb[24]; };
+  static thread_local GeoKey g_key = {};
+  static thread_local Geometry g_cached;
+  static thread_local bool g_valid = false;
+  GeoKey key; memset(&key, 0, sizeof(key));
+  key.w = p.width; key.h = p.height; key.lc = p.log2_ctb_size; key.lt = p.log2_min_tb_size; key.nc = p.num_tile_columns; key.nr = p.num_tile_rows;
+  memcpy(key.cb, p.col_bd, sizeof(key.cb)); memcpy(key.rb, p.row_bd, sizeof(key.rb));
+  if (!g_valid || memcmp(&key, &g_key, sizeof(key)) != 0) {
+    g_valid = false;
+    rc = make_geometry(p, g_cached);
+    if (rc) return rc;
+    g_key = key; g_valid = true;
+  }
+  const Geometry& g = g_cached;
   if (d->n_ctbs != g.ctbs_w * g.ctbs_h) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   for (int i = 0; i < d->n_ctbs; i++)
     if (d->ctbs[i].slice_idx >= d->n_slices) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
@@ -608,6 +638,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   P.cb_qp_offset = p.pic_cb_qp_offset; P.cr_qp_offset = p.pic_cr_qp_offset;
   P.lf_across_tiles = p.loop_filter_across_tiles_enabled_flag; P.scaling_list = p.scaling_list_enable_flag;
 
+  pt.mark("geometry");
   // dependencies between intra TUs from the units each mode reads (DE265HIP_NO_MODE_DEPS: from every available unit)
   const bool mode_deps = getenv("DE265HIP_NO_MODE_DEPS") == nullptr;
   ensure_used_units();
@@ -646,9 +677,12 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
         ((tu.flags & DE265HIP_TU_CBF) && ((int64_t)tu.coeff_offset + tu.n_coeff > d->n_coeffs || tu.n_coeff > nT * nT))) {
       delete pic; return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
     }
-    if (tu.flags & DE265HIP_TU_CBF)
-      for (int k = 0; k < tu.n_coeff; k++)
-        if (d->coeff_pos[tu.coeff_offset + k] >= nT * nT) { delete pic; return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE; }
+    if (tu.flags & DE265HIP_TU_CBF) {
+      const uint16_t* cp = d->coeff_pos + tu.coeff_offset;
+      unsigned worst = 0;
+      for (int k = 0; k < tu.n_coeff; k++) worst = std::max<unsigned>(worst, cp[k]);      // (vectorises)
+      if (worst >= (unsigned)(nT * nT)) { delete pic; return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE; }
+    }
     if (!(tu.flags & (DE265HIP_TU_INTRA | DE265HIP_TU_CBF))) continue;       // nothing to reconstruct
     TuTask t; memset(&t, 0, sizeof(t));
     t.x0 = tu.x0; t.y0 = tu.y0; t.log2_size = tu.log2_size; t.c_idx = tu.c_idx; t.flags = tu.flags;
@@ -709,6 +743,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     max_level = std::max(max_level, level);
     tasks.push_back(t); levels.push_back(level);
   }
+  pt.mark("tu_scan");
   pic->level_start.assign(max_level + 2, 0);
   for (int l : levels) pic->level_start[l + 1]++;
   for (int l = 0; l <= max_level; l++) pic->level_start[l + 1] += pic->level_start[l];
@@ -723,7 +758,9 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
 
   // ---- runs in dependency (ticket) order: producers first
   std::vector<RunTask> runs; std::vector<uint32_t> run_deps, slots; std::vector<TuTask> run_tus, resid_only;
+  { size_t n_intra = 0; for (const auto& R : rb) n_intra += R.tus.size(); run_tus.reserve(n_intra); resid_only.reserve(n_intra); }
   const bool micro_off = getenv("DE265HIP_NO_MICRO") != nullptr;
+  const bool no_dense = getenv("DE265HIP_NO_DENSE") != nullptr;           // (not per run: getenv walks the whole environment)
   const int micro_tus = getenv("DE265HIP_MICRO_TUS") ? std::min(16, atoi(getenv("DE265HIP_MICRO_TUS"))) : 16;   // MICRO_TUS of k_run
   int64_t sum_lvls = 0, dbg_foreign = 0, dbg_w[4] = { 0, 0, 0, 0 };
   std::vector<uint8_t> dbg_micro;
@@ -779,16 +816,21 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       // dense: the run's TUs cover its whole bounding box AND every available neighbour outside the box lies on the row
       // above it or the column left of it (two stacked CUs with an inter CU beside the upper one do not qualify: the
       // lower CU reads above-right samples from inside the box's row range)
-      bool dense = own_samples == (R.x1 - R.x0) * (R.y1 - R.y0) && !getenv("DE265HIP_NO_DENSE");
+      bool dense = own_samples == (R.x1 - R.x0) * (R.y1 - R.y0) && !no_dense;
+      // (with the box covered, the only neighbour units that can lie outside "box + row above + column to the left" are
+      //  above-right units beyond the box's right edge of TUs below its first row, and below-left units beyond its bottom
+      //  edge of TUs right of its first column: two mask tests per TU)
       for (size_t i = 0; dense && i < R.tus.size(); i++) {
         const TuTask& tt = R.tus[i];
         const int nT = 1 << tt.log2_size, xB = tt.x0, yB = tt.y0, corner = nT >> 1;
-        auto ok = [&](int x, int y) { return (x >= R.x0 && x < R.x1 && y >= R.y0 && y < R.y1) || y == R.y0 - 1 || x == R.x0 - 1; };
-        for (int u = 0; u < corner && dense; u++)                               // left column, bottom -> top
-          if ((tt.avail >> u) & 1) dense = ok(xB - 1, yB + 2 * nT - 4 * u - 4) && ok(xB - 1, yB + 2 * nT - 4 * u - 1);
-        if (dense && ((tt.avail >> corner) & 1)) dense = ok(xB - 1, yB - 1);
-        for (int k = 0; k < corner && dense; k++)                               // top row, left -> right
-          if ((tt.avail >> (corner + 1 + k)) & 1) dense = ok(xB + 4 * k, yB - 1) && ok(xB + 4 * k + 3, yB - 1);
+        if (xB > R.x0 && yB + 2 * nT > R.y1) {                 // left column, unit u = rows yB+2nT-4u-4 .. -1 (bottom -> top)
+          const int umax = std::min(corner - 1, (yB + 2 * nT - 1 - R.y1) >> 2);
+          if (tt.avail & ((2ull << umax) - 1ull)) dense = false;
+        }
+        if (yB > R.y0 && xB + 2 * nT > R.x1) {                 // top row, unit k = columns xB+4k .. +3
+          const int kmin = std::max(0, (R.x1 - xB) >> 2);
+          if (kmin < corner && (tt.avail >> (corner + 1 + kmin)) & ((1ull << (corner - kmin)) - 1ull)) dense = false;
+        }
       }
       o.c_idx = (uint8_t)R.c; o.micro = (uint8_t)(micro[order[k]] | (dense ? 2 : 0)); o.n_tus = (uint16_t)R.tus.size();
       o.first_tu = (uint32_t)run_tus.size(); o.dep_offset = (uint32_t)run_deps.size(); o.n_deps = (uint16_t)R.deps.size();
@@ -799,51 +841,41 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       if (nl > 256) { delete pic; return DE265HIP_ERROR_NOT_IMPLEMENTED; }      // RUN_MAX_TUS of k_run
       o.n_lvls = (uint16_t)nl;
       sum_lvls += nl;
-      std::vector<TuTask> ordered; ordered.reserve(R.tus.size());
-      std::vector<uint32_t> ordered_req; ordered_req.reserve(R.tus.size());
+      // Order of the run's TUs in its record: one list per wavefront (list w = the TUs dealt to wavefront w), each in
+      // in-run level order, then the collective list (16x16 / 32x32 TUs, reconstructed by all wavefronts together).
+      // The TUs of one in-run level are independent of each other and are dealt round-robin to the wavefronts; the chain
+      // passes one workgroup barrier per level.  One sort by (list, level, decode index) on a reused scratch array.
+      // (measured on a 4K all-intra picture: this 3.46 ms; list scheduling that keeps z-scan chains on one wavefront,
+      //  with barriers only where a producer sits on another wavefront, 4.0-4.2 ms: a wavefront that runs ahead
+      //  arrives late at the barrier the others need; progress counters in LDS polled by the waiting wavefronts
+      //  3.9 ms: the pollers take issue slots from the working wavefronts of the other workgroups on their SIMDs;
+      //  round-robin lists with barriers only at cross-wavefront edges plus early arrival of the producing wavefront:
+      //  54 % fewer barriers, 3.33 instead of 3.19 ms -- the workgroup barrier is not what the chain waits for)
+      static thread_local std::vector<uint64_t> keys;
+      static thread_local std::vector<int> rank;
+      keys.clear(); rank.assign(nl + 1, 0);
       {
         const int nwv = micro[order[k]] ? 1 : dec->run_waves;
-        // the TUs of one in-run level are independent of each other: dealt round-robin to the wavefronts of the
-        // workgroup, every list in level order; the chain passes one workgroup barrier per level.
-        // (measured on a 4K all-intra picture: this 3.46 ms; list scheduling that keeps z-scan chains on one wavefront,
-        //  with barriers only where a producer sits on another wavefront, 4.0-4.2 ms: a wavefront that runs ahead
-        //  arrives late at the barrier the others need; progress counters in LDS polled by the waiting wavefronts
-        //  3.9 ms: the pollers take issue slots from the working wavefronts of the other workgroups on their SIMDs;
-        //  round-robin lists with barriers only at cross-wavefront edges plus early arrival of the producing wavefront:
-        //  54 % fewer barriers, 3.33 instead of 3.19 ms -- the workgroup barrier is not what the chain waits for)
-        std::vector<std::vector<int>> lists(nwv);             // TU indices (decode order inside the run)
-        std::vector<int> collective;                          // the 16x16 / 32x32 TUs: a fifth list behind the wavefronts' lists
-        std::vector<uint16_t> epoch(R.tus.size(), 0);
-        int n_epochs = nl > 0 ? nl - 1 : 0;
-        {
-          std::vector<int> rank(nl + 1, 0);
-          for (size_t i = 0; i < R.tus.size(); i++) {
-            epoch[i] = (uint16_t)(R.llev[i] - 1);
-            if (R.tus[i].log2_size > 3 && !micro[order[k]]) collective.push_back((int)i);   // reconstructed by all wavefronts together
-            else lists[rank[R.llev[i]]++ % nwv].push_back((int)i);
-          }
-          for (int w = 0; w < nwv; w++)
-            std::stable_sort(lists[w].begin(), lists[w].end(), [&](int a, int b) { return R.llev[a] < R.llev[b]; });
-          std::stable_sort(collective.begin(), collective.end(), [&](int a, int b) { return R.llev[a] < R.llev[b]; });
+        const int n_epochs = nl > 0 ? nl - 1 : 0;
+        for (size_t i = 0; i < R.tus.size(); i++) {
+          const int lev = R.llev[i];
+          const int list = (R.tus[i].log2_size > 3 && !micro[order[k]]) ? 4 : rank[lev]++ % nwv;
+          keys.push_back(((uint64_t)list << 40) | ((uint64_t)lev << 20) | (uint64_t)i);
         }
+        std::sort(keys.begin(), keys.end());
+        size_t pos = 0;
         for (int w = 0; w < 4; w++) {
-          if (w < nwv)
-            for (int i : lists[w]) {
-              TuTask tt = R.tus[i];
-              ordered.push_back(tt);
-              ordered_req.push_back(epoch[i]);
-              dbg_w[w]++;
-            }
-          o.wave_end[w] = (uint16_t)ordered.size();
+          while (pos < keys.size() && (int)(keys[pos] >> 40) <= w) { dbg_w[w]++; pos++; }
+          o.wave_end[w] = (uint16_t)pos;
         }
-        for (int i : collective) { ordered.push_back(R.tus[i]); ordered_req.push_back(epoch[i]); }
         if (n_epochs > 255) { delete pic; return DE265HIP_ERROR_NOT_IMPLEMENTED; }
         o.n_lvls = (uint16_t)n_epochs;                   // workgroup barriers of the run's chain
         dbg_foreign += n_epochs;
       }
       uint32_t samp = 0;
-      for (size_t oi = 0; oi < ordered.size(); oi++) {
-        TuTask tt = ordered[oi];
+      for (size_t oi = 0; oi < keys.size(); oi++) {
+        const size_t ti = (size_t)(keys[oi] & 0xFFFFFu);
+        TuTask tt = R.tus[ti];
         const uint32_t coeff_offset = tt.coeff_offset;
         tt.coeff_offset = samp; samp += 1u << (2 * tt.log2_size);
         if (tt.flags & DE265HIP_TU_CBF) {
@@ -852,13 +884,14 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
           TuTask ro = tt; ro.flags |= D265_TU_RESID_ONLY; ro.coeff_offset = coeff_offset;
           resid_only.push_back(ro);
         }
-        tt.run_level = (uint8_t)ordered_req[oi];         // the run-ordered copy carries the TU's barrier epoch
+        tt.run_level = (uint8_t)(R.llev[ti] - 1);        // the run-ordered copy carries the TU's barrier epoch
         run_tus.push_back(tt);
       }
       o.n_samples = samp;
       for (int dp : R.deps) run_deps.push_back((uint32_t)newidx[dp]);
     }
   }
+  pt.mark("runs");
   pic->n_runs = (int)runs.size();
   {
     // worker count = widest dependency level (more workers would only wait), within [64, 4 per CU]
@@ -871,6 +904,14 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     int cap = wenv ? atoi(wenv) : 512;
     pic->n_batches = (int)(slots.size() / RUN_TICKET_SLOTS);
     pic->n_workers = std::min(pic->n_batches, std::max(64, std::min(cap, widest + widest / 4)));
+    // direct mode (see k_run): when the picture is wide rather than deep - most of its runs sit in its widest level
+    // (a B picture: isolated intra CUs, 8 levels; an I picture: 126+ levels of ~100 runs)
+    const char* denv = getenv("DE265HIP_RUN_DIRECT");
+    // Measured (4K Main10, tools/exp/ab_env.sh): a B picture alone 96-104 us either way (its time is the 7-level chain of
+    // run hand-overs, not the ticket loop), but with three GOP streams in flight direct mode for B pictures costs 6 % and
+    // for all pictures 23 % (6 390 -> 6 010 -> 4 890 frames/s): thousands of resident workgroups hold LDS the other
+    // streams' kernels need.  Off unless asked for.
+    pic->run_direct = denv ? atoi(denv) != 0 : false;
     if (getenv("DE265HIP_PRINT_CRIT")) {               // diagnostic: longest path through the run DAG
       // cost model of one run (us; fitted to ablation timings): fixed + per barrier level + per TU a wavefront has to do
       // in sequence inside a level + per 16x16 / 32x32 TU (collective)
@@ -944,6 +985,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   }
   pic->n_l0 = (int)l0.size();
 
+  pt.mark("l0");
   // ---- MC tasks: resolve references, bi->uni shortcut, split into <=16x16 tiles
   std::vector<McTask> mcs;
   int64_t alg_mc = 0;
@@ -991,6 +1033,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   }
   pic->n_mc = (int)mcs.size();
 
+  pt.mark("mc");
   // ---- PCM tasks
   std::vector<PcmTask> pcms;
   for (int i = 0; i < d->n_pcms; i++) {
@@ -1054,6 +1097,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       o.perm_c_hi = (uint8_t)(perm[1] >> 7);
     }
 
+  pt.mark("pcm_sao_scan");
   // ---- one arena, one upload
   ArenaLayout L;
   const size_t o_tus = L.add(sorted.size() * sizeof(TuTask));
@@ -1080,7 +1124,9 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   int stage_idx = -1;
   uint8_t* host_base = nullptr;
   hipEvent_t stage_event = nullptr;
-  {
+  std::vector<uint8_t> dry_stage;
+  if (dec->dry) { dry_stage.resize(upload_bytes); host_base = dry_stage.data(); }
+  else {
     std::lock_guard<std::mutex> lk(dec->mu);
     rc = acquire_stage(dec, upload_bytes, &stage_idx);
     if (!rc) {
@@ -1119,9 +1165,25 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   if (d->blk_motion) put(o_mot, d->blk_motion, nblk * sizeof(de265hip_motion));
   else memset(host.data() + o_mot, 0xFF, nblk * sizeof(de265hip_motion));       // ref_slot = -1 everywhere
 
+  pt.mark("staging");
+  if (dec->dry) {                                    // FNV-1a over everything the device would receive (tools/exp/build_hash.py)
+    uint64_t hsh = 1469598103934665603ull;
+    auto mix = [&](const void* ptr, size_t n) { const uint8_t* b = (const uint8_t*)ptr; for (size_t i = 0; i < n; i++) { hsh ^= b[i]; hsh *= 1099511628211ull; } };
+    const size_t offs[] = { o_tus, o_cval, o_cpos, o_scal, o_mc, o_pcm, o_pcms, o_sl, o_ctb, o_tile, o_sao, o_flags, o_qp, o_mot, o_runs, o_rdeps, o_rtus, o_slots, o_l0, upload_bytes };
+    const size_t lens[] = { sorted.size() * sizeof(TuTask), (size_t)d->n_coeffs * 2, (size_t)d->n_coeffs * 2, (size_t)DE265HIP_SCALING_BLOB_BYTES, mcs.size() * sizeof(McTask),
+                            pcms.size() * sizeof(PcmTask), (size_t)d->n_pcm_samples * 2, (size_t)d->n_slices * sizeof(de265hip_slice_params), (size_t)d->n_ctbs * sizeof(de265hip_ctb_info),
+                            (size_t)d->n_ctbs * 2, (size_t)d->n_ctbs * sizeof(SaoCtb), nblk, nblk, nblk * sizeof(de265hip_motion), runs.size() * sizeof(RunTask), run_deps.size() * 4,
+                            run_tus.size() * sizeof(TuTask), slots.size() * 4, l0.size() * sizeof(TuTask), 0 };
+    for (int i = 0; i < 19; i++) mix(host.data() + offs[i], lens[i]);      // (only the written bytes: padding between sections is undefined)
+    const int64_t scal[] = { pic->n_workers, pic->n_batches, pic->n_l0, pic->n_l0_size[0], pic->n_l0_size[1], pic->n_l0_size[2], pic->n_l0_size[3], pic->n_mc, pic->n_pcm,
+                             pic->n_tus, pic->n_runs, (int64_t)n_resid, (int64_t)L.total, (int64_t)pic->any_edges, (int64_t)P.has_exempt, (int64_t)pic->run_direct, max_level, max_rl, (int64_t)sum_lvls };
+    mix(scal, sizeof(scal));
+    mix(pic->level_start.data(), pic->level_start.size() * sizeof(int));
+    dec->pooled_bytes = (size_t)hsh;
+  }
   pic->arena = pic->arena_buf.ptr;
   pic->arena_bytes = L.total;
-  {
+  if (!dec->dry) {
     hipStream_t cs = dec->copy_stream;
     // a recycled arena may still be read by kernels of the picture that had it before
     if (pic->arena_buf.used && hipStreamWaitEvent(cs, pic->arena_buf.last_use, 0) != hipSuccess) return fail(DE265HIP_ERROR_DECODING);
@@ -1159,12 +1221,36 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   pic->stats.alg_bytes_mc = alg_mc; pic->stats.alg_bytes_resid = alg_resid; pic->stats.alg_bytes_intra = alg_intra;
   pic->stats.alg_bytes_deblock = pic->any_edges ? 2 * Pbytes : 0;       // one read + one write
   pic->stats.alg_bytes_sao = p.sample_adaptive_offset_enabled_flag ? 2 * Pbytes + 16 * (int64_t)d->n_ctbs : 0;
-  {
+  if (!dec->dry) {
     std::lock_guard<std::mutex> lk(dec->mu);
     dec->live.push_back(pic);
   }
+  pt.mark("upload");
+  pt.done();
   *out = pic;
   return DE265HIP_OK;
+}
+
+// Profiling aid (tools/time_build.py --host-only): the host stage of de265hip_picture_build `reps` times without a GPU
+// and without any HIP call (staging into plain memory, nothing uploaded).  Returns the build's return code.
+static thread_local uint64_t g_last_build_hash = 0;
+uint64_t de265hip_debug_last_build_hash(void) { return g_last_build_hash; }
+int de265hip_debug_build_host_only(const de265hip_picture_desc* d, int reps)
+{
+  if (!d) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  de265hip_decoder* dec = new de265hip_decoder();
+  dec->dry = true;
+  for (auto& sl : dec->slots) { sl.valid = true; sl.w = d->params.width; sl.h = d->params.height; sl.bdY = d->params.bit_depth_luma; sl.bdC = d->params.bit_depth_chroma; }
+  int rc = 0;
+  for (int i = 0; i < reps && !rc; i++) {
+    de265hip_picture* pic = nullptr;
+    rc = de265hip_picture_build(dec, DE265HIP_MAX_DPB_SLOTS - 1, d, &pic);
+    g_last_build_hash = (uint64_t)dec->pooled_bytes;
+    delete pic;
+  }
+  for (auto& sl : dec->slots) sl.valid = false;
+  delete dec;
+  return rc;
 }
 
 int de265hip_picture_get_stats(const de265hip_picture* p, de265hip_picture_stats* s)
@@ -1250,10 +1336,12 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
       // when it holds the run's generation number (cleared once, at build).  Several tickets per draw (experiment)
       // make the count depend on the schedule: clear instead.
       uint32_t base = 0, gen = 1;
-      if (pic->ticket_batch == 1) { gen = ++pic->gen; base = (gen - 1u) * (uint32_t)(pic->n_batches + pic->n_workers); }
+      if (pic->run_direct) gen = ++pic->gen;                        // (no ticket counter at all)
+      else if (pic->ticket_batch == 1) { gen = ++pic->gen; base = (gen - 1u) * (uint32_t)(pic->n_batches + pic->n_workers); }
       else { (void)hipMemsetAsync(pic->d_sync, 0, pic->sync_bytes, st); pic->gen = 0; }
-      hipLaunchKernelGGL((k_run<PX, 64>), dim3(pic->n_workers), dim3(64 * dec->run_waves), 0, st, P, d0, d1, d2, pic->d_runs, pic->d_deps,
-                         pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->d_slots, pic->n_batches, pic->ticket_batch, base, gen, dec->dbg);
+      hipLaunchKernelGGL((k_run<PX, 64>), dim3(pic->run_direct ? pic->n_batches : pic->n_workers), dim3(64 * dec->run_waves), 0, st, P, d0, d1, d2,
+                         pic->d_runs, pic->d_deps, pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->d_slots, pic->n_batches,
+                         pic->run_direct ? 0 : pic->ticket_batch, base, gen, dec->dbg);
     }
   } else {
     if (nlev > 0 && pic->level_start[1] > pic->level_start[0]) {

@@ -1538,14 +1538,25 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   //  run's stores and their drain - the flag then waits for the atomic: all-intra 2.06 -> 2.47 ms, B 100 -> 111 us;
   //  drawing one ticket ahead by the last wavefront while the others start the current run - a held ticket delays its
   //  dependants: B 100 -> 106-114 us.)
-  if (next_ticket == batch_end) {
+  // batch == 0: DIRECT mode for wide pictures (a B picture's thousands of independent small runs): the grid has one
+  // workgroup per ticket, ticket = blockIdx.x, no counter, no loop - the hardware's workgroup dispatcher fills the GPU
+  // instead of a few hundred persistent workgroups that each work ~6 tickets off in sequence (each a chain of dependent
+  // memory round trips).  Still no deadlock: every XCD dispatches its share of the grid in increasing order, so the
+  // workgroup of the smallest unfinished ticket is resident or next in line on its XCD, and it waits on nothing larger;
+  // spins are bounded anyway (err word).  Deep pictures (an I picture's long chains) keep the persistent mode: there a
+  // grid of thousands of waiting workgroups would only occupy LDS.
+  if (batch == 0) {
+    if (next_ticket) break;                                            // second pass: the flag of this workgroup's run is out
+    next_ticket = 1;
+    batch_end = 0xFFFFFFFFu;
+  } else if (next_ticket == batch_end) {
     if (wave == 0) { const uint32_t t = run_draw_ticket(sync, (uint32_t)batch) - ticket_base; if (lane == 0) s_ticket = t; }
     __syncthreads();
     next_ticket = __builtin_amdgcn_readfirstlane(s_ticket);
     batch_end = next_ticket + batch;
   }
   st.mark(6);
-  const uint32_t bticket = next_ticket++;                              // uniform: scalar loads/branches below
+  const uint32_t bticket = batch == 0 ? blockIdx.x : next_ticket++;    // uniform: scalar loads/branches below
   if (bticket >= (uint32_t)n_batches) break;
   // a ticket is RUN_TICKET_SLOTS slots: that many micro runs (a wavefront each, no workgroup barrier; slots q, q+4, ..
   // one after the other by the same wavefront: fewer draws per run; the runs of a ticket follow each other in the run

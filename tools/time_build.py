@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Host time of de265hip_picture_build for the bench GOP's I picture and first B picture (4K Main10)."""
+"""Host time of de265hip_picture_build for the bench GOP's I picture and first B pictures (4K Main10).
+    python tools/time_build.py              on the GPU box: the real call (host stage + staging + async upload)
+    python tools/time_build.py --host-only  anywhere: de265hip_debug_build_host_only (no HIP call at all)"""
 import os
 import sys
 import time
@@ -11,12 +13,21 @@ import pysynth  # noqa: E402
 from libde265_amd import backend, farm  # noqa: E402
 
 W, H, BD = 3840, 2160, 10
-dec = backend.Decoder()
+host_only = "--host-only" in sys.argv
+dec = None if host_only else backend.Decoder()
 for k, (st, refs) in enumerate(farm.gop_plan(3)):
     over = dict(ref_slots=refs) if refs else {}
     sp = pysynth.SynthPicture(pysynth.default_config(W, H, BD, st, seed=farm.gop_seed(4, 0) + k, **over))
-    dec.dpb_alloc(k, W, H, BD)
     best = 1e9
+    if host_only:
+        for _ in range(3):
+            t0 = time.perf_counter()
+            rc = backend.lib().de265hip_debug_build_host_only(sp.desc, 1)
+            best = min(best, time.perf_counter() - t0)
+            assert rc == 0, rc
+        print("picture %d (%s): host stage %.1f ms, %d TUs, %d PUs" % (k, "I" if k == 0 else "B", 1e3 * best, sp.d.n_tus, sp.d.n_pus))
+        continue
+    dec.dpb_alloc(k, W, H, BD)
     for _ in range(3):
         t0 = time.perf_counter()
         pic = dec.build(k, sp.desc)
