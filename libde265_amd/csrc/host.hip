@@ -65,6 +65,10 @@ struct de265hip_decoder {
   bool resid_one_launch = true;       // DE265HIP_RESID_ONE_LAUNCH=0: 8x8 / 4x4 residual TUs in their own launch (k_resid_small)
   bool resid16_big = false;           // DE265HIP_RESID16_BIG: 16x16 residual TUs by 4-wavefront workgroups (k_resid_big) instead of one wavefront
   bool two_pass_deblock = false;      // DE265HIP_TWO_PASS_DEBLOCK: k_deblock<V> then k_deblock<H> instead of k_deblock_fused
+  bool lf_tile = false;               // DE265HIP_LF_TILE=1: the one-pass k_lf_tile instead of k_deblock_fused + k_sao.  Measured (4K Main10): 45-47 us
+                                      // against 22 + 27.5 us alone, but no gain in the bench (3 streams 6 320 vs 6 400 frames/s, 1 stream equal):
+                                      // both filters are bound by VALU issue (811 / 377 VALU instructions per wavefront, tools/exp/pmc_insts.sh),
+                                      // not by the passes over memory the fusion removes, and the tile kernel needs 137 VGPRs + 20 KB of LDS
   bool separate_bs = false;           // DE265HIP_SEPARATE_BS: bS by its own kernel instead of inside the deblocking kernels
   int dbg = 0;                        // DE265HIP_DEBUG: timing-only ablations of k_run (results invalid)
   bool intra_levels = false;          // DE265HIP_INTRA_MODE=levels: one launch per dependency level
@@ -440,6 +444,7 @@ int de265hip_decoder_new(de265hip_decoder** out, int device)
   if (const char* dbg = getenv("DE265HIP_DEBUG")) d->dbg = atoi(dbg);
   if (const char* e = getenv("DE265HIP_SEPARATE_BS")) d->separate_bs = atoi(e) != 0;
   if (const char* e = getenv("DE265HIP_TWO_PASS_DEBLOCK")) d->two_pass_deblock = atoi(e) != 0;
+  if (const char* e = getenv("DE265HIP_LF_TILE")) d->lf_tile = atoi(e) != 0;
   if (const char* e = getenv("DE265HIP_RESID16_BIG")) d->resid16_big = atoi(e) != 0;
   if (const char* e = getenv("DE265HIP_RESID_ONE_LAUNCH")) d->resid_one_launch = atoi(e) != 0;
   if (const char* rw = getenv("DE265HIP_RUN_WAVES")) d->run_waves = std::min(RUN_WAVES, std::max(1, atoi(rw)));
@@ -1400,7 +1405,25 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
       }
     }
   }
-  if (last_stage >= DE265HIP_STAGE_DEBLOCKED && !pic->params.disable_deblocking && pic->any_edges) {
+  // DE265HIP_LF_TILE=1: deblocking + SAO in one tiled pass (k_lf_tile) when the picture goes all the way to SAO (parity
+  // variant, off by default: see de265hip_decoder::lf_tile)
+  const bool want_sao = last_stage >= DE265HIP_STAGE_FINAL && !pic->params.disable_sao && pic->params.sample_adaptive_offset_enabled_flag;
+  const bool want_deblock = last_stage >= DE265HIP_STAGE_DEBLOCKED && !pic->params.disable_deblocking && pic->any_edges;
+  const bool lf_tile = want_sao && dec->lf_tile && !dec->separate_bs && !dec->two_pass_deblock;
+  if (lf_tile) {
+    Slot& sp = dec->spare;
+    LfMeta LM{ pic->d_flags, pic->d_qp, nullptr, pic->d_motion, pic->d_ctbs, pic->d_slices };
+    SaoMeta SM{ pic->d_flags, pic->d_sao };
+    {
+      KTimer t(dec, DE265HIP_K_SAO, 1);
+      hipLaunchKernelGGL(k_lf_tile<PX>, dim3((P.width + LF_TILE_W - 1) / LF_TILE_W, (P.height + LF_TILE_H - 1) / LF_TILE_H, 3), dim3(256), 0, st,
+                         P, d0, d1, d2, sp.pl[0], sp.pl[1], sp.pl[2], LM, SM, want_deblock ? 1 : 0);
+    }
+    for (int c = 0; c < 3; c++) std::swap(dst.pl[c], sp.pl[c]);      // output picture now lives in the slot
+    if (hipGetLastError() != hipSuccess) return DE265HIP_ERROR_DECODING;
+    return DE265HIP_OK;
+  }
+  if (want_deblock) {
     // bS (a12) is derived inside the deblocking kernels (one launch and one pass over the unit grid less: 9 us of a 4K
     // picture); DE265HIP_SEPARATE_BS=1 keeps the separate k_bs launch that writes the bS plane first
     if (dec->separate_bs) {

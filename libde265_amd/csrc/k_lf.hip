@@ -310,153 +310,188 @@ template __global__ void k_deblock<uint16_t, false>(PicDev, PlaneRef, PlaneRef, 
 #ifndef DEBLOCK_FUSED_WAVES
 #define DEBLOCK_FUSED_WAVES 4     // (114 VGPRs; 5/6/8 wavefronts per SIMD spill 84/164/264 B to scratch: 3-stream bench 5 820 -> 5 660/5 330/4 970 frames/s)
 #endif
+// One 8x8 deblocking block (bx, by) of component comp in three stages, so that a caller can put other work (and other
+// loads) between them: meta1 issues the first round of metadata loads, meta2 derives bS as far as possible and issues the
+// second round (slice offsets, motion records), filter reads the block's samples at `base` + y * stride + x - a plane in
+// global memory (k_deblock_fused) or a tile of it staged in LDS (k_lf_tile: PX is then the tile's uint16_t whatever the
+// picture's depth) - filters and stores what changed.
+template <typename PX>
+struct DeblockLane {
+  bool chroma, live, any, any_m;
+  int comp, W, H, x0, y0;
+  bool ex[4]; int idx[4], pidx[4];
+  int f[4], fp[4], qq[4], qp_[4], sl[4];
+  int bs[4]; bool need_m[4];
+  int boff[4], toff[4];
+  uint32_t rp[4][3], rq[4][3];
+
+  __device__ __forceinline__ void meta1(const PicDev& P, const LfMeta& M, int comp_, int bx, int by)
+  {
+    comp = comp_; chroma = comp != 0;
+    W = chroma ? P.width >> 1 : P.width; H = chroma ? P.height >> 1 : P.height;
+    x0 = 8 * bx - 4; y0 = 8 * by - 4;
+    live = x0 < W && y0 < H;
+    any = false; any_m = false;
+    if (!live) return;
+    const int ush = chroma ? 1 : 2;                      // a unit is 4 luma = 2 chroma samples
+    // ---- the four edge segments of the block: k = 0, 1: vertical edge, rows 4k..4k+3; k = 2, 3: horizontal edge, columns
+    // 4(k-2)..  Everything is fetched in two rounds for all four together (not one dependent chain per segment):
+    // round 1: flags and QP of both sides, the Q side's slice index; round 2: the slice's offsets, the motion records
+    // where bS depends on them, and the block's samples.
+    const bool hasV = bx > 0 && 8 * bx < W, hasH = by > 0 && 8 * by < H;
+    int ux[4], uy[4];
+  #pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const bool vert = k < 2; const int sgm = k & 1;
+      ux[k] = vert ? (8 * bx) >> ush : (x0 + 4 * sgm) >> ush;
+      uy[k] = vert ? (y0 + 4 * sgm) >> ush : (8 * by) >> ush;
+      ex[k] = vert ? (hasV && y0 + 4 * sgm >= 0 && y0 + 4 * sgm < H) : (hasH && x0 + 4 * sgm >= 0 && x0 + 4 * sgm < W);
+      // (clamped: the loads below are unconditional)
+      const int cx = min(max(ux[k], vert ? 1 : 0), P.w4 - 1), cy = min(max(uy[k], vert ? 0 : 1), P.h4 - 1);
+      idx[k] = cx + cy * P.w4; pidx[k] = vert ? idx[k] - 1 : idx[k] - P.w4;
+      ux[k] = cx; uy[k] = cy;
+    }
+  #pragma unroll
+    for (int k = 0; k < 4; k++) {
+      f[k] = M.flags[idx[k]]; fp[k] = M.flags[pidx[k]];
+      qq[k] = M.qp[idx[k]]; qp_[k] = M.qp[pidx[k]];
+      sl[k] = M.ctbs[((ux[k] << 2) >> P.log2_ctb) + ((uy[k] << 2) >> P.log2_ctb) * P.ctbs_w].slice_idx;
+    }
+  }
+
+  __device__ __forceinline__ void meta2(const LfMeta& M)
+  {
+    if (!live) return;
+  #pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const bool vert = k < 2;
+      const int e_any = vert ? (DE265HIP_BLK_EDGE_TU_V | DE265HIP_BLK_EDGE_PB_V) : (DE265HIP_BLK_EDGE_TU_H | DE265HIP_BLK_EDGE_PB_H);
+      const int e_tu = vert ? DE265HIP_BLK_EDGE_TU_V : DE265HIP_BLK_EDGE_TU_H;
+      bs[k] = 0; need_m[k] = false;
+      if (ex[k] && (f[k] & e_any)) {                     // derive_boundaryStrength (deblock.cc:241-375), as in edge_bs
+        if ((f[k] | fp[k]) & DE265HIP_BLK_INTRA) bs[k] = 2;
+        else if (chroma) bs[k] = 0;                      // chroma filters bS == 2 only (deblock.cc:763)
+        else if ((f[k] & e_tu) && ((f[k] | fp[k]) & DE265HIP_BLK_NONZERO)) bs[k] = 1;
+        else need_m[k] = true;
+      }
+      any = any || bs[k] != 0 || need_m[k]; any_m = any_m || need_m[k];
+    }
+    if (!any) { live = false; return; }
+    // round 2
+  #pragma unroll
+    for (int k = 0; k < 4; k++) { boff[k] = M.slices[sl[k]].slice_beta_offset; toff[k] = M.slices[sl[k]].slice_tc_offset; }
+    // (the motion records as raw dwords, fetched here and looked at behind the sample loads: one wait for all; a struct
+    //  copy unpacks the fields inside the branch and waits there)
+    static_assert(sizeof(de265hip_motion) == 12, "de265hip_motion layout");
+  #pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (need_m[k]) {
+        const uint32_t* a = reinterpret_cast<const uint32_t*>(M.motion + pidx[k]);
+        const uint32_t* b = reinterpret_cast<const uint32_t*>(M.motion + idx[k]);
+        rp[k][0] = a[0]; rp[k][1] = a[1]; rp[k][2] = a[2]; rq[k][0] = b[0]; rq[k][1] = b[1]; rq[k][2] = b[2];
+      }
+  }
+
+  __device__ __forceinline__ void filter(const PicDev& P, PX* base, int stride)
+  {
+    if (!live) return;
+    const bool okx[2] = { x0 >= 0, x0 + 4 < W };
+    int px[8][8];
+    {
+      const int xa = okx[0] ? x0 : x0 + 4, xb = okx[1] ? x0 + 4 : x0;
+  #pragma unroll
+      for (int r = 0; r < 8; r++) {
+        const PX* row = base + min(max(y0 + r, 0), H - 1) * stride;
+        load4<PX>(row + xa, &px[r][0]);
+        load4<PX>(row + xb, &px[r][4]);
+      }
+    }
+    if (any_m) {
+  #pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (need_m[k]) {
+          de265hip_motion mp, mq;
+          __builtin_memcpy(&mp, rp[k], 12); __builtin_memcpy(&mq, rq[k], 12);
+          bs[k] = bs_motion(mp, mq);
+        }
+    }
+    const int cQp = comp == 1 ? P.cb_qp_offset : P.cr_qp_offset;
+    const int bd = chroma ? P.bd_chroma : P.bd_luma, maxv = (1 << bd) - 1;
+    const int need = chroma ? 2 : 1;
+    unsigned mod_rows = 0, mod_cols = 0;                 // bit s: segment s of the vertical / horizontal edge changed samples
+  #pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (bs[k] < need) continue;
+      const bool vert = k < 2; const int sgm = k & 1;
+      // edge parameters (deblock.cc:497-528 luma, :809-832 chroma): offsets of the Q side's slice
+      const int qavg = (qq[k] + qp_[k] + 1) >> 1;
+      const int qp = chroma ? lf_qpc(qavg + cQp) : qavg;
+      const int beta = chroma ? 0 : c_beta[lf_clip3(0, 51, qp + boff[k])] * (1 << (bd - 8));
+      const int tc = c_tc[lf_clip3(0, 53, qp + 2 * (bs[k] - 1) + toff[k])] * (1 << (bd - 8));
+      const bool fP = !lf_exempt(P, fp[k]), fQ = !lf_exempt(P, f[k]);
+      if (!chroma) {
+        int p[4][4], q[4][4];
+  #pragma unroll
+        for (int j = 0; j < 4; j++)
+  #pragma unroll
+          for (int i = 0; i < 4; i++) {
+            p[j][i] = vert ? px[4 * sgm + j][3 - i] : px[3 - i][4 * sgm + j];
+            q[j][i] = vert ? px[4 * sgm + j][4 + i] : px[4 + i][4 * sgm + j];
+          }
+        if (luma_filter_segment(p, q, beta, tc, bd, fP, fQ)) {
+          if (vert) mod_rows |= 1u << sgm; else mod_cols |= 1u << sgm;
+  #pragma unroll
+          for (int j = 0; j < 4; j++)
+  #pragma unroll
+            for (int i = 0; i < 3; i++) {
+              if (vert) { px[4 * sgm + j][3 - i] = p[j][i]; px[4 * sgm + j][4 + i] = q[j][i]; }
+              else { px[3 - i][4 * sgm + j] = p[j][i]; px[4 + i][4 * sgm + j] = q[j][i]; }
+            }
+        }
+      } else {
+        if (vert) mod_rows |= 1u << sgm; else mod_cols |= 1u << sgm;
+  #pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int c = 4 * sgm + j;
+          int &p1 = vert ? px[c][2] : px[2][c], &p0 = vert ? px[c][3] : px[3][c];
+          int &q0 = vert ? px[c][4] : px[4][c], &q1 = vert ? px[c][5] : px[5][c];
+          const int delta = lf_clip3(-tc, tc, ((((q0 - p0) << 2) + p1 - q1 + 4) >> 3));
+          if (fP) p0 = lf_clip3(0, maxv, p0 + delta);
+          if (fQ) q0 = lf_clip3(0, maxv, q0 - delta);
+        }
+      }
+    }
+    // ---- store the halves of rows that a filter touched (vertical segment s: rows 4s..4s+3, both halves; horizontal
+    // segment s: rows 1..6 of half s)
+  #pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const int y = y0 + r;
+      if (y < 0 || y >= H) continue;
+      const bool rowV = (mod_rows >> (r >> 2)) & 1u;
+      const bool inH = r >= 1 && r <= 6;
+  #pragma unroll
+      for (int h = 0; h < 2; h++)
+        if (okx[h] && (rowV || (inH && ((mod_cols >> h) & 1u)))) store4<PX>(base + y * stride + x0 + 4 * h, &px[r][4 * h]);
+    }
+  }
+};
+
+template <typename PX>
+__device__ __forceinline__ void deblock_block(const PicDev& P, const LfMeta& M, int comp, PX* base, int stride, int bx, int by)
+{
+  DeblockLane<PX> L;
+  L.meta1(P, M, comp, bx, by);
+  L.meta2(M);
+  L.filter(P, base, stride);
+}
+
 template <typename PX>
 __global__ __launch_bounds__(256, DEBLOCK_FUSED_WAVES)
 void k_deblock_fused(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, LfMeta M)
 {
   const int comp = blockIdx.z;
-  const bool chroma = comp != 0;
-  const int bx = blockIdx.x * blockDim.x + threadIdx.x, by = blockIdx.y;
   const PlaneRef pl = comp == 0 ? pl0 : (comp == 1 ? pl1 : pl2);
-  const int W = chroma ? P.width >> 1 : P.width, H = chroma ? P.height >> 1 : P.height;
-  const int x0 = 8 * bx - 4, y0 = 8 * by - 4;
-  if (x0 >= W || y0 >= H) return;
-  const int stride = pl.stride;
-  PX* base = (PX*)pl.ptr;
-  const int ush = chroma ? 1 : 2;                      // a unit is 4 luma = 2 chroma samples
-  // ---- the four edge segments of the block: k = 0, 1: vertical edge, rows 4k..4k+3; k = 2, 3: horizontal edge, columns
-  // 4(k-2)..  Everything is fetched in two rounds for all four together (not one dependent chain per segment):
-  // round 1: flags and QP of both sides, the Q side's slice index; round 2: the slice's offsets, the motion records
-  // where bS depends on them, and the block's samples.
-  const bool hasV = bx > 0 && 8 * bx < W, hasH = by > 0 && 8 * by < H;
-  bool ex[4]; int idx[4], pidx[4], ux[4], uy[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const bool vert = k < 2; const int sgm = k & 1;
-    ux[k] = vert ? (8 * bx) >> ush : (x0 + 4 * sgm) >> ush;
-    uy[k] = vert ? (y0 + 4 * sgm) >> ush : (8 * by) >> ush;
-    ex[k] = vert ? (hasV && y0 + 4 * sgm >= 0 && y0 + 4 * sgm < H) : (hasH && x0 + 4 * sgm >= 0 && x0 + 4 * sgm < W);
-    // (clamped: the loads below are unconditional)
-    const int cx = min(max(ux[k], vert ? 1 : 0), P.w4 - 1), cy = min(max(uy[k], vert ? 0 : 1), P.h4 - 1);
-    idx[k] = cx + cy * P.w4; pidx[k] = vert ? idx[k] - 1 : idx[k] - P.w4;
-    ux[k] = cx; uy[k] = cy;
-  }
-  int f[4], fp[4], qq[4], qp_[4], sl[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    f[k] = M.flags[idx[k]]; fp[k] = M.flags[pidx[k]];
-    qq[k] = M.qp[idx[k]]; qp_[k] = M.qp[pidx[k]];
-    sl[k] = M.ctbs[((ux[k] << 2) >> P.log2_ctb) + ((uy[k] << 2) >> P.log2_ctb) * P.ctbs_w].slice_idx;
-  }
-  int bs[4]; bool need_m[4]; bool any = false, any_m = false;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const bool vert = k < 2;
-    const int e_any = vert ? (DE265HIP_BLK_EDGE_TU_V | DE265HIP_BLK_EDGE_PB_V) : (DE265HIP_BLK_EDGE_TU_H | DE265HIP_BLK_EDGE_PB_H);
-    const int e_tu = vert ? DE265HIP_BLK_EDGE_TU_V : DE265HIP_BLK_EDGE_TU_H;
-    bs[k] = 0; need_m[k] = false;
-    if (ex[k] && (f[k] & e_any)) {                     // derive_boundaryStrength (deblock.cc:241-375), as in edge_bs
-      if ((f[k] | fp[k]) & DE265HIP_BLK_INTRA) bs[k] = 2;
-      else if (chroma) bs[k] = 0;                      // chroma filters bS == 2 only (deblock.cc:763)
-      else if ((f[k] & e_tu) && ((f[k] | fp[k]) & DE265HIP_BLK_NONZERO)) bs[k] = 1;
-      else need_m[k] = true;
-    }
-    any = any || bs[k] != 0 || need_m[k]; any_m = any_m || need_m[k];
-  }
-  if (!any) return;
-  // round 2
-  int boff[4], toff[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++) { boff[k] = M.slices[sl[k]].slice_beta_offset; toff[k] = M.slices[sl[k]].slice_tc_offset; }
-  // (the motion records as raw dwords, fetched here and looked at behind the sample loads: one wait for all; a struct
-  //  copy unpacks the fields inside the branch and waits there)
-  static_assert(sizeof(de265hip_motion) == 12, "de265hip_motion layout");
-  uint32_t rp[4][3], rq[4][3];
-#pragma unroll
-  for (int k = 0; k < 4; k++)
-    if (need_m[k]) {
-      const uint32_t* a = reinterpret_cast<const uint32_t*>(M.motion + pidx[k]);
-      const uint32_t* b = reinterpret_cast<const uint32_t*>(M.motion + idx[k]);
-      rp[k][0] = a[0]; rp[k][1] = a[1]; rp[k][2] = a[2]; rq[k][0] = b[0]; rq[k][1] = b[1]; rq[k][2] = b[2];
-    }
-  const bool okx[2] = { x0 >= 0, x0 + 4 < W };
-  int px[8][8];
-  {
-    const int xa = okx[0] ? x0 : x0 + 4, xb = okx[1] ? x0 + 4 : x0;
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-      const PX* row = base + min(max(y0 + r, 0), H - 1) * stride;
-      load4<PX>(row + xa, &px[r][0]);
-      load4<PX>(row + xb, &px[r][4]);
-    }
-  }
-  if (any_m) {
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      if (need_m[k]) {
-        de265hip_motion mp, mq;
-        __builtin_memcpy(&mp, rp[k], 12); __builtin_memcpy(&mq, rq[k], 12);
-        bs[k] = bs_motion(mp, mq);
-      }
-  }
-  const int cQp = comp == 1 ? P.cb_qp_offset : P.cr_qp_offset;
-  const int bd = chroma ? P.bd_chroma : P.bd_luma, maxv = (1 << bd) - 1;
-  const int need = chroma ? 2 : 1;
-  unsigned mod_rows = 0, mod_cols = 0;                 // bit s: segment s of the vertical / horizontal edge changed samples
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    if (bs[k] < need) continue;
-    const bool vert = k < 2; const int sgm = k & 1;
-    // edge parameters (deblock.cc:497-528 luma, :809-832 chroma): offsets of the Q side's slice
-    const int qavg = (qq[k] + qp_[k] + 1) >> 1;
-    const int qp = chroma ? lf_qpc(qavg + cQp) : qavg;
-    const int beta = chroma ? 0 : c_beta[lf_clip3(0, 51, qp + boff[k])] * (1 << (bd - 8));
-    const int tc = c_tc[lf_clip3(0, 53, qp + 2 * (bs[k] - 1) + toff[k])] * (1 << (bd - 8));
-    const bool fP = !lf_exempt(P, fp[k]), fQ = !lf_exempt(P, f[k]);
-    if (!chroma) {
-      int p[4][4], q[4][4];
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          p[j][i] = vert ? px[4 * sgm + j][3 - i] : px[3 - i][4 * sgm + j];
-          q[j][i] = vert ? px[4 * sgm + j][4 + i] : px[4 + i][4 * sgm + j];
-        }
-      if (luma_filter_segment(p, q, beta, tc, bd, fP, fQ)) {
-        if (vert) mod_rows |= 1u << sgm; else mod_cols |= 1u << sgm;
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-          for (int i = 0; i < 3; i++) {
-            if (vert) { px[4 * sgm + j][3 - i] = p[j][i]; px[4 * sgm + j][4 + i] = q[j][i]; }
-            else { px[3 - i][4 * sgm + j] = p[j][i]; px[4 + i][4 * sgm + j] = q[j][i]; }
-          }
-      }
-    } else {
-      if (vert) mod_rows |= 1u << sgm; else mod_cols |= 1u << sgm;
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int c = 4 * sgm + j;
-        int &p1 = vert ? px[c][2] : px[2][c], &p0 = vert ? px[c][3] : px[3][c];
-        int &q0 = vert ? px[c][4] : px[4][c], &q1 = vert ? px[c][5] : px[5][c];
-        const int delta = lf_clip3(-tc, tc, ((((q0 - p0) << 2) + p1 - q1 + 4) >> 3));
-        if (fP) p0 = lf_clip3(0, maxv, p0 + delta);
-        if (fQ) q0 = lf_clip3(0, maxv, q0 - delta);
-      }
-    }
-  }
-  // ---- store the halves of rows that a filter touched (vertical segment s: rows 4s..4s+3, both halves; horizontal
-  // segment s: rows 1..6 of half s)
-#pragma unroll
-  for (int r = 0; r < 8; r++) {
-    const int y = y0 + r;
-    if (y < 0 || y >= H) continue;
-    const bool rowV = (mod_rows >> (r >> 2)) & 1u;
-    const bool inH = r >= 1 && r <= 6;
-#pragma unroll
-    for (int h = 0; h < 2; h++)
-      if (okx[h] && (rowV || (inH && ((mod_cols >> h) & 1u)))) store4<PX>(base + y * stride + x0 + 4 * h, &px[r][4 * h]);
-  }
+  deblock_block<PX>(P, M, comp, (PX*)pl.ptr, pl.stride, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y);
 }
 template __global__ void k_deblock_fused<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, LfMeta);
 template __global__ void k_deblock_fused<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, LfMeta);
@@ -525,10 +560,13 @@ template <> __device__ __forceinline__ void store8_pk<uint8_t>(uint8_t* p, uint4
 struct SaoRec { uint32_t w[6]; };
 struct SaoRows { uint4 r[SAO_ROWS + 2]; };
 // The part of a strip behind its loads: w = the CTB's record, R = rows y0-1 .. y0+SAO_ROWS of the strip, packed.
-template <typename PX>
+// NB_DPP: the left / right neighbour samples of every row come from the adjacent lanes (k_sao: lanes 0 and 63 of a wavefront are
+// halo lanes); otherwise from nbL / nbR (k_lf_tile reads them from its LDS tile).
+struct SaoNb { uint32_t l[SAO_ROWS + 2], r[SAO_ROWS + 2]; };
+template <typename PX, bool NB_DPP>
 __device__ __forceinline__ void sao_strip(const PicDev& P, const SaoMeta& M, PX* dst, int dstride, int comp, int cs,
                                           int width, int height, int lane, int x0, int y0, bool inpic, int ctbshift,
-                                          const SaoRec rec, const SaoRows rows)
+                                          const SaoRec rec, const SaoRows rows, const SaoNb nb)
 {
   const uint32_t (&w)[6] = rec.w;
   const uint4 (&R)[SAO_ROWS + 2] = rows.r;
@@ -558,15 +596,18 @@ __device__ __forceinline__ void sao_strip(const PicDev& P, const SaoMeta& M, PX*
   uint32_t S[SAO_ROWS + 2][5];
 #pragma unroll
   for (int j = 0; j < SAO_ROWS + 2; j++) {
-    const uint32_t pw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)R[j].w, 0x138, 0xf, 0xf, false);   // wave_shr:1 -> lane-1's (v6, v7)
-    const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)R[j].x, 0x130, 0xf, 0xf, false);   // wave_shl:1 -> lane+1's (v0, v1)
+    uint32_t pw, nx;
+    if constexpr (NB_DPP) {
+      pw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)R[j].w, 0x138, 0xf, 0xf, false);   // wave_shr:1 -> lane-1's (v6, v7)
+      nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)R[j].x, 0x130, 0xf, 0xf, false);   // wave_shl:1 -> lane+1's (v0, v1)
+    } else { pw = nb.l[j] << 16; nx = nb.r[j]; }
     S[j][0] = __builtin_amdgcn_alignbit(R[j].x, pw, 16);
     S[j][1] = __builtin_amdgcn_alignbit(R[j].y, R[j].x, 16);
     S[j][2] = __builtin_amdgcn_alignbit(R[j].z, R[j].y, 16);
     S[j][3] = __builtin_amdgcn_alignbit(R[j].w, R[j].z, 16);
     S[j][4] = __builtin_amdgcn_alignbit(nx, R[j].w, 16);
   }
-  if (!inpic || lane == 0 || lane == 63) return;
+  if (!inpic || (NB_DPP && (lane == 0 || lane == 63))) return;
   if (P.dbg & 32) {                                           // ablation: pure copy
 #pragma unroll
     for (int r = 0; r < SAO_ROWS; r++)
@@ -747,8 +788,102 @@ void k_sao(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, PlaneRe
   }
 #pragma unroll
   for (int g = 0; g < SAO_GROUPS; g++)
-    sao_strip<PX>(P, M, dst, dstride, comp, cs, width, height, lane, x0[g], y0, inpic[g], ctbshift, w[g], R[g]);
+    sao_strip<PX, true>(P, M, dst, dstride, comp, cs, width, height, lane, x0[g], y0, inpic[g], ctbshift, w[g], R[g], SaoNb());
 }
+
+// ---------------------------------------------------------------- deblocking + SAO in one pass over the picture
+// One workgroup per LF_TW x LF_TH tile of a component: (0) the tile and a ring around it - the 8x8 deblocking blocks that
+// overlap it by 4 samples plus what SAO's 3x3 neighbourhood needs - are staged in LDS as 16-bit samples with coalesced
+// 16-byte loads; (1) one lane per 8x8 block deblocks it IN LDS (deblock_block: the blocks partition the staged region, so
+// nothing is read after a neighbour wrote it); (2) SAO reads the deblocked tile from LDS and writes the OUTPUT picture.
+// The input picture is never written, so the ring a neighbouring workgroup recomputes comes out identical.  Against
+// k_deblock_fused + k_sao: one launch instead of two, the picture is read once (x1.2 for the ring, mostly L2 hits) and
+// written once instead of read twice and written 1.5 times, and SAO's neighbours come from LDS instead of wave shifts.
+#define LF_PITCH (LF_TW + 16)                 // tile columns x0-8 .. x0+LF_TW+7: every 8-sample group 16-byte aligned
+#define LF_ROWS (LF_TH + 8)                   // tile rows y0-4 .. y0+LF_TH+3
+template <typename PX>
+__global__ __launch_bounds__(256)
+void k_lf_tile(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, PlaneRef d1, PlaneRef d2, LfMeta LM, SaoMeta SM,
+               int do_deblock)
+{
+  __shared__ __attribute__((aligned(16))) uint16_t tile[LF_ROWS * LF_PITCH];
+  const int comp = blockIdx.z, cs = comp ? 1 : 0;
+  const int W = P.width >> cs, H = P.height >> cs;
+  const int x0 = blockIdx.x * LF_TW, y0 = blockIdx.y * LF_TH;
+  if (x0 >= W || y0 >= H) return;                             // uniform per workgroup
+  const PlaneRef sp = comp == 0 ? s0 : (comp == 1 ? s1 : s2), dp = comp == 0 ? d0 : (comp == 1 ? d1 : d2);
+  const PX* src = (const PX*)sp.ptr;
+  const int tid = threadIdx.x;
+  // tile_at(x, y) for picture coordinates inside the staged region
+  uint16_t* const origin = tile - ((y0 - 4) * LF_PITCH + (x0 - 8));
+  // The workgroup's memory round trips are put side by side instead of one behind the other (all ~1 500 workgroups of a
+  // 4K picture are resident at once, so the kernel takes as long as ONE workgroup's chain): the tile's loads, the
+  // deblocking lanes' first metadata round and the SAO records are issued together; the second metadata round (slice
+  // offsets, motion) goes out while the tile is written to LDS.  Loads are unconditional (clamped addresses) - a load
+  // under a per-lane condition is compiled into its own branch + wait.
+  constexpr int NCH = LF_PITCH / 8, NLD = (LF_ROWS * NCH + 255) / 256;
+  const int Wal = (W + 7) & ~7;                                // (rows are padded to 64 samples: a partial last group is readable)
+  uint4 tv[NLD];
+#pragma unroll
+  for (int u = 0; u < NLD; u++) {
+    const int i = min(tid + 256 * u, LF_ROWS * NCH - 1);
+    const int r = i / NCH, c = i - r * NCH;
+    const int gy = min(max(y0 - 4 + r, 0), H - 1), gx = min(max(x0 - 8 + 8 * c, 0), Wal - 8);
+    tv[u] = load8_pk<PX>(src + gx + gy * sp.stride);
+  }
+  constexpr int NBX = LF_TW / 8 + 1, NBY = LF_TH / 8 + 1;
+  static_assert(NBX * NBY <= 256, "one deblocking block per lane");
+  DeblockLane<uint16_t> DL;
+  DL.live = false;
+  if (do_deblock && tid < NBX * NBY) DL.meta1(P, LM, comp, (x0 >> 3) + tid % NBX, (y0 >> 3) + tid / NBX);
+  const int ctbshift = P.log2_ctb - cs;
+  constexpr int SX = LF_TW / 8, SY = LF_TH / SAO_ROWS, NST = (SX * SY + 255) / 256;
+  SaoRec rec[NST];
+#pragma unroll
+  for (int u = 0; u < NST; u++) {
+    const int sidx = min(tid + 256 * u, SX * SY - 1);
+    const int xs = min(x0 + 8 * (sidx % SX), W - 1), ys = min(y0 + SAO_ROWS * (sidx / SX), H - 1);
+    const uint2* q = reinterpret_cast<const uint2*>(&SM.sao[(xs >> ctbshift) + (ys >> ctbshift) * P.ctbs_w]);
+    const uint2 q0 = q[0], q1 = q[1], q2 = q[2];
+    rec[u].w[0] = q0.x; rec[u].w[1] = q0.y; rec[u].w[2] = q1.x; rec[u].w[3] = q1.y; rec[u].w[4] = q2.x; rec[u].w[5] = q2.y;
+  }
+  // (0) the tile into LDS (a clamped load's duplicate lands in a cell that is never read unclamped)
+#pragma unroll
+  for (int u = 0; u < NLD; u++) {
+    const int i = tid + 256 * u;
+    if (i < LF_ROWS * NCH) {
+      const int r = i / NCH, c = i - r * NCH;
+      *reinterpret_cast<uint4*>(&tile[r * LF_PITCH + 8 * c]) = tv[u];
+    }
+  }
+  DL.meta2(LM);
+  __syncthreads();
+  // ---- (1) deblock the blocks that overlap the tile or its ring, in LDS
+  if (do_deblock) {
+    DL.filter(P, origin, LF_PITCH);
+    __syncthreads();
+  }
+  // ---- (2) SAO from the tile to the output picture, one 8 x SAO_ROWS strip per lane and step
+  PX* dst = (PX*)dp.ptr;
+#pragma unroll
+  for (int u = 0; u < NST; u++) {
+    const int sidx = tid + 256 * u;
+    const int sy = sidx / SX, sx = sidx - sy * SX;
+    const int xs = x0 + 8 * sx, ys = y0 + SAO_ROWS * sy;
+    if (sidx >= SX * SY || xs >= W || ys >= H) continue;
+    SaoRows R; SaoNb nb;
+#pragma unroll
+    for (int j = 0; j < SAO_ROWS + 2; j++) {
+      const int yy = min(max(ys - 1 + j, 0), H - 1);            // (clamped like k_sao: such neighbours are masked out)
+      const uint16_t* row = origin + yy * LF_PITCH;
+      R.r[j] = *reinterpret_cast<const uint4*>(row + xs);
+      nb.l[j] = row[max(xs - 1, 0)]; nb.r[j] = row[min(xs + 8, Wal - 1)];
+    }
+    sao_strip<PX, false>(P, SM, dst, dp.stride, comp, cs, W, H, 1, xs, ys, true, ctbshift, rec[u], R, nb);
+  }
+}
+template __global__ void k_lf_tile<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, LfMeta, SaoMeta, int);
+template __global__ void k_lf_tile<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, LfMeta, SaoMeta, int);
 
 template __global__ void k_sao<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, SaoMeta);
 template __global__ void k_sao<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, SaoMeta);

@@ -58,6 +58,16 @@ template <typename PX>
 __global__ void k_deblock_fused(PicDev, PlaneRef, PlaneRef, PlaneRef, LfMeta);
 template <typename PX>
 __global__ void k_sao(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, SaoMeta);
+#ifndef LF_TW
+#define LF_TW 128                        // tile of k_lf_tile (deblocking + SAO in one pass), luma / chroma samples alike
+#endif
+#ifndef LF_TH
+#define LF_TH 64
+#endif
+#define LF_TILE_W LF_TW
+#define LF_TILE_H LF_TH
+template <typename PX>
+__global__ void k_lf_tile(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, LfMeta, SaoMeta, int);
 
 // function-level kernels (k_fn.hip)
 template <typename PX>
