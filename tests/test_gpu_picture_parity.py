@@ -452,3 +452,33 @@ def test_reference_picture_exchange_on_dpb_planes(dec):
         assert all(np.array_equal(g, e) for g, e in zip(got, exp))
     finally:
         d2.close()
+
+
+def test_concurrent_builds_on_one_decoder(dec):
+    """de265hip_picture_build / _free from several host threads on ONE decoder (include/de265_hip.h THREADS; what
+    bench.py's host_inclusive leg does): the pools and the live list are shared, every picture still comes out right."""
+    from concurrent.futures import ThreadPoolExecutor
+    w, h, bd = 352, 288, 8
+    refs = {0: pysynth.fill_planes(w, h, bd, 21), 1: pysynth.fill_planes(w, h, bd, 22)}
+    for s, pl in refs.items():
+        dec.dpb_alloc(s, w, h, bd); dec.upload(s, pl)
+    dec.dpb_alloc(2, w, h, bd)
+    sps, exps = [], []
+    for k in range(8):
+        sp = pysynth.SynthPicture(pysynth.default_config(w, h, bd, (0, 1, 2, 0)[k % 4], seed=900 + k, tskip_pct=10, n_slices=1 + k % 3))
+        exp = pyoracle.alloc_planes(w, h, bd)
+        pyoracle.reconstruct(sp.desc, sp.order, refs, exp)
+        sps.append(sp); exps.append(exp)
+    with ThreadPoolExecutor(8) as pool:
+        for rep in range(4):
+            futs = [pool.submit(dec.build, 2, sps[k].desc) for k in range(8)]       # eight builds in flight at once
+            for k, f in enumerate(futs):
+                pic = f.result()
+                try:
+                    dec.upload(2, pyoracle.alloc_planes(w, h, bd))
+                    dec.run(pic, 2)
+                    dec.sync()
+                    got = dec.download(2, w, h, bd)
+                finally:
+                    pool.submit(pic.free).result()                                   # freed on a pool thread as well
+                assert all(np.array_equal(g, e) for g, e in zip(got, exps[k])), (rep, k)
