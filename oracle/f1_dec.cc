@@ -2,17 +2,33 @@
  * f1_dec.cc -- minimal driver of the PATCHED reference (oracle/Makefile `make f1`): pushes a bitstream through
  * libde265's public API (de265.h: de265_new_decoder, de265_push_data, de265_decode, de265_get_next_picture; scalar
  * DSP path, no worker threads = decode_slice_unit_sequential + run_postprocessing_filters_sequential) so that the
- * hooks of oracle/f1_recorder.cc see every picture.  usage: F1_OUT=dir f1_dec stream.bin
+ * hooks of oracle/f1_recorder.cc see every picture.
+ *   F1_OUT=dir f1_dec stream.bin                          dump mode: per-picture description + the reference's pictures
+ *   F1_MODE=hip F1_HIP_LIB=.../libde265_hip.so f1_dec stream.bin out.yuv
+ *                                                         offload mode: libde265 parses, the MI355X reconstructs; out.yuv receives
+ *                                                         what de265_get_next_picture hands out (planes, little-endian samples)
  */
 #include "libde265/de265.h"
 #include <stdio.h>
 #include <stdlib.h>
+
+static void write_picture(FILE* out, const de265_image* im)
+{
+  if (!out) return;
+  for (int c = 0; c < 3; c++) {
+    int stride = 0;
+    const uint8_t* p = de265_get_image_plane(im, c, &stride);
+    const int w = de265_get_image_width(im, c), h = de265_get_image_height(im, c), bpp = (de265_get_bits_per_pixel(im, c) + 7) / 8;
+    for (int y = 0; y < h; y++) fwrite(p + (size_t)y * stride, 1, (size_t)w * bpp, out);
+  }
+}
 
 int main(int argc, char** argv)
 {
   if (argc < 2) { fprintf(stderr, "usage: F1_OUT=dir %s stream.bin\n", argv[0]); return 2; }
   FILE* f = fopen(argv[1], "rb");
   if (!f) { perror(argv[1]); return 2; }
+  FILE* out = argc > 2 ? fopen(argv[2], "wb") : NULL;
   de265_decoder_context* ctx = de265_new_decoder();
   de265_set_parameter_int(ctx, DE265_DECODER_PARAM_ACCELERATION_CODE, de265_acceleration_SCALAR);
   de265_set_parameter_bool(ctx, DE265_DECODER_PARAM_BOOL_SEI_CHECK_HASH, 1);
@@ -23,7 +39,7 @@ int main(int argc, char** argv)
     if (de265_push_data(ctx, buf, (int)n, 0, NULL) != DE265_OK) return 3;
     for (;;) {
       de265_error e = de265_decode(ctx, &more);
-      while (de265_get_next_picture(ctx)) n_out++;
+      while (const de265_image* im = de265_get_next_picture(ctx)) { n_out++; write_picture(out, im); }
       if (e == DE265_ERROR_WAITING_FOR_INPUT_DATA || !more) break;
       if (e != DE265_OK) { fprintf(stderr, "decode error: %s\n", de265_get_error_text(e)); return 4; }
     }
@@ -32,7 +48,7 @@ int main(int argc, char** argv)
   more = 1;
   while (more) {
     de265_error e = de265_decode(ctx, &more);
-    while (de265_get_next_picture(ctx)) n_out++;
+    while (const de265_image* im = de265_get_next_picture(ctx)) { n_out++; write_picture(out, im); }
     if (e != DE265_OK && e != DE265_ERROR_WAITING_FOR_INPUT_DATA) break;
   }
   for (;;) {
@@ -42,6 +58,7 @@ int main(int argc, char** argv)
   }
   de265_free_decoder(ctx);
   fclose(f);
+  if (out) fclose(out);
   printf("%d pictures\n", n_out);
   return 0;
 }

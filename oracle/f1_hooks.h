@@ -6,8 +6,10 @@
  *   libde265/slice.cc:4185    read_pcm_samples                   -> f1_record_pcm
  *   libde265/decctx.cc:757    decode_some, after mark_all_CTB_progress(PREFILTER)  -> f1_submit  (what the product's
  *                             de265hip_recorder_submit would receive), and behind the post-filters -> f1_picture_done
- * TEST INFRASTRUCTURE (build container only): the hooks dump what the product's frame-level interface consumes
- * (de265hip_picture_desc) for real bitstreams, next to the reference's own decoded output.
+ * TEST INFRASTRUCTURE.  Two modes (oracle/f1_recorder.cc): dump (default) - the hooks write what the product's frame-level
+ * interface consumes (de265hip_picture_desc) for real bitstreams, next to the reference's own decoded output; F1_MODE=hip -
+ * the hooks feed libde265_hip.so (de265hip_record_* / recorder_submit / picture_run) INSTEAD of the CPU reconstruction:
+ * libde265 parses, the MI355X reconstructs, de265_get_next_picture hands out the GPU's pictures.
  */
 #ifndef F1_HOOKS_H
 #define F1_HOOKS_H
@@ -16,9 +18,13 @@ class slice_segment_header;
 struct de265_image;
 class PBMotion;
 
-void f1_record_tu(thread_context* tctx, int x0, int y0, int nT, int cIdx, int cuPredMode, bool cbf);
-void f1_record_pu(const slice_segment_header* shdr, de265_image* img, int xP, int yP, int nPbW, int nPbH, const PBMotion* vi);
+/* The three recording hooks return true when the picture is being OFFLOADED (F1_MODE=hip: the caller then skips its own
+ * reconstruction of that block), false when they only record next to the reference's own reconstruction (dump mode). */
+bool f1_record_tu(thread_context* tctx, int x0, int y0, int nT, int cIdx, int cuPredMode, bool cbf);
+bool f1_record_pu(const slice_segment_header* shdr, de265_image* img, int xP, int yP, int nPbW, int nPbH, const PBMotion* vi);
 void f1_record_pcm(thread_context* tctx, int x0, int y0, int log2CbSize);
-void f1_submit(de265_image* img);
+/* true: the picture was reconstructed, deblocked and SAO-filtered by the HIP back end and copied into img's planes (the
+ * caller skips run_postprocessing_filters_*); false: dump mode, the caller carries on */
+bool f1_submit(de265_image* img);
 void f1_picture_done(de265_image* img);
 #endif

@@ -105,3 +105,34 @@ def test_gpu_replays_recorded_stream_pictures_through_the_recorder_api(fx):
                 rec.free()
     finally:
         dec.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(F1_DEC), reason="patched reference decoder (make -C oracle f1) did not travel")
+@pytest.mark.parametrize("fx", FIXTURES, ids=IDS)
+def test_libde265_decodes_the_bitstream_with_the_hip_back_end(fx):
+    """SURVEY 8(f1) end to end: the PATCHED libde265 (oracle/f1_recorder.patch: 9 lines) parses the real bitstream on the
+    host - NAL, SPS/PPS, slice headers, CABAC - and every decode_TU / generate_inter_prediction_samples / post-filter call
+    is replaced by the MI355X back end through de265hip_record_* -> recorder_submit -> picture_run -> dpb_download
+    (F1_MODE=hip, oracle/f1_recorder.cc).  What de265_get_next_picture then hands out must be byte-identical to what
+    the unpatched CPU path decodes (the fixtures' MD5s): `dec265 --accel hip` in everything but the option parser."""
+    from libde265_amd import backend
+    assert backend.device_count() > 0
+    bits = fx[:-4] + ".bin"
+    fixture = f1_stream.load_fixture(fx)
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "out.yuv")
+        env = dict(os.environ, F1_MODE="hip", F1_HIP_LIB=backend.SO_PATH)
+        r = subprocess.run([F1_DEC, bits, out], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.stdout.split()[0] == str(len(fixture)), r.stdout
+        data = open(out, "rb").read()
+    off = 0
+    for i, (rp, dg) in enumerate(fixture):                 # all-intra streams: output order == decode order
+        P = rp.params
+        bpp = 2 if P.bit_depth_luma > 8 else 1
+        n = (P.width * P.height + 2 * (P.width // 2) * (P.height // 2)) * bpp
+        m = hashlib.md5(data[off:off + n]).hexdigest()
+        off += n
+        assert m == dg["final"], "%s picture %d: the HIP-backed decoder's output differs from the CPU decoder's" % (os.path.basename(fx), i)
+    assert off == len(data)
