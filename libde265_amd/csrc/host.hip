@@ -949,7 +949,9 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     // bench with 3 streams 5304 vs 5173 frames/s, one stream alone 2317 vs 2353
     int cap = wenv ? atoi(wenv) : 512;
     pic->n_batches = (int)(slots.size() / RUN_TICKET_SLOTS);
-    pic->n_workers = std::min(pic->n_batches, std::max(64, std::min(cap, widest + widest / 4)));
+    const char* menv = getenv("DE265HIP_RUN_WORKER_PCT");            // workers as a percentage of the widest level (experiments)
+    const int pct = menv ? atoi(menv) : 125;
+    pic->n_workers = std::min(pic->n_batches, std::max(64, std::min(cap, (int)((int64_t)widest * pct / 100))));
     // direct mode (see k_run): when the picture is wide rather than deep - most of its runs sit in its widest level
     // (a B picture: isolated intra CUs, 8 levels; an I picture: 126+ levels of ~100 runs)
     const char* denv = getenv("DE265HIP_RUN_DIRECT");

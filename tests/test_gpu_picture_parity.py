@@ -482,3 +482,36 @@ def test_concurrent_builds_on_one_decoder(dec):
                 finally:
                     pool.submit(pic.free).result()                                   # freed on a pool thread as well
                 assert all(np.array_equal(g, e) for g, e in zip(got, exps[k])), (rep, k)
+
+
+def test_extreme_picture_sizes(dec):
+    """Smallest (one 8x8 CU) and a very large picture (8K UHD, 7680x4320 Main10, I and B): coordinates, dependency levels and
+    per-picture tables at their extremes, bit-exact against the live compiled reference where it is present, else the restatement."""
+    import pyref
+    for (w, h, bd, st, seed, over) in [(8, 8, 8, 2, 1, dict(log2_ctb_size=4, log2_max_tb_size=3)),
+                                       (8, 8, 10, 0, 2, dict(log2_ctb_size=4, log2_max_tb_size=3)),
+                                       (16, 8, 8, 1, 3, dict(log2_ctb_size=4, log2_max_tb_size=4)),
+                                       (7680, 4320, 10, 0, 0xDE265008, dict()),
+                                       (7680, 4320, 10, 2, 0xDE265009, dict())]:
+        sp = pysynth.SynthPicture(pysynth.default_config(w, h, bd, st, seed=seed, **over))
+        refs = {0: pysynth.fill_planes(w, h, bd, 31), 1: pysynth.fill_planes(w, h, bd, 32)}
+        init = pysynth.fill_planes(w, h, bd, 33)
+        exp = [p.copy() for p in init]
+        if pyref.available():
+            pyref.reconstruct(sp.desc, sp.order, refs, exp, sp.structure())
+        else:
+            pyoracle.reconstruct(sp.desc, sp.order, refs, exp)
+        for s, pl in refs.items():
+            dec.dpb_alloc(s, w, h, bd); dec.upload(s, pl)
+        dec.dpb_alloc(2, w, h, bd); dec.upload(2, init)
+        pic = dec.build(2, sp.desc)
+        try:
+            dec.run(pic, 2); dec.sync()
+            got = dec.download(2, w, h, bd)
+        finally:
+            pic.free()
+        for c in range(3):
+            bad = np.argwhere(got[c] != exp[c])
+            assert bad.size == 0, "%dx%d bd=%d st=%d comp %d: %d samples differ, first %s" % (w, h, bd, st, c, len(bad), tuple(bad[0]))
+        for s in (0, 1, 2):
+            dec.dpb_alloc(s, 64, 64, 8)                # (give the 8K slots back)
