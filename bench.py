@@ -374,6 +374,12 @@ def main():
                                          / 1e9) / (v[0] / 1e3), 1) if k in ALG_KEY and v[0] > 0 else None}
                    for k, v in ktimes_all.items()}
 
+        # all kernels together: algorithmic bytes of a step (every stage of every picture) over the step's wall time
+        alg_step = sum(getattr(s_, a) for s_ in stats for a in ("alg_bytes_mc", "alg_bytes_resid", "alg_bytes_intra", "alg_bytes_deblock", "alg_bytes_sao"))
+        agg_gbs = (alg_step / 1e9) / (elapsed / args.steps)
+        aggregate = {"alg_bytes_per_step": int(alg_step), "achieved": round(agg_gbs, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                     "frac": round(agg_gbs / HBM_PEAK_GBS, 4),
+                     "note": "sum of every stage's algorithmic bytes of one step / wall time of the step (all streams, all kernels)"}
         st0 = [p.stats() for p in pics[0]]
         kernels_iso = {k: {"us_per_picture": round(1e3 * v[0] / max(v[1], 1), 1) if k != "resid" else
                            round(1e3 * v[0] / (2 * GOP), 1),
@@ -399,7 +405,7 @@ def main():
                        "host_enqueue_ms_per_step": round(1e3 * t_host / args.steps, 3),
                        "events_in_timed_region": "every kernel" if args.events == "all" else "dominant kernel (%s) only" % dom,
                        "parallelism": "%d gop stream(s) x %d gpu(s)" % (S, world)},
-            "roofline": roofline, "cpu_baseline": cpu, "host_inclusive": host_incl, "parity_vs_reference": parity, "kernels": kernels,
+            "roofline": roofline, "roofline_aggregate": aggregate, "cpu_baseline": cpu, "host_inclusive": host_incl, "parity_vs_reference": parity, "kernels": kernels,
             "kernels_isolated": kernels_iso,
         }
         print(json.dumps(line))
