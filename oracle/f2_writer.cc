@@ -1,0 +1,882 @@
+/*
+ * f2_writer.cc -- SURVEY.md 8(f2): a synthetic, conformance-style HEVC bitstream WRITER (build container only).
+ *
+ * TEST INFRASTRUCTURE, never part of the product.  The reference ships no conformance streams and its encoder CLI emits
+ * all-intra pictures only (its P path asserts/crashes, encoder-syntax.cc:1397-1437 is a stub), so no real bitstream
+ * could reach the inter, weighted-prediction, PCM, cu_qp_delta, AMP, multi-slice, deblocking-override and SAO-merge
+ * paths of the hot path end to end.  This tool writes such streams: a seeded random walk over the HEVC syntax
+ * (ITU-T H.265 7.3: VPS/SPS/PPS, slice_segment_header with explicit short-term RPS and pred_weight_table, SAO, coding
+ * quadtree, CU, PU, transform tree, transform unit, residual_coding, PCM), every element binarised and
+ * context-selected as the reference DECODER parses it (slice.cc read_* / decode_* cited at each function).  The
+ * pictures are noise-like but every stream is legal syntax, and WHAT they decode to is defined by the reference
+ * decoder alone: oracle/_ref/f1_dec (the recording libde265) turns the stream into the authoritative
+ * de265hip_picture_desc + picture MD5 fixtures (tools/make_stream_golden.py), which the oracle, the HIP path and the
+ * HIP-backed libde265 must then reproduce bit-exactly (tests/test_stream_golden.py).
+ *
+ * Linked against the compiled reference for exactly three things it would make no sense to restate: the CABAC
+ * arithmetic ENCODER + context initialisation tables (cabac.cc, contextmodel.cc), the coefficient scan tables (scan.cc)
+ * and the parameter-set writers (vps.cc/sps.cc/pps.cc write()).  The slice-level syntax below is this file's own: the
+ * reference's encoder cannot write it.
+ *
+ *   f2_writer out=stream.bin w=416 h=240 pics=6 gop=B seed=1 [key=value ...]      (keys: see struct Cfg)
+ */
+#include "libde265/cabac.h"
+#include "libde265/contextmodel.h"
+#include "libde265/decctx.h"
+#include "libde265/nal.h"
+#include "libde265/pps.h"
+#include "libde265/scan.h"
+#include "libde265/slice.h"
+#include "libde265/sps.h"
+#include "libde265/vps.h"
+
+#include <algorithm>
+#include <memory>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+namespace {
+
+/* ---------------------------------------------------------------- configuration ---------------------------------------------------------------- */
+struct Cfg {
+  std::string out = "f2.bin", gop = "I";
+  int w = 416, h = 240, bits = 8, pics = 3, slices = 1, seed = 1;
+  int log2ctb = 5, log2mincb = 3, log2mintb = 2, log2maxtb = 5, depth_intra = 2, depth_inter = 2;
+  int amp = 1, sao = 1, pcm = 1, pcm_bits = 0 /*0: bit depth*/, pcm_lf_off = 0, strong = 1, tmvp = 1, cip = 0;
+  int qp = 30, cuqpd = 1, qg_depth = 1, cb_off = 1, cr_off = -2, slice_cqp = 1;
+  int wp = 0, sdh = 0, tskip = 0, tqbypass = 0;
+  int deblock = 1, lf_slices = 1, cabac_init = 1, lists_mod = 0, merge_cand = 5, par_mrg = 2;
+  int nref = 2, max_level = 24, big_mv = 1;
+  int dens = 50;                      /* percent: how often cbf flags are set */
+};
+
+struct Kv { const char* k; int Cfg::* p; };
+const Kv KV[] = {
+  {"w",&Cfg::w},{"h",&Cfg::h},{"bits",&Cfg::bits},{"pics",&Cfg::pics},{"slices",&Cfg::slices},{"seed",&Cfg::seed},
+  {"log2ctb",&Cfg::log2ctb},{"log2mincb",&Cfg::log2mincb},{"log2mintb",&Cfg::log2mintb},{"log2maxtb",&Cfg::log2maxtb},
+  {"depth_intra",&Cfg::depth_intra},{"depth_inter",&Cfg::depth_inter},{"amp",&Cfg::amp},{"sao",&Cfg::sao},{"pcm",&Cfg::pcm},
+  {"pcm_bits",&Cfg::pcm_bits},{"pcm_lf_off",&Cfg::pcm_lf_off},{"strong",&Cfg::strong},{"tmvp",&Cfg::tmvp},{"cip",&Cfg::cip},
+  {"qp",&Cfg::qp},{"cuqpd",&Cfg::cuqpd},{"qg_depth",&Cfg::qg_depth},{"cb_off",&Cfg::cb_off},{"cr_off",&Cfg::cr_off},
+  {"slice_cqp",&Cfg::slice_cqp},{"wp",&Cfg::wp},{"sdh",&Cfg::sdh},{"tskip",&Cfg::tskip},{"tqbypass",&Cfg::tqbypass},
+  {"deblock",&Cfg::deblock},{"lf_slices",&Cfg::lf_slices},{"cabac_init",&Cfg::cabac_init},{"lists_mod",&Cfg::lists_mod},
+  {"merge_cand",&Cfg::merge_cand},{"par_mrg",&Cfg::par_mrg},{"nref",&Cfg::nref},{"max_level",&Cfg::max_level},
+  {"big_mv",&Cfg::big_mv},{"dens",&Cfg::dens},
+};
+
+[[noreturn]] void die(const char* msg) { fprintf(stderr, "f2_writer: %s\n", msg); exit(2); }
+
+/* ---------------------------------------------------------------- random source ---------------------------------------------------------------- */
+struct Rng {
+  uint64_t s;
+  explicit Rng(uint64_t seed) : s(seed * 0x9E3779B97F4A7C15ull + 0x2545F4914F6CDD1Dull) { for (int i=0;i<8;i++) next(); }
+  uint64_t next() { s ^= s >> 12; s ^= s << 25; s ^= s >> 27; return s * 0x2545F4914F6CDD1Dull; }
+  int below(int n) { return n <= 1 ? 0 : (int)((next() >> 33) % (uint64_t)n); }
+  int range(int lo, int hi) { return lo + below(hi - lo + 1); }
+  bool pct(int p) { return below(100) < p; }
+};
+
+/* ---------------------------------------------------------------- coding structure ---------------------------------------------------------------- */
+struct PicPlan {
+  int poc = 0, type = SLICE_TYPE_I;
+  bool idr = false;
+  std::vector<int> refs;              /* POCs this picture may predict from */
+};
+
+std::vector<PicPlan> plan_gop(const Cfg& c)
+{
+  std::vector<PicPlan> v;
+  auto add = [&](int poc, int type, std::vector<int> refs) { PicPlan p; p.poc = poc; p.type = type; p.refs = refs; p.idr = v.empty(); v.push_back(p); };
+  if (c.gop == "I") {
+    for (int i=0;i<c.pics;i++) add(i, SLICE_TYPE_I, {});
+  } else if (c.gop == "P" || c.gop == "LDB") {              /* low delay: the nref previous pictures */
+    for (int i=0;i<c.pics;i++) {
+      std::vector<int> r;
+      for (int k=1;k<=c.nref && i-k>=0;k++) r.push_back(i-k);
+      add(i, i==0 ? SLICE_TYPE_I : (c.gop == "P" ? SLICE_TYPE_P : SLICE_TYPE_B), r);
+    }
+  } else if (c.gop == "B") {                                /* random access, hierarchical GOP of 4 */
+    add(0, SLICE_TYPE_I, {});
+    for (int base=0; (int)v.size() < c.pics; base+=4) {
+      std::vector<int> back = {base}; if (base>=4) back.push_back(base-4);
+      add(base+4, SLICE_TYPE_P, back);
+      add(base+2, SLICE_TYPE_B, {base, base+4});
+      add(base+1, SLICE_TYPE_B, {base, base+2, base+4});
+      add(base+3, SLICE_TYPE_B, {base+2, base, base+4});
+    }
+    v.resize(c.pics);
+  } else die("gop must be I, P, LDB or B");
+  return v;
+}
+
+/* ---------------------------------------------------------------- the writer ---------------------------------------------------------------- */
+enum { PM_NONE=0, PM_INTRA=1, PM_INTER=2, PM_SKIP=3 };
+
+struct SliceCtx {
+  int type, addr /*SliceAddrRS*/, qp, n_l0, n_l1, max_merge, mvd_l1_zero;
+  bool sao_luma, sao_chroma;
+};
+
+struct Writer {
+  Cfg c;
+  Rng rng;
+  FILE* fout;
+  CABAC_encoder_bitstream cab;
+  context_model_table models;
+  error_queue errq;
+  std::shared_ptr<video_parameter_set> vps;
+  std::shared_ptr<seq_parameter_set> sps;
+  std::shared_ptr<pic_parameter_set> pps;
+
+  int W4, H4, ctbW, ctbH, nCtb;
+  std::vector<uint8_t> ct_depth, skipf, pmode, pcmf, ipm;       /* per 4x4 block */
+  std::vector<int> ctb_slice;                                   /* SliceAddrRS per CTB of the current picture, -1: not yet coded */
+  SliceCtx S;
+  struct Stats { long n_coeffs=0, abs_sum=0, n_pus=0, n_pcms=0, n_cus=0, n_resid=0; } st;   /* per picture, for the .chk sidecar */
+  FILE* fchk = nullptr;
+  bool qpd_coded = false;
+  int chroma_mode_cu = 0;                                       /* IntraPredModeC of the CU being coded */
+
+  explicit Writer(const Cfg& cfg) : c(cfg), rng(cfg.seed) {}
+
+  /* ---------- NAL plumbing: one CABAC_encoder_bitstream per NAL (it inserts the emulation prevention bytes) ---------- */
+  void nal_begin(int type) { cab.reset(); cab.write_bits(0,1); cab.write_bits(type,6); cab.write_bits(0,6); cab.write_bits(1,3); }
+  void nal_end() {
+    static const uint8_t sc[4] = {0,0,0,1};
+    fwrite(sc,1,4,fout); fwrite(cab.data(),1,cab.size(),fout);
+  }
+
+  /* ---------- parameter sets (vps.cc/sps.cc/pps.cc write()) ---------- */
+  void write_parameter_sets()
+  {
+    vps = std::make_shared<video_parameter_set>();
+    vps->set_defaults(c.bits > 8 ? Profile_Main10 : Profile_Main, 6, 2);
+    vps->layer[0].vps_max_dec_pic_buffering = 6; vps->layer[0].vps_max_num_reorder_pics = 4;
+
+    sps = std::make_shared<seq_parameter_set>();
+    sps->set_defaults();
+    sps->profile_tier_level_.general.set_defaults(c.bits > 8 ? Profile_Main10 : Profile_Main, 6, 2);
+    sps->set_resolution(c.w, c.h);
+    sps->bit_depth_luma = sps->bit_depth_chroma = c.bits;
+    sps->sps_max_dec_pic_buffering[0] = 6; sps->sps_max_num_reorder_pics[0] = 4;
+    sps->set_CB_log2size_range(c.log2mincb, c.log2ctb);
+    sps->set_TB_log2size_range(c.log2mintb, c.log2maxtb);
+    sps->max_transform_hierarchy_depth_inter = c.depth_inter;
+    sps->max_transform_hierarchy_depth_intra = c.depth_intra;
+    sps->amp_enabled_flag = c.amp; sps->sample_adaptive_offset_enabled_flag = c.sao;
+    sps->pcm_enabled_flag = c.pcm;
+    if (c.pcm) {
+      sps->pcm_sample_bit_depth_luma = sps->pcm_sample_bit_depth_chroma = c.pcm_bits ? c.pcm_bits : c.bits;
+      sps->log2_min_pcm_luma_coding_block_size = std::max(3, c.log2mincb);
+      sps->log2_diff_max_min_pcm_luma_coding_block_size = std::min(5, c.log2ctb) - sps->log2_min_pcm_luma_coding_block_size;
+      sps->pcm_loop_filter_disable_flag = c.pcm_lf_off;
+    }
+    sps->sps_temporal_mvp_enabled_flag = c.tmvp; sps->strong_intra_smoothing_enable_flag = c.strong;
+    if (sps->compute_derived_values() != DE265_OK) die("sps: invalid parameters");
+
+    pps = std::make_shared<pic_parameter_set>();
+    pps->set_defaults();
+    pps->sign_data_hiding_flag = c.sdh; pps->cabac_init_present_flag = c.cabac_init;
+    pps->num_ref_idx_l0_default_active = 1; pps->num_ref_idx_l1_default_active = 1;
+    pps->pic_init_qp = c.qp; pps->constrained_intra_pred_flag = c.cip; pps->transform_skip_enabled_flag = c.tskip;
+    pps->cu_qp_delta_enabled_flag = c.cuqpd; pps->diff_cu_qp_delta_depth = c.cuqpd ? std::min(c.qg_depth, c.log2ctb - c.log2mincb) : 0;
+    pps->pic_cb_qp_offset = c.cb_off; pps->pic_cr_qp_offset = c.cr_off; pps->pps_slice_chroma_qp_offsets_present_flag = c.slice_cqp;
+    pps->weighted_pred_flag = c.wp; pps->weighted_bipred_flag = c.wp; pps->transquant_bypass_enable_flag = c.tqbypass;
+    pps->pps_loop_filter_across_slices_enabled_flag = c.lf_slices;
+    pps->deblocking_filter_control_present_flag = 1; pps->deblocking_filter_override_enabled_flag = c.deblock ? 1 : 0;
+    pps->pic_disable_deblocking_filter_flag = c.deblock ? 0 : 1;
+    pps->beta_offset = c.deblock ? 2*rng.range(-3,3) : 0; pps->tc_offset = c.deblock ? 2*rng.range(-3,3) : 0;
+    pps->lists_modification_present_flag = c.lists_mod; pps->log2_parallel_merge_level = c.par_mrg;
+    pps->set_derived_values(sps.get());
+
+    nal_begin(NAL_UNIT_VPS_NUT); vps->write(&errq, cab); cab.add_trailing_bits(); cab.flush_VLC(); nal_end();
+    nal_begin(NAL_UNIT_SPS_NUT); sps->write(&errq, cab); cab.add_trailing_bits(); cab.flush_VLC(); nal_end();
+    nal_begin(NAL_UNIT_PPS_NUT); pps->write(&errq, cab, sps.get()); cab.add_trailing_bits(); cab.flush_VLC(); nal_end();
+
+    W4 = (c.w+3)/4; H4 = (c.h+3)/4;
+    ctbW = (c.w + (1<<c.log2ctb) - 1) >> c.log2ctb; ctbH = (c.h + (1<<c.log2ctb) - 1) >> c.log2ctb; nCtb = ctbW*ctbH;
+  }
+
+  /* ---------- block state ---------- */
+  void fill(std::vector<uint8_t>& a, int x0, int y0, int w, int h, int v) {
+    for (int y=y0/4; y<std::min(H4,(y0+h+3)/4); y++) for (int x=x0/4; x<std::min(W4,(x0+w+3)/4); x++) a[x+y*W4] = (uint8_t)v;
+  }
+  int at(const std::vector<uint8_t>& a, int x, int y) const { return a[(x>>2)+(y>>2)*W4]; }
+  /* slice.cc:2873 check_CTB_available (one tile) */
+  bool available(int xC, int yC, int xN, int yN) const {
+    if (xN<0 || yN<0 || xN>=c.w || yN>=c.h) return false;
+    const int cur = (xC>>c.log2ctb) + (yC>>c.log2ctb)*ctbW, nb = (xN>>c.log2ctb) + (yN>>c.log2ctb)*ctbW;
+    return ctb_slice[nb] == ctb_slice[cur];
+  }
+
+  /* ---------- slice header (slice.cc:352 slice_segment_header::read, refpic.cc:85, slice.cc:215 read_pred_weight_table) ---------- */
+  struct PicState { std::vector<int> dpb; };                 /* POCs of decoded pictures still held */
+  PicState dpbs;
+
+  void write_slice_header(const PicPlan& p, const std::vector<int>& neg, const std::vector<int>& pos,
+                          const std::vector<bool>& neg_used, const std::vector<bool>& pos_used,
+                          int slice_idx, int addr, int slice_type, int nal_type)
+  {
+    const int n_curr = (int)std::count(neg_used.begin(),neg_used.end(),true) + (int)std::count(pos_used.begin(),pos_used.end(),true);
+    cab.write_bit(slice_idx==0);                                    /* first_slice_segment_in_pic_flag */
+    if (nal_type >= 16 && nal_type <= 23) cab.write_bit(0);         /* no_output_of_prior_pics_flag */
+    cab.write_uvlc(0);                                              /* slice_pic_parameter_set_id */
+    if (slice_idx) { int nb = 0; while ((1<<nb) < nCtb) nb++; cab.write_bits(addr, nb); }
+    cab.write_uvlc(slice_type);
+    bool tmvp = false;
+    if (!p.idr) {
+      cab.write_bits(p.poc & 255, 8);                               /* slice_pic_order_cnt_lsb, log2_max_poc_lsb = 8 */
+      cab.write_bit(0);                                             /* short_term_ref_pic_set_sps_flag: explicit set, no prediction (idx 0) */
+      cab.write_uvlc((int)neg.size()); cab.write_uvlc((int)pos.size());
+      int last = p.poc;
+      for (size_t i=0;i<neg.size();i++) { cab.write_uvlc(last-neg[i]-1); cab.write_bit(neg_used[i]); last = neg[i]; }
+      last = p.poc;
+      for (size_t i=0;i<pos.size();i++) { cab.write_uvlc(pos[i]-last-1); cab.write_bit(pos_used[i]); last = pos[i]; }
+      if (c.tmvp) { tmvp = pic_tmvp; cab.write_bit(tmvp); }
+    }
+    S.sao_luma = S.sao_chroma = false;
+    if (c.sao) { S.sao_luma = rng.pct(80); S.sao_chroma = rng.pct(70); cab.write_bit(S.sao_luma); cab.write_bit(S.sao_chroma); }
+    S.n_l0 = S.n_l1 = 0; S.max_merge = 5; S.mvd_l1_zero = 0;
+    int cabac_init_flag = 0;
+    if (slice_type != SLICE_TYPE_I) {
+      S.n_l0 = rng.range(1, std::min(4, n_curr+1)); S.n_l1 = slice_type==SLICE_TYPE_B ? rng.range(1, std::min(3, n_curr+1)) : 0;
+      if (tmvp) { S.n_l0 = std::max(S.n_l0, pic_col_idx+1); if (slice_type==SLICE_TYPE_B) S.n_l1 = std::max(S.n_l1, pic_col_idx+1); }
+      const bool ovr = S.n_l0 != 1 || (slice_type==SLICE_TYPE_B && S.n_l1 != 1) || rng.pct(20);
+      cab.write_bit(ovr);
+      if (ovr) { cab.write_uvlc(S.n_l0-1); if (slice_type==SLICE_TYPE_B) cab.write_uvlc(S.n_l1-1); }
+      if (c.lists_mod && n_curr > 1) {
+        int nb = 0; while ((1<<nb) < n_curr) nb++;
+        for (int l=0; l<(slice_type==SLICE_TYPE_B ? 2 : 1); l++) {
+          const bool m = rng.pct(50); cab.write_bit(m);
+          if (m) for (int i=0;i<(l?S.n_l1:S.n_l0);i++) cab.write_bits(rng.below(n_curr), nb);
+        }
+      }
+      if (slice_type==SLICE_TYPE_B) { S.mvd_l1_zero = rng.pct(25); cab.write_bit(S.mvd_l1_zero); }
+      if (c.cabac_init) { cabac_init_flag = rng.pct(50); cab.write_bit(cabac_init_flag); }
+      if (tmvp) {
+        /* one collocated picture per picture (7.4.7.1): with lists_mod the same POC cannot be guaranteed -> idx 0 of L0 only then */
+        bool from_l0 = true;
+        if (slice_type==SLICE_TYPE_B) { from_l0 = pic_col_from_l0; cab.write_bit(from_l0); }
+        if ((from_l0 && S.n_l0>1) || (!from_l0 && S.n_l1>1)) cab.write_uvlc(pic_col_idx);
+      }
+      if (c.wp) write_pred_weight_table(slice_type);
+      S.max_merge = c.merge_cand > 0 ? c.merge_cand : rng.range(1,5);
+      cab.write_uvlc(5 - S.max_merge);
+    }
+    const int qpd = rng.range(-4,4);
+    S.qp = c.qp + qpd; cab.write_svlc(qpd);
+    if (c.slice_cqp) { cab.write_svlc(rng.range(-3,3)); cab.write_svlc(rng.range(-3,3)); }
+    bool dbk_off = !c.deblock;
+    if (c.deblock) {
+      const bool ovr = rng.pct(50); cab.write_bit(ovr);
+      if (ovr) { dbk_off = rng.pct(20); cab.write_bit(dbk_off); if (!dbk_off) { cab.write_svlc(rng.range(-4,4)); cab.write_svlc(rng.range(-4,4)); } }
+    }
+    if (c.lf_slices && (S.sao_luma || S.sao_chroma || !dbk_off)) cab.write_bit(rng.pct(60));   /* slice_loop_filter_across_slices_enabled_flag */
+    cab.add_trailing_bits(); cab.flush_VLC();                       /* byte_alignment() */
+
+    S.type = slice_type; S.addr = addr;
+    const int initType = slice_type==SLICE_TYPE_I ? 0 : slice_type==SLICE_TYPE_P ? (cabac_init_flag ? 2 : 1) : (cabac_init_flag ? 1 : 2);
+    models.init(initType, S.qp);
+    cab.set_context_models(&models);
+    cab.init_CABAC();
+  }
+
+  void write_pred_weight_table(int slice_type)
+  {
+    const int ld = rng.range(0,7); cab.write_uvlc(ld);
+    const int dc = rng.range(std::max(-ld,-2), std::min(7-ld,2)); cab.write_svlc(dc);       /* delta_chroma_log2_weight_denom */
+    for (int l=0; l<(slice_type==SLICE_TYPE_B ? 2 : 1); l++) {
+      const int n = l ? S.n_l1 : S.n_l0;
+      std::vector<int> lf(n), cf(n);
+      for (int i=0;i<n;i++) { lf[i] = rng.pct(60); cab.write_bit(lf[i]); }
+      for (int i=0;i<n;i++) { cf[i] = rng.pct(50); cab.write_bit(cf[i]); }
+      for (int i=0;i<n;i++) {
+        if (lf[i]) { cab.write_svlc(rng.range(-20,20)); cab.write_svlc(rng.range(-40,40)); }
+        if (cf[i]) for (int j=0;j<2;j++) { cab.write_svlc(rng.range(-20,20)); cab.write_svlc(rng.range(-100,100)); }
+      }
+    }
+  }
+
+  /* ---------- SAO (slice.cc:2695 read_sao) ---------- */
+  void code_sao(int xCtb, int yCtb)
+  {
+    const int addr = xCtb + yCtb*ctbW;
+    bool left = false, up = false;
+    if (xCtb>0 && addr > S.addr) { left = rng.pct(20); cab.write_CABAC_bit(CONTEXT_MODEL_SAO_MERGE_FLAG, left); }
+    if (yCtb>0 && !left && addr-ctbW >= S.addr) { up = rng.pct(20); cab.write_CABAC_bit(CONTEXT_MODEL_SAO_MERGE_FLAG, up); }
+    if (left || up) return;
+    int type_c = 0;
+    for (int cIdx=0;cIdx<3;cIdx++) {
+      if (!((cIdx==0 && S.sao_luma) || (cIdx>0 && S.sao_chroma))) continue;
+      int type;
+      if (cIdx<2) {
+        type = rng.pct(30) ? 0 : rng.range(1,2);
+        cab.write_CABAC_bit(CONTEXT_MODEL_SAO_TYPE_IDX, type!=0);
+        if (type) cab.write_CABAC_bypass(type==2);
+        if (cIdx==1) type_c = type;
+      } else type = type_c;
+      if (!type) continue;
+      const int cMax = (1 << (std::min(c.bits,10)-5)) - 1;
+      int off[4];
+      for (int i=0;i<4;i++) { off[i] = rng.pct(25) ? 0 : rng.range(0,cMax); cab.write_CABAC_TU_bypass(off[i], cMax); }
+      if (type==1) {
+        for (int i=0;i<4;i++) if (off[i]) cab.write_CABAC_bypass(rng.below(2));
+        cab.write_CABAC_FL_bypass(rng.below(32), 5);
+      } else if (cIdx<2) cab.write_CABAC_FL_bypass(rng.below(4), 2);
+    }
+  }
+
+  /* ---------- coding quadtree (slice.cc:4582) ---------- */
+  void code_quadtree(int x0, int y0, int log2, int depth)
+  {
+    bool split;
+    if (x0+(1<<log2) <= c.w && y0+(1<<log2) <= c.h && log2 > c.log2mincb) {
+      split = rng.pct(log2 >= 6 ? 75 : log2 == 5 ? 55 : 40);
+      const int condL = available(x0,y0,x0-1,y0) && at(ct_depth,x0-1,y0) > depth;
+      const int condA = available(x0,y0,x0,y0-1) && at(ct_depth,x0,y0-1) > depth;
+      cab.write_CABAC_bit(CONTEXT_MODEL_SPLIT_CU_FLAG + condL + condA, split);
+    } else split = log2 > c.log2mincb;
+    if (c.cuqpd && log2 >= c.log2ctb - pps->diff_cu_qp_delta_depth) qpd_coded = false;
+    if (split) {
+      const int x1 = x0 + (1<<(log2-1)), y1 = y0 + (1<<(log2-1));
+      code_quadtree(x0,y0,log2-1,depth+1);
+      if (x1<c.w) code_quadtree(x1,y0,log2-1,depth+1);
+      if (y1<c.h) code_quadtree(x0,y1,log2-1,depth+1);
+      if (x1<c.w && y1<c.h) code_quadtree(x1,y1,log2-1,depth+1);
+    } else {
+      fill(ct_depth, x0,y0, 1<<log2,1<<log2, depth);
+      code_cu(x0,y0,log2,depth);
+    }
+  }
+
+  /* ---------- coding unit (slice.cc:4245) ---------- */
+  bool cu_bypass = false;
+
+  void code_cu(int x0, int y0, int log2, int depth)
+  {
+    const int n = 1<<log2;
+    cu_bypass = false;
+    if (c.tqbypass) { cu_bypass = rng.pct(12); cab.write_CABAC_bit(CONTEXT_MODEL_CU_TRANSQUANT_BYPASS_FLAG, cu_bypass); }
+    bool skip = false;
+    if (S.type != SLICE_TYPE_I) {
+      skip = rng.pct(22);
+      const int condL = available(x0,y0,x0-1,y0) && at(skipf,x0-1,y0);
+      const int condA = available(x0,y0,x0,y0-1) && at(skipf,x0,y0-1);
+      cab.write_CABAC_bit(CONTEXT_MODEL_CU_SKIP_FLAG + condL + condA, skip);
+    }
+    fill(skipf, x0,y0,n,n, skip); fill(pcmf, x0,y0,n,n, 0);
+    st.n_cus++;
+    if (skip) { code_merge_idx(); st.n_pus++; fill(pmode, x0,y0,n,n, PM_SKIP); return; }
+
+    bool intra = true;
+    if (S.type != SLICE_TYPE_I) { intra = rng.pct(18); cab.write_CABAC_bit(CONTEXT_MODEL_PRED_MODE_FLAG, intra); }
+    fill(pmode, x0,y0,n,n, intra ? PM_INTRA : PM_INTER);
+
+    int part = PART_2Nx2N;
+    if (intra) {
+      if (log2 == c.log2mincb) { part = rng.pct(45) ? PART_NxN : PART_2Nx2N; cab.write_CABAC_bit(CONTEXT_MODEL_PART_MODE, part==PART_2Nx2N); }
+    } else {
+      part = choose_inter_part(log2);
+      code_inter_part_mode(part, log2);
+    }
+
+    bool merge_2Nx2N = false;
+    if (intra) {
+      bool pcm = false;
+      if (part==PART_2Nx2N && c.pcm && log2 >= sps->Log2MinIpcmCbSizeY && log2 <= sps->Log2MaxIpcmCbSizeY) {
+        pcm = rng.pct(log2 >= 5 ? 3 : 8);
+        cab.write_CABAC_term_bit(pcm);
+      }
+      if (pcm) { st.n_pcms++; fill(pcmf, x0,y0,n,n, 1); fill(ipm, x0,y0,n,n, 1); code_pcm_samples(log2); return; }
+      code_intra_modes(x0,y0,log2,part);
+    } else {
+      static const int geo[8][2][4] = {        /* per PartMode: PUs as x,y,w,h in quarters of the CB */
+        {{0,0,4,4},{0,0,0,0}}, {{0,0,4,2},{0,2,4,2}}, {{0,0,2,4},{2,0,2,4}}, {{0,0,2,2},{2,0,2,2}},
+        {{0,0,4,1},{0,1,4,3}}, {{0,0,4,3},{0,3,4,1}}, {{0,0,1,4},{1,0,3,4}}, {{0,0,3,4},{3,0,1,4}} };
+      if (part == PART_NxN) {
+        for (int k=0;k<4;k++) code_pu(n/2, n/2, depth);
+      } else {
+        const int npu = part==PART_2Nx2N ? 1 : 2;
+        for (int k=0;k<npu;k++) { const bool m = code_pu(geo[part][k][2]*n/4, geo[part][k][3]*n/4, depth); if (part==PART_2Nx2N) merge_2Nx2N = m; }
+      }
+    }
+
+    bool rqt = true;
+    if (!intra && !merge_2Nx2N) { rqt = rng.pct(65); cab.write_CABAC_bit(CONTEXT_MODEL_RQT_ROOT_CBF, rqt); }
+    if (rqt) {
+      const int intraSplit = intra && part==PART_NxN;
+      const int maxDepth = intra ? c.depth_intra + intraSplit : c.depth_inter;
+      code_transform_tree(x0,y0,x0,y0,log2,0,0,maxDepth,intraSplit,intra,part,1,1);
+    }
+  }
+
+  int choose_inter_part(int log2)
+  {
+    if (rng.pct(45)) return PART_2Nx2N;
+    std::vector<int> opt = {PART_2NxN, PART_Nx2N};
+    if (log2 > c.log2mincb) { if (c.amp) { opt.push_back(PART_2NxnU); opt.push_back(PART_2NxnD); opt.push_back(PART_nLx2N); opt.push_back(PART_nRx2N); } }
+    else if (log2 > 3) opt.push_back(PART_NxN);
+    return opt[rng.below((int)opt.size())];
+  }
+
+  /* slice.cc:1689 decode_part_mode, inter branch */
+  void code_inter_part_mode(int part, int log2)
+  {
+    cab.write_CABAC_bit(CONTEXT_MODEL_PART_MODE+0, part==PART_2Nx2N);
+    if (part==PART_2Nx2N) return;
+    const bool horiz = part==PART_2NxN || part==PART_2NxnU || part==PART_2NxnD;
+    if (log2 > c.log2mincb) {
+      cab.write_CABAC_bit(CONTEXT_MODEL_PART_MODE+1, horiz);
+      if (!c.amp) return;
+      const bool sym = part==PART_2NxN || part==PART_Nx2N;
+      cab.write_CABAC_bit(CONTEXT_MODEL_PART_MODE+3, sym);
+      if (!sym) cab.write_CABAC_bypass(part==PART_2NxnD || part==PART_nRx2N);
+    } else {
+      cab.write_CABAC_bit(CONTEXT_MODEL_PART_MODE+1, part==PART_2NxN);
+      if (part==PART_2NxN || log2==3) return;
+      cab.write_CABAC_bit(CONTEXT_MODEL_PART_MODE+2, part==PART_Nx2N);
+    }
+  }
+
+  /* slice.cc:4144-4243: pcm_flag was the terminating bin -> CABAC flush, stop bit, pcm_alignment_zero_bits, raw samples, CABAC restart */
+  void code_pcm_samples(int log2)
+  {
+    cab.flush_CABAC(); cab.write_bit(1); cab.write_bits(0, cab.number_free_bits_in_byte()); cab.flush_VLC();
+    const int nb = sps->pcm_sample_bit_depth_luma, n = 1<<log2;
+    const int mode = rng.below(3), base = rng.below(1<<nb);
+    for (int comp=0;comp<3;comp++) {
+      const int w = comp ? n/2 : n;
+      for (int i=0;i<w*w;i++) {
+        int v = mode==0 ? rng.below(1<<nb) : mode==1 ? base : std::min((1<<nb)-1, std::max(0, base + rng.range(-3,3)));
+        cab.write_bits(v, nb);
+      }
+    }
+    cab.flush_VLC();
+    cab.init_CABAC();
+  }
+
+  /* slice.cc:4336-4440 + intrapred.cc:62-152 */
+  void code_intra_modes(int x0, int y0, int log2, int part)
+  {
+    const int n = 1<<log2, npu = part==PART_NxN ? 4 : 1, pb = part==PART_NxN ? n/2 : n;
+    int prev[4], val[4];
+    for (int k=0;k<npu;k++) { prev[k] = rng.pct(55); val[k] = prev[k] ? rng.below(3) : rng.below(32); cab.write_CABAC_bit(CONTEXT_MODEL_PREV_INTRA_LUMA_PRED_FLAG, prev[k]); }
+    const bool availA0 = available(x0,y0,x0-1,y0), availB0 = available(x0,y0,x0,y0-1);
+    int mode0 = 0;
+    for (int k=0;k<npu;k++) {
+      if (prev[k]) cab.write_CABAC_TU_bypass(val[k], 2); else cab.write_CABAC_FL_bypass(val[k], 5);
+      const int i = (k&1)*pb, j = (k>>1)*pb, x = x0+i, y = y0+j;
+      const bool availA = availA0 || i>0, availB = availB0 || j>0;
+      int A = 1, B = 1;                                                              /* INTRA_DC */
+      if (availA && at(pmode,x-1,y)==PM_INTRA && !at(pcmf,x-1,y)) A = at(ipm,x-1,y);
+      if (availB && at(pmode,x,y-1)==PM_INTRA && !at(pcmf,x,y-1) && y-1 >= ((y>>c.log2ctb)<<c.log2ctb)) B = at(ipm,x,y-1);
+      int cand[3];
+      if (A==B) {
+        if (A<2) { cand[0]=0; cand[1]=1; cand[2]=26; }
+        else { cand[0]=A; cand[1]=2+((A-2-1+32)%32); cand[2]=2+((A-2+1)%32); }
+      } else {
+        cand[0]=A; cand[1]=B;
+        cand[2] = (A!=0 && B!=0) ? 0 : (A!=1 && B!=1) ? 1 : 26;
+      }
+      int mode;
+      if (prev[k]) mode = cand[val[k]];
+      else {
+        std::sort(cand, cand+3);
+        mode = val[k];
+        for (int t=0;t<3;t++) if (mode >= cand[t]) mode++;
+      }
+      fill(ipm, x,y,pb,pb, mode);
+      if (k==0) mode0 = mode;
+    }
+    const int cpm = rng.below(5);                                                    /* intra_chroma_pred_mode */
+    cab.write_CABAC_bit(CONTEXT_MODEL_INTRA_CHROMA_PRED_MODE, cpm!=4);
+    if (cpm!=4) cab.write_CABAC_FL_bypass(cpm, 2);
+    static const int tab[4] = {0,26,10,1};
+    chroma_mode_cu = cpm==4 ? mode0 : (tab[cpm]==mode0 ? 34 : tab[cpm]);
+  }
+
+  /* slice.cc:2503 */
+  void code_merge_idx()
+  {
+    if (S.max_merge <= 1) return;
+    const int idx = rng.below(S.max_merge);
+    cab.write_CABAC_bit(CONTEXT_MODEL_MERGE_IDX, idx!=0);
+    if (idx) for (int i=1; i<S.max_merge-1; i++) { const bool more = i < idx; cab.write_CABAC_bypass(more); if (!more) break; }
+  }
+
+  /* slice.cc:2574 */
+  void code_ref_idx(int n_active)
+  {
+    const int cMax = n_active-1;
+    if (!cMax) return;
+    const int idx = rng.below(n_active);
+    for (int i=0;i<cMax;i++) {
+      const bool bit = i < idx;
+      if (i<2) cab.write_CABAC_bit(CONTEXT_MODEL_REF_IDX_LX + i, bit); else cab.write_CABAC_bypass(bit);
+      if (!bit) break;
+    }
+  }
+
+  /* slice.cc:3986 */
+  void code_mvd()
+  {
+    int v[2];
+    for (int k=0;k<2;k++) {
+      const int r = rng.below(100);
+      int a = r<30 ? 0 : r<50 ? 1 : r<85 ? rng.range(2,24) : r<98 ? rng.range(25,160) : (c.big_mv ? rng.range(161,3000) : 2);
+      v[k] = rng.below(2) ? -a : a;
+    }
+    const int a0 = abs(v[0]), a1 = abs(v[1]);
+    cab.write_CABAC_bit(CONTEXT_MODEL_ABS_MVD_GREATER01_FLAG+0, a0>0);
+    cab.write_CABAC_bit(CONTEXT_MODEL_ABS_MVD_GREATER01_FLAG+0, a1>0);
+    if (a0) cab.write_CABAC_bit(CONTEXT_MODEL_ABS_MVD_GREATER01_FLAG+1, a0>1);
+    if (a1) cab.write_CABAC_bit(CONTEXT_MODEL_ABS_MVD_GREATER01_FLAG+1, a1>1);
+    if (a0) { if (a0>1) cab.write_CABAC_EGk(a0-2,1); cab.write_CABAC_bypass(v[0]<0); }
+    if (a1) { if (a1>1) cab.write_CABAC_EGk(a1-2,1); cab.write_CABAC_bypass(v[1]<0); }
+  }
+
+  /* slice.cc:4062 read_prediction_unit; returns merge_flag */
+  bool code_pu(int w, int h, int ctDepth)
+  {
+    const bool merge = rng.pct(40);
+    st.n_pus++;
+    cab.write_CABAC_bit(CONTEXT_MODEL_MERGE_FLAG, merge);
+    if (merge) { code_merge_idx(); return true; }
+    int idc = 0;                                                           /* 0: L0, 1: L1, 2: BI */
+    if (S.type == SLICE_TYPE_B) {
+      if (w+h==12) { idc = rng.below(2); cab.write_CABAC_bit(CONTEXT_MODEL_INTER_PRED_IDC+4, idc); }
+      else {
+        idc = rng.pct(40) ? 2 : rng.below(2);
+        cab.write_CABAC_bit(CONTEXT_MODEL_INTER_PRED_IDC+ctDepth, idc==2);
+        if (idc!=2) cab.write_CABAC_bit(CONTEXT_MODEL_INTER_PRED_IDC+4, idc);
+      }
+    }
+    if (idc != 1) { code_ref_idx(S.n_l0); code_mvd(); cab.write_CABAC_bit(CONTEXT_MODEL_MVP_LX_FLAG, rng.below(2)); }
+    if (idc != 0) {
+      code_ref_idx(S.n_l1);
+      if (!(S.mvd_l1_zero && idc==2)) code_mvd();
+      cab.write_CABAC_bit(CONTEXT_MODEL_MVP_LX_FLAG, rng.below(2));
+    }
+    return false;
+  }
+
+  /* ---------- transform tree (slice.cc:3821) and unit (slice.cc:3549) ---------- */
+  void code_transform_tree(int x0, int y0, int xBase, int yBase, int log2, int depth, int blkIdx, int maxDepth, int intraSplit,
+                           bool intra, int part, int parent_cb, int parent_cr)
+  {
+    bool split;
+    if (log2 <= c.log2maxtb && log2 > c.log2mintb && depth < maxDepth && !(intraSplit && depth==0)) {
+      split = rng.pct(log2 >= 5 ? 60 : 40);
+      cab.write_CABAC_bit(CONTEXT_MODEL_SPLIT_TRANSFORM_FLAG + 5-log2, split);
+    } else {
+      const bool interSplit = c.depth_inter==0 && depth==0 && !intra && part != PART_2Nx2N;
+      split = log2 > c.log2maxtb || (intraSplit && depth==0) || interSplit;
+    }
+    int cbf_cb = -1, cbf_cr = -1;
+    if (log2 > 2) {
+      if (parent_cb) { cbf_cb = rng.pct(c.dens*7/10); cab.write_CABAC_bit(CONTEXT_MODEL_CBF_CHROMA + depth, cbf_cb); }
+      if (parent_cr) { cbf_cr = rng.pct(c.dens*7/10); cab.write_CABAC_bit(CONTEXT_MODEL_CBF_CHROMA + depth, cbf_cr); }
+    }
+    if (cbf_cb < 0) cbf_cb = (depth>0 && log2==2) ? parent_cb : 0;
+    if (cbf_cr < 0) cbf_cr = (depth>0 && log2==2) ? parent_cr : 0;
+    if (split) {
+      const int x1 = x0 + (1<<(log2-1)), y1 = y0 + (1<<(log2-1));
+      code_transform_tree(x0,y0,x0,y0,log2-1,depth+1,0,maxDepth,intraSplit,intra,part,cbf_cb,cbf_cr);
+      code_transform_tree(x1,y0,x0,y0,log2-1,depth+1,1,maxDepth,intraSplit,intra,part,cbf_cb,cbf_cr);
+      code_transform_tree(x0,y1,x0,y0,log2-1,depth+1,2,maxDepth,intraSplit,intra,part,cbf_cb,cbf_cr);
+      code_transform_tree(x1,y1,x0,y0,log2-1,depth+1,3,maxDepth,intraSplit,intra,part,cbf_cb,cbf_cr);
+      return;
+    }
+    int cbf_luma = 1;
+    if (intra || depth != 0 || cbf_cb || cbf_cr) { cbf_luma = rng.pct(c.dens); cab.write_CABAC_bit(CONTEXT_MODEL_CBF_LUMA + (depth==0), cbf_luma); }
+
+    if (cbf_luma || cbf_cb || cbf_cr) {
+      if (c.cuqpd && !qpd_coded) { code_cu_qp_delta(); qpd_coded = true; }
+    }
+    if (cbf_luma) code_residual(log2, 0, intra ? scan_idx(log2, at(ipm,x0,y0), 0) : 0);
+    if (log2 > 2) {
+      if (cbf_cb) code_residual(log2-1, 1, intra ? scan_idx(log2-1, chroma_mode_cu, 1) : 0);
+      if (cbf_cr) code_residual(log2-1, 2, intra ? scan_idx(log2-1, chroma_mode_cu, 2) : 0);
+    } else if (blkIdx == 3) {
+      if (cbf_cb) code_residual(2, 1, intra ? scan_idx(2, chroma_mode_cu, 1) : 0);
+      if (cbf_cr) code_residual(2, 2, intra ? scan_idx(2, chroma_mode_cu, 2) : 0);
+    }
+  }
+
+  /* intrapred.cc:279 get_intra_scan_idx, 4:2:0 */
+  static int scan_idx(int log2, int mode, int cIdx)
+  {
+    if (log2==2 || (log2==3 && cIdx==0)) { if (mode>=6 && mode<=14) return 2; if (mode>=22 && mode<=30) return 1; }
+    return 0;
+  }
+
+  /* slice.cc:1884 */
+  void code_cu_qp_delta()
+  {
+    const int r = rng.below(100);
+    const int a = r<55 ? 0 : r<90 ? rng.range(1,3) : rng.range(4,9);
+    cab.write_CABAC_bit(CONTEXT_MODEL_CU_QP_DELTA_ABS+0, a>0);
+    if (!a) return;
+    for (int i=1;i<std::min(a,5);i++) cab.write_CABAC_bit(CONTEXT_MODEL_CU_QP_DELTA_ABS+1, 1);
+    if (a<5) cab.write_CABAC_bit(CONTEXT_MODEL_CU_QP_DELTA_ABS+1, 0); else cab.write_CABAC_EGk(a-5, 0);
+    cab.write_CABAC_bypass(rng.below(2));
+  }
+
+  /* ---------- residual_coding (slice.cc:2905-3420 and the context helpers at 1861-2490) ---------- */
+  void random_block(int16_t* co, int n, int cIdx)
+  {
+    memset(co, 0, sizeof(int16_t)*n*n);
+    const int r = rng.below(100);
+    int k = r<30 ? 1 : r<70 ? rng.range(2,5) : r<93 ? rng.range(6, std::min(n*n, 24)) : rng.range(1, std::min(n*n, n*n/2+1));
+    const bool dc_only = k==1 && rng.pct(60);
+    for (int i=0;i<k;i++) {
+      int x, y;
+      if (dc_only) x = y = 0;
+      else if (rng.pct(70)) { x = std::min(n-1, rng.below(n)*rng.below(n)/n); y = std::min(n-1, rng.below(n)*rng.below(n)/n); }
+      else { x = rng.below(n); y = rng.below(n); }
+      const int m = rng.below(100);
+      int a = m<50 ? 1 : m<72 ? 2 : m<84 ? 3 : m<97 ? rng.range(4, std::max(4,c.max_level)) : rng.range(c.max_level, 40*c.max_level);
+      if (cIdx && a > 3) a = 1 + a/2;
+      co[x+y*n] = (int16_t)(rng.below(2) ? -a : a);
+    }
+    if (!dc_only && rng.pct(4)) co[n*n-1] = (int16_t)(rng.below(2) ? -1 : 1);      /* last position of the block */
+  }
+
+  void code_last_prefix(int prefix, int log2, int cIdx, int model)
+  {
+    const int cMax = (log2<<1)-1;
+    int ctxOffset, ctxShift;
+    if (cIdx==0) { ctxOffset = 3*(log2-2) + ((log2-1)>>2); ctxShift = (log2+1)>>2; }
+    else { ctxOffset = 15; ctxShift = log2-2; }
+    for (int b=0;b<prefix;b++) cab.write_CABAC_bit(model + ctxOffset + (b>>ctxShift), 1);
+    if (prefix<cMax) cab.write_CABAC_bit(model + ctxOffset + (prefix>>ctxShift), 0);
+  }
+
+  static void split_last(int pos, int* prefix, int* suffix, int* nbits)
+  {
+    if (pos<4) { *prefix = pos; *suffix = 0; *nbits = 0; return; }
+    for (int p=4;;p++) {
+      const int nb = (p>>1)-1, base = (2+(p&1))<<nb;
+      if (pos < base + (1<<nb)) { *prefix = p; *suffix = pos-base; *nbits = nb; return; }
+    }
+  }
+
+  void code_abs_remaining(int v, int k)
+  {
+    if ((v>>k) <= 3) { for (int i=0;i<(v>>k);i++) cab.write_CABAC_bypass(1); cab.write_CABAC_bypass(0); cab.write_CABAC_FL_bypass(v & ((1<<k)-1), k); return; }
+    for (int p=4;;p++) {
+      const int base = ((1<<(p-3))+2)<<k, nb = p-3+k;
+      if (v < base + (1<<nb)) { for (int i=0;i<p;i++) cab.write_CABAC_bypass(1); cab.write_CABAC_bypass(0); cab.write_CABAC_FL_bypass(v-base, nb); return; }
+    }
+  }
+
+  void code_residual(int log2, int cIdx, int scanIdx)
+  {
+    const int n = 1<<log2;
+    int16_t co[32*32];
+    random_block(co, n, cIdx);
+    st.n_resid++;
+    for (int i=0;i<n*n;i++) if (co[i]) { st.n_coeffs++; st.abs_sum += abs(co[i]); }
+    bool tskip = false;
+    if (c.tskip && !cu_bypass && log2 <= 2) { tskip = rng.pct(35); cab.write_CABAC_bit(CONTEXT_MODEL_TRANSFORM_SKIP_FLAG + (cIdx?1:0), tskip); }
+
+    const position* subScan = get_scan_order(log2-2, scanIdx);
+    const position* posScan = get_scan_order(2, scanIdx);
+    const int nSub = 1<<(2*(log2-2));
+    int lastSub = -1, lastPos = -1;
+    for (int i=nSub-1;i>=0 && lastSub<0;i--)
+      for (int p=15;p>=0;p--) {
+        const int x = (subScan[i].x<<2)+posScan[p].x, y = (subScan[i].y<<2)+posScan[p].y;
+        if (co[x+y*n]) { lastSub = i; lastPos = p; break; }
+      }
+    int lx = (subScan[lastSub].x<<2)+posScan[lastPos].x, ly = (subScan[lastSub].y<<2)+posScan[lastPos].y;
+    if (scanIdx==2) std::swap(lx,ly);
+    int px,sx,nx, py,sy,ny;
+    split_last(lx,&px,&sx,&nx); split_last(ly,&py,&sy,&ny);
+    code_last_prefix(px, log2, cIdx, CONTEXT_MODEL_LAST_SIGNIFICANT_COEFFICIENT_X_PREFIX);
+    code_last_prefix(py, log2, cIdx, CONTEXT_MODEL_LAST_SIGNIFICANT_COEFFICIENT_Y_PREFIX);
+    if (px>3) cab.write_CABAC_FL_bypass(sx,nx);
+    if (py>3) cab.write_CABAC_FL_bypass(sy,ny);
+
+    const int sbW = 1<<(log2-2);
+    uint8_t nbr[64]; memset(nbr,0,sizeof(nbr));
+    int c1 = 1;
+    for (int i=lastSub;i>=0;i--) {
+      const position Sb = subScan[i];
+      const int bx = Sb.x<<2, by = Sb.y<<2;
+      bool has = false;
+      for (int p=0;p<16;p++) if (co[bx+posScan[p].x + (by+posScan[p].y)*n]) has = true;
+      bool coded, inferDc = false;
+      if (i<lastSub && i>0) {
+        const int nb = nbr[Sb.x+Sb.y*sbW];
+        cab.write_CABAC_bit(CONTEXT_MODEL_CODED_SUB_BLOCK_FLAG + ((nb&1)|(nb>>1)) + (cIdx?2:0), has);
+        coded = has; inferDc = true;
+      } else coded = true;
+      if (!coded) continue;
+      if (Sb.x>0) nbr[Sb.x-1+Sb.y*sbW] |= 1;
+      if (Sb.y>0) nbr[Sb.x+(Sb.y-1)*sbW] |= 2;
+      const int prevCsbf = nbr[Sb.x+Sb.y*sbW];
+
+      int lev[16], nc = 0, firstP = 0, lastP = 0;                   /* levels in coding order; scan position of the first / last one */
+      const int start = i==lastSub ? lastPos-1 : 15;
+      if (i==lastSub) { lev[nc++] = co[bx+posScan[lastPos].x + (by+posScan[lastPos].y)*n]; firstP = lastP = lastPos; }
+      for (int p=start;p>0;p--) {
+        const int xC = bx+posScan[p].x, yC = by+posScan[p].y, v = co[xC+yC*n];
+        cab.write_CABAC_bit(CONTEXT_MODEL_SIGNIFICANT_COEFF_FLAG + sig_ctx(xC,yC,log2,cIdx,scanIdx,prevCsbf), v!=0);
+        if (v) { if (!nc) firstP = p; lastP = p; lev[nc++] = v; inferDc = false; }
+      }
+      if (start>=0) {
+        const int v = co[bx+by*n];
+        if (!inferDc) { cab.write_CABAC_bit(CONTEXT_MODEL_SIGNIFICANT_COEFF_FLAG + sig_ctx(bx,by,log2,cIdx,scanIdx,prevCsbf), v!=0); if (v) { if (!nc) firstP = 0; lastP = 0; lev[nc++] = v; } }
+        else { firstP = lastP = 0; lev[nc++] = v; }                  /* inferred significant: the only coefficient of the sub-block */
+      }
+      if (!nc) continue;
+
+      int ctxSet = (i==0 || cIdx>0) ? 0 : 2;
+      if (c1==0) ctxSet++;
+      c1 = 1;
+      int g1ctx = 1, firstG1 = -1, lastFlag = 0;
+      const int n8 = std::min(8,nc);
+      for (int k=0;k<n8;k++) {
+        if (k>0 && g1ctx>0) { if (lastFlag) g1ctx = 0; else g1ctx++; }
+        const int flag = abs(lev[k])>1;
+        cab.write_CABAC_bit(CONTEXT_MODEL_COEFF_ABS_LEVEL_GREATER1_FLAG + ctxSet*4 + std::min(3,g1ctx) + (cIdx?16:0), flag);
+        lastFlag = flag;
+        if (flag) { c1 = 0; if (firstG1<0) firstG1 = k; }
+        else if (c1<3 && c1>0) c1++;
+      }
+      if (firstG1>=0) cab.write_CABAC_bit(CONTEXT_MODEL_COEFF_ABS_LEVEL_GREATER2_FLAG + ctxSet + (cIdx?4:0), abs(lev[firstG1])>2);
+      /* sign_data_hiding: the sign of the last (lowest-frequency) level is the parity of the sum; noise content, so it is simply left out */
+      const bool hidden = c.sdh && !cu_bypass && firstP-lastP > 3;
+      for (int k=0;k<nc-(hidden?1:0);k++) cab.write_CABAC_bypass(lev[k]<0);
+      int rice = 0;
+      for (int k=0;k<nc;k++) {
+        const int a = abs(lev[k]);
+        int base; bool more;
+        if (k<8) {
+          if (a==1) { base = 1; more = false; }
+          else if (k==firstG1) { base = a>2 ? 3 : 2; more = a>2; }
+          else { base = 2; more = true; }
+        } else { base = 1; more = true; }
+        if (!more) continue;
+        code_abs_remaining(a-base, rice);
+        if (a > 3*(1<<rice)) rice = std::min(rice+1, 4);
+      }
+    }
+  }
+
+  /* slice.cc:2140-2240: sig_coeff_flag context increment */
+  static int sig_ctx(int xC, int yC, int log2, int cIdx, int scanIdx, int prevCsbf)
+  {
+    static const uint8_t map4[16] = {0,1,4,5, 2,3,4,5, 6,6,8,8, 7,7,8,8};
+    int sigCtx;
+    const int sbW = 1<<(log2-2);
+    if (sbW==1) sigCtx = map4[(yC<<2)+xC];
+    else if (xC+yC==0) sigCtx = 0;
+    else {
+      const int xS = xC>>2, yS = yC>>2, xP = xC&3, yP = yC&3;
+      switch (prevCsbf) {
+      case 0: sigCtx = (xP+yP>=3) ? 0 : (xP+yP>0) ? 1 : 2; break;
+      case 1: sigCtx = (yP==0) ? 2 : (yP==1) ? 1 : 0; break;
+      case 2: sigCtx = (xP==0) ? 2 : (xP==1) ? 1 : 0; break;
+      default: sigCtx = 2;
+      }
+      if (cIdx==0) { if (xS+yS>0) sigCtx += 3; sigCtx += sbW==2 ? (scanIdx==0 ? 9 : 15) : 21; }
+      else sigCtx += sbW==2 ? 9 : 12;
+    }
+    return cIdx==0 ? sigCtx : 27+sigCtx;
+  }
+
+  /* ---------- pictures ---------- */
+  bool pic_tmvp = false, pic_col_from_l0 = true; int pic_col_idx = 0;
+
+  void write_picture(const std::vector<PicPlan>& plan, size_t k)
+  {
+    const PicPlan& p = plan[k];
+    /* reference picture set: what this picture uses + what later pictures still need (8.3.2) */
+    std::vector<int> keep;
+    for (int poc : dpbs.dpb) {
+      bool need = std::find(p.refs.begin(),p.refs.end(),poc) != p.refs.end();
+      for (size_t j=k+1;j<plan.size() && !need;j++) need = std::find(plan[j].refs.begin(),plan[j].refs.end(),poc) != plan[j].refs.end();
+      if (need && !p.idr) keep.push_back(poc);
+    }
+    std::vector<int> neg, pos;
+    for (int poc : keep) (poc < p.poc ? neg : pos).push_back(poc);
+    std::sort(neg.begin(),neg.end(),[](int a,int b){return a>b;}); std::sort(pos.begin(),pos.end());
+    std::vector<bool> nu, pu;
+    for (int poc : neg) nu.push_back(std::find(p.refs.begin(),p.refs.end(),poc) != p.refs.end());
+    for (int poc : pos) pu.push_back(std::find(p.refs.begin(),p.refs.end(),poc) != p.refs.end());
+    dpbs.dpb = keep; dpbs.dpb.push_back(p.poc);
+
+    std::fill(ct_depth.begin(),ct_depth.end(),0); std::fill(skipf.begin(),skipf.end(),0); std::fill(pmode.begin(),pmode.end(),PM_NONE);
+    std::fill(pcmf.begin(),pcmf.end(),0); std::fill(ipm.begin(),ipm.end(),1); std::fill(ctb_slice.begin(),ctb_slice.end(),-1);
+
+    pic_tmvp = c.tmvp && p.type != SLICE_TYPE_I && rng.pct(75);
+    pic_col_from_l0 = true; pic_col_idx = 0;                  /* idx 0 of L0 in every slice: the same picture whatever n_l0 is (no list modification then) */
+    if (c.lists_mod) pic_tmvp = false;
+
+    const int nal_type = p.idr ? NAL_UNIT_IDR_W_RADL : NAL_UNIT_TRAIL_R;
+    const int ns = std::max(1, std::min(c.slices, nCtb));
+    std::vector<int> start(ns);
+    for (int s=0;s<ns;s++) start[s] = s==0 ? 0 : std::max(start[s-1]+1, std::min(nCtb-(ns-s), s*nCtb/ns + rng.range(-2,2)));
+    for (int s=0;s<ns;s++) {
+      const int end = s+1<ns ? start[s+1] : nCtb;
+      int type = p.type;
+      if (type != SLICE_TYPE_I && ns>1 && rng.pct(15)) type = SLICE_TYPE_I;      /* an intra slice inside an inter picture */
+      if (type == SLICE_TYPE_B && ns>1 && rng.pct(20)) type = SLICE_TYPE_P;
+      nal_begin(nal_type);
+      write_slice_header(p, neg, pos, nu, pu, s, start[s], type, nal_type);
+      for (int a=start[s]; a<end; a++) {
+        const int cx = a % ctbW, cy = a / ctbW;
+        ctb_slice[a] = start[s];
+        if (S.sao_luma || S.sao_chroma) code_sao(cx,cy);
+        code_quadtree(cx<<c.log2ctb, cy<<c.log2ctb, c.log2ctb, 0);
+        cab.write_CABAC_term_bit(a==end-1);                   /* end_of_slice_segment_flag */
+      }
+      cab.flush_CABAC(); cab.add_trailing_bits(); cab.flush_VLC();
+      nal_end();
+    }
+    /* what the decoder must find in this picture if it stayed in sync with every bin (tools/f2_check.py) */
+    fprintf(fchk, "pic %zu poc %d cus %ld pus %ld pcms %ld resid %ld coeffs %ld abs_sum %ld\n", k, p.poc, st.n_cus, st.n_pus, st.n_pcms, st.n_resid, st.n_coeffs, st.abs_sum);
+    st = Stats();
+  }
+
+  void run()
+  {
+    fout = fopen(c.out.c_str(), "wb");
+    if (!fout) die("cannot open output");
+    fchk = fopen((c.out + ".chk").c_str(), "w");
+    if (!fchk) die("cannot open .chk output");
+    init_scan_orders();
+    write_parameter_sets();
+    ct_depth.assign(W4*H4,0); skipf = pmode = pcmf = ipm = ct_depth; ctb_slice.assign(nCtb,-1);
+    const std::vector<PicPlan> plan = plan_gop(c);
+    for (size_t k=0;k<plan.size();k++) write_picture(plan, k);
+    fclose(fout); fclose(fchk);
+  }
+};
+
+} // namespace
+
+int main(int argc, char** argv)
+{
+  Cfg c;
+  for (int i=1;i<argc;i++) {
+    const char* eq = strchr(argv[i], '=');
+    if (!eq) die("arguments are key=value");
+    const std::string k(argv[i], eq-argv[i]), v(eq+1);
+    if (k=="out") { c.out = v; continue; }
+    if (k=="gop") { c.gop = v; continue; }
+    bool ok = false;
+    for (const Kv& kv : KV) if (k==kv.k) { c.*(kv.p) = atoi(v.c_str()); ok = true; }
+    if (!ok) { fprintf(stderr, "f2_writer: unknown key %s\n", k.c_str()); return 2; }
+  }
+  if (c.w % (1<<c.log2mincb) || c.h % (1<<c.log2mincb)) die("w and h must be multiples of the minimum coding block size");
+  if (c.log2mintb >= c.log2mincb || c.log2maxtb > std::min(5,c.log2ctb) || c.bits < 8 || c.bits > 12) die("inconsistent block sizes / bit depth");
+  Writer w(c);
+  w.run();
+  return 0;
+}
