@@ -144,7 +144,8 @@ bool f1_record_pu(const slice_segment_header* shdr, de265_image*, int xP, int yP
   p.x = (uint16_t)xP; p.y = (uint16_t)yP; p.w = (uint8_t)nPbW; p.h = (uint8_t)nPbH;
   p.pred_flag = (uint8_t)((vi->predFlag[0]?1:0) | (vi->predFlag[1]?2:0));
   p.slice_idx = (uint16_t)shdr->slice_index;
-  for (int l=0;l<2;l++) { p.ref_idx[l] = vi->refIdx[l]; p.mv[l][0] = vi->mv[l].x; p.mv[l][1] = vi->mv[l].y; }
+  for (int l=0;l<2;l++)                                 // libde265 leaves the unused list's refIdx / mv undefined: record zeros
+    if (vi->predFlag[l]) { p.ref_idx[l] = vi->refIdx[l]; p.mv[l][0] = vi->mv[l].x; p.mv[l][1] = vi->mv[l].y; }
   S.pus.push_back(p);
   return hip_mode();
 }
@@ -306,8 +307,9 @@ void f1_picture_done(de265_image* img)
   put(edges.data(), edges.size());
   put_planes(img);                                     // ... and after deblocking + SAO
   const char* dir = getenv("F1_OUT");
+  if (!dir) { S.file.clear(); S.n_pictures++; return; }   // plain CPU decode (f1_dec stream.bin out.yuv): nothing to dump
   char name[1024];
-  snprintf(name, sizeof(name), "%s/pic_%03d.f1", dir ? dir : ".", S.n_pictures++);
+  snprintf(name, sizeof(name), "%s/pic_%03d.f1", dir, S.n_pictures++);
   FILE* f = fopen(name, "wb");
   if (!f || fwrite(S.file.data(), 1, S.file.size(), f) != S.file.size()) { fprintf(stderr, "f1_recorder: cannot write %s\n", name); exit(5); }
   fclose(f);

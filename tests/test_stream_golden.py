@@ -1,5 +1,8 @@
-"""real bitstreams.  tests/golden/stream_*.bin are HEVC streams (the reference's enc265 on seeded
-synthetic YUV, all-intra: the only structure its encoder emits); tests/golden/stream_*.npz hold, per picture, what the
+"""SURVEY.md 8(f1) + 8(f2): real bitstreams.  tests/golden/stream_*.bin are HEVC streams: the reference's enc265 on seeded
+synthetic YUV (all-intra: the only structure its encoder emits) and, as stream_f2_*, the output of the synthetic
+bitstream WRITER oracle/f2_writer.cc (I/P/B pictures with reference picture sets, weighted prediction, PCM, cu_qp_delta,
+AMP, several slices per picture, deblocking overrides, SAO merge ...: tools/make_stream_golden.py lists the settings).
+tests/golden/stream_*.npz hold, per picture in DECODE order, what the
 hooks of the RECORDING reference decoder (oracle/f1_recorder.patch + oracle/f1_recorder.cc, built by `make -C oracle f1`)
 collected at slice.cc:3424 / motion.cc:279 / slice.cc:4185 / decctx.cc:757 -- a de265hip_picture_desc -- and the MD5 of
 libde265's own decoded picture before and after its post-filters.
@@ -27,6 +30,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FIXTURES = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "stream_*.npz")))
 IDS = [os.path.basename(f)[7:-4] for f in FIXTURES]
 F1_DEC = os.path.join(ROOT, "oracle", "_ref", "f1_dec")
+F2_WRITER = os.path.join(ROOT, "oracle", "_ref", "f2_writer")
 
 
 def md5(planes):
@@ -37,18 +41,28 @@ def md5(planes):
 
 
 def test_fixtures_present():
-    assert len(FIXTURES) >= 4 and "720p_intra_q30" in IDS
+    assert len(FIXTURES) >= 8 and "720p_intra_q30" in IDS and "f2_b_10bit_wp_ctb64" in IDS
+
+
+def test_f2_fixtures_hold_inter_pictures_with_real_reference_lists():
+    """the f2 streams exist to bring P/B pictures through the real parser: PUs, both lists, weights, several slices"""
+    pics = f1_stream.load_fixture(os.path.join(ROOT, "tests", "golden", "stream_f2_b_10bit_wp_ctb64.npz"))
+    assert [rp.meta["poc"] for rp, _ in pics] == [0, 4, 2, 1, 3]                 # decode order of a hierarchical GOP
+    assert all(rp.meta["n_pus"] > 0 for rp, _ in pics[1:]) and all(rp.meta["n_slices"] == 2 for rp, _ in pics)
+    assert {rp.to_desc().slices[0].slice_type for rp, _ in pics} >= {0, 2}       # B and I slices
 
 
 @pytest.mark.parametrize("fx", FIXTURES, ids=IDS)
 def test_oracle_replays_recorded_stream_pictures(fx):
+    dpb = {}                                                     # libde265's own DPB index -> decoded picture
     for i, (rp, dg) in enumerate(f1_stream.load_fixture(fx)):
         P = rp.params
         d = rp.to_desc()
         for stage, key in ((_abi.STAGE_PREFILTER, "prefilter"), (_abi.STAGE_FINAL, "final")):
             out = pyoracle.alloc_planes(P.width, P.height, P.bit_depth_luma)
-            pyoracle.reconstruct(d, None, {}, out, stage)
+            pyoracle.reconstruct(d, None, dpb, out, stage)
             assert md5(out) == dg[key], "%s picture %d: %s differs from libde265's decoder" % (os.path.basename(fx), i, key)
+        dpb[rp.meta["dst_slot"]] = out
 
 
 @pytest.mark.parametrize("fx", FIXTURES, ids=IDS)
@@ -90,7 +104,8 @@ def test_gpu_replays_recorded_stream_pictures_through_the_recorder_api(fx):
             sf = rp.a["scaling"] if rp.a["scaling"].size else None
             rec = backend.Recorder(P, sf)
             rec.record_desc(d)                                   # record_slice / _ctb / _tu / _pu / _pcm / _blk_planes one by one
-            slot = rp.meta["dst_slot"] % _abi.MAX_DPB_SLOTS
+            slot = rp.meta["dst_slot"]                           # reference lists name libde265's DPB indices: keep them
+            assert slot < _abi.MAX_DPB_SLOTS
             dec.dpb_alloc(slot, P.width, P.height, P.bit_depth_luma)
             pic = rec.submit(dec, slot)
             try:
@@ -128,7 +143,8 @@ def test_libde265_decodes_the_bitstream_with_the_hip_back_end(fx):
         assert r.stdout.split()[0] == str(len(fixture)), r.stdout
         data = open(out, "rb").read()
     off = 0
-    for i, (rp, dg) in enumerate(fixture):                 # all-intra streams: output order == decode order
+    fixture = sorted(fixture, key=lambda e: e[0].meta["poc"])     # fixtures are in decode order, the decoder outputs by POC
+    for i, (rp, dg) in enumerate(fixture):
         P = rp.params
         bpp = 2 if P.bit_depth_luma > 8 else 1
         n = (P.width * P.height + 2 * (P.width // 2) * (P.height // 2)) * bpp
@@ -136,3 +152,41 @@ def test_libde265_decodes_the_bitstream_with_the_hip_back_end(fx):
         off += n
         assert m == dg["final"], "%s picture %d: the HIP-backed decoder's output differs from the CPU decoder's" % (os.path.basename(fx), i)
     assert off == len(data)
+
+
+# SURVEY 8(d) picture formats at FULL size, from real bitstreams written on the spot (too large to commit as fixtures):
+# config 2's format (1080p 8-bit, inter) and the north-star format (3840x2160 10-bit, inter)
+FULL_SIZE = [
+    ("1080p8_B_wp_2slices", "gop=B pics=5 w=1920 h=1080 log2ctb=6 slices=2 wp=1 seed=11"),
+    ("1080p8_LDB_ctb16_3refs", "gop=LDB pics=4 w=1920 h=1080 log2ctb=4 log2maxtb=4 nref=3 slices=5 sdh=1 tskip=1 seed=12"),
+    ("4k10_B", "gop=B pics=4 w=3840 h=2160 bits=10 log2ctb=6 seed=13"),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (os.path.exists(F1_DEC) and os.path.exists(F2_WRITER)), reason="f1_dec / f2_writer (make -C oracle f1 f2) did not travel")
+@pytest.mark.parametrize("name,args", FULL_SIZE, ids=[n for n, _ in FULL_SIZE])
+def test_full_size_synthetic_streams_decode_identically_with_the_hip_back_end(name, args):
+    """SURVEY 8(f1)+8(f2) at BASELINE.json's picture sizes: f2_writer writes an inter stream, the reference decodes it on
+    the CPU (its scalar path) and again with every reconstruction call offloaded to the MI355X (F1_MODE=hip); the two
+    output files must be byte-identical."""
+    from libde265_amd import backend
+    assert backend.device_count() > 0
+    with tempfile.TemporaryDirectory() as td:
+        bits, cpu, hip = (os.path.join(td, f) for f in ("s.bin", "cpu.yuv", "hip.yuv"))
+        subprocess.check_call([F2_WRITER, "out=" + bits] + args.split())
+        env = {k: v for k, v in os.environ.items() if k not in ("F1_OUT", "F1_MODE")}
+        r = subprocess.run([F1_DEC, bits, cpu], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and not r.stderr.strip(), r.stderr[-2000:]
+        n = int(r.stdout.split()[0])
+        assert n == int(dict(a.split("=") for a in args.split())["pics"])
+        r = subprocess.run([F1_DEC, bits, hip], env=dict(env, F1_MODE="hip", F1_HIP_LIB=backend.SO_PATH), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and not r.stderr.strip(), r.stderr[-2000:]
+        assert int(r.stdout.split()[0]) == n
+        a, b = open(cpu, "rb").read(), open(hip, "rb").read()
+        assert len(a) == len(b) and len(a) > 0
+        if a != b:
+            A, B = np.frombuffer(a, np.uint8), np.frombuffer(b, np.uint8)
+            first = int(np.nonzero(A != B)[0][0])
+            raise AssertionError("%s: HIP-backed decode differs from the CPU decode: %d bytes, first at offset %d of %d (picture %d)"
+                                 % (name, int((A != B).sum()), first, len(a), first // (len(a) // n)))

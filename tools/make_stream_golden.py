@@ -7,7 +7,7 @@ which dumps per picture the de265hip_picture_desc the product consumes and libde
   tests/golden/stream_<name>.bin     the bitstream (an output of the reference's tools on synthetic input)
   tests/golden/stream_<name>.npz     the recorded descs + MD5 of libde265's picture before / after its post-filters
 
-    make -C oracle f1 && python tools/make_stream_golden.py
+    make -C oracle f1 f2 && python tools/make_stream_golden.py
 """
 import hashlib
 import os
@@ -36,6 +36,17 @@ STREAMS = [
 ]
 
 
+# streams of the synthetic bitstream WRITER (oracle/f2_writer.cc, `make -C oracle f2`): the inter, weighted,
+# PCM, cu_qp_delta, AMP, multi-slice, deblocking-override and SAO-merge syntax the reference's own encoder cannot emit.
+F2_STREAMS = [
+    dict(name="f2_p_ctb32", args="gop=P pics=4 w=192 h=128 seed=1"),
+    dict(name="f2_b_10bit_wp_ctb64", args="gop=B pics=5 w=256 h=144 log2ctb=6 bits=10 wp=1 slices=2 seed=2"),
+    dict(name="f2_ldb_slices_ctb16", args="gop=LDB pics=4 w=176 h=144 log2ctb=4 log2maxtb=4 slices=4 lists_mod=1 sdh=1 tskip=1 "
+                                          "tqbypass=1 cip=1 nref=3 seed=3"),
+    dict(name="f2_i_10bit_pcm7", args="gop=I pics=2 w=200 h=136 log2ctb=6 bits=10 pcm_bits=7 pcm_lf_off=1 seed=4"),
+]
+
+
 def synth_yuv(w, h, n, seed, noise):
     """luma sin(x/23)*cos(y/31)*A + 128 + noise, seeded; chroma smooth + noise."""
     rng = np.random.default_rng(seed)
@@ -61,7 +72,8 @@ def md5(planes):
 
 def record(bitstream, outdir):
     env = dict(os.environ, F1_OUT=outdir)
-    subprocess.check_call([os.path.join(REFDIR, "f1_dec"), bitstream], env=env, stdout=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(REFDIR, "f1_dec"), bitstream], env=env, capture_output=True, text=True)
+    assert r.returncode == 0 and not r.stderr.strip(), r.stderr
     pics = []
     for fn in sorted(os.listdir(outdir)):
         rp, pre, fin = f1_stream.load_dump(os.path.join(outdir, fn))
@@ -83,6 +95,16 @@ def main():
             assert len(pics) == st["frames"], (st["name"], len(pics))
             f1_stream.save_fixture(os.path.join(GOLD, "stream_%s.npz" % st["name"]), pics)
             print(st["name"], "bitstream %d B," % os.path.getsize(bits), len(pics), "pictures,",
+                  sum(rp.meta["n_tus"] for rp, _ in pics), "TUs,", sum(rp.meta["n_coeffs"] for rp, _ in pics), "coefficients; fixture",
+                  os.path.getsize(os.path.join(GOLD, "stream_%s.npz" % st["name"])), "B")
+    for st in F2_STREAMS:
+        with tempfile.TemporaryDirectory() as td:
+            bits = os.path.join(GOLD, "stream_%s.bin" % st["name"])
+            subprocess.check_call([os.path.join(REFDIR, "f2_writer"), "out=" + bits] + st["args"].split())
+            os.remove(bits + ".chk")
+            pics = record(bits, td)
+            f1_stream.save_fixture(os.path.join(GOLD, "stream_%s.npz" % st["name"]), pics)
+            print(st["name"], "bitstream %d B," % os.path.getsize(bits), len(pics), "pictures,", sum(rp.meta["n_pus"] for rp, _ in pics), "PUs,",
                   sum(rp.meta["n_tus"] for rp, _ in pics), "TUs,", sum(rp.meta["n_coeffs"] for rp, _ in pics), "coefficients; fixture",
                   os.path.getsize(os.path.join(GOLD, "stream_%s.npz" % st["name"])), "B")
     shutil.rmtree(os.path.join(GOLD, "__pycache__"), ignore_errors=True)
