@@ -21,6 +21,8 @@
  *   f2_writer out=stream.bin w=416 h=240 pics=6 gop=B seed=1 [key=value ...]      (keys: see struct Cfg)
  */
 #include "libde265/cabac.h"
+#include "libde265/de265.h"
+#include "libde265/md5.h"
 #include "libde265/contextmodel.h"
 #include "libde265/decctx.h"
 #include "libde265/nal.h"
@@ -51,6 +53,7 @@ struct Cfg {
   int wp = 0, sdh = 0, tskip = 0, tqbypass = 0;
   int deblock = 1, lf_slices = 1, cabac_init = 1, lists_mod = 0, merge_cand = 5, par_mrg = 2;
   int nref = 2, max_level = 24, big_mv = 1;
+  int wpp = 0, tile_cols = 1, tile_rows = 1, tile_uniform = 1, lf_tiles = 1, md5 = 1;
   int dens = 50;                      /* percent: how often cbf flags are set */
 };
 
@@ -64,7 +67,8 @@ const Kv KV[] = {
   {"slice_cqp",&Cfg::slice_cqp},{"wp",&Cfg::wp},{"sdh",&Cfg::sdh},{"tskip",&Cfg::tskip},{"tqbypass",&Cfg::tqbypass},
   {"deblock",&Cfg::deblock},{"lf_slices",&Cfg::lf_slices},{"cabac_init",&Cfg::cabac_init},{"lists_mod",&Cfg::lists_mod},
   {"merge_cand",&Cfg::merge_cand},{"par_mrg",&Cfg::par_mrg},{"nref",&Cfg::nref},{"max_level",&Cfg::max_level},
-  {"big_mv",&Cfg::big_mv},{"dens",&Cfg::dens},
+  {"big_mv",&Cfg::big_mv},{"dens",&Cfg::dens},{"wpp",&Cfg::wpp},{"tile_cols",&Cfg::tile_cols},{"tile_rows",&Cfg::tile_rows},
+  {"tile_uniform",&Cfg::tile_uniform},{"lf_tiles",&Cfg::lf_tiles},{"md5",&Cfg::md5},
 };
 
 [[noreturn]] void die(const char* msg) { fprintf(stderr, "f2_writer: %s\n", msg); exit(2); }
@@ -116,16 +120,18 @@ std::vector<PicPlan> plan_gop(const Cfg& c)
 enum { PM_NONE=0, PM_INTRA=1, PM_INTER=2, PM_SKIP=3 };
 
 struct SliceCtx {
-  int type, addr /*SliceAddrRS*/, qp, n_l0, n_l1, max_merge, mvd_l1_zero;
+  int type, addr /*SliceAddrRS*/, qp, n_l0, n_l1, max_merge, mvd_l1_zero, init_type;
   bool sao_luma, sao_chroma;
 };
 
 struct Writer {
   Cfg c;
   Rng rng;
-  FILE* fout;
-  CABAC_encoder_bitstream cab;
+  CABAC_encoder_bitstream hdr;                                  /* NAL header, parameter sets, slice segment headers */
+  CABAC_encoder_bitstream cab;                                  /* slice segment data */
   context_model_table models;
+  struct Nal { std::vector<uint8_t> bytes; int pic; };          /* without start code; pic: index in decode order, -1 for parameter sets */
+  std::vector<Nal> nals;
   error_queue errq;
   std::shared_ptr<video_parameter_set> vps;
   std::shared_ptr<seq_parameter_set> sps;
@@ -143,10 +149,13 @@ struct Writer {
   explicit Writer(const Cfg& cfg) : c(cfg), rng(cfg.seed) {}
 
   /* ---------- NAL plumbing: one CABAC_encoder_bitstream per NAL (it inserts the emulation prevention bytes) ---------- */
-  void nal_begin(int type) { cab.reset(); cab.write_bits(0,1); cab.write_bits(type,6); cab.write_bits(0,6); cab.write_bits(1,3); }
-  void nal_end() {
-    static const uint8_t sc[4] = {0,0,0,1};
-    fwrite(sc,1,4,fout); fwrite(cab.data(),1,cab.size(),fout);
+  void nal_begin(int type) { hdr.reset(); hdr.write_bits(0,1); hdr.write_bits(type,6); hdr.write_bits(0,6); hdr.write_bits(1,3); }
+  void nal_end(int pic, bool with_data) {
+    Nal n; n.pic = pic;
+    n.bytes.assign(hdr.data(), hdr.data()+hdr.size());
+    /* the slice segment header ends in a non-zero byte (byte_alignment()), so the emulation prevention of the data does not depend on it */
+    if (with_data) n.bytes.insert(n.bytes.end(), cab.data(), cab.data()+cab.size());
+    nals.push_back(n);
   }
 
   /* ---------- parameter sets (vps.cc/sps.cc/pps.cc write()) ---------- */
@@ -190,14 +199,27 @@ struct Writer {
     pps->pic_disable_deblocking_filter_flag = c.deblock ? 0 : 1;
     pps->beta_offset = c.deblock ? 2*rng.range(-3,3) : 0; pps->tc_offset = c.deblock ? 2*rng.range(-3,3) : 0;
     pps->lists_modification_present_flag = c.lists_mod; pps->log2_parallel_merge_level = c.par_mrg;
-    pps->set_derived_values(sps.get());
-
-    nal_begin(NAL_UNIT_VPS_NUT); vps->write(&errq, cab); cab.add_trailing_bits(); cab.flush_VLC(); nal_end();
-    nal_begin(NAL_UNIT_SPS_NUT); sps->write(&errq, cab); cab.add_trailing_bits(); cab.flush_VLC(); nal_end();
-    nal_begin(NAL_UNIT_PPS_NUT); pps->write(&errq, cab, sps.get()); cab.add_trailing_bits(); cab.flush_VLC(); nal_end();
-
+    pps->entropy_coding_sync_enabled_flag = c.wpp;
     W4 = (c.w+3)/4; H4 = (c.h+3)/4;
     ctbW = (c.w + (1<<c.log2ctb) - 1) >> c.log2ctb; ctbH = (c.h + (1<<c.log2ctb) - 1) >> c.log2ctb; nCtb = ctbW*ctbH;
+    if (c.tile_cols > 1 || c.tile_rows > 1) {
+      if (c.tile_cols > ctbW || c.tile_rows > ctbH || c.tile_cols > DE265_MAX_TILE_COLUMNS || c.tile_rows > DE265_MAX_TILE_ROWS) die("more tiles than CTBs");
+      pps->tiles_enabled_flag = 1; pps->num_tile_columns = c.tile_cols; pps->num_tile_rows = c.tile_rows;
+      pps->uniform_spacing_flag = c.tile_uniform; pps->loop_filter_across_tiles_enabled_flag = c.lf_tiles;
+      if (!c.tile_uniform) {                                        /* random boundaries, every tile at least one CTB */
+        for (int d=0; d<2; d++) {
+          const int n = d ? c.tile_rows : c.tile_cols, tot = d ? ctbH : ctbW;
+          int left = tot;
+          for (int i=0;i<n;i++) { const int sz = i==n-1 ? left : rng.range(1, left-(n-1-i)); (d ? pps->rowHeight : pps->colWidth)[i] = sz; left -= sz; }
+        }
+      }
+    }
+    pps->set_derived_values(sps.get());
+
+    nal_begin(NAL_UNIT_VPS_NUT); vps->write(&errq, hdr); hdr.add_trailing_bits(); hdr.flush_VLC(); nal_end(-1,false);
+    nal_begin(NAL_UNIT_SPS_NUT); sps->write(&errq, hdr); hdr.add_trailing_bits(); hdr.flush_VLC(); nal_end(-1,false);
+    nal_begin(NAL_UNIT_PPS_NUT); pps->write(&errq, hdr, sps.get()); hdr.add_trailing_bits(); hdr.flush_VLC(); nal_end(-1,false);
+
   }
 
   /* ---------- block state ---------- */
@@ -209,7 +231,7 @@ struct Writer {
   bool available(int xC, int yC, int xN, int yN) const {
     if (xN<0 || yN<0 || xN>=c.w || yN>=c.h) return false;
     const int cur = (xC>>c.log2ctb) + (yC>>c.log2ctb)*ctbW, nb = (xN>>c.log2ctb) + (yN>>c.log2ctb)*ctbW;
-    return ctb_slice[nb] == ctb_slice[cur];
+    return ctb_slice[nb] == ctb_slice[cur] && pps->TileIdRS[nb] == pps->TileIdRS[cur];
   }
 
   /* ---------- slice header (slice.cc:352 slice_segment_header::read, refpic.cc:85, slice.cc:215 read_pred_weight_table) ---------- */
@@ -221,81 +243,101 @@ struct Writer {
                           int slice_idx, int addr, int slice_type, int nal_type)
   {
     const int n_curr = (int)std::count(neg_used.begin(),neg_used.end(),true) + (int)std::count(pos_used.begin(),pos_used.end(),true);
-    cab.write_bit(slice_idx==0);                                    /* first_slice_segment_in_pic_flag */
-    if (nal_type >= 16 && nal_type <= 23) cab.write_bit(0);         /* no_output_of_prior_pics_flag */
-    cab.write_uvlc(0);                                              /* slice_pic_parameter_set_id */
-    if (slice_idx) { int nb = 0; while ((1<<nb) < nCtb) nb++; cab.write_bits(addr, nb); }
-    cab.write_uvlc(slice_type);
+    hdr.write_bit(slice_idx==0);                                    /* first_slice_segment_in_pic_flag */
+    if (nal_type >= 16 && nal_type <= 23) hdr.write_bit(0);         /* no_output_of_prior_pics_flag */
+    hdr.write_uvlc(0);                                              /* slice_pic_parameter_set_id */
+    if (slice_idx) { int nb = 0; while ((1<<nb) < nCtb) nb++; hdr.write_bits(addr, nb); }
+    hdr.write_uvlc(slice_type);
     bool tmvp = false;
     if (!p.idr) {
-      cab.write_bits(p.poc & 255, 8);                               /* slice_pic_order_cnt_lsb, log2_max_poc_lsb = 8 */
-      cab.write_bit(0);                                             /* short_term_ref_pic_set_sps_flag: explicit set, no prediction (idx 0) */
-      cab.write_uvlc((int)neg.size()); cab.write_uvlc((int)pos.size());
+      hdr.write_bits(p.poc & 255, 8);                               /* slice_pic_order_cnt_lsb, log2_max_poc_lsb = 8 */
+      hdr.write_bit(0);                                             /* short_term_ref_pic_set_sps_flag: explicit set, no prediction (idx 0) */
+      hdr.write_uvlc((int)neg.size()); hdr.write_uvlc((int)pos.size());
       int last = p.poc;
-      for (size_t i=0;i<neg.size();i++) { cab.write_uvlc(last-neg[i]-1); cab.write_bit(neg_used[i]); last = neg[i]; }
+      for (size_t i=0;i<neg.size();i++) { hdr.write_uvlc(last-neg[i]-1); hdr.write_bit(neg_used[i]); last = neg[i]; }
       last = p.poc;
-      for (size_t i=0;i<pos.size();i++) { cab.write_uvlc(pos[i]-last-1); cab.write_bit(pos_used[i]); last = pos[i]; }
-      if (c.tmvp) { tmvp = pic_tmvp; cab.write_bit(tmvp); }
+      for (size_t i=0;i<pos.size();i++) { hdr.write_uvlc(pos[i]-last-1); hdr.write_bit(pos_used[i]); last = pos[i]; }
+      if (c.tmvp) { tmvp = pic_tmvp; hdr.write_bit(tmvp); }
     }
     S.sao_luma = S.sao_chroma = false;
-    if (c.sao) { S.sao_luma = rng.pct(80); S.sao_chroma = rng.pct(70); cab.write_bit(S.sao_luma); cab.write_bit(S.sao_chroma); }
+    if (c.sao) { S.sao_luma = rng.pct(80); S.sao_chroma = rng.pct(70); hdr.write_bit(S.sao_luma); hdr.write_bit(S.sao_chroma); }
     S.n_l0 = S.n_l1 = 0; S.max_merge = 5; S.mvd_l1_zero = 0;
     int cabac_init_flag = 0;
     if (slice_type != SLICE_TYPE_I) {
       S.n_l0 = rng.range(1, std::min(4, n_curr+1)); S.n_l1 = slice_type==SLICE_TYPE_B ? rng.range(1, std::min(3, n_curr+1)) : 0;
       if (tmvp) { S.n_l0 = std::max(S.n_l0, pic_col_idx+1); if (slice_type==SLICE_TYPE_B) S.n_l1 = std::max(S.n_l1, pic_col_idx+1); }
       const bool ovr = S.n_l0 != 1 || (slice_type==SLICE_TYPE_B && S.n_l1 != 1) || rng.pct(20);
-      cab.write_bit(ovr);
-      if (ovr) { cab.write_uvlc(S.n_l0-1); if (slice_type==SLICE_TYPE_B) cab.write_uvlc(S.n_l1-1); }
+      hdr.write_bit(ovr);
+      if (ovr) { hdr.write_uvlc(S.n_l0-1); if (slice_type==SLICE_TYPE_B) hdr.write_uvlc(S.n_l1-1); }
       if (c.lists_mod && n_curr > 1) {
         int nb = 0; while ((1<<nb) < n_curr) nb++;
         for (int l=0; l<(slice_type==SLICE_TYPE_B ? 2 : 1); l++) {
-          const bool m = rng.pct(50); cab.write_bit(m);
-          if (m) for (int i=0;i<(l?S.n_l1:S.n_l0);i++) cab.write_bits(rng.below(n_curr), nb);
+          const bool m = rng.pct(50); hdr.write_bit(m);
+          if (m) for (int i=0;i<(l?S.n_l1:S.n_l0);i++) hdr.write_bits(rng.below(n_curr), nb);
         }
       }
-      if (slice_type==SLICE_TYPE_B) { S.mvd_l1_zero = rng.pct(25); cab.write_bit(S.mvd_l1_zero); }
-      if (c.cabac_init) { cabac_init_flag = rng.pct(50); cab.write_bit(cabac_init_flag); }
+      if (slice_type==SLICE_TYPE_B) { S.mvd_l1_zero = rng.pct(25); hdr.write_bit(S.mvd_l1_zero); }
+      if (c.cabac_init) { cabac_init_flag = rng.pct(50); hdr.write_bit(cabac_init_flag); }
       if (tmvp) {
         /* one collocated picture per picture (7.4.7.1): with lists_mod the same POC cannot be guaranteed -> idx 0 of L0 only then */
         bool from_l0 = true;
-        if (slice_type==SLICE_TYPE_B) { from_l0 = pic_col_from_l0; cab.write_bit(from_l0); }
-        if ((from_l0 && S.n_l0>1) || (!from_l0 && S.n_l1>1)) cab.write_uvlc(pic_col_idx);
+        if (slice_type==SLICE_TYPE_B) { from_l0 = pic_col_from_l0; hdr.write_bit(from_l0); }
+        if ((from_l0 && S.n_l0>1) || (!from_l0 && S.n_l1>1)) hdr.write_uvlc(pic_col_idx);
       }
       if (c.wp) write_pred_weight_table(slice_type);
       S.max_merge = c.merge_cand > 0 ? c.merge_cand : rng.range(1,5);
-      cab.write_uvlc(5 - S.max_merge);
+      hdr.write_uvlc(5 - S.max_merge);
     }
     const int qpd = rng.range(-4,4);
-    S.qp = c.qp + qpd; cab.write_svlc(qpd);
-    if (c.slice_cqp) { cab.write_svlc(rng.range(-3,3)); cab.write_svlc(rng.range(-3,3)); }
+    S.qp = c.qp + qpd; hdr.write_svlc(qpd);
+    if (c.slice_cqp) { hdr.write_svlc(rng.range(-3,3)); hdr.write_svlc(rng.range(-3,3)); }
     bool dbk_off = !c.deblock;
     if (c.deblock) {
-      const bool ovr = rng.pct(50); cab.write_bit(ovr);
-      if (ovr) { dbk_off = rng.pct(20); cab.write_bit(dbk_off); if (!dbk_off) { cab.write_svlc(rng.range(-4,4)); cab.write_svlc(rng.range(-4,4)); } }
+      const bool ovr = rng.pct(50); hdr.write_bit(ovr);
+      if (ovr) { dbk_off = rng.pct(20); hdr.write_bit(dbk_off); if (!dbk_off) { hdr.write_svlc(rng.range(-4,4)); hdr.write_svlc(rng.range(-4,4)); } }
     }
-    if (c.lf_slices && (S.sao_luma || S.sao_chroma || !dbk_off)) cab.write_bit(rng.pct(60));   /* slice_loop_filter_across_slices_enabled_flag */
-    cab.add_trailing_bits(); cab.flush_VLC();                       /* byte_alignment() */
-
+    if (c.lf_slices && (S.sao_luma || S.sao_chroma || !dbk_off)) hdr.write_bit(rng.pct(60));   /* slice_loop_filter_across_slices_enabled_flag */
+    /* entry points and byte_alignment() follow once the data is coded: finish_slice_header() */
     S.type = slice_type; S.addr = addr;
-    const int initType = slice_type==SLICE_TYPE_I ? 0 : slice_type==SLICE_TYPE_P ? (cabac_init_flag ? 2 : 1) : (cabac_init_flag ? 1 : 2);
-    models.init(initType, S.qp);
+    S.init_type = slice_type==SLICE_TYPE_I ? 0 : slice_type==SLICE_TYPE_P ? (cabac_init_flag ? 2 : 1) : (cabac_init_flag ? 1 : 2);
+    models.init(S.init_type, S.qp);
+    cab.reset();
     cab.set_context_models(&models);
     cab.init_CABAC();
   }
 
+  /* slice.cc:660-700: entry_point_offset_minus1[] = bytes of every substream but the last, emulation prevention bytes included */
+  void finish_slice_header(const std::vector<int>& sub_end)
+  {
+    if (c.wpp || pps->tiles_enabled_flag) {
+      const int n = (int)sub_end.size()-1;
+      hdr.write_uvlc(n);
+      if (n > 0) {
+        int mx = 0;
+        for (int i=0;i<n;i++) mx = std::max(mx, sub_end[i]-(i?sub_end[i-1]:0)-1);
+        int len = 1; while ((mx >> len) != 0) len++;
+        hdr.write_uvlc(len-1);
+        for (int i=0;i<n;i++) {
+          const uint32_t v = (uint32_t)(sub_end[i]-(i?sub_end[i-1]:0)-1);
+          if (len > 16) { hdr.write_bits(v >> 16, len-16); hdr.write_bits(v & 0xFFFF, 16); } else hdr.write_bits(v, len);
+        }
+      }
+    }
+    hdr.add_trailing_bits(); hdr.flush_VLC();                       /* byte_alignment() */
+  }
+
   void write_pred_weight_table(int slice_type)
   {
-    const int ld = rng.range(0,7); cab.write_uvlc(ld);
-    const int dc = rng.range(std::max(-ld,-2), std::min(7-ld,2)); cab.write_svlc(dc);       /* delta_chroma_log2_weight_denom */
+    const int ld = rng.range(0,7); hdr.write_uvlc(ld);
+    const int dc = rng.range(std::max(-ld,-2), std::min(7-ld,2)); hdr.write_svlc(dc);       /* delta_chroma_log2_weight_denom */
     for (int l=0; l<(slice_type==SLICE_TYPE_B ? 2 : 1); l++) {
       const int n = l ? S.n_l1 : S.n_l0;
       std::vector<int> lf(n), cf(n);
-      for (int i=0;i<n;i++) { lf[i] = rng.pct(60); cab.write_bit(lf[i]); }
-      for (int i=0;i<n;i++) { cf[i] = rng.pct(50); cab.write_bit(cf[i]); }
+      for (int i=0;i<n;i++) { lf[i] = rng.pct(60); hdr.write_bit(lf[i]); }
+      for (int i=0;i<n;i++) { cf[i] = rng.pct(50); hdr.write_bit(cf[i]); }
       for (int i=0;i<n;i++) {
-        if (lf[i]) { cab.write_svlc(rng.range(-20,20)); cab.write_svlc(rng.range(-40,40)); }
-        if (cf[i]) for (int j=0;j<2;j++) { cab.write_svlc(rng.range(-20,20)); cab.write_svlc(rng.range(-100,100)); }
+        if (lf[i]) { hdr.write_svlc(rng.range(-20,20)); hdr.write_svlc(rng.range(-40,40)); }
+        if (cf[i]) for (int j=0;j<2;j++) { hdr.write_svlc(rng.range(-20,20)); hdr.write_svlc(rng.range(-100,100)); }
       }
     }
   }
@@ -305,8 +347,8 @@ struct Writer {
   {
     const int addr = xCtb + yCtb*ctbW;
     bool left = false, up = false;
-    if (xCtb>0 && addr > S.addr) { left = rng.pct(20); cab.write_CABAC_bit(CONTEXT_MODEL_SAO_MERGE_FLAG, left); }
-    if (yCtb>0 && !left && addr-ctbW >= S.addr) { up = rng.pct(20); cab.write_CABAC_bit(CONTEXT_MODEL_SAO_MERGE_FLAG, up); }
+    if (xCtb>0 && addr > S.addr && pps->TileIdRS[addr] == pps->TileIdRS[addr-1]) { left = rng.pct(20); cab.write_CABAC_bit(CONTEXT_MODEL_SAO_MERGE_FLAG, left); }
+    if (yCtb>0 && !left && addr-ctbW >= S.addr && pps->TileIdRS[addr] == pps->TileIdRS[addr-ctbW]) { up = rng.pct(20); cab.write_CABAC_bit(CONTEXT_MODEL_SAO_MERGE_FLAG, up); }
     if (left || up) return;
     int type_c = 0;
     for (int cIdx=0;cIdx<3;cIdx++) {
@@ -819,43 +861,123 @@ struct Writer {
     if (c.lists_mod) pic_tmvp = false;
 
     const int nal_type = p.idr ? NAL_UNIT_IDR_W_RADL : NAL_UNIT_TRAIL_R;
-    const int ns = std::max(1, std::min(c.slices, nCtb));
-    std::vector<int> start(ns);
-    for (int s=0;s<ns;s++) start[s] = s==0 ? 0 : std::max(start[s-1]+1, std::min(nCtb-(ns-s), s*nCtb/ns + rng.range(-2,2)));
+    /* slices are runs of CTBs in TILE SCAN; with tiles they start at tile starts, with WPP at CTB row starts (7.4.7.1) */
+    std::vector<int> cand;                                    /* tile-scan addresses a slice may start at */
+    for (int ts=1; ts<nCtb; ts++) {
+      const int rs = pps->CtbAddrTStoRS[ts];
+      if (pps->tiles_enabled_flag) { if (pps->TileId[ts] != pps->TileId[ts-1]) cand.push_back(ts); }
+      else if (!c.wpp || rs % ctbW == 0) cand.push_back(ts);
+    }
+    std::vector<int> start = {0};
+    for (int s=1; s<c.slices && !cand.empty(); s++) { const int k = rng.below((int)cand.size()); start.push_back(cand[k]); cand.erase(cand.begin()+k); }
+    std::sort(start.begin(), start.end());
+    const int ns = (int)start.size();
+    std::vector<context_model_table> wpp_saved(ctbH);
     for (int s=0;s<ns;s++) {
-      const int end = s+1<ns ? start[s+1] : nCtb;
+      const int end = s+1<ns ? start[s+1] : nCtb, addr0 = pps->CtbAddrTStoRS[start[s]];
       int type = p.type;
       if (type != SLICE_TYPE_I && ns>1 && rng.pct(15)) type = SLICE_TYPE_I;      /* an intra slice inside an inter picture */
       if (type == SLICE_TYPE_B && ns>1 && rng.pct(20)) type = SLICE_TYPE_P;
       nal_begin(nal_type);
-      write_slice_header(p, neg, pos, nu, pu, s, start[s], type, nal_type);
-      for (int a=start[s]; a<end; a++) {
-        const int cx = a % ctbW, cy = a / ctbW;
-        ctb_slice[a] = start[s];
+      write_slice_header(p, neg, pos, nu, pu, s, addr0, type, nal_type);
+      std::vector<int> sub_end;
+      for (int ts=start[s]; ts<end; ts++) {
+        const int a = pps->CtbAddrTStoRS[ts], cx = a % ctbW, cy = a / ctbW;
+        if (ts > start[s]) {                                  /* slice.cc:4664-4690 / 5050-5075: what a new substream starts from */
+          if (pps->tiles_enabled_flag && pps->TileId[ts] != pps->TileId[ts-1]) models.init(S.init_type, S.qp);
+          else if (c.wpp && cx == 0) { if (ctbW > 1) models = wpp_saved[cy-1].copy(); else models.init(S.init_type, S.qp); }
+        }
+        ctb_slice[a] = addr0;
         if (S.sao_luma || S.sao_chroma) code_sao(cx,cy);
         code_quadtree(cx<<c.log2ctb, cy<<c.log2ctb, c.log2ctb, 0);
-        cab.write_CABAC_term_bit(a==end-1);                   /* end_of_slice_segment_flag */
+        if (c.wpp && cx == 1) wpp_saved[cy] = models.copy();  /* 9.3.2.2: storage after the second CTB of a row */
+        const bool last = ts == end-1;
+        cab.write_CABAC_term_bit(last);                       /* end_of_slice_segment_flag */
+        if (!last) {
+          const int an = pps->CtbAddrTStoRS[ts+1];
+          const bool sub = (pps->tiles_enabled_flag && pps->TileId[ts+1] != pps->TileId[ts]) || (c.wpp && an / ctbW != cy);
+          if (sub) {                                          /* end_of_subset_one_bit, byte_alignment(), CABAC restart */
+            cab.write_CABAC_term_bit(1);
+            cab.flush_CABAC(); cab.write_bit(1); cab.write_bits(0, cab.number_free_bits_in_byte()); cab.flush_VLC();
+            sub_end.push_back(cab.size());
+            cab.init_CABAC();
+          }
+        }
       }
       cab.flush_CABAC(); cab.add_trailing_bits(); cab.flush_VLC();
-      nal_end();
+      sub_end.push_back(cab.size());
+      finish_slice_header(sub_end);
+      nal_end((int)k, true);
     }
     /* what the decoder must find in this picture if it stayed in sync with every bin (tools/f2_check.py) */
     fprintf(fchk, "pic %zu poc %d cus %ld pus %ld pcms %ld resid %ld coeffs %ld abs_sum %ld\n", k, p.poc, st.n_cus, st.n_pus, st.n_pcms, st.n_resid, st.n_coeffs, st.abs_sum);
     st = Stats();
   }
 
+  /* ---------- decoded picture hash SEI (sei.cc:251-330 checks it): the stream is decoded once with the linked reference ---------- */
+  static void plane_md5(const de265_image* im, int cIdx, uint8_t out[16])
+  {
+    int stride = 0;
+    const uint8_t* p = de265_get_image_plane(im, cIdx, &stride);
+    const int w = de265_get_image_width(im, cIdx), h = de265_get_image_height(im, cIdx), bpp = (de265_get_bits_per_pixel(im, cIdx)+7)/8;
+    MD5_CTX m; MD5_Init(&m);
+    for (int y=0;y<h;y++) MD5_Update(&m, (void*)(p + (size_t)y*stride), (unsigned long)w*bpp);     /* little-endian samples, as sei.cc:131-157 on this host */
+    MD5_Final(out, &m);
+  }
+
+  std::vector<std::vector<uint8_t>> decode_md5s(int n_pics)
+  {
+    std::vector<std::vector<uint8_t>> md5(n_pics);
+    de265_decoder_context* ctx = de265_new_decoder();
+    de265_set_parameter_int(ctx, DE265_DECODER_PARAM_ACCELERATION_CODE, de265_acceleration_SCALAR);
+    auto drain = [&]() {
+      int more = 1;
+      while (more) {
+        de265_error e = de265_decode(ctx, &more);
+        while (const de265_image* im = de265_get_next_picture(ctx)) {
+          const int k = (int)de265_get_image_PTS(im);
+          md5[k].resize(48);
+          for (int cI=0;cI<3;cI++) plane_md5(im, cI, &md5[k][16*cI]);
+        }
+        if (e != DE265_OK) break;
+      }
+    };
+    for (const Nal& n : nals) { de265_push_NAL(ctx, n.bytes.data(), (int)n.bytes.size(), n.pic < 0 ? 0 : n.pic, NULL); drain(); }
+    de265_flush_data(ctx); drain();
+    for (;;) { de265_error w = de265_get_warning(ctx); if (w == DE265_OK) break; fprintf(stderr, "f2_writer: the reference decoder warns: %s\n", de265_get_error_text(w)); }
+    de265_free_decoder(ctx);
+    for (int k=0;k<n_pics;k++) if (md5[k].size() != 48) die("md5 pass: a picture was not output by the reference decoder");
+    return md5;
+  }
+
   void run()
   {
-    fout = fopen(c.out.c_str(), "wb");
-    if (!fout) die("cannot open output");
-    fchk = fopen((c.out + ".chk").c_str(), "w");
-    if (!fchk) die("cannot open .chk output");
     init_scan_orders();
     write_parameter_sets();
     ct_depth.assign(W4*H4,0); skipf = pmode = pcmf = ipm = ct_depth; ctb_slice.assign(nCtb,-1);
+    fchk = fopen((c.out + ".chk").c_str(), "w");
+    if (!fchk) die("cannot open .chk output");
     const std::vector<PicPlan> plan = plan_gop(c);
     for (size_t k=0;k<plan.size();k++) write_picture(plan, k);
-    fclose(fout); fclose(fchk);
+    fclose(fchk);
+
+    std::vector<std::vector<uint8_t>> md5;
+    if (c.md5) md5 = decode_md5s((int)plan.size());
+    FILE* fout = fopen(c.out.c_str(), "wb");
+    if (!fout) die("cannot open output");
+    static const uint8_t sc[4] = {0,0,0,1};
+    for (size_t i=0;i<nals.size();i++) {
+      fwrite(sc,1,4,fout); fwrite(nals[i].bytes.data(),1,nals[i].bytes.size(),fout);
+      const int k = nals[i].pic;
+      if (c.md5 && k >= 0 && (i+1 == nals.size() || nals[i+1].pic != k)) {        /* suffix SEI after the picture's last slice segment */
+        nal_begin(NAL_UNIT_SUFFIX_SEI_NUT);
+        hdr.write_bits(132,8); hdr.write_bits(49,8); hdr.write_bits(0,8);            /* decoded_picture_hash, 1+3*16 bytes, MD5 */
+        for (int b=0;b<48;b++) hdr.write_bits(md5[k][b],8);
+        hdr.add_trailing_bits(); hdr.flush_VLC();
+        fwrite(sc,1,4,fout); fwrite(hdr.data(),1,hdr.size(),fout);
+      }
+    }
+    fclose(fout);
   }
 };
 

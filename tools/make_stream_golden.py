@@ -37,13 +37,16 @@ STREAMS = [
 
 
 # streams of the synthetic bitstream WRITER (oracle/f2_writer.cc, `make -C oracle f2`): the inter, weighted,
-# PCM, cu_qp_delta, AMP, multi-slice, deblocking-override and SAO-merge syntax the reference's own encoder cannot emit.
+# PCM, cu_qp_delta, AMP, multi-slice, WPP, tiles, deblocking-override and SAO-merge syntax the reference's own encoder cannot
+# emit.  Every picture carries a decoded-picture-hash SEI (MD5), which libde265 checks while it decodes (sei.cc:273).
 F2_STREAMS = [
     dict(name="f2_p_ctb32", args="gop=P pics=4 w=192 h=128 seed=1"),
     dict(name="f2_b_10bit_wp_ctb64", args="gop=B pics=5 w=256 h=144 log2ctb=6 bits=10 wp=1 slices=2 seed=2"),
     dict(name="f2_ldb_slices_ctb16", args="gop=LDB pics=4 w=176 h=144 log2ctb=4 log2maxtb=4 slices=4 lists_mod=1 sdh=1 tskip=1 "
                                           "tqbypass=1 cip=1 nref=3 seed=3"),
     dict(name="f2_i_10bit_pcm7", args="gop=I pics=2 w=200 h=136 log2ctb=6 bits=10 pcm_bits=7 pcm_lf_off=1 seed=4"),
+    dict(name="f2_b_wpp_slices", args="gop=B pics=5 w=256 h=192 wpp=1 slices=3 seed=5"),
+    dict(name="f2_p_tiles_4x3", args="gop=P pics=3 w=256 h=192 log2ctb=4 log2maxtb=4 tile_cols=4 tile_rows=3 tile_uniform=0 lf_tiles=0 slices=5 seed=6"),
 ]
 
 
