@@ -240,6 +240,20 @@ int  de265hip_dpb_upload(de265hip_decoder*, int slot, int c_idx,
                          const void* src, ptrdiff_t stride_bytes);
 int  de265hip_dpb_download(de265hip_decoder*, int slot, int c_idx,
                            void* dst, ptrdiff_t stride_bytes);
+/* Picture-level pipelining (the reference's parallel host side is decctx.cc:976-1178): copy a plane out
+ * WITHOUT waiting on the host.  The copy is ordered behind everything enqueued on the decoder's stream so far (the
+ * picture's kernels) and runs on the decoder's output stream, so the kernels of the pictures enqueued after it overlap
+ * it; de265hip_dpb_wait() blocks until every copy-out of the slot has landed (and reports a failed picture like
+ * decoder_sync).  A picture run into the slot later, an upload or a re-allocation waits for the copy-out by itself.
+ * dst should be pinned memory (de265hip_host_alloc) - with pageable memory the call degrades to a staged copy.
+ * de265hip_dpb_wait() may be called from another thread than the one that enqueues pictures. */
+int  de265hip_dpb_download_async(de265hip_decoder*, int slot, int c_idx,
+                                 void* dst, ptrdiff_t stride_bytes);
+int  de265hip_dpb_wait(de265hip_decoder*, int slot);
+/* Pinned host memory for the planes pictures are copied out to: what a libde265 host installs as its
+ * de265_image_allocation (de265.h:325-343).  NULL when the allocation fails. */
+void* de265hip_host_alloc(size_t bytes);
+void  de265hip_host_free(void*);
 /* Geometry of the picture a DPB slot currently holds (what upload / download copy): the counterpart of
  * de265_get_image_width / _height / de265_get_bits_per_pixel (de265.h:160-171) for a device-resident picture.
  * DE265_ERROR_PARAMETER_OUT_OF_RANGE for an unallocated slot; any out pointer may be NULL. */

@@ -19,7 +19,8 @@ EXPORTS = [
     "de265hip_version", "de265hip_device_count",
     "de265hip_decoder_new", "de265hip_decoder_free",
     "de265hip_dpb_alloc", "de265hip_dpb_upload", "de265hip_dpb_download", "de265hip_dpb_plane", "de265hip_dpb_info",
-    "de265hip_dpb_copy", "de265hip_debug_build_host_only", "de265hip_debug_last_build_hash",
+    "de265hip_dpb_copy", "de265hip_dpb_download_async", "de265hip_dpb_wait", "de265hip_host_alloc", "de265hip_host_free",
+    "de265hip_debug_build_host_only", "de265hip_debug_last_build_hash",
     "de265hip_picture_build", "de265hip_picture_run", "de265hip_decoder_sync", "de265hip_picture_free",
     "de265hip_decode_picture", "de265hip_picture_get_stats",
     "de265hip_set_profiling", "de265hip_get_kernel_times", "de265hip_derive_edge_flags", "de265hip_intra_used_units",
@@ -61,6 +62,12 @@ def lib():
     L.de265hip_dpb_plane.argtypes = [vp, i32, i32, pp(vp), pp(C.c_ssize_t)]
     L.de265hip_dpb_info.argtypes = [vp, i32, pp(i32), pp(i32), pp(i32), pp(i32)]
     L.de265hip_dpb_copy.argtypes = [vp, i32, vp, i32]
+    L.de265hip_dpb_download_async.argtypes = [vp, i32, i32, vp, C.c_ssize_t]
+    L.de265hip_dpb_wait.argtypes = [vp, i32]
+    L.de265hip_host_alloc.argtypes = [C.c_size_t]
+    L.de265hip_host_alloc.restype = vp
+    L.de265hip_host_free.argtypes = [vp]
+    L.de265hip_host_free.restype = None
     L.de265hip_debug_build_host_only.argtypes = [pp(_abi.PictureDesc), i32]
     L.de265hip_debug_last_build_hash.restype = C.c_uint64
     L.de265hip_debug_last_build_hash.argtypes = []
@@ -131,6 +138,29 @@ class Picture:
             pass
 
 
+class _PendingDownload:
+    def __init__(self, dec, slot, shapes, dt):
+        self._dec, self._slot, self._ptrs, self.planes = dec, slot, [], []
+        for c, sh in enumerate(shapes):
+            nbytes = sh[0] * sh[1] * np.dtype(dt).itemsize
+            ptr = lib().de265hip_host_alloc(nbytes)
+            if not ptr:
+                raise MemoryError("de265hip_host_alloc(%d)" % nbytes)
+            self._ptrs.append(ptr)
+            self.planes.append(np.frombuffer((C.c_uint8 * nbytes).from_address(ptr), dt).reshape(sh))
+            _chk(lib().de265hip_dpb_download_async(dec._h, slot, c, ptr, sh[1] * np.dtype(dt).itemsize), "dpb_download_async")
+
+    def wait(self):
+        _chk(lib().de265hip_dpb_wait(self._dec._h, self._slot), "dpb_wait")
+        return self.planes
+
+    def free(self):
+        self.planes = []
+        for ptr in self._ptrs:
+            lib().de265hip_host_free(ptr)
+        self._ptrs = []
+
+
 class Decoder:
     """Mirror of de265hip_decoder: one HIP stream + device-resident DPB."""
 
@@ -185,6 +215,14 @@ class Decoder:
             _chk(lib().de265hip_dpb_download(self._h, slot, c, a.ctypes.data, a.strides[0]), "dpb_download")
             out.append(a)
         return out
+
+    def download_async(self, slot, width, height, bit_depth):
+        """enqueue the copy-out of a decoded picture into pinned planes without waiting; returns a handle whose
+        wait() blocks until the planes have landed and hands them out (numpy views of the pinned memory, valid until free())."""
+        dt = np.uint16 if bit_depth > 8 else np.uint8
+        shapes = [(height, width), (height // 2, width // 2), (height // 2, width // 2)]
+        self._check_planes(slot, [(sh, dt) for sh in shapes], "download_async")
+        return _PendingDownload(self, slot, shapes, dt)
 
     def plane(self, slot, c_idx):
         p, s = C.c_void_p(), C.c_ssize_t()

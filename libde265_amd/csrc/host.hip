@@ -34,6 +34,10 @@ struct Slot {
   PlaneRef pl[3] = {};
   int w = 0, h = 0, bdY = 0, bdC = 0;
   bool valid = false;
+  // de265hip_dpb_download_async: recorded on the output stream behind the slot's latest copy-out; whoever writes the
+  // slot next (a new picture, an upload) or frees it waits for it.  dl_seq counts the copy-outs (dpb_wait compares it).
+  hipEvent_t dl_done = nullptr;
+  uint64_t dl_seq = 0, dl_waited = 0;
 };
 
 struct PendingEvent { int kid; hipEvent_t a, b; };
@@ -53,6 +57,8 @@ struct de265hip_decoder {
   bool dry = false;                   // de265hip_debug_build_host_only: the host stage without any HIP call (profiling on a CPU box)
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;  // uploads of command buffers (de265hip_picture_build), overlapping the kernels of earlier pictures
+  hipStream_t out_stream = nullptr;   // de265hip_dpb_download_async: decoded pictures leave on their own stream, behind an event of `stream`
+  hipEvent_t out_fence = nullptr;
   std::mutex mu;                      // guards live, the two pools and slot allocation: build()/free() may come from several host threads
   std::vector<de265hip_picture*> live;        // pictures built on this decoder and not yet freed (decoder_free orphans them)
   std::vector<ArenaBuf> free_arenas;
@@ -121,6 +127,8 @@ size_t px_bytes(int bd) { return bd > 8 ? 2 : 1; }
 
 int free_slot(Slot& s)
 {
+  if (s.dl_done) { (void)hipEventSynchronize(s.dl_done); (void)hipEventDestroy(s.dl_done); s.dl_done = nullptr; }
+  s.dl_seq = s.dl_waited = 0;
   for (int c = 0; c < 3; c++) if (s.pl[c].ptr) { (void)hipFree(s.pl[c].ptr); s.pl[c].ptr = nullptr; }
   s.valid = false;
   return 0;
@@ -460,6 +468,8 @@ void de265hip_decoder_free(de265hip_decoder* d)
   if (!d) return;
   (void)hipStreamSynchronize(d->copy_stream);
   (void)hipStreamSynchronize(d->stream);
+  if (d->out_stream) { (void)hipStreamSynchronize(d->out_stream); (void)hipStreamDestroy(d->out_stream); }
+  if (d->out_fence) (void)hipEventDestroy(d->out_fence);
   {
     std::lock_guard<std::mutex> lk(d->mu);
     for (de265hip_picture* p : d->live) {
@@ -506,6 +516,7 @@ int de265hip_dpb_upload(de265hip_decoder* d, int slot, int c, const void* src, p
 {
   Slot* s; int w, h; size_t bpp;
   int rc = plane_geom(d, slot, c, &s, &w, &h, &bpp); if (rc) return rc;
+  if (s->dl_done && s->dl_waited != s->dl_seq) HIPCHK(hipEventSynchronize(s->dl_done), DE265HIP_ERROR_DECODING);
   HIPCHK(hipStreamSynchronize(d->stream), DE265HIP_ERROR_DECODING);
   HIPCHK(hipMemcpy2D(s->pl[c].ptr, s->pl[c].stride * bpp, src, (size_t)stride_bytes, w * bpp, h, hipMemcpyHostToDevice),
          DE265HIP_ERROR_DECODING);
@@ -520,6 +531,49 @@ int de265hip_dpb_download(de265hip_decoder* d, int slot, int c, void* dst, ptrdi
   HIPCHK(hipMemcpy2D(dst, (size_t)stride_bytes, s->pl[c].ptr, s->pl[c].stride * bpp, w * bpp, h, hipMemcpyDeviceToHost),
          DE265HIP_ERROR_DECODING);
   return 0;
+}
+
+/* Pinned host memory for the planes decoded pictures are copied into (de265.h:325-343: a libde265 host installs it as its
+ * de265_image_allocation), so that de265hip_dpb_download_async is a true DMA that overlaps the next pictures' kernels. */
+void* de265hip_host_alloc(size_t bytes)
+{
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+
+void de265hip_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+int de265hip_dpb_download_async(de265hip_decoder* d, int slot, int c, void* dst, ptrdiff_t stride_bytes)
+{
+  Slot* s; int w, h; size_t bpp;
+  int rc = plane_geom(d, slot, c, &s, &w, &h, &bpp); if (rc) return rc;
+  std::lock_guard<std::mutex> lk(d->mu);
+  if (!d->out_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&d->out_stream, hipStreamNonBlocking), DE265HIP_ERROR_DECODING);
+    HIPCHK(hipEventCreateWithFlags(&d->out_fence, hipEventDisableTiming), DE265HIP_ERROR_DECODING);
+  }
+  if (!s->dl_done) HIPCHK(hipEventCreateWithFlags(&s->dl_done, hipEventDisableTiming), DE265HIP_ERROR_DECODING);
+  // behind everything enqueued on the decoder's stream so far (the picture's kernels), but not in FRONT of what comes next
+  HIPCHK(hipEventRecord(d->out_fence, d->stream), DE265HIP_ERROR_DECODING);
+  HIPCHK(hipStreamWaitEvent(d->out_stream, d->out_fence, 0), DE265HIP_ERROR_DECODING);
+  HIPCHK(hipMemcpy2DAsync(dst, (size_t)stride_bytes, s->pl[c].ptr, s->pl[c].stride * bpp, w * bpp, h, hipMemcpyDeviceToHost, d->out_stream),
+         DE265HIP_ERROR_DECODING);
+  HIPCHK(hipEventRecord(s->dl_done, d->out_stream), DE265HIP_ERROR_DECODING);
+  s->dl_seq++;
+  return 0;
+}
+
+int de265hip_dpb_wait(de265hip_decoder* d, int slot)
+{
+  if (!d || slot < 0 || slot >= DE265HIP_MAX_DPB_SLOTS || !d->slots[slot].valid) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  hipEvent_t ev; uint64_t seq;
+  { std::lock_guard<std::mutex> lk(d->mu); Slot& s = d->slots[slot]; ev = s.dl_done; seq = s.dl_seq; if (!ev || s.dl_waited == seq) return 0; }
+  HIPCHK(hipEventSynchronize(ev), DE265HIP_ERROR_DECODING);        // outside the lock: another thread may be enqueueing the next picture
+  uint32_t err = 0;                                                 // as de265hip_decoder_sync: a k_run dependency wait that expired
+  HIPCHK(hipMemcpy(&err, d->d_err, 4, hipMemcpyDeviceToHost), DE265HIP_ERROR_DECODING);
+  { std::lock_guard<std::mutex> lk(d->mu); Slot& s = d->slots[slot]; if (s.dl_seq == seq) s.dl_waited = seq; }
+  return err ? DE265HIP_ERROR_DECODING : 0;
 }
 
 int de265hip_dpb_info(de265hip_decoder* d, int slot, int* width, int* height, int* bit_depth_luma, int* bit_depth_chroma)
@@ -1328,6 +1382,10 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
   Slot& dst = dec->slots[pic->dst_slot];
   if (!dst.valid) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   hipStream_t st = dec->stream;
+  {                                     // a copy-out of the picture this slot held before must have left (de265hip_dpb_download_async)
+    std::lock_guard<std::mutex> lk(dec->mu);
+    if (dst.dl_done && dst.dl_waited != dst.dl_seq && hipStreamWaitEvent(st, dst.dl_done, 0) != hipSuccess) return DE265HIP_ERROR_DECODING;
+  }
   if (!pic->upload_waited) {            // the command buffers arrive on the copy stream
     if (hipStreamWaitEvent(st, pic->uploaded, 0) != hipSuccess) return DE265HIP_ERROR_DECODING;
     pic->upload_waited = true;

@@ -7,8 +7,15 @@
  *   F1_MODE=hip F1_HIP_LIB=.../libde265_hip.so f1_dec stream.bin out.yuv
  *                                                         offload mode: libde265 parses, the MI355X reconstructs; out.yuv receives
  *                                                         what de265_get_next_picture hands out (planes, little-endian samples)
+ *   F1_THREADS=n        libde265's own worker threads (de265_start_worker_threads: WPP rows / tiles parse in parallel, decctx.cc:976-1178)
+ *   F1_PIPELINE=1       (offload mode) SURVEY 8(f3): pictures are only ENQUEUED on the device, pinned picture memory, copy-out waited
+ *                       for at output time - libde265 parses picture n+1 while the MI355X reconstructs picture n
+ *   F1_CHECK_HASH=0     do not verify decoded-picture-hash SEIs (the check reads every picture on the host right after its decode)
+ *   F1_TIMING=1         print pictures/s of the decode loop (file read and output writing included) on stderr... as the last stdout line
  */
 #include "libde265/de265.h"
+#include "f1_hooks.h"
+#include <chrono>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -31,7 +38,11 @@ int main(int argc, char** argv)
   FILE* out = argc > 2 ? fopen(argv[2], "wb") : NULL;
   de265_decoder_context* ctx = de265_new_decoder();
   de265_set_parameter_int(ctx, DE265_DECODER_PARAM_ACCELERATION_CODE, de265_acceleration_SCALAR);
-  de265_set_parameter_bool(ctx, DE265_DECODER_PARAM_BOOL_SEI_CHECK_HASH, 1);
+  const char* e;
+  de265_set_parameter_bool(ctx, DE265_DECODER_PARAM_BOOL_SEI_CHECK_HASH, (e = getenv("F1_CHECK_HASH")) ? atoi(e) : 1);
+  if ((e = getenv("F1_THREADS")) && atoi(e) > 0 && de265_start_worker_threads(ctx, atoi(e)) != DE265_OK) return 3;
+  f1_install_pinned_allocator(ctx);                        // offload mode only
+  const auto t0 = std::chrono::steady_clock::now();
   unsigned char buf[65536];
   int n_out = 0, more = 1;
   size_t n;
@@ -51,6 +62,8 @@ int main(int argc, char** argv)
     while (const de265_image* im = de265_get_next_picture(ctx)) { n_out++; write_picture(out, im); }
     if (e != DE265_OK && e != DE265_ERROR_WAITING_FOR_INPUT_DATA) break;
   }
+  f1_drain();
+  const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   for (;;) {
     de265_error w = de265_get_warning(ctx);
     if (w == DE265_OK) break;
@@ -60,5 +73,6 @@ int main(int argc, char** argv)
   fclose(f);
   if (out) fclose(out);
   printf("%d pictures\n", n_out);
+  if ((e = getenv("F1_TIMING")) && atoi(e)) printf("%.3f s  %.2f pictures/s\n", secs, n_out / secs);
   return 0;
 }

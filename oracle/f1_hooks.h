@@ -27,4 +27,12 @@ void f1_record_pcm(thread_context* tctx, int x0, int y0, int log2CbSize);
  * caller skips run_postprocessing_filters_*); false: dump mode, the caller carries on */
 bool f1_submit(de265_image* img);
 void f1_picture_done(de265_image* img);
+/* SURVEY 8(f3), F1_MODE=hip F1_PIPELINE=1: f1_submit only ENQUEUES the picture (a submit thread builds the command buffers
+ * and launches; the copy-out into libde265's pinned planes is asynchronous) and libde265 carries on parsing; the picture is
+ * waited for where somebody is about to look at it: de265_peek_next_picture (de265.cc:392) -> f1_before_output. */
+void f1_before_output(const de265_image* img);
+/* for the application (oracle/f1_dec.cc): install the pinned-memory image allocator (de265.h:325-343) before decoding, and
+ * drain the pipeline before the decoder is freed */
+void f1_install_pinned_allocator(void* de265_decoder_ctx);
+void f1_drain();
 #endif

@@ -19,27 +19,94 @@
 #include "f1_hooks.h"
 #include "../include/de265_hip.h"
 
+#include <algorithm>
+#include <condition_variable>
+#include <deque>
 #include <dlfcn.h>
+#include <map>
+#include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <thread>
 #include <vector>
 
 bool derive_edgeFlags(de265_image* img);          // deblock.cc:228
 
 namespace {
 
-struct State {
+/* What the hooks collect for the picture being parsed.  With libde265's worker threads (WPP rows / tiles,
+ * decctx.cc:976-1178) the hooks fire on several threads at once: every thread appends to a buffer of its own, each record
+ * tagged with its CTB's address in tile scan; f1_submit merges the buffers by that address.  A CTB is parsed by one
+ * thread, so the merged order is exactly the order of a sequential decode. */
+struct Rec {
+  std::vector<de265hip_tu> tus;   std::vector<uint32_t> tu_ts;
+  std::vector<int16_t> cval;      std::vector<uint16_t> cpos;
+  std::vector<de265hip_pu> pus;   std::vector<uint32_t> pu_ts;
+  std::vector<de265hip_pcm> pcms; std::vector<uint32_t> pcm_ts;
+  std::vector<uint16_t> pcm_samples;
+  void clear() { tus.clear(); tu_ts.clear(); cval.clear(); cpos.clear(); pus.clear(); pu_ts.clear(); pcms.clear(); pcm_ts.clear(); pcm_samples.clear(); }
+};
+std::mutex reg_mu;
+std::vector<Rec*> all_recs;
+thread_local Rec* my_rec = nullptr;
+Rec& mine()
+{
+  if (!my_rec) { my_rec = new Rec; std::lock_guard<std::mutex> lk(reg_mu); all_recs.push_back(my_rec); }
+  return *my_rec;
+}
+
+struct PicRec {                        // one picture's merged records (decode order)
   std::vector<de265hip_tu> tus;
   std::vector<int16_t> cval;
   std::vector<uint16_t> cpos;
   std::vector<de265hip_pu> pus;
   std::vector<de265hip_pcm> pcms;
   std::vector<uint16_t> pcm_samples;
+};
+struct State {
   std::vector<uint8_t> file;          // the dump being assembled between f1_submit and f1_picture_done
   int n_pictures = 0;
 };
 State S;
+
+void merge_records(PicRec& M)
+{
+  std::lock_guard<std::mutex> lk(reg_mu);
+  struct Ref { uint32_t ts; uint16_t rec; uint32_t idx; };
+  std::vector<Ref> order;
+  auto sorted = [&](std::vector<uint32_t> Rec::* key) {
+    order.clear();
+    for (size_t r=0;r<all_recs.size();r++) { const auto& k = all_recs[r]->*key; for (size_t i=0;i<k.size();i++) order.push_back(Ref{k[i],(uint16_t)r,(uint32_t)i}); }
+    std::stable_sort(order.begin(), order.end(), [](const Ref& a, const Ref& b) { return a.ts < b.ts; });
+  };
+  sorted(&Rec::tu_ts);
+  M.tus.reserve(order.size());
+  for (const Ref& o : order) {
+    const Rec& R = *all_recs[o.rec];
+    de265hip_tu t = R.tus[o.idx];
+    if (t.n_coeff) {
+      const uint32_t src = t.coeff_offset;
+      t.coeff_offset = (uint32_t)M.cval.size();
+      M.cval.insert(M.cval.end(), R.cval.begin()+src, R.cval.begin()+src+t.n_coeff);
+      M.cpos.insert(M.cpos.end(), R.cpos.begin()+src, R.cpos.begin()+src+t.n_coeff);
+    }
+    M.tus.push_back(t);
+  }
+  sorted(&Rec::pu_ts);
+  for (const Ref& o : order) M.pus.push_back(all_recs[o.rec]->pus[o.idx]);
+  sorted(&Rec::pcm_ts);
+  for (const Ref& o : order) {
+    const Rec& R = *all_recs[o.rec];
+    de265hip_pcm pc = R.pcms[o.idx];
+    const int n = 1 << pc.log2_cb_size, cnt = n*n + 2*(n/2)*(n/2);
+    const uint32_t src = pc.sample_offset;
+    pc.sample_offset = (uint32_t)M.pcm_samples.size();
+    M.pcm_samples.insert(M.pcm_samples.end(), R.pcm_samples.begin()+src, R.pcm_samples.begin()+src+cnt);
+    M.pcms.push_back(pc);
+  }
+  for (Rec* r : all_recs) r->clear();
+}
 
 /* ---- offload mode (F1_MODE=hip): the product library, loaded at run time (this decoder never links it) ---- */
 struct Hip {
@@ -61,6 +128,11 @@ struct Hip {
   int  (*picture_run)(de265hip_decoder*, de265hip_picture*, int);
   int  (*decoder_sync)(de265hip_decoder*);
   void (*picture_free)(de265hip_picture*);
+  int  (*dpb_download_async)(de265hip_decoder*, int, int, void*, ptrdiff_t);
+  int  (*dpb_wait)(de265hip_decoder*, int);
+  void* (*host_alloc)(size_t);
+  void (*host_free)(void*);
+  bool pipeline = false;               // F1_PIPELINE=1: SURVEY 8(f3), see f1_submit
 };
 Hip H;
 
@@ -78,8 +150,10 @@ bool hip_mode()
 #define SYM(f) do { *(void**)&H.f = dlsym(H.lib, "de265hip_" #f); if (!H.f) hip_die("dlsym de265hip_" #f, 0); } while (0)
   SYM(decoder_new); SYM(dpb_alloc); SYM(dpb_download); SYM(recorder_new); SYM(recorder_free); SYM(record_tu); SYM(record_pu);
   SYM(record_pcm); SYM(record_slice); SYM(record_ctb); SYM(record_blk_planes); SYM(recorder_submit); SYM(picture_run);
-  SYM(decoder_sync); SYM(picture_free);
+  SYM(decoder_sync); SYM(picture_free); SYM(dpb_download_async); SYM(dpb_wait); SYM(host_alloc); SYM(host_free);
 #undef SYM
+  const char* pl = getenv("F1_PIPELINE");
+  H.pipeline = pl && atoi(pl) != 0;
   int rc = H.decoder_new(&H.dec, -1);
   if (rc) hip_die("de265hip_decoder_new", rc);
   H.on = true;
@@ -105,7 +179,149 @@ int dpb_index_of(const de265_image* img)
   return 0;
 }
 
+/* ---- one picture on its way to the device (offload mode) ---- */
+struct Job {
+  de265hip_pic_params P;
+  std::vector<uint8_t> scaling;
+  std::vector<de265hip_slice_params> slices;
+  std::vector<de265hip_ctb_info> ctbs;
+  PicRec M;
+  std::vector<uint8_t> flags; std::vector<int8_t> qp; std::vector<de265hip_motion> mot;
+  int slot = 0;
+  void* plane[3] = {nullptr,nullptr,nullptr}; ptrdiff_t stride_bytes[3] = {0,0,0};   // the decoder's own picture memory
+  bool enqueued = false;               // pipeline mode: the submit thread has put it on the device's streams
+};
+
+/* What an integrated libde265 does at decctx.cc:757-766 instead of run_postprocessing_filters_*: hand the recorded picture
+ * to the MI355X.  wait = true: ... and wait for it (the picture is in the decoder's planes on return); wait = false
+ * (SURVEY 8(f3)): only enqueue kernels and the copy-out into the (pinned) planes; f1_before_output waits for them. */
+void run_job(Job& j, bool wait)
+{
+  int rc;
+  de265hip_recorder* rec = NULL;
+  if ((rc = H.recorder_new(&rec, &j.P, j.scaling.empty() ? NULL : j.scaling.data()))) hip_die("recorder_new", rc);
+  for (const auto& sl : j.slices) if ((rc = H.record_slice(rec, &sl))) hip_die("record_slice", rc);
+  for (size_t a=0;a<j.ctbs.size();a++) if ((rc = H.record_ctb(rec, (int)a, &j.ctbs[a]))) hip_die("record_ctb", rc);
+  for (const auto& t : j.M.tus) if ((rc = H.record_tu(rec, &t, j.M.cval.data()+t.coeff_offset, j.M.cpos.data()+t.coeff_offset))) hip_die("record_tu", rc);
+  for (const auto& pu : j.M.pus) if ((rc = H.record_pu(rec, &pu))) hip_die("record_pu", rc);
+  for (const auto& pc : j.M.pcms) if ((rc = H.record_pcm(rec, pc.x0, pc.y0, pc.log2_cb_size, j.M.pcm_samples.data()+pc.sample_offset))) hip_die("record_pcm", rc);
+  if ((rc = H.record_blk_planes(rec, j.flags.data(), j.qp.data(), j.mot.data()))) hip_die("record_blk_planes", rc);
+  de265hip_picture* pic = NULL;
+  if ((rc = H.dpb_alloc(H.dec, j.slot, j.P.width, j.P.height, j.P.bit_depth_luma, j.P.bit_depth_chroma))) hip_die("dpb_alloc", rc);
+  if ((rc = H.recorder_submit(H.dec, j.slot, rec, &pic))) hip_die("recorder_submit", rc);
+  if ((rc = H.picture_run(H.dec, pic, DE265HIP_STAGE_FINAL))) hip_die("picture_run", rc);
+  if (wait) {
+    if ((rc = H.decoder_sync(H.dec))) hip_die("decoder_sync", rc);
+    for (int c=0;c<3;c++)                                           // the GPU's picture becomes the decoder's picture
+      if ((rc = H.dpb_download(H.dec, j.slot, c, j.plane[c], j.stride_bytes[c]))) hip_die("dpb_download", rc);
+  } else {
+    for (int c=0;c<3;c++)
+      if ((rc = H.dpb_download_async(H.dec, j.slot, c, j.plane[c], j.stride_bytes[c]))) hip_die("dpb_download_async", rc);
+  }
+  H.picture_free(pic);                                              // never waits: the decoder owns the device side (de265_hip.h LIFETIME)
+  H.recorder_free(rec);
+}
+
+/* SURVEY 8(f3) picture-level pipelining: libde265's thread(s) parse picture n+1 while the submit thread builds picture n's
+ * command buffers (de265hip_recorder_submit -> picture_build) and the device reconstructs picture n-1. */
+struct Pipe {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::shared_ptr<Job>> q;
+  std::map<const de265_image*, std::shared_ptr<Job>> pending;       // submitted, not yet known to have landed in the image's planes
+  bool started = false;
+};
+Pipe PL;
+
+void pipe_worker()
+{
+  for (;;) {
+    std::shared_ptr<Job> j;
+    { std::unique_lock<std::mutex> lk(PL.mu); PL.cv.wait(lk, []{ return !PL.q.empty(); }); j = PL.q.front(); }
+    run_job(*j, false);
+    { std::lock_guard<std::mutex> lk(PL.mu); PL.q.pop_front(); j->enqueued = true; }
+    PL.cv.notify_all();
+  }
+}
+
+void pipe_submit(const de265_image* img, std::shared_ptr<Job> j)
+{
+  std::unique_lock<std::mutex> lk(PL.mu);
+  if (!PL.started) { PL.started = true; PL.th = std::thread(pipe_worker); PL.th.detach(); }
+  PL.cv.wait(lk, []{ return PL.q.size() < 3; });                     // bounded: at most three pictures between parser and device
+  PL.q.push_back(j);
+  PL.pending[img] = j;
+  lk.unlock();
+  PL.cv.notify_all();
+}
+
+void pipe_wait(const de265_image* img)
+{
+  std::shared_ptr<Job> j;
+  {
+    std::unique_lock<std::mutex> lk(PL.mu);
+    auto it = PL.pending.find(img);
+    if (it == PL.pending.end()) return;
+    j = it->second;
+    PL.pending.erase(it);
+    PL.cv.wait(lk, [&]{ return j->enqueued; });
+  }
+  int rc = H.dpb_wait(H.dec, j->slot);
+  if (rc) hip_die("dpb_wait", rc);
+}
+
+/* pinned picture memory for libde265 (de265.h:325-343), pooled: libde265 releases and re-requests the planes of a DPB entry
+ * for every picture (image.cc:244) */
+struct PinPool { std::mutex mu; std::multimap<size_t, void*> free; std::map<void*, size_t> size; };
+PinPool PP;
+
+void* pin_get(size_t bytes)
+{
+  { std::lock_guard<std::mutex> lk(PP.mu); auto it = PP.free.find(bytes); if (it != PP.free.end()) { void* p = it->second; PP.free.erase(it); return p; } }
+  void* p = H.host_alloc(bytes);
+  if (p) { std::lock_guard<std::mutex> lk(PP.mu); PP.size[p] = bytes; }
+  return p;
+}
+
+int pin_get_buffer(de265_decoder_context*, de265_image_spec* spec, de265_image* img, void*)
+{                                                                   // geometry as the default allocator, image.cc:106-156
+  const int cw = spec->width / img->SubWidthC, ch = spec->height / img->SubHeightC;
+  const int ls = (spec->width + spec->alignment-1) / spec->alignment * spec->alignment, cs = (cw + spec->alignment-1) / spec->alignment * spec->alignment;
+  void* y = pin_get((size_t)spec->height * ls * ((img->BitDepth_Y+7)/8) + 64);
+  void* u = pin_get((size_t)ch * cs * ((img->BitDepth_C+7)/8) + 64);
+  void* v = pin_get((size_t)ch * cs * ((img->BitDepth_C+7)/8) + 64);
+  if (!y || !u || !v) return 0;
+  img->set_image_plane(0, (uint8_t*)y, ls, NULL); img->set_image_plane(1, (uint8_t*)u, cs, NULL); img->set_image_plane(2, (uint8_t*)v, cs, NULL);
+  return 1;
+}
+
+void pin_release_buffer(de265_decoder_context*, de265_image* img, void*)
+{
+  pipe_wait(img);                                                   // a copy-out still on its way into these planes
+  std::lock_guard<std::mutex> lk(PP.mu);
+  for (int c=0;c<3;c++) { void* p = img->get_image_plane(c); auto it = PP.size.find(p); if (p && it != PP.size.end()) PP.free.insert({it->second, p}); }
+}
+
 } // namespace
+
+void f1_install_pinned_allocator(void* ctx)
+{
+  if (!hip_mode()) return;
+  static de265_image_allocation a = { pin_get_buffer, pin_release_buffer };
+  de265_set_image_allocation_functions(ctx, &a, NULL);
+}
+
+void f1_before_output(const de265_image* img) { if (H.on && H.pipeline) pipe_wait(img); }
+
+void f1_drain()
+{
+  if (!(H.on && H.pipeline)) return;
+  std::vector<const de265_image*> imgs;
+  { std::lock_guard<std::mutex> lk(PL.mu); for (auto& kv : PL.pending) imgs.push_back(kv.first); }
+  for (const de265_image* im : imgs) pipe_wait(im);
+  H.decoder_sync(H.dec);
+}
 
 bool f1_record_tu(thread_context* tctx, int x0, int y0, int nT, int cIdx, int cuPredMode, bool cbf)
 {
@@ -126,19 +342,20 @@ bool f1_record_tu(thread_context* tctx, int x0, int y0, int nT, int cIdx, int cu
     t.intra_mode = (uint8_t)m;
   }
   t.qp = (int8_t)(cIdx==0 ? tctx->qPYPrime : (cIdx==1 ? tctx->qPCbPrime : tctx->qPCrPrime));   // transform.cc:362-368
+  Rec& R = mine();
   if (cbf) {
     t.n_coeff = (uint16_t)tctx->nCoeff[cIdx];
-    t.coeff_offset = (uint32_t)S.cval.size();
+    t.coeff_offset = (uint32_t)R.cval.size();
     for (int i=0;i<tctx->nCoeff[cIdx];i++) {
-      S.cval.push_back(tctx->coeffList[cIdx][i]);
-      S.cpos.push_back((uint16_t)tctx->coeffPos[cIdx][i]);
+      R.cval.push_back(tctx->coeffList[cIdx][i]);
+      R.cpos.push_back((uint16_t)tctx->coeffPos[cIdx][i]);
     }
   }
-  S.tus.push_back(t);
+  R.tus.push_back(t); R.tu_ts.push_back((uint32_t)tctx->CtbAddrInTS);
   return hip_mode();
 }
 
-bool f1_record_pu(const slice_segment_header* shdr, de265_image*, int xP, int yP, int nPbW, int nPbH, const PBMotion* vi)
+bool f1_record_pu(const slice_segment_header* shdr, de265_image* img, int xP, int yP, int nPbW, int nPbH, const PBMotion* vi)
 {
   de265hip_pu p; memset(&p,0,sizeof(p));
   p.x = (uint16_t)xP; p.y = (uint16_t)yP; p.w = (uint8_t)nPbW; p.h = (uint8_t)nPbH;
@@ -146,7 +363,10 @@ bool f1_record_pu(const slice_segment_header* shdr, de265_image*, int xP, int yP
   p.slice_idx = (uint16_t)shdr->slice_index;
   for (int l=0;l<2;l++)                                 // libde265 leaves the unused list's refIdx / mv undefined: record zeros
     if (vi->predFlag[l]) { p.ref_idx[l] = vi->refIdx[l]; p.mv[l][0] = vi->mv[l].x; p.mv[l][1] = vi->mv[l].y; }
-  S.pus.push_back(p);
+  const seq_parameter_set& sps = img->get_sps();
+  Rec& R = mine();
+  R.pus.push_back(p);
+  R.pu_ts.push_back((uint32_t)img->get_pps().CtbAddrRStoTS[(xP>>sps.Log2CtbSizeY) + (yP>>sps.Log2CtbSizeY)*sps.PicWidthInCtbsY]);
   return hip_mode();
 }
 
@@ -155,14 +375,15 @@ void f1_record_pcm(thread_context* tctx, int x0, int y0, int log2CbSize)
   de265_image* img = tctx->img;
   de265hip_pcm p; memset(&p,0,sizeof(p));
   p.x0 = (uint16_t)x0; p.y0 = (uint16_t)y0; p.log2_cb_size = (uint8_t)log2CbSize;
-  p.sample_offset = (uint32_t)S.pcm_samples.size();
+  Rec& R = mine();
+  p.sample_offset = (uint32_t)R.pcm_samples.size();
   for (int c=0;c<3;c++) {                              // the samples as read_pcm_samples_internal stored them (already << shift)
     const int n = (1<<log2CbSize) >> (c?1:0), xx = x0 >> (c?1:0), yy = y0 >> (c?1:0), stride = img->get_image_stride(c);
     for (int y=0;y<n;y++) for (int x=0;x<n;x++)
-      S.pcm_samples.push_back(img->high_bit_depth(c) ? ((const uint16_t*)img->get_image_plane(c))[xx+x+(yy+y)*stride]
+      R.pcm_samples.push_back(img->high_bit_depth(c) ? ((const uint16_t*)img->get_image_plane(c))[xx+x+(yy+y)*stride]
                                                       : img->get_image_plane(c)[xx+x+(yy+y)*stride]);
   }
-  S.pcms.push_back(p);
+  R.pcms.push_back(p); R.pcm_ts.push_back((uint32_t)tctx->CtbAddrInTS);
 }
 
 bool f1_submit(de265_image* img)
@@ -170,7 +391,10 @@ bool f1_submit(de265_image* img)
   const seq_parameter_set& sps = img->get_sps();
   const pic_parameter_set& pps = img->get_pps();
   const bool hip = hip_mode();
-  de265hip_pic_params P; memset(&P,0,sizeof(P));
+  std::shared_ptr<Job> job = std::make_shared<Job>();
+  merge_records(job->M);
+  const PicRec& M = job->M;
+  de265hip_pic_params& P = job->P; memset(&P,0,sizeof(P));
   P.width = sps.pic_width_in_luma_samples; P.height = sps.pic_height_in_luma_samples;
   P.bit_depth_luma = sps.BitDepth_Y; P.bit_depth_chroma = sps.BitDepth_C; P.chroma_format_idc = sps.chroma_format_idc;
   P.log2_ctb_size = sps.Log2CtbSizeY; P.log2_min_cb_size = sps.Log2MinCbSizeY; P.log2_min_tb_size = sps.Log2MinTrafoSize;
@@ -191,7 +415,7 @@ bool f1_submit(de265_image* img)
   const int w4 = (P.width+3)/4, h4 = (P.height+3)/4, nctb = sps.PicSizeInCtbsY;
   const int cbw = sps.PicWidthInMinCbsY, cbh = sps.PicHeightInMinCbsY, tbw = sps.PicWidthInTbsY, tbh = sps.PicHeightInTbsY;
   const uint8_t* scaling = sps.scaling_list_enable_flag ? (const uint8_t*)&pps.scaling_list : NULL;      // transform.cc:487-493
-  std::vector<de265hip_slice_params> slices;
+  std::vector<de265hip_slice_params>& slices = job->slices;
   for (slice_segment_header* h : img->slices) {
     de265hip_slice_params s; memset(&s,0,sizeof(s));
     s.slice_type = h->slice_type; s.slice_addr_rs = h->SliceAddrRS;
@@ -207,7 +431,7 @@ bool f1_submit(de265_image* img)
     }
     slices.push_back(s);
   }
-  std::vector<de265hip_ctb_info> ctbs(nctb);
+  std::vector<de265hip_ctb_info>& ctbs = job->ctbs; ctbs.resize(nctb);
   for (int a=0;a<nctb;a++) {
     const int cx = a % sps.PicWidthInCtbsY, cy = a / sps.PicWidthInCtbsY;
     de265hip_ctb_info ci; memset(&ci,0,sizeof(ci));
@@ -219,7 +443,8 @@ bool f1_submit(de265_image* img)
     ctbs[a] = ci;
   }
   // flattened per-4x4 views (include/de265_hip.h DE265HIP_BLK_*), without the edge bits
-  std::vector<uint8_t> flags((size_t)w4*h4); std::vector<int8_t> qp((size_t)w4*h4); std::vector<de265hip_motion> mot((size_t)w4*h4);
+  std::vector<uint8_t>& flags = job->flags; std::vector<int8_t>& qp = job->qp; std::vector<de265hip_motion>& mot = job->mot;
+  flags.resize((size_t)w4*h4); qp.resize((size_t)w4*h4); mot.resize((size_t)w4*h4);
   for (int y=0;y<h4;y++) for (int x=0;x<w4;x++) {
     const int xl = x<<2, yl = y<<2;
     const bool intra = img->get_pred_mode(xl,yl)==MODE_INTRA;
@@ -238,30 +463,13 @@ bool f1_submit(de265_image* img)
   }
 
   if (hip) {
-    // ---- OFFLOAD: what an integrated libde265 does at decctx.cc:757-766 instead of run_postprocessing_filters_*
+    // ---- OFFLOAD
     if (!P.disable_deblocking) derive_edgeFlags(img);               // cheap host code; or de265hip_derive_edge_flags
     for (int y=0;y<h4;y++) for (int x=0;x<w4;x++) flags[x+y*w4] |= img->get_deblk_flags(x<<2,y<<2) & 0xF0;
-    const int slot = dpb_index_of(img) % DE265HIP_MAX_DPB_SLOTS;
-    int rc;
-    de265hip_recorder* rec = NULL;
-    if ((rc = H.recorder_new(&rec, &P, scaling))) hip_die("recorder_new", rc);
-    for (const auto& sl : slices) if ((rc = H.record_slice(rec, &sl))) hip_die("record_slice", rc);
-    for (int a=0;a<nctb;a++) if ((rc = H.record_ctb(rec, a, &ctbs[a]))) hip_die("record_ctb", rc);
-    for (const auto& t : S.tus) if ((rc = H.record_tu(rec, &t, S.cval.data()+t.coeff_offset, S.cpos.data()+t.coeff_offset))) hip_die("record_tu", rc);
-    for (const auto& pu : S.pus) if ((rc = H.record_pu(rec, &pu))) hip_die("record_pu", rc);
-    for (const auto& pc : S.pcms) if ((rc = H.record_pcm(rec, pc.x0, pc.y0, pc.log2_cb_size, S.pcm_samples.data()+pc.sample_offset))) hip_die("record_pcm", rc);
-    if ((rc = H.record_blk_planes(rec, flags.data(), qp.data(), mot.data()))) hip_die("record_blk_planes", rc);
-    de265hip_picture* pic = NULL;
-    if ((rc = H.dpb_alloc(H.dec, slot, P.width, P.height, P.bit_depth_luma, P.bit_depth_chroma))) hip_die("dpb_alloc", rc);
-    if ((rc = H.recorder_submit(H.dec, slot, rec, &pic))) hip_die("recorder_submit", rc);
-    if ((rc = H.picture_run(H.dec, pic, DE265HIP_STAGE_FINAL))) hip_die("picture_run", rc);
-    if ((rc = H.decoder_sync(H.dec))) hip_die("decoder_sync", rc);
-    for (int c=0;c<3;c++)                                           // the GPU's picture becomes the decoder's picture
-      if ((rc = H.dpb_download(H.dec, slot, c, img->get_image_plane(c), (ptrdiff_t)img->get_image_stride(c)*img->get_bytes_per_pixel(c))))
-        hip_die("dpb_download", rc);
-    H.picture_free(pic);
-    H.recorder_free(rec);
-    S.tus.clear(); S.cval.clear(); S.cpos.clear(); S.pus.clear(); S.pcms.clear(); S.pcm_samples.clear();
+    job->slot = dpb_index_of(img) % DE265HIP_MAX_DPB_SLOTS;
+    if (scaling) job->scaling.assign(scaling, scaling + DE265HIP_SCALING_BLOB_BYTES);
+    for (int c=0;c<3;c++) { job->plane[c] = img->get_image_plane(c); job->stride_bytes[c] = (ptrdiff_t)img->get_image_stride(c)*img->get_bytes_per_pixel(c); }
+    if (H.pipeline) pipe_submit(img, job); else run_job(*job, true);
     S.n_pictures++;
     return true;
   }
@@ -270,14 +478,14 @@ bool f1_submit(de265_image* img)
   S.file.clear();
   put("F1DESC02", 8);
   put(&P,1);
-  put_i32((int)slices.size()); put_i32(nctb); put_i32((int)S.tus.size()); put_i32((int)S.cval.size());
-  put_i32((int)S.pus.size()); put_i32((int)S.pcms.size()); put_i32((int)S.pcm_samples.size());
+  put_i32((int)slices.size()); put_i32(nctb); put_i32((int)M.tus.size()); put_i32((int)M.cval.size());
+  put_i32((int)M.pus.size()); put_i32((int)M.pcms.size()); put_i32((int)M.pcm_samples.size());
   put_i32(w4); put_i32(h4); put_i32(cbw*cbh); put_i32(tbw*tbh);
   put_i32(dpb_index_of(img)); put_i32(img->PicOrderCntVal); put_i32(scaling ? 1 : 0);
   if (scaling) put(scaling, DE265HIP_SCALING_BLOB_BYTES);
   put(slices.data(), slices.size()); put(ctbs.data(), ctbs.size());
-  put(S.tus.data(), S.tus.size()); put(S.cval.data(), S.cval.size()); put(S.cpos.data(), S.cpos.size());
-  put(S.pus.data(), S.pus.size()); put(S.pcms.data(), S.pcms.size()); put(S.pcm_samples.data(), S.pcm_samples.size());
+  put(M.tus.data(), M.tus.size()); put(M.cval.data(), M.cval.size()); put(M.cpos.data(), M.cpos.size());
+  put(M.pus.data(), M.pus.size()); put(M.pcms.data(), M.pcms.size()); put(M.pcm_samples.data(), M.pcm_samples.size());
   put(flags.data(), flags.size()); put(qp.data(), qp.size()); put(mot.data(), mot.size());
   // CU/TU structure: the inputs of de265hip_derive_edge_flags
   std::vector<uint8_t> cb_log2((size_t)cbw*cbh), cb_part((size_t)cbw*cbh), tu_split((size_t)tbw*tbh);
@@ -294,13 +502,15 @@ bool f1_submit(de265_image* img)
   }
   put(cb_log2.data(), cb_log2.size()); put(cb_part.data(), cb_part.size()); put(tu_split.data(), tu_split.size());
   put_planes(img);                                     // the reference's picture before its post-filters
-  S.tus.clear(); S.cval.clear(); S.cpos.clear(); S.pus.clear(); S.pcms.clear(); S.pcm_samples.clear();
   return false;
 }
 
 void f1_picture_done(de265_image* img)
 {
-  if (hip_mode()) return;
+  if (hip_mode()) {                                    // libde265 checks the picture hash SEI right after this hook (decctx.cc:768-778)
+    if (H.pipeline && img->decctx->param_sei_check_hash) pipe_wait(img);
+    return;
+  }
   const int w4 = (img->get_width(0)+3)/4, h4 = (img->get_height(0)+3)/4;
   std::vector<uint8_t> edges((size_t)w4*h4);
   for (int y=0;y<h4;y++) for (int x=0;x<w4;x++) edges[x+y*w4] = img->get_deblk_flags(x<<2,y<<2) & 0xF0;   // as derive_edgeFlags marked them

@@ -515,3 +515,38 @@ def test_extreme_picture_sizes(dec):
             assert bad.size == 0, "%dx%d bd=%d st=%d comp %d: %d samples differ, first %s" % (w, h, bd, st, c, len(bad), tuple(bad[0]))
         for s in (0, 1, 2):
             dec.dpb_alloc(s, 64, 64, 8)                # (give the 8K slots back)
+
+
+def test_async_copy_out_overlaps_later_pictures_and_survives_slot_reuse(dec):
+    """SURVEY 8(f3), picture-level pipelining through the C ABI: pictures are enqueued back to back with
+    de265hip_dpb_download_async behind each (pinned planes from de265hip_host_alloc), nothing waits on the host until
+    the end; one slot is decoded into twice in a row, so the second picture's kernels must wait for the first one's
+    copy-out by themselves.  Every picture that arrives must be the one the oracle computes."""
+    w, h, bd = 352, 288, 10
+    refs = {0: pysynth.fill_planes(w, h, bd, 21), 1: pysynth.fill_planes(w, h, bd, 22)}
+    for s, pl in refs.items():
+        dec.dpb_alloc(s, w, h, bd); dec.upload(s, pl)
+    slots = [2, 3, 3, 4, 2, 2]                       # 3,3 and 2,2: immediate reuse of a slot whose copy-out is still in flight
+    for s in set(slots):
+        dec.dpb_alloc(s, w, h, bd); dec.upload(s, pyoracle.alloc_planes(w, h, bd))
+    sps, exps = [], []
+    for k in range(len(slots)):
+        sp = pysynth.SynthPicture(pysynth.default_config(w, h, bd, k % 3, seed=900 + k, n_slices=1 + k % 2))
+        exp = pyoracle.alloc_planes(w, h, bd)
+        pyoracle.reconstruct(sp.desc, sp.order, refs, exp)
+        sps.append(sp); exps.append(exp)
+    pics, pend = [], []
+    try:
+        for k, s in enumerate(slots):
+            pics.append(dec.build(s, sps[k].desc))
+            dec.run(pics[-1], 2)
+            pend.append(dec.download_async(s, w, h, bd))
+        for k in reversed(range(len(slots))):        # any order of waiting
+            got = pend[k].wait()
+            assert all(np.array_equal(g, e) for g, e in zip(got, exps[k])), k
+    finally:
+        dec.sync()
+        for p in pend:
+            p.free()
+        for p in pics:
+            p.free()

@@ -77,11 +77,14 @@ def test_host_helper_derives_the_edge_flags_libde265_derived(fx):
 
 
 @pytest.mark.skipif(not os.path.exists(F1_DEC), reason="recording decoder (make -C oracle f1) not built here")
+@pytest.mark.parametrize("threads", [0, 4], ids=["sequential", "4_worker_threads"])
 @pytest.mark.parametrize("fx", FIXTURES, ids=IDS)
-def test_recording_decoder_still_reproduces_the_fixture(fx):
+def test_recording_decoder_still_reproduces_the_fixture(fx, threads):
+    """threads: libde265's own worker threads (WPP rows / tiles parse concurrently, decctx.cc:976-1178): the hooks then fire
+    on several threads and the recorder's per-thread buffers must merge to exactly the sequential decode order"""
     bits = fx[:-4] + ".bin"
     with tempfile.TemporaryDirectory() as td:
-        r = subprocess.run([F1_DEC, bits], env=dict(os.environ, F1_OUT=td), capture_output=True, text=True)
+        r = subprocess.run([F1_DEC, bits], env=dict(os.environ, F1_OUT=td, F1_THREADS=str(threads)), capture_output=True, text=True)
         assert r.returncode == 0 and not r.stderr.strip(), r.stderr[-2000:]   # no warnings, SEI picture hashes (f2 streams) verified
         dumps = sorted(os.listdir(td))
         fixture = f1_stream.load_fixture(fx)
@@ -125,13 +128,16 @@ def test_gpu_replays_recorded_stream_pictures_through_the_recorder_api(fx):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(F1_DEC), reason="patched reference decoder (make -C oracle f1) did not travel")
+@pytest.mark.parametrize("mode", ["sync", "pipelined"])
 @pytest.mark.parametrize("fx", FIXTURES, ids=IDS)
-def test_libde265_decodes_the_bitstream_with_the_hip_back_end(fx):
+def test_libde265_decodes_the_bitstream_with_the_hip_back_end(fx, mode):
     """SURVEY 8(f1) end to end: the PATCHED libde265 (oracle/f1_recorder.patch: 9 lines) parses the real bitstream on the
     host - NAL, SPS/PPS, slice headers, CABAC - and every decode_TU / generate_inter_prediction_samples / post-filter call
     is replaced by the MI355X back end through de265hip_record_* -> recorder_submit -> picture_run -> dpb_download
     (F1_MODE=hip, oracle/f1_recorder.cc).  What de265_get_next_picture then hands out must be byte-identical to what
-    the unpatched CPU path decodes (the fixtures' MD5s): `dec265 --accel hip` in everything but the option parser."""
+    the unpatched CPU path decodes (the fixtures' MD5s): `dec265 --accel hip` in everything but the option parser.
+    mode "pipelined" (SURVEY 8(f3)): four libde265 worker threads parse, pictures are only enqueued on the device by a submit
+    thread, their copy-out into pinned picture memory is waited for at output time (F1_PIPELINE=1 F1_THREADS=4)."""
     from libde265_amd import backend
     assert backend.device_count() > 0
     bits = fx[:-4] + ".bin"
@@ -139,6 +145,8 @@ def test_libde265_decodes_the_bitstream_with_the_hip_back_end(fx):
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "out.yuv")
         env = dict(os.environ, F1_MODE="hip", F1_HIP_LIB=backend.SO_PATH)
+        if mode == "pipelined":
+            env.update(F1_PIPELINE="1", F1_THREADS="4", F1_CHECK_HASH="0")      # the hash check would wait for every picture at once
         r = subprocess.run([F1_DEC, bits, out], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and not r.stderr.strip(), r.stderr[-2000:]   # stderr: libde265's own SEI MD5 check (f2 streams carry the hash)
         assert r.stdout.split()[0] == str(len(fixture)), r.stdout
@@ -183,13 +191,15 @@ def test_full_size_synthetic_streams_decode_identically_with_the_hip_back_end(na
         assert r.returncode == 0 and not r.stderr.strip(), r.stderr[-2000:]
         n = int(r.stdout.split()[0])
         assert n == int(dict(a.split("=") for a in args.split())["pics"])
-        r = subprocess.run([F1_DEC, bits, hip], env=dict(env, F1_MODE="hip", F1_HIP_LIB=backend.SO_PATH), capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0 and not r.stderr.strip(), r.stderr[-2000:]
-        assert int(r.stdout.split()[0]) == n
-        a, b = open(cpu, "rb").read(), open(hip, "rb").read()
-        assert len(a) == len(b) and len(a) > 0
-        if a != b:
-            A, B = np.frombuffer(a, np.uint8), np.frombuffer(b, np.uint8)
-            first = int(np.nonzero(A != B)[0][0])
-            raise AssertionError("%s: HIP-backed decode differs from the CPU decode: %d bytes, first at offset %d of %d (picture %d)"
-                                 % (name, int((A != B).sum()), first, len(a), first // (len(a) // n)))
+        a = open(cpu, "rb").read()
+        for mode in ({}, dict(F1_PIPELINE="1", F1_THREADS="4", F1_CHECK_HASH="0")):       # synchronous; pipelined with worker threads
+            r = subprocess.run([F1_DEC, bits, hip], env=dict(env, F1_MODE="hip", F1_HIP_LIB=backend.SO_PATH, **mode), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0 and not r.stderr.strip(), r.stderr[-2000:]
+            assert int(r.stdout.split()[0]) == n
+            b = open(hip, "rb").read()
+            assert len(a) == len(b) and len(a) > 0
+            if a != b:
+                A, B = np.frombuffer(a, np.uint8), np.frombuffer(b, np.uint8)
+                first = int(np.nonzero(A != B)[0][0])
+                raise AssertionError("%s %s: HIP-backed decode differs from the CPU decode: %d bytes, first at offset %d of %d (picture %d)"
+                                     % (name, mode, int((A != B).sum()), first, len(a), first // (len(a) // n)))
