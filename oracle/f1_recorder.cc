@@ -230,7 +230,7 @@ struct Pipe {
   std::condition_variable cv;
   std::deque<std::shared_ptr<Job>> q;
   std::map<const de265_image*, std::shared_ptr<Job>> pending;       // submitted, not yet known to have landed in the image's planes
-  bool started = false;
+  bool started = false, stop = false;
 };
 Pipe PL;
 
@@ -238,7 +238,7 @@ void pipe_worker()
 {
   for (;;) {
     std::shared_ptr<Job> j;
-    { std::unique_lock<std::mutex> lk(PL.mu); PL.cv.wait(lk, []{ return !PL.q.empty(); }); j = PL.q.front(); }
+    { std::unique_lock<std::mutex> lk(PL.mu); PL.cv.wait(lk, []{ return PL.stop || !PL.q.empty(); }); if (PL.q.empty()) return; j = PL.q.front(); }
     run_job(*j, false);
     { std::lock_guard<std::mutex> lk(PL.mu); PL.q.pop_front(); j->enqueued = true; }
     PL.cv.notify_all();
@@ -248,7 +248,7 @@ void pipe_worker()
 void pipe_submit(const de265_image* img, std::shared_ptr<Job> j)
 {
   std::unique_lock<std::mutex> lk(PL.mu);
-  if (!PL.started) { PL.started = true; PL.th = std::thread(pipe_worker); PL.th.detach(); }
+  if (!PL.started) { PL.started = true; PL.stop = false; PL.th = std::thread(pipe_worker); }
   PL.cv.wait(lk, []{ return PL.q.size() < 3; });                     // bounded: at most three pictures between parser and device
   PL.q.push_back(j);
   PL.pending[img] = j;
@@ -321,6 +321,10 @@ void f1_drain()
   { std::lock_guard<std::mutex> lk(PL.mu); for (auto& kv : PL.pending) imgs.push_back(kv.first); }
   for (const de265_image* im : imgs) pipe_wait(im);
   H.decoder_sync(H.dec);
+  bool join = false;
+  { std::lock_guard<std::mutex> lk(PL.mu); if (PL.started) { PL.stop = true; PL.started = false; join = true; } }
+  PL.cv.notify_all();
+  if (join) PL.th.join();                              // the submit thread must be gone before the process tears its statics down
 }
 
 bool f1_record_tu(thread_context* tctx, int x0, int y0, int nT, int cIdx, int cuPredMode, bool cbf)

@@ -33,6 +33,11 @@ F1_DEC = os.path.join(ROOT, "oracle", "_ref", "f1_dec")
 F2_WRITER = os.path.join(ROOT, "oracle", "_ref", "f2_writer")
 
 
+def warnings_of(stderr):
+    """what the decoder printed, minus libde265's notice that a stream without WPP / tiles is decoded by one thread"""
+    return [l for l in stderr.splitlines() if l.strip() and "Cannot run decoder multi-threaded" not in l]
+
+
 def md5(planes):
     m = hashlib.md5()
     for p in planes:
@@ -85,7 +90,7 @@ def test_recording_decoder_still_reproduces_the_fixture(fx, threads):
     bits = fx[:-4] + ".bin"
     with tempfile.TemporaryDirectory() as td:
         r = subprocess.run([F1_DEC, bits], env=dict(os.environ, F1_OUT=td, F1_THREADS=str(threads)), capture_output=True, text=True)
-        assert r.returncode == 0 and not r.stderr.strip(), r.stderr[-2000:]   # no warnings, SEI picture hashes (f2 streams) verified
+        assert r.returncode == 0 and not warnings_of(r.stderr), r.stderr[-2000:]   # no warnings, SEI picture hashes (f2 streams) verified
         dumps = sorted(os.listdir(td))
         fixture = f1_stream.load_fixture(fx)
         assert len(dumps) == len(fixture)
@@ -147,8 +152,8 @@ def test_libde265_decodes_the_bitstream_with_the_hip_back_end(fx, mode):
         env = dict(os.environ, F1_MODE="hip", F1_HIP_LIB=backend.SO_PATH)
         if mode == "pipelined":
             env.update(F1_PIPELINE="1", F1_THREADS="4", F1_CHECK_HASH="0")      # the hash check would wait for every picture at once
-        r = subprocess.run([F1_DEC, bits, out], env=env, capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0 and not r.stderr.strip(), r.stderr[-2000:]   # stderr: libde265's own SEI MD5 check (f2 streams carry the hash)
+        r = subprocess.run([F1_DEC, bits, out], env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and not warnings_of(r.stderr), r.stderr[-2000:]   # stderr: libde265's own SEI MD5 check (f2 streams carry the hash)
         assert r.stdout.split()[0] == str(len(fixture)), r.stdout
         data = open(out, "rb").read()
     off = 0
@@ -193,8 +198,8 @@ def test_full_size_synthetic_streams_decode_identically_with_the_hip_back_end(na
         assert n == int(dict(a.split("=") for a in args.split())["pics"])
         a = open(cpu, "rb").read()
         for mode in ({}, dict(F1_PIPELINE="1", F1_THREADS="4", F1_CHECK_HASH="0")):       # synchronous; pipelined with worker threads
-            r = subprocess.run([F1_DEC, bits, hip], env=dict(env, F1_MODE="hip", F1_HIP_LIB=backend.SO_PATH, **mode), capture_output=True, text=True, timeout=600)
-            assert r.returncode == 0 and not r.stderr.strip(), r.stderr[-2000:]
+            r = subprocess.run([F1_DEC, bits, hip], env=dict(env, F1_MODE="hip", F1_HIP_LIB=backend.SO_PATH, **mode), capture_output=True, text=True, timeout=120)
+            assert r.returncode == 0 and not warnings_of(r.stderr), r.stderr[-2000:]
             assert int(r.stdout.split()[0]) == n
             b = open(hip, "rb").read()
             assert len(a) == len(b) and len(a) > 0
