@@ -160,6 +160,13 @@ bool hip_mode()
   return true;
 }
 
+// plain CPU decode (neither offload nor dump): the hooks stay out of the way, so that `f1_dec stream.bin` times the reference itself
+bool passive()
+{
+  static const bool p = !hip_mode() && !getenv("F1_OUT");
+  return p;
+}
+
 template <class T> void put(const T* p, size_t n) { const uint8_t* b = (const uint8_t*)p; S.file.insert(S.file.end(), b, b + n*sizeof(T)); }
 void put_i32(int32_t v) { put(&v, 1); }
 
@@ -329,6 +336,7 @@ void f1_drain()
 
 bool f1_record_tu(thread_context* tctx, int x0, int y0, int nT, int cIdx, int cuPredMode, bool cbf)
 {
+  if (passive()) return false;
   const bool intra = cuPredMode == MODE_INTRA;
   if (!intra && !cbf) return hip_mode();                          // decode_TU does nothing for it (slice.cc:3424-3488)
   de265_image* img = tctx->img;
@@ -361,6 +369,7 @@ bool f1_record_tu(thread_context* tctx, int x0, int y0, int nT, int cIdx, int cu
 
 bool f1_record_pu(const slice_segment_header* shdr, de265_image* img, int xP, int yP, int nPbW, int nPbH, const PBMotion* vi)
 {
+  if (passive()) return false;
   de265hip_pu p; memset(&p,0,sizeof(p));
   p.x = (uint16_t)xP; p.y = (uint16_t)yP; p.w = (uint8_t)nPbW; p.h = (uint8_t)nPbH;
   p.pred_flag = (uint8_t)((vi->predFlag[0]?1:0) | (vi->predFlag[1]?2:0));
@@ -376,6 +385,7 @@ bool f1_record_pu(const slice_segment_header* shdr, de265_image* img, int xP, in
 
 void f1_record_pcm(thread_context* tctx, int x0, int y0, int log2CbSize)
 {
+  if (passive()) return;
   de265_image* img = tctx->img;
   de265hip_pcm p; memset(&p,0,sizeof(p));
   p.x0 = (uint16_t)x0; p.y0 = (uint16_t)y0; p.log2_cb_size = (uint8_t)log2CbSize;
@@ -392,6 +402,7 @@ void f1_record_pcm(thread_context* tctx, int x0, int y0, int log2CbSize)
 
 bool f1_submit(de265_image* img)
 {
+  if (passive()) return false;
   const seq_parameter_set& sps = img->get_sps();
   const pic_parameter_set& pps = img->get_pps();
   const bool hip = hip_mode();
@@ -511,6 +522,7 @@ bool f1_submit(de265_image* img)
 
 void f1_picture_done(de265_image* img)
 {
+  if (passive()) return;
   if (hip_mode()) {                                    // libde265 checks the picture hash SEI right after this hook (decctx.cc:768-778)
     if (H.pipeline && img->decctx->param_sei_check_hash) pipe_wait(img);
     return;
@@ -521,7 +533,7 @@ void f1_picture_done(de265_image* img)
   put(edges.data(), edges.size());
   put_planes(img);                                     // ... and after deblocking + SAO
   const char* dir = getenv("F1_OUT");
-  if (!dir) { S.file.clear(); S.n_pictures++; return; }   // plain CPU decode (f1_dec stream.bin out.yuv): nothing to dump
+  if (!dir) return;                                    // passive()
   char name[1024];
   snprintf(name, sizeof(name), "%s/pic_%03d.f1", dir, S.n_pictures++);
   FILE* f = fopen(name, "wb");
