@@ -557,8 +557,13 @@ int de265hip_dpb_download_async(de265hip_decoder* d, int slot, int c, void* dst,
   // behind everything enqueued on the decoder's stream so far (the picture's kernels), but not in FRONT of what comes next
   HIPCHK(hipEventRecord(d->out_fence, d->stream), DE265HIP_ERROR_DECODING);
   HIPCHK(hipStreamWaitEvent(d->out_stream, d->out_fence, 0), DE265HIP_ERROR_DECODING);
-  HIPCHK(hipMemcpy2DAsync(dst, (size_t)stride_bytes, s->pl[c].ptr, s->pl[c].stride * bpp, w * bpp, h, hipMemcpyDeviceToHost, d->out_stream),
-         DE265HIP_ERROR_DECODING);
+  // rows that are contiguous on both sides leave as ONE linear DMA: enqueueing a pitched copy costs the host about 2 us per row
+  // (4.3 ms for the three planes of a 4K picture, tools/exp/e2e_profile.sh), more than the whole host stage can afford
+  if ((size_t)stride_bytes == w * bpp && s->pl[c].stride * bpp == w * bpp)
+    HIPCHK(hipMemcpyAsync(dst, s->pl[c].ptr, (size_t)w * bpp * h, hipMemcpyDeviceToHost, d->out_stream), DE265HIP_ERROR_DECODING);
+  else
+    HIPCHK(hipMemcpy2DAsync(dst, (size_t)stride_bytes, s->pl[c].ptr, s->pl[c].stride * bpp, w * bpp, h, hipMemcpyDeviceToHost, d->out_stream),
+           DE265HIP_ERROR_DECODING);
   HIPCHK(hipEventRecord(s->dl_done, d->out_stream), DE265HIP_ERROR_DECODING);
   s->dl_seq++;
   return 0;

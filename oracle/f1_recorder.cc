@@ -20,6 +20,7 @@
 #include "../include/de265_hip.h"
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <dlfcn.h>
@@ -70,9 +71,17 @@ struct State {
 };
 State S;
 
-void merge_records(PicRec& M)
+/* the main thread, picture finished, no hook running: take the per-thread buffers of the picture away (moves, no copies) */
+void take_records(std::vector<Rec>& out)
 {
   std::lock_guard<std::mutex> lk(reg_mu);
+  out.resize(all_recs.size());
+  for (size_t r=0;r<all_recs.size();r++) { out[r] = std::move(*all_recs[r]); all_recs[r]->clear(); }
+}
+
+void merge_records(std::vector<Rec>& recs, PicRec& M)
+{
+  std::vector<Rec*> all_recs; for (Rec& r : recs) all_recs.push_back(&r);
   struct Ref { uint32_t ts; uint16_t rec; uint32_t idx; };
   std::vector<Ref> order;
   auto sorted = [&](std::vector<uint32_t> Rec::* key) {
@@ -105,7 +114,7 @@ void merge_records(PicRec& M)
     M.pcm_samples.insert(M.pcm_samples.end(), R.pcm_samples.begin()+src, R.pcm_samples.begin()+src+cnt);
     M.pcms.push_back(pc);
   }
-  for (Rec* r : all_recs) r->clear();
+  recs.clear();
 }
 
 /* ---- offload mode (F1_MODE=hip): the product library, loaded at run time (this decoder never links it) ---- */
@@ -132,7 +141,8 @@ struct Hip {
   int  (*dpb_wait)(de265hip_decoder*, int);
   void* (*host_alloc)(size_t);
   void (*host_free)(void*);
-  bool pipeline = false;               // F1_PIPELINE=1: SURVEY 8(f3), see f1_submit
+  bool pipeline = false;               // F1_PIPELINE=n: SURVEY 8(f3), n worker threads between parser and device, see f1_submit
+  int n_workers = 1;
 };
 Hip H;
 
@@ -154,6 +164,7 @@ bool hip_mode()
 #undef SYM
   const char* pl = getenv("F1_PIPELINE");
   H.pipeline = pl && atoi(pl) != 0;
+  H.n_workers = H.pipeline ? std::min(8, std::max(1, atoi(pl))) : 1;
   int rc = H.decoder_new(&H.dec, -1);
   if (rc) hip_die("de265hip_decoder_new", rc);
   H.on = true;
@@ -165,6 +176,18 @@ bool passive()
 {
   static const bool p = !hip_mode() && !getenv("F1_OUT");
   return p;
+}
+
+// F1_PROFILE=1: where the host side of a picture goes (printed by f1_drain / at the last picture)
+struct Prof { double merge=0, flatten=0, edges=0, record=0, submit=0, run=0, out=0; int n=0; bool on=false, init=false; };
+Prof PR;
+bool prof_on() { if (!PR.init) { PR.init = true; const char* e = getenv("F1_PROFILE"); PR.on = e && atoi(e); } return PR.on; }
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+void prof_print()
+{
+  if (!prof_on() || !PR.n) return;
+  fprintf(stderr, "f1 profile, ms per picture over %d pictures: merge %.2f  flatten %.2f  edge flags %.2f | record_* %.2f  recorder_submit(build) %.2f  picture_run %.2f  copy-out %.2f\n",
+          PR.n, 1e3*PR.merge/PR.n, 1e3*PR.flatten/PR.n, 1e3*PR.edges/PR.n, 1e3*PR.record/PR.n, 1e3*PR.submit/PR.n, 1e3*PR.run/PR.n, 1e3*PR.out/PR.n);
 }
 
 template <class T> void put(const T* p, size_t n) { const uint8_t* b = (const uint8_t*)p; S.file.insert(S.file.end(), b, b + n*sizeof(T)); }
@@ -188,6 +211,9 @@ int dpb_index_of(const de265_image* img)
 
 /* ---- one picture on its way to the device (offload mode) ---- */
 struct Job {
+  de265_image* img = nullptr;          // its metadata stays untouched until libde265 re-allocates the DPB entry (pin_release_buffer waits)
+  std::vector<Rec> recs;               // the hooks' per-thread buffers of this picture
+  uint64_t seq = 0;                    // decode order: pictures are launched on the device in this order
   de265hip_pic_params P;
   std::vector<uint8_t> scaling;
   std::vector<de265hip_slice_params> slices;
@@ -196,27 +222,129 @@ struct Job {
   std::vector<uint8_t> flags; std::vector<int8_t> qp; std::vector<de265hip_motion> mot;
   int slot = 0;
   void* plane[3] = {nullptr,nullptr,nullptr}; ptrdiff_t stride_bytes[3] = {0,0,0};   // the decoder's own picture memory
-  bool enqueued = false;               // pipeline mode: the submit thread has put it on the device's streams
+  de265hip_recorder* rec = nullptr; de265hip_picture* pic = nullptr;
+  bool enqueued = false;               // pipeline mode: a worker has put it on the device's streams
 };
 
+/* Everything the product's frame-level interface wants to know about a parsed picture, read out of libde265's own picture
+ * metadata (image.h).  Runs on the calling thread in dump / synchronous mode and on a worker thread in pipelined mode. */
+void prepare_job(Job* job, bool hip)
+{
+  de265_image* img = job->img;
+  const seq_parameter_set& sps = img->get_sps();
+  const pic_parameter_set& pps = img->get_pps();
+  const double tp0 = now_s();
+  merge_records(job->recs, job->M);
+  const double tp1 = now_s();
+  de265hip_pic_params& P = job->P; memset(&P,0,sizeof(P));
+  P.width = sps.pic_width_in_luma_samples; P.height = sps.pic_height_in_luma_samples;
+  P.bit_depth_luma = sps.BitDepth_Y; P.bit_depth_chroma = sps.BitDepth_C; P.chroma_format_idc = sps.chroma_format_idc;
+  P.log2_ctb_size = sps.Log2CtbSizeY; P.log2_min_cb_size = sps.Log2MinCbSizeY; P.log2_min_tb_size = sps.Log2MinTrafoSize;
+  P.pcm_loop_filter_disable_flag = sps.pcm_loop_filter_disable_flag;
+  P.strong_intra_smoothing_enable_flag = sps.strong_intra_smoothing_enable_flag;
+  P.constrained_intra_pred_flag = pps.constrained_intra_pred_flag;
+  P.sample_adaptive_offset_enabled_flag = sps.sample_adaptive_offset_enabled_flag;
+  P.scaling_list_enable_flag = sps.scaling_list_enable_flag;
+  P.weighted_pred_flag = pps.weighted_pred_flag; P.weighted_bipred_flag = pps.weighted_bipred_flag;
+  P.pic_cb_qp_offset = pps.pic_cb_qp_offset; P.pic_cr_qp_offset = pps.pic_cr_qp_offset;
+  P.loop_filter_across_tiles_enabled_flag = pps.loop_filter_across_tiles_enabled_flag;
+  P.num_tile_columns = pps.num_tile_columns; P.num_tile_rows = pps.num_tile_rows;
+  for (int i=0;i<=pps.num_tile_columns && i<24;i++) P.col_bd[i] = (uint16_t)pps.colBd[i];
+  for (int i=0;i<=pps.num_tile_rows && i<24;i++) P.row_bd[i] = (uint16_t)pps.rowBd[i];
+  P.disable_deblocking = img->decctx->param_disable_deblocking;
+  P.disable_sao = img->decctx->param_disable_sao;
+
+  const int w4 = (P.width+3)/4, h4 = (P.height+3)/4, nctb = sps.PicSizeInCtbsY;
+  const uint8_t* scaling = sps.scaling_list_enable_flag ? (const uint8_t*)&pps.scaling_list : NULL;      // transform.cc:487-493
+  std::vector<de265hip_slice_params>& slices = job->slices;
+  for (slice_segment_header* h : img->slices) {
+    de265hip_slice_params s; memset(&s,0,sizeof(s));
+    s.slice_type = h->slice_type; s.slice_addr_rs = h->SliceAddrRS;
+    s.slice_deblocking_filter_disabled_flag = h->slice_deblocking_filter_disabled_flag;
+    s.slice_beta_offset = h->slice_beta_offset; s.slice_tc_offset = h->slice_tc_offset;
+    s.slice_loop_filter_across_slices_enabled_flag = h->slice_loop_filter_across_slices_enabled_flag;
+    s.slice_sao_luma_flag = h->slice_sao_luma_flag; s.slice_sao_chroma_flag = h->slice_sao_chroma_flag;
+    s.luma_log2_weight_denom = h->luma_log2_weight_denom; s.chroma_log2_weight_denom = h->ChromaLog2WeightDenom;
+    for (int l=0;l<2;l++) for (int i=0;i<16;i++) {
+      s.luma_weight[l][i] = h->LumaWeight[l][i]; s.luma_offset[l][i] = h->luma_offset[l][i];
+      for (int c=0;c<2;c++) { s.chroma_weight[l][i][c] = h->ChromaWeight[l][i][c]; s.chroma_offset[l][i][c] = h->ChromaOffset[l][i][c]; }
+      s.ref_pic_list[l][i] = (int8_t)h->RefPicList[l][i];
+    }
+    slices.push_back(s);
+  }
+  std::vector<de265hip_ctb_info>& ctbs = job->ctbs; ctbs.resize(nctb);
+  for (int a=0;a<nctb;a++) {
+    const int cx = a % sps.PicWidthInCtbsY, cy = a / sps.PicWidthInCtbsY;
+    de265hip_ctb_info ci; memset(&ci,0,sizeof(ci));
+    ci.slice_addr_rs = (uint16_t)img->get_SliceAddrRS(cx,cy);
+    ci.slice_idx = (uint16_t)img->get_SliceHeaderIndexCtb(cx,cy);
+    const sao_info* sao = img->get_sao_info(cx,cy);
+    ci.sao_type_idx = sao->SaoTypeIdx; ci.sao_eo_class = sao->SaoEoClass;
+    for (int c=0;c<3;c++) { ci.sao_band_position[c] = sao->sao_band_position[c]; for (int k=0;k<4;k++) ci.sao_offset_val[c][k] = sao->saoOffsetVal[c][k]; }
+    ctbs[a] = ci;
+  }
+  // flattened per-4x4 views (include/de265_hip.h DE265HIP_BLK_*), without the edge bits
+  std::vector<uint8_t>& flags = job->flags; std::vector<int8_t>& qp = job->qp; std::vector<de265hip_motion>& mot = job->mot;
+  flags.resize((size_t)w4*h4); qp.resize((size_t)w4*h4); mot.resize((size_t)w4*h4);
+  for (int y=0;y<h4;y++) for (int x=0;x<w4;x++) {
+    const int xl = x<<2, yl = y<<2;
+    const bool intra = img->get_pred_mode(xl,yl)==MODE_INTRA;
+    flags[x+y*w4] = (uint8_t)((intra ? DE265HIP_BLK_INTRA : 0) | (img->get_nonzero_coefficient(xl,yl) ? DE265HIP_BLK_NONZERO : 0) |
+                              (img->get_pcm_flag(xl,yl) ? DE265HIP_BLK_PCM : 0) | (img->get_cu_transquant_bypass(xl,yl) ? DE265HIP_BLK_BYPASS : 0));
+    qp[x+y*w4] = (int8_t)img->get_QPY(xl,yl);
+    de265hip_motion m; memset(&m,0,sizeof(m)); m.ref_slot[0] = m.ref_slot[1] = -1;
+    if (!intra) {
+      const PBMotion& pb = img->get_mv_info(xl,yl);
+      const slice_segment_header* sh = img->get_SliceHeader(xl,yl);
+      for (int l=0;l<2;l++) if (pb.predFlag[l] && sh) {           // deblock.cc:295-304 compares these
+        m.ref_slot[l] = (int8_t)sh->RefPicList[l][pb.refIdx[l]]; m.mv[l][0] = pb.mv[l].x; m.mv[l][1] = pb.mv[l].y;
+      }
+    }
+    mot[x+y*w4] = m;
+  }
+
+  const double tp2 = now_s();
+  if (hip) {
+    if (!P.disable_deblocking) derive_edgeFlags(img);               // cheap host code; or de265hip_derive_edge_flags
+    for (int y=0;y<h4;y++) for (int x=0;x<w4;x++) flags[x+y*w4] |= img->get_deblk_flags(x<<2,y<<2) & 0xF0;
+    if (scaling) job->scaling.assign(scaling, scaling + DE265HIP_SCALING_BLOB_BYTES);
+  }
+  static std::mutex pm; std::lock_guard<std::mutex> lk(pm);
+  PR.merge += tp1-tp0; PR.flatten += tp2-tp1; PR.edges += now_s()-tp2; PR.n++;
+}
+
 /* What an integrated libde265 does at decctx.cc:757-766 instead of run_postprocessing_filters_*: hand the recorded picture
- * to the MI355X.  wait = true: ... and wait for it (the picture is in the decoder's planes on return); wait = false
- * (SURVEY 8(f3)): only enqueue kernels and the copy-out into the (pinned) planes; f1_before_output waits for them. */
-void run_job(Job& j, bool wait)
+ * to the MI355X.  build_job: the product's recorder + host stage (any thread, several pictures at once: de265_hip.h THREADS);
+ * launch_job: kernels + copy-out, in decode order.  wait = true: ... and wait (the picture is in the decoder's planes on
+ * return); wait = false: the copy-out into the (pinned) planes is only enqueued; f1_before_output waits. */
+void build_job(Job& j)
 {
   int rc;
-  de265hip_recorder* rec = NULL;
-  if ((rc = H.recorder_new(&rec, &j.P, j.scaling.empty() ? NULL : j.scaling.data()))) hip_die("recorder_new", rc);
+  const double t0 = now_s();
+  if ((rc = H.recorder_new(&j.rec, &j.P, j.scaling.empty() ? NULL : j.scaling.data()))) hip_die("recorder_new", rc);
+  de265hip_recorder* rec = j.rec;
   for (const auto& sl : j.slices) if ((rc = H.record_slice(rec, &sl))) hip_die("record_slice", rc);
   for (size_t a=0;a<j.ctbs.size();a++) if ((rc = H.record_ctb(rec, (int)a, &j.ctbs[a]))) hip_die("record_ctb", rc);
   for (const auto& t : j.M.tus) if ((rc = H.record_tu(rec, &t, j.M.cval.data()+t.coeff_offset, j.M.cpos.data()+t.coeff_offset))) hip_die("record_tu", rc);
   for (const auto& pu : j.M.pus) if ((rc = H.record_pu(rec, &pu))) hip_die("record_pu", rc);
   for (const auto& pc : j.M.pcms) if ((rc = H.record_pcm(rec, pc.x0, pc.y0, pc.log2_cb_size, j.M.pcm_samples.data()+pc.sample_offset))) hip_die("record_pcm", rc);
   if ((rc = H.record_blk_planes(rec, j.flags.data(), j.qp.data(), j.mot.data()))) hip_die("record_blk_planes", rc);
-  de265hip_picture* pic = NULL;
-  if ((rc = H.dpb_alloc(H.dec, j.slot, j.P.width, j.P.height, j.P.bit_depth_luma, j.P.bit_depth_chroma))) hip_die("dpb_alloc", rc);
-  if ((rc = H.recorder_submit(H.dec, j.slot, rec, &pic))) hip_die("recorder_submit", rc);
-  if ((rc = H.picture_run(H.dec, pic, DE265HIP_STAGE_FINAL))) hip_die("picture_run", rc);
+  const double t1 = now_s();
+  {                                                                 // slot allocation belongs to one thread at a time
+    static std::mutex am; std::lock_guard<std::mutex> lk(am);
+    if ((rc = H.dpb_alloc(H.dec, j.slot, j.P.width, j.P.height, j.P.bit_depth_luma, j.P.bit_depth_chroma))) hip_die("dpb_alloc", rc);
+  }
+  if ((rc = H.recorder_submit(H.dec, j.slot, rec, &j.pic))) hip_die("recorder_submit", rc);
+  static std::mutex pm; std::lock_guard<std::mutex> lk(pm);
+  PR.record += t1-t0; PR.submit += now_s()-t1;
+}
+
+void launch_job(Job& j, bool wait)
+{
+  int rc;
+  const double t2 = now_s();
+  if ((rc = H.picture_run(H.dec, j.pic, DE265HIP_STAGE_FINAL))) hip_die("picture_run", rc);
+  const double t3 = now_s();
   if (wait) {
     if ((rc = H.decoder_sync(H.dec))) hip_die("decoder_sync", rc);
     for (int c=0;c<3;c++)                                           // the GPU's picture becomes the decoder's picture
@@ -225,18 +353,25 @@ void run_job(Job& j, bool wait)
     for (int c=0;c<3;c++)
       if ((rc = H.dpb_download_async(H.dec, j.slot, c, j.plane[c], j.stride_bytes[c]))) hip_die("dpb_download_async", rc);
   }
-  H.picture_free(pic);                                              // never waits: the decoder owns the device side (de265_hip.h LIFETIME)
-  H.recorder_free(rec);
+  H.picture_free(j.pic);                                            // never waits: the decoder owns the device side (de265_hip.h LIFETIME)
+  H.recorder_free(j.rec);
+  j.pic = NULL; j.rec = NULL;
+  static std::mutex pm; std::lock_guard<std::mutex> lk(pm);
+  PR.run += t3-t2; PR.out += now_s()-t3;
 }
 
-/* SURVEY 8(f3) picture-level pipelining: libde265's thread(s) parse picture n+1 while the submit thread builds picture n's
- * command buffers (de265hip_recorder_submit -> picture_build) and the device reconstructs picture n-1. */
+/* SURVEY 8(f3) picture-level pipelining: libde265's thread(s) parse picture n+1 while F1_PIPELINE worker threads turn the
+ * pictures before it into command buffers (metadata read-out, de265hip_record_*, de265hip_recorder_submit -> picture_build:
+ * the product's host stage may run for several pictures at once) and the device reconstructs the pictures before those.
+ * Pictures are LAUNCHED in decode order (a picture's kernels read the DPB slots its references were launched into). */
 struct Pipe {
-  std::thread th;
+  std::vector<std::thread> th;
   std::mutex mu;
   std::condition_variable cv;
-  std::deque<std::shared_ptr<Job>> q;
+  std::deque<std::shared_ptr<Job>> q;                                // submitted, not yet taken by a worker
   std::map<const de265_image*, std::shared_ptr<Job>> pending;       // submitted, not yet known to have landed in the image's planes
+  uint64_t next_seq = 0, next_launch = 0;
+  int in_flight = 0;                                                // taken or queued, not yet launched
   bool started = false, stop = false;
 };
 Pipe PL;
@@ -245,9 +380,12 @@ void pipe_worker()
 {
   for (;;) {
     std::shared_ptr<Job> j;
-    { std::unique_lock<std::mutex> lk(PL.mu); PL.cv.wait(lk, []{ return PL.stop || !PL.q.empty(); }); if (PL.q.empty()) return; j = PL.q.front(); }
-    run_job(*j, false);
-    { std::lock_guard<std::mutex> lk(PL.mu); PL.q.pop_front(); j->enqueued = true; }
+    { std::unique_lock<std::mutex> lk(PL.mu); PL.cv.wait(lk, []{ return PL.stop || !PL.q.empty(); }); if (PL.q.empty()) return; j = PL.q.front(); PL.q.pop_front(); }
+    prepare_job(j.get(), true);
+    build_job(*j);
+    { std::unique_lock<std::mutex> lk(PL.mu); PL.cv.wait(lk, [&]{ return PL.next_launch == j->seq; }); }
+    launch_job(*j, false);
+    { std::lock_guard<std::mutex> lk(PL.mu); PL.next_launch++; PL.in_flight--; j->enqueued = true; }
     PL.cv.notify_all();
   }
 }
@@ -255,8 +393,10 @@ void pipe_worker()
 void pipe_submit(const de265_image* img, std::shared_ptr<Job> j)
 {
   std::unique_lock<std::mutex> lk(PL.mu);
-  if (!PL.started) { PL.started = true; PL.stop = false; PL.th = std::thread(pipe_worker); }
-  PL.cv.wait(lk, []{ return PL.q.size() < 3; });                     // bounded: at most three pictures between parser and device
+  if (!PL.started) { PL.started = true; PL.stop = false; for (int i=0;i<H.n_workers;i++) PL.th.emplace_back(pipe_worker); }
+  PL.cv.wait(lk, []{ return PL.in_flight < H.n_workers + 2; });      // bounded: a few pictures between parser and device
+  j->seq = PL.next_seq++;
+  PL.in_flight++;
   PL.q.push_back(j);
   PL.pending[img] = j;
   lk.unlock();
@@ -323,7 +463,7 @@ void f1_before_output(const de265_image* img) { if (H.on && H.pipeline) pipe_wai
 
 void f1_drain()
 {
-  if (!(H.on && H.pipeline)) return;
+  if (!(H.on && H.pipeline)) { prof_print(); return; }
   std::vector<const de265_image*> imgs;
   { std::lock_guard<std::mutex> lk(PL.mu); for (auto& kv : PL.pending) imgs.push_back(kv.first); }
   for (const de265_image* im : imgs) pipe_wait(im);
@@ -331,7 +471,8 @@ void f1_drain()
   bool join = false;
   { std::lock_guard<std::mutex> lk(PL.mu); if (PL.started) { PL.stop = true; PL.started = false; join = true; } }
   PL.cv.notify_all();
-  if (join) PL.th.join();                              // the submit thread must be gone before the process tears its statics down
+  if (join) { for (auto& t : PL.th) t.join(); PL.th.clear(); }   // the workers must be gone before the process tears its statics down
+  prof_print();
 }
 
 bool f1_record_tu(thread_context* tctx, int x0, int y0, int nT, int cIdx, int cuPredMode, bool cbf)
@@ -403,92 +544,30 @@ void f1_record_pcm(thread_context* tctx, int x0, int y0, int log2CbSize)
 bool f1_submit(de265_image* img)
 {
   if (passive()) return false;
-  const seq_parameter_set& sps = img->get_sps();
-  const pic_parameter_set& pps = img->get_pps();
   const bool hip = hip_mode();
   std::shared_ptr<Job> job = std::make_shared<Job>();
-  merge_records(job->M);
-  const PicRec& M = job->M;
-  de265hip_pic_params& P = job->P; memset(&P,0,sizeof(P));
-  P.width = sps.pic_width_in_luma_samples; P.height = sps.pic_height_in_luma_samples;
-  P.bit_depth_luma = sps.BitDepth_Y; P.bit_depth_chroma = sps.BitDepth_C; P.chroma_format_idc = sps.chroma_format_idc;
-  P.log2_ctb_size = sps.Log2CtbSizeY; P.log2_min_cb_size = sps.Log2MinCbSizeY; P.log2_min_tb_size = sps.Log2MinTrafoSize;
-  P.pcm_loop_filter_disable_flag = sps.pcm_loop_filter_disable_flag;
-  P.strong_intra_smoothing_enable_flag = sps.strong_intra_smoothing_enable_flag;
-  P.constrained_intra_pred_flag = pps.constrained_intra_pred_flag;
-  P.sample_adaptive_offset_enabled_flag = sps.sample_adaptive_offset_enabled_flag;
-  P.scaling_list_enable_flag = sps.scaling_list_enable_flag;
-  P.weighted_pred_flag = pps.weighted_pred_flag; P.weighted_bipred_flag = pps.weighted_bipred_flag;
-  P.pic_cb_qp_offset = pps.pic_cb_qp_offset; P.pic_cr_qp_offset = pps.pic_cr_qp_offset;
-  P.loop_filter_across_tiles_enabled_flag = pps.loop_filter_across_tiles_enabled_flag;
-  P.num_tile_columns = pps.num_tile_columns; P.num_tile_rows = pps.num_tile_rows;
-  for (int i=0;i<=pps.num_tile_columns && i<24;i++) P.col_bd[i] = (uint16_t)pps.colBd[i];
-  for (int i=0;i<=pps.num_tile_rows && i<24;i++) P.row_bd[i] = (uint16_t)pps.rowBd[i];
-  P.disable_deblocking = img->decctx->param_disable_deblocking;
-  P.disable_sao = img->decctx->param_disable_sao;
-
-  const int w4 = (P.width+3)/4, h4 = (P.height+3)/4, nctb = sps.PicSizeInCtbsY;
-  const int cbw = sps.PicWidthInMinCbsY, cbh = sps.PicHeightInMinCbsY, tbw = sps.PicWidthInTbsY, tbh = sps.PicHeightInTbsY;
-  const uint8_t* scaling = sps.scaling_list_enable_flag ? (const uint8_t*)&pps.scaling_list : NULL;      // transform.cc:487-493
-  std::vector<de265hip_slice_params>& slices = job->slices;
-  for (slice_segment_header* h : img->slices) {
-    de265hip_slice_params s; memset(&s,0,sizeof(s));
-    s.slice_type = h->slice_type; s.slice_addr_rs = h->SliceAddrRS;
-    s.slice_deblocking_filter_disabled_flag = h->slice_deblocking_filter_disabled_flag;
-    s.slice_beta_offset = h->slice_beta_offset; s.slice_tc_offset = h->slice_tc_offset;
-    s.slice_loop_filter_across_slices_enabled_flag = h->slice_loop_filter_across_slices_enabled_flag;
-    s.slice_sao_luma_flag = h->slice_sao_luma_flag; s.slice_sao_chroma_flag = h->slice_sao_chroma_flag;
-    s.luma_log2_weight_denom = h->luma_log2_weight_denom; s.chroma_log2_weight_denom = h->ChromaLog2WeightDenom;
-    for (int l=0;l<2;l++) for (int i=0;i<16;i++) {
-      s.luma_weight[l][i] = h->LumaWeight[l][i]; s.luma_offset[l][i] = h->luma_offset[l][i];
-      for (int c=0;c<2;c++) { s.chroma_weight[l][i][c] = h->ChromaWeight[l][i][c]; s.chroma_offset[l][i][c] = h->ChromaOffset[l][i][c]; }
-      s.ref_pic_list[l][i] = (int8_t)h->RefPicList[l][i];
-    }
-    slices.push_back(s);
-  }
-  std::vector<de265hip_ctb_info>& ctbs = job->ctbs; ctbs.resize(nctb);
-  for (int a=0;a<nctb;a++) {
-    const int cx = a % sps.PicWidthInCtbsY, cy = a / sps.PicWidthInCtbsY;
-    de265hip_ctb_info ci; memset(&ci,0,sizeof(ci));
-    ci.slice_addr_rs = (uint16_t)img->get_SliceAddrRS(cx,cy);
-    ci.slice_idx = (uint16_t)img->get_SliceHeaderIndexCtb(cx,cy);
-    const sao_info* sao = img->get_sao_info(cx,cy);
-    ci.sao_type_idx = sao->SaoTypeIdx; ci.sao_eo_class = sao->SaoEoClass;
-    for (int c=0;c<3;c++) { ci.sao_band_position[c] = sao->sao_band_position[c]; for (int k=0;k<4;k++) ci.sao_offset_val[c][k] = sao->saoOffsetVal[c][k]; }
-    ctbs[a] = ci;
-  }
-  // flattened per-4x4 views (include/de265_hip.h DE265HIP_BLK_*), without the edge bits
-  std::vector<uint8_t>& flags = job->flags; std::vector<int8_t>& qp = job->qp; std::vector<de265hip_motion>& mot = job->mot;
-  flags.resize((size_t)w4*h4); qp.resize((size_t)w4*h4); mot.resize((size_t)w4*h4);
-  for (int y=0;y<h4;y++) for (int x=0;x<w4;x++) {
-    const int xl = x<<2, yl = y<<2;
-    const bool intra = img->get_pred_mode(xl,yl)==MODE_INTRA;
-    flags[x+y*w4] = (uint8_t)((intra ? DE265HIP_BLK_INTRA : 0) | (img->get_nonzero_coefficient(xl,yl) ? DE265HIP_BLK_NONZERO : 0) |
-                              (img->get_pcm_flag(xl,yl) ? DE265HIP_BLK_PCM : 0) | (img->get_cu_transquant_bypass(xl,yl) ? DE265HIP_BLK_BYPASS : 0));
-    qp[x+y*w4] = (int8_t)img->get_QPY(xl,yl);
-    de265hip_motion m; memset(&m,0,sizeof(m)); m.ref_slot[0] = m.ref_slot[1] = -1;
-    if (!intra) {
-      const PBMotion& pb = img->get_mv_info(xl,yl);
-      const slice_segment_header* sh = img->get_SliceHeader(xl,yl);
-      for (int l=0;l<2;l++) if (pb.predFlag[l] && sh) {           // deblock.cc:295-304 compares these
-        m.ref_slot[l] = (int8_t)sh->RefPicList[l][pb.refIdx[l]]; m.mv[l][0] = pb.mv[l].x; m.mv[l][1] = pb.mv[l].y;
-      }
-    }
-    mot[x+y*w4] = m;
-  }
-
+  job->img = img;
+  take_records(job->recs);
   if (hip) {
     // ---- OFFLOAD
-    if (!P.disable_deblocking) derive_edgeFlags(img);               // cheap host code; or de265hip_derive_edge_flags
-    for (int y=0;y<h4;y++) for (int x=0;x<w4;x++) flags[x+y*w4] |= img->get_deblk_flags(x<<2,y<<2) & 0xF0;
     job->slot = dpb_index_of(img) % DE265HIP_MAX_DPB_SLOTS;
-    if (scaling) job->scaling.assign(scaling, scaling + DE265HIP_SCALING_BLOB_BYTES);
     for (int c=0;c<3;c++) { job->plane[c] = img->get_image_plane(c); job->stride_bytes[c] = (ptrdiff_t)img->get_image_stride(c)*img->get_bytes_per_pixel(c); }
-    if (H.pipeline) pipe_submit(img, job); else run_job(*job, true);
+    if (H.pipeline) pipe_submit(img, job);                          // the workers prepare, build and launch; libde265 goes on parsing
+    else { prepare_job(job.get(), true); build_job(*job); launch_job(*job, true); }
     S.n_pictures++;
     return true;
   }
 
+  prepare_job(job.get(), false);
+  const seq_parameter_set& sps = img->get_sps();
+  const PicRec& M = job->M;
+  const de265hip_pic_params& P = job->P;
+  const std::vector<de265hip_slice_params>& slices = job->slices;
+  const std::vector<de265hip_ctb_info>& ctbs = job->ctbs;
+  const std::vector<uint8_t>& flags = job->flags; const std::vector<int8_t>& qp = job->qp; const std::vector<de265hip_motion>& mot = job->mot;
+  const int w4 = (P.width+3)/4, h4 = (P.height+3)/4, nctb = sps.PicSizeInCtbsY;
+  const int cbw = sps.PicWidthInMinCbsY, cbh = sps.PicHeightInMinCbsY, tbw = sps.PicWidthInTbsY, tbh = sps.PicHeightInTbsY;
+  const uint8_t* scaling = sps.scaling_list_enable_flag ? (const uint8_t*)&img->get_pps().scaling_list : NULL;
   // ---- DUMP: the description + the reference's own pictures to $F1_OUT/pic_NNN.f1
   S.file.clear();
   put("F1DESC02", 8);

@@ -142,7 +142,7 @@ def test_libde265_decodes_the_bitstream_with_the_hip_back_end(fx, mode):
     (F1_MODE=hip, oracle/f1_recorder.cc).  What de265_get_next_picture then hands out must be byte-identical to what
     the unpatched CPU path decodes (the fixtures' MD5s): `dec265 --accel hip` in everything but the option parser.
     mode "pipelined" (SURVEY 8(f3)): four libde265 worker threads parse, pictures are only enqueued on the device by a submit
-    thread, their copy-out into pinned picture memory is waited for at output time (F1_PIPELINE=1 F1_THREADS=4)."""
+    pool of three worker threads, their copy-out into pinned picture memory is waited for at output time (F1_PIPELINE=3 F1_THREADS=4)."""
     from libde265_amd import backend
     assert backend.device_count() > 0
     bits = fx[:-4] + ".bin"
@@ -151,7 +151,7 @@ def test_libde265_decodes_the_bitstream_with_the_hip_back_end(fx, mode):
         out = os.path.join(td, "out.yuv")
         env = dict(os.environ, F1_MODE="hip", F1_HIP_LIB=backend.SO_PATH)
         if mode == "pipelined":
-            env.update(F1_PIPELINE="1", F1_THREADS="4", F1_CHECK_HASH="0")      # the hash check would wait for every picture at once
+            env.update(F1_PIPELINE="3", F1_THREADS="4", F1_CHECK_HASH="0")      # the hash check would wait for every picture at once
         r = subprocess.run([F1_DEC, bits, out], env=env, capture_output=True, text=True, timeout=120)
         assert r.returncode == 0 and not warnings_of(r.stderr), r.stderr[-2000:]   # stderr: libde265's own SEI MD5 check (f2 streams carry the hash)
         assert r.stdout.split()[0] == str(len(fixture)), r.stdout
@@ -197,7 +197,7 @@ def test_full_size_synthetic_streams_decode_identically_with_the_hip_back_end(na
         n = int(r.stdout.split()[0])
         assert n == int(dict(a.split("=") for a in args.split())["pics"])
         a = open(cpu, "rb").read()
-        for mode in ({}, dict(F1_PIPELINE="1", F1_THREADS="4", F1_CHECK_HASH="0")):       # synchronous; pipelined with worker threads
+        for mode in ({}, dict(F1_PIPELINE="3", F1_THREADS="4", F1_CHECK_HASH="0")):       # synchronous; pipelined with worker threads
             r = subprocess.run([F1_DEC, bits, hip], env=dict(env, F1_MODE="hip", F1_HIP_LIB=backend.SO_PATH, **mode), capture_output=True, text=True, timeout=120)
             assert r.returncode == 0 and not warnings_of(r.stderr), r.stderr[-2000:]
             assert int(r.stdout.split()[0]) == n

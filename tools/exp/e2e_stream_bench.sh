@@ -1,7 +1,7 @@
 #!/bin/bash
 # SURVEY 8(f1)+(f2)+(f3) end to end on the GPU box: the SAME libde265 binary (oracle/_ref/f1_dec) decodes the SAME synthetic
 # 4K Main10 / 1080p bitstreams (oracle/_ref/f2_writer) (a) entirely on the host CPU, 1 and N worker threads, and (b) with every
-# reconstruction call offloaded to the MI355X, synchronous and pipelined (F1_PIPELINE=1).  Pictures/s of the decode loop, no
+# reconstruction call offloaded to the MI355X, synchronous and pipelined (F1_PIPELINE=n: n host worker threads between parser and device).  Pictures/s of the decode loop, no
 # output file, no hash check.   usage: tools/exp/e2e_stream_bench.sh [out_dir]
 set -e
 cd "$(dirname "$0")/../.."
@@ -27,8 +27,10 @@ for cfg in "4k10_B_wpp:gop=B pics=24 w=3840 h=2160 bits=10 log2ctb=6 wpp=1 md5=0
   run "cpu libde265, 1 thread" -- $TMP/$name.bin
   run "cpu libde265, $NT threads" F1_THREADS=$NT -- $TMP/$name.bin
   run "hip sync, 1 thread" F1_MODE=hip F1_HIP_LIB=$LIB -- $TMP/$name.bin
-  run "hip pipelined, 1 thread" F1_MODE=hip F1_HIP_LIB=$LIB F1_PIPELINE=1 -- $TMP/$name.bin
-  run "hip pipelined, 4 threads" F1_MODE=hip F1_HIP_LIB=$LIB F1_PIPELINE=1 F1_THREADS=4 -- $TMP/$name.bin
-  run "hip pipelined, $NT threads" F1_MODE=hip F1_HIP_LIB=$LIB F1_PIPELINE=1 F1_THREADS=$NT -- $TMP/$name.bin
+  run "hip pipelined(1), 1 thread" F1_MODE=hip F1_HIP_LIB=$LIB F1_PIPELINE=1 -- $TMP/$name.bin
+  run "hip pipelined(2), 4 threads" F1_MODE=hip F1_HIP_LIB=$LIB F1_PIPELINE=2 F1_THREADS=4 -- $TMP/$name.bin
+  run "hip pipelined(2), $NT threads" F1_MODE=hip F1_HIP_LIB=$LIB F1_PIPELINE=2 F1_THREADS=$NT -- $TMP/$name.bin
+  run "hip pipelined(4), $NT threads" F1_MODE=hip F1_HIP_LIB=$LIB F1_PIPELINE=4 F1_THREADS=$NT -- $TMP/$name.bin
+  run "hip pipelined(6), $NT threads" F1_MODE=hip F1_HIP_LIB=$LIB F1_PIPELINE=6 F1_THREADS=$NT -- $TMP/$name.bin
 done
 rm -rf "$TMP"
