@@ -31,6 +31,9 @@ void f1_picture_done(de265_image* img);
  * and launches; the copy-out into libde265's pinned planes is asynchronous) and libde265 carries on parsing; the picture is
  * waited for where somebody is about to look at it: de265_peek_next_picture (de265.cc:392) -> f1_before_output. */
 void f1_before_output(const de265_image* img);
+/* decctx.cc:1999: with SAO on, libde265 decodes into an internal picture and lets its SAO write the output picture; when the
+ * device runs SAO the decoded picture IS the output picture (and is allocated with the application's allocator) */
+bool f1_offloading();
 /* for the application (oracle/f1_dec.cc): install the pinned-memory image allocator (de265.h:325-343) before decoding, and
  * drain the pipeline before the decoder is freed */
 void f1_install_pinned_allocator(void* de265_decoder_ctx);

@@ -179,7 +179,7 @@ bool passive()
 }
 
 // F1_PROFILE=1: where the host side of a picture goes (printed by f1_drain / at the last picture)
-struct Prof { double merge=0, flatten=0, edges=0, record=0, submit=0, run=0, out=0; int n=0; bool on=false, init=false; };
+struct Prof { double merge=0, flatten=0, edges=0, record=0, submit=0, run=0, out=0, free_=0, w_out=0, w_queue=0, w_turn=0, t_first=0, t_last=0, in_submit=0; int n=0; bool on=false, init=false; };
 Prof PR;
 bool prof_on() { if (!PR.init) { PR.init = true; const char* e = getenv("F1_PROFILE"); PR.on = e && atoi(e); } return PR.on; }
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -188,6 +188,8 @@ void prof_print()
   if (!prof_on() || !PR.n) return;
   fprintf(stderr, "f1 profile, ms per picture over %d pictures: merge %.2f  flatten %.2f  edge flags %.2f | record_* %.2f  recorder_submit(build) %.2f  picture_run %.2f  copy-out %.2f\n",
           PR.n, 1e3*PR.merge/PR.n, 1e3*PR.flatten/PR.n, 1e3*PR.edges/PR.n, 1e3*PR.record/PR.n, 1e3*PR.submit/PR.n, 1e3*PR.run/PR.n, 1e3*PR.out/PR.n);
+  fprintf(stderr, "            frees %.2f  worker waits for its launch turn %.2f | parser thread: %.2f ms between two f1_submit calls, of which inside f1_submit %.2f (waiting for a free pipeline place %.2f), waiting for copy-outs %.2f\n",
+          1e3*PR.free_/PR.n, 1e3*PR.w_turn/PR.n, PR.n > 1 ? 1e3*(PR.t_last-PR.t_first)/(PR.n-1) : 0.0, 1e3*PR.in_submit/PR.n, 1e3*PR.w_queue/PR.n, 1e3*PR.w_out/PR.n);
 }
 
 template <class T> void put(const T* p, size_t n) { const uint8_t* b = (const uint8_t*)p; S.file.insert(S.file.end(), b, b + n*sizeof(T)); }
@@ -353,11 +355,19 @@ void launch_job(Job& j, bool wait)
     for (int c=0;c<3;c++)
       if ((rc = H.dpb_download_async(H.dec, j.slot, c, j.plane[c], j.stride_bytes[c]))) hip_die("dpb_download_async", rc);
   }
+  static std::mutex pm; std::lock_guard<std::mutex> lk(pm);
+  PR.run += t3-t2; PR.out += now_s()-t3;
+}
+
+void free_job(Job& j)
+{
+  const double t0 = now_s();
   H.picture_free(j.pic);                                            // never waits: the decoder owns the device side (de265_hip.h LIFETIME)
   H.recorder_free(j.rec);
   j.pic = NULL; j.rec = NULL;
+  j.M = PicRec(); j.flags = std::vector<uint8_t>(); j.qp = std::vector<int8_t>(); j.mot = std::vector<de265hip_motion>();
   static std::mutex pm; std::lock_guard<std::mutex> lk(pm);
-  PR.run += t3-t2; PR.out += now_s()-t3;
+  PR.free_ += now_s()-t0;
 }
 
 /* SURVEY 8(f3) picture-level pipelining: libde265's thread(s) parse picture n+1 while F1_PIPELINE worker threads turn the
@@ -383,10 +393,11 @@ void pipe_worker()
     { std::unique_lock<std::mutex> lk(PL.mu); PL.cv.wait(lk, []{ return PL.stop || !PL.q.empty(); }); if (PL.q.empty()) return; j = PL.q.front(); PL.q.pop_front(); }
     prepare_job(j.get(), true);
     build_job(*j);
-    { std::unique_lock<std::mutex> lk(PL.mu); PL.cv.wait(lk, [&]{ return PL.next_launch == j->seq; }); }
+    { const double t0 = now_s(); std::unique_lock<std::mutex> lk(PL.mu); PL.cv.wait(lk, [&]{ return PL.next_launch == j->seq; }); PR.w_turn += now_s()-t0; }
     launch_job(*j, false);
     { std::lock_guard<std::mutex> lk(PL.mu); PL.next_launch++; PL.in_flight--; j->enqueued = true; }
     PL.cv.notify_all();
+    free_job(*j);
   }
 }
 
@@ -394,7 +405,7 @@ void pipe_submit(const de265_image* img, std::shared_ptr<Job> j)
 {
   std::unique_lock<std::mutex> lk(PL.mu);
   if (!PL.started) { PL.started = true; PL.stop = false; for (int i=0;i<H.n_workers;i++) PL.th.emplace_back(pipe_worker); }
-  PL.cv.wait(lk, []{ return PL.in_flight < H.n_workers + 2; });      // bounded: a few pictures between parser and device
+  { const double t0 = now_s(); PL.cv.wait(lk, []{ return PL.in_flight < H.n_workers + 2; }); PR.w_queue += now_s()-t0; }   // bounded: a few pictures between parser and device
   j->seq = PL.next_seq++;
   PL.in_flight++;
   PL.q.push_back(j);
@@ -412,10 +423,14 @@ void pipe_wait(const de265_image* img)
     if (it == PL.pending.end()) return;
     j = it->second;
     PL.pending.erase(it);
+    const double t0 = now_s();
     PL.cv.wait(lk, [&]{ return j->enqueued; });
+    PR.w_out += now_s()-t0;
   }
+  const double t0 = now_s();
   int rc = H.dpb_wait(H.dec, j->slot);
   if (rc) hip_die("dpb_wait", rc);
+  PR.w_out += now_s()-t0;
 }
 
 /* pinned picture memory for libde265 (de265.h:325-343), pooled: libde265 releases and re-requests the planes of a DPB entry
@@ -458,6 +473,8 @@ void f1_install_pinned_allocator(void* ctx)
   static de265_image_allocation a = { pin_get_buffer, pin_release_buffer };
   de265_set_image_allocation_functions(ctx, &a, NULL);
 }
+
+bool f1_offloading() { return hip_mode(); }
 
 void f1_before_output(const de265_image* img) { if (H.on && H.pipeline) pipe_wait(img); }
 
@@ -545,6 +562,10 @@ bool f1_submit(de265_image* img)
 {
   if (passive()) return false;
   const bool hip = hip_mode();
+  const double ts0 = now_s();
+  if (!PR.t_first) PR.t_first = ts0;
+  PR.t_last = ts0;
+  struct InSubmit { double t0; ~InSubmit() { PR.in_submit += now_s()-t0; } } in_submit{ts0};
   std::shared_ptr<Job> job = std::make_shared<Job>();
   job->img = img;
   take_records(job->recs);
@@ -553,7 +574,7 @@ bool f1_submit(de265_image* img)
     job->slot = dpb_index_of(img) % DE265HIP_MAX_DPB_SLOTS;
     for (int c=0;c<3;c++) { job->plane[c] = img->get_image_plane(c); job->stride_bytes[c] = (ptrdiff_t)img->get_image_stride(c)*img->get_bytes_per_pixel(c); }
     if (H.pipeline) pipe_submit(img, job);                          // the workers prepare, build and launch; libde265 goes on parsing
-    else { prepare_job(job.get(), true); build_job(*job); launch_job(*job, true); }
+    else { prepare_job(job.get(), true); build_job(*job); launch_job(*job, true); free_job(*job); }
     S.n_pictures++;
     return true;
   }
