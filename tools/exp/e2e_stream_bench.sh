@@ -18,9 +18,9 @@ run() { # label env... -- stream
   printf "%-34s %8.2f pictures/s\n" "$label" "$best" | tee -a "$OUT/e2e.txt"
 }
 : > "$OUT/e2e.txt"
-for cfg in "4k10_B_wpp:gop=B pics=24 w=3840 h=2160 bits=10 log2ctb=6 wpp=1 md5=0 seed=31" \
-           "4k10_B_wpp_dense:gop=B pics=16 w=3840 h=2160 bits=10 log2ctb=6 wpp=1 md5=0 dens=90 max_level=60 seed=32" \
-           "1080p8_B_wpp:gop=B pics=32 w=1920 h=1080 log2ctb=6 wpp=1 md5=0 seed=33"; do
+for cfg in "4k10_B_wpp:gop=B pics=96 w=3840 h=2160 bits=10 log2ctb=6 wpp=1 md5=0 seed=31" \
+           "4k10_B_wpp_dense:gop=B pics=64 w=3840 h=2160 bits=10 log2ctb=6 wpp=1 md5=0 dens=90 max_level=60 seed=32" \
+           "1080p8_B_wpp:gop=B pics=128 w=1920 h=1080 log2ctb=6 wpp=1 md5=0 seed=33"; do
   name=${cfg%%:*}; args=${cfg#*:}
   $WR out=$TMP/$name.bin $args
   echo "== $name ($args; $(stat -c %s $TMP/$name.bin) bytes)" | tee -a "$OUT/e2e.txt"
