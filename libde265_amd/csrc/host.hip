@@ -75,6 +75,7 @@ struct de265hip_decoder {
                                       // against 22 + 27.5 us alone, but no gain in the bench (3 streams 6 320 vs 6 400 frames/s, 1 stream equal):
                                       // both filters are bound by VALU issue (811 / 377 VALU instructions per wavefront, tools/exp/pmc_insts.sh),
                                       // not by the passes over memory the fusion removes, and the tile kernel needs 137 VGPRs + 20 KB of LDS
+  bool sao_strips = false;            // DE265HIP_SAO_STRIPS=1: k_sao (a wavefront along one row pair) instead of the CTB-local k_sao_ctb
   bool separate_bs = false;           // DE265HIP_SEPARATE_BS: bS by its own kernel instead of inside the deblocking kernels
   int dbg = 0;                        // DE265HIP_DEBUG: timing-only ablations of k_run (results invalid)
   bool intra_levels = false;          // DE265HIP_INTRA_MODE=levels: one launch per dependency level
@@ -451,6 +452,7 @@ int de265hip_decoder_new(de265hip_decoder** out, int device)
   d->intra_levels = mode && !strcmp(mode, "levels");
   if (const char* dbg = getenv("DE265HIP_DEBUG")) d->dbg = atoi(dbg);
   if (const char* e = getenv("DE265HIP_SEPARATE_BS")) d->separate_bs = atoi(e) != 0;
+  if (const char* e = getenv("DE265HIP_SAO_STRIPS")) d->sao_strips = atoi(e) != 0;
   if (const char* e = getenv("DE265HIP_TWO_PASS_DEBLOCK")) d->two_pass_deblock = atoi(e) != 0;
   if (const char* e = getenv("DE265HIP_LF_TILE")) d->lf_tile = atoi(e) != 0;
   if (const char* e = getenv("DE265HIP_RESID16_BIG")) d->resid16_big = atoi(e) != 0;
@@ -1518,8 +1520,17 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
     SaoMeta M{ pic->d_flags, pic->d_sao };
     {
       KTimer t(dec, DE265HIP_K_SAO, 1);
-      hipLaunchKernelGGL(k_sao<PX>, dim3((P.width / 8 + 4 * SAO_GROUPS * 62 - 1) / (4 * SAO_GROUPS * 62), (P.height + SAO_ROWS - 1) / SAO_ROWS, 3), dim3(256), 0, st, P, d0, d1, d2,
-                         sp.pl[0], sp.pl[1], sp.pl[2], M);
+      if (dec->sao_strips)
+        hipLaunchKernelGGL(k_sao<PX>, dim3((P.width / 8 + 4 * SAO_GROUPS * 62 - 1) / (4 * SAO_GROUPS * 62), (P.height + SAO_ROWS - 1) / SAO_ROWS, 3), dim3(256), 0, st, P, d0, d1, d2,
+                           sp.pl[0], sp.pl[1], sp.pl[2], M);
+      else {
+        // luma tile geometry (chroma tiles are half as wide and twice as high: the grid covers both, surplus tiles return)
+        const int lsw = std::min(3, P.log2_ctb - 3), tw = 8 << lsw, th = (64 >> lsw) * SAO_ROWS;
+        const int lswc = std::min(3, P.log2_ctb - 4), twc = 8 << lswc, thc = (64 >> lswc) * SAO_ROWS;
+        const int gx = std::max((P.width + tw - 1) / tw, (P.width / 2 + twc - 1) / twc);
+        const int gy = std::max((P.height + 4 * th - 1) / (4 * th), (P.height / 2 + 4 * thc - 1) / (4 * thc));
+        hipLaunchKernelGGL(k_sao_ctb<PX>, dim3(gx, gy, 3), dim3(256), 0, st, P, d0, d1, d2, sp.pl[0], sp.pl[1], sp.pl[2], M);
+      }
     }
     for (int c = 0; c < 3; c++) std::swap(dst.pl[c], sp.pl[c]);      // output picture now lives in the slot
   }

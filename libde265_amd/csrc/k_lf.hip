@@ -791,6 +791,73 @@ void k_sao(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, PlaneRe
     sao_strip<PX, true>(P, M, dst, dstride, comp, cs, width, height, lane, x0[g], y0, inpic[g], ctbshift, w[g], R[g], SaoNb());
 }
 
+// CTB-local lane mapping (default; k_sao above stays as the parity variant DE265HIP_SAO_STRIPS=1).  k_sao lays the 62 useful
+// lanes of a wavefront along one row pair, i.e. across eight 64-sample CTBs: SaoTypeIdx / the edge class differ from CTB to CTB,
+// so every wavefront executes the copy, the band AND the edge path (377 VALU instructions per wavefront, tools/exp/pmc_insts.sh:
+// the kernel is bound by instruction issue, not by HBM).  Here a wavefront is a tile SW strips wide and 64/SW row pairs high with
+// SW = min(8, CTB width / 8): 64x16 luma / 32x32 chroma samples of ONE CTB for 64x64 CTBs (one CTB, 32x32, for 32x32 luma CTBs), so the
+// type is wavefront-uniform and only one of the three paths is executed.  Left / right neighbours come from the adjacent lanes
+// by DPP row shifts (SW divides 16: lane-1 / lane+1 of an inner strip lie in the same DPP row); the strips on the tile's left and
+// right edge fetch the one sample beyond it themselves: one divergent block of four 2-byte loads, issued together with the rows.
+template <typename PX>
+__global__ __launch_bounds__(256, SAO_WAVES)
+void k_sao_ctb(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, PlaneRef d1, PlaneRef d2, SaoMeta M)
+{
+  const int comp = blockIdx.z, cs = comp ? 1 : 0;
+  const int width = P.width >> cs, height = P.height >> cs;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ctbshift = P.log2_ctb - cs;
+  const int lsw = min(3, ctbshift - 3);                         // log2 strips per tile row (CTB 16 chroma: one strip)
+  const int sx = lane & ((1 << lsw) - 1), sy = lane >> lsw;
+  const int tw = 8 << lsw, th = (64 >> lsw) * SAO_ROWS;         // tile size in samples
+  const int x0 = blockIdx.x * tw + sx * 8;
+  const int y0 = (blockIdx.y * 4 + wave) * th + sy * SAO_ROWS;
+  const PlaneRef sp = comp == 0 ? s0 : (comp == 1 ? s1 : s2);
+  const PlaneRef dp = comp == 0 ? d0 : (comp == 1 ? d1 : d2);
+  const PX* src = (const PX*)sp.ptr;
+  const int sstride = sp.stride;
+  const bool inpic = x0 < width && y0 < height;
+  const int ctbX = min(x0 >> ctbshift, P.ctbs_w - 1), ctbY = min(y0 >> ctbshift, P.ctbs_h - 1);
+  SaoRec w;
+  {
+    const uint2* q = reinterpret_cast<const uint2*>(&M.sao[ctbX + ctbY * P.ctbs_w]);
+    const uint2 q0 = q[0], q1 = q[1], q2 = q[2];
+    w.w[0] = q0.x; w.w[1] = q0.y; w.w[2] = q1.x; w.w[3] = q1.y; w.w[4] = q2.x; w.w[5] = q2.y;
+  }
+  SaoRows R;
+  const int xc = min(x0, (width - 1) & ~7);                      // all loads unconditional, addresses clamped (see k_sao)
+  int yr[SAO_ROWS + 2];
+#pragma unroll
+  for (int j = 0; j < SAO_ROWS + 2; j++) { yr[j] = min(max(y0 - 1 + j, 0), height - 1); R.r[j] = load8_pk<PX>(src + xc + yr[j] * sstride); }
+  uint32_t halo[SAO_ROWS + 2];
+#pragma unroll
+  for (int j = 0; j < SAO_ROWS + 2; j++) halo[j] = 0;
+  const bool first = sx == 0, last = sx == (1 << lsw) - 1;
+  if (first || last) {
+    // (a one-strip tile needs both: the right one then goes through a second block; tiles that narrow exist for 16x16 chroma CTBs only)
+    const int xh = first ? max(xc - 1, 0) : min(xc + 8, width - 1);
+#pragma unroll
+    for (int j = 0; j < SAO_ROWS + 2; j++) halo[j] = src[xh + yr[j] * sstride];
+  }
+  uint32_t halo2[SAO_ROWS + 2];
+#pragma unroll
+  for (int j = 0; j < SAO_ROWS + 2; j++) halo2[j] = 0;
+  if (lsw == 0) {
+    const int xh = min(xc + 8, width - 1);
+#pragma unroll
+    for (int j = 0; j < SAO_ROWS + 2; j++) halo2[j] = src[xh + yr[j] * sstride];
+  }
+  SaoNb nb;
+#pragma unroll
+  for (int j = 0; j < SAO_ROWS + 2; j++) {
+    const uint32_t pw = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)R.r[j].w, 0x111, 0xf, 0xf, false);   // row_shr:1 -> lane-1's (v6, v7)
+    const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)R.r[j].x, 0x101, 0xf, 0xf, false);   // row_shl:1 -> lane+1's (v0, v1)
+    nb.l[j] = first ? halo[j] : pw >> 16;
+    nb.r[j] = last ? (lsw == 0 ? halo2[j] : halo[j]) : nx;
+  }
+  sao_strip<PX, false>(P, M, (PX*)dp.ptr, dp.stride, comp, cs, width, height, lane, x0, y0, inpic, ctbshift, w, R, nb);
+}
+
 // ---------------------------------------------------------------- deblocking + SAO in one pass over the picture
 // One workgroup per LF_TW x LF_TH tile of a component: (0) the tile and a ring around it - the 8x8 deblocking blocks that
 // overlap it by 4 samples plus what SAO's 3x3 neighbourhood needs - are staged in LDS as 16-bit samples with coalesced
@@ -887,5 +954,7 @@ template __global__ void k_lf_tile<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRe
 
 template __global__ void k_sao<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, SaoMeta);
 template __global__ void k_sao<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, SaoMeta);
+template __global__ void k_sao_ctb<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, SaoMeta);
+template __global__ void k_sao_ctb<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, SaoMeta);
 
 }  // namespace d265

@@ -58,6 +58,8 @@ template <typename PX>
 __global__ void k_deblock_fused(PicDev, PlaneRef, PlaneRef, PlaneRef, LfMeta);
 template <typename PX>
 __global__ void k_sao(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, SaoMeta);
+template <typename PX>
+__global__ void k_sao_ctb(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, SaoMeta);
 #ifndef LF_TW
 #define LF_TW 128                        // tile of k_lf_tile (deblocking + SAO in one pass), luma / chroma samples alike
 #endif

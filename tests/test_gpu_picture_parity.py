@@ -343,7 +343,7 @@ def test_recorder_submit_matches_oracle(dec):
 @pytest.mark.parametrize("env", [{"DE265HIP_RUN_WAVES": "1"}, {"DE265HIP_RUN_WAVES": "2"}, {"DE265HIP_NO_MICRO": "1"},
                                  {"DE265HIP_MICRO_TUS": "4"}, {"DE265HIP_TICKET_BATCH": "4"}, {"DE265HIP_SEPARATE_BS": "1"},
                                  {"DE265HIP_TWO_PASS_DEBLOCK": "1"}, {"DE265HIP_MICRO16": "0"}, {"DE265HIP_RESID16_BIG": "1"}, {"DE265HIP_RESID_ONE_LAUNCH": "0"},
-                                 {"DE265HIP_LF_TILE": "1"}, {"DE265HIP_NO_MERGE": "1"}, {"DE265HIP_RUN_DIRECT": "1"}])
+                                 {"DE265HIP_LF_TILE": "1"}, {"DE265HIP_NO_MERGE": "1"}, {"DE265HIP_RUN_DIRECT": "1"}, {"DE265HIP_SAO_STRIPS": "1"}])
 def test_run_kernel_schedule_variants(env):
     """k_run's schedule knobs (wavefronts per workgroup, micro runs on/off, tickets per draw) only change who does what when: every variant is bit-exact against the oracle."""
     import os
