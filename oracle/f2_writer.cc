@@ -54,6 +54,7 @@ struct Cfg {
   int deblock = 1, lf_slices = 1, cabac_init = 1, lists_mod = 0, merge_cand = 5, par_mrg = 2;
   int nref = 2, max_level = 24, big_mv = 1;
   int wpp = 0, tile_cols = 1, tile_rows = 1, tile_uniform = 1, lf_tiles = 1, md5 = 1;
+  int scaling = 0;                    /* 1: scaling lists on, default lists (sps); 2: explicit lists in the PPS (7.3.4 scaling_list_data) */
   int dens = 50;                      /* percent: how often cbf flags are set */
 };
 
@@ -68,7 +69,7 @@ const Kv KV[] = {
   {"deblock",&Cfg::deblock},{"lf_slices",&Cfg::lf_slices},{"cabac_init",&Cfg::cabac_init},{"lists_mod",&Cfg::lists_mod},
   {"merge_cand",&Cfg::merge_cand},{"par_mrg",&Cfg::par_mrg},{"nref",&Cfg::nref},{"max_level",&Cfg::max_level},
   {"big_mv",&Cfg::big_mv},{"dens",&Cfg::dens},{"wpp",&Cfg::wpp},{"tile_cols",&Cfg::tile_cols},{"tile_rows",&Cfg::tile_rows},
-  {"tile_uniform",&Cfg::tile_uniform},{"lf_tiles",&Cfg::lf_tiles},{"md5",&Cfg::md5},
+  {"tile_uniform",&Cfg::tile_uniform},{"lf_tiles",&Cfg::lf_tiles},{"md5",&Cfg::md5},{"scaling",&Cfg::scaling},
 };
 
 [[noreturn]] void die(const char* msg) { fprintf(stderr, "f2_writer: %s\n", msg); exit(2); }
@@ -184,6 +185,7 @@ struct Writer {
       sps->pcm_loop_filter_disable_flag = c.pcm_lf_off;
     }
     sps->sps_temporal_mvp_enabled_flag = c.tmvp; sps->strong_intra_smoothing_enable_flag = c.strong;
+    sps->scaling_list_enable_flag = c.scaling ? 1 : 0; sps->sps_scaling_list_data_present_flag = 0;   /* default lists unless the PPS sends its own */
     if (sps->compute_derived_values() != DE265_OK) die("sps: invalid parameters");
 
     pps = std::make_shared<pic_parameter_set>();
@@ -218,8 +220,54 @@ struct Writer {
 
     nal_begin(NAL_UNIT_VPS_NUT); vps->write(&errq, hdr); hdr.add_trailing_bits(); hdr.flush_VLC(); nal_end(-1,false);
     nal_begin(NAL_UNIT_SPS_NUT); sps->write(&errq, hdr); hdr.add_trailing_bits(); hdr.flush_VLC(); nal_end(-1,false);
-    nal_begin(NAL_UNIT_PPS_NUT); pps->write(&errq, hdr, sps.get()); hdr.add_trailing_bits(); hdr.flush_VLC(); nal_end(-1,false);
+    nal_begin(NAL_UNIT_PPS_NUT);
+    if (c.scaling == 2) write_pps_with_scaling_lists(); else pps->write(&errq, hdr, sps.get());
+    hdr.add_trailing_bits(); hdr.flush_VLC(); nal_end(-1,false);
 
+  }
+
+  /* pps.cc:276 pic_parameter_set::read, field by field (the reference's write() cannot emit scaling_list_data: sps.cc:979 is a stub),
+     with pic_scaling_list_data_present_flag = 1 and random lists: explicit coefficients, copies of earlier lists and default lists */
+  void write_pps_with_scaling_lists()
+  {
+    const pic_parameter_set& p = *pps;
+    hdr.write_uvlc(p.pic_parameter_set_id); hdr.write_uvlc(p.seq_parameter_set_id);
+    hdr.write_bit(p.dependent_slice_segments_enabled_flag); hdr.write_bit(p.output_flag_present_flag); hdr.write_bits(p.num_extra_slice_header_bits,3);
+    hdr.write_bit(p.sign_data_hiding_flag); hdr.write_bit(p.cabac_init_present_flag);
+    hdr.write_uvlc(p.num_ref_idx_l0_default_active-1); hdr.write_uvlc(p.num_ref_idx_l1_default_active-1);
+    hdr.write_svlc(p.pic_init_qp-26); hdr.write_bit(p.constrained_intra_pred_flag); hdr.write_bit(p.transform_skip_enabled_flag);
+    hdr.write_bit(p.cu_qp_delta_enabled_flag); if (p.cu_qp_delta_enabled_flag) hdr.write_uvlc(p.diff_cu_qp_delta_depth);
+    hdr.write_svlc(p.pic_cb_qp_offset); hdr.write_svlc(p.pic_cr_qp_offset); hdr.write_bit(p.pps_slice_chroma_qp_offsets_present_flag);
+    hdr.write_bit(p.weighted_pred_flag); hdr.write_bit(p.weighted_bipred_flag); hdr.write_bit(p.transquant_bypass_enable_flag);
+    hdr.write_bit(p.tiles_enabled_flag); hdr.write_bit(p.entropy_coding_sync_enabled_flag);
+    if (p.tiles_enabled_flag) {
+      hdr.write_uvlc(p.num_tile_columns-1); hdr.write_uvlc(p.num_tile_rows-1); hdr.write_bit(p.uniform_spacing_flag);
+      if (!p.uniform_spacing_flag) { for (int i=0;i<p.num_tile_columns-1;i++) hdr.write_uvlc(p.colWidth[i]-1); for (int i=0;i<p.num_tile_rows-1;i++) hdr.write_uvlc(p.rowHeight[i]-1); }
+      hdr.write_bit(p.loop_filter_across_tiles_enabled_flag);
+    }
+    hdr.write_bit(p.pps_loop_filter_across_slices_enabled_flag);
+    hdr.write_bit(p.deblocking_filter_control_present_flag);
+    if (p.deblocking_filter_control_present_flag) {
+      hdr.write_bit(p.deblocking_filter_override_enabled_flag); hdr.write_bit(p.pic_disable_deblocking_filter_flag);
+      if (!p.pic_disable_deblocking_filter_flag) { hdr.write_svlc(p.beta_offset/2); hdr.write_svlc(p.tc_offset/2); }
+    }
+    hdr.write_bit(1);                                               /* pic_scaling_list_data_present_flag */
+    for (int sizeId=0;sizeId<4;sizeId++)                            /* sps.cc:770 read_scaling_list */
+      for (int matrixId=0; matrixId<(sizeId==3 ? 2 : 6); matrixId++) {
+        const bool explicit_list = rng.pct(60);
+        hdr.write_bit(explicit_list);                               /* scaling_list_pred_mode_flag */
+        if (!explicit_list) { hdr.write_uvlc(rng.below(matrixId+1)); continue; }   /* pred_matrix_id_delta: 0 = default list, else copy an earlier one */
+        int next = 8;
+        if (sizeId > 1) { const int dc = rng.range(1,200); hdr.write_svlc(dc-8); next = dc; }
+        for (int i=0;i<(sizeId==0 ? 16 : 64);i++) {
+          int v = std::min(255, std::max(1, next + rng.range(-12,14)));       /* the list entries must stay in 1..255 */
+          if (rng.pct(3)) v = rng.range(1,255);
+          int d = v - next; if (d > 127) d -= 256; if (d < -128) d += 256;
+          hdr.write_svlc(d); next = v;
+        }
+      }
+    hdr.write_bit(p.lists_modification_present_flag); hdr.write_uvlc(p.log2_parallel_merge_level-2);
+    hdr.write_bit(p.slice_segment_header_extension_present_flag); hdr.write_bit(0);   /* pps_extension_flag */
   }
 
   /* ---------- block state ---------- */

@@ -174,6 +174,7 @@ FULL_SIZE = [
     ("1080p8_B_wp_2slices", "gop=B pics=5 w=1920 h=1080 log2ctb=6 slices=2 wp=1 seed=11"),
     ("1080p8_LDB_ctb16_3refs", "gop=LDB pics=4 w=1920 h=1080 log2ctb=4 log2maxtb=4 nref=3 slices=5 sdh=1 tskip=1 seed=12"),
     ("1080p8_P_tiles_wpp_off", "gop=P pics=3 w=1920 h=1080 log2ctb=5 tile_cols=5 tile_rows=3 tile_uniform=0 slices=4 seed=14"),
+    ("1080p8_B_scaling_lists", "gop=B pics=3 w=1920 h=1080 log2ctb=5 scaling=2 seed=16"),
     ("4k10_B", "gop=B pics=4 w=3840 h=2160 bits=10 log2ctb=6 seed=13"),
     ("4k10_B_wpp", "gop=B pics=3 w=3840 h=2160 bits=10 log2ctb=6 wpp=1 slices=2 seed=15"),
 ]
