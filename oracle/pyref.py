@@ -37,11 +37,12 @@ def build(force=False):
 
 
 def build_f1():
-    """make -C oracle f1: the RECORDING decoder (reference + f1_recorder.patch + f1_recorder.cc) and the reference's encoder
-    CLI, both only where the reference sources exist.  Returns the decoder's path or None."""
+    """make -C oracle f1 f2: the patched (recording / offloading) decoder (reference + f1_recorder.patch + f1_recorder.cc), the
+    reference's encoder CLI and the synthetic bitstream writer (f2_writer.cc), only where the reference sources exist.
+    Returns the decoder's path or None."""
     exe = os.path.join(_HERE, "_ref", "f1_dec")
     if can_build():
-        subprocess.check_call(["make", "-s", "-j8", "-C", _HERE, "f1", "REF=" + REF_ROOT])
+        subprocess.check_call(["make", "-s", "-j8", "-C", _HERE, "f1", "f2", "REF=" + REF_ROOT])
     return exe if os.path.exists(exe) else None
 
 
