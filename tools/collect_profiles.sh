@@ -10,17 +10,17 @@ out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
-python3 bench.py --streams 1 --no-cpu-baseline --no-host-inclusive > $out/bench_1stream.json 2> $out/bench_1stream.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats3 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-inclusive \
+python3 bench.py --streams 1 --no-cpu-baseline --no-host-inclusive --no-e2e > $out/bench_1stream.json 2> $out/bench_1stream.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats3 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-inclusive --no-e2e \
   > $out/bench_under_rocprof_3streams.json 2> $out/stats3.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1 -- python3 bench.py --streams 1 --steps 3 --warmup 1 --no-cpu-baseline --no-host-inclusive \
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1 -- python3 bench.py --streams 1 --steps 3 --warmup 1 --no-cpu-baseline --no-host-inclusive --no-e2e \
   > $out/bench_under_rocprof_1stream.json 2> $out/stats1.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --streams 1 --steps 2 --warmup 1 --no-cpu-baseline --no-host-inclusive \
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --streams 1 --steps 2 --warmup 1 --no-cpu-baseline --no-host-inclusive --no-e2e \
   > $out/pmc_fetch.json 2> $out/pmc_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --streams 1 --steps 2 --warmup 1 --no-cpu-baseline --no-host-inclusive \
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --streams 1 --steps 2 --warmup 1 --no-cpu-baseline --no-host-inclusive --no-e2e \
   > $out/pmc_write.json 2> $out/pmc_write.err
 python3 tools/pmc_summary.py $out/pmc_fetch $out/pmc_write $out/pmc_traffic.json \
-  "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --streams 1 --steps 2 --warmup 1 --no-cpu-baseline --no-host-inclusive (two separate passes)" > /dev/null
+  "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --streams 1 --steps 2 --warmup 1 --no-cpu-baseline --no-host-inclusive --no-e2e (two separate passes)" > /dev/null
 # keep the merged-back payload small: the per-dispatch traces are not needed, only the stats
 find $out -name "*kernel_trace.csv" -delete
 find $out -name "*counter_collection.csv" -delete
