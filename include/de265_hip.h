@@ -310,6 +310,26 @@ int  de265hip_record_blk_planes(de265hip_recorder*, const uint8_t* blk_flags, co
 const de265hip_picture_desc* de265hip_recorder_desc(de265hip_recorder*);
 int  de265hip_recorder_submit(de265hip_decoder*, int dst_slot, de265hip_recorder*, de265hip_picture** out);
 
+/* ---- pipeline: picture-level pipelining (the reference's parallel host side is decctx.cc:976-1178).
+ * While the host parser works on picture n+1, `n_workers` threads owned by the pipeline run this library's host stage for the
+ * pictures before it - `prepare` (the integration fills a recorder from what its parser left behind: it is called on a worker
+ * thread, several pictures at once) and de265hip_recorder_submit (= de265hip_picture_build) - and the device reconstructs the
+ * pictures before those.  Pictures are LAUNCHED in submission order (a picture's kernels read the DPB slots its references were
+ * launched into): de265hip_picture_run(STAGE_FINAL) + de265hip_dpb_download_async of every non-NULL `planes[c]` (pinned memory,
+ * de265hip_host_alloc; strides as in de265hip_dpb_download).  submit() returns as soon as there is room (at most n_workers + 2
+ * pictures between parser and device); nobody waits for a picture until de265hip_pipeline_wait(ticket) - what a decoder calls
+ * when the picture is about to be output or read (de265.cc:392 de265_peek_next_picture).  While a pipeline exists, run / dpb_* /
+ * sync of its decoder belong to the pipeline; dpb_alloc of slots no queued picture uses is allowed.  An error of prepare, build
+ * or run is returned by wait() of that ticket (or by drain()).  oracle/f1_recorder.cc is the libde265-side user. ---- */
+typedef struct de265hip_pipeline de265hip_pipeline;
+typedef int (*de265hip_prepare_fn)(void* user, de265hip_recorder** out);   /* 0 and a filled recorder (the pipeline frees it) */
+int  de265hip_pipeline_new(de265hip_pipeline** out, de265hip_decoder*, int n_workers /* 1..16 */);
+int  de265hip_pipeline_submit(de265hip_pipeline*, int dst_slot, de265hip_prepare_fn prepare, void* user,
+                              void* const planes[3], const ptrdiff_t stride_bytes[3], uint64_t* ticket);
+int  de265hip_pipeline_wait(de265hip_pipeline*, uint64_t ticket);
+int  de265hip_pipeline_drain(de265hip_pipeline*);          /* every submitted picture launched, finished and copied out */
+void de265hip_pipeline_free(de265hip_pipeline*);           /* drains first */
+
 /* Profiling aid: the host stage of de265hip_picture_build `reps` times, without a GPU and without any HIP call. */
 int  de265hip_debug_build_host_only(const de265hip_picture_desc*, int reps);
 /* FNV-1a hash over everything the last de265hip_debug_build_host_only of this thread would have uploaded (regression

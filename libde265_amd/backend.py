@@ -20,6 +20,7 @@ EXPORTS = [
     "de265hip_decoder_new", "de265hip_decoder_free",
     "de265hip_dpb_alloc", "de265hip_dpb_upload", "de265hip_dpb_download", "de265hip_dpb_plane", "de265hip_dpb_info",
     "de265hip_dpb_copy", "de265hip_dpb_download_async", "de265hip_dpb_wait", "de265hip_host_alloc", "de265hip_host_free",
+    "de265hip_pipeline_new", "de265hip_pipeline_submit", "de265hip_pipeline_wait", "de265hip_pipeline_drain", "de265hip_pipeline_free",
     "de265hip_debug_build_host_only", "de265hip_debug_last_build_hash",
     "de265hip_picture_build", "de265hip_picture_run", "de265hip_decoder_sync", "de265hip_picture_free",
     "de265hip_decode_picture", "de265hip_picture_get_stats",
@@ -40,6 +41,10 @@ class De265HipError(RuntimeError):
 
 
 _lib = None
+
+
+# de265hip_prepare_fn: int (*)(void* user, de265hip_recorder** out)
+PREPARE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_void_p))
 
 
 def lib():
@@ -68,6 +73,12 @@ def lib():
     L.de265hip_host_alloc.restype = vp
     L.de265hip_host_free.argtypes = [vp]
     L.de265hip_host_free.restype = None
+    L.de265hip_pipeline_new.argtypes = [pp(vp), vp, i32]
+    L.de265hip_pipeline_submit.argtypes = [vp, i32, PREPARE_FN, vp, pp(vp), pp(C.c_ssize_t), pp(C.c_uint64)]
+    L.de265hip_pipeline_wait.argtypes = [vp, C.c_uint64]
+    L.de265hip_pipeline_drain.argtypes = [vp]
+    L.de265hip_pipeline_free.argtypes = [vp]
+    L.de265hip_pipeline_free.restype = None
     L.de265hip_debug_build_host_only.argtypes = [pp(_abi.PictureDesc), i32]
     L.de265hip_debug_last_build_hash.restype = C.c_uint64
     L.de265hip_debug_last_build_hash.argtypes = []
@@ -136,6 +147,69 @@ class Picture:
             self.free()
         except Exception:
             pass
+
+
+class Pipeline:
+    """the C ABI's picture pipeline (de265hip_pipeline_*): pictures are prepared + built on worker threads and
+    launched in submission order; submit(slot, make_recorder, planes) -> ticket, wait(ticket)."""
+
+    def __init__(self, dec, n_workers=2):
+        self._dec, self._h, self._keep = dec, C.c_void_p(), {}
+        _chk(lib().de265hip_pipeline_new(C.byref(self._h), dec._h, n_workers), "pipeline_new")
+
+    def submit(self, slot, make_recorder, pinned=None):
+        """make_recorder() -> backend.Recorder, called on a pipeline worker thread; pinned: _PinnedPlanes or None"""
+        def cb(user, out):
+            try:
+                rec = make_recorder()
+                out[0] = rec._h.value
+                rec._h = C.c_void_p()                 # the pipeline frees it
+                return 0
+            except Exception:                          # noqa: BLE001 - reported through the C error path
+                return _abi.ERROR_DECODING if hasattr(_abi, "ERROR_DECODING") else 1
+        fn = PREPARE_FN(cb)
+        planes = (C.c_void_p * 3)(*(pinned.ptrs if pinned else [None] * 3))
+        strides = (C.c_ssize_t * 3)(*(pinned.strides if pinned else [0] * 3))
+        t = C.c_uint64()
+        _chk(lib().de265hip_pipeline_submit(self._h, slot, fn, None, planes, strides, C.byref(t)), "pipeline_submit")
+        self._keep[t.value] = (fn, planes, strides)   # the callback object must outlive the call on the worker thread
+        return t.value
+
+    def wait(self, ticket):
+        _chk(lib().de265hip_pipeline_wait(self._h, ticket), "pipeline_wait")
+        self._keep.pop(ticket, None)
+
+    def drain(self):
+        _chk(lib().de265hip_pipeline_drain(self._h), "pipeline_drain")
+        self._keep.clear()
+
+    def close(self):
+        if self._h:
+            lib().de265hip_pipeline_free(self._h)
+            self._h = C.c_void_p()
+            self._keep.clear()
+
+
+class PinnedPlanes:
+    """three planes in de265hip_host_alloc memory (numpy views in .planes), for asynchronous copy-outs"""
+
+    def __init__(self, width, height, bit_depth):
+        dt = np.uint16 if bit_depth > 8 else np.uint8
+        self.ptrs, self.planes, self.strides = [], [], []
+        for sh in [(height, width), (height // 2, width // 2), (height // 2, width // 2)]:
+            nbytes = sh[0] * sh[1] * np.dtype(dt).itemsize
+            ptr = lib().de265hip_host_alloc(nbytes)
+            if not ptr:
+                raise MemoryError("de265hip_host_alloc(%d)" % nbytes)
+            self.ptrs.append(ptr)
+            self.strides.append(sh[1] * np.dtype(dt).itemsize)
+            self.planes.append(np.frombuffer((C.c_uint8 * nbytes).from_address(ptr), dt).reshape(sh))
+
+    def free(self):
+        self.planes = []
+        for ptr in self.ptrs:
+            lib().de265hip_host_free(ptr)
+        self.ptrs = []
 
 
 class _PendingDownload:

@@ -141,6 +141,12 @@ struct Hip {
   int  (*dpb_wait)(de265hip_decoder*, int);
   void* (*host_alloc)(size_t);
   void (*host_free)(void*);
+  int  (*pipeline_new)(de265hip_pipeline**, de265hip_decoder*, int);
+  int  (*pipeline_submit)(de265hip_pipeline*, int, de265hip_prepare_fn, void*, void* const*, const ptrdiff_t*, uint64_t*);
+  int  (*pipeline_wait)(de265hip_pipeline*, uint64_t);
+  int  (*pipeline_drain)(de265hip_pipeline*);
+  void (*pipeline_free)(de265hip_pipeline*);
+  de265hip_pipeline* pipe = nullptr;
   bool pipeline = false;               // F1_PIPELINE=n: SURVEY 8(f3), n worker threads between parser and device, see f1_submit
   int n_workers = 1;
 };
@@ -161,6 +167,7 @@ bool hip_mode()
   SYM(decoder_new); SYM(dpb_alloc); SYM(dpb_download); SYM(recorder_new); SYM(recorder_free); SYM(record_tu); SYM(record_pu);
   SYM(record_pcm); SYM(record_slice); SYM(record_ctb); SYM(record_blk_planes); SYM(recorder_submit); SYM(picture_run);
   SYM(decoder_sync); SYM(picture_free); SYM(dpb_download_async); SYM(dpb_wait); SYM(host_alloc); SYM(host_free);
+  SYM(pipeline_new); SYM(pipeline_submit); SYM(pipeline_wait); SYM(pipeline_drain); SYM(pipeline_free);
 #undef SYM
   const char* pl = getenv("F1_PIPELINE");
   H.pipeline = pl && atoi(pl) != 0;
@@ -370,66 +377,59 @@ void free_job(Job& j)
   PR.free_ += now_s()-t0;
 }
 
-/* SURVEY 8(f3) picture-level pipelining: libde265's thread(s) parse picture n+1 while F1_PIPELINE worker threads turn the
- * pictures before it into command buffers (metadata read-out, de265hip_record_*, de265hip_recorder_submit -> picture_build:
- * the product's host stage may run for several pictures at once) and the device reconstructs the pictures before those.
- * Pictures are LAUNCHED in decode order (a picture's kernels read the DPB slots its references were launched into). */
-struct Pipe {
-  std::vector<std::thread> th;
-  std::mutex mu;
-  std::condition_variable cv;
-  std::deque<std::shared_ptr<Job>> q;                                // submitted, not yet taken by a worker
-  std::map<const de265_image*, std::shared_ptr<Job>> pending;       // submitted, not yet known to have landed in the image's planes
-  uint64_t next_seq = 0, next_launch = 0;
-  int in_flight = 0;                                                // taken or queued, not yet launched
-  bool started = false, stop = false;
-};
-Pipe PL;
+/* SURVEY 8(f3) picture-level pipelining = the product's own pipeline (include/de265_hip.h de265hip_pipeline_*): libde265's
+ * thread(s) parse picture n+1 while F1_PIPELINE worker threads of the library call prepare_cb (metadata read-out + de265hip_record_*)
+ * and build the pictures before it, and the device reconstructs the pictures before those; launches happen in decode order. */
+struct Pend { std::shared_ptr<Job> job; uint64_t ticket; };
+std::mutex pend_mu;
+std::map<const de265_image*, Pend> pending;            // submitted, not yet known to have landed in the image's planes
 
-void pipe_worker()
+int prepare_cb(void* user, de265hip_recorder** out)
 {
-  for (;;) {
-    std::shared_ptr<Job> j;
-    { std::unique_lock<std::mutex> lk(PL.mu); PL.cv.wait(lk, []{ return PL.stop || !PL.q.empty(); }); if (PL.q.empty()) return; j = PL.q.front(); PL.q.pop_front(); }
-    prepare_job(j.get(), true);
-    build_job(*j);
-    { const double t0 = now_s(); std::unique_lock<std::mutex> lk(PL.mu); PL.cv.wait(lk, [&]{ return PL.next_launch == j->seq; }); PR.w_turn += now_s()-t0; }
-    launch_job(*j, false);
-    { std::lock_guard<std::mutex> lk(PL.mu); PL.next_launch++; PL.in_flight--; j->enqueued = true; }
-    PL.cv.notify_all();
-    free_job(*j);
-  }
+  Job& j = *(Job*)user;
+  prepare_job(&j, true);
+  int rc;
+  const double t0 = now_s();
+  de265hip_recorder* rec = NULL;
+  if ((rc = H.recorder_new(&rec, &j.P, j.scaling.empty() ? NULL : j.scaling.data()))) return rc;
+  for (const auto& sl : j.slices) if ((rc = H.record_slice(rec, &sl))) return rc;
+  for (size_t a=0;a<j.ctbs.size();a++) if ((rc = H.record_ctb(rec, (int)a, &j.ctbs[a]))) return rc;
+  for (const auto& t : j.M.tus) if ((rc = H.record_tu(rec, &t, j.M.cval.data()+t.coeff_offset, j.M.cpos.data()+t.coeff_offset))) return rc;
+  for (const auto& pu : j.M.pus) if ((rc = H.record_pu(rec, &pu))) return rc;
+  for (const auto& pc : j.M.pcms) if ((rc = H.record_pcm(rec, pc.x0, pc.y0, pc.log2_cb_size, j.M.pcm_samples.data()+pc.sample_offset))) return rc;
+  if ((rc = H.record_blk_planes(rec, j.flags.data(), j.qp.data(), j.mot.data()))) return rc;
+  j.M = PicRec(); j.flags = std::vector<uint8_t>(); j.qp = std::vector<int8_t>(); j.mot = std::vector<de265hip_motion>();
+  *out = rec;
+  static std::mutex pm; std::lock_guard<std::mutex> lk(pm);
+  PR.record += now_s()-t0;
+  return 0;
 }
 
 void pipe_submit(const de265_image* img, std::shared_ptr<Job> j)
 {
-  std::unique_lock<std::mutex> lk(PL.mu);
-  if (!PL.started) { PL.started = true; PL.stop = false; for (int i=0;i<H.n_workers;i++) PL.th.emplace_back(pipe_worker); }
-  { const double t0 = now_s(); PL.cv.wait(lk, []{ return PL.in_flight < H.n_workers + 2; }); PR.w_queue += now_s()-t0; }   // bounded: a few pictures between parser and device
-  j->seq = PL.next_seq++;
-  PL.in_flight++;
-  PL.q.push_back(j);
-  PL.pending[img] = j;
-  lk.unlock();
-  PL.cv.notify_all();
+  int rc;
+  if (!H.pipe && (rc = H.pipeline_new(&H.pipe, H.dec, H.n_workers))) hip_die("pipeline_new", rc);
+  uint64_t ticket = 0;
+  const double t0 = now_s();
+  if ((rc = H.pipeline_submit(H.pipe, j->slot, prepare_cb, j.get(), j->plane, j->stride_bytes, &ticket))) hip_die("pipeline_submit", rc);
+  PR.w_queue += now_s()-t0;
+  std::lock_guard<std::mutex> lk(pend_mu);
+  pending[img] = Pend{ j, ticket };
 }
 
 void pipe_wait(const de265_image* img)
 {
-  std::shared_ptr<Job> j;
+  Pend p;
   {
-    std::unique_lock<std::mutex> lk(PL.mu);
-    auto it = PL.pending.find(img);
-    if (it == PL.pending.end()) return;
-    j = it->second;
-    PL.pending.erase(it);
-    const double t0 = now_s();
-    PL.cv.wait(lk, [&]{ return j->enqueued; });
-    PR.w_out += now_s()-t0;
+    std::lock_guard<std::mutex> lk(pend_mu);
+    auto it = pending.find(img);
+    if (it == pending.end()) return;
+    p = it->second;
+    pending.erase(it);
   }
   const double t0 = now_s();
-  int rc = H.dpb_wait(H.dec, j->slot);
-  if (rc) hip_die("dpb_wait", rc);
+  int rc = H.pipeline_wait(H.pipe, p.ticket);
+  if (rc) hip_die("pipeline_wait", rc);
   PR.w_out += now_s()-t0;
 }
 
@@ -481,14 +481,13 @@ void f1_before_output(const de265_image* img) { if (H.on && H.pipeline) pipe_wai
 void f1_drain()
 {
   if (!(H.on && H.pipeline)) { prof_print(); return; }
-  std::vector<const de265_image*> imgs;
-  { std::lock_guard<std::mutex> lk(PL.mu); for (auto& kv : PL.pending) imgs.push_back(kv.first); }
-  for (const de265_image* im : imgs) pipe_wait(im);
-  H.decoder_sync(H.dec);
-  bool join = false;
-  { std::lock_guard<std::mutex> lk(PL.mu); if (PL.started) { PL.stop = true; PL.started = false; join = true; } }
-  PL.cv.notify_all();
-  if (join) { for (auto& t : PL.th) t.join(); PL.th.clear(); }   // the workers must be gone before the process tears its statics down
+  if (H.pipe) {
+    int rc = H.pipeline_drain(H.pipe);
+    if (rc) hip_die("pipeline_drain", rc);
+    H.pipeline_free(H.pipe);                             // joins the workers before the process tears its statics down
+    H.pipe = nullptr;
+  }
+  { std::lock_guard<std::mutex> lk(pend_mu); pending.clear(); }
   prof_print();
 }
 

@@ -550,3 +550,42 @@ def test_async_copy_out_overlaps_later_pictures_and_survives_slot_reuse(dec):
             p.free()
         for p in pics:
             p.free()
+
+
+def test_pipeline_builds_concurrently_and_launches_in_order(dec):
+    """SURVEY 8(f3) through the C ABI's own pipeline (de265hip_pipeline_*): a chain of pictures in which every picture
+    predicts from the one before it (its DPB slot) is submitted without waiting; three worker threads prepare and build them
+    concurrently, the pipeline launches them in submission order and copies each out into pinned planes.  Every picture must be
+    what the oracle computes from the ORACLE's own chain of reference pictures - any launch out of order would read a slot too early."""
+    from libde265_amd import backend
+    w, h, bd = 352, 288, 10
+    n = 7
+    first = pysynth.fill_planes(w, h, bd, 31)
+    dec.dpb_alloc(0, w, h, bd); dec.upload(0, first)
+    for s in range(1, n + 1):
+        dec.dpb_alloc(s, w, h, bd)
+    sps, exps, prev = [], [], first
+    for k in range(n):
+        # a P picture whose only reference is slot k = where picture k-1 is decoded into (picture k goes into slot k+1)
+        sp = pysynth.SynthPicture(pysynth.default_config(w, h, bd, 1, seed=950 + k, ref_slots=[k]))
+        exp = pyoracle.alloc_planes(w, h, bd)
+        pyoracle.reconstruct(sp.desc, sp.order, {k: prev}, exp)
+        sps.append(sp); exps.append(exp); prev = exp
+    pipe = backend.Pipeline(dec, 3)
+    pins = [backend.PinnedPlanes(w, h, bd) for _ in range(n)]
+    try:
+        tickets = []
+        for k in range(n):
+            def make(k=k):
+                rec = backend.Recorder(sps[k].desc.params, None)
+                rec.record_desc(sps[k].desc)
+                return rec
+            tickets.append(pipe.submit(k + 1, make, pins[k]))
+        for k in reversed(range(n)):
+            pipe.wait(tickets[k])
+            assert all(np.array_equal(g, e) for g, e in zip(pins[k].planes, exps[k])), k
+        pipe.drain()
+    finally:
+        pipe.close()
+        for p in pins:
+            p.free()
