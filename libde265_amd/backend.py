@@ -165,8 +165,10 @@ class Pipeline:
                 out[0] = rec._h.value
                 rec._h = C.c_void_p()                 # the pipeline frees it
                 return 0
-            except Exception:                          # noqa: BLE001 - reported through the C error path
-                return _abi.ERROR_DECODING if hasattr(_abi, "ERROR_DECODING") else 1
+            except Exception:                          # noqa: BLE001 - reported through the C error path (pipeline_wait of this ticket)
+                import traceback
+                traceback.print_exc()
+                return 18
         fn = PREPARE_FN(cb)
         planes = (C.c_void_p * 3)(*(pinned.ptrs if pinned else [None] * 3))
         strides = (C.c_ssize_t * 3)(*(pinned.strides if pinned else [0] * 3))

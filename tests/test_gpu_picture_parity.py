@@ -577,8 +577,10 @@ def test_pipeline_builds_concurrently_and_launches_in_order(dec):
         tickets = []
         for k in range(n):
             def make(k=k):
-                rec = backend.Recorder(sps[k].desc.params, None)
-                rec.record_desc(sps[k].desc)
+                d = sps[k].d
+                sf = np.ctypeslib.as_array(d.scaling_factors, shape=(_abi.SCALING_BLOB_BYTES,)).copy() if d.params.scaling_list_enable_flag else None
+                rec = backend.Recorder(d.params, sf)
+                rec.record_desc(d)
                 return rec
             tickets.append(pipe.submit(k + 1, make, pins[k]))
         for k in reversed(range(n)):
