@@ -54,6 +54,7 @@ struct Cfg {
   int deblock = 1, lf_slices = 1, cabac_init = 1, lists_mod = 0, merge_cand = 5, par_mrg = 2;
   int nref = 2, max_level = 24, big_mv = 1;
   int wpp = 0, tile_cols = 1, tile_rows = 1, tile_uniform = 1, lf_tiles = 1, md5 = 1;
+  int dep = 0;                        /* percent: a cut point inside a slice starts a DEPENDENT slice segment (7.3.6.1, 9.3.1) */
   int scaling = 0;                    /* 1: scaling lists on, default lists (sps); 2: explicit lists in the PPS (7.3.4 scaling_list_data) */
   int dens = 50;                      /* percent: how often cbf flags are set */
 };
@@ -69,7 +70,7 @@ const Kv KV[] = {
   {"deblock",&Cfg::deblock},{"lf_slices",&Cfg::lf_slices},{"cabac_init",&Cfg::cabac_init},{"lists_mod",&Cfg::lists_mod},
   {"merge_cand",&Cfg::merge_cand},{"par_mrg",&Cfg::par_mrg},{"nref",&Cfg::nref},{"max_level",&Cfg::max_level},
   {"big_mv",&Cfg::big_mv},{"dens",&Cfg::dens},{"wpp",&Cfg::wpp},{"tile_cols",&Cfg::tile_cols},{"tile_rows",&Cfg::tile_rows},
-  {"tile_uniform",&Cfg::tile_uniform},{"lf_tiles",&Cfg::lf_tiles},{"md5",&Cfg::md5},{"scaling",&Cfg::scaling},
+  {"tile_uniform",&Cfg::tile_uniform},{"lf_tiles",&Cfg::lf_tiles},{"md5",&Cfg::md5},{"scaling",&Cfg::scaling},{"dep",&Cfg::dep},
 };
 
 [[noreturn]] void die(const char* msg) { fprintf(stderr, "f2_writer: %s\n", msg); exit(2); }
@@ -202,6 +203,7 @@ struct Writer {
     pps->beta_offset = c.deblock ? 2*rng.range(-3,3) : 0; pps->tc_offset = c.deblock ? 2*rng.range(-3,3) : 0;
     pps->lists_modification_present_flag = c.lists_mod; pps->log2_parallel_merge_level = c.par_mrg;
     pps->entropy_coding_sync_enabled_flag = c.wpp;
+    pps->dependent_slice_segments_enabled_flag = c.dep ? 1 : 0;
     W4 = (c.w+3)/4; H4 = (c.h+3)/4;
     ctbW = (c.w + (1<<c.log2ctb) - 1) >> c.log2ctb; ctbH = (c.h + (1<<c.log2ctb) - 1) >> c.log2ctb; nCtb = ctbW*ctbH;
     if (c.tile_cols > 1 || c.tile_rows > 1) {
@@ -294,7 +296,7 @@ struct Writer {
     hdr.write_bit(slice_idx==0);                                    /* first_slice_segment_in_pic_flag */
     if (nal_type >= 16 && nal_type <= 23) hdr.write_bit(0);         /* no_output_of_prior_pics_flag */
     hdr.write_uvlc(0);                                              /* slice_pic_parameter_set_id */
-    if (slice_idx) { int nb = 0; while ((1<<nb) < nCtb) nb++; hdr.write_bits(addr, nb); }
+    if (slice_idx) { if (c.dep) hdr.write_bit(0); int nb = 0; while ((1<<nb) < nCtb) nb++; hdr.write_bits(addr, nb); }   /* dependent_slice_segment_flag = 0 */
     hdr.write_uvlc(slice_type);
     bool tmvp = false;
     if (!p.idr) {
@@ -349,6 +351,20 @@ struct Writer {
     S.type = slice_type; S.addr = addr;
     S.init_type = slice_type==SLICE_TYPE_I ? 0 : slice_type==SLICE_TYPE_P ? (cabac_init_flag ? 2 : 1) : (cabac_init_flag ? 1 : 2);
     models.init(S.init_type, S.qp);
+    cab.reset();
+    cab.set_context_models(&models);
+    cab.init_CABAC();
+  }
+
+  /* a dependent slice segment: everything but the address is inherited from the slice's first segment (slice.cc:372-395) */
+  void write_dependent_segment_header(int addr, int nal_type)
+  {
+    hdr.write_bit(0);                                               /* first_slice_segment_in_pic_flag */
+    if (nal_type >= 16 && nal_type <= 23) hdr.write_bit(0);         /* no_output_of_prior_pics_flag */
+    hdr.write_uvlc(0);                                              /* slice_pic_parameter_set_id */
+    hdr.write_bit(1);                                               /* dependent_slice_segment_flag */
+    int nb = 0; while ((1<<nb) < nCtb) nb++;
+    hdr.write_bits(addr, nb);
     cab.reset();
     cab.set_context_models(&models);
     cab.init_CABAC();
@@ -921,41 +937,62 @@ struct Writer {
     std::sort(start.begin(), start.end());
     const int ns = (int)start.size();
     std::vector<context_model_table> wpp_saved(ctbH);
+    context_model_table seg_end;                              /* 9.3.2.2 TableStateIdxDs: the contexts at the end of the previous slice segment */
+    int n_nal = 0;
     for (int s=0;s<ns;s++) {
       const int end = s+1<ns ? start[s+1] : nCtb, addr0 = pps->CtbAddrTStoRS[start[s]];
       int type = p.type;
       if (type != SLICE_TYPE_I && ns>1 && rng.pct(15)) type = SLICE_TYPE_I;      /* an intra slice inside an inter picture */
       if (type == SLICE_TYPE_B && ns>1 && rng.pct(20)) type = SLICE_TYPE_P;
-      nal_begin(nal_type);
-      write_slice_header(p, neg, pos, nu, pu, s, addr0, type, nal_type);
-      std::vector<int> sub_end;
-      for (int ts=start[s]; ts<end; ts++) {
-        const int a = pps->CtbAddrTStoRS[ts], cx = a % ctbW, cy = a / ctbW;
-        if (ts > start[s]) {                                  /* slice.cc:4664-4690 / 5050-5075: what a new substream starts from */
-          if (pps->tiles_enabled_flag && pps->TileId[ts] != pps->TileId[ts-1]) models.init(S.init_type, S.qp);
-          else if (c.wpp && cx == 0) { if (ctbW > 1) models = wpp_saved[cy-1].copy(); else models.init(S.init_type, S.qp); }
+      /* the slice's segments: the first is independent, every further one (cut at the same kind of place slices may start) dependent */
+      std::vector<int> seg = {start[s]};
+      if (c.dep)
+        for (int ts=start[s]+1; ts<end; ts++) {
+          const int rs = pps->CtbAddrTStoRS[ts];
+          const bool ok = pps->tiles_enabled_flag ? pps->TileId[ts] != pps->TileId[ts-1] : (!c.wpp || rs % ctbW == 0);
+          if (ok && rng.pct(c.wpp || pps->tiles_enabled_flag ? c.dep : std::max(1, c.dep/8))) seg.push_back(ts);
         }
-        ctb_slice[a] = addr0;
-        if (S.sao_luma || S.sao_chroma) code_sao(cx,cy);
-        code_quadtree(cx<<c.log2ctb, cy<<c.log2ctb, c.log2ctb, 0);
-        if (c.wpp && cx == 1) wpp_saved[cy] = models.copy();  /* 9.3.2.2: storage after the second CTB of a row */
-        const bool last = ts == end-1;
-        cab.write_CABAC_term_bit(last);                       /* end_of_slice_segment_flag */
-        if (!last) {
-          const int an = pps->CtbAddrTStoRS[ts+1];
-          const bool sub = (pps->tiles_enabled_flag && pps->TileId[ts+1] != pps->TileId[ts]) || (c.wpp && an / ctbW != cy);
-          if (sub) {                                          /* end_of_subset_one_bit, byte_alignment(), CABAC restart */
-            cab.write_CABAC_term_bit(1);
-            cab.flush_CABAC(); cab.write_bit(1); cab.write_bits(0, cab.number_free_bits_in_byte()); cab.flush_VLC();
-            sub_end.push_back(cab.size());
-            cab.init_CABAC();
+      for (size_t g=0; g<seg.size(); g++) {
+        const int s0 = seg[g], s1 = g+1<seg.size() ? seg[g+1] : end;
+        nal_begin(nal_type);
+        if (g == 0) write_slice_header(p, neg, pos, nu, pu, n_nal, addr0, type, nal_type);
+        else {
+          write_dependent_segment_header(pps->CtbAddrTStoRS[s0], nal_type);
+          /* slice.cc:4834-4889: a tile start initialises, otherwise the contexts of the previous segment's end carry on */
+          if (pps->tiles_enabled_flag && pps->TileId[s0] != pps->TileId[s0-1]) models.init(S.init_type, S.qp);
+          else models = seg_end.copy();
+        }
+        n_nal++;
+        std::vector<int> sub_end;
+        for (int ts=s0; ts<s1; ts++) {
+          const int a = pps->CtbAddrTStoRS[ts], cx = a % ctbW, cy = a / ctbW;
+          if (ts > s0 || g > 0) {                             /* slice.cc:4664-4690 / 5050-5075: what a new substream starts from */
+            if (ts > s0 && pps->tiles_enabled_flag && pps->TileId[ts] != pps->TileId[ts-1]) models.init(S.init_type, S.qp);
+            else if (c.wpp && cx == 0 && cy > 0) { if (ctbW > 1) models = wpp_saved[cy-1].copy(); else models.init(S.init_type, S.qp); }
+          }
+          ctb_slice[a] = addr0;
+          if (S.sao_luma || S.sao_chroma) code_sao(cx,cy);
+          code_quadtree(cx<<c.log2ctb, cy<<c.log2ctb, c.log2ctb, 0);
+          if (c.wpp && cx == 1) wpp_saved[cy] = models.copy();  /* 9.3.2.2: storage after the second CTB of a row */
+          const bool last = ts == s1-1;
+          cab.write_CABAC_term_bit(last);                     /* end_of_slice_segment_flag */
+          if (!last) {
+            const int an = pps->CtbAddrTStoRS[ts+1];
+            const bool sub = (pps->tiles_enabled_flag && pps->TileId[ts+1] != pps->TileId[ts]) || (c.wpp && an / ctbW != cy);
+            if (sub) {                                        /* end_of_subset_one_bit, byte_alignment(), CABAC restart */
+              cab.write_CABAC_term_bit(1);
+              cab.flush_CABAC(); cab.write_bit(1); cab.write_bits(0, cab.number_free_bits_in_byte()); cab.flush_VLC();
+              sub_end.push_back(cab.size());
+              cab.init_CABAC();
+            }
           }
         }
+        seg_end = models.copy();
+        cab.flush_CABAC(); cab.add_trailing_bits(); cab.flush_VLC();
+        sub_end.push_back(cab.size());
+        finish_slice_header(sub_end);
+        nal_end((int)k, true);
       }
-      cab.flush_CABAC(); cab.add_trailing_bits(); cab.flush_VLC();
-      sub_end.push_back(cab.size());
-      finish_slice_header(sub_end);
-      nal_end((int)k, true);
     }
     /* what the decoder must find in this picture if it stayed in sync with every bin (tools/f2_check.py) */
     fprintf(fchk, "pic %zu poc %d cus %ld pus %ld pcms %ld resid %ld coeffs %ld abs_sum %ld\n", k, p.poc, st.n_cus, st.n_pus, st.n_pcms, st.n_resid, st.n_coeffs, st.abs_sum);

@@ -20,6 +20,7 @@ CONFIGS = {
     "hier_b_10bit_weighted_slices": "gop=B pics=5 w=192 h=128 bits=10 wp=1 slices=3 log2ctb=6",
     "ldb_wpp_scaling_lists": "gop=LDB pics=3 w=256 h=192 wpp=1 slices=2 scaling=2",
     "p_tiles": "gop=P pics=3 w=256 h=192 log2ctb=4 log2maxtb=4 tile_cols=3 tile_rows=2 tile_uniform=0 lf_tiles=0 slices=4",
+    "p_wpp_dependent_segments": "gop=P pics=3 w=256 h=192 dep=60 wpp=1 slices=2",
     "i_12bit_pcm": "gop=I pics=1 w=136 h=104 bits=12 pcm_bits=9 pcm_lf_off=1 cip=1",
 }
 

@@ -31,6 +31,8 @@ gop=P pics=4 w=192 h=128 bits=12 wp=1 deblock=0 sao=1 qp=40
 gop=LDB pics=4 w=192 h=128 bits=9 tmvp=0 strong=0 cuqpd=0 cb_off=-6 cr_off=7 qp=18 dens=90
 gop=B pics=5 w=256 h=192 wpp=1 slices=3 scaling=2
 gop=P pics=3 w=256 h=192 log2ctb=4 log2maxtb=4 tile_cols=4 tile_rows=3 tile_uniform=0 lf_tiles=0 slices=5 scaling=1
+gop=LDB pics=4 w=256 h=192 dep=50 wpp=1 slices=2 bits=10
+gop=P pics=3 w=256 h=192 log2ctb=4 log2maxtb=4 dep=40 tile_cols=3 tile_rows=2 slices=2
 gop=B pics=5 w=136 h=104 log2ctb=4 log2maxtb=4 depth_inter=0 depth_intra=0 amp=0 pcm=0 bits=8 tqbypass=1 tskip=1
 CFGS
 echo "$((tot-bad)) of $tot streams identical" | tee -a "$OUT"

@@ -47,6 +47,7 @@ F2_STREAMS = [
     dict(name="f2_i_10bit_pcm7", args="gop=I pics=2 w=200 h=136 log2ctb=6 bits=10 pcm_bits=7 pcm_lf_off=1 seed=4"),
     dict(name="f2_b_wpp_slices", args="gop=B pics=5 w=256 h=192 wpp=1 slices=3 seed=5"),
     dict(name="f2_ldb_scaling_lists_10bit", args="gop=LDB pics=3 w=192 h=128 scaling=2 bits=10 tskip=1 seed=7"),
+    dict(name="f2_p_wpp_dependent_segments", args="gop=P pics=3 w=256 h=192 dep=60 wpp=1 slices=2 seed=8"),
     dict(name="f2_p_tiles_4x3", args="gop=P pics=3 w=256 h=192 log2ctb=4 log2maxtb=4 tile_cols=4 tile_rows=3 tile_uniform=0 lf_tiles=0 slices=5 seed=6"),
 ]
 
