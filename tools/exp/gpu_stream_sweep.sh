@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: many small synthetic streams (oracle/_ref/f2_writer, all features, several configurations x seeds) decoded by the patched
 # libde265 on the CPU and with the MI355X back end (synchronous and pipelined with worker threads); outputs must be byte-identical.
-#   tools/exp/gpu_stream_sweep.sh [seeds_per_config] [out_file]
+#   tools/exp/gpu_stream_sweep.sh [seeds_per_config] [out_file] [config_file: one f2_writer argument list per line; default: the list below]
 cd "$(dirname "$0")/../.."
 N=${1:-12}; OUT=${2:-gpurun_out/gpu_stream_sweep.txt}; mkdir -p "$(dirname "$OUT")"; TMP=$(mktemp -d)
 LIB=$PWD/libde265_amd/libde265_hip.so; DEC=oracle/_ref/f1_dec; WR=oracle/_ref/f2_writer
@@ -21,7 +21,7 @@ while read -r cfg; do
     fi
   done
   echo "done: $cfg" >> "$OUT"
-done <<'CFGS'
+done < <(if [ -n "$3" ]; then cat "$3"; else cat <<'CFGS'
 gop=B pics=5 w=256 h=144 log2ctb=6 slices=2 wp=1
 gop=P pics=4 w=176 h=144 log2ctb=4 log2maxtb=4 nref=4 lists_mod=1
 gop=LDB pics=4 w=208 h=120 log2ctb=5 bits=10 sdh=1 tskip=1 cip=1 slices=4 lf_slices=0
@@ -35,6 +35,7 @@ gop=LDB pics=4 w=256 h=192 dep=50 wpp=1 slices=2 bits=10
 gop=P pics=3 w=256 h=192 log2ctb=4 log2maxtb=4 dep=40 tile_cols=3 tile_rows=2 slices=2
 gop=B pics=5 w=136 h=104 log2ctb=4 log2maxtb=4 depth_inter=0 depth_intra=0 amp=0 pcm=0 bits=8 tqbypass=1 tskip=1
 CFGS
+fi)
 echo "$((tot-bad)) of $tot streams identical" | tee -a "$OUT"
 rm -rf "$TMP"
 [ $bad = 0 ]
