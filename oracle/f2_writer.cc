@@ -54,6 +54,7 @@ struct Cfg {
   int deblock = 1, lf_slices = 1, cabac_init = 1, lists_mod = 0, merge_cand = 5, par_mrg = 2;
   int nref = 2, max_level = 24, big_mv = 1;
   int wpp = 0, tile_cols = 1, tile_rows = 1, tile_uniform = 1, lf_tiles = 1, md5 = 1;
+  int idr_period = 0;                 /* gop=I/P/LDB: an IDR picture every so many pictures (POC restarts, the DPB is flushed) */
   int dep = 0;                        /* percent: a cut point inside a slice starts a DEPENDENT slice segment (7.3.6.1, 9.3.1) */
   int scaling = 0;                    /* 1: scaling lists on, default lists (sps); 2: explicit lists in the PPS (7.3.4 scaling_list_data) */
   int dens = 50;                      /* percent: how often cbf flags are set */
@@ -70,7 +71,7 @@ const Kv KV[] = {
   {"deblock",&Cfg::deblock},{"lf_slices",&Cfg::lf_slices},{"cabac_init",&Cfg::cabac_init},{"lists_mod",&Cfg::lists_mod},
   {"merge_cand",&Cfg::merge_cand},{"par_mrg",&Cfg::par_mrg},{"nref",&Cfg::nref},{"max_level",&Cfg::max_level},
   {"big_mv",&Cfg::big_mv},{"dens",&Cfg::dens},{"wpp",&Cfg::wpp},{"tile_cols",&Cfg::tile_cols},{"tile_rows",&Cfg::tile_rows},
-  {"tile_uniform",&Cfg::tile_uniform},{"lf_tiles",&Cfg::lf_tiles},{"md5",&Cfg::md5},{"scaling",&Cfg::scaling},{"dep",&Cfg::dep},
+  {"tile_uniform",&Cfg::tile_uniform},{"lf_tiles",&Cfg::lf_tiles},{"md5",&Cfg::md5},{"scaling",&Cfg::scaling},{"dep",&Cfg::dep},{"idr_period",&Cfg::idr_period},
 };
 
 [[noreturn]] void die(const char* msg) { fprintf(stderr, "f2_writer: %s\n", msg); exit(2); }
@@ -96,13 +97,16 @@ std::vector<PicPlan> plan_gop(const Cfg& c)
 {
   std::vector<PicPlan> v;
   auto add = [&](int poc, int type, std::vector<int> refs) { PicPlan p; p.poc = poc; p.type = type; p.refs = refs; p.idr = v.empty(); v.push_back(p); };
+  const int period = c.idr_period > 0 ? c.idr_period : 1 << 30;
   if (c.gop == "I") {
-    for (int i=0;i<c.pics;i++) add(i, SLICE_TYPE_I, {});
-  } else if (c.gop == "P" || c.gop == "LDB") {              /* low delay: the nref previous pictures */
+    for (int i=0;i<c.pics;i++) { add(i % period, SLICE_TYPE_I, {}); v.back().idr = i % period == 0; }
+  } else if (c.gop == "P" || c.gop == "LDB") {              /* low delay: the nref previous pictures (of the same coded video sequence) */
     for (int i=0;i<c.pics;i++) {
+      const int j = i % period;                               /* POC = position behind the last IDR */
       std::vector<int> r;
-      for (int k=1;k<=c.nref && i-k>=0;k++) r.push_back(i-k);
-      add(i, i==0 ? SLICE_TYPE_I : (c.gop == "P" ? SLICE_TYPE_P : SLICE_TYPE_B), r);
+      for (int k=1;k<=c.nref && j-k>=0;k++) r.push_back(j-k);
+      add(j, j==0 ? SLICE_TYPE_I : (c.gop == "P" ? SLICE_TYPE_P : SLICE_TYPE_B), r);
+      v.back().idr = j == 0;
     }
   } else if (c.gop == "B") {                                /* random access, hierarchical GOP of 4 */
     add(0, SLICE_TYPE_I, {});
@@ -906,7 +910,7 @@ struct Writer {
     std::vector<int> keep;
     for (int poc : dpbs.dpb) {
       bool need = std::find(p.refs.begin(),p.refs.end(),poc) != p.refs.end();
-      for (size_t j=k+1;j<plan.size() && !need;j++) need = std::find(plan[j].refs.begin(),plan[j].refs.end(),poc) != plan[j].refs.end();
+      for (size_t j=k+1;j<plan.size() && !need && !plan[j].idr;j++) need = std::find(plan[j].refs.begin(),plan[j].refs.end(),poc) != plan[j].refs.end();
       if (need && !p.idr) keep.push_back(poc);
     }
     std::vector<int> neg, pos;
@@ -915,6 +919,7 @@ struct Writer {
     std::vector<bool> nu, pu;
     for (int poc : neg) nu.push_back(std::find(p.refs.begin(),p.refs.end(),poc) != p.refs.end());
     for (int poc : pos) pu.push_back(std::find(p.refs.begin(),p.refs.end(),poc) != p.refs.end());
+    if (p.idr) keep.clear();
     dpbs.dpb = keep; dpbs.dpb.push_back(p.poc);
 
     std::fill(ct_depth.begin(),ct_depth.end(),0); std::fill(skipf.begin(),skipf.end(),0); std::fill(pmode.begin(),pmode.end(),PM_NONE);
