@@ -29,6 +29,10 @@ __device__ __constant__ uint32_t c_qpel_pk[4][4] = {
   { QPK(-1, 4), QPK(-10, 58), QPK(17, -5), QPK(1, 0) },
   { QPK(-1, 4), QPK(-11, 40), QPK(40, -11), QPK(4, -1) },
   { QPK(0, 1), QPK(-5, 17), QPK(58, -10), QPK(4, -1) } };
+// the chroma taps the same way: (tap0, tap1), (tap2, tap3)
+__device__ __constant__ uint32_t c_epel_pk[8][2] = {
+  { QPK(0, 64), QPK(0, 0) }, { QPK(-2, 58), QPK(10, -2) }, { QPK(-4, 54), QPK(16, -2) }, { QPK(-6, 46), QPK(28, -4) },
+  { QPK(-4, 36), QPK(36, -4) }, { QPK(-4, 28), QPK(46, -6) }, { QPK(-2, 16), QPK(54, -4) }, { QPK(-2, 10), QPK(58, -2) } };
 #undef QPK
 typedef short mc_s2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int mc_dot2(uint32_t a, uint32_t b, int acc)
@@ -301,43 +305,44 @@ void k_mc(PicDev P, DpbTable dpb, PlaneRef d0, PlaneRef d1, PlaneRef d2,
       continue;
     }
     const int nrow = h + 7;
-#pragma unroll
-    for (int it = 0; it < 2; it++) {               // horizontal pass -> s_tmp[row][16]
-      const int rr = ly + 16 * it;
+    {                                              // horizontal pass -> s_tmp[row][16]: lane -> row lane>>1, eight adjacent columns
+      // (all <= 23 rows in ONE step of 46 lanes; four columns per lane took two steps, the second with 28 of 64 lanes at work)
+      const int rr = lane >> 1, x8 = (lane & 1) * 8;
       if (rr < nrow) {
-        int o[4];
+        int o[8];
         if (xF == 0) {
 #pragma unroll
-          for (int j = 0; j < 4; j++) o[j] = in[rr * MCL_P + lx4 + j + 3];
+          for (int j = 0; j < 8; j++) o[j] = in[rr * MCL_P + x8 + j + 3];
         } else {
-          // the 11 samples sv[0..10] the four outputs need, as pairs: E[m] = (sv[2m], sv[2m+1]) read as dwords (from the
+          // the 15 samples sv[0..14] the eight outputs need, as pairs: E[m] = (sv[2m], sv[2m+1]) read as dwords (from the
           // even element below the row's start, shifted by one sample when the start is odd), O[m] = (sv[2m+1], sv[2m+2])
-          const int e0 = rr * MCL_P + lx4 + (oxL[l] & ~1);
+          const int e0 = rr * MCL_P + x8 + (oxL[l] & ~1);
           const uint32_t* rowd = reinterpret_cast<const uint32_t*>(&s_inL[l][e0]);
-          uint32_t D[7], E[6], O[5];
+          uint32_t D[9], E[8], O[7];
 #pragma unroll
-          for (int m = 0; m < 7; m++) D[m] = rowd[m];
+          for (int m = 0; m < 9; m++) D[m] = rowd[m];
           if (oxL[l] & 1) {
 #pragma unroll
-            for (int m = 0; m < 6; m++) E[m] = __builtin_amdgcn_alignbit(D[m + 1], D[m], 16);
+            for (int m = 0; m < 8; m++) E[m] = __builtin_amdgcn_alignbit(D[m + 1], D[m], 16);
           } else {
 #pragma unroll
-            for (int m = 0; m < 6; m++) E[m] = D[m];
+            for (int m = 0; m < 8; m++) E[m] = D[m];
           }
 #pragma unroll
-          for (int m = 0; m < 5; m++) O[m] = __builtin_amdgcn_alignbit(E[m + 1], E[m], 16);
-          int sum[4] = { 0, 0, 0, 0 };
+          for (int m = 0; m < 7; m++) O[m] = __builtin_amdgcn_alignbit(E[m + 1], E[m], 16);
+          int sum[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 #pragma unroll
           for (int m = 0; m < 4; m++) {
             const uint32_t tp = c_qpel_pk[xF][m];
-            sum[0] = mc_dot2(E[m], tp, sum[0]); sum[1] = mc_dot2(O[m], tp, sum[1]);
-            sum[2] = mc_dot2(E[m + 1], tp, sum[2]); sum[3] = mc_dot2(O[m + 1], tp, sum[3]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) { sum[2 * i] = mc_dot2(E[i + m], tp, sum[2 * i]); sum[2 * i + 1] = mc_dot2(O[i + m], tp, sum[2 * i + 1]); }
           }
 #pragma unroll
-          for (int j = 0; j < 4; j++) o[j] = (int16_t)(sum[j] >> shift1);
+          for (int j = 0; j < 8; j++) o[j] = (int16_t)(sum[j] >> shift1);
         }
-        *reinterpret_cast<uint2*>(&s_tmp[rr * MCT_P + lx4]) =
-          make_uint2((uint32_t)(uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16), (uint32_t)(uint16_t)o[2] | ((uint32_t)(uint16_t)o[3] << 16));
+        uint2* dstp = reinterpret_cast<uint2*>(&s_tmp[rr * MCT_P + x8]);
+        dstp[0] = make_uint2((uint32_t)(uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16), (uint32_t)(uint16_t)o[2] | ((uint32_t)(uint16_t)o[3] << 16));
+        dstp[1] = make_uint2((uint32_t)(uint16_t)o[4] | ((uint32_t)(uint16_t)o[5] << 16), (uint32_t)(uint16_t)o[6] | ((uint32_t)(uint16_t)o[7] << 16));
       }
     }
     MC_LDS_SYNC();
@@ -395,24 +400,39 @@ void k_mc(PicDev P, DpbTable dpb, PlaneRef d0, PlaneRef d1, PlaneRef d2,
       continue;
     }
     const int nrow = hc + 3;
-    // horizontal pass, plane by plane: lane -> row (lane>>2, 11 rows), 2 columns -> s_tmp[plane*176 + row*16 + x]
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-      const uint16_t* in = &s_inC[l][q][oxC[l]];
-      const int rr = lane >> 2, x2 = (lane & 3) * 2;
+    // horizontal pass, both planes at once: lane -> plane (lane>>5), row ((lane&31)>>1, 11 rows), 4 columns -> s_tmp[plane*11*MCT_P + row*MCT_P + x]
+    {
+      const int q = lane >> 5, rr = (lane & 31) >> 1, x4 = (lane & 1) * 4;
       if (rr < nrow) {
-        int o0v, o1v;
-        if (xF == 0) { o0v = in[rr * MCC_P + x2 + 1]; o1v = in[rr * MCC_P + x2 + 2]; }
-        else {
-          int sv[5];
+        int o[4];
+        if (xF == 0) {
+          const uint16_t* in = &s_inC[l][q][oxC[l]];
 #pragma unroll
-          for (int k = 0; k < 5; k++) sv[k] = in[rr * MCC_P + x2 + k];
-          int s0 = 0, s1 = 0;
+          for (int j = 0; j < 4; j++) o[j] = in[rr * MCC_P + x4 + j + 1];
+        } else {
+          // sv[0..6] as pairs (see the luma pass); 4 taps = two dot2 per output
+          const int e0 = rr * MCC_P + x4 + (oxC[l] & ~1);
+          const uint32_t* rowd = reinterpret_cast<const uint32_t*>(&s_inC[l][q][e0]);
+          uint32_t D[5], E[4], O[3];
 #pragma unroll
-          for (int k = 0; k < 4; k++) { const int tap = c_epel_filt[xF][k]; s0 += __mul24(tap, sv[k]); s1 += __mul24(tap, sv[k + 1]); }
-          o0v = (int16_t)(s0 >> shift1); o1v = (int16_t)(s1 >> shift1);
+          for (int m = 0; m < 5; m++) D[m] = rowd[m];
+          if (oxC[l] & 1) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) E[m] = __builtin_amdgcn_alignbit(D[m + 1], D[m], 16);
+          } else {
+#pragma unroll
+            for (int m = 0; m < 4; m++) E[m] = D[m];
+          }
+#pragma unroll
+          for (int m = 0; m < 3; m++) O[m] = __builtin_amdgcn_alignbit(E[m + 1], E[m], 16);
+          const uint32_t p0 = c_epel_pk[xF][0], p1 = c_epel_pk[xF][1];
+          o[0] = (int16_t)(mc_dot2(E[1], p1, mc_dot2(E[0], p0, 0)) >> shift1);
+          o[1] = (int16_t)(mc_dot2(O[1], p1, mc_dot2(O[0], p0, 0)) >> shift1);
+          o[2] = (int16_t)(mc_dot2(E[2], p1, mc_dot2(E[1], p0, 0)) >> shift1);
+          o[3] = (int16_t)(mc_dot2(O[2], p1, mc_dot2(O[1], p0, 0)) >> shift1);
         }
-        *reinterpret_cast<uint32_t*>(&s_tmp[q * (11 * MCT_P) + rr * MCT_P + x2]) = (uint32_t)(uint16_t)o0v | ((uint32_t)(uint16_t)o1v << 16);
+        *reinterpret_cast<uint2*>(&s_tmp[q * (11 * MCT_P) + rr * MCT_P + x4]) =
+          make_uint2((uint32_t)(uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16), (uint32_t)(uint16_t)o[2] | ((uint32_t)(uint16_t)o[3] << 16));
       }
     }
     MC_LDS_SYNC();
@@ -420,13 +440,13 @@ void k_mc(PicDev P, DpbTable dpb, PlaneRef d0, PlaneRef d1, PlaneRef d2,
     if (yF == 0) { prC[l][0] = tp[(cy + 1) * MCT_P + cx2]; prC[l][1] = tp[(cy + 1) * MCT_P + cx2 + 1]; }
     else {
       const int vshift = (xF == 0) ? shift1 : 6;
-      int a0 = 0, a1 = 0;
+      uint32_t rv[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const uint32_t rv = *reinterpret_cast<const uint32_t*>(&tp[(cy + k) * MCT_P + cx2]);
-        const int tap = c_epel_filt[yF][k];
-        a0 += __mul24(tap, (int)(int16_t)(rv & 0xFFFF)); a1 += __mul24(tap, (int)(int16_t)(rv >> 16));
-      }
+      for (int k = 0; k < 4; k++) rv[k] = *reinterpret_cast<const uint32_t*>(&tp[(cy + k) * MCT_P + cx2]);
+      // rows k, k+1 of one column as a pair: one dot2 per two taps
+      const uint32_t q0 = c_epel_pk[yF][0], q1 = c_epel_pk[yF][1];
+      const int a0 = mc_dot2(__builtin_amdgcn_perm(rv[3], rv[2], 0x05040100u), q1, mc_dot2(__builtin_amdgcn_perm(rv[1], rv[0], 0x05040100u), q0, 0));
+      const int a1 = mc_dot2(__builtin_amdgcn_perm(rv[3], rv[2], 0x07060302u), q1, mc_dot2(__builtin_amdgcn_perm(rv[1], rv[0], 0x07060302u), q0, 0));
       prC[l][0] = (int16_t)(a0 >> vshift); prC[l][1] = (int16_t)(a1 >> vshift);
     }
     MC_LDS_SYNC();
