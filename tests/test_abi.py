@@ -100,3 +100,17 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".inc")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "pyoracle" not in txt and "hevc_oracle" not in txt and "liboracle" not in txt, f
+
+
+def test_bench_touches_the_oracle_only_in_its_cpu_baseline_leg():
+    """oracle/ (the restatement, the compiled reference, the patched decoder, the bitstream writer) is test infrastructure:
+    bench.py may use it as the CPU baseline / checker and nowhere else (the end-to-end stream rates come from tools/exp/)."""
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    allowed = [(n.lineno, n.end_lineno) for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == "cpu_baseline"]
+    assert allowed
+    for i, line in enumerate(src.splitlines(), 1):
+        code = line.split("#", 1)[0]
+        if any(w in code for w in ("pyoracle", "pyref", "f1_dec", "f2_writer", "liboracle", "_ref/", "\"_ref\"")):
+            assert any(a <= i <= b for a, b in allowed), "bench.py:%d uses the oracle outside cpu_baseline: %s" % (i, line.strip())
