@@ -320,7 +320,8 @@ int  de265hip_recorder_submit(de265hip_decoder*, int dst_slot, de265hip_recorder
  * pictures between parser and device); nobody waits for a picture until de265hip_pipeline_wait(ticket) - what a decoder calls
  * when the picture is about to be output or read (de265.cc:392 de265_peek_next_picture).  While a pipeline exists, run / dpb_* /
  * sync of its decoder belong to the pipeline; dpb_alloc of slots no queued picture uses is allowed.  An error of prepare, build
- * or run is returned by wait() of that ticket (or by drain()).  oracle/f1_recorder.cc is the libde265-side user. ---- */
+ * or run is returned by wait() of that ticket (or by drain()).  Free the pipeline before its decoder.  oracle/f1_recorder.cc
+ * (test infrastructure: the patched reference decoder) is the libde265-side user. ---- */
 typedef struct de265hip_pipeline de265hip_pipeline;
 typedef int (*de265hip_prepare_fn)(void* user, de265hip_recorder** out);   /* 0 and a filled recorder (the pipeline frees it) */
 int  de265hip_pipeline_new(de265hip_pipeline** out, de265hip_decoder*, int n_workers /* 1..16 */);
