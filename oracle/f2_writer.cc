@@ -1088,6 +1088,8 @@ int main(int argc, char** argv)
   }
   if (c.w % (1<<c.log2mincb) || c.h % (1<<c.log2mincb)) die("w and h must be multiples of the minimum coding block size");
   if (c.log2mintb >= c.log2mincb || c.log2maxtb > std::min(5,c.log2ctb) || c.bits < 8 || c.bits > 12) die("inconsistent block sizes / bit depth");
+  if (c.log2ctb < 4 || c.log2ctb > 6 || c.log2mincb < 3 || c.log2mincb > c.log2ctb || c.log2mintb < 2 || c.log2maxtb < c.log2mintb) die("block sizes outside 7.4.3.2.1");
+  if (c.wpp && (c.tile_cols > 1 || c.tile_rows > 1)) die("wpp together with tiles is not written (the reference's parser does not combine them either, slice.cc:4664)");
   Writer w(c);
   w.run();
   return 0;
