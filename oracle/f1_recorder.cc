@@ -570,7 +570,8 @@ bool f1_submit(de265_image* img)
   take_records(job->recs);
   if (hip) {
     // ---- OFFLOAD
-    job->slot = dpb_index_of(img) % DE265HIP_MAX_DPB_SLOTS;
+    job->slot = dpb_index_of(img);                                  // reference lists name libde265's DPB indices: the slot IS the index
+    if (job->slot >= DE265HIP_MAX_DPB_SLOTS) hip_die("libde265 holds more pictures than the back end has DPB slots", job->slot);
     for (int c=0;c<3;c++) { job->plane[c] = img->get_image_plane(c); job->stride_bytes[c] = (ptrdiff_t)img->get_image_stride(c)*img->get_bytes_per_pixel(c); }
     if (H.pipeline) pipe_submit(img, job);                          // the workers prepare, build and launch; libde265 goes on parsing
     else { prepare_job(job.get(), true); build_job(*job); launch_job(*job, true); free_job(*job); }
