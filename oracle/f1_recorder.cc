@@ -72,11 +72,17 @@ struct State {
 State S;
 
 /* the main thread, picture finished, no hook running: take the per-thread buffers of the picture away (moves, no copies) */
+std::vector<Rec> spare_recs;            // emptied buffers that kept their capacity (guarded by reg_mu)
 void take_records(std::vector<Rec>& out)
 {
   std::lock_guard<std::mutex> lk(reg_mu);
   out.resize(all_recs.size());
-  for (size_t r=0;r<all_recs.size();r++) { out[r] = std::move(*all_recs[r]); all_recs[r]->clear(); }
+  for (size_t r=0;r<all_recs.size();r++) {
+    out[r] = std::move(*all_recs[r]);
+    // the parse thread gets a buffer that has been through a picture already: no re-growing, no fresh pages to fault in
+    if (!spare_recs.empty()) { *all_recs[r] = std::move(spare_recs.back()); spare_recs.pop_back(); }
+    all_recs[r]->clear();
+  }
 }
 
 void merge_records(std::vector<Rec>& recs, PicRec& M)
@@ -113,6 +119,10 @@ void merge_records(std::vector<Rec>& recs, PicRec& M)
     pc.sample_offset = (uint32_t)M.pcm_samples.size();
     M.pcm_samples.insert(M.pcm_samples.end(), R.pcm_samples.begin()+src, R.pcm_samples.begin()+src+cnt);
     M.pcms.push_back(pc);
+  }
+  {
+    std::lock_guard<std::mutex> lk(reg_mu);
+    for (Rec& r : recs) if (spare_recs.size() < 64) { r.clear(); spare_recs.push_back(std::move(r)); }
   }
   recs.clear();
 }
