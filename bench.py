@@ -37,7 +37,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
         sys.path.insert(0, p)
 
 PMC_FILE = os.path.join(ROOT, "profiles", "r02_c_pmc_traffic.json")
-PMC_KERNEL = {"intra": ["k_run<unsigned short, 64>"], "mc": ["k_mc<unsigned short>"], "sao": ["k_sao<unsigned short>"],
+PMC_KERNEL = {"intra": ["k_run<unsigned short, 64>"], "mc": ["k_mc<unsigned short>"], "sao": ["k_sao_ctb<unsigned short>"],
               "deblock_v": ["k_deblock_fused<unsigned short>"],   # both directions in one kernel, reported under deblock_v
               "resid": ["k_resid_big<unsigned short>"]}     # all sizes in one launch
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
@@ -386,6 +386,8 @@ def main():
         st0 = [p.stats() for p in pics[0]]
         kernels_iso = {k: {"us_per_picture": round(1e3 * v[0] / max(v[1], 1), 1) if k != "resid" else
                            round(1e3 * v[0] / (2 * GOP), 1),
+                           "alg_bytes_per_picture": int(sum(getattr(x, ALG_KEY[k]) for x in st0) / (2 if k.startswith("deblock") and two_pass else 1)
+                                                        / GOP) if k in ALG_KEY else None,
                            "alg_GBs": round((sum(getattr(x, ALG_KEY[k]) for x in st0) / (2 if k.startswith("deblock") and two_pass else 1)
                                              / 1e9) / (v[0] / 2 / 1e3), 1) if k in ALG_KEY and v[0] > 0 else None}
                        for k, v in iso.items() if v[1]}

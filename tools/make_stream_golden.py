@@ -93,7 +93,8 @@ def main():
             open(yuv, "wb").write(synth_yuv(st["w"], st["h"], st["frames"], st["seed"], st["noise"]))
             subprocess.check_call([os.path.join(REFDIR, "enc265"), "-i", yuv, "-w", str(st["w"]), "-h", str(st["h"]),
                                    "-f", str(st["frames"]), "--sop-structure", "intra", "-o", bits] + st["enc"],
-                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                  cwd=td)                   # (enc265 drops a recon.yuv into its working directory)
             dumps = os.path.join(td, "dumps")
             os.makedirs(dumps)
             pics = record(bits, dumps)
