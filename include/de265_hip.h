@@ -224,6 +224,14 @@ int  de265hip_device_count(void);
  * handle) and to de265hip_picture_get_stats(); de265hip_picture_run() refuses it with
  * DE265_ERROR_CODED_PARAMETER_OUT_OF_RANGE.  de265hip_picture_free() never touches a freed decoder.
  *
+ * GEOMETRY: a picture is reconstructed with the size and bit depths of ITS de265hip_pic_params.  de265hip_picture_build()
+ * (re)allocates the destination slot (and the decoder's internal SAO target) when it is empty or when no picture of the
+ * decoder is waiting for its first launch; otherwise a slot that holds planes of another geometry is re-allocated by
+ * de265hip_picture_run(), i.e. in launch order: pictures of the old size that are built but not launched yet
+ * (de265hip_pipeline_*, builds on several threads) keep their planes, and the re-allocation waits for the device.  That every reference slot holds a picture of the picture's own geometry is checked by de265hip_picture_run()
+ * (DE265_ERROR_CODED_PARAMETER_OUT_OF_RANGE, nothing is launched): at build time a reference may still be under construction
+ * on another thread.  de265hip_dpb_alloc() of a slot that queued pictures still use is the caller's error.
+ *
  * THREADS: de265hip_picture_build() and de265hip_picture_free() may be called from several host threads
  * on the same decoder at once (the host stage of picture n+1 overlaps the device work of picture n:
  * decctx.cc:976-1178 is the reference's parallel host side); de265hip_picture_run(), the dpb_* calls and
@@ -266,7 +274,8 @@ int  de265hip_dpb_plane(de265hip_decoder*, int slot, int c_idx,
 /* Reference-picture exchange (open GOPs / inter-GOP references): copy the three planes of
  * src_dec's slot src_slot into dst_dec's slot dst_slot, device to device (hipMemcpyPeerAsync when the
  * decoders sit on different GPUs of this process, one xGMI hop; a plain device copy otherwise), ordered
- * behind everything enqueued on src_dec's stream so far; dst_dec's stream waits for the copy.  The
+ * behind everything enqueued on src_dec's stream so far AND on dst_dec's stream so far (pictures already queued on dst_dec
+ * that read the slot's old content finish first; so does a pending copy-out of it); dst_dec's stream waits for the copy.  The
  * destination slot is (re)allocated to the source's geometry.  Between PROCESSES (one rank per GPU) the same
  * planes are sent with RCCL on zero-copy tensor views of de265hip_dpb_plane (libde265_amd/farm.py). */
 int  de265hip_dpb_copy(de265hip_decoder* src_dec, int src_slot, de265hip_decoder* dst_dec, int dst_slot);

@@ -79,6 +79,11 @@ struct de265hip_decoder {
   bool separate_bs = false;           // DE265HIP_SEPARATE_BS: bS by its own kernel instead of inside the deblocking kernels
   int dbg = 0;                        // DE265HIP_DEBUG: timing-only ablations of k_run (results invalid)
   bool intra_levels = false;          // DE265HIP_INTRA_MODE=levels: one launch per dependency level
+  // Fault injection for the one device-side failure mode the design admits (tests/test_gpu_picture_parity.py): a picture
+  // built while DE265HIP_TEST_DROP_PRODUCER is set leaves one run that other runs wait for out of its ticket list, so that
+  // run's flag is never raised; DE265HIP_TEST_SPIN_LIMIT (read when the decoder is created) bounds the waits so that they
+  // expire within milliseconds instead of seconds.
+  uint32_t spin_limit = RUN_SPIN_LIMIT_DEFAULT;
   uint32_t profiling = 0;             // bit k: launches of kernel id k are bracketed by hipEvents
   std::vector<PendingEvent> pending;
   double ms[DE265HIP_K_COUNT] = {};
@@ -119,6 +124,8 @@ struct de265hip_picture {
   std::vector<int> level_start;       // level_start[l] .. level_start[l+1] in d_tus
   int n_mc = 0, n_pcm = 0, n_tus = 0;
   bool any_edges = false;
+  uint32_t ref_mask = 0;              // DPB slots the picture's MC tasks read (validated when the picture is launched)
+  int n_launched = 0;                 // de265hip_picture_run calls so far
   de265hip_picture_stats stats = {};
 };
 
@@ -457,6 +464,7 @@ int de265hip_decoder_new(de265hip_decoder** out, int device)
   if (const char* e = getenv("DE265HIP_LF_TILE")) d->lf_tile = atoi(e) != 0;
   if (const char* e = getenv("DE265HIP_RESID16_BIG")) d->resid16_big = atoi(e) != 0;
   if (const char* e = getenv("DE265HIP_RESID_ONE_LAUNCH")) d->resid_one_launch = atoi(e) != 0;
+  if (const char* e = getenv("DE265HIP_TEST_SPIN_LIMIT")) d->spin_limit = (uint32_t)std::max(1, atoi(e));
   if (const char* rw = getenv("DE265HIP_RUN_WAVES")) d->run_waves = std::min(RUN_WAVES, std::max(1, atoi(rw)));
   *out = d;
   return DE265HIP_OK;
@@ -501,6 +509,7 @@ int de265hip_dpb_alloc(de265hip_decoder* d, int slot, int width, int height, int
   if (width <= 0 || height <= 0 || (width & 7) || (height & 7) || bdY < 8 || bdY > 12 || bdC < 8 || bdC > 12)
     return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   if ((bdY > 8) != (bdC > 8)) return DE265HIP_ERROR_NOT_IMPLEMENTED;
+  std::lock_guard<std::mutex> lk(d->mu);          // (run_picture snapshots the slot table under the same lock)
   return alloc_slot(d->slots[slot], width, height, bdY, bdC);
 }
 
@@ -622,6 +631,16 @@ int de265hip_dpb_copy(de265hip_decoder* sd, int ss, de265hip_decoder* dd, int ds
   hipEvent_t ev = nullptr;
   HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming), DE265HIP_ERROR_OUT_OF_MEMORY);
   int rc = 0;
+  // The copy runs on the SOURCE decoder's stream.  It must also come behind what the destination decoder has already
+  // enqueued - pictures that still read the slot's old content as a reference, or write it - and behind a copy-out of
+  // that old content (de265hip_dpb_download_async): overwriting a live reference slot is what an open-GOP hand-over does.
+  if (sd != dd) {
+    if (hipEventRecord(ev, dd->stream) != hipSuccess || hipStreamWaitEvent(sd->stream, ev, 0) != hipSuccess) rc = DE265HIP_ERROR_DECODING;
+  }
+  {
+    std::lock_guard<std::mutex> lk(dd->mu);
+    if (!rc && D.dl_done && D.dl_waited != D.dl_seq && hipStreamWaitEvent(sd->stream, D.dl_done, 0) != hipSuccess) rc = DE265HIP_ERROR_DECODING;
+  }
   for (int c = 0; c < 3 && !rc; c++) {
     const int h = c ? S.h / 2 : S.h;
     const size_t bytes = (size_t)S.pl[c].stride * h * px_bytes(c ? S.bdC : S.bdY);      // same pitch on both sides (alloc_slot)
@@ -669,9 +688,17 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   if (dst_slot < 0 || dst_slot >= DE265HIP_MAX_DPB_SLOTS) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   int rc = 0;
   if (!dec->dry) {
+    // Builds run ahead of launches (de265hip_pipeline_*, several host threads): a slot or the spare that already holds
+    // planes of ANOTHER geometry may still be read or written by pictures that are built but not launched yet, so it is
+    // not touched here - de265hip_picture_run re-allocates it when this picture's turn comes (launches are in decode
+    // order, and the re-allocation waits for the device).  An empty slot is allocated right away, so that the planes of
+    // a picture exist once it is built (de265hip_dpb_plane / upload of its initial content).
+    // With no picture waiting for its first launch nothing can be disturbed either (the synchronous build -> upload -> run use).
     std::lock_guard<std::mutex> lk(dec->mu);
-    rc = alloc_slot(dec->slots[dst_slot], p.width, p.height, p.bit_depth_luma, p.bit_depth_chroma);
-    if (!rc) rc = alloc_slot(dec->spare, p.width, p.height, p.bit_depth_luma, p.bit_depth_chroma);
+    bool pending = false;
+    for (const de265hip_picture* q : dec->live) pending = pending || q->n_launched == 0;
+    if (!dec->slots[dst_slot].valid || !pending) rc = alloc_slot(dec->slots[dst_slot], p.width, p.height, p.bit_depth_luma, p.bit_depth_chroma);
+    if (!rc && (!dec->spare.valid || !pending)) rc = alloc_slot(dec->spare, p.width, p.height, p.bit_depth_luma, p.bit_depth_chroma);
   }
   if (rc) return rc;
 
@@ -914,6 +941,11 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       }
     }
     while (slots.size() % RUN_TICKET_SLOTS) slots.push_back(0xFFFFFFFFu);
+    if (getenv("DE265HIP_TEST_DROP_PRODUCER")) {         // fault injection: the first run somebody depends on is never executed
+      int victim = -1;
+      for (size_t i = 0; i < rb.size() && victim < 0; i++) if (!rb[i].deps.empty()) victim = newidx[rb[i].deps[0]];
+      for (uint32_t& v : slots) if (v != 0xFFFFFFFFu && (int)(v & 0x7FFFFFFFu) == victim) v = 0xFFFFFFFFu;
+    }
     for (size_t k = 0; k < rb.size(); k++) {
       const RunBuild& R = rb[order[k]];
       RunTask& o = runs[k]; memset(&o, 0, sizeof(o));
@@ -1123,10 +1155,10 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       t.slot[l] = -1; t.ref_idx[l] = pu.ref_idx[l];
       if (!pf[l]) continue;
       int slot = sh.ref_pic_list[l][pu.ref_idx[l]];
-      if (slot < 0 || slot >= DE265HIP_MAX_DPB_SLOTS || !dec->slots[slot].valid || dec->slots[slot].w != p.width ||
-          dec->slots[slot].h != p.height || dec->slots[slot].bdY != p.bit_depth_luma || slot == dst_slot) {
-        delete pic; return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
-      }
+      // (that the slot holds a picture of this geometry is checked when the picture is launched: its reference may be a
+      //  picture that is being built on another thread right now)
+      if (slot < 0 || slot >= DE265HIP_MAX_DPB_SLOTS || slot == dst_slot) { delete pic; return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE; }
+      pic->ref_mask |= 1u << slot;
       t.slot[l] = (int8_t)slot; t.mv[l][0] = pu.mv[l][0]; t.mv[l][1] = pu.mv[l][1];
     }
     const int nref = (t.slot[0] >= 0) + (t.slot[1] >= 0);
@@ -1386,13 +1418,29 @@ struct KTimer {
 template <typename PX>
 int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
 {
+  // The slot table is read (plane pointers of the references, the destination and the spare) and the destination's planes
+  // are swapped with the spare's below: all under the decoder's lock, which the build threads take for slot / pool work.
+  std::lock_guard<std::mutex> lk(dec->mu);
   Slot& dst = dec->slots[pic->dst_slot];
-  if (!dst.valid) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
-  hipStream_t st = dec->stream;
-  {                                     // a copy-out of the picture this slot held before must have left (de265hip_dpb_download_async)
-    std::lock_guard<std::mutex> lk(dec->mu);
-    if (dst.dl_done && dst.dl_waited != dst.dl_seq && hipStreamWaitEvent(st, dst.dl_done, 0) != hipSuccess) return DE265HIP_ERROR_DECODING;
+  {
+    // Geometry is the PICTURE's (recorded at build): the destination and the spare are (re)allocated now, in launch order -
+    // a change of picture size with pictures of the old size still queued is therefore safe (everything launched before has
+    // the old planes, hipFree waits for it) - and every reference must hold a picture of this geometry by now.
+    const de265hip_pic_params& pp = pic->params;
+    int rc = alloc_slot(dst, pp.width, pp.height, pp.bit_depth_luma, pp.bit_depth_chroma);
+    if (!rc) rc = alloc_slot(dec->spare, pp.width, pp.height, pp.bit_depth_luma, pp.bit_depth_chroma);
+    if (rc) return rc;
+    for (int s = 0; s < DE265HIP_MAX_DPB_SLOTS; s++)
+      if ((pic->ref_mask >> s) & 1u) {
+        const Slot& r = dec->slots[s];
+        if (!r.valid || r.w != pp.width || r.h != pp.height || r.bdY != pp.bit_depth_luma || r.bdC != pp.bit_depth_chroma)
+          return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+      }
   }
+  pic->n_launched++;
+  hipStream_t st = dec->stream;
+  // a copy-out of the picture this slot held before must have left (de265hip_dpb_download_async)
+  if (dst.dl_done && dst.dl_waited != dst.dl_seq && hipStreamWaitEvent(st, dst.dl_done, 0) != hipSuccess) return DE265HIP_ERROR_DECODING;
   if (!pic->upload_waited) {            // the command buffers arrive on the copy stream
     if (hipStreamWaitEvent(st, pic->uploaded, 0) != hipSuccess) return DE265HIP_ERROR_DECODING;
     pic->upload_waited = true;
@@ -1454,7 +1502,7 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
       else { (void)hipMemsetAsync(pic->d_sync, 0, pic->sync_bytes, st); pic->gen = 0; }
       hipLaunchKernelGGL((k_run<PX, 64>), dim3(pic->run_direct ? pic->n_batches : pic->n_workers), dim3(64 * dec->run_waves), 0, st, P, d0, d1, d2,
                          pic->d_runs, pic->d_deps, pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->d_slots, pic->n_batches,
-                         pic->run_direct ? 0 : pic->ticket_batch, base, gen, dec->dbg);
+                         pic->run_direct ? 0 : pic->ticket_batch, base, gen, dec->dbg, dec->spin_limit);
     }
   } else {
     if (nlev > 0 && pic->level_start[1] > pic->level_start[0]) {

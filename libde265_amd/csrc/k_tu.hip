@@ -779,7 +779,8 @@ void k_tu(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const TuTask* __re
 #define RUN_POLL_FAST_N 4
 #define RUN_POLL_SLOW 16
 #endif
-#define RUN_SPIN_LIMIT (1 << 21)      // x ~1 us per poll: a couple of seconds, then the picture fails instead of hanging
+// (bound of the dependency waits: the kernel argument spin_limit, RUN_SPIN_LIMIT_DEFAULT polls of ~1 us: a couple of
+//  seconds, then the picture fails - error word -> DE265_ERROR_UNSPECIFIED_DECODING_ERROR - instead of hanging)
 
 // 8 consecutive samples <-> 8 x uint16 in LDS
 __device__ __forceinline__ uint4 load8_as_u16(const uint16_t* p) { return *reinterpret_cast<const uint4*>(p); }
@@ -789,6 +790,32 @@ __device__ __forceinline__ uint4 load8_as_u16(const uint8_t* p)
   uint4 o;
   o.x = (r.x & 0xFF) | ((r.x & 0xFF00) << 8);           o.y = ((r.x >> 16) & 0xFF) | ((r.x >> 24) << 16);
   o.z = (r.y & 0xFF) | ((r.y & 0xFF00) << 8);           o.w = ((r.y >> 16) & 0xFF) | ((r.y >> 24) << 16);
+  return o;
+}
+// The same 8 samples by an agent-coherent (sc1) load that bypasses this CU's L1: what the run kernel reads other runs'
+// samples with.  Producer: sc1 stores, drained (vmcnt(0)) in every storing wavefront, workgroup barrier, sc1 flag store;
+// consumer: sc1 poll of the flag, workgroup barrier, sc1 loads - the hand-off form of MI355X_MICROARCH.md that needs
+// neither an L2 write-back on the producer nor an L1 invalidate (buffer_inv sc1: 1.7 us alone on a CU, 4x that with four
+// workgroups per CU) on the consumer.  RUN_SC1_WINDOW=0: plain loads behind an agent-scope acquire (the older form).
+#ifndef RUN_SC1_WINDOW
+#define RUN_SC1_WINDOW 1
+#endif
+typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
+typedef unsigned int v4u32_ld __attribute__((ext_vector_type(4)));
+#define D265_BUF_SC1 16                          // cache-policy operand of the raw buffer loads: bit 4 = sc1 (gfx940+)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const void* plane)
+{ return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(plane), 0, 0x7FFFFFFF, 0x00020000); }
+__device__ __forceinline__ uint4 load8_as_u16_sc1(__amdgpu_buffer_rsrc_t r, const uint16_t*, int sample)
+{
+  const v4u32_ld v = __builtin_amdgcn_raw_buffer_load_b128(r, sample * 2, 0, D265_BUF_SC1);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint4 load8_as_u16_sc1(__amdgpu_buffer_rsrc_t r, const uint8_t*, int sample)
+{
+  const v2u32 q = __builtin_amdgcn_raw_buffer_load_b64(r, sample, 0, D265_BUF_SC1);
+  uint4 o;
+  o.x = (q.x & 0xFF) | ((q.x & 0xFF00) << 8);           o.y = ((q.x >> 16) & 0xFF) | ((q.x >> 24) << 16);
+  o.z = (q.y & 0xFF) | ((q.y & 0xFF00) << 8);           o.w = ((q.y >> 16) & 0xFF) | ((q.y >> 24) << 16);
   return o;
 }
 // Write-through (sc1) stores: the run kernel hands these bytes to other CUs without an L2
@@ -1368,7 +1395,7 @@ __device__ __forceinline__ void micro_run(const PicDev& P, const PlaneRef& pl0, 
                                           const RunTask* __restrict__ runs, const uint32_t* __restrict__ deps,
                                           uint32_t* sync, uint32_t* err, const TuTask* __restrict__ tasks,
                                           const int16_t* __restrict__ resid, uint16_t* mt, int16_t* mres,
-                                          uint32_t r, int lane, uint32_t gen, int dbg)
+                                          uint32_t r, int lane, uint32_t gen, int dbg, uint32_t spin_limit)
 {
   const RunTask run = load_run_task(runs, r);
   const int n_tus = min((int)run.n_tus, MICRO_TUS);
@@ -1417,18 +1444,21 @@ __device__ __forceinline__ void micro_run(const PicDev& P, const PlaneRef& pl0, 
   // producers (bounded spin, as in the workgroup path)
   for (int i = lane; i < (int)run.n_deps; i += 64) {
     const uint32_t* flag = &sync[2 + (i == lane ? dep_id : deps[run.dep_offset + i])];
-    int spins = 0;
+    uint32_t spins = 0;
     uint32_t f = (i == lane) ? flag0 : gen - 1u;
     while (f != gen && !(RUN_DBG & 32)) {
       if (spins) { if (spins < RUN_POLL_FAST_N) __builtin_amdgcn_s_sleep(RUN_POLL_FAST); else __builtin_amdgcn_s_sleep(RUN_POLL_SLOW); }
-      if (++spins > RUN_SPIN_LIMIT) { atomicExch(err, 1u); break; }
+      if (++spins > spin_limit) { atomicExch(err, 1u); break; }
       f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+#if !RUN_SC1_WINDOW
   if (run.n_deps && !(RUN_DBG & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // this wavefront's own loads follow
+#endif
   // window: at most 41 rows x 6 chunks of 8 samples
   const int nchx = (wx1 - ax0 + 7) >> 3, nrows = wy1 - wy0, nchunks = nchx * nrows;
   {
+    const __amdgpu_buffer_rsrc_t wrs = plane_rsrc(plane);
     uint4 v[4]; int off[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -1437,7 +1467,14 @@ __device__ __forceinline__ void micro_run(const PicDev& P, const PlaneRef& pl0, 
       if (idx < nchunks) {
         const int rr = idx / nchx, cx = idx - rr * nchx;
         const int gx = ax0 + 8 * cx, gy = wy0 + rr;
-        if (gx >= 0 && gy >= 0) { v[u] = load8_as_u16(plane + gx + gy * stride); off[u] = rr * MICRO_P + 8 * cx; }
+        if (gx >= 0 && gy >= 0) {
+#if RUN_SC1_WINDOW
+          v[u] = load8_as_u16_sc1(wrs, plane, gx + gy * stride);
+#else
+          v[u] = load8_as_u16(plane + gx + gy * stride);
+#endif
+          off[u] = rr * MICRO_P + 8 * cx;
+        }
       }
     }
 #pragma unroll
@@ -1483,7 +1520,7 @@ __global__ __launch_bounds__(64 * RUN_WAVES)
 void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __restrict__ runs,
            const uint32_t* __restrict__ deps, uint32_t* sync, uint32_t* err, const TuTask* __restrict__ tasks,
            const int16_t* __restrict__ resid, const uint32_t* __restrict__ slots, int n_batches, int batch, uint32_t ticket_base,
-           uint32_t gen, int dbg)
+           uint32_t gen, int dbg, uint32_t spin_limit)
 {
   constexpr int RUN_TILE_H = RUN_TILE_H_OF(BOX), RUN_TILE_P = RUN_TILE_P_OF(BOX);
   constexpr int MAX_TUS = BOX * BOX / 16;
@@ -1574,7 +1611,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
       for (int i = 1; i < RUN_TICKET_SLOTS; i++) mine = q == i ? slv[i] : mine;     // (scalar selects: no register array)
       if (mine != 0xFFFFFFFFu)
         micro_run<PX>(P, pl0, pl1, pl2, runs, deps, sync, err, tasks, resid, tile + (q & 3) * MICRO_SLICE,
-                      reinterpret_cast<int16_t*>(s_res) + (q & 3) * MICRO_RES, mine & 0x7FFFFFFFu, lane, gen, dbg);
+                      reinterpret_cast<int16_t*>(s_res) + (q & 3) * MICRO_RES, mine & 0x7FFFFFFFu, lane, gen, dbg, spin_limit);
     }
     continue;
   }
@@ -1621,6 +1658,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   const bool dense = run.micro & 2;
   const int nchunks = dense ? nchx + nrows - 1 : nchx * nrows;
   uint4 wv[4]; int woff[4];
+  const __amdgpu_buffer_rsrc_t wrs = plane_rsrc(plane);
   auto window_issue = [&](int base, int nth, int id) {
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -1633,7 +1671,11 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
         const int gx = ax0 + 8 * cx, gy = wy0 + r;
         // the bottom-right 32x32 corner of the window is never read
         if (gx >= 0 && gy >= 0 && !(gx >= (int)run.x1 && gy >= (int)run.y1)) {
+#if RUN_SC1_WINDOW
+          wv[u] = load8_as_u16_sc1(wrs, plane, gx + gy * stride);
+#else
           wv[u] = load8_as_u16(plane + gx + gy * stride);
+#endif
           woff[u] = r * RUN_TILE_P + 8 * cx;
         }
       }
@@ -1648,12 +1690,15 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   // under the preparation of the samples, instead of after it
   const bool early = !(RUN_DBG & 8) && (run.n_deps == 0 || __syncthreads_and(flag0 == gen));
   if (early) {
+#if !RUN_SC1_WINDOW
     if (run.n_deps && !(RUN_DBG & 2)) {
       // one acquire per workgroup (the L1 belongs to the CU): wavefront 0 invalidates and waits for it,
       // the others load behind the barrier
       if (wave == 0) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
       __syncthreads();
     }
+#endif
+    // (sc1 window loads: the barrier inside __syncthreads_and above is the one every wavefront's loads must come behind)
     window_issue(0, nthr, tid);
   }
   if (!(RUN_DBG & 64))
@@ -1665,17 +1710,18 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   else if (run.n_deps) {
     for (int i = tid; i < run.n_deps; i += nthr) {
       const uint32_t* flag = &sync[2 + (i == tid ? dep_id : deps[run.dep_offset + i])];
-      int spins = 0;
+      uint32_t spins = 0;
       uint32_t f = (i == tid) ? flag0 : gen - 1u;
       while (f != gen && !(RUN_DBG & 32)) {                                  // (dbg 32: timing-only ablation, ignores producers)
         // back off: hundreds of waiting wavefronts polling at full rate starve the fabric (s_sleep 64 instead of 16 here
         // costs 3 % of an all-intra picture: the flag is seen up to 2 us late)
         if (spins) { if (spins < RUN_POLL_FAST_N) __builtin_amdgcn_s_sleep(RUN_POLL_FAST); else __builtin_amdgcn_s_sleep(RUN_POLL_SLOW); }
-        if (++spins > RUN_SPIN_LIMIT) { atomicExch(err, 1u); break; }           // never hang the grid
+        if (++spins > spin_limit) { atomicExch(err, 1u); break; }               // never hang the grid
         f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     __syncthreads();
+#if !RUN_SC1_WINDOW
     if (dense && nchunks <= 256 && !(RUN_DBG & 2)) {
       // the few border chunks of a dense run: the acquiring wavefront fetches them itself, straight behind the invalidate
       // (its own loads need neither the wait for it nor a barrier), instead of acquire -> wait -> barrier -> loads by all
@@ -1688,6 +1734,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
       if (wave == 0) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
       __syncthreads();
     }
+#endif
   }
   st.mark(3);
   if (!(RUN_DBG & 8))
@@ -1857,8 +1904,8 @@ template __global__ void k_tu<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, con
                                        const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
 template __global__ void k_tu<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int,
                                         const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
-template __global__ void k_run<uint8_t, 64>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, const uint32_t*, int, int, uint32_t, uint32_t, int);
-template __global__ void k_run<uint16_t, 64>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, const uint32_t*, int, int, uint32_t, uint32_t, int);
+template __global__ void k_run<uint8_t, 64>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, const uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t);
+template __global__ void k_run<uint16_t, 64>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, const uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t);
 template __global__ void k_fn_residual<uint8_t>(int, int, int, uint8_t*, int, const int32_t*, const int16_t*);
 template __global__ void k_fn_residual<uint16_t>(int, int, int, uint16_t*, int, const int32_t*, const int16_t*);
 

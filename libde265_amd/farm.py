@@ -108,8 +108,10 @@ def send_reference_picture_dpb(dist, dec, slot, src, dst, rank):
     import torch
     if rank not in (src, dst):
         return
-    if rank == src:
-        dec.sync()                                   # the picture is finished before it leaves
+    # both sides: the sender's picture is finished before it leaves; on the receiver, everything its decoder has already
+    # enqueued (pictures that still read the slot's old content as a reference, a copy-out of it) is done before RCCL,
+    # which runs on torch's stream, overwrites the slot
+    dec.sync()
     for t in dpb_plane_tensors(dec, slot):
         if rank == src:
             dist.send(t, dst=dst)
@@ -122,8 +124,7 @@ def broadcast_reference_picture_dpb(dist, dec, slot, src, rank, group=None):
     """The same for several consumers: RCCL broadcast of the three planes from rank `src` (per-link bound on xGMI:
     prefer send_reference_picture_dpb to the actual consumers when they are few)."""
     import torch
-    if rank == src:
-        dec.sync()
+    dec.sync()                                       # (sender: picture finished; receivers: nothing queued still uses the slot)
     for t in dpb_plane_tensors(dec, slot):
         dist.broadcast(t, src=src, group=group)
     torch.cuda.synchronize()

@@ -591,3 +591,123 @@ def test_pipeline_builds_concurrently_and_launches_in_order(dec):
         pipe.close()
         for p in pins:
             p.free()
+
+
+def _recorder_maker(sp):
+    def make():
+        d = sp.d
+        sf = np.ctypeslib.as_array(d.scaling_factors, shape=(_abi.SCALING_BLOB_BYTES,)).copy() if d.params.scaling_list_enable_flag else None
+        rec = backend.Recorder(d.params, sf)
+        rec.record_desc(d)
+        return rec
+    return make
+
+
+def test_picture_size_change_with_pictures_still_in_flight():
+    """A new sequence with another picture size while pictures of the old size are built but not launched yet (the pipeline
+    builds ahead of its launches): the old pictures must keep their planes - slots and the SAO target are re-allocated in
+    launch order, by the first picture of the new size - and every picture of both sizes must come out as the oracle has it.
+    A picture of the new size that refers to a slot still holding the old size is refused when it is launched."""
+    wa, ha, wb, hb, bd = 416, 240, 208, 120, 10
+    d = backend.Decoder()
+    first = pysynth.fill_planes(wa, ha, bd, 41)
+    d.dpb_alloc(0, wa, ha, bd); d.upload(0, first)
+    jobs, prev = [], first                           # (slot, SynthPicture, expected planes, (w, h))
+    for k in range(4):                               # size A: a chain of P pictures, picture k -> slot k + 1
+        sp = pysynth.SynthPicture(pysynth.default_config(wa, ha, bd, 1, seed=1200 + k, ref_slots=[k]))
+        exp = pyoracle.alloc_planes(wa, ha, bd)
+        pyoracle.reconstruct(sp.desc, sp.order, {k: prev}, exp)
+        jobs.append((k + 1, sp, exp, (wa, ha))); prev = exp
+    spi = pysynth.SynthPicture(pysynth.default_config(wb, hb, bd, 2, seed=1210))       # size B: an I picture into slot 1 ...
+    expi = pyoracle.alloc_planes(wb, hb, bd)
+    pyoracle.reconstruct(spi.desc, spi.order, {}, expi)
+    jobs.append((1, spi, expi, (wb, hb)))
+    spp = pysynth.SynthPicture(pysynth.default_config(wb, hb, bd, 1, seed=1211, ref_slots=[1]))   # ... and a P picture from it into slot 2
+    expp = pyoracle.alloc_planes(wb, hb, bd)
+    pyoracle.reconstruct(spp.desc, spp.order, {1: expi}, expp)
+    jobs.append((2, spp, expp, (wb, hb)))
+    bad = pysynth.SynthPicture(pysynth.default_config(wb, hb, bd, 1, seed=1212, ref_slots=[4]))   # slot 4 still holds size A
+    pipe = backend.Pipeline(d, 3)
+    pins = [backend.PinnedPlanes(w, h, bd) for _, _, _, (w, h) in jobs]
+    try:
+        tickets = [pipe.submit(slot, _recorder_maker(sp), pins[i]) for i, (slot, sp, _, _) in enumerate(jobs)]
+        t_bad = pipe.submit(5, _recorder_maker(bad), None)
+        for i in reversed(range(len(jobs))):
+            pipe.wait(tickets[i])
+            assert all(np.array_equal(g, e) for g, e in zip(pins[i].planes, jobs[i][2])), i
+        with pytest.raises(backend.De265HipError) as e:
+            pipe.wait(t_bad)
+        assert e.value.code == _abi.ERROR_PARAMETER_OUT_OF_RANGE
+        assert d.dpb_info(1)[:2] == (wb, hb) and d.dpb_info(3)[:2] == (wa, ha)
+        pipe.drain()
+    finally:
+        pipe.close()
+        for p in pins:
+            p.free()
+        d.close()
+
+
+def test_dpb_copy_into_a_slot_that_queued_pictures_still_read():
+    """Open-GOP hand-over into a LIVE reference slot: the destination decoder has pictures queued that predict
+    from slot 0 when de265hip_dpb_copy overwrites slot 0 from another decoder.  The queued pictures must see the old content,
+    the picture enqueued after the copy the new one."""
+    w, h, bd = 1280, 720, 8
+    old0, ref1, new0 = (pysynth.fill_planes(w, h, bd, s) for s in (51, 52, 53))
+    sp = pysynth.SynthPicture(pysynth.default_config(w, h, bd, 0, seed=1300, ref_slots=[0, 1], intra_pct=5))
+    exp_old, exp_new = pyoracle.alloc_planes(w, h, bd), pyoracle.alloc_planes(w, h, bd)
+    pyoracle.reconstruct(sp.desc, sp.order, {0: old0, 1: ref1}, exp_old)
+    pyoracle.reconstruct(sp.desc, sp.order, {0: new0, 1: ref1}, exp_new)
+    src, dst = backend.Decoder(), backend.Decoder()
+    try:
+        src.dpb_alloc(7, w, h, bd); src.upload(7, new0)
+        for s, pl in ((0, old0), (1, ref1)):
+            dst.dpb_alloc(s, w, h, bd); dst.upload(s, pl)
+        for s in (2, 3):
+            dst.dpb_alloc(s, w, h, bd); dst.upload(s, pyoracle.alloc_planes(w, h, bd))
+        pic2, pic3 = dst.build(2, sp.desc), dst.build(3, sp.desc)
+        for _ in range(8):                             # a queue of pictures that read slot 0 ...
+            dst.run(pic2, 2)
+        pend = dst.download_async(0, w, h, bd)         # ... and a copy-out of its old content
+        src.copy_slot_to(7, dst, 0)                    # overwrite it, stream-ordered on both sides
+        dst.run(pic3, 2)
+        dst.sync()
+        assert all(np.array_equal(g, e) for g, e in zip(pend.wait(), old0))
+        assert all(np.array_equal(g, e) for g, e in zip(dst.download(2, w, h, bd), exp_old))
+        assert all(np.array_equal(g, e) for g, e in zip(dst.download(3, w, h, bd), exp_new))
+        pend.free(); pic2.free(); pic3.free()
+    finally:
+        src.close(); dst.close()
+
+
+def test_expired_dependency_wait_surfaces_as_decoding_error(monkeypatch):
+    """The one device-side failure mode of the design: a k_run wavefront waits for a producer run whose flag never comes.
+    Fault injection in the host stage (DE265HIP_TEST_DROP_PRODUCER: one run that others depend on is left out of the ticket
+    list) with a short bound on the waits: the picture must FAIL - de265hip_decoder_sync returns
+    DE265_ERROR_UNSPECIFIED_DECODING_ERROR - within the bound instead of hanging or passing as a wrong picture, and the next
+    picture on the same decoder must decode correctly."""
+    import time
+    w, h, bd = 416, 240, 8
+    monkeypatch.setenv("DE265HIP_TEST_SPIN_LIMIT", "400")
+    d = backend.Decoder()
+    try:
+        sp = pysynth.SynthPicture(pysynth.default_config(w, h, bd, 2, seed=1400))
+        exp = pyoracle.alloc_planes(w, h, bd)
+        pyoracle.reconstruct(sp.desc, sp.order, {}, exp)
+        d.dpb_alloc(2, w, h, bd)
+        monkeypatch.setenv("DE265HIP_TEST_DROP_PRODUCER", "1")
+        bad = d.build(2, sp.desc)
+        monkeypatch.delenv("DE265HIP_TEST_DROP_PRODUCER")
+        assert bad.stats().n_run_levels > 1              # there is something to wait for
+        t0 = time.perf_counter()
+        d.run(bad, 2)
+        with pytest.raises(backend.De265HipError) as e:
+            d.sync()
+        assert e.value.code == _abi.ERROR_DECODING
+        assert time.perf_counter() - t0 < 5.0
+        bad.free()
+        good = d.build(2, sp.desc)                       # same decoder, same slot: the error state is gone
+        d.run(good, 2); d.sync()
+        assert all(np.array_equal(g, e_) for g, e_ in zip(d.download(2, w, h, bd), exp))
+        good.free()
+    finally:
+        d.close()
