@@ -43,7 +43,7 @@ PMC_KERNEL = {"intra": ["k_run<unsigned short, 64>"], "mc": ["k_mc<unsigned shor
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 CONFIG_ID = 4                  # SURVEY 8d config 4 -> seed 0xDE265000 + 4
 
-ALG_KEY = {"mc": "alg_bytes_mc", "resid": "alg_bytes_resid", "intra": "alg_bytes_intra",
+ALG_KEY = {"mc": "alg_bytes_mc", "resid": "alg_bytes_resid", "intra": "alg_bytes_intra", "intra_front": "alg_bytes_intra_front",
            "deblock_v": "alg_bytes_deblock", "deblock_h": "alg_bytes_deblock", "sao": "alg_bytes_sao"}
 
 
@@ -378,7 +378,7 @@ def main():
                    for k, v in ktimes_all.items()}
 
         # all kernels together: algorithmic bytes of a step (every stage of every picture) over the step's wall time
-        alg_step = sum(getattr(s_, a) for s_ in stats for a in ("alg_bytes_mc", "alg_bytes_resid", "alg_bytes_intra", "alg_bytes_deblock", "alg_bytes_sao"))
+        alg_step = sum(getattr(s_, a) for s_ in stats for a in ("alg_bytes_mc", "alg_bytes_resid", "alg_bytes_intra", "alg_bytes_intra_front", "alg_bytes_deblock", "alg_bytes_sao"))
         agg_gbs = (alg_step / 1e9) / (elapsed / args.steps)
         aggregate = {"alg_bytes_per_step": int(alg_step), "achieved": round(agg_gbs, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
                      "frac": round(agg_gbs / HBM_PEAK_GBS, 4),

@@ -357,9 +357,12 @@ typedef struct de265hip_picture_stats {
   int64_t device_bytes;      /* command-buffer bytes resident in HBM */
   int64_t alg_bytes_mc;      /* algorithmic bytes, SURVEY 8d definitions */
   int64_t alg_bytes_resid;
-  int64_t alg_bytes_intra;
+  int64_t alg_bytes_intra;       /* run kernel only; see alg_bytes_intra_front */
   int64_t alg_bytes_deblock;
   int64_t alg_bytes_sao;
+  int64_t alg_bytes_intra_front; /* the part of the intra work done by the front kernel (alg_bytes_intra: the run kernel's part) */
+  int32_t n_front_runs;          /* of n_runs: runs without producers, reconstructed ahead of the run kernel */
+  int32_t pad;
 } de265hip_picture_stats;
 int  de265hip_picture_get_stats(const de265hip_picture*, de265hip_picture_stats*);
 
@@ -373,7 +376,8 @@ int  de265hip_picture_get_stats(const de265hip_picture*, de265hip_picture_stats*
 #define DE265HIP_K_DEBLOCK_H 5
 #define DE265HIP_K_SAO       6
 #define DE265HIP_K_PCM       7
-#define DE265HIP_K_COUNT     8
+#define DE265HIP_K_INTRA_FRONT 8 /* intra runs without producers (k_intra_front), ahead of the run kernel */
+#define DE265HIP_K_COUNT     9
 /* enable: 0 = off, 1 = every kernel, otherwise a mask with bit (id + 1) set for each kernel id to be timed
  * (DE265HIP_PROFILE_ONLY(id)): every timed launch costs two event records on the stream. */
 #define DE265HIP_PROFILE_ONLY(id) (2 << (id))

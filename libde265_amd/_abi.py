@@ -21,7 +21,7 @@ TU_INTRA, TU_CBF, TU_TSKIP, TU_BYPASS = 1, 2, 4, 8
 BLK_INTRA, BLK_NONZERO, BLK_PCM, BLK_BYPASS = 1, 2, 4, 8
 BLK_EDGE_TU_V, BLK_EDGE_TU_H, BLK_EDGE_PB_V, BLK_EDGE_PB_H = 0x10, 0x20, 0x40, 0x80
 
-K_NAMES = ["mc", "resid", "intra", "bs", "deblock_v", "deblock_h", "sao", "pcm"]
+K_NAMES = ["mc", "resid", "intra", "bs", "deblock_v", "deblock_h", "sao", "pcm", "intra_front"]
 
 
 class PicParams(C.Structure):
@@ -126,4 +126,5 @@ class PictureStats(C.Structure):
         ("alg_bytes_mc", C.c_int64), ("alg_bytes_resid", C.c_int64),
         ("alg_bytes_intra", C.c_int64), ("alg_bytes_deblock", C.c_int64),
         ("alg_bytes_sao", C.c_int64),
+        ("alg_bytes_intra_front", C.c_int64), ("n_front_runs", C.c_int32), ("pad", C.c_int32),
     ]

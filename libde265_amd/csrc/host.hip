@@ -118,6 +118,7 @@ struct de265hip_picture {
   TuTask* d_l0 = nullptr; int n_l0 = 0;       // run mode: inter residual TUs + residual-only copies of intra TUs
   int16_t* d_resid = nullptr;                 // precomputed residual blocks of intra TUs
   int n_runs = 0, n_batches = 0, n_workers = 0, run_box = 64, ticket_batch = 1; size_t sync_bytes = 0;
+  int n_front = 0;                            // runs [0, n_front): micro runs without producers, reconstructed by k_intra_front ahead of k_run
   bool run_direct = false;                    // k_run with one workgroup per ticket instead of persistent workers (wide pictures)
   uint32_t* d_slots = nullptr;
   uint32_t gen = 0;                           // runs of this picture so far (k_run flag generation)
@@ -747,11 +748,11 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   const int map_h[3] = { g.h4, (p.height / 2 + 3) / 4, (p.height / 2 + 3) / 4 };
   for (int c = 0; c < 3; c++) lvl[c].assign((size_t)map_w[c] * map_h[c], 0);
   int max_level = 0;
-  int64_t alg_resid = 0, alg_intra = 0;
+  int64_t alg_resid = 0, alg_intra = 0, alg_intra_front = 0;
   // runs: maximal intervals of the per-component intra TU sequence inside one CTB in which
   // every TU reads from the run so far (see k_run); independent TUs start a new run
   struct RunBuild { int c, ctu, x0, y0, x1, y1, level, wx1, wy1; std::vector<TuTask> tus; std::vector<int> deps;
-                    std::vector<uint16_t> llev; int est = 1; };     // est: run level as far as known during the scan (merge heuristic)
+                    std::vector<uint16_t> llev; int est = 1; int64_t alg = 0; };     // est: run level as far as known during the scan (merge heuristic)
   std::vector<RunBuild> rb;
   std::vector<int32_t> runmap[3];
   for (int c = 0; c < 3; c++) runmap[c].assign((size_t)map_w[c] * map_h[c], -1);
@@ -869,6 +870,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
           runmap[c][x + (size_t)y * map_w[c]] = r;
         }
       alg_intra += (int64_t)bpp * (4 * nT + 1) + (int64_t)bpp * nT * nT;
+      R.alg += (int64_t)bpp * (4 * nT + 1) + (int64_t)bpp * nT * nT;
       if (level >= 65535) { delete pic; return DE265HIP_ERROR_NOT_IMPLEMENTED; }
     }
     if (t.flags & DE265HIP_TU_CBF)
@@ -899,7 +901,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   int64_t sum_lvls = 0, dbg_foreign = 0, dbg_w[4] = { 0, 0, 0, 0 };
   std::vector<uint8_t> dbg_micro;
   size_t n_resid = 0;
-  int max_rl = 0;
+  int max_rl = 0, n_front = 0;
   {
     for (auto& R : rb) { int l = 0; for (int dp : R.deps) l = std::max(l, rb[dp].level); R.level = l + 1; max_rl = std::max(max_rl, R.level); }
     std::vector<int> count(max_rl + 2, 0), order(rb.size()), newidx(rb.size());
@@ -931,8 +933,16 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     for (size_t l = 0; l + 1 < count2.size(); l++) count2[l + 1] += count2[l];
     for (size_t i = 0; i < rb.size(); i++) { int k = count2[2 * rb[i].level + (micro[i] ? 0 : 1)]++; order[k] = (int)i; newidx[i] = k; }
     runs.resize(rb.size());
+    // Front runs: the micro runs of level 1 (no producer among the intra runs) - the first block of the run order.  They are
+    // reconstructed by k_intra_front, one small workgroup each, ahead of k_run: no ticket, no flag, and the runs that read
+    // from them do not list them as producers (the kernel boundary orders them).  DE265HIP_NO_FRONT=1: through k_run as all others.
+    static const bool front_off = getenv("DE265HIP_NO_FRONT") != nullptr;
+    n_front = 0;
+    if (!front_off && !dec->intra_levels)
+      while ((size_t)n_front < rb.size() && micro[order[n_front]] && rb[order[n_front]].level == 1) n_front++;
     // ticket slots: a ticket is a batch of RUN_TICKET_SLOTS slots: that many micro runs, or one ordinary run (+ empty slots)
-    for (size_t k = 0; k < rb.size(); k++) {
+    for (int k = 0; k < n_front; k++) alg_intra_front += rb[order[k]].alg;
+    for (size_t k = (size_t)n_front; k < rb.size(); k++) {
       if (micro[order[k]]) slots.push_back((uint32_t)k | 0x80000000u);
       else {
         while (slots.size() % RUN_TICKET_SLOTS) slots.push_back(0xFFFFFFFFu);
@@ -943,7 +953,8 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     while (slots.size() % RUN_TICKET_SLOTS) slots.push_back(0xFFFFFFFFu);
     if (getenv("DE265HIP_TEST_DROP_PRODUCER")) {         // fault injection: the first run somebody depends on is never executed
       int victim = -1;
-      for (size_t i = 0; i < rb.size() && victim < 0; i++) if (!rb[i].deps.empty()) victim = newidx[rb[i].deps[0]];
+      for (size_t i = 0; i < rb.size() && victim < 0; i++)
+        for (int dp : rb[i].deps) if (victim < 0 && newidx[dp] >= n_front) victim = newidx[dp];
       for (uint32_t& v : slots) if (v != 0xFFFFFFFFu && (int)(v & 0x7FFFFFFFu) == victim) v = 0xFFFFFFFFu;
     }
     for (size_t k = 0; k < rb.size(); k++) {
@@ -972,7 +983,8 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
         }
       }
       o.c_idx = (uint8_t)R.c; o.micro = (uint8_t)(micro[order[k]] | (dense ? 2 : 0)); o.n_tus = (uint16_t)R.tus.size();
-      o.first_tu = (uint32_t)run_tus.size(); o.dep_offset = (uint32_t)run_deps.size(); o.n_deps = (uint16_t)R.deps.size();
+      o.first_tu = (uint32_t)run_tus.size(); o.dep_offset = (uint32_t)run_deps.size();
+      { int nd = 0; for (int dp : R.deps) nd += newidx[dp] >= n_front; o.n_deps = (uint16_t)nd; }
       o.res_offset = (uint32_t)n_resid;
       // TUs of the run: the TUs of one in-run level are independent of each other and are dealt round-robin to
       // the wavefronts of the workgroup; stored as one list per wavefront, each in level order, level in the record
@@ -1016,10 +1028,12 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
         const size_t ti = (size_t)(keys[oi] & 0xFFFFFu);
         TuTask tt = R.tus[ti];
         const uint32_t coeff_offset = tt.coeff_offset;
+        // the run's residual range is laid out by SAMPLE of the run (blocks of TUs without coefficients stay unwritten and are
+        // masked by the kernels): a run's residuals are one contiguous, 16-byte aligned vector the run kernels fetch right
+        // behind the run record, before they have seen a single TU record
+        tt.resid_offset = (uint32_t)n_resid + samp;
         tt.coeff_offset = samp; samp += 1u << (2 * tt.log2_size);
         if (tt.flags & DE265HIP_TU_CBF) {
-          tt.resid_offset = (uint32_t)n_resid;
-          n_resid += (size_t)1 << (2 * tt.log2_size);
           TuTask ro = tt; ro.flags |= D265_TU_RESID_ONLY; ro.coeff_offset = coeff_offset;
           resid_only.push_back(ro);
         }
@@ -1027,15 +1041,18 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
         run_tus.push_back(tt);
       }
       o.n_samples = samp;
-      for (int dp : R.deps) run_deps.push_back((uint32_t)newidx[dp]);
+      n_resid += (samp + 7u) & ~7u;
+      for (int dp : R.deps) if (newidx[dp] >= n_front) run_deps.push_back((uint32_t)newidx[dp]);
     }
   }
   pt.mark("runs");
   pic->n_runs = (int)runs.size();
+  pic->n_front = n_front;
   {
     // worker count = widest dependency level (more workers would only wait), within [64, 4 per CU]
     std::vector<int> width(max_rl + 2, 0);
     for (auto& R : rb) width[R.level]++;
+    if (max_rl >= 1) width[1] -= n_front;
     int widest = 0; for (int wv : width) widest = std::max(widest, wv);
     const char* wenv = getenv("DE265HIP_RUN_WORKERS");
     // LDS-limited residency is 3 workgroups per CU (768); 2 per CU leave LDS for the kernels of the other GOP streams:
@@ -1054,6 +1071,13 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     // streams' kernels need.  Off unless asked for.
     pic->run_direct = denv ? atoi(denv) != 0 : false;
     if (getenv("DE265HIP_PRINT_CRIT")) {               // diagnostic: longest path through the run DAG
+      {
+        std::vector<int> wm(max_rl + 2, 0), wo(max_rl + 2, 0);
+        for (size_t i = 0; i < rb.size(); i++) (dbg_micro[i] ? wm : wo)[rb[i].level]++;
+        fprintf(stderr, "de265hip runs per level (micro/ordinary):");
+        for (int l = 1; l <= std::min(max_rl, 12); l++) fprintf(stderr, " %d/%d", wm[l], wo[l]);
+        fprintf(stderr, "\n");
+      }
       // cost model of one run (us; fitted to ablation timings): fixed + per barrier level + per TU a wavefront has to do
       // in sequence inside a level + per 16x16 / 32x32 TU (collective)
       struct Path { double t = 0, lv = 0, slots = 0, n16 = 0, n32 = 0; int runs = 0; };
@@ -1317,7 +1341,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
                             run_tus.size() * sizeof(TuTask), slots.size() * 4, l0.size() * sizeof(TuTask), 0 };
     for (int i = 0; i < 19; i++) mix(host.data() + offs[i], lens[i]);      // (only the written bytes: padding between sections is undefined)
     const int64_t scal[] = { pic->n_workers, pic->n_batches, pic->n_l0, pic->n_l0_size[0], pic->n_l0_size[1], pic->n_l0_size[2], pic->n_l0_size[3], pic->n_mc, pic->n_pcm,
-                             pic->n_tus, pic->n_runs, (int64_t)n_resid, (int64_t)L.total, (int64_t)pic->any_edges, (int64_t)P.has_exempt, (int64_t)pic->run_direct, max_level, max_rl, (int64_t)sum_lvls };
+                             pic->n_tus, pic->n_runs, (int64_t)n_resid, (int64_t)L.total, (int64_t)pic->any_edges, (int64_t)P.has_exempt, (int64_t)pic->run_direct, max_level, max_rl, (int64_t)sum_lvls, (int64_t)pic->n_front };
     mix(scal, sizeof(scal));
     mix(pic->level_start.data(), pic->level_start.size() * sizeof(int));
     dec->pooled_bytes = (size_t)hsh;
@@ -1359,7 +1383,8 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   pic->stats.n_runs = pic->n_runs; pic->stats.n_run_levels = max_rl;
   pic->stats.n_in_run_levels = (int32_t)sum_lvls;
   pic->stats.device_bytes = (int64_t)L.total;
-  pic->stats.alg_bytes_mc = alg_mc; pic->stats.alg_bytes_resid = alg_resid; pic->stats.alg_bytes_intra = alg_intra;
+  pic->stats.alg_bytes_mc = alg_mc; pic->stats.alg_bytes_resid = alg_resid; pic->stats.alg_bytes_intra = alg_intra - alg_intra_front;
+  pic->stats.alg_bytes_intra_front = alg_intra_front; pic->stats.n_front_runs = pic->n_front;
   pic->stats.alg_bytes_deblock = pic->any_edges ? 2 * Pbytes : 0;       // one read + one write
   pic->stats.alg_bytes_sao = p.sample_adaptive_offset_enabled_flag ? 2 * Pbytes + 16 * (int64_t)d->n_ctbs : 0;
   if (!dec->dry) {
@@ -1490,7 +1515,12 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
                              pic->d_cval, pic->d_cpos, pic->d_scaling, pic->d_resid);
       }
     }
-    if (pic->n_runs > 0) {
+    if (pic->n_front > 0) {                                         // the runs nobody has to wait for: one small workgroup each
+      KTimer t(dec, DE265HIP_K_INTRA_FRONT, 1);
+      hipLaunchKernelGGL(k_intra_front<PX>, dim3(pic->n_front), dim3(64), 0, st, P, d0, d1, d2, pic->d_runs, pic->d_run_tus, pic->d_resid,
+                         pic->n_front);
+    }
+    if (pic->n_batches > 0) {
       KTimer t(dec, DE265HIP_K_INTRA, 1);
       // ticket counter and run flags are not cleared between runs of a picture: every workgroup draws exactly one
       // ticket beyond the last batch, so run g starts at ticket g * (n_batches + n_workers), and a flag is "raised"

@@ -935,11 +935,17 @@ __device__ __forceinline__ int wave_max_dpp(int v)
 #define WAVE_BARRIER_ONLY() asm volatile("" ::: "memory")
 #define RUN_MAX_TUS 256                 // a run lies inside one 64x64 CTB: at most 256 TUs / levels
 
-template <typename PX> __device__ __forceinline__ void store4_packed(PX* g, int v0123_lo, int v0123_hi);
-template <> __device__ __forceinline__ void store4_packed<uint16_t>(uint16_t* g, int lo, int hi)
+// WT: write-through (sc1) store - the bytes are handed to another run through a flag; otherwise a plain store (runs of
+// the front kernel: nobody reads them before the kernel boundary)
+template <typename PX, bool WT> __device__ __forceinline__ void store4_packed(PX* g, int v0123_lo, int v0123_hi);
+template <> __device__ __forceinline__ void store4_packed<uint16_t, true>(uint16_t* g, int lo, int hi)
 { store4_from_u16(g, make_uint2((uint32_t)lo, (uint32_t)hi)); }
-template <> __device__ __forceinline__ void store4_packed<uint8_t>(uint8_t* g, int lo, int hi)
+template <> __device__ __forceinline__ void store4_packed<uint8_t, true>(uint8_t* g, int lo, int hi)
 { store4_from_u16(g, make_uint2((uint32_t)lo, (uint32_t)hi)); }
+template <> __device__ __forceinline__ void store4_packed<uint16_t, false>(uint16_t* g, int lo, int hi)
+{ *reinterpret_cast<uint2*>(g) = make_uint2((uint32_t)lo, (uint32_t)hi); }
+template <> __device__ __forceinline__ void store4_packed<uint8_t, false>(uint8_t* g, int lo, int hi)
+{ *reinterpret_cast<uint32_t*>(g) = ((uint32_t)lo & 0xFF) | (((uint32_t)lo >> 8) & 0xFF00) | (((uint32_t)hi & 0xFF) << 16) | (((uint32_t)hi >> 16) << 24); }
 
 // LDS byte address (inside the pixel window) that border entry p of a TU reads; const_addr when no
 // neighbour is available at all.  Border order as intrapred.cc:577-688: p = 0 bottom-left ... 2nT corner ... 4nT.
@@ -968,8 +974,7 @@ __device__ __forceinline__ int run_gather_addr(int p, int nT, int xB, int yB, ui
 // Off-chain preparation of sample s of the run (one thread per sample).
 template <int RUN_TILE_P>
 __device__ __forceinline__ void run_prepare_sample(int s, const uint4* s_task, const uint8_t* s_own, int32_t* s_res,
-                                                   uint32_t* s_ctl, uint32_t* s_ex, uint32_t* s_mine,
-                                                   const int16_t* __restrict__ resid, uint32_t res_base, int const_addr)
+                                                   uint32_t* s_ctl, uint32_t* s_ex, uint32_t* s_mine, int const_addr)
 {
   const int k = s_own[s >> 4];
   const uint4 r = s_task[k];
@@ -977,13 +982,13 @@ __device__ __forceinline__ void run_prepare_sample(int s, const uint4* s_task, c
   const int samp = (r.y & 0x3FFF) >> 2, local = s - samp;
   const int x = local & (nT - 1), y = local >> log2;
   const int xB = (r.w >> 13) & 0x7F, yB = (r.w >> 20) & 0x7F;
-  const int rs16 = (r.x & RTU_CBF) ? (int)resid[res_base + ((r.w >> 1) & 0xFFF) + local] : 0;
   if ((x & 3) == 0) atomicOr(&s_mine[yB + y], 1u << ((xB + x) >> 2));
   const int kind = (r.x >> 24) & 3;
   const bool vert = r.x & RTU_VERT;
   // the sample's residual and, above it, its angular weight ((x+1) or (y+1)) * angle & 31: the chain's common path then
   // needs neither the TU's angle nor the lane's position
-  s_res[s] = (rs16 & 0xFFFF) | ((__mul24(vert ? y + 1 : x + 1, (int)(int8_t)(r.y >> 24)) & 31) << 16);
+  // (the residual is already there, low half: fetched as one vector per run behind the run record, k_run)
+  s_res[s] = (s_res[s] & 0xFFFF) | ((__mul24(vert ? y + 1 : x + 1, (int)(int8_t)(r.y >> 24)) & 31) << 16);
   const int C = 2 * nT;
   int A = C - 1 - y, B = C + 1 + x;                   // planar / DC: A = left[y], B = top[x]
   if (kind >= 2) {                                    // angular (intrapred.cc:903-1069), reference array evaluated in place
@@ -1210,7 +1215,7 @@ __device__ __forceinline__ RunTask load_run_task(const RunTask* __restrict__ run
 
 // one 4x4 / 8x8 TU, operands computed on the spot (intrapred.cc:395-431 substitution, :816-889 smoothing,
 // :903-1069 predictors); t in window coordinates; rs = this lane's residual
-template <int LOG2, typename PX>
+template <int LOG2, typename PX, bool WT>
 __device__ __forceinline__ void micro_intra_tu(const RunTu& t, uint16_t* tile, int lane, int rs, int bd, PX* gdst, int gstride)
 {
   constexpr int nT = 1 << LOG2, nS = nT * nT, NB = 4 * nT + 1, C = 2 * nT;       // C: lane of border[0]
@@ -1285,14 +1290,14 @@ __device__ __forceinline__ void micro_intra_tu(const RunTu& t, uint16_t* tile, i
   // four adjacent lanes are packed with two DPP row shifts, every fourth lane issues one write-through store
   const int w01 = outv | (__builtin_amdgcn_update_dpp(0, outv, 0x101, 0xf, 0xf, true) << 16);   // row_shl:1
   const int w23 = __builtin_amdgcn_update_dpp(0, w01, 0x102, 0xf, 0xf, true);                   // row_shl:2
-  if (lane < nS && (x & 3) == 0) store4_packed<PX>(gdst + x + y * gstride, w01, w23);
+  if (lane < nS && (x & 3) == 0) store4_packed<PX, WT>(gdst + x + y * gstride, w01, w23);
   WAVE_BARRIER_ONLY();
 }
 
 // A 16x16 TU inside a micro run (one wavefront): 65 border entries - lanes 0..63 hold border[-32..31] as in
 // micro_intra_tu, the top-right end border[32] lives in a register of its own (bx, the same in every lane) - and four
 // samples per lane (rows y, y+4, y+8, y+12 of column lane & 15).  Availability: 17 units.
-template <typename PX>
+template <typename PX, bool WT>
 __device__ __forceinline__ void micro_intra_tu16(const RunTu& t, uint16_t* tile, int lane, const int16_t* res, int bd, PX* gdst, int gstride)
 {
   constexpr int nT = 16, NB = 65, C = 32, cornerUnit = 8;
@@ -1378,7 +1383,7 @@ __device__ __forceinline__ void micro_intra_tu16(const RunTu& t, uint16_t* tile,
     // four adjacent lanes are packed with two DPP row shifts, every fourth lane issues one write-through store
     const int w01 = outv | (__builtin_amdgcn_update_dpp(0, outv, 0x101, 0xf, 0xf, true) << 16);   // row_shl:1
     const int w23 = __builtin_amdgcn_update_dpp(0, w01, 0x102, 0xf, 0xf, true);                   // row_shl:2
-    if ((x & 3) == 0) store4_packed<PX>(gdst + x + y * gstride, w01, w23);
+    if ((x & 3) == 0) store4_packed<PX, WT>(gdst + x + y * gstride, w01, w23);
   }
   WAVE_BARRIER_ONLY();
 }
@@ -1390,7 +1395,9 @@ __device__ __forceinline__ void micro_intra_tu16(const RunTu& t, uint16_t* tile,
 #else
 #define RUN_DBG 0
 #endif
-template <typename PX>
+// FRONT: a run without producers inside the picture's intra graph (k_intra_front): no flags, no hand-off - plain loads and
+// stores, nothing to publish.
+template <typename PX, bool FRONT>
 __device__ __forceinline__ void micro_run(const PicDev& P, const PlaneRef& pl0, const PlaneRef& pl1, const PlaneRef& pl2,
                                           const RunTask* __restrict__ runs, const uint32_t* __restrict__ deps,
                                           uint32_t* sync, uint32_t* err, const TuTask* __restrict__ tasks,
@@ -1401,7 +1408,7 @@ __device__ __forceinline__ void micro_run(const PicDev& P, const PlaneRef& pl0, 
   const int n_tus = min((int)run.n_tus, MICRO_TUS);
   // one round trip: producer ids (a lane each) and the TU records (a lane each, two 16-byte loads)
   uint32_t dep_id = 0;
-  const bool has_dep = lane < (int)run.n_deps;
+  const bool has_dep = !FRONT && lane < (int)run.n_deps;
   if (has_dep) dep_id = deps[run.dep_offset + lane];
   uint4 ra = make_uint4(0, 0, 0, 0), rb = ra;
   if (lane < n_tus) {
@@ -1417,31 +1424,54 @@ __device__ __forceinline__ void micro_run(const PicDev& P, const PlaneRef& pl0, 
   const int wx0 = (int)run.x0 - 1, wy0 = (int)run.y0 - 1;
   const int ax0 = wx0 & ~7;
   const int wx1 = min(min((int)run.wx1, cw), ax0 + MICRO_P), wy1 = min(min((int)run.wy1, ch), wy0 + MICRO_H);
-  // second round trip: residuals (into this wavefront's LDS slice) and the first look at the producers' flags
+  // The run's residuals (one contiguous int16 vector, by sample of the run: two 16-byte pieces per lane cover the 1024
+  // samples a micro run can have) and, for a front run, its window are fetched in the SAME round trip as the TU records:
+  // neither needs them.  A run with producers takes its first look at their flags instead, the window follows the flags.
+  const int n_samp = min((int)run.n_samples, MICRO_RES);
+  uint4 rres[2];
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const int i = 8 * (64 * u + lane);
+    rres[u] = i < n_samp ? *reinterpret_cast<const uint4*>(resid + run.res_offset + i) : make_uint4(0, 0, 0, 0);
+  }
+  const int nchx = (wx1 - ax0 + 7) >> 3, nrows = wy1 - wy0, nchunks = nchx * nrows;    // window: at most 41 rows x 6 chunks of 8 samples
+  const __amdgpu_buffer_rsrc_t wrs = plane_rsrc(plane);
+  uint4 wv[4]; int woff[4];
+  auto window_issue = [&]() {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int idx = u * 64 + lane;
+      woff[u] = -1;
+      if (idx < nchunks) {
+        const int rr = idx / nchx, cx = idx - rr * nchx;
+        const int gx = ax0 + 8 * cx, gy = wy0 + rr;
+        if (gx >= 0 && gy >= 0) {
+#if RUN_SC1_WINDOW
+          wv[u] = FRONT ? load8_as_u16(plane + gx + gy * stride) : load8_as_u16_sc1(wrs, plane, gx + gy * stride);
+#else
+          wv[u] = load8_as_u16(plane + gx + gy * stride);
+#endif
+          woff[u] = rr * MICRO_P + 8 * cx;
+        }
+      }
+    }
+  };
+  if (FRONT) window_issue();
   uint32_t flag0 = gen;
   if (has_dep) flag0 = __hip_atomic_load(&sync[2 + dep_id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // (in pieces of 64 samples - a 16x16 TU has four -, four loads in flight; the run holds at most MICRO_RES samples)
-  {
-    const int n_samp = min((int)run.n_samples, MICRO_RES);
-    // TU of this lane's sample in piece q: the TUs lie back to back in sample order, a lane finds its TU by its first sample
-    for (int q0 = 0; q0 < n_samp; q0 += 256) {
-      int16_t rv[4]; int ro[4];
+  // residual pieces into this wavefront's LDS slice; the pieces of TUs without coefficients are zero (a piece lies inside
+  // one TU: TUs hold multiples of 16 samples back to back; its TU = the last one whose first sample is <= the piece's)
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int sidx = q0 + 64 * u + lane;                             // sample of the run
-        ro[u] = sidx < n_samp ? sidx : -1;
-        // the TU that holds it: the last one whose first sample is <= sidx (<= 16 TUs: a short scan of scalars)
-        int kk = 0;
-        for (int k = 1; k < n_tus; k++) kk = ((int)(__builtin_amdgcn_readlane(ra.w, k) & (MICRO_RES - 1)) <= sidx) ? k : kk;
-        const uint32_t w1 = __builtin_amdgcn_ds_bpermute(kk << 2, (int)ra.y), first = __builtin_amdgcn_ds_bpermute(kk << 2, (int)ra.w) & (MICRO_RES - 1);
-        const uint32_t roff = __builtin_amdgcn_ds_bpermute(kk << 2, (int)rb.z);
-        rv[u] = (ro[u] >= 0 && ((w1 >> 16) & DE265HIP_TU_CBF)) ? resid[roff + (sidx - (int)first)] : (int16_t)0;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) if (ro[u] >= 0) mres[ro[u]] = rv[u];
-    }
+  for (int u = 0; u < 2; u++) {
+    const int i = 8 * (64 * u + lane);
+    int kk = 0;
+    for (int k = 1; k < n_tus; k++) kk = ((int)(__builtin_amdgcn_readlane(ra.w, k) & (MICRO_RES - 1)) <= i) ? k : kk;
+    const uint32_t w1 = __builtin_amdgcn_ds_bpermute(kk << 2, (int)ra.y);
+    const bool cbf = (w1 >> 16) & DE265HIP_TU_CBF;
+    if (i < n_samp) *reinterpret_cast<uint4*>(&mres[i]) = cbf ? rres[u] : make_uint4(0, 0, 0, 0);
   }
   // producers (bounded spin, as in the workgroup path)
+  if (!FRONT)
   for (int i = lane; i < (int)run.n_deps; i += 64) {
     const uint32_t* flag = &sync[2 + (i == lane ? dep_id : deps[run.dep_offset + i])];
     uint32_t spins = 0;
@@ -1455,32 +1485,10 @@ __device__ __forceinline__ void micro_run(const PicDev& P, const PlaneRef& pl0, 
 #if !RUN_SC1_WINDOW
   if (run.n_deps && !(RUN_DBG & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // this wavefront's own loads follow
 #endif
-  // window: at most 41 rows x 6 chunks of 8 samples
-  const int nchx = (wx1 - ax0 + 7) >> 3, nrows = wy1 - wy0, nchunks = nchx * nrows;
-  {
-    const __amdgpu_buffer_rsrc_t wrs = plane_rsrc(plane);
-    uint4 v[4]; int off[4];
+  if (!FRONT) window_issue();
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int idx = u * 64 + lane;
-      off[u] = -1;
-      if (idx < nchunks) {
-        const int rr = idx / nchx, cx = idx - rr * nchx;
-        const int gx = ax0 + 8 * cx, gy = wy0 + rr;
-        if (gx >= 0 && gy >= 0) {
-#if RUN_SC1_WINDOW
-          v[u] = load8_as_u16_sc1(wrs, plane, gx + gy * stride);
-#else
-          v[u] = load8_as_u16(plane + gx + gy * stride);
-#endif
-          off[u] = rr * MICRO_P + 8 * cx;
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++)
-      if (off[u] >= 0) *reinterpret_cast<uint4*>(&mt[off[u]]) = v[u];
-  }
+  for (int u = 0; u < 4; u++)
+    if (woff[u] >= 0) *reinterpret_cast<uint4*>(&mt[woff[u]]) = wv[u];
   LDS_SYNC();
   // the chain
   for (int k = 0; k < n_tus; k++) {
@@ -1494,15 +1502,36 @@ __device__ __forceinline__ void micro_run(const PicDev& P, const PlaneRef& pl0, 
     t.avail = w4; t.resid_offset = 0;
     t.angle = (int)(int8_t)(w7 & 0xFF); t.inv_angle = (int)(int16_t)(w7 >> 16);
     PX* gdst = plane + gx0 + gy0 * stride;
-    if (t.log2_size == 4) { micro_intra_tu16<PX>(t, mt, lane, mres + (w3 & (MICRO_RES - 1)), bd, gdst, stride); continue; }
+    if (t.log2_size == 4) { micro_intra_tu16<PX, !FRONT>(t, mt, lane, mres + (w3 & (MICRO_RES - 1)), bd, gdst, stride); continue; }
     const int rs = mres[(w3 & (MICRO_RES - 1)) + (lane & ((1 << (2 * t.log2_size)) - 1))];
-    if (t.log2_size == 2) micro_intra_tu<2, PX>(t, mt, lane, rs, bd, gdst, stride);
-    else micro_intra_tu<3, PX>(t, mt, lane, rs, bd, gdst, stride);
+    if (t.log2_size == 2) micro_intra_tu<2, PX, !FRONT>(t, mt, lane, rs, bd, gdst, stride);
+    else micro_intra_tu<3, PX, !FRONT>(t, mt, lane, rs, bd, gdst, stride);
   }
+  if (FRONT) return;
   // publish: write-through stores drained, then the flag
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (lane == 0) __hip_atomic_store(&sync[2 + r], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+// ---- front kernel: the micro runs that read from no other intra run (in a picture with inter PUs: nine runs out of ten -
+// isolated intra CUs whose neighbours are inter samples, final since the MC and residual launches).  They need neither
+// tickets nor flags, so they do not go through the persistent workers of k_run (where a wavefront works its runs off one
+// after the other, each a chain of five dependent memory round trips, at 8 wavefronts per CU): one 64-thread workgroup
+// with 7 KB of LDS per run, dispatched by the hardware - every CU holds twenty of them, so all of a 4K B picture's ~6 800
+// are in flight within two rounds.  k_run, launched behind it, sees them as finished (the host drops them from the
+// producer lists of the runs that read from them).
+template <typename PX>
+__global__ __launch_bounds__(64)
+void k_intra_front(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __restrict__ runs,
+                   const TuTask* __restrict__ tasks, const int16_t* __restrict__ resid, int n)
+{
+  __shared__ __attribute__((aligned(16))) uint16_t mt[MICRO_SLICE];
+  __shared__ __attribute__((aligned(16))) int16_t mres[MICRO_RES];
+  if ((int)blockIdx.x >= n) return;
+  micro_run<PX, true>(P, pl0, pl1, pl2, runs, nullptr, nullptr, nullptr, tasks, resid, mt, mres, blockIdx.x, threadIdx.x, 0u, 0, 0u);
+}
+template __global__ void k_intra_front<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const TuTask*, const int16_t*, int);
+template __global__ void k_intra_front<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const TuTask*, const int16_t*, int);
 
 
 // Ticket draw on the scalar unit (s_atomic_add ... glc returns the old value through lgkmcnt): unlike a vector
@@ -1610,7 +1639,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
 #pragma unroll
       for (int i = 1; i < RUN_TICKET_SLOTS; i++) mine = q == i ? slv[i] : mine;     // (scalar selects: no register array)
       if (mine != 0xFFFFFFFFu)
-        micro_run<PX>(P, pl0, pl1, pl2, runs, deps, sync, err, tasks, resid, tile + (q & 3) * MICRO_SLICE,
+        micro_run<PX, false>(P, pl0, pl1, pl2, runs, deps, sync, err, tasks, resid, tile + (q & 3) * MICRO_SLICE,
                       reinterpret_cast<int16_t*>(s_res) + (q & 3) * MICRO_RES, mine & 0x7FFFFFFFu, lane, gen, dbg, spin_limit);
     }
     continue;
@@ -1636,6 +1665,30 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   const int n_tus = min((int)run.n_tus, MAX_TUS), n_samples = min((int)run.n_samples, BOX * BOX);
   const uint32_t res_base = run.res_offset;
 
+  // the run's residuals: one contiguous int16 vector (laid out by sample of the run), the first two 16-byte pieces per
+  // thread (= the whole 64x64 run with 256 threads) in flight from here on, together with the TU records
+  constexpr int RCH = 2;
+  uint4 rres[RCH];
+  auto resid_issue = [&](int base) {
+#pragma unroll
+    for (int u = 0; u < RCH; u++) {
+      const int i = base + 8 * (u * nthr + tid);
+      rres[u] = i < n_samples ? *reinterpret_cast<const uint4*>(resid + res_base + i) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto resid_commit = [&](int base) {                // (behind the barrier that publishes s_task / s_own: blocks of TUs without coefficients are masked)
+#pragma unroll
+    for (int u = 0; u < RCH; u++) {
+      const int i = base + 8 * (u * nthr + tid);
+      if (i < n_samples) {
+        const bool cbf = s_task[s_own[i >> 4]].x & RTU_CBF;
+        const uint4 v = cbf ? rres[u] : make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(&s_res[i]) = make_uint4(v.x & 0xFFFF, v.x >> 16, v.y & 0xFFFF, v.y >> 16);
+        *reinterpret_cast<uint4*>(&s_res[i + 4]) = make_uint4(v.z & 0xFFFF, v.z >> 16, v.w & 0xFFFF, v.w >> 16);
+      }
+    }
+  };
+  resid_issue(0);
   // ---- preparation, independent of the producers: pack the TU records, then one thread per sample
   for (int i = tid; i < RUN_TILE_H; i += nthr) s_mine[i] = 0;
   for (int i = tid; i < n_tus; i += nthr) {
@@ -1701,9 +1754,12 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
     // (sc1 window loads: the barrier inside __syncthreads_and above is the one every wavefront's loads must come behind)
     window_issue(0, nthr, tid);
   }
+  resid_commit(0);
+  for (int base = 8 * RCH * nthr; base < n_samples; base += 8 * RCH * nthr) { resid_issue(base); resid_commit(base); }   // (fewer than 256 threads only)
+  __syncthreads();                                   // a sample's residual is written by the thread that fetched its piece
   if (!(RUN_DBG & 64))
   for (int s = tid; s < n_samples; s += nthr)
-    run_prepare_sample<RUN_TILE_P>(s, s_task, s_own, s_res, s_ctl, s_ex, s_mine, resid, res_base, CONST_ADDR);
+    run_prepare_sample<RUN_TILE_P>(s, s_task, s_own, s_res, s_ctl, s_ex, s_mine, CONST_ADDR);
   st.mark(2);
   int wbase = 0;
   if (early) { window_commit(); wbase = 4 * nthr; }
