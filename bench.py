@@ -12,11 +12,11 @@ GPU); all command buffers and reference pictures are resident in HBM before
 the timed region starts.  value = pictures/s over all ranks (weak scaling:
 every rank decodes its own independent GOPs, no data-path collective).
 
-`value` is a DEVICE REPLAY rate (config.timed_region): the pictures' command buffers were built
-(de265hip_picture_build: host stage + upload) before the timed region and are re-run every step.
-`host_inclusive` next to it is the rate of the C ABI as a libde265 host would drive it: build -> run -> free
-of every picture inside the timed region, the host stage of later pictures on a pool of host threads while
-the device works on earlier ones (thread and core counts stated).
+`value` is the rate of the PRODUCT PATH: every picture goes build -> run -> free through the C ABI inside the timed
+region (de265hip_pipeline_*: the library's worker threads run the host stage + pinned asynchronous upload of later
+pictures while the device reconstructs earlier ones; thread and core counts in `config`).  `device_replay` next to it
+is what the device alone sustains: the same pictures, command buffers built and uploaded before the timed region and
+re-run every step.  `roofline` is about kernel device time (hipEvents on the decoder's stream inside the timed region).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]         N > 1: starts N ranks itself (one per GPU)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -91,28 +91,25 @@ def launch_ranks(n, argv):
     return rc
 
 
-def host_inclusive_pass(decs, gops, pool, window, final_stage, stagger):
-    """build -> run -> free of every picture of every stream through the C ABI.  Builds (host stage + async upload) run
-    on `pool`, at most `window` ahead of the consumer; this thread enqueues the pictures in decode order per stream."""
-    S, GOP = len(decs), len(gops[0])
-    order = [(s_i, (j + s_i * (GOP // S)) % GOP if stagger else j) for j in range(GOP) for s_i in range(S)]
-    futs = collections.deque()
-    it = iter(order)
+def product_pass(pipes, gops, stagger, steps=1):
+    """`steps` steps through the product path: every picture of every stream is SUBMITTED to its decoder's pipeline
+    (de265hip_pipeline_submit_desc: the library's own worker threads build it - host stage + pinned asynchronous upload -,
+    launch it in decode order and free it).  submit() blocks while 2 n_workers + 2 pictures of that decoder are between
+    parser and device, so every stream has its own submitting thread, as every stream of a server has its own parser
+    (one thread feeding all streams would stall them all behind the one whose window is full)."""
+    S, GOP = len(pipes), len(gops[0])
 
-    def submit():
-        nxt = next(it, None)
-        if nxt is not None:
-            s_i, k = nxt
-            futs.append((s_i, pool.submit(decs[s_i].build, k, gops[s_i][k].desc)))
+    def feed(s_i):
+        for _ in range(steps):
+            for j in range(GOP):
+                k = (j + s_i * (GOP // S)) % GOP if stagger else j
+                pipes[s_i].submit_desc(k, gops[s_i][k].desc)
 
-    for _ in range(window):
-        submit()
-    while futs:
-        s_i, f = futs.popleft()
-        pic = f.result()
-        submit()
-        decs[s_i].run(pic, final_stage)
-        pic.free()                          # no wait: the arena returns to the pool behind an event on the stream
+    if S == 1:
+        feed(0)
+        return
+    with ThreadPoolExecutor(S) as pool:
+        list(pool.map(feed, range(S)))
 
 
 def cpu_baseline(gops, decs, W, H, BD, GOP):
@@ -184,8 +181,12 @@ def main():
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal only: every rank uses GPU 0 (a 1-GPU box cannot give each rank its own GPU)")
     ap.add_argument("--host-threads", type=int, default=0,
-                    help="host threads building pictures in the host_inclusive leg (0: the cores this process may use, at most 16)")
-    ap.add_argument("--no-host-inclusive", action="store_true")
+                    help="host threads building pictures in the product-path region, over all decoders' pipelines "
+                         "(0: the cores this process may use divided by the ranks, at most 16)")
+    ap.add_argument("--no-host-inclusive", action="store_true",
+                    help="profiling runs: skip the product-path region; value is then the device replay rate (labelled so)")
+    ap.add_argument("--open-gop", action="store_true",
+                    help="N > 1: also time the hand-off of the last picture of a GOP from rank r to rank r + 1 (open_gop object)")
     ap.add_argument("--no-e2e", action="store_true", help=argparse.SUPPRESS)   # accepted and ignored (older command lines): the
     # real-bitstream end-to-end measurement drives the product through the PATCHED REFERENCE DECODER, which is test infrastructure
     # (oracle/f1_recorder.cc) - it lives in tools/exp/e2e_stream_bench.sh, not in the bench (profiles/r02_e2e_*.txt)
@@ -267,12 +268,13 @@ def main():
             d.sync()
         torch.cuda.synchronize()
 
+    # ---- (1) device replay: what the device alone sustains on prebuilt pictures
     for _ in range(args.warmup):
         step()
     sync()
-    # One profiled pass ahead of the timed region, every kernel's launches bracketed by hipEvents: the per-kernel
-    # breakdown (`kernels`) and the dominant kernel.  Inside the timed region only the dominant kernel is timed
-    # (--events all: every kernel): each timed launch costs two event records on its stream.
+    # One profiled pass, every kernel's launches bracketed by hipEvents: the per-kernel breakdown (`kernels`) and the
+    # dominant kernel.  Inside the timed regions only the dominant kernel is timed (--events all: every kernel): each
+    # timed launch costs two event records on its stream.
     def collect():
         kt = {}
         for d in decs:
@@ -296,40 +298,82 @@ def main():
     for _ in range(args.steps):
         step()
     t_host = time.perf_counter() - t_host   # host time spent enqueueing (the device runs behind it)
-    elapsed = timer.stop()              # synchronize + barrier, MAX over ranks
-    ktimes = collect()                  # the dominant kernel's launches of the timed region (all kernels' with --events all)
+    replay_elapsed = timer.stop()       # synchronize + barrier, MAX over ranks
+    ktimes_replay = collect()           # the dominant kernel's launches of that region (all kernels' with --events all)
     for d in decs:
         d.set_profiling(False)
+    device_replay = {"value": round(world * args.steps * GOP * S / replay_elapsed, 2), "unit": "frames/s", "steps": args.steps,
+                     "ms_per_step": round(1e3 * replay_elapsed / args.steps, 3),
+                     "host_enqueue_ms_per_step": round(1e3 * t_host / args.steps, 3),
+                     "what": "device replay of prebuilt pictures: command buffers built and uploaded before this region, every "
+                             "picture's kernels re-enqueued each step (not the product's rate: no host stage, no upload)"}
 
-    # ---- host-inclusive leg: the same GOPs, every picture built, run and freed inside the timed region
-    host_incl = None
+    # ---- (2) the product path, THE TIMED REGION of this bench: every picture built, launched and freed through the C ABI
+    elapsed, ktimes, product = replay_elapsed, ktimes_replay, None
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     if not args.no_host_inclusive:
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        nthr = args.host_threads if args.host_threads > 0 else max(1, min(16, cores // max(1, world if args.single_device or world > 1 else 1)))
-        for ps in pics:                                 # the prebuilt pictures go back to the pools
+        nthr = args.host_threads if args.host_threads > 0 else max(1, min(16, cores // max(1, world)))
+        per = max(1, min(16, nthr // S))                 # worker threads of each decoder's pipeline
+        for ps in pics:                                  # the prebuilt pictures go back to the pools
             for p_ in ps:
                 p_.free()
         sync()
-        hi_steps = max(2, min(args.steps, 5))
+        pipes = [backend.Pipeline(d, per) for d in decs]
 
-        def timed_passes(threads, passes):
-            with ThreadPoolExecutor(threads) as pool:
-                host_inclusive_pass(decs, gops, pool, 2 * threads + 2, _abi.STAGE_FINAL, args.stagger)   # warm-up: fills the pools
-                sync()
-                tm = farm.RankTimer(dist, sync, device=red_dev)
-                tm.start()
-                for _ in range(passes):
-                    host_inclusive_pass(decs, gops, pool, 2 * threads + 2, _abi.STAGE_FINAL, args.stagger)
-                return tm.stop()
+        def drain():
+            for pp_ in pipes:
+                pp_.drain()
 
-        t_n = timed_passes(nthr, hi_steps)
-        t_1 = timed_passes(1, 1)
-        host_incl = {"value": round(world * hi_steps * GOP * S / t_n, 2), "unit": "frames/s", "host_threads": nthr,
-                     "host_cores_available": cores, "steps": hi_steps,
-                     "value_1_host_thread": round(world * GOP * S / t_1, 2),
-                     "what": "de265hip_picture_build -> de265hip_picture_run -> de265hip_picture_free per picture through the C ABI "
-                             "(host stage + pinned async upload + all kernels), builds on a pool of host threads ahead of the device"}
+        for _ in range(max(1, args.warmup)):             # fills the arena / staging pools and the workers' scratch
+            product_pass(pipes, gops, args.stagger)
+        drain()
+        for d in decs:
+            d.set_profiling(True, only=None if args.events == "all" else [dom])
+            d.kernel_times(reset=True)
+        timer = farm.RankTimer(dist, sync, device=red_dev)
+        timer.start()
+        product_pass(pipes, gops, args.stagger, steps=args.steps)
+        drain()                                          # every picture launched, finished, freed
+        elapsed = timer.stop()
+        ktimes = collect()
+        for d in decs:
+            d.set_profiling(False)
+        for pp_ in pipes:
+            pp_.close()
+        # one host thread: stream 0 alone through a one-worker pipeline
+        one = backend.Pipeline(decs[0], 1)
+        product_pass([one], gops[:1], False); one.drain()
+        t1 = time.perf_counter()
+        product_pass([one], gops[:1], False); one.drain()
+        t1 = time.perf_counter() - t1
+        one.close()
+        product = {"host_threads": per * S, "workers_per_decoder": per, "host_cores_available": cores,
+                   "value_1_host_thread": round(GOP / t1, 2),
+                   "what": "de265hip_pipeline_submit_desc per picture: the library's worker threads run de265hip_picture_build (host stage + "
+                           "pinned asynchronous upload), launch in decode order (de265hip_picture_run) and free; decoded pictures stay in the "
+                           "device-resident DPB (no copy-out in the timed region)"}
         pics = [[d.build(k, g[k].desc) for k in range(GOP)] for d, g in zip(decs, gops)]   # (for the isolated pass below)
+
+    # ---- (3) open-GOP hand-off, timed separately from `value`: the last picture of a GOP of rank r
+    # goes to rank r + 1 (DPB slot GOP, beside the receiver's own GOP).  RCCL point-to-point on the DPB planes with
+    # --backend nccl; a gloo rehearsal stages through the host (gloo sends CPU tensors only).
+    open_gop = None
+    if args.open_gop and world > 1:
+        slot_in = GOP if GOP < 20 else 19
+        decs[0].dpb_alloc(slot_in, W, H, BD)
+        sync()
+        tm = farm.RankTimer(dist, sync, device=red_dev)
+        tm.start()
+        for r in range(world - 1):
+            if args.backend == "nccl":
+                farm.exchange_reference_picture_dpb(dist, decs[0], GOP - 1, slot_in, r, r + 1, rank)
+            else:
+                farm.exchange_reference_picture_host(dist, decs[0], GOP - 1, slot_in, r, r + 1, rank, W, H, BD)
+        t_x = tm.stop()
+        nbytes = W * H * 3 // 2 * (2 if BD > 8 else 1)
+        open_gop = {"handoffs": world - 1, "ms_per_handoff": round(1e3 * t_x / (world - 1), 3), "bytes_per_picture": nbytes,
+                    "GBs": round(nbytes / 1e9 / (t_x / (world - 1)), 2), "transport": "rccl p2p on DPB planes" if args.backend == "nccl" else "gloo via host (rehearsal)",
+                    "checksum_ok": farm.check_handoff(dist, decs[0], GOP - 1, slot_in, rank, world, W, H, BD, device=red_dev)}
 
     # one more, untimed, pass of stream 0 alone: per-kernel device times without the other streams'
     # kernels competing for the GPU (reported as kernels_isolated; value/roofline come from the timed region)
@@ -342,11 +386,14 @@ def main():
                 decs[0].run(p, _abi.STAGE_FINAL)
         iso = decs[0].kernel_times(reset=True)
         decs[0].set_profiling(False)
+    sync()
+    if dist is not None:
+        dist.barrier()                  # every rank has finished its GPU work before rank 0 loads the host cores with the CPU baseline
 
     if rank == 0:
         frames = world * args.steps * GOP * S
         fps = frames / elapsed
-        # ---- roofline of the dominant kernel (device time from hipEvents on the decoder's stream)
+        # ---- roofline of the dominant kernel (device time from hipEvents on the decoder's stream, inside the timed region)
         dom_ms, dom_launches = ktimes[dom]
         alg_total = sum(getattr(s, ALG_KEY[dom]) for s in stats) * args.steps if dom in ALG_KEY else 0
         two_pass = ktimes_all.get("deblock_h", (0, 0))[1] > 0      # DE265HIP_TWO_PASS_DEBLOCK: SURVEY 8d's 2P is for both passes together
@@ -371,18 +418,21 @@ def main():
                     "note": ("intra (k_run) is bound by the z-scan dependency chain (single-wavefront latency), not by HBM; "
                              "the streaming kernels' algorithmic GB/s are under kernels / kernels_isolated")
                     if dom == "intra" else ""}
-        # per-kernel breakdown of one step with all streams in flight: the profiled pass ahead of the timed region
+        # per-kernel breakdown of one step with all streams in flight: the profiled device-replay pass
         kernels = {k: {"ms_per_step": round(v[0], 4), "launches_per_step": v[1],
                        "alg_GBs": round((sum(getattr(s, ALG_KEY[k]) for s in stats) / (2 if k.startswith("deblock") and two_pass else 1)
                                          / 1e9) / (v[0] / 1e3), 1) if k in ALG_KEY and v[0] > 0 else None}
                    for k, v in ktimes_all.items()}
 
-        # all kernels together: algorithmic bytes of a step (every stage of every picture) over the step's wall time
+        # all kernels together: algorithmic bytes of a step (every stage of every picture) over the step's wall time,
+        # in the timed region and in the device replay
         alg_step = sum(getattr(s_, a) for s_ in stats for a in ("alg_bytes_mc", "alg_bytes_resid", "alg_bytes_intra", "alg_bytes_intra_front", "alg_bytes_deblock", "alg_bytes_sao"))
-        agg_gbs = (alg_step / 1e9) / (elapsed / args.steps)
-        aggregate = {"alg_bytes_per_step": int(alg_step), "achieved": round(agg_gbs, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                     "frac": round(agg_gbs / HBM_PEAK_GBS, 4),
-                     "note": "sum of every stage's algorithmic bytes of one step / wall time of the step (all streams, all kernels)"}
+
+        def agg(el):
+            gbs = (alg_step / 1e9) / (el / args.steps)
+            return {"achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        aggregate = dict(agg(elapsed), alg_bytes_per_step=int(alg_step), unit="GB/s", peak=HBM_PEAK_GBS, device_replay=agg(replay_elapsed),
+                         note="sum of every stage's algorithmic bytes of one step / wall time of the step (all streams, all kernels)")
         st0 = [p.stats() for p in pics[0]]
         kernels_iso = {k: {"us_per_picture": round(1e3 * v[0] / max(v[1], 1), 1) if k != "resid" else
                            round(1e3 * v[0] / (2 * GOP), 1),
@@ -395,6 +445,11 @@ def main():
         parity = "not checked"
         if not args.no_cpu_baseline:
             cpu, parity = cpu_baseline(gops, decs, W, H, BD, GOP)
+        if product is not None:
+            region = ("product path: every picture of the step goes build -> run -> free through the C ABI inside the timed region "
+                      "(%d host threads in the library's pipelines); device_replay is the device alone" % product["host_threads"])
+        else:
+            region = "--no-host-inclusive: device replay of prebuilt pictures only (NOT the product's rate; profiling runs)"
         line = {
             "metric": "decoded frames/sec (4K Main10)", "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -403,19 +458,24 @@ def main():
             "config": {"workload": "%dx%d %d-bit 4:2:0 random-access closed GOPs of %d pictures (1 I + %d B, 2 refs), "
                                    "%d independent GOP(s) in flight per GPU, all stages on device"
                                    % (W, H, BD, GOP, GOP - 1, S),
-                       "timed_region": "device replay of prebuilt pictures (command buffers built and uploaded before the timed "
-                                       "region; see host_inclusive for build -> run -> free)",
+                       "timed_region": region,
                        "gop": GOP, "streams_per_gpu": S, "pictures_per_step": GOP * S,
-                       "host_enqueue_ms_per_step": round(1e3 * t_host / args.steps, 3),
+                       "host_threads": product["host_threads"] if product else 0, "host_cores_available": cores,
                        "events_in_timed_region": "every kernel" if args.events == "all" else "dominant kernel (%s) only" % dom,
                        "parallelism": "%d gop stream(s) x %d gpu(s)" % (S, world)},
-            "roofline": roofline, "roofline_aggregate": aggregate, "cpu_baseline": cpu, "host_inclusive": host_incl, "parity_vs_reference": parity, "kernels": kernels,
+            "roofline": roofline, "roofline_aggregate": aggregate, "cpu_baseline": cpu, "device_replay": device_replay,
+            "product_path": product, "open_gop": open_gop, "parity_vs_reference": parity, "kernels": kernels,
             "kernels_isolated": kernels_iso,
         }
         print(json.dumps(line))
+        sys.stdout.flush()
         if parity == "MISMATCH":
+            if dist is not None:
+                dist.barrier()
+                dist.destroy_process_group()
             sys.exit(2)
     if dist is not None:
+        dist.barrier()                  # the other ranks stay until rank 0 is through with the CPU baseline
         dist.destroy_process_group()
 
 

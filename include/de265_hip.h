@@ -325,7 +325,7 @@ int  de265hip_recorder_submit(de265hip_decoder*, int dst_slot, de265hip_recorder
  * thread, several pictures at once) and de265hip_recorder_submit (= de265hip_picture_build) - and the device reconstructs the
  * pictures before those.  Pictures are LAUNCHED in submission order (a picture's kernels read the DPB slots its references were
  * launched into): de265hip_picture_run(STAGE_FINAL) + de265hip_dpb_download_async of every non-NULL `planes[c]` (pinned memory,
- * de265hip_host_alloc; strides as in de265hip_dpb_download).  submit() returns as soon as there is room (at most n_workers + 2
+ * de265hip_host_alloc; strides as in de265hip_dpb_download).  submit() returns as soon as there is room (at most 2 n_workers + 2
  * pictures between parser and device); nobody waits for a picture until de265hip_pipeline_wait(ticket) - what a decoder calls
  * when the picture is about to be output or read (de265.cc:392 de265_peek_next_picture).  While a pipeline exists, run / dpb_* /
  * sync of its decoder belong to the pipeline; dpb_alloc of slots no queued picture uses is allowed.  An error of prepare, build
@@ -336,6 +336,10 @@ typedef int (*de265hip_prepare_fn)(void* user, de265hip_recorder** out);   /* 0 
 int  de265hip_pipeline_new(de265hip_pipeline** out, de265hip_decoder*, int n_workers /* 1..16 */);
 int  de265hip_pipeline_submit(de265hip_pipeline*, int dst_slot, de265hip_prepare_fn prepare, void* user,
                               void* const planes[3], const ptrdiff_t stride_bytes[3], uint64_t* ticket);
+/* The same for a host that already holds the picture's description (no prepare step): `desc` and the arrays it points to
+ * stay valid and unchanged until the ticket has been waited for (or the pipeline drained). */
+int  de265hip_pipeline_submit_desc(de265hip_pipeline*, int dst_slot, const de265hip_picture_desc* desc,
+                                   void* const planes[3], const ptrdiff_t stride_bytes[3], uint64_t* ticket);
 int  de265hip_pipeline_wait(de265hip_pipeline*, uint64_t ticket);
 int  de265hip_pipeline_drain(de265hip_pipeline*);          /* every submitted picture launched, finished and copied out */
 void de265hip_pipeline_free(de265hip_pipeline*);           /* drains first */

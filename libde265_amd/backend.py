@@ -20,7 +20,7 @@ EXPORTS = [
     "de265hip_decoder_new", "de265hip_decoder_free",
     "de265hip_dpb_alloc", "de265hip_dpb_upload", "de265hip_dpb_download", "de265hip_dpb_plane", "de265hip_dpb_info",
     "de265hip_dpb_copy", "de265hip_dpb_download_async", "de265hip_dpb_wait", "de265hip_host_alloc", "de265hip_host_free",
-    "de265hip_pipeline_new", "de265hip_pipeline_submit", "de265hip_pipeline_wait", "de265hip_pipeline_drain", "de265hip_pipeline_free",
+    "de265hip_pipeline_new", "de265hip_pipeline_submit", "de265hip_pipeline_submit_desc", "de265hip_pipeline_wait", "de265hip_pipeline_drain", "de265hip_pipeline_free",
     "de265hip_debug_build_host_only", "de265hip_debug_last_build_hash",
     "de265hip_picture_build", "de265hip_picture_run", "de265hip_decoder_sync", "de265hip_picture_free",
     "de265hip_decode_picture", "de265hip_picture_get_stats",
@@ -75,6 +75,7 @@ def lib():
     L.de265hip_host_free.restype = None
     L.de265hip_pipeline_new.argtypes = [pp(vp), vp, i32]
     L.de265hip_pipeline_submit.argtypes = [vp, i32, PREPARE_FN, vp, pp(vp), pp(C.c_ssize_t), pp(C.c_uint64)]
+    L.de265hip_pipeline_submit_desc.argtypes = [vp, i32, C.POINTER(_abi.PictureDesc), pp(vp), pp(C.c_ssize_t), pp(C.c_uint64)]
     L.de265hip_pipeline_wait.argtypes = [vp, C.c_uint64]
     L.de265hip_pipeline_drain.argtypes = [vp]
     L.de265hip_pipeline_free.argtypes = [vp]
@@ -175,6 +176,16 @@ class Pipeline:
         t = C.c_uint64()
         _chk(lib().de265hip_pipeline_submit(self._h, slot, fn, None, planes, strides, C.byref(t)), "pipeline_submit")
         self._keep[t.value] = (fn, planes, strides)   # the callback object must outlive the call on the worker thread
+        return t.value
+
+    def submit_desc(self, slot, desc, pinned=None):
+        """a ready-made description (POINTER(PictureDesc), kept alive by the caller until the ticket is waited for)"""
+        planes = (C.c_void_p * 3)(*(pinned.ptrs if pinned else [None] * 3))
+        strides = (C.c_ssize_t * 3)(*(pinned.strides if pinned else [0] * 3))
+        t = C.c_uint64()
+        dptr = desc if isinstance(desc, C.POINTER(_abi.PictureDesc)) else C.pointer(desc)
+        _chk(lib().de265hip_pipeline_submit_desc(self._h, slot, dptr, planes, strides, C.byref(t)), "pipeline_submit_desc")
+        self._keep[t.value] = (dptr, planes, strides)
         return t.value
 
     def wait(self, ticket):

@@ -271,75 +271,33 @@ static uint64_t needed_units(uint64_t used, uint64_t avail)
   return need;
 }
 
-// Neighbour availability of one intra TU (8.4.4.2.2; intrapred.cc:437-527 preproc,
-// :577-688 fill_from_image) as a unit bitmask, and the TU's dependency level.
-uint64_t intra_availability(const de265hip_picture_desc& d, const Geometry& g, const de265hip_tu& tu,
-                            const std::vector<uint16_t>& lvl, int map_w, int* level_out,
-                            const std::vector<int32_t>& runmap, std::vector<int>& producers,
-                            const std::vector<uint16_t>& llvl, int cur_run, int* local_level_out,
-                            bool mode_deps, bool* in_cur_run, int* any_level_out)
-{
-  producers.clear();
-  const de265hip_pic_params& p = d.params;
-  const int nT = 1 << tu.log2_size, sub = tu.c_idx ? 2 : 1;
-  const int xB = tu.x0, yB = tu.y0, xL = xB * sub, yL = yB * sub;
-  bool aL = xL > 0, aT = yL > 0, aTL = aL && aT, aTR = aT && (xL + nT * sub < p.width);
-  const int lc = p.log2_ctb_size;
-  const int cx = xL >> lc, cy = yL >> lc;
-  auto same_ctb_group = [&](int ox, int oy) {
-    const int a = cx + cy * g.ctbs_w, b = ox + oy * g.ctbs_w;
-    return d.ctbs[a].slice_addr_rs == d.ctbs[b].slice_addr_rs && g.tile_id[a] == g.tile_id[b];
-  };
-  if (aL) aL = same_ctb_group((xL - 1) >> lc, cy);
-  if (aT) aT = same_ctb_group(cx, (yL - 1) >> lc);
-  if (aTL) aTL = same_ctb_group((xL - 1) >> lc, (yL - 1) >> lc);
-  if (aTR) aTR = same_ctb_group((xL + nT * sub) >> lc, (yL - 1) >> lc);
-
-  int nBottom = (p.height - yL + sub - 1) / sub; if (nBottom > 2 * nT) nBottom = 2 * nT;
-  int nRight = (p.width - xL + sub - 1) / sub;   if (nRight > 2 * nT) nRight = 2 * nT;
-  const int lt = p.log2_min_tb_size;
-  const int cur = g.min_tb_zs[(xL >> lt) + (size_t)(yL >> lt) * g.tbs_w];
-  auto usable = [&](int xs, int ys) {                     // component-sample position of the neighbour
-    int nx = xs * sub, ny = ys * sub;
-    if (g.min_tb_zs[(nx >> lt) + (size_t)(ny >> lt) * g.tbs_w] > cur) return false;
-    if (p.constrained_intra_pred_flag && !(d.blk_flags[(nx >> 2) + (ny >> 2) * g.w4] & DE265HIP_BLK_INTRA)) return false;
-    return true;
-  };
-  uint64_t mask = 0; int lev = 0, llev = 0;
-  const int corner = nT >> 1;
-  int32_t cell[33];                                       // 4x4 map cell of every available unit
-  auto take = [&](int u, int xs, int ys) {
-    mask |= 1ull << u;
-    cell[u] = (xs >> 2) + (ys >> 2) * map_w;
-  };
-  if (aL)
-    for (int y = nBottom - 1; y >= 0; y -= 4)
-      if (usable(xB - 1, yB + y)) take((2 * nT - 1 - y) >> 2, xB - 1, yB + y);
-  if (aTL && usable(xB - 1, yB - 1)) take(corner, xB - 1, yB - 1);
-  for (int x = 0; x < nRight; x += 4)
-    if ((x < nT ? aT : aTR) && usable(xB + x, yB - 1)) take(corner + 1 + (x >> 2), xB + x, yB - 1);
-  // dependencies: only the units the mode reads (mode_deps), or every available unit
-  const int mode = tu.intra_mode < 35 ? tu.intra_mode : 1;
-  uint64_t need = mode_deps ? needed_units(g_used_units[tu.log2_size - 2][mode][tu.c_idx == 0], mask) : mask;
-  *in_cur_run = false;
-  for (uint64_t m = mask; m; m &= m - 1) {
-    const int r = runmap[cell[__builtin_ctzll(m)]];
-    if (r >= 0 && r == cur_run) *in_cur_run = true;       // (the run structure is decided on the full neighbourhood)
-  }
-  int alev = 0;
-  for (; need; need &= need - 1) {
-    const int c4 = cell[__builtin_ctzll(need)];
-    lev = std::max(lev, (int)lvl[c4]);
-    const int r = runmap[c4];
-    if (r >= 0) alev = std::max(alev, (int)llvl[c4]);
-    if (r >= 0 && r == cur_run) llev = std::max(llev, (int)llvl[c4]);
-    if (r >= 0 && std::find(producers.begin(), producers.end(), r) == producers.end()) producers.push_back(r);
-  }
-  *level_out = lev + 1;
-  *local_level_out = llev + 1;      // only meaningful when the TU ends up extending cur_run
-  *any_level_out = alev + 1;        // ... when all its producers are one run and it is merged into that one
-  return mask;
-}
+// ---- flat, reused working set of the host stage (one per host thread): a picture's build allocates nothing in the
+// steady state and touches no fresh page
+struct Cell { int32_t run; uint16_t lvl, llvl; };        // per 4x4 unit of a component: run of the intra TU covering it (-1: none), its TU level, its in-run level
+struct RunB {                                            // a run under construction
+  int32_t c, ctu, x0, y0, x1, y1, wx1, wy1, level, est;  // est: run level as far as known during the scan
+  int32_t n_tus, head, tail;                             // its TUs: list through BuildScratch::it_next, decode order
+  int32_t n_deps, dep_head, dep_tail;                    // its producer runs: list through BuildScratch::dep_next, order of discovery
+  int64_t alg;
+};
+struct BuildScratch {
+  std::vector<Cell> cells[3];
+  int32_t epoch_base = 0;
+  std::vector<uint32_t> ctb_group;
+  std::vector<TuTask> it; std::vector<int32_t> it_next; std::vector<uint16_t> it_llev;     // intra TUs in decode order
+  std::vector<RunB> rb;
+  std::vector<int32_t> dep_val, dep_next;
+  std::vector<int> level_hist;
+  std::vector<TuTask> all_tasks; std::vector<int> all_levels;                              // DE265HIP_INTRA_MODE=levels only
+  std::vector<TuTask> l0, run_tus;
+  std::vector<RunTask> runs; std::vector<uint32_t> run_deps, slots;
+  std::vector<int> order, newidx, count2, width; std::vector<uint8_t> micro;
+  std::vector<McTask> mcs; std::vector<PcmTask> pcms; std::vector<SaoCtb> saos;
+};
+static thread_local BuildScratch g_scratch;
+static const int8_t k_intra_angle[35] = { 0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26,
+                                          -32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };
+static const int16_t k_inv_angle[15] = { -4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096 };
 
 // ---- pools (caller holds dec->mu)
 constexpr size_t kPoolLimitBytes = (size_t)24 << 30;      // free arenas kept for reuse (of 288 GB of HBM)
@@ -740,38 +698,65 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   const bool mode_deps = getenv("DE265HIP_NO_MODE_DEPS") == nullptr;
   const bool merge_runs = getenv("DE265HIP_NO_MERGE") == nullptr;
   ensure_used_units();
-  // ---- TU tasks: availability, dependency level, stable sort by level
-  std::vector<TuTask> tasks; tasks.reserve(d->n_tus);
-  std::vector<int> levels; levels.reserve(d->n_tus);
-  std::vector<uint16_t> lvl[3];
+  // ---- TU scan: tasks, intra availability, dependency levels, runs.  One linear pass over the TU records on flat,
+  // reused arrays (BuildScratch): no allocation and no page fault in the steady state.
+  BuildScratch& SC = g_scratch;
   const int map_w[3] = { g.w4, (p.width / 2 + 3) / 4, (p.width / 2 + 3) / 4 };
   const int map_h[3] = { g.h4, (p.height / 2 + 3) / 4, (p.height / 2 + 3) / 4 };
-  for (int c = 0; c < 3; c++) lvl[c].assign((size_t)map_w[c] * map_h[c], 0);
+  // The cell maps are not cleared per picture (6 MB at 4K): a cell counts only if its run id is of THIS build - ids start at
+  // an epoch base that grows from build to build (cleared when the ids would wrap or the geometry changes).
+  {
+    bool fresh = SC.epoch_base > 0x70000000 || SC.epoch_base < 0;
+    for (int c = 0; c < 3; c++) fresh = fresh || SC.cells[c].size() != (size_t)map_w[c] * map_h[c];
+    if (fresh) { for (int c = 0; c < 3; c++) SC.cells[c].assign((size_t)map_w[c] * map_h[c], Cell{ -1, 0, 0 }); SC.epoch_base = 0; }
+  }
+  const int32_t E = SC.epoch_base;                     // a cell's run id r (>= 0) is stored as E + r
+  SC.epoch_base = E + d->n_tus + 1;                    // (the next build's ids lie above everything this one can write, even if it fails half way)
   int max_level = 0;
   int64_t alg_resid = 0, alg_intra = 0, alg_intra_front = 0;
   // runs: maximal intervals of the per-component intra TU sequence inside one CTB in which
   // every TU reads from the run so far (see k_run); independent TUs start a new run
-  struct RunBuild { int c, ctu, x0, y0, x1, y1, level, wx1, wy1; std::vector<TuTask> tus; std::vector<int> deps;
-                    std::vector<uint16_t> llev; int est = 1; int64_t alg = 0; };     // est: run level as far as known during the scan (merge heuristic)
-  std::vector<RunBuild> rb;
-  std::vector<int32_t> runmap[3];
-  for (int c = 0; c < 3; c++) runmap[c].assign((size_t)map_w[c] * map_h[c], -1);
-  std::vector<uint16_t> llvl[3];                 // in-run dependency level of the TU covering a 4x4 unit
-  for (int c = 0; c < 3; c++) llvl[c].assign((size_t)map_w[c] * map_h[c], 0);
+  std::vector<RunB>& rb = SC.rb; rb.clear();
+  SC.it.clear(); SC.it_next.clear(); SC.it_llev.clear(); SC.dep_val.clear(); SC.dep_next.clear();
+  SC.level_hist.assign(2, 0);
+  SC.all_tasks.clear(); SC.all_levels.clear();
   int cur_run[3] = { -1, -1, -1 };
-  std::vector<int> producers;
   // dense intra (no inter PUs at all): one run per CTB and component, fewest hand-offs on the z-scan chain.
-  // sparse intra: small runs (<= 32x32) need a quarter of the LDS, so ~3x more of them are in flight.
-  // (measured: with <= 32x32 runs and 2816 workers a 4K B picture got slower, 231 -> 273 us: the longer
-  //  producer chains cost more than the extra residency buys, so every picture uses 64x64 runs for now)
-  const int run_box = 64;      // (32x32 boxes: more runs in flight but 13-15 instead of 8 run levels on a 4K B picture: slower)
+  // (32x32 run boxes: more runs in flight but 13-15 instead of 8 run levels on a 4K B picture: slower; every picture uses 64x64)
+  const int run_box = 64;
   pic->run_box = run_box;
+  // CTBs of one slice and tile share a group word (the availability tests of intrapred.cc:486-508 compare exactly these two)
+  SC.ctb_group.resize((size_t)d->n_ctbs);
+  for (int a = 0; a < d->n_ctbs; a++) SC.ctb_group[a] = (uint32_t)d->ctbs[a].slice_addr_rs | ((uint32_t)g.tile_id[a] << 16);
+  const uint32_t* ctb_group = SC.ctb_group.data();
+  const int lc = p.log2_ctb_size, lt = p.log2_min_tb_size;
+  const int* zs = g.min_tb_zs.data();
+  const bool cip = p.constrained_intra_pred_flag != 0;
+  // pre-pass: how many level-0 tasks of each size there will be - inter TUs with residual, then the residual-only copies of the
+  // intra TUs: [32x32 | 16x16 | 8x8 | 4x4], inside a size the inter TUs first - so that both are written to their final place
+  int n_inter_size[4] = { 0, 0, 0, 0 }, n_ro_size[4] = { 0, 0, 0, 0 }, n_intra = 0;
+  for (int i = 0; i < d->n_tus; i++) {
+    const de265hip_tu& tu = d->tus[i];
+    if (tu.log2_size < 2 || tu.log2_size > 5) { delete pic; return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE; }
+    if (tu.flags & DE265HIP_TU_INTRA) { n_intra++; if ((tu.flags & DE265HIP_TU_CBF) && tu.n_coeff) n_ro_size[tu.log2_size - 2]++; }
+    else if (tu.flags & DE265HIP_TU_CBF) n_inter_size[tu.log2_size - 2]++;
+  }
+  size_t inter_cur[4], ro_cur[4];
+  {
+    size_t at = 0;
+    for (int k = 3; k >= 0; k--) { inter_cur[k] = at; at += n_inter_size[k]; ro_cur[k] = at; at += n_ro_size[k]; pic->n_l0_size[k] = n_inter_size[k] + n_ro_size[k]; }
+    SC.l0.resize(at);
+  }
+  TuTask* l0p = SC.l0.data();
+  SC.it.reserve(n_intra); SC.it_next.reserve(n_intra); SC.it_llev.reserve(n_intra);
+  int n_tasks = 0;
+  int32_t cell[33];                                        // 4x4 map cell of every available unit of the current TU
+  int prod[40];
   for (int i = 0; i < d->n_tus; i++) {
     const de265hip_tu& tu = d->tus[i];
     const int nT = 1 << tu.log2_size;
     const int cw = tu.c_idx ? p.width / 2 : p.width, ch = tu.c_idx ? p.height / 2 : p.height;
-    if (tu.c_idx > 2 || tu.log2_size < 2 || tu.log2_size > 5 || (tu.x0 & 3) || (tu.y0 & 3) ||
-        tu.x0 + nT > cw || tu.y0 + nT > ch || tu.qp < 0 ||
+    if (tu.c_idx > 2 || (tu.x0 & 3) || (tu.y0 & 3) || tu.x0 + nT > cw || tu.y0 + nT > ch || tu.qp < 0 ||
         ((tu.flags & DE265HIP_TU_CBF) && ((int64_t)tu.coeff_offset + tu.n_coeff > d->n_coeffs || tu.n_coeff > nT * nT))) {
       delete pic; return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
     }
@@ -791,28 +776,68 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     const size_t bpp = px_bytes(tu.c_idx ? p.bit_depth_chroma : p.bit_depth_luma);
     if (tu.flags & DE265HIP_TU_INTRA) {
       const int c = tu.c_idx, sub = c ? 2 : 1;
-      {
-        static const int8_t k_angle[35] = { 0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26,
-                                            -32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };
-        static const int16_t k_inv[15] = { -4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630,
-                                           -910, -1638, -4096 };
-        const int m = tu.intra_mode < 35 ? tu.intra_mode : 1;
-        t.angle = k_angle[m];
-        t.inv_angle = (m >= 11 && m <= 25 && k_angle[m] < 0) ? k_inv[m - 11] : 0;
+      const int m = tu.intra_mode < 35 ? tu.intra_mode : 1;
+      t.angle = k_intra_angle[m];
+      t.inv_angle = (m >= 11 && m <= 25 && k_intra_angle[m] < 0) ? k_inv_angle[m - 11] : 0;
+      // -- neighbour availability (8.4.4.2.2; intrapred.cc:437-527 preproc, :577-688 fill_from_image) as a unit bit mask.
+      // The left column beside the TU, the row above it and the corner precede the TU in z-scan order whenever they lie in
+      // the same slice and tile (Morton order: the highest differing coordinate bit is set in the TU's own position), so
+      // only the below-left and above-right units need the MinTbAddrZS comparison.
+      const int xB = tu.x0, yB = tu.y0, xL = xB * sub, yL = yB * sub;
+      const int cx = xL >> lc, cy = yL >> lc, ctu = cx + cy * g.ctbs_w;
+      const uint32_t own = ctb_group[ctu];
+      const bool aL = xL > 0 && ctb_group[((xL - 1) >> lc) + cy * g.ctbs_w] == own;
+      const bool aT = yL > 0 && ctb_group[cx + ((yL - 1) >> lc) * g.ctbs_w] == own;
+      const bool aTL = xL > 0 && yL > 0 && ctb_group[((xL - 1) >> lc) + ((yL - 1) >> lc) * g.ctbs_w] == own;
+      const bool aTR = yL > 0 && (xL + nT * sub < p.width) && ctb_group[((xL + nT * sub) >> lc) + ((yL - 1) >> lc) * g.ctbs_w] == own;
+      int nBottom = (p.height - yL + sub - 1) / sub; if (nBottom > 2 * nT) nBottom = 2 * nT;
+      int nRight = (p.width - xL + sub - 1) / sub;   if (nRight > 2 * nT) nRight = 2 * nT;
+      const int cur = zs[(xL >> lt) + (size_t)(yL >> lt) * g.tbs_w];
+      const int mw = map_w[c], corner = nT >> 1;
+      uint64_t mask = 0;
+      auto intra_ok = [&](int xs, int ys) {                 // constrained_intra_pred: only samples of intra CUs (intrapred.cc:612-615)
+        return !cip || (d->blk_flags[((xs * sub) >> 2) + ((ys * sub) >> 2) * g.w4] & DE265HIP_BLK_INTRA);
+      };
+      auto take = [&](int u, int xs, int ys) { mask |= 1ull << u; cell[u] = (xs >> 2) + (ys >> 2) * mw; };
+      if (aL) {
+        for (int y = nT - 1; y >= 0; y -= 4) if (intra_ok(xB - 1, yB + y)) take((2 * nT - 1 - y) >> 2, xB - 1, yB + y);
+        for (int y = nBottom - 1; y >= nT; y -= 4) {
+          const int nx = (xB - 1) * sub, ny = (yB + y) * sub;
+          if (zs[(nx >> lt) + (size_t)(ny >> lt) * g.tbs_w] <= cur && intra_ok(xB - 1, yB + y)) take((2 * nT - 1 - y) >> 2, xB - 1, yB + y);
+        }
       }
-      int llev = 1;
-      bool in_cur_run = false;
-      int alev = 1;
-      t.avail = intra_availability(*d, g, tu, lvl[c], map_w[c], &level, runmap[c], producers, llvl[c], cur_run[c], &llev,
-                                   mode_deps, &in_cur_run, &alev);
-      const int ctu = ((tu.x0 * sub) >> p.log2_ctb_size) + ((tu.y0 * sub) >> p.log2_ctb_size) * g.ctbs_w;
-      int r = cur_run[c];
-      bool extends = r >= 0 && rb[r].ctu == ctu && rb[r].tus.size() < 255 &&        /* RUN_MAX_TUS of k_run; positions + 1 fit a byte */
-                     in_cur_run;
-      if (extends && run_box < 64) {       // sparse-intra pictures: keep every run inside a run_box^2 bounding box
-        const int bw = std::max(rb[r].x1, tu.x0 + nT) - std::min(rb[r].x0, (int)tu.x0);
-        const int bh = std::max(rb[r].y1, tu.y0 + nT) - std::min(rb[r].y0, (int)tu.y0);
-        extends = bw <= run_box && bh <= run_box;
+      if (aTL && intra_ok(xB - 1, yB - 1)) take(corner, xB - 1, yB - 1);
+      if (aT) for (int x = 0; x < nT; x += 4) if (intra_ok(xB + x, yB - 1)) take(corner + 1 + (x >> 2), xB + x, yB - 1);
+      if (aTR)
+        for (int x = nT; x < nRight; x += 4) {
+          const int nx = (xB + x) * sub, ny = (yB - 1) * sub;
+          if (zs[(nx >> lt) + (size_t)(ny >> lt) * g.tbs_w] <= cur && intra_ok(xB + x, yB - 1)) take(corner + 1 + (x >> 2), xB + x, yB - 1);
+        }
+      t.avail = mask;
+      // -- dependencies: only the units the mode reads (mode_deps), or every available unit
+      const Cell* cells = SC.cells[c].data();
+      uint64_t need = mode_deps ? needed_units(g_used_units[tu.log2_size - 2][m][c == 0], mask) : mask;
+      int lev = 0, llev = 0, n_prod = 0;
+      const int crun = cur_run[c];
+      for (; need; need &= need - 1) {
+        const Cell C = cells[cell[__builtin_ctzll(need)]];
+        const int cr = C.run - E;                           // (< 0: no intra TU of this picture covers the cell)
+        if (cr >= 0) {
+          lev = std::max(lev, (int)C.lvl);
+          if (cr == crun) llev = std::max(llev, (int)C.llvl);
+          bool seen = false;
+          for (int q = 0; q < n_prod; q++) seen = seen || prod[q] == cr;
+          if (!seen) prod[n_prod++] = cr;
+        }
+      }
+      level = lev + 1; llev += 1;
+      // -- which run: the current one of its component if the TU lies in the same CTB and reads from it (the run structure is
+      // decided on the FULL neighbourhood, so that an all-intra CTB stays one run per component) ...
+      int r = crun;
+      bool extends = r >= 0 && rb[r].ctu == ctu && rb[r].n_tus < 255;       /* RUN_MAX_TUS of k_run; positions + 1 fit a byte */
+      if (extends) {
+        extends = false;
+        for (uint64_t mm = mask; mm && !extends; mm &= mm - 1) extends = cells[cell[__builtin_ctzll(mm)]].run == E + r;
       }
       // A TU that cannot extend the current run but reads from exactly ONE run joins that run instead of starting its
       // own (e.g. an intra CU next to an intra CU of the neighbouring CTB, or below one decoded long ago): a hand-over
@@ -821,92 +846,102 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       // graph stays acyclic: the joined run gains no producer, and every other edge still points from a later-created
       // run to an earlier-created one.  The run is then no interval of the decode order any more; its TUs keep their
       // order by in-run level.  DE265HIP_NO_MERGE=1 switches it off.
-      // More than one producer: the TU may join the LATEST-created of them, X (its other producers were all created
-      // before X, so the new edges X -> Y keep pointing backwards in creation order), if that does not raise X's level,
-      // i.e. every other producer sits on a lower level than X as far as known now.
-      bool merged = false;
       // (Measured, 4K Main10: joining only single-producer TUs takes a B picture from 8 813 to 8 086 runs and 7 to 6 levels,
       //  99 -> 90 us, I pictures unchanged; with several producers allowed the B pictures gain nothing more (8 067 runs) and
       //  the I picture loses - chroma runs merge across CTBs, 6 120 -> 4 142 runs, 1.94 -> 2.04 ms.  So: one producer only.)
-      if (!extends && merge_runs && producers.size() == 1) {
-        int x = producers[0];
-        for (int pr : producers) x = std::max(x, pr);
-        RunBuild& X = rb[x];
-        bool ok = true;
-        for (int pr : producers) if (pr != x && rb[pr].est >= X.est) ok = false;
+      bool merged = false;
+      if (!extends && merge_runs && n_prod == 1) {
+        const int x = prod[0];
+        const RunB& X = rb[x];
         const int bw = std::max(X.x1, tu.x0 + nT) - std::min(X.x0, (int)tu.x0);
         const int bh = std::max(X.y1, tu.y0 + nT) - std::min(X.y0, (int)tu.y0);
-        if (ok && X.c == c && X.tus.size() < 255 && bw <= run_box && bh <= run_box) {
-          // in-run level: behind everything of X it reads (the other producers are whole runs X waits for anyway)
+        if (X.c == c && X.n_tus < 255 && bw <= run_box && bh <= run_box) {
+          // in-run level: behind everything of X it reads; the needed cells are not kept: every cell of X the TU's
+          // neighbourhood touches is a safe upper bound
           int lx = 0;
-          {
-            const int cw4 = map_w[c];
-            // the needed cells are not kept: every cell of X the TU's neighbourhood touches is a safe upper bound
-            const int ux0 = std::max(0, (int)tu.x0 - 4) >> 2, uy0 = std::max(0, (int)tu.y0 - 4) >> 2;
-            const int ux1 = std::min(cw - 1, (int)tu.x0 + 2 * nT + 3) >> 2, uy1 = std::min(ch - 1, (int)tu.y0 + 2 * nT + 3) >> 2;
-            for (int x4 = ux0; x4 <= ux1; x4++) if (uy0 < (tu.y0 >> 2) && runmap[c][x4 + (size_t)uy0 * cw4] == x) lx = std::max(lx, (int)llvl[c][x4 + (size_t)uy0 * cw4]);
-            for (int y4 = uy0; y4 <= uy1; y4++) if (ux0 < (tu.x0 >> 2) && runmap[c][ux0 + (size_t)y4 * cw4] == x) lx = std::max(lx, (int)llvl[c][ux0 + (size_t)y4 * cw4]);
-          }
+          const int ux0 = std::max(0, (int)tu.x0 - 4) >> 2, uy0 = std::max(0, (int)tu.y0 - 4) >> 2;
+          const int ux1 = std::min(cw - 1, (int)tu.x0 + 2 * nT + 3) >> 2, uy1 = std::min(ch - 1, (int)tu.y0 + 2 * nT + 3) >> 2;
+          if (uy0 < (tu.y0 >> 2)) for (int x4 = ux0; x4 <= ux1; x4++) { const Cell C = cells[x4 + (size_t)uy0 * mw]; if (C.run == E + x) lx = std::max(lx, (int)C.llvl); }
+          if (ux0 < (tu.x0 >> 2)) for (int y4 = uy0; y4 <= uy1; y4++) { const Cell C = cells[ux0 + (size_t)y4 * mw]; if (C.run == E + x) lx = std::max(lx, (int)C.llvl); }
           if (lx + 1 <= 250) { r = x; llev = lx + 1; merged = true; }
         }
       }
       if (!extends && !merged) {
         r = (int)rb.size();
-        rb.push_back(RunBuild{ c, ctu, tu.x0, tu.y0, tu.x0 + nT, tu.y0 + nT, 0, 0, 0, {}, {} });
+        RunB nr; memset(&nr, 0, sizeof(nr));
+        nr.c = c; nr.ctu = ctu; nr.x0 = tu.x0; nr.y0 = tu.y0; nr.x1 = tu.x0 + nT; nr.y1 = tu.y0 + nT; nr.est = 1;
+        nr.head = nr.tail = -1; nr.dep_head = nr.dep_tail = -1;
+        rb.push_back(nr);
         cur_run[c] = r;
         llev = 1;
       }
-      RunBuild& R = rb[r];
+      RunB& R = rb[r];
       R.x0 = std::min(R.x0, (int)tu.x0); R.y0 = std::min(R.y0, (int)tu.y0);
       R.x1 = std::max(R.x1, tu.x0 + nT); R.y1 = std::max(R.y1, tu.y0 + nT);
       R.wx1 = std::max(R.wx1, tu.x0 + 2 * nT); R.wy1 = std::max(R.wy1, tu.y0 + 2 * nT);    // top-right / bottom-left reach
-      for (int pr : producers)
-        if (pr != r && std::find(R.deps.begin(), R.deps.end(), pr) == R.deps.end()) { R.deps.push_back(pr); R.est = std::max(R.est, rb[pr].est + 1); }
-      R.tus.push_back(t); R.llev.push_back((uint16_t)llev);
-      for (int y = tu.y0 >> 2; y < (tu.y0 + nT) >> 2; y++)
-        for (int x = tu.x0 >> 2; x < (tu.x0 + nT) >> 2; x++) {
-          lvl[c][x + (size_t)y * map_w[c]] = (uint16_t)level;
-          llvl[c][x + (size_t)y * map_w[c]] = (uint16_t)llev;
-          runmap[c][x + (size_t)y * map_w[c]] = r;
-        }
+      for (int q = 0; q < n_prod; q++) {
+        const int pr = prod[q];
+        if (pr == r) continue;
+        bool seen = false;
+        for (int e = R.dep_head; e >= 0 && !seen; e = SC.dep_next[e]) seen = SC.dep_val[e] == pr;
+        if (seen) continue;
+        const int e = (int)SC.dep_val.size();
+        SC.dep_val.push_back(pr); SC.dep_next.push_back(-1);
+        if (R.dep_tail >= 0) SC.dep_next[R.dep_tail] = e; else R.dep_head = e;
+        R.dep_tail = e; R.n_deps++;
+        R.est = std::max(R.est, rb[pr].est + 1);
+      }
+      {                                                     // the run's TUs: a list in decode order
+        const int ti = (int)SC.it.size();
+        SC.it.push_back(t); SC.it_next.push_back(-1); SC.it_llev.push_back((uint16_t)llev);
+        if (R.tail >= 0) SC.it_next[R.tail] = ti; else R.head = ti;
+        R.tail = ti; R.n_tus++;
+      }
+      {
+        Cell* wc = SC.cells[c].data();
+        const Cell v{ E + r, (uint16_t)level, (uint16_t)llev };
+        for (int y = tu.y0 >> 2; y < (tu.y0 + nT) >> 2; y++)
+          for (int x = tu.x0 >> 2; x < (tu.x0 + nT) >> 2; x++) wc[x + (size_t)y * mw] = v;
+      }
       alg_intra += (int64_t)bpp * (4 * nT + 1) + (int64_t)bpp * nT * nT;
       R.alg += (int64_t)bpp * (4 * nT + 1) + (int64_t)bpp * nT * nT;
       if (level >= 65535) { delete pic; return DE265HIP_ERROR_NOT_IMPLEMENTED; }
-    }
+    } else
+      l0p[inter_cur[tu.log2_size - 2]++] = t;               // level 0: residual added into the (inter-predicted) picture
     if (t.flags & DE265HIP_TU_CBF)
       alg_resid += std::min<int64_t>(4 * (int64_t)t.n_coeff, 2 * (int64_t)nT * nT) +
                    ((tu.flags & DE265HIP_TU_INTRA) ? 0 : 2 * (int64_t)bpp * nT * nT);
-    max_level = std::max(max_level, level);
-    tasks.push_back(t); levels.push_back(level);
+    if (level > max_level) { max_level = level; SC.level_hist.resize(max_level + 2, 0); }
+    SC.level_hist[level + 1]++;
+    n_tasks++;
+    if (dec->intra_levels) { SC.all_tasks.push_back(t); SC.all_levels.push_back(level); }
   }
   pt.mark("tu_scan");
-  pic->level_start.assign(max_level + 2, 0);
-  for (int l : levels) pic->level_start[l + 1]++;
+  pic->level_start.assign(SC.level_hist.begin(), SC.level_hist.begin() + max_level + 2);
   for (int l = 0; l <= max_level; l++) pic->level_start[l + 1] += pic->level_start[l];
   // the level-sorted task array is only needed by the level-launch schedule (DE265HIP_INTRA_MODE=levels)
   std::vector<TuTask> sorted;
   if (dec->intra_levels) {
-    sorted.resize(tasks.size());
+    sorted.resize(SC.all_tasks.size());
     std::vector<int> cursor(pic->level_start.begin(), pic->level_start.end() - 1);
-    for (size_t i = 0; i < tasks.size(); i++) sorted[cursor[levels[i]]++] = tasks[i];
+    for (size_t i = 0; i < SC.all_tasks.size(); i++) sorted[cursor[SC.all_levels[i]]++] = SC.all_tasks[i];
   }
-  pic->n_tus = (int)tasks.size();
+  pic->n_tus = n_tasks;
 
   // ---- runs in dependency (ticket) order: producers first
-  std::vector<RunTask> runs; std::vector<uint32_t> run_deps, slots; std::vector<TuTask> run_tus, resid_only;
-  { size_t n_intra = 0; for (const auto& R : rb) n_intra += R.tus.size(); run_tus.reserve(n_intra); resid_only.reserve(n_intra); }
+  std::vector<RunTask>& runs = SC.runs; std::vector<uint32_t>& run_deps = SC.run_deps; std::vector<uint32_t>& slots = SC.slots;
+  std::vector<TuTask>& run_tus = SC.run_tus;
+  runs.clear(); run_deps.clear(); slots.clear(); run_tus.clear(); run_tus.reserve(SC.it.size());
   const bool micro_off = getenv("DE265HIP_NO_MICRO") != nullptr;
-  const bool no_dense = getenv("DE265HIP_NO_DENSE") != nullptr;           // (not per run: getenv walks the whole environment)
+  const bool no_dense = getenv("DE265HIP_NO_DENSE") != nullptr;    // (not per run: getenv walks the whole environment)
   const int micro_tus = getenv("DE265HIP_MICRO_TUS") ? std::min(16, atoi(getenv("DE265HIP_MICRO_TUS"))) : 16;   // MICRO_TUS of k_run
   int64_t sum_lvls = 0, dbg_foreign = 0, dbg_w[4] = { 0, 0, 0, 0 };
-  std::vector<uint8_t> dbg_micro;
   size_t n_resid = 0;
   int max_rl = 0, n_front = 0;
   {
-    for (auto& R : rb) { int l = 0; for (int dp : R.deps) l = std::max(l, rb[dp].level); R.level = l + 1; max_rl = std::max(max_rl, R.level); }
-    std::vector<int> count(max_rl + 2, 0), order(rb.size()), newidx(rb.size());
-    for (auto& R : rb) count[R.level + 1]++;
-    for (int l = 0; l <= max_rl; l++) count[l + 1] += count[l];
+    for (auto& R : rb) { int l = 0; for (int e = R.dep_head; e >= 0; e = SC.dep_next[e]) l = std::max(l, rb[SC.dep_val[e]].level); R.level = l + 1; max_rl = std::max(max_rl, R.level); }
+    std::vector<int>& order = SC.order; std::vector<int>& newidx = SC.newidx;
+    order.resize(rb.size()); newidx.resize(rb.size());
     // micro runs (<= 16 TUs of <= 8x8 inside a 32x32 box: most runs of a picture with inter PUs) are reconstructed by
     // one wavefront each, four per workgroup and ticket; inside a level they come first (same-level runs are independent)
     // (up to 32 TUs per micro run instead of 16 - the records live one per lane - measured slower: a long run is better
@@ -914,21 +949,24 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     // micro runs: <= 16 TUs of <= 8x8 in a 32x32 box; 16x16 TUs too (DE265HIP_MICRO16=0: not) when the run's samples
     // fit the wavefront's residual slice (1024) and its window the wavefront's slice of the window array (k_tu.hip:
     // MICRO_P 56 columns from the 8-aligned left edge, MICRO_H 41 rows, 256 chunks of 8 samples)
-    static const bool micro16 = !getenv("DE265HIP_MICRO16") || atoi(getenv("DE265HIP_MICRO16")) != 0;
-    auto is_micro = [&](const RunBuild& R) {
-      if (micro_off || (int)R.tus.size() > micro_tus || R.x1 - R.x0 > 32 || R.y1 - R.y0 > 32) return false;
+    const bool micro16 = !getenv("DE265HIP_MICRO16") || atoi(getenv("DE265HIP_MICRO16")) != 0;
+    auto is_micro = [&](const RunB& R) {
+      if (micro_off || R.n_tus > micro_tus || R.x1 - R.x0 > 32 || R.y1 - R.y0 > 32) return false;
       int samples = 0; bool big = false;
-      for (const TuTask& t : R.tus) { if (t.log2_size > 4) return false; big = big || t.log2_size == 4; samples += 1 << (2 * t.log2_size); }
+      for (int ti = R.head; ti >= 0; ti = SC.it_next[ti]) {
+        const TuTask& t = SC.it[ti];
+        if (t.log2_size > 4) return false;
+        big = big || t.log2_size == 4; samples += 1 << (2 * t.log2_size);
+      }
       if (!big) return true;
       if (!micro16 || samples > 1024) return false;
       const int ax0 = (R.x0 - 1) & ~7, wx1 = std::min(R.wx1, R.x1 + 32), wy1 = std::min(R.wy1, R.y1 + 32);
       const int cols = wx1 - ax0, rows = wy1 - (R.y0 - 1);
       return cols <= 56 && rows <= 41 && ((cols + 7) >> 3) * rows <= 256;
     };
-    std::vector<uint8_t> micro(rb.size(), 0);
+    std::vector<uint8_t>& micro = SC.micro; micro.resize(rb.size());
     for (size_t i = 0; i < rb.size(); i++) micro[i] = is_micro(rb[i]);
-    dbg_micro = micro;
-    std::vector<int> count2(2 * (max_rl + 2) + 1, 0);
+    std::vector<int>& count2 = SC.count2; count2.assign(2 * (max_rl + 2) + 1, 0);
     for (size_t i = 0; i < rb.size(); i++) count2[2 * rb[i].level + (micro[i] ? 0 : 1) + 1]++;
     for (size_t l = 0; l + 1 < count2.size(); l++) count2[l + 1] += count2[l];
     for (size_t i = 0; i < rb.size(); i++) { int k = count2[2 * rb[i].level + (micro[i] ? 0 : 1)]++; order[k] = (int)i; newidx[i] = k; }
@@ -936,7 +974,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     // Front runs: the micro runs of level 1 (no producer among the intra runs) - the first block of the run order.  They are
     // reconstructed by k_intra_front, one small workgroup each, ahead of k_run: no ticket, no flag, and the runs that read
     // from them do not list them as producers (the kernel boundary orders them).  DE265HIP_NO_FRONT=1: through k_run as all others.
-    static const bool front_off = getenv("DE265HIP_NO_FRONT") != nullptr;
+    const bool front_off = getenv("DE265HIP_NO_FRONT") != nullptr;
     n_front = 0;
     if (!front_off && !dec->intra_levels)
       while ((size_t)n_front < rb.size() && micro[order[n_front]] && rb[order[n_front]].level == 1) n_front++;
@@ -954,15 +992,17 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     if (getenv("DE265HIP_TEST_DROP_PRODUCER")) {         // fault injection: the first run somebody depends on is never executed
       int victim = -1;
       for (size_t i = 0; i < rb.size() && victim < 0; i++)
-        for (int dp : rb[i].deps) if (victim < 0 && newidx[dp] >= n_front) victim = newidx[dp];
+        for (int e = rb[i].dep_head; e >= 0; e = SC.dep_next[e]) if (victim < 0 && newidx[SC.dep_val[e]] >= n_front) victim = newidx[SC.dep_val[e]];
       for (uint32_t& v : slots) if (v != 0xFFFFFFFFu && (int)(v & 0x7FFFFFFFu) == victim) v = 0xFFFFFFFFu;
     }
+    int tix[256];                                        // the run's TUs (indices into SC.it) in decode order
     for (size_t k = 0; k < rb.size(); k++) {
-      const RunBuild& R = rb[order[k]];
+      const RunB& R = rb[order[k]];
       RunTask& o = runs[k]; memset(&o, 0, sizeof(o));
       o.x0 = (uint16_t)R.x0; o.y0 = (uint16_t)R.y0; o.x1 = (uint16_t)R.x1; o.y1 = (uint16_t)R.y1;
       o.wx1 = (uint16_t)std::min(R.wx1, R.x1 + 32); o.wy1 = (uint16_t)std::min(R.wy1, R.y1 + 32);
-      int own_samples = 0; for (const TuTask& tt : R.tus) own_samples += 1 << (2 * tt.log2_size);
+      int n = 0, own_samples = 0, nl = 0;
+      for (int ti = R.head; ti >= 0; ti = SC.it_next[ti]) { tix[n++] = ti; own_samples += 1 << (2 * SC.it[ti].log2_size); nl = std::max(nl, (int)SC.it_llev[ti]); }
       // dense: the run's TUs cover its whole bounding box AND every available neighbour outside the box lies on the row
       // above it or the column left of it (two stacked CUs with an inter CU beside the upper one do not qualify: the
       // lower CU reads above-right samples from inside the box's row range)
@@ -970,8 +1010,8 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       // (with the box covered, the only neighbour units that can lie outside "box + row above + column to the left" are
       //  above-right units beyond the box's right edge of TUs below its first row, and below-left units beyond its bottom
       //  edge of TUs right of its first column: two mask tests per TU)
-      for (size_t i = 0; dense && i < R.tus.size(); i++) {
-        const TuTask& tt = R.tus[i];
+      for (int i = 0; dense && i < n; i++) {
+        const TuTask& tt = SC.it[tix[i]];
         const int nT = 1 << tt.log2_size, xB = tt.x0, yB = tt.y0, corner = nT >> 1;
         if (xB > R.x0 && yB + 2 * nT > R.y1) {                 // left column, unit u = rows yB+2nT-4u-4 .. -1 (bottom -> top)
           const int umax = std::min(corner - 1, (yB + 2 * nT - 1 - R.y1) >> 2);
@@ -982,41 +1022,36 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
           if (kmin < corner && (tt.avail >> (corner + 1 + kmin)) & ((1ull << (corner - kmin)) - 1ull)) dense = false;
         }
       }
-      o.c_idx = (uint8_t)R.c; o.micro = (uint8_t)(micro[order[k]] | (dense ? 2 : 0)); o.n_tus = (uint16_t)R.tus.size();
+      o.c_idx = (uint8_t)R.c; o.micro = (uint8_t)(micro[order[k]] | (dense ? 2 : 0)); o.n_tus = (uint16_t)n;
       o.first_tu = (uint32_t)run_tus.size(); o.dep_offset = (uint32_t)run_deps.size();
-      { int nd = 0; for (int dp : R.deps) nd += newidx[dp] >= n_front; o.n_deps = (uint16_t)nd; }
+      { int nd = 0; for (int e = R.dep_head; e >= 0; e = SC.dep_next[e]) nd += newidx[SC.dep_val[e]] >= n_front; o.n_deps = (uint16_t)nd; }
       o.res_offset = (uint32_t)n_resid;
-      // TUs of the run: the TUs of one in-run level are independent of each other and are dealt round-robin to
-      // the wavefronts of the workgroup; stored as one list per wavefront, each in level order, level in the record
-      int nl = 0; for (uint16_t l : R.llev) nl = std::max(nl, (int)l);
       if (nl > 256) { delete pic; return DE265HIP_ERROR_NOT_IMPLEMENTED; }      // RUN_MAX_TUS of k_run
-      o.n_lvls = (uint16_t)nl;
       sum_lvls += nl;
       // Order of the run's TUs in its record: one list per wavefront (list w = the TUs dealt to wavefront w), each in
       // in-run level order, then the collective list (16x16 / 32x32 TUs, reconstructed by all wavefronts together).
       // The TUs of one in-run level are independent of each other and are dealt round-robin to the wavefronts; the chain
-      // passes one workgroup barrier per level.  One sort by (list, level, decode index) on a reused scratch array.
+      // passes one workgroup barrier per level.  One sort by (list, level, decode index).
       // (measured on a 4K all-intra picture: this 3.46 ms; list scheduling that keeps z-scan chains on one wavefront,
       //  with barriers only where a producer sits on another wavefront, 4.0-4.2 ms: a wavefront that runs ahead
       //  arrives late at the barrier the others need; progress counters in LDS polled by the waiting wavefronts
       //  3.9 ms: the pollers take issue slots from the working wavefronts of the other workgroups on their SIMDs;
       //  round-robin lists with barriers only at cross-wavefront edges plus early arrival of the producing wavefront:
       //  54 % fewer barriers, 3.33 instead of 3.19 ms -- the workgroup barrier is not what the chain waits for)
-      static thread_local std::vector<uint64_t> keys;
-      static thread_local std::vector<int> rank;
-      keys.clear(); rank.assign(nl + 1, 0);
+      uint32_t keys[256]; uint8_t rank[260];
+      memset(rank, 0, (size_t)nl + 1);
       {
         const int nwv = micro[order[k]] ? 1 : dec->run_waves;
         const int n_epochs = nl > 0 ? nl - 1 : 0;
-        for (size_t i = 0; i < R.tus.size(); i++) {
-          const int lev = R.llev[i];
-          const int list = (R.tus[i].log2_size > 3 && !micro[order[k]]) ? 4 : rank[lev]++ % nwv;
-          keys.push_back(((uint64_t)list << 40) | ((uint64_t)lev << 20) | (uint64_t)i);
+        for (int i = 0; i < n; i++) {
+          const int lev = SC.it_llev[tix[i]];
+          const int list = (SC.it[tix[i]].log2_size > 3 && !micro[order[k]]) ? 4 : rank[lev]++ % nwv;
+          keys[i] = ((uint32_t)list << 20) | ((uint32_t)lev << 8) | (uint32_t)i;
         }
-        std::sort(keys.begin(), keys.end());
-        size_t pos = 0;
+        if (n > 1) std::sort(keys, keys + n);
+        int pos = 0;
         for (int w = 0; w < 4; w++) {
-          while (pos < keys.size() && (int)(keys[pos] >> 40) <= w) { dbg_w[w]++; pos++; }
+          while (pos < n && (int)(keys[pos] >> 20) <= w) { dbg_w[w]++; pos++; }
           o.wave_end[w] = (uint16_t)pos;
         }
         if (n_epochs > 255) { delete pic; return DE265HIP_ERROR_NOT_IMPLEMENTED; }
@@ -1024,9 +1059,9 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
         dbg_foreign += n_epochs;
       }
       uint32_t samp = 0;
-      for (size_t oi = 0; oi < keys.size(); oi++) {
-        const size_t ti = (size_t)(keys[oi] & 0xFFFFFu);
-        TuTask tt = R.tus[ti];
+      for (int oi = 0; oi < n; oi++) {
+        const int ti = tix[keys[oi] & 0xFFu];
+        TuTask tt = SC.it[ti];
         const uint32_t coeff_offset = tt.coeff_offset;
         // the run's residual range is laid out by SAMPLE of the run (blocks of TUs without coefficients stay unwritten and are
         // masked by the kernels): a run's residuals are one contiguous, 16-byte aligned vector the run kernels fetch right
@@ -1035,14 +1070,14 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
         tt.coeff_offset = samp; samp += 1u << (2 * tt.log2_size);
         if (tt.flags & DE265HIP_TU_CBF) {
           TuTask ro = tt; ro.flags |= D265_TU_RESID_ONLY; ro.coeff_offset = coeff_offset;
-          resid_only.push_back(ro);
+          l0p[ro_cur[ro.log2_size - 2]++] = ro;
         }
-        tt.run_level = (uint8_t)(R.llev[ti] - 1);        // the run-ordered copy carries the TU's barrier epoch
+        tt.run_level = (uint8_t)(SC.it_llev[ti] - 1);    // the run-ordered copy carries the TU's barrier epoch
         run_tus.push_back(tt);
       }
       o.n_samples = samp;
       n_resid += (samp + 7u) & ~7u;
-      for (int dp : R.deps) if (newidx[dp] >= n_front) run_deps.push_back((uint32_t)newidx[dp]);
+      for (int e = R.dep_head; e >= 0; e = SC.dep_next[e]) if (newidx[SC.dep_val[e]] >= n_front) run_deps.push_back((uint32_t)newidx[SC.dep_val[e]]);
     }
   }
   pt.mark("runs");
@@ -1050,7 +1085,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   pic->n_front = n_front;
   {
     // worker count = widest dependency level (more workers would only wait), within [64, 4 per CU]
-    std::vector<int> width(max_rl + 2, 0);
+    std::vector<int>& width = SC.width; width.assign(max_rl + 2, 0);
     for (auto& R : rb) width[R.level]++;
     if (max_rl >= 1) width[1] -= n_front;
     int widest = 0; for (int wv : width) widest = std::max(widest, wv);
@@ -1059,7 +1094,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     // bench with 3 streams 5304 vs 5173 frames/s, one stream alone 2317 vs 2353
     int cap = wenv ? atoi(wenv) : 512;
     pic->n_batches = (int)(slots.size() / RUN_TICKET_SLOTS);
-    const char* menv = getenv("DE265HIP_RUN_WORKER_PCT");            // workers as a percentage of the widest level (experiments)
+    const char* menv = getenv("DE265HIP_RUN_WORKER_PCT");     // workers as a percentage of the widest level (experiments)
     const int pct = menv ? atoi(menv) : 125;
     pic->n_workers = std::min(pic->n_batches, std::max(64, std::min(cap, (int)((int64_t)widest * pct / 100))));
     // direct mode (see k_run): when the picture is wide rather than deep - most of its runs sit in its widest level
@@ -1070,61 +1105,30 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     // for all pictures 23 % (6 390 -> 6 010 -> 4 890 frames/s): thousands of resident workgroups hold LDS the other
     // streams' kernels need.  Off unless asked for.
     pic->run_direct = denv ? atoi(denv) != 0 : false;
-    if (getenv("DE265HIP_PRINT_CRIT")) {               // diagnostic: longest path through the run DAG
-      {
-        std::vector<int> wm(max_rl + 2, 0), wo(max_rl + 2, 0);
-        for (size_t i = 0; i < rb.size(); i++) (dbg_micro[i] ? wm : wo)[rb[i].level]++;
-        fprintf(stderr, "de265hip runs per level (micro/ordinary):");
-        for (int l = 1; l <= std::min(max_rl, 12); l++) fprintf(stderr, " %d/%d", wm[l], wo[l]);
-        fprintf(stderr, "\n");
-      }
+    if (getenv("DE265HIP_PRINT_CRIT")) {               // diagnostic: run counts per level, longest path through the run DAG
+      std::vector<int> wm(max_rl + 2, 0), wo(max_rl + 2, 0);
+      for (size_t i = 0; i < rb.size(); i++) (SC.micro[i] ? wm : wo)[rb[i].level]++;
+      fprintf(stderr, "de265hip runs %zu (front %d); per level (micro/ordinary):", rb.size(), n_front);
+      for (int l = 1; l <= std::min(max_rl, 12); l++) fprintf(stderr, " %d/%d", wm[l], wo[l]);
+      fprintf(stderr, "\n");
       // cost model of one run (us; fitted to ablation timings): fixed + per barrier level + per TU a wavefront has to do
       // in sequence inside a level + per 16x16 / 32x32 TU (collective)
       struct Path { double t = 0, lv = 0, slots = 0, n16 = 0, n32 = 0; int runs = 0; };
       std::vector<Path> fin(rb.size()); Path worst;
-      for (size_t i = 0; i < rb.size(); i++) {           // rb is in decode order: producers precede consumers
-        int nl = 0; for (uint16_t l : rb[i].llev) nl = std::max(nl, (int)l);
+      for (size_t i = 0; i < rb.size(); i++) {           // rb is in creation order: producers precede consumers
+        int nl = 0; for (int ti = rb[i].head; ti >= 0; ti = SC.it_next[ti]) nl = std::max(nl, (int)SC.it_llev[ti]);
         std::vector<int> per(nl + 1, 0); int n16 = 0, n32 = 0;
-        for (size_t k = 0; k < rb[i].tus.size(); k++) {
-          const int l2 = rb[i].tus[k].log2_size;
-          if (l2 == 4) n16++; else if (l2 == 5) n32++; else per[rb[i].llev[k]]++;
+        for (int ti = rb[i].head; ti >= 0; ti = SC.it_next[ti]) {
+          const int l2 = SC.it[ti].log2_size;
+          if (l2 == 4) n16++; else if (l2 == 5) n32++; else per[SC.it_llev[ti]]++;
         }
-        int slots = 0; for (int l = 1; l <= nl; l++) slots += (per[l] + 3) / 4;
+        int nslots = 0; for (int l = 1; l <= nl; l++) nslots += (per[l] + 3) / 4;
         Path st;
-        for (int dp : rb[i].deps) if (fin[dp].t > st.t) st = fin[dp];
-        st.t += 4.5 + 0.13 * nl + 0.10 * slots + 0.55 * n16 + 0.65 * n32;
-        st.lv += nl; st.slots += slots; st.n16 += n16; st.n32 += n32; st.runs++;
+        for (int e = rb[i].dep_head; e >= 0; e = SC.dep_next[e]) if (fin[SC.dep_val[e]].t > st.t) st = fin[SC.dep_val[e]];
+        st.t += 4.5 + 0.13 * nl + 0.10 * nslots + 0.55 * n16 + 0.65 * n32;
+        st.lv += nl; st.slots += nslots; st.n16 += n16; st.n32 += n32; st.runs++;
         fin[i] = st;
         if (st.t > worst.t) worst = st;
-      }
-      int hist[8] = {0}, small32 = 0, nmicro = 0, with16 = 0, single16 = 0, single32 = 0, only_big = 0;
-      for (size_t i = 0; i < rb.size(); i++) {
-        const size_t n = rb[i].tus.size();
-        {
-          int mx = 0, mn = 9; for (const TuTask& t : rb[i].tus) { mx = std::max(mx, (int)t.log2_size); mn = std::min(mn, (int)t.log2_size); }
-          const bool box32 = rb[i].x1 - rb[i].x0 <= 32 && rb[i].y1 - rb[i].y0 <= 32;
-          with16 += mx == 4 && n <= 16 && box32; single16 += n == 1 && mx == 4; single32 += n == 1 && mx == 5; only_big += mn >= 4;
-        }
-        hist[n <= 1 ? 0 : n <= 2 ? 1 : n <= 4 ? 2 : n <= 8 ? 3 : n <= 16 ? 4 : n <= 32 ? 5 : n <= 64 ? 6 : 7]++;
-        bool ok = rb[i].x1 - rb[i].x0 <= 32 && rb[i].y1 - rb[i].y0 <= 32 && n <= 64;
-        for (const TuTask& t : rb[i].tus) if (t.log2_size > 3) ok = false;
-        small32 += ok; nmicro += ok && n <= 4 && rb[i].x1 - rb[i].x0 <= 16 && rb[i].y1 - rb[i].y0 <= 16;
-      }
-      fprintf(stderr, "de265hip runs: %zu, micro %d, <=8x8 TUs in 32x32 box %d; by TU count 1:%d 2:%d 3-4:%d 5-8:%d 9-16:%d 17-32:%d 33-64:%d >64:%d\n",
-              rb.size(), nmicro, small32, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7]);
-      fprintf(stderr, "de265hip runs with 16x16 as largest TU, <= 16 TUs, 32x32 box: %d; a single 16x16 TU: %d; a single 32x32 TU: %d; only 16x16/32x32 TUs: %d\n",
-              with16, single16, single32, only_big);
-      {
-        int n_mic = 0, r_tus = 0, r_box = 0, r_32 = 0, r_fit = 0, sparse_box = 0;
-        for (size_t i = 0; i < rb.size(); i++) {
-          if (dbg_micro[i]) { n_mic++; continue; }
-          const RunBuild& R = rb[i];
-          int mx = 0, own = 0; for (const TuTask& t : R.tus) { mx = std::max(mx, (int)t.log2_size); own += 1 << (2 * t.log2_size); }
-          const bool box = R.x1 - R.x0 > 32 || R.y1 - R.y0 > 32;
-          if (mx == 5) r_32++; else if (box) { r_box++; sparse_box += own < (R.x1 - R.x0) * (R.y1 - R.y0); } else if ((int)R.tus.size() > 16) r_tus++; else r_fit++;
-        }
-        fprintf(stderr, "de265hip micro runs %d; ordinary because of: a 32x32 TU %d, box > 32 %d (sparse %d), > 16 TUs %d, samples/window do not fit %d\n",
-                n_mic, r_32, r_box, sparse_box, r_tus, r_fit);
       }
       fprintf(stderr, "de265hip chain: %lld barrier epochs in all runs; TUs per wavefront %lld %lld %lld %lld\n",
               (long long)dbg_foreign, (long long)dbg_w[0], (long long)dbg_w[1], (long long)dbg_w[2], (long long)dbg_w[3]);
@@ -1136,23 +1140,14 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     const char* benv = getenv("DE265HIP_TICKET_BATCH");
     pic->ticket_batch = benv ? std::max(1, std::min(64, atoi(benv))) : 1;
   }
-  // level-0 launch of run mode: inter TUs with residual, then the residual-only intra TUs
-  // largest first: [32x32 | 16x16 | 8x8 | 4x4] (counting sort); the two small sizes get their own packed kernel
-  std::vector<TuTask> l0;
-  {
-    for (int k = 0; k < 4; k++) pic->n_l0_size[k] = 0;
-    for (size_t i = 0; i < tasks.size(); i++) if (levels[i] == 0) pic->n_l0_size[tasks[i].log2_size - 2]++;
-    for (const TuTask& tt : resid_only) pic->n_l0_size[tt.log2_size - 2]++;
-    size_t cur[4]; cur[3] = 0; cur[2] = pic->n_l0_size[3]; cur[1] = cur[2] + pic->n_l0_size[2]; cur[0] = cur[1] + pic->n_l0_size[1];
-    l0.resize(cur[0] + pic->n_l0_size[0]);
-    for (size_t i = 0; i < tasks.size(); i++) if (levels[i] == 0) l0[cur[tasks[i].log2_size - 2]++] = tasks[i];
-    for (const TuTask& tt : resid_only) l0[cur[tt.log2_size - 2]++] = tt;
-  }
+  // level-0 launch of run mode: inter TUs with residual, then the residual-only intra TUs, largest first
+  // [32x32 | 16x16 | 8x8 | 4x4]: both were written to their place above
+  std::vector<TuTask>& l0 = SC.l0;
   pic->n_l0 = (int)l0.size();
 
   pt.mark("l0");
   // ---- MC tasks: resolve references, bi->uni shortcut, split into <=16x16 tiles
-  std::vector<McTask> mcs;
+  std::vector<McTask>& mcs = SC.mcs; mcs.clear();
   int64_t alg_mc = 0;
   for (int i = 0; i < d->n_pus; i++) {
     const de265hip_pu& pu = d->pus[i];
@@ -1200,7 +1195,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
 
   pt.mark("mc");
   // ---- PCM tasks
-  std::vector<PcmTask> pcms;
+  std::vector<PcmTask>& pcms = SC.pcms; pcms.clear();
   for (int i = 0; i < d->n_pcms; i++) {
     const de265hip_pcm& pc = d->pcms[i];
     const int n = 1 << pc.log2_cb_size;
@@ -1222,7 +1217,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
 
   // ---- per-CTB SAO records: slice flags applied, slice / tile permissions of the 3x3 neighbourhood
   // (sao.cc:127-163) evaluated once here instead of per sample on the device
-  std::vector<SaoCtb> saos((size_t)d->n_ctbs);
+  std::vector<SaoCtb>& saos = SC.saos; saos.resize((size_t)d->n_ctbs);
   for (int cy = 0; cy < g.ctbs_h; cy++)
     for (int cx = 0; cx < g.ctbs_w; cx++) {
       const int a = cx + cy * g.ctbs_w;
@@ -1331,7 +1326,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   else memset(host.data() + o_mot, 0xFF, nblk * sizeof(de265hip_motion));       // ref_slot = -1 everywhere
 
   pt.mark("staging");
-  if (dec->dry) {                                    // FNV-1a over everything the device would receive (tools/exp/build_hash.py)
+  if (dec->dry && !getenv("DE265HIP_DRY_NO_HASH")) { // FNV-1a over everything the device would receive (tools/exp/build_hash.py)
     uint64_t hsh = 1469598103934665603ull;
     auto mix = [&](const void* ptr, size_t n) { const uint8_t* b = (const uint8_t*)ptr; for (size_t i = 0; i < n; i++) { hsh ^= b[i]; hsh *= 1099511628211ull; } };
     const size_t offs[] = { o_tus, o_cval, o_cpos, o_scal, o_mc, o_pcm, o_pcms, o_sl, o_ctb, o_tile, o_sao, o_flags, o_qp, o_mot, o_runs, o_rdeps, o_rtus, o_slots, o_l0, upload_bytes };

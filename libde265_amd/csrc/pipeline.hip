@@ -8,7 +8,10 @@
 // DPB slots its references were launched into).  Host-only code: no kernel lives here.
 #include "../../include/de265_hip.h"
 
+#include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <deque>
 #include <map>
 #include <mutex>
@@ -23,6 +26,7 @@ struct PipeJob {
   int slot = 0;
   de265hip_prepare_fn prepare = nullptr;
   void* user = nullptr;
+  const de265hip_picture_desc* desc = nullptr;  // de265hip_pipeline_submit_desc: a ready-made description instead of prepare()
   void* plane[3] = { nullptr, nullptr, nullptr };
   ptrdiff_t stride[3] = { 0, 0, 0 };
 };
@@ -38,9 +42,15 @@ struct de265hip_pipeline {
   std::deque<PipeJob> q;                        // submitted, not yet taken by a worker
   std::map<uint64_t, int> slot_of;              // launched, copy-out possibly still in flight: ticket -> slot
   std::map<uint64_t, int> failed;               // ticket -> error of prepare / build / run
+  struct Built { PipeJob job; de265hip_picture* pic; int rc; };
+  std::map<uint64_t, Built> ready;              // built (or failed), waiting for their turn to be launched
+  bool launching = false;                       // a worker is launching the ready pictures, in order
   uint64_t next_ticket = 0, next_launch = 0;    // tickets are handed out and launched in submission order
   int in_flight = 0;                            // queued or being built, not yet launched
   bool stop = false;
+  // DE265HIP_PIPE_TIMING=1: where the workers' time goes (seconds, summed over workers; printed when the pipeline is freed)
+  bool timing = false;
+  double t_idle = 0, t_build = 0, t_turn = 0, t_launch = 0, t_free = 0; long n_jobs = 0;
 };
 
 namespace {
@@ -49,34 +59,62 @@ void worker(de265hip_pipeline* p)
 {
   for (;;) {
     PipeJob j;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     {
       std::unique_lock<std::mutex> lk(p->mu);
       p->cv.wait(lk, [&] { return p->stop || !p->q.empty(); });
       if (p->q.empty()) return;
       j = p->q.front(); p->q.pop_front();
     }
+    const double t1 = now();
     // host stage, concurrently with the other workers' pictures
     de265hip_recorder* rec = nullptr;
     de265hip_picture* pic = nullptr;
-    int rc = j.prepare(j.user, &rec);
-    if (!rc && !rec) rc = DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
-    if (!rc) rc = de265hip_recorder_submit(p->dec, j.slot, rec, &pic);
-    if (rec) de265hip_recorder_free(rec);
-    // device stage, in submission order (also when the picture failed: the turn must pass on)
+    int rc = 0;
+    if (j.desc) rc = de265hip_picture_build(p->dec, j.slot, j.desc, &pic);
+    else {
+      rc = j.prepare(j.user, &rec);
+      if (!rc && !rec) rc = DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+      if (!rc) rc = de265hip_recorder_submit(p->dec, j.slot, rec, &pic);
+      if (rec) de265hip_recorder_free(rec);
+    }
+    const double t2 = now();
+    // Device stage, in submission order (also when the picture failed: the turn must pass on).  The worker leaves its picture
+    // with the built ones and goes back to work; whoever finds the next picture to be launched among them - and nobody
+    // launching - launches every picture whose turn has come.  (Workers that WAITED for their turn held one picture each:
+    // with an expensive picture at the head, every other worker idled behind it after building a single picture.)
+    double t_l = 0;
     {
       std::unique_lock<std::mutex> lk(p->mu);
-      p->cv.wait(lk, [&] { return p->next_launch == j.ticket; });
+      p->ready[j.ticket] = de265hip_pipeline::Built{ j, pic, rc };
+      if (!p->launching) {
+        p->launching = true;
+        for (auto it = p->ready.find(p->next_launch); it != p->ready.end(); it = p->ready.find(p->next_launch)) {
+          de265hip_pipeline::Built b = it->second;
+          p->ready.erase(it);
+          lk.unlock();
+          const double ta = now();
+          int r = b.rc;
+          if (!r) r = de265hip_picture_run(p->dec, b.pic, DE265HIP_STAGE_FINAL);
+          for (int c = 0; c < 3 && !r; c++)
+            if (b.job.plane[c]) r = de265hip_dpb_download_async(p->dec, b.job.slot, c, b.job.plane[c], b.job.stride[c]);
+          if (b.pic) de265hip_picture_free(b.pic);          // never waits (de265_hip.h LIFETIME)
+          t_l += now() - ta;
+          lk.lock();
+          if (r) p->failed[b.job.ticket] = r; else p->slot_of[b.job.ticket] = b.job.slot;
+          p->next_launch++; p->in_flight--;
+          p->cv.notify_all();
+        }
+        p->launching = false;
+      }
     }
-    if (!rc) rc = de265hip_picture_run(p->dec, pic, DE265HIP_STAGE_FINAL);
-    for (int c = 0; c < 3 && !rc; c++)
-      if (j.plane[c]) rc = de265hip_dpb_download_async(p->dec, j.slot, c, j.plane[c], j.stride[c]);
-    {
+    const double t3 = now(), t4 = t3;
+    if (p->timing) {
+      const double t5 = now();
       std::lock_guard<std::mutex> lk(p->mu);
-      if (rc) p->failed[j.ticket] = rc; else p->slot_of[j.ticket] = j.slot;
-      p->next_launch++; p->in_flight--;
+      p->t_idle += t1 - t0; p->t_build += t2 - t1; p->t_turn += t3 - t2 - t_l; p->t_launch += t_l; p->t_free += t5 - t4; p->n_jobs++;
     }
-    p->cv.notify_all();
-    if (pic) de265hip_picture_free(pic);          // never waits (de265_hip.h LIFETIME)
   }
 }
 
@@ -89,22 +127,25 @@ int de265hip_pipeline_new(de265hip_pipeline** out, de265hip_decoder* dec, int n_
   if (!out || !dec || n_workers < 1 || n_workers > 16) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   de265hip_pipeline* p = new (std::nothrow) de265hip_pipeline();
   if (!p) return DE265HIP_ERROR_OUT_OF_MEMORY;
-  p->dec = dec; p->n_workers = n_workers;
+  p->dec = dec; p->n_workers = n_workers; p->timing = getenv("DE265HIP_PIPE_TIMING") != nullptr;
   for (int i = 0; i < n_workers; i++) p->th.emplace_back(worker, p);
   *out = p;
   return 0;
 }
 
-int de265hip_pipeline_submit(de265hip_pipeline* p, int dst_slot, de265hip_prepare_fn prepare, void* user,
-                             void* const planes[3], const ptrdiff_t stride_bytes[3], uint64_t* ticket)
+static int pipeline_submit_job(de265hip_pipeline* p, int dst_slot, de265hip_prepare_fn prepare, void* user, const de265hip_picture_desc* desc,
+                               void* const planes[3], const ptrdiff_t stride_bytes[3], uint64_t* ticket)
 {
-  if (!p || !prepare || dst_slot < 0 || dst_slot >= DE265HIP_MAX_DPB_SLOTS) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  if (!p || (!prepare && !desc) || dst_slot < 0 || dst_slot >= DE265HIP_MAX_DPB_SLOTS) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   PipeJob j;
-  j.slot = dst_slot; j.prepare = prepare; j.user = user;
+  j.slot = dst_slot; j.prepare = prepare; j.user = user; j.desc = desc;
   for (int c = 0; c < 3; c++) { j.plane[c] = planes ? planes[c] : nullptr; j.stride[c] = (planes && stride_bytes) ? stride_bytes[c] : 0; }
   {
     std::unique_lock<std::mutex> lk(p->mu);
-    p->cv.wait(lk, [&] { return p->in_flight < p->n_workers + 2; });     // bounded: a few pictures between parser and device
+    // bounded: a few pictures between parser and device.  Twice the workers: pictures are launched in submission order, so
+    // while one worker is busy with an expensive picture (an all-intra picture's host stage takes 3-4x a B picture's) the
+    // others need that many cheaper ones behind it to stay busy
+    p->cv.wait(lk, [&] { return p->in_flight < 2 * p->n_workers + 2; });
     j.ticket = p->next_ticket++;
     p->in_flight++;
     p->q.push_back(j);
@@ -112,6 +153,20 @@ int de265hip_pipeline_submit(de265hip_pipeline* p, int dst_slot, de265hip_prepar
   p->cv.notify_all();
   if (ticket) *ticket = j.ticket;
   return 0;
+}
+
+int de265hip_pipeline_submit(de265hip_pipeline* p, int dst_slot, de265hip_prepare_fn prepare, void* user,
+                             void* const planes[3], const ptrdiff_t stride_bytes[3], uint64_t* ticket)
+{
+  if (!prepare) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  return pipeline_submit_job(p, dst_slot, prepare, user, nullptr, planes, stride_bytes, ticket);
+}
+
+int de265hip_pipeline_submit_desc(de265hip_pipeline* p, int dst_slot, const de265hip_picture_desc* desc,
+                                  void* const planes[3], const ptrdiff_t stride_bytes[3], uint64_t* ticket)
+{
+  if (!desc) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  return pipeline_submit_job(p, dst_slot, nullptr, nullptr, desc, planes, stride_bytes, ticket);
 }
 
 int de265hip_pipeline_wait(de265hip_pipeline* p, uint64_t ticket)
@@ -159,6 +214,10 @@ void de265hip_pipeline_free(de265hip_pipeline* p)
   { std::lock_guard<std::mutex> lk(p->mu); p->stop = true; }
   p->cv.notify_all();
   for (auto& t : p->th) t.join();
+  if (p->timing && p->n_jobs)
+    fprintf(stderr, "de265hip pipeline: %ld pictures, %d workers; ms per picture: idle %.2f build %.2f wait-for-turn %.2f launch %.2f free %.2f\n",
+            p->n_jobs, p->n_workers, 1e3 * p->t_idle / p->n_jobs, 1e3 * p->t_build / p->n_jobs, 1e3 * p->t_turn / p->n_jobs,
+            1e3 * p->t_launch / p->n_jobs, 1e3 * p->t_free / p->n_jobs);
   delete p;
 }
 

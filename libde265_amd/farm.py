@@ -128,3 +128,53 @@ def broadcast_reference_picture_dpb(dist, dec, slot, src, rank, group=None):
     for t in dpb_plane_tensors(dec, slot):
         dist.broadcast(t, src=src, group=group)
     torch.cuda.synchronize()
+
+
+def exchange_reference_picture_dpb(dist, dec, src_slot, dst_slot, src, dst, rank):
+    """send_reference_picture_dpb with different slots on the two sides: rank `src` sends its DPB slot `src_slot`, rank `dst`
+    receives into its slot `dst_slot` (already dpb_alloc'ed to the same geometry).  RCCL point-to-point on the planes where they live."""
+    import torch
+    if rank not in (src, dst):
+        return
+    dec.sync()                                       # sender: the picture is finished; receiver: nothing queued still uses the slot
+    for t in dpb_plane_tensors(dec, src_slot if rank == src else dst_slot):
+        if rank == src:
+            dist.send(t, dst=dst)
+        else:
+            dist.recv(t, src=src)
+    torch.cuda.synchronize()
+
+
+def exchange_reference_picture_host(dist, dec, src_slot, dst_slot, src, dst, rank, width, height, bit_depth):
+    """The same hand-off staged through host memory (gloo sends CPU tensors only): a REHEARSAL of the open-GOP step on boxes
+    without RCCL peers, not a transport anybody would deploy."""
+    import numpy as np
+    import torch
+    if rank == src:
+        for p in dec.download(src_slot, width, height, bit_depth):
+            dist.send(torch.from_numpy(np.ascontiguousarray(p).view(np.uint8).reshape(-1)), dst=dst)
+    elif rank == dst:
+        dt = np.uint16 if bit_depth > 8 else np.uint8
+        planes = []
+        for (h, w) in ((height, width), (height // 2, width // 2), (height // 2, width // 2)):
+            buf = torch.empty(h * w * np.dtype(dt).itemsize, dtype=torch.uint8)
+            dist.recv(buf, src=src)
+            planes.append(buf.numpy().view(dt).reshape(h, w))
+        dec.upload(dst_slot, planes)
+
+
+def check_handoff(dist, dec, src_slot, dst_slot, rank, world, width, height, bit_depth, device="cpu"):
+    """After the chain of hand-offs r -> r + 1: what rank r + 1 holds in `dst_slot` must be what rank r holds in `src_slot`
+    (CRC32 of the three planes, gathered over all ranks)."""
+    import zlib
+    import torch
+
+    def crc(slot):
+        v = 0
+        for p in dec.download(slot, width, height, bit_depth):
+            v = zlib.crc32(p.tobytes(), v)
+        return v
+    mine = torch.tensor([crc(src_slot), crc(dst_slot) if rank > 0 else 0], dtype=torch.int64, device=device)
+    allv = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(allv, mine)
+    return all(int(allv[r + 1][1]) == int(allv[r][0]) for r in range(world - 1))
