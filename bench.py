@@ -91,6 +91,21 @@ def launch_ranks(n, argv):
     return rc
 
 
+class _stdout_to_stderr:
+    """C-level stdout -> stderr for the duration (gloo prints a connection banner on stdout while the process group comes up;
+    rank 0's stdout carries the ONE JSON line and nothing else)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def product_pass(pipes, gops, stagger, steps=1):
     """`steps` steps through the product path: every picture of every stream is SUBMITTED to its decoder's pipeline
     (de265hip_pipeline_submit_desc: the library's own worker threads build it - host stage + pinned asynchronous upload -,
@@ -209,16 +224,42 @@ def main():
         import torch.distributed as dist
         from libde265_amd import farm
         if world > 1:
-            dist.init_process_group("gloo")
+            with _stdout_to_stderr():
+                dist.init_process_group("gloo")
+                dist.barrier()
         timer = farm.RankTimer(dist if world > 1 else None)
         timer.start()
         time.sleep(0.01 * (rank + 1))
         elapsed = timer.stop()
         units = farm.total_units(dist if world > 1 else None, args.gop * max(1, args.streams) * args.steps)
+        open_gop = None
+        if args.open_gop and world > 1:
+            # the open-GOP leg without a GPU: the same chain of hand-offs r -> r + 1 (farm.send_reference_picture) on CPU planes
+            import zlib
+            import torch
+            g = torch.Generator().manual_seed(1234 + rank)
+            mine = [torch.randint(0, 255, (n,), dtype=torch.uint8, generator=g) for n in (4096, 1024, 1024)]
+            got = [torch.zeros_like(t) for t in mine]
+            tm = farm.RankTimer(dist)
+            tm.start()
+            for r in range(world - 1):
+                farm.send_reference_picture(dist, mine if rank == r else got, r, r + 1, rank)
+            t_x = tm.stop()
+
+            def crc(planes):
+                v = 0
+                for t in planes:
+                    v = zlib.crc32(t.numpy().tobytes(), v)
+                return v
+            me = torch.tensor([crc(mine), crc(got)], dtype=torch.int64)
+            allv = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(allv, me)
+            open_gop = {"handoffs": world - 1, "ms_per_handoff": round(1e3 * t_x / (world - 1), 3),
+                        "checksum_ok": all(int(allv[r + 1][1]) == int(allv[r][0]) for r in range(world - 1))}
         if rank == 0:
             print(json.dumps({"metric": "decoded frames/sec (4K Main10)", "value": None, "unit": "frames/s", "n_gpus": world,
                               "steps": args.steps, "warmup": args.warmup, "dry_run": True, "units_all_ranks": units,
-                              "ms_per_step": round(1e3 * elapsed / max(1, args.steps), 3)}))
+                              "open_gop": open_gop, "ms_per_step": round(1e3 * elapsed / max(1, args.steps), 3)}))
         if world > 1:
             dist.destroy_process_group()
         return
@@ -235,10 +276,12 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend)
+        with _stdout_to_stderr():
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(args.backend)
+                dist.barrier()              # (gloo connects lazily: its banner comes with the first collective)
     red_dev = "cuda" if args.backend == "nccl" else "cpu"
 
     W, H, BD, GOP, S = args.width, args.height, args.bit_depth, args.gop, max(1, args.streams)

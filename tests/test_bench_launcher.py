@@ -21,10 +21,10 @@ def test_gpus_n_starts_n_ranks_and_prints_one_line():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--dry-run"], env=_env(),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]        # (gloo itself chats on stdout)
-    assert len(lines) == 1, r.stdout
+    lines = r.stdout.splitlines()              # rank 0's stdout carries the one JSON line and NOTHING else (gloo's banner goes to stderr)
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["dry_run"] is True
+    assert out["n_gpus"] == 2 and out["dry_run"] is True and out["open_gop"] is None
     assert out["units_all_ranks"] == 2 * 16 * 3 * 3          # both ranks' pictures: world x GOP x streams x steps
     assert out["ms_per_step"] >= 20.0 / 3 - 1e-6              # MAX over ranks: rank 1 slept 20 ms
 
@@ -49,3 +49,13 @@ def test_a_failing_rank_fails_the_launch():
     e["DE265HIP_BENCH_FAIL_RANK"] = "1"
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run"], env=e, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
+
+
+def test_open_gop_leg_hands_the_last_picture_to_the_next_rank():
+    """--open-gop: after the timed region rank r hands a reference picture to rank r + 1; rehearsed with
+    three gloo ranks on CPU planes, every receiver must hold what its sender sent."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "3", "--steps", "2", "--dry-run", "--open-gop"], env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.splitlines()[-1])
+    assert out["n_gpus"] == 3 and out["open_gop"]["handoffs"] == 2 and out["open_gop"]["checksum_ok"] is True
