@@ -27,8 +27,12 @@
  *    wants to call single DSP functions.
  *
  * Units: all positions/sizes of TUs are in samples of their own component,
- * PUs/PCM/metadata in luma samples.  Only ChromaArrayType==1 (4:2:0) is
- * supported (Main / Main10); others return DE265_ERROR_NOT_IMPLEMENTED_YET.
+ * PUs/PCM/metadata in luma samples.  ChromaArrayType 1 (4:2:0), 2 (4:2:2) and 3 (4:4:4) are supported, with the
+ * range-extension sample tools the reference implements: cross-component prediction, implicit and
+ * explicit RDPCM, transform-skip rotation, transform skip beyond 4x4, intra smoothing switched off, chroma smoothing
+ * in 4:4:4.  Monochrome (0) and extended_precision_processing return DE265_ERROR_NOT_IMPLEMENTED_YET (the reference's
+ * inter path reads chroma planes a monochrome picture does not have, motion.cc:302-305, and its transform path hard-codes
+ * extended_precision_processing_flag = 0, transform.cc:535).
  */
 #ifndef DE265_HIP_H
 #define DE265_HIP_H
@@ -64,7 +68,7 @@ typedef struct de265hip_pic_params {
   int32_t width, height;              /* pic_{width,height}_in_luma_samples */
   int32_t bit_depth_luma;             /* BitDepth_Y */
   int32_t bit_depth_chroma;           /* BitDepth_C */
-  int32_t chroma_format_idc;          /* must be 1 */
+  int32_t chroma_format_idc;          /* 1, 2 or 3 (ChromaArrayType; separate_colour_plane is not supported) */
   int32_t log2_ctb_size;              /* Log2CtbSizeY 4..6 */
   int32_t log2_min_cb_size;           /* Log2MinCbSizeY >=3 */
   int32_t log2_min_tb_size;           /* Log2MinTrafoSize 2..5 */
@@ -84,6 +88,13 @@ typedef struct de265hip_pic_params {
   uint16_t row_bd[24];                /* rowBd[0..num_tile_rows],    CTB units */
   int32_t disable_deblocking;         /* DE265_DECODER_PARAM_DISABLE_DEBLOCKING */
   int32_t disable_sao;                /* DE265_DECODER_PARAM_DISABLE_SAO */
+  /* range extensions (sps.h:66-84 sps_range_extension, pps.h pps_range_extension): all 0 for Main / Main10 */
+  int32_t implicit_rdpcm_enabled_flag;            /* slice.cc:3456-3461, intrapred.cc:1102-1104 */
+  int32_t transform_skip_rotation_enabled_flag;   /* transform.cc:393-395 */
+  int32_t intra_smoothing_disabled_flag;          /* intrapred.cc:1085 */
+  int32_t cross_component_prediction_enabled_flag;/* pps; transform.cc:592-598: residuals go through the int32 transform forms */
+  int32_t extended_precision_processing_flag;     /* must be 0 */
+  int32_t high_precision_offsets_enabled_flag;    /* WpOffsetBdShift = 0 instead of BitDepth - 8 (sps.cc:554-563) */
 } de265hip_pic_params;
 
 /* Size of the flat scaling-factor blob: ScalingFactor_Size0[6][4][4],
@@ -126,6 +137,8 @@ typedef struct de265hip_ctb_info {
 #define DE265HIP_TU_CBF        0x02   /* residual present */
 #define DE265HIP_TU_TSKIP      0x04   /* transform_skip_flag[cIdx] */
 #define DE265HIP_TU_BYPASS     0x08   /* cu_transquant_bypass_flag */
+#define DE265HIP_TU_EXPLICIT_RDPCM      0x10   /* explicit_rdpcm_flag (inter CUs, transform skip / bypass TUs; slice.cc:3464-3468) */
+#define DE265HIP_TU_EXPLICIT_RDPCM_VERT 0x20   /* explicit_rdpcm_dir */
 
 /* One transform unit of one colour component, in decode order
  * (arguments of decode_TU, slice.cc:3424, plus the thread_context values it
@@ -137,7 +150,9 @@ typedef struct de265hip_tu {
   uint8_t  flags;                     /* DE265HIP_TU_* */
   uint8_t  intra_mode;                /* 0..34 (only if INTRA) */
   int8_t   qp;                        /* qP{Y,Cb,Cr}Prime (transform.cc:362-368) */
-  uint8_t  pad;
+  int8_t   res_scale_val;             /* ResScaleVal of cross-component prediction (chroma TUs of 4:4:4, slice.cc:3522-3541): 0, +-1, +-2, +-4, +-8.
+                                         A chroma TU with res_scale_val != 0 is recorded even without CBF; it follows the luma TU of
+                                         the same position and size in the TU array (slice.cc:3699-3750) */
   uint16_t n_coeff;                   /* nCoeff[cIdx] */
   uint32_t coeff_offset;              /* first entry in coeff_val/coeff_pos */
 } de265hip_tu;
@@ -155,7 +170,7 @@ typedef struct de265hip_pu {
 } de265hip_pu;
 
 /* One PCM coding unit (slice.cc:4143-4183); samples already << (bitDepth-pcmBits),
- * stored Y (size^2) then Cb, Cr ((size/2)^2 each) as uint16. */
+ * stored Y (size^2) then Cb, Cr ((size/SubWidthC) x (size/SubHeightC) each) as uint16. */
 typedef struct de265hip_pcm {
   uint16_t x0, y0;
   uint8_t  log2_cb_size;
@@ -241,6 +256,12 @@ void de265hip_decoder_free(de265hip_decoder*);
 /* Allocate (or re-use) DPB slot `slot` for a picture of this geometry. */
 int  de265hip_dpb_alloc(de265hip_decoder*, int slot, int width, int height,
                         int bit_depth_luma, int bit_depth_chroma);
+/* The same for any chroma format (chroma_format_idc 1, 2, 3); de265hip_dpb_alloc is the 4:2:0 form.  A picture is always
+ * reconstructed with the format of ITS de265hip_pic_params (de265hip_picture_build / _run re-allocate the slot if need be). */
+int  de265hip_dpb_alloc_ex(de265hip_decoder*, int slot, int width, int height,
+                           int bit_depth_luma, int bit_depth_chroma, int chroma_format_idc);
+/* chroma_format_idc of the picture a slot holds; -1 for an unallocated slot */
+int  de265hip_dpb_chroma_format(de265hip_decoder*, int slot);
 /* Copy host planes into / out of a DPB slot.  stride_bytes as in
  * de265_get_image_plane (de265.h:173-174).  Sample type is uint8_t when the
  * component's bit depth is <=8, else uint16_t. */
@@ -308,7 +329,7 @@ void de265hip_recorder_free(de265hip_recorder*);
 /* TU in decode order; vals/pos hold tu->n_coeff entries (coeff_offset is filled in here) */
 int  de265hip_record_tu(de265hip_recorder*, const de265hip_tu* tu, const int16_t* vals, const uint16_t* pos);
 int  de265hip_record_pu(de265hip_recorder*, const de265hip_pu* pu);
-/* samples: Y (size^2) then Cb, Cr ((size/2)^2 each), already << (bitDepth - pcmBits) */
+/* samples: Y (size^2) then Cb, Cr ((size/SubWidthC) x (size/SubHeightC) each), already << (bitDepth - pcmBits) */
 int  de265hip_record_pcm(de265hip_recorder*, int x0, int y0, int log2_cb_size, const uint16_t* samples);
 int  de265hip_record_slice(de265hip_recorder*, const de265hip_slice_params* slice);      /* returns its index via n_slices-1 */
 int  de265hip_record_ctb(de265hip_recorder*, int ctb_addr_rs, const de265hip_ctb_info* info);

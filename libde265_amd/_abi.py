@@ -18,6 +18,7 @@ ERROR_NOT_IMPLEMENTED = 502
 STAGE_PREFILTER, STAGE_DEBLOCKED, STAGE_FINAL = 0, 1, 2
 
 TU_INTRA, TU_CBF, TU_TSKIP, TU_BYPASS = 1, 2, 4, 8
+TU_EXPLICIT_RDPCM, TU_EXPLICIT_RDPCM_VERT = 0x10, 0x20
 BLK_INTRA, BLK_NONZERO, BLK_PCM, BLK_BYPASS = 1, 2, 4, 8
 BLK_EDGE_TU_V, BLK_EDGE_TU_H, BLK_EDGE_PB_V, BLK_EDGE_PB_H = 0x10, 0x20, 0x40, 0x80
 
@@ -42,6 +43,9 @@ class PicParams(C.Structure):
         ("num_tile_columns", C.c_int32), ("num_tile_rows", C.c_int32),
         ("col_bd", C.c_uint16 * 24), ("row_bd", C.c_uint16 * 24),
         ("disable_deblocking", C.c_int32), ("disable_sao", C.c_int32),
+        ("implicit_rdpcm_enabled_flag", C.c_int32), ("transform_skip_rotation_enabled_flag", C.c_int32),
+        ("intra_smoothing_disabled_flag", C.c_int32), ("cross_component_prediction_enabled_flag", C.c_int32),
+        ("extended_precision_processing_flag", C.c_int32), ("high_precision_offsets_enabled_flag", C.c_int32),
     ]
 
 
@@ -74,7 +78,7 @@ class TU(C.Structure):
     _fields_ = [
         ("x0", C.c_uint16), ("y0", C.c_uint16),
         ("log2_size", C.c_uint8), ("c_idx", C.c_uint8), ("flags", C.c_uint8),
-        ("intra_mode", C.c_uint8), ("qp", C.c_int8), ("pad", C.c_uint8),
+        ("intra_mode", C.c_uint8), ("qp", C.c_int8), ("res_scale_val", C.c_int8),
         ("n_coeff", C.c_uint16), ("coeff_offset", C.c_uint32),
     ]
 

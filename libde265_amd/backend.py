@@ -18,7 +18,7 @@ SO_PATH = os.environ.get("DE265HIP_SO") or os.path.join(_HERE, "libde265_hip.so"
 EXPORTS = [
     "de265hip_version", "de265hip_device_count",
     "de265hip_decoder_new", "de265hip_decoder_free",
-    "de265hip_dpb_alloc", "de265hip_dpb_upload", "de265hip_dpb_download", "de265hip_dpb_plane", "de265hip_dpb_info",
+    "de265hip_dpb_alloc", "de265hip_dpb_alloc_ex", "de265hip_dpb_chroma_format", "de265hip_dpb_upload", "de265hip_dpb_download", "de265hip_dpb_plane", "de265hip_dpb_info",
     "de265hip_dpb_copy", "de265hip_dpb_download_async", "de265hip_dpb_wait", "de265hip_host_alloc", "de265hip_host_free",
     "de265hip_pipeline_new", "de265hip_pipeline_submit", "de265hip_pipeline_submit_desc", "de265hip_pipeline_wait", "de265hip_pipeline_drain", "de265hip_pipeline_free",
     "de265hip_debug_build_host_only", "de265hip_debug_last_build_hash",
@@ -62,6 +62,8 @@ def lib():
     L.de265hip_decoder_free.argtypes = [vp]
     L.de265hip_decoder_free.restype = None
     L.de265hip_dpb_alloc.argtypes = [vp, i32, i32, i32, i32, i32]
+    L.de265hip_dpb_alloc_ex.argtypes = [vp, i32, i32, i32, i32, i32, i32]
+    L.de265hip_dpb_chroma_format.argtypes = [vp, i32]
     L.de265hip_dpb_upload.argtypes = [vp, i32, i32, vp, C.c_ssize_t]
     L.de265hip_dpb_download.argtypes = [vp, i32, i32, vp, C.c_ssize_t]
     L.de265hip_dpb_plane.argtypes = [vp, i32, i32, pp(vp), pp(C.c_ssize_t)]
@@ -268,9 +270,13 @@ class Decoder:
             pass
 
     # --- DPB ---
-    def dpb_alloc(self, slot, width, height, bit_depth_luma, bit_depth_chroma=None):
+    def dpb_alloc(self, slot, width, height, bit_depth_luma, bit_depth_chroma=None, chroma_format=1):
         bdc = bit_depth_luma if bit_depth_chroma is None else bit_depth_chroma
-        _chk(lib().de265hip_dpb_alloc(self._h, slot, width, height, bit_depth_luma, bdc), "dpb_alloc")
+        _chk(lib().de265hip_dpb_alloc_ex(self._h, slot, width, height, bit_depth_luma, bdc, chroma_format), "dpb_alloc")
+
+    def _chroma_dims(self, slot, w, h):
+        cf = lib().de265hip_dpb_chroma_format(self._h, slot)
+        return (w if cf == 3 else w // 2, h // 2 if cf == 1 else h)
 
     def dpb_info(self, slot):
         """(width, height, bit_depth_luma, bit_depth_chroma) of the picture the slot holds."""
@@ -280,8 +286,9 @@ class Decoder:
 
     def _check_planes(self, slot, shapes_dtypes, what):
         w, h, by, bc = self.dpb_info(slot)
+        cw, ch = self._chroma_dims(slot, w, h)
         for c, (shape, dt) in enumerate(shapes_dtypes):
-            want = (h, w) if c == 0 else (h // 2, w // 2)
+            want = (h, w) if c == 0 else (ch, cw)
             wdt = np.uint16 if (by if c == 0 else bc) > 8 else np.uint8
             if tuple(shape) != want or np.dtype(dt) != np.dtype(wdt):
                 raise ValueError("%s: plane %d is %s %s, DPB slot %d holds %s %s" % (what, c, tuple(shape), np.dtype(dt), slot, want, np.dtype(wdt)))
@@ -295,9 +302,10 @@ class Decoder:
 
     def download(self, slot, width, height, bit_depth):
         dt = np.uint16 if bit_depth > 8 else np.uint8
-        self._check_planes(slot, [((height, width), dt), ((height // 2, width // 2), dt), ((height // 2, width // 2), dt)], "download")
+        cw, ch = self._chroma_dims(slot, width, height)
+        self._check_planes(slot, [((height, width), dt), ((ch, cw), dt), ((ch, cw), dt)], "download")
         out = []
-        for c, (w, h) in enumerate([(width, height), (width // 2, height // 2), (width // 2, height // 2)]):
+        for c, (w, h) in enumerate([(width, height), (cw, ch), (cw, ch)]):
             a = np.empty((h, w), dt)
             _chk(lib().de265hip_dpb_download(self._h, slot, c, a.ctypes.data, a.strides[0]), "dpb_download")
             out.append(a)
@@ -307,7 +315,8 @@ class Decoder:
         """enqueue the copy-out of a decoded picture into pinned planes without waiting; returns a handle whose
         wait() blocks until the planes have landed and hands them out (numpy views of the pinned memory, valid until free())."""
         dt = np.uint16 if bit_depth > 8 else np.uint8
-        shapes = [(height, width), (height // 2, width // 2), (height // 2, width // 2)]
+        cw, ch = self._chroma_dims(slot, width, height)
+        shapes = [(height, width), (ch, cw), (ch, cw)]
         self._check_planes(slot, [(sh, dt) for sh in shapes], "download_async")
         return _PendingDownload(self, slot, shapes, dt)
 

@@ -31,7 +31,17 @@ struct PicDev {
   int32_t scaling_list;
   int32_t dbg;                      // DE265HIP_DEBUG ablation bits (timing only)
   int32_t has_exempt;               // some 4x4 unit is pcm (with pcm_loop_filter_disable) or transquant-bypass
+  // chroma format and range-extension tools (all "4:2:0, off" for Main / Main10)
+  int32_t chroma_format;            // 1, 2, 3
+  int32_t csw, csh;                 // log2 SubWidthC / SubHeightC
+  int32_t cwidth, cheight;          // chroma plane size
+  int32_t smooth_luma, smooth_chroma;   // intra neighbour smoothing applies (intrapred.cc:1085-1089)
+  int32_t implicit_rdpcm;           // sps flag: with cu_transquant_bypass it switches the mode 10 / 26 edge filters off (intrapred.cc:1102)
+  int32_t xcc_enabled;              // pps cross_component_prediction_enabled_flag
+  int32_t wp_shift_luma, wp_shift_chroma;   // WpOffsetBdShift
 };
+
+__device__ __forceinline__ bool intra_smooth_on(const PicDev& P, int c_idx) { return c_idx ? P.smooth_chroma != 0 : P.smooth_luma != 0; }
 
 // TU task: de265hip_tu plus the host-derived neighbour availability.
 // avail bit u (scan order of intrapred.cc:577-688): u < 2nT/4 left column
@@ -53,7 +63,17 @@ static_assert(sizeof(TuTask) == 32, "TuTask layout");
 // internal TuTask flag: compute the residual only (into the residual buffer), no prediction, no picture access
 #define D265_TU_RESID_ONLY 0x80
 
-// MC task: a <=16x16 luma tile of one PU (plus its two 4:2:0 chroma tiles).
+// Range-extension residual tasks (level-0 tasks only: TuTask::pad3 and friends are free there).  A TU takes the generic
+// k_resid_rext path when any of these applies; everything else stays on the tuned residual kernels.
+#define D265_RX_RDPCM_H   0x01      // residual DPCM, horizontal / vertical (fallback-dct.cc:160-213)
+#define D265_RX_RDPCM_V   0x02
+#define D265_RX_ROTATE    0x04      // rotate_coefficients (fallback-dct.cc:251-257)
+#define D265_RX_XCC       0x08      // cross-component prediction: TuTask::angle = ResScaleVal, TuTask::avail = the luma TU's
+                                    // coeff_offset | n_coeff << 32 | (uint8)qp << 48 | flags << 56 (transform.cc:235-251)
+#define D265_RX_LUMA_ROT  0x10      // ... and the luma TU's coefficients are rotated
+#define D265_RX_LUMA_RDPCM_SHIFT 5  // ... bits 5-6: the luma TU's RDPCM mode
+
+// MC task: a <=16x16 luma tile of one PU (plus its two chroma tiles).
 struct __attribute__((aligned(4))) McTask {   // (4-byte aligned: the kernel fetches its task with scalar loads)
   uint16_t x, y;          // luma position of the tile
   uint8_t  w, h;          // luma size (multiples of 4, <=16)

@@ -32,8 +32,10 @@ namespace {
 
 struct Slot {
   PlaneRef pl[3] = {};
-  int w = 0, h = 0, bdY = 0, bdC = 0;
+  int w = 0, h = 0, bdY = 0, bdC = 0, cf = 1;      // cf: chroma_format_idc (1, 2, 3)
   bool valid = false;
+  int cw() const { return cf == 3 ? w : w / 2; }      // chroma plane size (SubWidthC / SubHeightC, sps.cc:540-552)
+  int ch() const { return cf == 1 ? h / 2 : h; }
   // de265hip_dpb_download_async: recorded on the output stream behind the slot's latest copy-out; whoever writes the
   // slot next (a new picture, an upload) or frees it waits for it.  dl_seq counts the copy-outs (dpb_wait compares it).
   hipEvent_t dl_done = nullptr;
@@ -116,6 +118,7 @@ struct de265hip_picture {
   TuTask* d_run_tus = nullptr;
   int n_l0_size[4] = { 0, 0, 0, 0 };          // TU count per size in d_l0 (sorted 32,16,8,4)
   TuTask* d_l0 = nullptr; int n_l0 = 0;       // run mode: inter residual TUs + residual-only copies of intra TUs
+  TuTask* d_l0_rext = nullptr; int n_l0_rext = 0;   // ... those with a range-extension tool (k_resid_rext)
   int16_t* d_resid = nullptr;                 // precomputed residual blocks of intra TUs
   int n_runs = 0, n_batches = 0, n_workers = 0, run_box = 64, ticket_batch = 1; size_t sync_bytes = 0;
   int n_front = 0;                            // runs [0, n_front): micro runs without producers, reconstructed by k_intra_front ahead of k_run
@@ -143,18 +146,18 @@ int free_slot(Slot& s)
   return 0;
 }
 
-int alloc_slot(Slot& s, int w, int h, int bdY, int bdC)
+int alloc_slot(Slot& s, int w, int h, int bdY, int bdC, int cf = 1)
 {
-  if (s.valid && s.w == w && s.h == h && s.bdY == bdY && s.bdC == bdC) return 0;
+  if (s.valid && s.w == w && s.h == h && s.bdY == bdY && s.bdC == bdC && s.cf == cf) return 0;
   free_slot(s);
   for (int c = 0; c < 3; c++) {
-    int cw = c ? w / 2 : w, ch = c ? h / 2 : h;
+    int cw = c ? (cf == 3 ? w : w / 2) : w, ch = c ? (cf == 1 ? h / 2 : h) : h;
     int stride = (cw + 63) & ~63;                         // samples; rows start 128/64-byte aligned
     size_t bytes = (size_t)stride * ch * px_bytes(c ? bdC : bdY) + 256;
     HIPCHK(hipMalloc(&s.pl[c].ptr, bytes), DE265HIP_ERROR_OUT_OF_MEMORY);
     s.pl[c].stride = stride;
   }
-  s.w = w; s.h = h; s.bdY = bdY; s.bdC = bdC; s.valid = true;
+  s.w = w; s.h = h; s.bdY = bdY; s.bdC = bdC; s.cf = cf; s.valid = true;
   return 0;
 }
 
@@ -285,6 +288,8 @@ struct BuildScratch {
   int32_t epoch_base = 0;
   std::vector<uint32_t> ctb_group;
   std::vector<TuTask> it; std::vector<int32_t> it_next; std::vector<uint16_t> it_llev;     // intra TUs in decode order
+  std::vector<uint8_t> it_rx; std::vector<int8_t> it_rsv; std::vector<uint64_t> it_luma;                                // ... their range-extension bits (D265_RX_*) and, for cross-component prediction, the luma TU
+  std::vector<TuTask> l0_rext;                                                              // level-0 tasks of k_resid_rext
   std::vector<RunB> rb;
   std::vector<int32_t> dep_val, dep_next;
   std::vector<int> level_hist;
@@ -463,13 +468,17 @@ void de265hip_decoder_free(de265hip_decoder* d)
 }
 
 int de265hip_dpb_alloc(de265hip_decoder* d, int slot, int width, int height, int bdY, int bdC)
+{ return de265hip_dpb_alloc_ex(d, slot, width, height, bdY, bdC, 1); }
+
+int de265hip_dpb_alloc_ex(de265hip_decoder* d, int slot, int width, int height, int bdY, int bdC, int chroma_format_idc)
 {
   if (!d || slot < 0 || slot >= DE265HIP_MAX_DPB_SLOTS) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  if (chroma_format_idc < 1 || chroma_format_idc > 3) return DE265HIP_ERROR_NOT_IMPLEMENTED;
   if (width <= 0 || height <= 0 || (width & 7) || (height & 7) || bdY < 8 || bdY > 12 || bdC < 8 || bdC > 12)
     return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   if ((bdY > 8) != (bdC > 8)) return DE265HIP_ERROR_NOT_IMPLEMENTED;
   std::lock_guard<std::mutex> lk(d->mu);          // (run_picture snapshots the slot table under the same lock)
-  return alloc_slot(d->slots[slot], width, height, bdY, bdC);
+  return alloc_slot(d->slots[slot], width, height, bdY, bdC, chroma_format_idc);
 }
 
 static int plane_geom(de265hip_decoder* d, int slot, int c, Slot** s, int* w, int* h, size_t* bpp)
@@ -477,7 +486,7 @@ static int plane_geom(de265hip_decoder* d, int slot, int c, Slot** s, int* w, in
   if (!d || slot < 0 || slot >= DE265HIP_MAX_DPB_SLOTS || c < 0 || c > 2 || !d->slots[slot].valid)
     return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   *s = &d->slots[slot];
-  *w = c ? (*s)->w / 2 : (*s)->w; *h = c ? (*s)->h / 2 : (*s)->h;
+  *w = c ? (*s)->cw() : (*s)->w; *h = c ? (*s)->ch() : (*s)->h;
   *bpp = px_bytes(c ? (*s)->bdC : (*s)->bdY);
   return 0;
 }
@@ -562,6 +571,12 @@ int de265hip_dpb_info(de265hip_decoder* d, int slot, int* width, int* height, in
   return 0;
 }
 
+int de265hip_dpb_chroma_format(de265hip_decoder* d, int slot)
+{
+  if (!d || slot < 0 || slot >= DE265HIP_MAX_DPB_SLOTS || !d->slots[slot].valid) return -1;
+  return d->slots[slot].cf;
+}
+
 int de265hip_dpb_plane(de265hip_decoder* d, int slot, int c, void** dev_ptr, ptrdiff_t* stride_bytes)
 {
   Slot* s; int w, h; size_t bpp;
@@ -582,7 +597,7 @@ int de265hip_dpb_copy(de265hip_decoder* sd, int ss, de265hip_decoder* dd, int ds
     int prev = 0;
     (void)hipGetDevice(&prev);
     if (hipSetDevice(dd->device) != hipSuccess) return DE265HIP_ERROR_DECODING;
-    int rc = alloc_slot(dd->slots[ds], S.w, S.h, S.bdY, S.bdC);
+    int rc = alloc_slot(dd->slots[ds], S.w, S.h, S.bdY, S.bdC, S.cf);
     (void)hipSetDevice(prev);
     if (rc) return rc;
   }
@@ -601,7 +616,7 @@ int de265hip_dpb_copy(de265hip_decoder* sd, int ss, de265hip_decoder* dd, int ds
     if (!rc && D.dl_done && D.dl_waited != D.dl_seq && hipStreamWaitEvent(sd->stream, D.dl_done, 0) != hipSuccess) rc = DE265HIP_ERROR_DECODING;
   }
   for (int c = 0; c < 3 && !rc; c++) {
-    const int h = c ? S.h / 2 : S.h;
+    const int h = c ? S.ch() : S.h;
     const size_t bytes = (size_t)S.pl[c].stride * h * px_bytes(c ? S.bdC : S.bdY);      // same pitch on both sides (alloc_slot)
     hipError_t e = sd->device == dd->device
       ? hipMemcpyAsync(D.pl[c].ptr, S.pl[c].ptr, bytes, hipMemcpyDeviceToDevice, sd->stream)
@@ -634,7 +649,10 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   if (!dec || !d || !out) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   *out = nullptr;
   const de265hip_pic_params& p = d->params;
-  if (p.chroma_format_idc != 1) return DE265HIP_ERROR_NOT_IMPLEMENTED;
+  // monochrome: the reference's inter path reads chroma planes a monochrome picture does not have (motion.cc:302-305);
+  // extended precision: its transform path hard-codes extended_precision_processing_flag = 0 (transform.cc:535)
+  if (p.chroma_format_idc < 1 || p.chroma_format_idc > 3 || p.extended_precision_processing_flag) return DE265HIP_ERROR_NOT_IMPLEMENTED;
+  if (p.cross_component_prediction_enabled_flag && p.chroma_format_idc != 3) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   if ((p.bit_depth_luma > 8) != (p.bit_depth_chroma > 8)) return DE265HIP_ERROR_NOT_IMPLEMENTED;
   if (p.bit_depth_luma < 8 || p.bit_depth_luma > 12 || p.bit_depth_chroma < 8 || p.bit_depth_chroma > 12 ||
       p.width <= 0 || p.height <= 0 || (p.width & 7) || (p.height & 7) ||
@@ -656,8 +674,8 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     std::lock_guard<std::mutex> lk(dec->mu);
     bool pending = false;
     for (const de265hip_picture* q : dec->live) pending = pending || q->n_launched == 0;
-    if (!dec->slots[dst_slot].valid || !pending) rc = alloc_slot(dec->slots[dst_slot], p.width, p.height, p.bit_depth_luma, p.bit_depth_chroma);
-    if (!rc && (!dec->spare.valid || !pending)) rc = alloc_slot(dec->spare, p.width, p.height, p.bit_depth_luma, p.bit_depth_chroma);
+    if (!dec->slots[dst_slot].valid || !pending) rc = alloc_slot(dec->slots[dst_slot], p.width, p.height, p.bit_depth_luma, p.bit_depth_chroma, p.chroma_format_idc);
+    if (!rc && (!dec->spare.valid || !pending)) rc = alloc_slot(dec->spare, p.width, p.height, p.bit_depth_luma, p.bit_depth_chroma, p.chroma_format_idc);
   }
   if (rc) return rc;
 
@@ -692,6 +710,15 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   P.weighted_pred = p.weighted_pred_flag; P.weighted_bipred = p.weighted_bipred_flag;
   P.cb_qp_offset = p.pic_cb_qp_offset; P.cr_qp_offset = p.pic_cr_qp_offset;
   P.lf_across_tiles = p.loop_filter_across_tiles_enabled_flag; P.scaling_list = p.scaling_list_enable_flag;
+  const int cf = p.chroma_format_idc, subw = cf == 3 ? 1 : 2, subh = cf == 1 ? 2 : 1;      // SubWidthC, SubHeightC
+  const int cwid = p.width / subw, chei = p.height / subh;
+  P.chroma_format = cf; P.csw = subw - 1; P.csh = subh - 1; P.cwidth = cwid; P.cheight = chei;
+  P.smooth_luma = !p.intra_smoothing_disabled_flag; P.smooth_chroma = !p.intra_smoothing_disabled_flag && cf == 3;
+  P.implicit_rdpcm = p.implicit_rdpcm_enabled_flag; P.xcc_enabled = p.cross_component_prediction_enabled_flag;
+  P.wp_shift_luma = p.high_precision_offsets_enabled_flag ? 0 : p.bit_depth_luma - 8;
+  P.wp_shift_chroma = p.high_precision_offsets_enabled_flag ? 0 : p.bit_depth_chroma - 8;
+  const bool rext_tools = p.implicit_rdpcm_enabled_flag || p.transform_skip_rotation_enabled_flag || p.cross_component_prediction_enabled_flag;
+  if (dec->intra_levels && rext_tools) { delete pic; return DE265HIP_ERROR_NOT_IMPLEMENTED; }   // (the level-launch schedule knows the Main tools only)
 
   pt.mark("geometry");
   // dependencies between intra TUs from the units each mode reads (DE265HIP_NO_MODE_DEPS: from every available unit)
@@ -701,8 +728,8 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   // ---- TU scan: tasks, intra availability, dependency levels, runs.  One linear pass over the TU records on flat,
   // reused arrays (BuildScratch): no allocation and no page fault in the steady state.
   BuildScratch& SC = g_scratch;
-  const int map_w[3] = { g.w4, (p.width / 2 + 3) / 4, (p.width / 2 + 3) / 4 };
-  const int map_h[3] = { g.h4, (p.height / 2 + 3) / 4, (p.height / 2 + 3) / 4 };
+  const int map_w[3] = { g.w4, (cwid + 3) / 4, (cwid + 3) / 4 };
+  const int map_h[3] = { g.h4, (chei + 3) / 4, (chei + 3) / 4 };
   // The cell maps are not cleared per picture (6 MB at 4K): a cell counts only if its run id is of THIS build - ids start at
   // an epoch base that grows from build to build (cleared when the ids would wrap or the geometry changes).
   {
@@ -734,10 +761,33 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   const bool cip = p.constrained_intra_pred_flag != 0;
   // pre-pass: how many level-0 tasks of each size there will be - inter TUs with residual, then the residual-only copies of the
   // intra TUs: [32x32 | 16x16 | 8x8 | 4x4], inside a size the inter TUs first - so that both are written to their final place
+  // Range-extension tools of a TU (D265_RX_* bits; 0 for every TU of a Main / Main10 picture): such a TU's residual is
+  // computed by k_resid_rext instead of the tuned residual kernels.
+  //  RDPCM: implicit for intra TUs (mode 10 / 26 with transform skip or bypass, slice.cc:3456-3461), explicit for inter TUs;
+  //  rotation: 4x4 transform-skip / bypass TUs of intra CUs - the reference looks the CU up at the TU's position in samples
+  //    of ITS COMPONENT through an accessor that takes luma samples (transform.cc:393-395): reproduced;
+  //  cross-component prediction: res_scale_val of a chroma TU;  transform skip beyond 8x8 (log2_max_transform_skip_block_size).
+  auto rx_bits = [&](const de265hip_tu& tu) -> int {
+    if (!(tu.flags & (DE265HIP_TU_TSKIP | DE265HIP_TU_BYPASS | DE265HIP_TU_EXPLICIT_RDPCM)) && !tu.res_scale_val) return 0;
+    const bool cbf = (tu.flags & DE265HIP_TU_CBF) && tu.n_coeff;
+    const bool ts_or_bp = tu.flags & (DE265HIP_TU_TSKIP | DE265HIP_TU_BYPASS);
+    int rx = 0;
+    if (cbf && ts_or_bp) {
+      if (tu.flags & DE265HIP_TU_INTRA) {
+        if (p.implicit_rdpcm_enabled_flag && (tu.intra_mode == 10 || tu.intra_mode == 26)) rx |= tu.intra_mode == 26 ? D265_RX_RDPCM_V : D265_RX_RDPCM_H;
+      } else if (tu.flags & DE265HIP_TU_EXPLICIT_RDPCM) rx |= (tu.flags & DE265HIP_TU_EXPLICIT_RDPCM_VERT) ? D265_RX_RDPCM_V : D265_RX_RDPCM_H;
+      if (p.transform_skip_rotation_enabled_flag && tu.log2_size == 2 &&
+          (d->blk_flags[(tu.x0 >> 2) + (tu.y0 >> 2) * g.w4] & DE265HIP_BLK_INTRA)) rx |= D265_RX_ROTATE;
+      if ((tu.flags & DE265HIP_TU_TSKIP) && !(tu.flags & DE265HIP_TU_BYPASS) && tu.log2_size > 3) rx |= 0x80;      // (big transform skip: no tool bit of its own)
+    }
+    if (tu.c_idx && tu.res_scale_val) rx |= D265_RX_XCC;
+    return rx;
+  };
   int n_inter_size[4] = { 0, 0, 0, 0 }, n_ro_size[4] = { 0, 0, 0, 0 }, n_intra = 0;
   for (int i = 0; i < d->n_tus; i++) {
     const de265hip_tu& tu = d->tus[i];
     if (tu.log2_size < 2 || tu.log2_size > 5) { delete pic; return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE; }
+    if (rx_bits(tu)) { if (tu.flags & DE265HIP_TU_INTRA) n_intra++; continue; }                 // (k_resid_rext's list, not bucketed by size)
     if (tu.flags & DE265HIP_TU_INTRA) { n_intra++; if ((tu.flags & DE265HIP_TU_CBF) && tu.n_coeff) n_ro_size[tu.log2_size - 2]++; }
     else if (tu.flags & DE265HIP_TU_CBF) n_inter_size[tu.log2_size - 2]++;
   }
@@ -749,13 +799,15 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   }
   TuTask* l0p = SC.l0.data();
   SC.it.reserve(n_intra); SC.it_next.reserve(n_intra); SC.it_llev.reserve(n_intra);
+  SC.it_rx.clear(); SC.it_rsv.clear(); SC.it_luma.clear(); SC.l0_rext.clear();
+  int last_luma_tu = -1;                                   // most recent luma TU record (cross-component prediction reads its residual)
   int n_tasks = 0;
   int32_t cell[33];                                        // 4x4 map cell of every available unit of the current TU
   int prod[40];
   for (int i = 0; i < d->n_tus; i++) {
     const de265hip_tu& tu = d->tus[i];
     const int nT = 1 << tu.log2_size;
-    const int cw = tu.c_idx ? p.width / 2 : p.width, ch = tu.c_idx ? p.height / 2 : p.height;
+    const int cw = tu.c_idx ? cwid : p.width, ch = tu.c_idx ? chei : p.height;
     if (tu.c_idx > 2 || (tu.x0 & 3) || (tu.y0 & 3) || tu.x0 + nT > cw || tu.y0 + nT > ch || tu.qp < 0 ||
         ((tu.flags & DE265HIP_TU_CBF) && ((int64_t)tu.coeff_offset + tu.n_coeff > d->n_coeffs || tu.n_coeff > nT * nT))) {
       delete pic; return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
@@ -766,7 +818,22 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       for (int k = 0; k < tu.n_coeff; k++) worst = std::max<unsigned>(worst, cp[k]);      // (vectorises)
       if (worst >= (unsigned)(nT * nT)) { delete pic; return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE; }
     }
-    if (!(tu.flags & (DE265HIP_TU_INTRA | DE265HIP_TU_CBF))) continue;       // nothing to reconstruct
+    if (tu.c_idx == 0) last_luma_tu = i;
+    const int rx = rx_bits(tu);
+    if (!(tu.flags & (DE265HIP_TU_INTRA | DE265HIP_TU_CBF)) && !(rx & D265_RX_XCC)) continue;       // nothing to reconstruct
+    // cross-component prediction: the luma TU of the same position and size comes right before the chroma TUs (4:4:4,
+    // slice.cc:3699-3750); its coefficient list is what k_resid_rext recomputes the luma residual from
+    uint64_t luma_info = 0; int rx_luma = 0;
+    if (rx & D265_RX_XCC) {
+      if (cf != 3 || last_luma_tu < 0) { delete pic; return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE; }
+      const de265hip_tu& lt = d->tus[last_luma_tu];
+      if (lt.x0 != tu.x0 || lt.y0 != tu.y0 || lt.log2_size != tu.log2_size) { delete pic; return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE; }
+      const int lrx = rx_bits(lt);
+      const bool lcbf = (lt.flags & DE265HIP_TU_CBF) && lt.n_coeff;
+      luma_info = (uint64_t)lt.coeff_offset | ((uint64_t)(lcbf ? lt.n_coeff : 0) << 32) | ((uint64_t)(uint8_t)lt.qp << 48) | ((uint64_t)lt.flags << 56);
+      rx_luma = ((lrx & D265_RX_ROTATE) ? D265_RX_LUMA_ROT : 0) |
+                (((lrx & D265_RX_RDPCM_V) ? 2 : ((lrx & D265_RX_RDPCM_H) ? 1 : 0)) << D265_RX_LUMA_RDPCM_SHIFT);
+    }
     TuTask t; memset(&t, 0, sizeof(t));
     t.x0 = tu.x0; t.y0 = tu.y0; t.log2_size = tu.log2_size; t.c_idx = tu.c_idx; t.flags = tu.flags;
     t.intra_mode = tu.intra_mode; t.qp = tu.qp; t.n_coeff = (tu.flags & DE265HIP_TU_CBF) ? tu.n_coeff : 0;
@@ -775,7 +842,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     int level = 0;
     const size_t bpp = px_bytes(tu.c_idx ? p.bit_depth_chroma : p.bit_depth_luma);
     if (tu.flags & DE265HIP_TU_INTRA) {
-      const int c = tu.c_idx, sub = c ? 2 : 1;
+      const int c = tu.c_idx, sbw = c ? subw : 1, sbh = c ? subh : 1;
       const int m = tu.intra_mode < 35 ? tu.intra_mode : 1;
       t.angle = k_intra_angle[m];
       t.inv_angle = (m >= 11 && m <= 25 && k_intra_angle[m] < 0) ? k_inv_angle[m - 11] : 0;
@@ -783,40 +850,40 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       // The left column beside the TU, the row above it and the corner precede the TU in z-scan order whenever they lie in
       // the same slice and tile (Morton order: the highest differing coordinate bit is set in the TU's own position), so
       // only the below-left and above-right units need the MinTbAddrZS comparison.
-      const int xB = tu.x0, yB = tu.y0, xL = xB * sub, yL = yB * sub;
+      const int xB = tu.x0, yB = tu.y0, xL = xB * sbw, yL = yB * sbh;
+      // (a 4:2:2 chroma TU covers a 2:1 luma area: the shortcut for the left / top neighbours is not taken there)
+      const bool full_z = c != 0 && cf == 2;
       const int cx = xL >> lc, cy = yL >> lc, ctu = cx + cy * g.ctbs_w;
       const uint32_t own = ctb_group[ctu];
       const bool aL = xL > 0 && ctb_group[((xL - 1) >> lc) + cy * g.ctbs_w] == own;
       const bool aT = yL > 0 && ctb_group[cx + ((yL - 1) >> lc) * g.ctbs_w] == own;
       const bool aTL = xL > 0 && yL > 0 && ctb_group[((xL - 1) >> lc) + ((yL - 1) >> lc) * g.ctbs_w] == own;
-      const bool aTR = yL > 0 && (xL + nT * sub < p.width) && ctb_group[((xL + nT * sub) >> lc) + ((yL - 1) >> lc) * g.ctbs_w] == own;
-      int nBottom = (p.height - yL + sub - 1) / sub; if (nBottom > 2 * nT) nBottom = 2 * nT;
-      int nRight = (p.width - xL + sub - 1) / sub;   if (nRight > 2 * nT) nRight = 2 * nT;
+      const bool aTR = yL > 0 && (xL + nT * sbw < p.width) && ctb_group[((xL + nT * sbw) >> lc) + ((yL - 1) >> lc) * g.ctbs_w] == own;
+      int nBottom = (p.height - yL + sbh - 1) / sbh; if (nBottom > 2 * nT) nBottom = 2 * nT;
+      int nRight = (p.width - xL + sbw - 1) / sbw;   if (nRight > 2 * nT) nRight = 2 * nT;
       const int cur = zs[(xL >> lt) + (size_t)(yL >> lt) * g.tbs_w];
       const int mw = map_w[c], corner = nT >> 1;
       uint64_t mask = 0;
       auto intra_ok = [&](int xs, int ys) {                 // constrained_intra_pred: only samples of intra CUs (intrapred.cc:612-615)
-        return !cip || (d->blk_flags[((xs * sub) >> 2) + ((ys * sub) >> 2) * g.w4] & DE265HIP_BLK_INTRA);
+        return !cip || (d->blk_flags[((xs * sbw) >> 2) + ((ys * sbh) >> 2) * g.w4] & DE265HIP_BLK_INTRA);
       };
+      auto z_ok = [&](int xs, int ys) { return zs[((xs * sbw) >> lt) + (size_t)((ys * sbh) >> lt) * g.tbs_w] <= cur; };
       auto take = [&](int u, int xs, int ys) { mask |= 1ull << u; cell[u] = (xs >> 2) + (ys >> 2) * mw; };
       if (aL) {
-        for (int y = nT - 1; y >= 0; y -= 4) if (intra_ok(xB - 1, yB + y)) take((2 * nT - 1 - y) >> 2, xB - 1, yB + y);
-        for (int y = nBottom - 1; y >= nT; y -= 4) {
-          const int nx = (xB - 1) * sub, ny = (yB + y) * sub;
-          if (zs[(nx >> lt) + (size_t)(ny >> lt) * g.tbs_w] <= cur && intra_ok(xB - 1, yB + y)) take((2 * nT - 1 - y) >> 2, xB - 1, yB + y);
-        }
+        for (int y = nT - 1; y >= 0; y -= 4) if ((!full_z || z_ok(xB - 1, yB + y)) && intra_ok(xB - 1, yB + y)) take((2 * nT - 1 - y) >> 2, xB - 1, yB + y);
+        for (int y = nBottom - 1; y >= nT; y -= 4)
+          if (z_ok(xB - 1, yB + y) && intra_ok(xB - 1, yB + y)) take((2 * nT - 1 - y) >> 2, xB - 1, yB + y);
       }
-      if (aTL && intra_ok(xB - 1, yB - 1)) take(corner, xB - 1, yB - 1);
-      if (aT) for (int x = 0; x < nT; x += 4) if (intra_ok(xB + x, yB - 1)) take(corner + 1 + (x >> 2), xB + x, yB - 1);
+      if (aTL && (!full_z || z_ok(xB - 1, yB - 1)) && intra_ok(xB - 1, yB - 1)) take(corner, xB - 1, yB - 1);
+      if (aT) for (int x = 0; x < nT; x += 4) if ((!full_z || z_ok(xB + x, yB - 1)) && intra_ok(xB + x, yB - 1)) take(corner + 1 + (x >> 2), xB + x, yB - 1);
       if (aTR)
-        for (int x = nT; x < nRight; x += 4) {
-          const int nx = (xB + x) * sub, ny = (yB - 1) * sub;
-          if (zs[(nx >> lt) + (size_t)(ny >> lt) * g.tbs_w] <= cur && intra_ok(xB + x, yB - 1)) take(corner + 1 + (x >> 2), xB + x, yB - 1);
-        }
+        for (int x = nT; x < nRight; x += 4)
+          if (z_ok(xB + x, yB - 1) && intra_ok(xB + x, yB - 1)) take(corner + 1 + (x >> 2), xB + x, yB - 1);
       t.avail = mask;
       // -- dependencies: only the units the mode reads (mode_deps), or every available unit
       const Cell* cells = SC.cells[c].data();
-      uint64_t need = mode_deps ? needed_units(g_used_units[tu.log2_size - 2][m][c == 0], mask) : mask;
+      // (4:4:4 chroma is smoothed like luma: it takes luma's table, a superset of what it reads)
+      uint64_t need = mode_deps ? needed_units(g_used_units[tu.log2_size - 2][m][c == 0 || cf == 3], mask) : mask;
       int lev = 0, llev = 0, n_prod = 0;
       const int crun = cur_run[c];
       for (; need; need &= need - 1) {
@@ -894,6 +961,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       {                                                     // the run's TUs: a list in decode order
         const int ti = (int)SC.it.size();
         SC.it.push_back(t); SC.it_next.push_back(-1); SC.it_llev.push_back((uint16_t)llev);
+        SC.it_rx.push_back((uint8_t)(rx | rx_luma)); SC.it_rsv.push_back(tu.res_scale_val); SC.it_luma.push_back(luma_info);
         if (R.tail >= 0) SC.it_next[R.tail] = ti; else R.head = ti;
         R.tail = ti; R.n_tus++;
       }
@@ -906,6 +974,10 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       alg_intra += (int64_t)bpp * (4 * nT + 1) + (int64_t)bpp * nT * nT;
       R.alg += (int64_t)bpp * (4 * nT + 1) + (int64_t)bpp * nT * nT;
       if (level >= 65535) { delete pic; return DE265HIP_ERROR_NOT_IMPLEMENTED; }
+    } else if (rx) {                                        // level 0, a range-extension tool: k_resid_rext's list
+      TuTask rt = t;
+      rt.pad3 = (uint8_t)(rx | rx_luma); rt.angle = tu.res_scale_val; rt.avail = luma_info;
+      SC.l0_rext.push_back(rt);
     } else
       l0p[inter_cur[tu.log2_size - 2]++] = t;               // level 0: residual added into the (inter-predicted) picture
     if (t.flags & DE265HIP_TU_CBF)
@@ -1068,9 +1140,12 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
         // behind the run record, before they have seen a single TU record
         tt.resid_offset = (uint32_t)n_resid + samp;
         tt.coeff_offset = samp; samp += 1u << (2 * tt.log2_size);
-        if (tt.flags & DE265HIP_TU_CBF) {
+        const int trx = SC.it_rx[ti];
+        if ((tt.flags & DE265HIP_TU_CBF) || (trx & D265_RX_XCC)) {
           TuTask ro = tt; ro.flags |= D265_TU_RESID_ONLY; ro.coeff_offset = coeff_offset;
-          l0p[ro_cur[ro.log2_size - 2]++] = ro;
+          if (trx) { ro.pad3 = (uint8_t)trx; ro.angle = SC.it_rsv[ti]; ro.avail = SC.it_luma[ti]; SC.l0_rext.push_back(ro); }
+          else l0p[ro_cur[ro.log2_size - 2]++] = ro;
+          tt.flags |= DE265HIP_TU_CBF;                     // (the run kernels read the residual block whenever there is one)
         }
         tt.run_level = (uint8_t)(SC.it_llev[ti] - 1);    // the run-ordered copy carries the TU's barrier epoch
         run_tus.push_back(tt);
@@ -1182,7 +1257,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     }
     const int nref = (t.slot[0] >= 0) + (t.slot[1] >= 0);
     const int64_t bppY = px_bytes(p.bit_depth_luma);
-    alg_mc += (int64_t)pu.w * pu.h * 3 / 2 * bppY * (nref + 1);
+    alg_mc += ((int64_t)pu.w * pu.h + 2 * (int64_t)(pu.w / subw) * (pu.h / subh)) * bppY * (nref + 1);
     for (int ty = 0; ty < pu.h; ty += 16)
       for (int tx = 0; tx < pu.w; tx += 16) {
         McTask q = t;
@@ -1200,7 +1275,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     const de265hip_pcm& pc = d->pcms[i];
     const int n = 1 << pc.log2_cb_size;
     if (pc.log2_cb_size < 3 || pc.log2_cb_size > 5 || (pc.x0 & 7) || (pc.y0 & 7) || pc.x0 + n > p.width ||
-        pc.y0 + n > p.height || (int64_t)pc.sample_offset + n * n * 3 / 2 > d->n_pcm_samples) {
+        pc.y0 + n > p.height || (int64_t)pc.sample_offset + n * n + 2 * (n / subw) * (n / subh) > d->n_pcm_samples) {
       delete pic; return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
     }
     PcmTask t; t.x0 = pc.x0; t.y0 = pc.y0; t.log2_cb_size = pc.log2_cb_size; t.sample_offset = pc.sample_offset;
@@ -1237,7 +1312,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       // chroma gets its own permission set, in which even the CTB itself can be "another slice".
       unsigned perm[2] = { 0, 0 };
       for (int ch = 0; ch < 2; ch++) {
-        const int own_addr = ch ? d->ctbs[(cx >> 1) + (cy >> 1) * g.ctbs_w].slice_addr_rs : ci.slice_addr_rs;
+        const int own_addr = ch ? d->ctbs[(cx / subw) + (cy / subh) * g.ctbs_w].slice_addr_rs : ci.slice_addr_rs;
         for (int dy = -1; dy <= 1; dy++)
           for (int dx = -1; dx <= 1; dx++) {
             const int nx = cx + dx, ny = cy + dy;
@@ -1274,6 +1349,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   const size_t o_rtus = L.add(run_tus.size() * sizeof(TuTask));
   const size_t o_slots = L.add(slots.size() * 4);
   const size_t o_l0 = L.add(l0.size() * sizeof(TuTask));
+  const size_t o_l0x = L.add(SC.l0_rext.size() * sizeof(TuTask));
   const size_t upload_bytes = L.total;                 // everything above is written by the host
   // device-only scratch: boundary strengths, residual blocks, run flags (no staging, no upload)
   const size_t o_bs = L.add(nblk);
@@ -1321,6 +1397,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   put(o_rtus, run_tus.data(), run_tus.size() * sizeof(TuTask));
   put(o_slots, slots.data(), slots.size() * 4);
   put(o_l0, l0.data(), l0.size() * sizeof(TuTask));
+  put(o_l0x, SC.l0_rext.data(), SC.l0_rext.size() * sizeof(TuTask));
   put(o_flags, d->blk_flags, nblk); put(o_qp, d->blk_qp_y, nblk);
   if (d->blk_motion) put(o_mot, d->blk_motion, nblk * sizeof(de265hip_motion));
   else memset(host.data() + o_mot, 0xFF, nblk * sizeof(de265hip_motion));       // ref_slot = -1 everywhere
@@ -1338,6 +1415,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     const int64_t scal[] = { pic->n_workers, pic->n_batches, pic->n_l0, pic->n_l0_size[0], pic->n_l0_size[1], pic->n_l0_size[2], pic->n_l0_size[3], pic->n_mc, pic->n_pcm,
                              pic->n_tus, pic->n_runs, (int64_t)n_resid, (int64_t)L.total, (int64_t)pic->any_edges, (int64_t)P.has_exempt, (int64_t)pic->run_direct, max_level, max_rl, (int64_t)sum_lvls, (int64_t)pic->n_front };
     mix(scal, sizeof(scal));
+    if (!SC.l0_rext.empty()) mix(host.data() + o_l0x, SC.l0_rext.size() * sizeof(TuTask));
     mix(pic->level_start.data(), pic->level_start.size() * sizeof(int));
     dec->pooled_bytes = (size_t)hsh;
   }
@@ -1371,8 +1449,9 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   pic->d_runs = (RunTask*)(base + o_runs); pic->d_deps = (uint32_t*)(base + o_rdeps);
   pic->d_run_tus = (TuTask*)(base + o_rtus); pic->d_slots = (uint32_t*)(base + o_slots); pic->d_sync = (uint32_t*)(base + o_sync);
   pic->d_l0 = (TuTask*)(base + o_l0); pic->d_resid = (int16_t*)(base + o_resid);
+  pic->d_l0_rext = (TuTask*)(base + o_l0x); pic->n_l0_rext = (int)SC.l0_rext.size();
 
-  const int64_t Pbytes = (int64_t)p.width * p.height * 3 / 2 * px_bytes(p.bit_depth_luma);
+  const int64_t Pbytes = ((int64_t)p.width * p.height + 2 * (int64_t)cwid * chei) * px_bytes(p.bit_depth_luma);
   pic->stats.n_levels = max_level + (pic->level_start[1] > 0 ? 1 : 0);
   pic->stats.n_tu_tasks = pic->n_tus; pic->stats.n_mc_tasks = pic->n_mc;
   pic->stats.n_runs = pic->n_runs; pic->stats.n_run_levels = max_rl;
@@ -1401,7 +1480,7 @@ int de265hip_debug_build_host_only(const de265hip_picture_desc* d, int reps)
   if (!d) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   de265hip_decoder* dec = new de265hip_decoder();
   dec->dry = true;
-  for (auto& sl : dec->slots) { sl.valid = true; sl.w = d->params.width; sl.h = d->params.height; sl.bdY = d->params.bit_depth_luma; sl.bdC = d->params.bit_depth_chroma; }
+  for (auto& sl : dec->slots) { sl.valid = true; sl.w = d->params.width; sl.h = d->params.height; sl.bdY = d->params.bit_depth_luma; sl.bdC = d->params.bit_depth_chroma; sl.cf = d->params.chroma_format_idc; }
   int rc = 0;
   for (int i = 0; i < reps && !rc; i++) {
     de265hip_picture* pic = nullptr;
@@ -1447,13 +1526,13 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
     // a change of picture size with pictures of the old size still queued is therefore safe (everything launched before has
     // the old planes, hipFree waits for it) - and every reference must hold a picture of this geometry by now.
     const de265hip_pic_params& pp = pic->params;
-    int rc = alloc_slot(dst, pp.width, pp.height, pp.bit_depth_luma, pp.bit_depth_chroma);
-    if (!rc) rc = alloc_slot(dec->spare, pp.width, pp.height, pp.bit_depth_luma, pp.bit_depth_chroma);
+    int rc = alloc_slot(dst, pp.width, pp.height, pp.bit_depth_luma, pp.bit_depth_chroma, pp.chroma_format_idc);
+    if (!rc) rc = alloc_slot(dec->spare, pp.width, pp.height, pp.bit_depth_luma, pp.bit_depth_chroma, pp.chroma_format_idc);
     if (rc) return rc;
     for (int s = 0; s < DE265HIP_MAX_DPB_SLOTS; s++)
       if ((pic->ref_mask >> s) & 1u) {
         const Slot& r = dec->slots[s];
-        if (!r.valid || r.w != pp.width || r.h != pp.height || r.bdY != pp.bit_depth_luma || r.bdC != pp.bit_depth_chroma)
+        if (!r.valid || r.w != pp.width || r.h != pp.height || r.bdY != pp.bit_depth_luma || r.bdC != pp.bit_depth_chroma || r.cf != pp.chroma_format_idc)
           return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
       }
   }
@@ -1476,10 +1555,12 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
     KTimer t(dec, DE265HIP_K_MC, 1);
     hipLaunchKernelGGL(k_mc<PX>, dim3(((pic->n_mc + 7) / 8) * 8), dim3(64), 0, st, P, tab, d0, d1, d2, pic->d_mc, pic->d_slices,
                        pic->n_mc);
+    if (P.chroma_format != 1)                          // 4:2:2 / 4:4:4: k_mc predicts luma only, the chroma planes by the plain kernel
+      hipLaunchKernelGGL(k_mc_chroma_any<PX>, dim3(pic->n_mc, 2), dim3(64), 0, st, P, tab, d1, d2, pic->d_mc, pic->d_slices, pic->n_mc);
   }
   if (pic->n_pcm) {
     KTimer t(dec, DE265HIP_K_PCM, 1);
-    hipLaunchKernelGGL(k_pcm<PX>, dim3(pic->n_pcm), dim3(256), 0, st, d0, d1, d2, pic->d_pcm, pic->d_pcm_samples);
+    hipLaunchKernelGGL(k_pcm<PX>, dim3(pic->n_pcm), dim3(256), 0, st, P, d0, d1, d2, pic->d_pcm, pic->d_pcm_samples);
   }
   const int nlev = (int)pic->level_start.size() - 1;
   if (!dec->intra_levels) {
@@ -1509,6 +1590,11 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
           hipLaunchKernelGGL(k_resid_small<PX>, dim3(w_small), dim3(64), 0, st, P, d0, d1, d2, pic->d_l0, n32 + n16, n8, n4,
                              pic->d_cval, pic->d_cpos, pic->d_scaling, pic->d_resid);
       }
+    }
+    if (pic->n_l0_rext > 0) {                                       // TUs with a range-extension tool (RDPCM, rotation, cross-component prediction, big transform skip)
+      KTimer t(dec, DE265HIP_K_RESID, 1);
+      hipLaunchKernelGGL(k_resid_rext<PX>, dim3(pic->n_l0_rext), dim3(64), 0, st, P, d0, d1, d2, pic->d_l0_rext, pic->n_l0_rext,
+                         pic->d_cval, pic->d_cpos, pic->d_scaling, pic->d_resid);
     }
     if (pic->n_front > 0) {                                         // the runs nobody has to wait for: one small workgroup each
       KTimer t(dec, DE265HIP_K_INTRA_FRONT, 1);
@@ -1549,7 +1635,8 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
   // variant, off by default: see de265hip_decoder::lf_tile)
   const bool want_sao = last_stage >= DE265HIP_STAGE_FINAL && !pic->params.disable_sao && pic->params.sample_adaptive_offset_enabled_flag;
   const bool want_deblock = last_stage >= DE265HIP_STAGE_DEBLOCKED && !pic->params.disable_deblocking && pic->any_edges;
-  const bool lf_tile = want_sao && dec->lf_tile && !dec->separate_bs && !dec->two_pass_deblock;
+  const bool c420 = P.chroma_format == 1;           // (4:2:2 / 4:4:4: luma through the tuned kernels, the chroma planes through k_*_chroma_any)
+  const bool lf_tile = want_sao && dec->lf_tile && !dec->separate_bs && !dec->two_pass_deblock && c420;
   if (lf_tile) {
     Slot& sp = dec->spare;
     LfMeta LM{ pic->d_flags, pic->d_qp, nullptr, pic->d_motion, pic->d_ctbs, pic->d_slices };
@@ -1566,17 +1653,23 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
   if (want_deblock) {
     // bS (a12) is derived inside the deblocking kernels (one launch and one pass over the unit grid less: 9 us of a 4K
     // picture); DE265HIP_SEPARATE_BS=1 keeps the separate k_bs launch that writes the bS plane first
-    if (dec->separate_bs) {
+    if (dec->separate_bs && c420) {
       KTimer t(dec, DE265HIP_K_BS, 1);
       hipLaunchKernelGGL(k_bs, dim3((P.w4 + 255) / 256, P.h4), dim3(256), 0, st, P, pic->d_flags, pic->d_motion, pic->d_bs);
     }
-    LfMeta M{ pic->d_flags, pic->d_qp, dec->separate_bs ? pic->d_bs : nullptr, pic->d_motion, pic->d_ctbs, pic->d_slices };
-    if (!dec->two_pass_deblock && !dec->separate_bs) {
+    LfMeta M{ pic->d_flags, pic->d_qp, (dec->separate_bs && c420) ? pic->d_bs : nullptr, pic->d_motion, pic->d_ctbs, pic->d_slices };
+    if ((!dec->two_pass_deblock && !dec->separate_bs) || !c420) {
       // both directions in one pass over 8x8 blocks centred on the edge crossings (k_deblock_fused); reported under
       // the "deblock_v" kernel id
       KTimer t(dec, DE265HIP_K_DEBLOCK_V, 1);
       const int nbx = (P.width + 3) / 8 + 1, nby = (P.height + 3) / 8 + 1;
-      hipLaunchKernelGGL((k_deblock_fused<PX>), dim3((nbx + 255) / 256, nby, 3), dim3(256), 0, st, P, d0, d1, d2, M);
+      hipLaunchKernelGGL((k_deblock_fused<PX>), dim3((nbx + 255) / 256, nby, c420 ? 3 : 1), dim3(256), 0, st, P, d0, d1, d2, M);
+      if (!c420)
+        for (int vertical = 1; vertical >= 0; vertical--) {       // vertical edges of the whole plane before any horizontal one
+          const int xi = (vertical ? 2 : 1) << P.csw, yi = (vertical ? 1 : 2) << P.csh;
+          hipLaunchKernelGGL((k_deblock_chroma_any<PX>), dim3(((P.w4 + xi - 1) / xi + 255) / 256, (P.h4 + yi - 1) / yi, 2), dim3(256), 0, st,
+                             P, d1, d2, M, vertical);
+        }
     } else {
       {
         KTimer t(dec, DE265HIP_K_DEBLOCK_V, 1);
@@ -1593,7 +1686,7 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
     SaoMeta M{ pic->d_flags, pic->d_sao };
     {
       KTimer t(dec, DE265HIP_K_SAO, 1);
-      if (dec->sao_strips)
+      if (dec->sao_strips && c420)
         hipLaunchKernelGGL(k_sao<PX>, dim3((P.width / 8 + 4 * SAO_GROUPS * 62 - 1) / (4 * SAO_GROUPS * 62), (P.height + SAO_ROWS - 1) / SAO_ROWS, 3), dim3(256), 0, st, P, d0, d1, d2,
                            sp.pl[0], sp.pl[1], sp.pl[2], M);
       else {
@@ -1602,7 +1695,9 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
         const int lswc = std::min(3, P.log2_ctb - 4), twc = 8 << lswc, thc = (64 >> lswc) * SAO_ROWS;
         const int gx = std::max((P.width + tw - 1) / tw, (P.width / 2 + twc - 1) / twc);
         const int gy = std::max((P.height + 4 * th - 1) / (4 * th), (P.height / 2 + 4 * thc - 1) / (4 * thc));
-        hipLaunchKernelGGL(k_sao_ctb<PX>, dim3(gx, gy, 3), dim3(256), 0, st, P, d0, d1, d2, sp.pl[0], sp.pl[1], sp.pl[2], M);
+        hipLaunchKernelGGL(k_sao_ctb<PX>, dim3(gx, gy, c420 ? 3 : 1), dim3(256), 0, st, P, d0, d1, d2, sp.pl[0], sp.pl[1], sp.pl[2], M);
+        if (!c420)
+          hipLaunchKernelGGL(k_sao_chroma_any<PX>, dim3((P.cwidth + 255) / 256, P.cheight, 2), dim3(256), 0, st, P, d1, d2, sp.pl[1], sp.pl[2], M);
       }
     }
     for (int c = 0; c < 3; c++) std::swap(dst.pl[c], sp.pl[c]);      // output picture now lives in the slot
@@ -1827,7 +1922,8 @@ int de265hip_record_pcm(de265hip_recorder* r, int x0, int y0, int log2_cb_size, 
   p.x0 = (uint16_t)x0; p.y0 = (uint16_t)y0; p.log2_cb_size = (uint8_t)log2_cb_size;
   p.sample_offset = (uint32_t)r->pcm_samples.size();
   const int n = 1 << log2_cb_size;
-  r->pcm_samples.insert(r->pcm_samples.end(), samples, samples + n * n * 3 / 2);
+  const int rcf = r->d.params.chroma_format_idc;
+  r->pcm_samples.insert(r->pcm_samples.end(), samples, samples + n * n + 2 * (n / (rcf == 3 ? 1 : 2)) * (n / (rcf == 1 ? 2 : 1)));
   r->pcms.push_back(p);
   return DE265HIP_OK;
 }

@@ -45,13 +45,12 @@ __device__ __forceinline__ int mc_clip3(int lo, int hi, int v) { return min(max(
 // Interpolates a w x h block (w,h <= 16 for NT=8, <= 8 for NT=4) of one reference
 // plane into out[] (sample s = lane + 64*k, row-major over w).  Intermediates are
 // truncated to int16 after each stage (fallback-motion.cc:346,:377,:508-545).
-template <typename PX, int NT>
+template <typename PX, int NT, int KMAX = (NT == 8 ? 4 : 1)>     // KMAX: outputs per lane (chroma blocks beyond 8x8: 4)
 __device__ void mc_block(const PX* __restrict__ ref, int rstride, int picW, int picH,
                          int xInt, int yInt, int xF, int yF, int w, int h, int bd,
                          uint16_t* in, int16_t* tmp, int lane, int16_t* out)
 {
   constexpr int before = NT == 8 ? 3 : 1;
-  constexpr int KMAX = NT == 8 ? 4 : 1;     // outputs per lane
   const int IW = w + NT - 1, IH = h + NT - 1;
   for (int idx = lane; idx < IW * IH; idx += 64) {
     int r = idx / IW, c = idx - r * IW;
@@ -194,6 +193,7 @@ void k_mc(PicDev P, DpbTable dpb, PlaneRef d0, PlaneRef d1, PlaneRef d2,
   const int l_uni = use0 ? 0 : 1;
   const int w = t.w, h = t.h, wc = w >> 1, hc = h >> 1;
   const int cW = P.width >> 1, cH = P.height >> 1;
+  const bool c420 = P.chroma_format == 1;           // (4:2:2 / 4:4:4: the chroma planes are predicted by k_mc_chroma_any)
 
   int mode;                                         // motion.cc:440-620
   if (sh->slice_type == 1) mode = P.weighted_pred ? 1 : 0;
@@ -227,7 +227,7 @@ void k_mc(PicDev P, DpbTable dpb, PlaneRef d0, PlaneRef d1, PlaneRef d2,
         }
       }
     }
-    {   // chroma: rows yI-1 .. yI+hc+1, columns xI-1 .. xI+wc+1
+    if (c420) {   // chroma: rows yI-1 .. yI+hc+1, columns xI-1 .. xI+wc+1
       const int xs = (t.x >> 1) + (mvx >> 3) - 1, ys = (t.y >> 1) + (mvy >> 3) - 1;
       const int nrow = hc + 3, ncol = wc + 3;
       insC[l] = xs >= 0 && ys >= 0 && xs + ncol <= cW && ys + nrow <= cH;
@@ -268,6 +268,7 @@ void k_mc(PicDev P, DpbTable dpb, PlaneRef d0, PlaneRef d1, PlaneRef d2,
         }
       }
     }
+    if (c420)
 #pragma unroll
     for (int cp = 0; cp < 2; cp++) {
       const int nrow = hc + 3, ncol = wc + 3;
@@ -374,8 +375,8 @@ void k_mc(PicDev P, DpbTable dpb, PlaneRef d0, PlaneRef d1, PlaneRef d2,
   if (mode == 1 || mode == 3) {
     const int bd = P.bd_luma;
     log2WD = sh->luma_log2_weight_denom + max(2, 14 - bd);
-    w0 = sh->luma_weight[la][t.ref_idx[la]]; o0 = sh->luma_offset[la][t.ref_idx[la]] * (1 << (bd - 8));
-    if (mode == 3) { w1 = sh->luma_weight[1][t.ref_idx[1]]; o1 = sh->luma_offset[1][t.ref_idx[1]] * (1 << (bd - 8)); }
+    w0 = sh->luma_weight[la][t.ref_idx[la]]; o0 = sh->luma_offset[la][t.ref_idx[la]] * (1 << P.wp_shift_luma);
+    if (mode == 3) { w1 = sh->luma_weight[1][t.ref_idx[1]]; o1 = sh->luma_offset[1][t.ref_idx[1]] * (1 << P.wp_shift_luma); }
   }
   if (ly < h && lx4 < w) {
     int o[4];
@@ -385,6 +386,7 @@ void k_mc(PicDev P, DpbTable dpb, PlaneRef d0, PlaneRef d1, PlaneRef d2,
     st4_px<PX>((PX*)d0.ptr + t.x + lx4 + (t.y + ly) * d0.stride, o);
   }
 
+  if (!c420) return;
   // ---------------- chroma: both planes at once, lane -> plane (lane>>5), row, 2 adjacent columns
   const int cp = lane >> 5, cy = (lane & 31) >> 2, cx2 = (lane & 3) * 2;
   int prC[2][2];
@@ -454,8 +456,8 @@ void k_mc(PicDev P, DpbTable dpb, PlaneRef d0, PlaneRef d1, PlaneRef d2,
   if (mode == 1 || mode == 3) {
     const int bd = P.bd_chroma;
     log2WD = sh->chroma_log2_weight_denom + max(2, 14 - bd);
-    w0 = sh->chroma_weight[la][t.ref_idx[la]][cp]; o0 = sh->chroma_offset[la][t.ref_idx[la]][cp] * (1 << (bd - 8));
-    if (mode == 3) { w1 = sh->chroma_weight[1][t.ref_idx[1]][cp]; o1 = sh->chroma_offset[1][t.ref_idx[1]][cp] * (1 << (bd - 8)); }
+    w0 = sh->chroma_weight[la][t.ref_idx[la]][cp]; o0 = sh->chroma_offset[la][t.ref_idx[la]][cp] * (1 << P.wp_shift_chroma);
+    if (mode == 3) { w1 = sh->chroma_weight[1][t.ref_idx[1]][cp]; o1 = sh->chroma_offset[1][t.ref_idx[1]][cp] * (1 << P.wp_shift_chroma); }
   }
   if (cy < hc && cx2 < wc) {
     const PlaneRef dc = cp ? d2 : d1;
@@ -471,10 +473,61 @@ template __global__ void k_mc<uint8_t>(PicDev, DpbTable, PlaneRef, PlaneRef, Pla
 template __global__ void k_mc<uint16_t>(PicDev, DpbTable, PlaneRef, PlaneRef, PlaneRef, const McTask*,
                                         const de265hip_slice_params*, int);
 
+// ---- chroma prediction of one MC task for any chroma format (4:2:2 / 4:4:4 pictures; mc_chroma, motion.cc:175-273: the
+// vector scaled by 2 / SubWidthC, 2 / SubHeightC, eighth-sample fractions).  One wavefront per task and plane
+// (blockIdx.y), the tile of at most 16x16 chroma samples through the function-level block interpolator.
+template <typename PX>
+__global__ __launch_bounds__(64)
+void k_mc_chroma_any(PicDev P, DpbTable dpb, PlaneRef d1, PlaneRef d2, const McTask* __restrict__ tasks,
+                     const de265hip_slice_params* __restrict__ slices, int n_tasks)
+{
+  __shared__ uint16_t s_in[23 * MC_IWP];
+  __shared__ int16_t s_tmp[23 * 16];
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x >= n_tasks) return;
+  const McTask t = tasks[blockIdx.x];
+  const int cp = blockIdx.y;
+  const de265hip_slice_params* sh = &slices[t.slice_idx];
+  const bool use0 = t.slot[0] >= 0, use1 = t.slot[1] >= 0, bi = use0 && use1;
+  const int wc = t.w >> P.csw, hc = t.h >> P.csh, xc = t.x >> P.csw, yc = t.y >> P.csh;
+  int mode;
+  if (sh->slice_type == 1) mode = P.weighted_pred ? 1 : 0;
+  else if (bi) mode = P.weighted_bipred ? 3 : 2;
+  else mode = P.weighted_bipred ? 1 : 0;
+  int16_t pr[2][4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
+#pragma unroll
+  for (int l = 0; l < 2; l++) {
+    if (t.slot[l] < 0) continue;
+    const int mvx = t.mv[l][0] * (2 >> P.csw), mvy = t.mv[l][1] * (2 >> P.csh);
+    const PlaneRef r = dpb.p[t.slot[l]][cp + 1];
+    mc_block<PX, 4, 4>((const PX*)r.ptr, r.stride, P.cwidth, P.cheight, xc + (mvx >> 3), yc + (mvy >> 3), mvx & 7, mvy & 7,
+                    wc, hc, P.bd_chroma, s_in, s_tmp, lane, pr[l]);
+  }
+  int w0 = 0, o0 = 0, w1 = 0, o1 = 0, log2WD = 1;
+  if (mode == 1 || mode == 3) {
+    const int la = mode == 3 ? 0 : (use0 ? 0 : 1);
+    log2WD = sh->chroma_log2_weight_denom + max(2, 14 - P.bd_chroma);
+    w0 = sh->chroma_weight[la][t.ref_idx[la]][cp]; o0 = sh->chroma_offset[la][t.ref_idx[la]][cp] * (1 << P.wp_shift_chroma);
+    if (mode == 3) { w1 = sh->chroma_weight[1][t.ref_idx[1]][cp]; o1 = sh->chroma_offset[1][t.ref_idx[1]][cp] * (1 << P.wp_shift_chroma); }
+  }
+  const PlaneRef dc = cp ? d2 : d1;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int s = lane + 64 * k;
+    if (s < wc * hc) {
+      const int y = s / wc, x = s - y * wc;
+      const int a = bi ? pr[0][k] : (use0 ? pr[0][k] : pr[1][k]);
+      ((PX*)dc.ptr)[xc + x + (yc + y) * dc.stride] = mc_combine<PX>(mode, a, pr[1][k], P.bd_chroma, w0, o0, w1, o1, log2WD);
+    }
+  }
+}
+template __global__ void k_mc_chroma_any<uint8_t>(PicDev, DpbTable, PlaneRef, PlaneRef, const McTask*, const de265hip_slice_params*, int);
+template __global__ void k_mc_chroma_any<uint16_t>(PicDev, DpbTable, PlaneRef, PlaneRef, const McTask*, const de265hip_slice_params*, int);
+
 // ---- PCM sample copy (slice.cc:4143-4183), one workgroup per PCM CU
 template <typename PX>
 __global__ __launch_bounds__(256)
-void k_pcm(PlaneRef d0, PlaneRef d1, PlaneRef d2, const PcmTask* __restrict__ tasks,
+void k_pcm(PicDev P, PlaneRef d0, PlaneRef d1, PlaneRef d2, const PcmTask* __restrict__ tasks,
            const uint16_t* __restrict__ samples)
 {
   const PcmTask t = tasks[blockIdx.x];
@@ -482,18 +535,18 @@ void k_pcm(PlaneRef d0, PlaneRef d1, PlaneRef d2, const PcmTask* __restrict__ ta
   const uint16_t* s = samples + t.sample_offset;
   const PlaneRef dsts[3] = { d0, d1, d2 };
   for (int comp = 0; comp < 3; comp++) {
-    const int w = comp ? n >> 1 : n;
-    const int x0 = comp ? t.x0 >> 1 : t.x0, y0 = comp ? t.y0 >> 1 : t.y0;
+    const int w = comp ? n >> P.csw : n, h = comp ? n >> P.csh : n;
+    const int x0 = comp ? t.x0 >> P.csw : t.x0, y0 = comp ? t.y0 >> P.csh : t.y0;
     PX* dst = (PX*)dsts[comp].ptr;
-    for (int i = threadIdx.x; i < w * w; i += 256) {
+    for (int i = threadIdx.x; i < w * h; i += 256) {
       int y = i / w, x = i - y * w;
       dst[(x0 + x) + (y0 + y) * dsts[comp].stride] = (PX)s[i];
     }
-    s += w * w;
+    s += w * h;
   }
 }
-template __global__ void k_pcm<uint8_t>(PlaneRef, PlaneRef, PlaneRef, const PcmTask*, const uint16_t*);
-template __global__ void k_pcm<uint16_t>(PlaneRef, PlaneRef, PlaneRef, const PcmTask*, const uint16_t*);
+template __global__ void k_pcm<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const PcmTask*, const uint16_t*);
+template __global__ void k_pcm<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const PcmTask*, const uint16_t*);
 
 // ---- function-level forms (acceleration.h:31-120 slot semantics) ----
 // put_hevc_qpel_* / put_hevc_epel_*: one workgroup per block; blocks wider/higher

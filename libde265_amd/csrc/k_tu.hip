@@ -132,13 +132,13 @@ __device__ void intra_predict(const PicDev& P, const TuTask& t, const PX* plane,
   // ---- smoothing (intra_prediction_sample_filtering), luma only in 4:2:0
   const int mode = t.intra_mode >= 35 ? 1 : t.intra_mode;
   int filterFlag = 0;
-  if (cIdx == 0 && mode != 1 && nT != 4) {
+  if (intra_smooth_on(P, cIdx) && mode != 1 && nT != 4) {     // (chroma too in 4:4:4, nobody with intra_smoothing_disabled)
     int minDist = min(abs(mode - 26), abs(mode - 10));
     filterFlag = (nT == 8) ? (minDist > 7) : (nT == 16 ? (minDist > 1) : (minDist > 0));
   }
   if (filterFlag) {
     bool biInt = false;
-    if (P.strong_intra && nT == 32) {
+    if (P.strong_intra && nT == 32 && cIdx == 0) {
       int th = 1 << (P.bd_luma - 5);
       biInt = abs(border[0] + border[64] - 2 * border[32]) < th &&
               abs(border[0] + border[-64] - 2 * border[-32]) < th;
@@ -208,7 +208,7 @@ __device__ void intra_predict(const PicDev& P, const TuTask& t, const PX* plane,
       int o;
       if (iFact) o = ((32 - iFact) * bf[b + iIdx + 1] + iFact * bf[b + iIdx + 2] + 16) >> 5;
       else o = bf[b + iIdx + 1];
-      if (cIdx == 0 && nT < 32) {
+      if (cIdx == 0 && nT < 32 && !(P.implicit_rdpcm && (t.flags & DE265HIP_TU_BYPASS))) {   // intrapred.cc:1102-1104
         if (mode == 26 && x == 0) o = clip3(0, (1 << bd) - 1, border[1] + ((border[-1 - y] - border[0]) >> 1));
         if (mode == 10 && y == 0) o = clip3(0, (1 << bd) - 1, border[-1] + ((border[1 + x] - border[0]) >> 1));
       }
@@ -347,6 +347,7 @@ __device__ void tu_reconstruct(const PicDev& P, const TuTask& t, PX* plane, int 
       const long long offset = 1ll << (bdShift - 1);
       int matrixID = cIdx;
       if (!intra) matrixID += (nT < 32) ? 3 : 1;
+      if (nT == 32 && matrixID > 1) matrixID = intra ? 0 : 1;   // (32x32 chroma, 4:4:4: the reference indexes beyond its two 32x32 matrices - undefined there)
       const uint8_t* scl = scaling + (log2 == 2 ? 0 : (log2 == 3 ? 96 : (log2 == 4 ? 96 + 384 : 96 + 384 + 1536))) +
                            matrixID * nS;
       for (int i = lane; i < t.n_coeff; i += 64) {
@@ -424,6 +425,7 @@ __device__ __forceinline__ void resid_big_body(const PicDev& P, const PlaneRef& 
       const int bdShift = bd + log2 - 5;
       int matrixID = cIdx;
       if (!intra) matrixID += (nT < 32) ? 3 : 1;
+      if (nT == 32 && matrixID > 1) matrixID = intra ? 0 : 1;
       const uint8_t* scl = scaling + (log2 == 4 ? 96 + 384 : 96 + 384 + 1536) + matrixID * nS;
       for (int i = tid; i < t.n_coeff; i += 256) {
         const int p = i == tid ? p_first : pos[i];
@@ -852,6 +854,7 @@ __device__ __forceinline__ void store8_from_u16(uint8_t* g, uint4 v)
 // each followed by a vmcnt(0) that also waits for the previous TU's write-through stores).
 struct RunTu {
   int x0, y0, log2_size, c_idx, flags, intra_mode, angle, inv_angle;
+  bool smooth_on, edge_off;       // neighbour smoothing applies to this component; mode 10 / 26 edge filter switched off
   uint32_t resid_offset;
   uint64_t avail;
 };
@@ -868,7 +871,8 @@ struct RunTu {
 #define RTU_BIG (1u << 28)
 #define RTU_CBF (1u << 29)
 template <int RUN_TILE_P>
-__device__ __forceinline__ uint4 run_tu_pack(const TuTask* __restrict__ tp, int k, int ax0, int wy0, uint32_t res_base, int c)
+__device__ __forceinline__ uint4 run_tu_pack(const TuTask* __restrict__ tp, int k, int ax0, int wy0, uint32_t res_base, int c,
+                                              bool smooth_on, bool implicit_rdpcm)
 {
   const uint4* q = reinterpret_cast<const uint4*>(tp + k);
   const uint4 a = q[0], b = q[1];
@@ -877,11 +881,13 @@ __device__ __forceinline__ uint4 run_tu_pack(const TuTask* __restrict__ tp, int 
   uint32_t mode = a.y >> 24; if (mode >= 35) mode = 1;
   const uint32_t level = (a.z >> 8) & 0xFF, samp = a.w;
   const int md = min(abs((int)mode - 26), abs((int)mode - 10));
-  const uint32_t kind = mode == 0 ? 0u : (mode == 1 ? 1u : ((c == 0 && md == 0 && log2 < 5) ? 3u : 2u));
+  // (the mode 10 / 26 edge filter: luma only, and not for a transquant-bypass CU under implicit RDPCM, intrapred.cc:1102-1104)
+  const bool edge = c == 0 && md == 0 && log2 < 5 && !(implicit_rdpcm && (flags & DE265HIP_TU_BYPASS));
+  const uint32_t kind = mode == 0 ? 0u : (mode == 1 ? 1u : (edge ? 3u : 2u));
   uint4 o;
   o.x = ((yw * RUN_TILE_P + xw) * 2) | (log2 == 2 ? RTU_IS4 : 0u) | (level << 16) | (kind << 24) |
         (mode >= 18 ? RTU_VERT : 0u) |
-        ((c == 0 && mode != 1 && (log2 == 3 ? md > 7 : (log2 == 4 ? md > 1 : (log2 == 5 && md > 0)))) ? RTU_SMOOTH : 0u) |
+        ((smooth_on && mode != 1 && (log2 == 3 ? md > 7 : (log2 == 4 ? md > 1 : (log2 == 5 && md > 0)))) ? RTU_SMOOTH : 0u) |
         (log2 > 3 ? RTU_BIG : 0u) | ((flags & DE265HIP_TU_CBF) ? RTU_CBF : 0u);
   o.y = (samp << 2) | (mode << 14) | ((b.w & 0xFF) << 24);
   o.z = b.x;
@@ -1146,7 +1152,7 @@ __device__ __forceinline__ void run_chain_big(const PicDev& P, uint32_t w0, int 
   const uint16_t* bord = S.b1;
   auto win = [&](uint32_t word) { return (int)*reinterpret_cast<uint16_t*>(tile_b + (word >> 16)); };   // border sample p <- ctl[p]
   if (smooth) {
-    const bool strong = P.strong_intra && nT == 32;
+    const bool strong = P.strong_intra && nT == 32 && c == 0;
     for (int p = tid; p < NB; p += nthr) {
       const uint32_t am = ctl[p ? p - 1 : 0], ac = ctl[p], ap = ctl[p < NB - 1 ? p + 1 : p];
       uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
@@ -1245,7 +1251,7 @@ __device__ __forceinline__ void micro_intra_tu(const RunTu& t, uint16_t* tile, i
     bv = tile[sx + sy * MICRO_P];
   }
   const int mode = t.intra_mode >= 35 ? 1 : t.intra_mode;
-  if (LOG2 == 3 && cIdx == 0 && mode != 1 && min(abs(mode - 26), abs(mode - 10)) > 7) {
+  if (LOG2 == 3 && t.smooth_on && mode != 1 && min(abs(mode - 26), abs(mode - 10)) > 7) {
     const int prev = __builtin_amdgcn_update_dpp(bv, bv, 0x138, 0xf, 0xf, false);   // wave_shr:1 -> lane-1
     const int next = __builtin_amdgcn_update_dpp(bv, bv, 0x130, 0xf, 0xf, false);   // wave_shl:1 -> lane+1
     const int f = (prev + 2 * bv + next + 2) >> 2;
@@ -1277,7 +1283,7 @@ __device__ __forceinline__ void micro_intra_tu(const RunTu& t, uint16_t* tile, i
     const int r0 = BORD(vert ? k0 : -k0), r1 = BORD(vert ? min(k1, C) : -min(k1, C));
     const int ev = BORD(vert ? -1 - y : 1 + x);
     pv = ((32 - iFact) * r0 + iFact * r1 + 16) >> 5;
-    if (cIdx == 0 && (mode == 26 || mode == 10)) {
+    if (cIdx == 0 && (mode == 26 || mode == 10) && !t.edge_off) {
       const int b0 = __builtin_amdgcn_readlane(bv, C);
       const int b1 = vert ? __builtin_amdgcn_readlane(bv, C + 1) : __builtin_amdgcn_readlane(bv, C - 1);
       const int e = clip3(0, maxv, b1 + ((ev - b0) >> 1));
@@ -1330,7 +1336,7 @@ __device__ __forceinline__ void micro_intra_tu16(const RunTu& t, uint16_t* tile,
     bx = fetch(NB - 1);
   }
   const int mode = t.intra_mode >= 35 ? 1 : t.intra_mode;
-  if (cIdx == 0 && mode != 1 && min(abs(mode - 26), abs(mode - 10)) > 1) {           // [1 2 1], both ends keep their value
+  if (t.smooth_on && mode != 1 && min(abs(mode - 26), abs(mode - 10)) > 1) {          // [1 2 1], both ends keep their value
     const int prev = __builtin_amdgcn_update_dpp(bv, bv, 0x138, 0xf, 0xf, false);   // wave_shr:1 -> lane-1
     int next = __builtin_amdgcn_update_dpp(bv, bv, 0x130, 0xf, 0xf, false);         // wave_shl:1 -> lane+1
     if (lane == 63) next = bx;
@@ -1371,7 +1377,7 @@ __device__ __forceinline__ void micro_intra_tu16(const RunTu& t, uint16_t* tile,
       const int k1 = i1 >= 0 ? i1 : -((i1 * inv + 128) >> 8);
       const int r0 = bord(vert ? k0 : -k0), r1 = bord(vert ? min(k1, C) : -min(k1, C));
       pv = ((32 - iFact) * r0 + iFact * r1 + 16) >> 5;
-      if (cIdx == 0 && (mode == 26 || mode == 10)) {
+      if (cIdx == 0 && (mode == 26 || mode == 10) && !t.edge_off) {
         const int ev = bord(vert ? -1 - y : 1 + x);
         const int b0 = bord(0), b1 = vert ? bord(1) : bord(-1);
         const int e = clip3(0, maxv, b1 + ((ev - b0) >> 1));
@@ -1419,7 +1425,7 @@ __device__ __forceinline__ void micro_run(const PicDev& P, const PlaneRef& pl0, 
   const PlaneRef pr = c == 0 ? pl0 : (c == 1 ? pl1 : pl2);
   PX* plane = (PX*)pr.ptr;
   const int stride = pr.stride;
-  const int cw = c ? P.width >> 1 : P.width, ch = c ? P.height >> 1 : P.height;
+  const int cw = c ? P.cwidth : P.width, ch = c ? P.cheight : P.height;
   const int bd = c ? P.bd_chroma : P.bd_luma;
   const int wx0 = (int)run.x0 - 1, wy0 = (int)run.y0 - 1;
   const int ax0 = wx0 & ~7;
@@ -1500,6 +1506,7 @@ __device__ __forceinline__ void micro_run(const PicDev& P, const PlaneRef& pl0, 
     t.x0 = gx0 - ax0; t.y0 = gy0 - wy0;
     t.log2_size = w1 & 0xFF; t.c_idx = c; t.flags = (w1 >> 16) & 0xFF; t.intra_mode = w1 >> 24;
     t.avail = w4; t.resid_offset = 0;
+    t.smooth_on = intra_smooth_on(P, c); t.edge_off = P.implicit_rdpcm && (t.flags & DE265HIP_TU_BYPASS);
     t.angle = (int)(int8_t)(w7 & 0xFF); t.inv_angle = (int)(int16_t)(w7 >> 16);
     PX* gdst = plane + gx0 + gy0 * stride;
     if (t.log2_size == 4) { micro_intra_tu16<PX, !FRONT>(t, mt, lane, mres + (w3 & (MICRO_RES - 1)), bd, gdst, stride); continue; }
@@ -1655,7 +1662,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   const PlaneRef pr = c == 0 ? pl0 : (c == 1 ? pl1 : pl2);
   PX* plane = (PX*)pr.ptr;
   const int stride = pr.stride;
-  const int cw = c ? P.width >> 1 : P.width, ch = c ? P.height >> 1 : P.height;
+  const int cw = c ? P.cwidth : P.width, ch = c ? P.cheight : P.height;
   const int bd = c ? P.bd_chroma : P.bd_luma;
   const int maxv = (1 << bd) - 1;
   // pixel window: bbox + 1 left/top + the top-right / bottom-left reach of its TUs (host-computed)
@@ -1692,7 +1699,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   // ---- preparation, independent of the producers: pack the TU records, then one thread per sample
   for (int i = tid; i < RUN_TILE_H; i += nthr) s_mine[i] = 0;
   for (int i = tid; i < n_tus; i += nthr) {
-    const uint4 r = run_tu_pack<RUN_TILE_P>(tasks + run.first_tu, i, ax0, wy0, res_base, c);
+    const uint4 r = run_tu_pack<RUN_TILE_P>(tasks + run.first_tu, i, ax0, wy0, res_base, c, intra_smooth_on(P, c), P.implicit_rdpcm != 0);
     s_task[i] = r;
     const int samp = (r.y & 0x3FFF) >> 2, cells = 1 << (2 * ((r.w >> 27) & 7) - 4);
     for (int q = 0; q < cells; q++) s_own[(samp >> 4) + q] = (uint8_t)i;

@@ -53,7 +53,7 @@ template <typename PX>
 __global__ void k_mc(PicDev, DpbTable, PlaneRef, PlaneRef, PlaneRef, const McTask*,
                      const de265hip_slice_params*, int);
 template <typename PX>
-__global__ void k_pcm(PlaneRef, PlaneRef, PlaneRef, const PcmTask*, const uint16_t*);
+__global__ void k_pcm(PicDev, PlaneRef, PlaneRef, PlaneRef, const PcmTask*, const uint16_t*);
 __global__ void k_bs(PicDev, const uint8_t*, const de265hip_motion*, uint8_t*);
 template <typename PX, bool VERT>
 __global__ void k_deblock(PicDev, PlaneRef, PlaneRef, PlaneRef, LfMeta);
@@ -73,6 +73,16 @@ __global__ void k_sao_ctb(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneR
 #define LF_TILE_H LF_TH
 template <typename PX>
 __global__ void k_lf_tile(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, LfMeta, SaoMeta, int);
+
+// range-extension paths (k_rext.hip; k_mc_chroma_any in k_mc.hip)
+template <typename PX>
+__global__ void k_resid_rext(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int, const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
+template <typename PX>
+__global__ void k_deblock_chroma_any(PicDev, PlaneRef, PlaneRef, LfMeta, int);
+template <typename PX>
+__global__ void k_sao_chroma_any(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, SaoMeta);
+template <typename PX>
+__global__ void k_mc_chroma_any(PicDev, DpbTable, PlaneRef, PlaneRef, const McTask*, const de265hip_slice_params*, int);
 
 // function-level kernels (k_fn.hip)
 template <typename PX>

@@ -87,6 +87,9 @@ typedef struct octx {
   int w4, h4;                  /* deblk_width/height = ceil(W/4), ceil(H/4) (image.cc:432-433) */
   int* min_tb_addr_zs;         /* pps.cc:671-690 */
   int* tile_id;                /* TileIdRS, pps.cc:646-660 */
+  int sw, sh;                  /* SubWidthC, SubHeightC (sps.cc:540-552) */
+  int cw, chh;                 /* chroma plane width / height */
+  int32_t* residual_luma;      /* thread_context::residual_luma (decctx.h): the last luma TU's residual, read by cross_comp_pred */
 } octx;
 
 static inline int blk_flags_at(const octx* c, int xL, int yL)
@@ -115,10 +118,13 @@ static int octx_init(octx* c, const de265hip_picture_desc* d, oracle_image* img,
 {
   const de265hip_pic_params* P = &d->params;
   memset(c, 0, sizeof(*c));
-  if (P->chroma_format_idc != 1) return DE265HIP_ERROR_NOT_IMPLEMENTED;
+  if (P->chroma_format_idc < 1 || P->chroma_format_idc > 3 || P->extended_precision_processing_flag) return DE265HIP_ERROR_NOT_IMPLEMENTED;
   if (P->num_tile_columns < 1 || P->num_tile_rows < 1 ||
       P->num_tile_columns > 20 || P->num_tile_rows > 22) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   c->d = d; c->img = img; c->dpb = dpb;
+  c->sw = P->chroma_format_idc == 3 ? 1 : 2; c->sh = P->chroma_format_idc == 1 ? 2 : 1;
+  c->cw = P->width / c->sw; c->chh = P->height / c->sh;
+  c->residual_luma = (int32_t*)calloc(32 * 32, sizeof(int32_t));
   int ctb = 1 << P->log2_ctb_size;
   c->ctbs_w = (P->width + ctb - 1) >> P->log2_ctb_size;
   c->ctbs_h = (P->height + ctb - 1) >> P->log2_ctb_size;
@@ -164,7 +170,7 @@ static int octx_init(octx* c, const de265hip_picture_desc* d, oracle_image* img,
   free(rs2ts);
   return 0;
 }
-static void octx_free(octx* c) { free(c->min_tb_addr_zs); free(c->tile_id); }
+static void octx_free(octx* c) { free(c->min_tb_addr_zs); free(c->tile_id); free(c->residual_luma); }
 
 /* ---------------- a1: dequantisation, transform.cc:452-510 ---------------- */
 void oracle_dequant(int16_t* coeff_buf, int log2_size, int c_idx, int intra, int qp,
@@ -365,7 +371,7 @@ static int hi_depth(const de265hip_pic_params* P) { return P->bit_depth_luma > 8
 
 static int check_params(const de265hip_pic_params* P)
 {
-  if (P->chroma_format_idc != 1) return DE265HIP_ERROR_NOT_IMPLEMENTED;
+  if (P->chroma_format_idc < 1 || P->chroma_format_idc > 3 || P->extended_precision_processing_flag) return DE265HIP_ERROR_NOT_IMPLEMENTED;
   if ((P->bit_depth_luma > 8) != (P->bit_depth_chroma > 8)) return DE265HIP_ERROR_NOT_IMPLEMENTED;
   if (P->bit_depth_luma < 8 || P->bit_depth_luma > 12 || P->bit_depth_chroma < 8 ||
       P->bit_depth_chroma > 12) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
@@ -527,10 +533,10 @@ void oracle_intra_predict(int bit_depth, int strong, void* dst, ptrdiff_t stride
   if (bit_depth > 8) {
     uint16_t mem[4*32 + 1]; uint16_t* b = &mem[2*32];
     memcpy(b - 2*nT, (const uint16_t*)border_centre - 2*nT, (4*nT + 1)*sizeof(uint16_t));
-    intra_from_border_16((uint16_t*)dst, stride, nT, c_idx, mode, b, strong, bit_depth, bit_depth);
+    intra_from_border_16((uint16_t*)dst, stride, nT, c_idx, mode, b, strong, bit_depth, bit_depth, c_idx == 0, 0);
   } else {
     uint8_t mem[4*32 + 1]; uint8_t* b = &mem[2*32];
     memcpy(b - 2*nT, (const uint8_t*)border_centre - 2*nT, 4*nT + 1);
-    intra_from_border_8((uint8_t*)dst, stride, nT, c_idx, mode, b, strong, bit_depth, bit_depth);
+    intra_from_border_8((uint8_t*)dst, stride, nT, c_idx, mode, b, strong, bit_depth, bit_depth, c_idx == 0, 0);
   }
 }

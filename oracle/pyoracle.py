@@ -95,9 +95,10 @@ def make_image(planes):
     return img
 
 
-def alloc_planes(width, height, bit_depth, fill=None):
+def alloc_planes(width, height, bit_depth, fill=None, chroma_format=1):
     dt = np.uint16 if bit_depth > 8 else np.uint8
-    shapes = [(height, width), (height // 2, width // 2), (height // 2, width // 2)]
+    cw, ch = width // (1 if chroma_format == 3 else 2), height // (2 if chroma_format == 1 else 1)
+    shapes = [(height, width), (ch, cw), (ch, cw)]
     if fill is None:
         return [np.zeros(s, dt) for s in shapes]
     return [np.full(s, fill, dt) for s in shapes]

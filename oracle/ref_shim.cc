@@ -90,7 +90,7 @@ struct ref_picture {
   std::vector<de265_image*> refs;
   std::vector<slice_segment_header*> shdrs;
   thread_context* tctx;
-  int w, h, bytes;
+  int w, h, bytes, cw, ch;
 
   ref_picture() : dctx(NULL), sctx(NULL), img(NULL), tctx(NULL) {}
   ~ref_picture() {
@@ -131,6 +131,14 @@ static int build_headers(ref_picture& R, const de265hip_pic_params& P, const uin
   sps->pcm_loop_filter_disable_flag = P.pcm_loop_filter_disable_flag;
   sps->strong_intra_smoothing_enable_flag = P.strong_intra_smoothing_enable_flag;
   sps->scaling_list_enable_flag = P.scaling_list_enable_flag;
+  // range extensions (sps.cc:1254-1264): only what the sample paths read
+  if (P.implicit_rdpcm_enabled_flag || P.transform_skip_rotation_enabled_flag || P.intra_smoothing_disabled_flag ||
+      P.high_precision_offsets_enabled_flag || P.cross_component_prediction_enabled_flag) sps->sps_range_extension_flag = 1;
+  sps->range_extension.implicit_rdpcm_enabled_flag = P.implicit_rdpcm_enabled_flag;
+  sps->range_extension.explicit_rdpcm_enabled_flag = 1;
+  sps->range_extension.transform_skip_rotation_enabled_flag = P.transform_skip_rotation_enabled_flag;
+  sps->range_extension.intra_smoothing_disabled_flag = P.intra_smoothing_disabled_flag;
+  sps->range_extension.high_precision_offsets_enabled_flag = P.high_precision_offsets_enabled_flag;
   if (sps->compute_derived_values(true) != DE265_OK) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
 
   pps->set_defaults();
@@ -143,6 +151,8 @@ static int build_headers(ref_picture& R, const de265hip_pic_params& P, const uin
   pps->pic_cb_qp_offset = P.pic_cb_qp_offset;
   pps->pic_cr_qp_offset = P.pic_cr_qp_offset;
   pps->loop_filter_across_tiles_enabled_flag = P.loop_filter_across_tiles_enabled_flag;
+  pps->range_extension.cross_component_prediction_enabled_flag = P.cross_component_prediction_enabled_flag;
+  pps->range_extension.log2_max_transform_skip_block_size = 5;
   pps->num_tile_columns = P.num_tile_columns;
   pps->num_tile_rows = P.num_tile_rows;
   pps->tiles_enabled_flag = (P.num_tile_columns>1 || P.num_tile_rows>1);
@@ -286,7 +296,9 @@ static int setup(ref_picture& R, const de265hip_picture_desc* d, const oracle_im
                  const uint8_t* cb_log2_size, const uint8_t* cb_part_mode, const uint8_t* tu_split)
 {
   const de265hip_pic_params& P = d->params;
-  if (P.chroma_format_idc != 1) return DE265HIP_ERROR_NOT_IMPLEMENTED;
+  if (P.chroma_format_idc < 1 || P.chroma_format_idc > 3 || P.extended_precision_processing_flag) return DE265HIP_ERROR_NOT_IMPLEMENTED;
+  const enum de265_chroma chroma = P.chroma_format_idc == 1 ? de265_chroma_420 : (P.chroma_format_idc == 2 ? de265_chroma_422 : de265_chroma_444);
+  const int cw = P.width / (P.chroma_format_idc == 3 ? 1 : 2), ch = P.height / (P.chroma_format_idc == 1 ? 2 : 1);
   int rc = build_headers(R, P, d->scaling_factors);
   if (rc) return rc;
   R.w = P.width; R.h = P.height; R.bytes = P.bit_depth_luma>8 ? 2 : 1;
@@ -294,22 +306,23 @@ static int setup(ref_picture& R, const de265hip_picture_desc* d, const oracle_im
   R.dctx->set_acceleration_functions(de265_acceleration_SCALAR);
   R.sctx = new shim_ctx;
   R.img = new de265_image;
-  if (R.img->alloc_image(P.width,P.height,de265_chroma_420,R.sps,true,R.dctx,NULL,0,NULL,false) != DE265_OK)
+  R.cw = cw; R.ch = ch;
+  if (R.img->alloc_image(P.width,P.height,chroma,R.sps,true,R.dctx,NULL,0,NULL,false) != DE265_OK)
     return DE265HIP_ERROR_OUT_OF_MEMORY;
   R.img->set_headers(R.vps,R.sps,R.pps);
   R.img->integrity = INTEGRITY_CORRECT;      // dpb.cc new_image(); any reference-side complaint lowers it
   if (cur)
     for (int c=0;c<3;c++)
-      copy_in(R.img,c,cur->plane[c],cur->stride[c], c?P.width/2:P.width, c?P.height/2:P.height, R.bytes);
+      copy_in(R.img,c,cur->plane[c],cur->stride[c], c?cw:P.width, c?ch:P.height, R.bytes);
   if (dpb)
     for (int s=0;s<DE265HIP_MAX_DPB_SLOTS;s++) {
       if (!dpb[s].plane[0]) continue;
       de265_image* r = new de265_image;
-      if (r->alloc_image(P.width,P.height,de265_chroma_420,R.sps,false,R.dctx,NULL,0,NULL,false) != DE265_OK)
+      if (r->alloc_image(P.width,P.height,chroma,R.sps,false,R.dctx,NULL,0,NULL,false) != DE265_OK)
         { delete r; return DE265HIP_ERROR_OUT_OF_MEMORY; }
       r->PicState = UsedForShortTermReference;
       for (int c=0;c<3;c++)
-        copy_in(r,c,dpb[s].plane[c],dpb[s].stride[c], c?P.width/2:P.width, c?P.height/2:P.height, R.bytes);
+        copy_in(r,c,dpb[s].plane[c],dpb[s].stride[c], c?cw:P.width, c?ch:P.height, R.bytes);
       R.refs.push_back(r);
       R.sctx->slots[s] = r;
     }
@@ -326,25 +339,39 @@ static int setup(ref_picture& R, const de265hip_picture_desc* d, const oracle_im
   return 0;
 }
 
-/* decode_TU (slice.cc:3424-3488) for one recorded TU */
+/* decode_TU (slice.cc:3424-3488) for one recorded TU: the same few lines, on the values the parser leaves in the
+ * thread context (transform_skip_flag, cu_transquant_bypass_flag, explicit_rdpcm_*, ResScaleVal, qP*Prime, coeffList) */
 static void do_tu(ref_picture& R, const de265hip_picture_desc* d, int i)
 {
   const de265hip_tu& tu = d->tus[i];
   thread_context* t = R.tctx;
+  const seq_parameter_set& sps = *R.sps;
   const int nT = 1<<tu.log2_size, c = tu.c_idx;
   const bool intra = tu.flags & DE265HIP_TU_INTRA;
   const bool cbf = tu.flags & DE265HIP_TU_CBF;
   t->cu_transquant_bypass_flag = (tu.flags & DE265HIP_TU_BYPASS) ? 1 : 0;
   memset(t->transform_skip_flag,0,3);
   t->transform_skip_flag[c] = (tu.flags & DE265HIP_TU_TSKIP) ? 1 : 0;
+  t->explicit_rdpcm_flag = (tu.flags & DE265HIP_TU_EXPLICIT_RDPCM) ? 1 : 0;
+  t->explicit_rdpcm_dir = (tu.flags & DE265HIP_TU_EXPLICIT_RDPCM_VERT) ? 1 : 0;
+  t->ResScaleVal = c ? tu.res_scale_val : 0;
   t->qPYPrime = t->qPCbPrime = t->qPCrPrime = tu.qp;
-  if (intra) decode_intra_prediction(R.img, tu.x0,tu.y0, (enum IntraPredMode)tu.intra_mode, nT, c);
+  int residualDpcm = 0;
+  if (intra) {
+    decode_intra_prediction(R.img, tu.x0,tu.y0, (enum IntraPredMode)tu.intra_mode, nT, c);
+    residualDpcm = sps.range_extension.implicit_rdpcm_enabled_flag &&
+      (t->cu_transquant_bypass_flag || t->transform_skip_flag[c]) && (tu.intra_mode == 10 || tu.intra_mode == 26);
+    if (residualDpcm && tu.intra_mode == 26) residualDpcm = 2;
+  } else if (t->explicit_rdpcm_flag) residualDpcm = t->explicit_rdpcm_dir ? 2 : 1;
   if (cbf) {
     t->nCoeff[c] = tu.n_coeff;
     for (int k=0;k<tu.n_coeff;k++) {
       t->coeffList[c][k] = d->coeff_val[tu.coeff_offset+k];
       t->coeffPos[c][k]  = (int16_t)d->coeff_pos[tu.coeff_offset+k];
     }
+    scale_coefficients(t, tu.x0,tu.y0, tu.x0,tu.y0, nT, c, t->transform_skip_flag[c], intra, residualDpcm);
+  } else if (c != 0 && t->ResScaleVal) {            // cross-component prediction with CBF == 0 (slice.cc:3478-3487)
+    t->nCoeff[c] = 0;
     scale_coefficients(t, tu.x0,tu.y0, tu.x0,tu.y0, nT, c, t->transform_skip_flag[c], intra, 0);
   }
 }
@@ -367,12 +394,13 @@ static void do_pcm(ref_picture& R, const de265hip_picture_desc* d, int i)
 {
   const de265hip_pcm& p = d->pcms[i];
   const uint16_t* s = d->pcm_samples + p.sample_offset;
+  const int sw = R.sps->SubWidthC, sh = R.sps->SubHeightC;
   for (int c=0;c<3;c++) {
-    int n = (1<<p.log2_cb_size) >> (c?1:0);
-    int x0 = p.x0 >> (c?1:0), y0 = p.y0 >> (c?1:0);
+    int nw = (1<<p.log2_cb_size) / (c?sw:1), nh = (1<<p.log2_cb_size) / (c?sh:1);
+    int x0 = p.x0 / (c?sw:1), y0 = p.y0 / (c?sh:1);
     int stride = R.img->get_image_stride(c);
-    for (int y=0;y<n;y++)
-      for (int x=0;x<n;x++) {
+    for (int y=0;y<nh;y++)
+      for (int x=0;x<nw;x++) {
         if (R.bytes==2) ((uint16_t*)R.img->get_image_plane(c))[x0+x + (y0+y)*stride] = *s++;
         else            R.img->get_image_plane(c)[x0+x + (y0+y)*stride] = (uint8_t)*s++;
       }
@@ -416,7 +444,7 @@ int ref_reconstruct(const de265hip_picture_desc* d, const uint32_t* order, int n
   if (last_stage >= DE265HIP_STAGE_DEBLOCKED && !d->params.disable_deblocking) apply_deblocking_filter(R.img);
   if (last_stage >= DE265HIP_STAGE_FINAL && !d->params.disable_sao) apply_sample_adaptive_offset_sequential(R.img);
   for (int c=0;c<3;c++)
-    copy_out(R.img,c,img->plane[c],img->stride[c], c?R.w/2:R.w, c?R.h/2:R.h, R.bytes);
+    copy_out(R.img,c,img->plane[c],img->stride[c], c?R.cw:R.w, c?R.ch:R.h, R.bytes);
   if (out_deblk) {
     int w4 = (R.w+3)/4, h4 = (R.h+3)/4;
     for (int y=0;y<h4;y++) for (int x=0;x<w4;x++) out_deblk[x+y*w4] = R.img->get_deblk_flags(x<<2,y<<2);

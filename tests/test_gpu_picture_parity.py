@@ -105,11 +105,18 @@ def test_empty_picture_and_errors(dec):
     pic.free()
     d.n_tus = n_tus
     # unsupported / invalid parameters surface as de265_error codes, never as a fallback
-    d.params.chroma_format_idc = 3
+    # what is still refused of the range extensions: monochrome (the reference's inter path has no chroma planes to read) and
+    # extended_precision_processing (the reference hard-codes it off)
+    d.params.chroma_format_idc = 0
     with pytest.raises(backend.De265HipError) as e:
         dec.build(2, sp.desc)
     assert e.value.code == _abi.ERROR_NOT_IMPLEMENTED
     d.params.chroma_format_idc = 1
+    d.params.extended_precision_processing_flag = 1
+    with pytest.raises(backend.De265HipError) as e:
+        dec.build(2, sp.desc)
+    assert e.value.code == _abi.ERROR_NOT_IMPLEMENTED
+    d.params.extended_precision_processing_flag = 0
     d.tus[0].x0 = 4000
     with pytest.raises(backend.De265HipError) as e:
         dec.build(2, sp.desc)
@@ -709,5 +716,45 @@ def test_expired_dependency_wait_surfaces_as_decoding_error(monkeypatch):
         d.run(good, 2); d.sync()
         assert all(np.array_equal(g, e_) for g, e_ in zip(d.download(2, w, h, bd), exp))
         good.free()
+    finally:
+        d.close()
+
+
+@pytest.mark.parametrize("cf", [2, 3])
+@pytest.mark.parametrize("seed", range(6))
+def test_range_extension_pictures_against_the_oracle(seed, cf):
+    """SURVEY 8 f4 on random small pictures: 4:2:2 / 4:4:4, every stage, with the range-extension sample tools drawn at random
+    (cross-component prediction in 4:4:4, implicit / explicit RDPCM, rotation, transform skip up to 32x32, intra smoothing off,
+    high-precision offsets), next to tiles / slices / PCM / bypass / scaling lists / weighted prediction."""
+    rng = np.random.default_rng([seed, cf, 77])
+    w, h = [(208, 120), (352, 288), (416, 240)][seed % 3]
+    bd = int(rng.choice([8, 10, 12]))
+    over = dict(chroma_format=cf, tskip_pct=int(rng.integers(0, 50)), bypass_pct=int(rng.integers(0, 20)), pcm_pct=int(rng.integers(0, 10)),
+                implicit_rdpcm=int(rng.integers(0, 2)), explicit_rdpcm_pct=int(rng.choice([0, 50])), rotation=int(rng.integers(0, 2)),
+                log2_max_tskip_size=int(rng.integers(2, 6)), intra_smoothing_disabled=int(rng.integers(0, 2)),
+                high_precision_offsets=int(rng.integers(0, 2)), weighted_pred=int(rng.integers(0, 2)),
+                cross_component_pct=int(rng.choice([0, 60])) if cf == 3 else 0, scaling_list=int(rng.integers(0, 2)),
+                n_slices=int(rng.integers(1, 4)), lf_across_slices_pct=50, log2_ctb_size=int(rng.choice([4, 5, 6])),
+                intra_pct=int(rng.choice([15, 50])), big_coeff_pct=int(rng.choice([0, 3])))
+    if over["log2_ctb_size"] == 4:
+        over["log2_max_tb_size"] = 4
+    cfg = pysynth.default_config(w, h, bd, seed % 3, seed=5000 + 10 * seed + cf, **over)
+    sp = pysynth.SynthPicture(cfg)
+    d = backend.Decoder()
+    try:
+        refs = {0: pysynth.fill_planes(w, h, bd, 100 + seed, cf), 1: pysynth.fill_planes(w, h, bd, 200 + seed, cf)}
+        for slot, pl in refs.items():
+            d.dpb_alloc(slot, w, h, bd, chroma_format=cf); d.upload(slot, pl)
+        pic = d.build(2, sp.desc)
+        for stage in (0, 1, 2):
+            init = pysynth.fill_planes(w, h, bd, 999, cf)
+            exp = [p.copy() for p in init]
+            pyoracle.reconstruct(sp.desc, sp.order, refs, exp, last_stage=stage)
+            d.upload(2, init); d.run(pic, stage); d.sync()
+            got = d.download(2, w, h, bd)
+            for c in range(3):
+                bad = np.argwhere(got[c] != exp[c])
+                assert bad.size == 0, "cf %d seed %d stage %d comp %d: %d mismatches, first at %s (%s)" % (cf, seed, stage, c, len(bad), tuple(bad[0]), over)
+        pic.free()
     finally:
         d.close()

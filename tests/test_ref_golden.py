@@ -146,11 +146,11 @@ def dec():
 
 def _gpu_picture_digests(dec, case):
     sp, refs, init = ref_cases.make_picture(case)
-    w, h, bd = case["w"], case["h"], case["bd"]
+    w, h, bd, cf = case["w"], case["h"], case["bd"], case.get("chroma_format", 1)
     for s, pl in refs.items():
-        dec.dpb_alloc(s, w, h, bd)
+        dec.dpb_alloc(s, w, h, bd, chroma_format=cf)
         dec.upload(s, pl)
-    dec.dpb_alloc(2, w, h, bd)
+    dec.dpb_alloc(2, w, h, bd, chroma_format=cf)
     pic = dec.build(2, sp.desc)
     out = {}
     try:

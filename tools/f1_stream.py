@@ -27,7 +27,9 @@ _DTYPE = {"coeff_val": np.int16, "coeff_pos": np.uint16, "pcm_samples": np.uint1
 
 class RecordedPicture:
     def __init__(self, params_bytes, meta, arrays):
-        self.params_bytes = bytes(params_bytes)
+        # (fixtures recorded before the range-extension fields were appended to de265hip_pic_params hold the shorter struct:
+        #  the new fields are all 0 for Main / Main10 streams)
+        self.params_bytes = bytes(params_bytes).ljust(C.sizeof(_abi.PicParams), b"\0")
         self.meta = dict(meta)                 # dst_slot, poc, counts
         self.a = {k: np.ascontiguousarray(v) for k, v in arrays.items()}     # raw uint8 for struct sections
         self._keep = None
@@ -67,7 +69,8 @@ class RecordedPicture:
 
 def _plane_shapes(P):
     dt = np.uint16 if P.bit_depth_luma > 8 else np.uint8
-    return [((P.height, P.width), dt), ((P.height // 2, P.width // 2), dt), ((P.height // 2, P.width // 2), dt)]
+    cw, ch = P.width // (1 if P.chroma_format_idc == 3 else 2), P.height // (2 if P.chroma_format_idc == 1 else 1)
+    return [((P.height, P.width), dt), ((ch, cw), dt), ((ch, cw), dt)]
 
 
 def load_dump(path):

@@ -32,6 +32,9 @@ class SynthConfig(C.Structure):
         ("lf_across_slices_pct", C.c_int32), ("lf_across_tiles", C.c_int32),
         ("big_coeff_pct", C.c_int32), ("qp_min", C.c_int32), ("qp_max", C.c_int32),
         ("amp", C.c_int32), ("split_bias", C.c_int32),
+        ("chroma_format", C.c_int32), ("cross_component_pct", C.c_int32), ("implicit_rdpcm", C.c_int32),
+        ("explicit_rdpcm_pct", C.c_int32), ("rotation", C.c_int32), ("intra_smoothing_disabled", C.c_int32),
+        ("log2_max_tskip_size", C.c_int32), ("high_precision_offsets", C.c_int32),
     ]
 
 
@@ -136,11 +139,17 @@ class SynthPicture:
             pass
 
 
-def fill_planes(width, height, bit_depth, seed):
+def chroma_dims(width, height, chroma_format=1):
+    """(w, h) of a chroma plane: SubWidthC / SubHeightC of sps.cc:540-552"""
+    return (width // (2 if chroma_format in (1, 2) else 1), height // (2 if chroma_format == 1 else 1))
+
+
+def fill_planes(width, height, bit_depth, seed, chroma_format=1):
     """Seeded reference picture [y, cb, cr] (noise + gradient)."""
     dt = np.uint16 if bit_depth > 8 else np.uint8
     out = []
-    for c, (w, h) in enumerate([(width, height), (width // 2, height // 2), (width // 2, height // 2)]):
+    cw, ch = chroma_dims(width, height, chroma_format)
+    for c, (w, h) in enumerate([(width, height), (cw, ch), (cw, ch)]):
         a = np.zeros((h, w), dt)
         lib().synth_fill_plane(a.ctypes.data, w, w, h, bit_depth, seed * 3 + c)
         out.append(a)

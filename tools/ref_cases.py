@@ -77,6 +77,28 @@ PICTURE_CASES = [
     dict(name="1080p8_B_config3", w=1920, h=1080, bd=8, st=0, seed=0xDE265003, weighted_pred=1),
     dict(name="4k10_I_config4", w=3840, h=2160, bd=10, st=2, seed=0xDE265004),
     dict(name="4k10_B_config4", w=3840, h=2160, bd=10, st=0, seed=0xDE265005),
+    # 4:2:2 / 4:4:4 at 8 and 10 bit, I and B; the range-extension sample tools the reference implements
+    # (cross-component prediction, implicit / explicit RDPCM, transform-skip rotation, transform skip up to 32x32,
+    # intra smoothing switched off, high-precision weighting offsets)
+    dict(name="cif8_I_422", w=352, h=288, bd=8, st=2, seed=3001, chroma_format=2),
+    dict(name="cif10_B_422", w=352, h=288, bd=10, st=0, seed=3002, chroma_format=2, weighted_pred=1),
+    dict(name="cif8_B_444", w=352, h=288, bd=8, st=0, seed=3003, chroma_format=3),
+    dict(name="cif10_I_444", w=352, h=288, bd=10, st=2, seed=3004, chroma_format=3),
+    dict(name="cif8_P_422_features", w=352, h=288, bd=8, st=1, seed=3005, chroma_format=2, pcm_loop_filter_disable=1, scaling_list=1,
+         n_slices=3, lf_across_slices_pct=50, **_F),
+    dict(name="wvga10_B_444_tiles_slices", w=832, h=480, bd=10, st=0, seed=3006, chroma_format=3, tile_cols=3, tile_rows=2,
+         slice_per_tile=1, lf_across_tiles=0, lf_across_slices_pct=0, **_F),
+    dict(name="cif8_I_444_rext", w=352, h=288, bd=8, st=2, seed=3007, chroma_format=3, tskip_pct=40, bypass_pct=15, pcm_pct=5,
+         implicit_rdpcm=1, rotation=1, log2_max_tskip_size=5, cross_component_pct=60, big_coeff_pct=2),
+    dict(name="cif10_B_444_rext", w=352, h=288, bd=10, st=0, seed=3008, chroma_format=3, tskip_pct=40, bypass_pct=15,
+         implicit_rdpcm=1, explicit_rdpcm_pct=50, rotation=1, log2_max_tskip_size=5, cross_component_pct=60, weighted_pred=1,
+         high_precision_offsets=1, n_slices=2, lf_across_slices_pct=50),
+    dict(name="cif10_P_422_rext", w=352, h=288, bd=10, st=1, seed=3009, chroma_format=2, tskip_pct=40, bypass_pct=15,
+         implicit_rdpcm=1, explicit_rdpcm_pct=50, rotation=1, log2_max_tskip_size=4, intra_smoothing_disabled=1, intra_pct=40),
+    dict(name="cif8_B_420_rext", w=352, h=288, bd=8, st=0, seed=3010, tskip_pct=40, bypass_pct=15, implicit_rdpcm=1,
+         explicit_rdpcm_pct=50, rotation=1, log2_max_tskip_size=5, intra_smoothing_disabled=1, intra_pct=40, scaling_list=1),
+    dict(name="1080p10_B_444_rext", w=1920, h=1080, bd=10, st=0, seed=3011, chroma_format=3, tskip_pct=20, bypass_pct=5,
+         implicit_rdpcm=1, explicit_rdpcm_pct=30, rotation=1, log2_max_tskip_size=5, cross_component_pct=40),
 ]
 # three cases whose final planes are stored in full (tests/golden/ref_small_pictures.npz)
 FULL_PICTURE_CASES = ["qcif8_I", "qcif10_B", "ctb16_12_B"]
@@ -95,8 +117,9 @@ def make_picture(c):
     over = {k: v for k, v in c.items() if k not in ("name", "w", "h", "bd", "st", "seed")}
     sp = pysynth.SynthPicture(pysynth.default_config(c["w"], c["h"], c["bd"], c["st"], seed=c["seed"], **over))
     s = c["seed"] & 0xFFFF
-    refs = {0: pysynth.fill_planes(c["w"], c["h"], c["bd"], s + 1), 1: pysynth.fill_planes(c["w"], c["h"], c["bd"], s + 2)}
-    init = pysynth.fill_planes(c["w"], c["h"], c["bd"], s + 3)
+    cf = c.get("chroma_format", 1)
+    refs = {0: pysynth.fill_planes(c["w"], c["h"], c["bd"], s + 1, cf), 1: pysynth.fill_planes(c["w"], c["h"], c["bd"], s + 2, cf)}
+    init = pysynth.fill_planes(c["w"], c["h"], c["bd"], s + 3, cf)
     return sp, refs, init
 
 

@@ -63,7 +63,8 @@ struct synth_picture {
   uint8_t* scaling;
   /* per-CU state */
   int cur_slice, cur_qp, cur_bypass, cur_intra, cur_deblk_off;
-  int cu_luma_mode[4], cu_chroma_mode;
+  int cu_luma_mode[4], cu_chroma_mode[4], cu_chroma_derived[4];   /* chroma modes per PU quadrant (4:4:4 NxN: four; else [0]); derived: intra_chroma_pred_mode == 4 */
+  int cf, sw, sh;                       /* chroma_format_idc, SubWidthC, SubHeightC */
 };
 
 static int clip3i(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -141,26 +142,31 @@ static void gen_coeffs(synth_picture* s, de265hip_tu* tu)
 }
 
 /* ---------- TU emission ---------- */
-static void emit_tu(synth_picture* s, int x0, int y0, int log2, int cIdx, int cbf, int mode)
+static void emit_tu(synth_picture* s, int x0, int y0, int log2, int cIdx, int cbf, int mode, int res_scale)
 {
   const synth_config* g = &s->cfg;
-  if (!s->cur_intra && !cbf) return;                     /* nothing to do for inter TU without residual */
+  if (!s->cur_intra && !cbf && !res_scale) return;       /* nothing to do for inter TU without residual */
   de265hip_tu tu; memset(&tu, 0, sizeof(tu));
   tu.x0 = (uint16_t)x0; tu.y0 = (uint16_t)y0; tu.log2_size = (uint8_t)log2; tu.c_idx = (uint8_t)cIdx;
   tu.flags = (uint8_t)((s->cur_intra ? DE265HIP_TU_INTRA : 0) | (cbf ? DE265HIP_TU_CBF : 0) |
                        (s->cur_bypass ? DE265HIP_TU_BYPASS : 0));
   tu.intra_mode = (uint8_t)mode;
+  tu.res_scale_val = (int8_t)res_scale;
   int qpbd = 6 * (g->bit_depth - 8);
   if (cIdx == 0) tu.qp = (int8_t)(s->cur_qp + qpbd);
   else {
     int off = cIdx == 1 ? s->desc.params.pic_cb_qp_offset : s->desc.params.pic_cr_qp_offset;
-    int qpi = clip3i(-qpbd, 57, s->cur_qp + off);       /* transform.cc:149-172 */
-    tu.qp = (int8_t)(table8_22(qpi) + qpbd);
+    int qpi = clip3i(-qpbd, 57, s->cur_qp + off);       /* transform.cc:149-172: the table only in 4:2:0 */
+    tu.qp = (int8_t)((s->cf == 1 ? table8_22(qpi) : qpi) + qpbd);
   }
   if (cbf) {
-    if (log2 == 2 && !s->cur_bypass && rnd_pct(&s->rng, g->tskip_pct)) tu.flags |= DE265HIP_TU_TSKIP;
+    int max_ts = g->log2_max_tskip_size > 2 ? g->log2_max_tskip_size : 2;
+    if (log2 <= max_ts && !s->cur_bypass && rnd_pct(&s->rng, g->tskip_pct)) tu.flags |= DE265HIP_TU_TSKIP;
+    /* explicit RDPCM: inter CU, transform skip or bypass (slice.cc:3313-3330) */
+    if (g->explicit_rdpcm_pct > 0 && !s->cur_intra && (s->cur_bypass || (tu.flags & DE265HIP_TU_TSKIP)) && rnd_pct(&s->rng, g->explicit_rdpcm_pct))
+      tu.flags |= (uint8_t)(DE265HIP_TU_EXPLICIT_RDPCM | (rnd_pct(&s->rng, 50) ? DE265HIP_TU_EXPLICIT_RDPCM_VERT : 0));
     gen_coeffs(s, &tu);
-    if (tu.n_coeff == 0) tu.flags &= (uint8_t)~(DE265HIP_TU_CBF | DE265HIP_TU_TSKIP);
+    if (tu.n_coeff == 0) tu.flags &= (uint8_t)~(DE265HIP_TU_CBF | DE265HIP_TU_TSKIP | DE265HIP_TU_EXPLICIT_RDPCM | DE265HIP_TU_EXPLICIT_RDPCM_VERT);
   }
   VPUSH(s->order, ORD_TU | (uint32_t)s->tus.n);
   VPUSH(s->tus, tu);
@@ -195,22 +201,43 @@ static void gen_ttree(synth_picture* s, int x0, int y0, int xBase, int yBase, in
     for (int k = 0; k < (1 << log2); k += 4) set_edge(s, x0, y0 + k, left);
     for (int k = 0; k < (1 << log2); k += 4) set_edge(s, x0 + k, y0, top);
   }
-  /* luma intra mode of the PU covering this TU */
-  int lmode = 0;
+  /* luma / chroma intra mode of the PU covering this TU */
+  int lmode = 0, cmode = 0, pidx = 0;
   if (s->cur_intra) {
     int h2 = 1 << (log2Cb - 1);
-    int pidx = ((x0 - cuX) >= h2 ? 1 : 0) + ((y0 - cuY) >= h2 ? 2 : 0);
+    pidx = ((x0 - cuX) >= h2 ? 1 : 0) + ((y0 - cuY) >= h2 ? 2 : 0);
     lmode = s->cu_luma_mode[pidx];
+    cmode = s->cu_chroma_mode[s->cf == 3 ? pidx : 0];
   }
   int cbfY = rnd_pct(&s->rng, g->cbf_pct);
+  /* chroma cbf: bit 0 the (upper) chroma TU, bit 1 the lower one of 4:2:2 (slice.cc:3699-3750) */
   int cbfCb = rnd_pct(&s->rng, g->cbf_pct * 2 / 3), cbfCr = rnd_pct(&s->rng, g->cbf_pct * 2 / 3);
-  emit_tu(s, x0, y0, log2, 0, cbfY, lmode);
-  if (log2 > 2) {
-    emit_tu(s, x0/2, y0/2, log2-1, 1, cbfCb, s->cu_chroma_mode);
-    emit_tu(s, x0/2, y0/2, log2-1, 2, cbfCr, s->cu_chroma_mode);
+  int cbfCb2 = 0, cbfCr2 = 0;                            /* (drawn for 4:2:2 only: the 4:2:0 pictures of a seed stay what they were) */
+  if (s->cf == 2) { cbfCb2 = rnd_pct(&s->rng, g->cbf_pct * 2 / 3); cbfCr2 = rnd_pct(&s->rng, g->cbf_pct * 2 / 3); }
+  int n_before = s->tus.n;
+  emit_tu(s, x0, y0, log2, 0, cbfY, lmode, 0);
+  int luma_cbf = s->tus.n > n_before && (s->tus.p[s->tus.n - 1].flags & DE265HIP_TU_CBF) && s->tus.p[s->tus.n - 1].c_idx == 0;
+  if (s->cf == 3) {
+    /* 4:4:4: chroma TUs of the luma TU's size, cross-component prediction when the luma TU has coefficients and the CU is
+     * inter or its chroma mode is derived (intra_chroma_pred_mode 4), slice.cc:3672-3684 */
+    int elig = g->cross_component_pct > 0 && luma_cbf && (!s->cur_intra || s->cu_chroma_derived[pidx]);
+    static const int rsv[8] = { 1, 2, 4, 8, -1, -2, -4, -8 };
+    int rCb = (elig && rnd_pct(&s->rng, g->cross_component_pct)) ? rsv[rnd_int(&s->rng, 0, 7)] : 0;
+    int rCr = (elig && rnd_pct(&s->rng, g->cross_component_pct)) ? rsv[rnd_int(&s->rng, 0, 7)] : 0;
+    emit_tu(s, x0, y0, log2, 1, cbfCb, cmode, rCb);
+    emit_tu(s, x0, y0, log2, 2, cbfCr, cmode, rCr);
+  } else if (log2 > 2) {
+    int xc = x0 / s->sw, yc = y0 / s->sh, nC = 1 << (log2 - 1);
+    emit_tu(s, xc, yc, log2-1, 1, cbfCb, cmode, 0);
+    if (s->cf == 2) emit_tu(s, xc, yc + nC, log2-1, 1, cbfCb2, cmode, 0);
+    emit_tu(s, xc, yc, log2-1, 2, cbfCr, cmode, 0);
+    if (s->cf == 2) emit_tu(s, xc, yc + nC, log2-1, 2, cbfCr2, cmode, 0);
   } else if (blkIdx == 3) {
-    emit_tu(s, xBase/2, yBase/2, 2, 1, cbfCb, s->cu_chroma_mode);
-    emit_tu(s, xBase/2, yBase/2, 2, 2, cbfCr, s->cu_chroma_mode);
+    int xc = xBase / s->sw, yc = yBase / s->sh;
+    emit_tu(s, xc, yc, 2, 1, cbfCb, cmode, 0);
+    if (s->cf == 2) emit_tu(s, xc, yc + 4, 2, 1, cbfCb2, cmode, 0);
+    emit_tu(s, xc, yc, 2, 2, cbfCr, cmode, 0);
+    if (s->cf == 2) emit_tu(s, xc, yc + 4, 2, 2, cbfCr2, cmode, 0);
   }
 }
 
@@ -297,7 +324,7 @@ static void gen_cu(synth_picture* s, int x0, int y0, int log2Cb)
     pc.x0 = (uint16_t)x0; pc.y0 = (uint16_t)y0; pc.log2_cb_size = (uint8_t)log2Cb;
     pc.sample_offset = (uint32_t)s->pcm_samples.n;
     int pcm_bits = g->bit_depth - rnd_int(r, 0, 2);
-    int n = cb*cb + 2*(cb/2)*(cb/2);
+    int n = cb*cb + 2*(cb/s->sw)*(cb/s->sh);
     for (int i = 0; i < n; i++)
       VPUSH(s->pcm_samples, (uint16_t)(rnd_int(r, 0, (1 << pcm_bits) - 1) << (g->bit_depth - pcm_bits)));
     VPUSH(s->order, ORD_PCM | (uint32_t)s->pcms.n);
@@ -318,7 +345,13 @@ static void gen_cu(synth_picture* s, int x0, int y0, int log2Cb)
     /* favour the modes with special filters */
     if (rnd_pct(r, 25)) { static const int fav[5] = { 0, 1, 10, 26, 34 }; s->cu_luma_mode[0] = fav[rnd_int(r, 0, 4)];
       if (!nxn) s->cu_luma_mode[1] = s->cu_luma_mode[2] = s->cu_luma_mode[3] = s->cu_luma_mode[0]; }
-    s->cu_chroma_mode = rnd_pct(r, 40) ? s->cu_luma_mode[0] : rnd_int(r, 0, 34);
+    /* one chroma mode per CU, except NxN in 4:4:4: one per PU (slice.cc:4440-4470) */
+    for (int i = 0; i < ((nxn && s->cf == 3) ? 4 : 1); i++) {
+      s->cu_chroma_derived[i] = rnd_pct(r, 40);
+      s->cu_chroma_mode[i] = s->cu_chroma_derived[i] ? s->cu_luma_mode[i] : rnd_int(r, 0, 34);
+    }
+    if (!(nxn && s->cf == 3))
+      for (int i = 1; i < 4; i++) { s->cu_chroma_mode[i] = s->cu_chroma_mode[0]; s->cu_chroma_derived[i] = s->cu_chroma_derived[0]; }
     if (nxn && !s->cur_deblk_off)
       for (int k = 0; k < cb; k++) {
         set_edge(s, x0 + cb/2, y0 + k, DE265HIP_BLK_EDGE_PB_V);
@@ -358,7 +391,7 @@ static void gen_cu(synth_picture* s, int x0, int y0, int log2Cb)
       }
   int root_cbf = rnd_pct(r, 70);
   if (root_cbf) {
-    s->cu_chroma_mode = 0; memset(s->cu_luma_mode, 0, sizeof(s->cu_luma_mode));
+    memset(s->cu_chroma_mode, 0, sizeof(s->cu_chroma_mode)); memset(s->cu_luma_mode, 0, sizeof(s->cu_luma_mode));
     gen_ttree(s, x0, y0, x0, y0, log2Cb, 0, 0, 0, left, top, x0, y0, log2Cb);
   } else if (!s->cur_deblk_off) {
     /* rqt_root_cbf==0: no transform tree is read (slice.cc:4551-4574), all
@@ -393,7 +426,17 @@ synth_picture* synth_generate(const synth_config* cfg)
   de265hip_pic_params* P = &s->desc.params;
   P->width = g->width; P->height = g->height;
   P->bit_depth_luma = P->bit_depth_chroma = g->bit_depth;
-  P->chroma_format_idc = 1;
+  s->cf = g->chroma_format ? g->chroma_format : 1;
+  /* 4:4:4 with scaling lists: no 32x32 TUs.  The reference indexes ScalingFactor_Size3[matrixID] with matrixID up to 5 for a
+   * 32x32 chroma TU although the array holds two matrices (transform.cc:487-493, sps.h:57): undefined, nothing to be pinned to. */
+  if (s->cf == 3 && g->scaling_list && s->cfg.log2_max_tb_size > 4) s->cfg.log2_max_tb_size = 4;
+  s->sw = s->cf == 3 ? 1 : 2; s->sh = s->cf == 1 ? 2 : 1;
+  P->chroma_format_idc = s->cf;
+  P->implicit_rdpcm_enabled_flag = g->implicit_rdpcm;
+  P->transform_skip_rotation_enabled_flag = g->rotation;
+  P->intra_smoothing_disabled_flag = g->intra_smoothing_disabled;
+  P->cross_component_prediction_enabled_flag = (s->cf == 3 && g->cross_component_pct > 0);
+  P->high_precision_offsets_enabled_flag = g->high_precision_offsets;
   P->log2_ctb_size = g->log2_ctb_size; P->log2_min_cb_size = 3; P->log2_min_tb_size = g->log2_min_tb_size;
   P->pcm_loop_filter_disable_flag = g->pcm_loop_filter_disable;
   P->strong_intra_smoothing_enable_flag = g->strong_intra_smoothing;

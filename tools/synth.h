@@ -47,6 +47,15 @@ typedef struct synth_config {
   int32_t qp_min, qp_max;       /* QP_Y range */
   int32_t amp;                  /* allow asymmetric partitions */
   int32_t split_bias;           /* 0..100, higher = smaller blocks */
+  /* range extensions; all 0 = Main / Main10 */
+  int32_t chroma_format;        /* 0 -> 1 (4:2:0); 2 = 4:2:2, 3 = 4:4:4 */
+  int32_t cross_component_pct;  /* 4:4:4: % of eligible TUs (luma cbf, inter CU or chroma mode 4) with ResScaleVal != 0 per chroma component */
+  int32_t implicit_rdpcm;       /* sps flag */
+  int32_t explicit_rdpcm_pct;   /* % of inter transform-skip / bypass TUs with explicit_rdpcm_flag (sets the sps flag when > 0) */
+  int32_t rotation;             /* transform_skip_rotation_enabled_flag */
+  int32_t intra_smoothing_disabled;
+  int32_t log2_max_tskip_size;  /* 0 -> 2; transform skip on TUs up to this size (tskip_pct applies) */
+  int32_t high_precision_offsets;
 } synth_config;
 
 typedef struct synth_picture synth_picture;
