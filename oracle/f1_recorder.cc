@@ -114,8 +114,8 @@ void merge_records(std::vector<Rec>& recs, PicRec& M)
   for (const Ref& o : order) {
     const Rec& R = *all_recs[o.rec];
     de265hip_pcm pc = R.pcms[o.idx];
-    const int n = 1 << pc.log2_cb_size, cnt = n*n + 2*(n/2)*(n/2);
-    const uint32_t src = pc.sample_offset;
+    const uint32_t src = pc.sample_offset;                 // luma + both chroma blocks, sized by the chroma format
+    const uint32_t cnt = (o.idx+1 < R.pcms.size() ? R.pcms[o.idx+1].sample_offset : (uint32_t)R.pcm_samples.size()) - src;
     pc.sample_offset = (uint32_t)M.pcm_samples.size();
     M.pcm_samples.insert(M.pcm_samples.end(), R.pcm_samples.begin()+src, R.pcm_samples.begin()+src+cnt);
     M.pcms.push_back(pc);
@@ -133,7 +133,7 @@ struct Hip {
   void* lib = nullptr;
   de265hip_decoder* dec = nullptr;
   int  (*decoder_new)(de265hip_decoder**, int);
-  int  (*dpb_alloc)(de265hip_decoder*, int, int, int, int, int);
+  int  (*dpb_alloc)(de265hip_decoder*, int, int, int, int, int, int);      // de265hip_dpb_alloc_ex
   int  (*dpb_download)(de265hip_decoder*, int, int, void*, ptrdiff_t);
   int  (*recorder_new)(de265hip_recorder**, const de265hip_pic_params*, const uint8_t*);
   void (*recorder_free)(de265hip_recorder*);
@@ -174,7 +174,7 @@ bool hip_mode()
   H.lib = dlopen(path ? path : "libde265_hip.so", RTLD_NOW);
   if (!H.lib) { fprintf(stderr, "f1_recorder: %s\n", dlerror()); exit(6); }
 #define SYM(f) do { *(void**)&H.f = dlsym(H.lib, "de265hip_" #f); if (!H.f) hip_die("dlsym de265hip_" #f, 0); } while (0)
-  SYM(decoder_new); SYM(dpb_alloc); SYM(dpb_download); SYM(recorder_new); SYM(recorder_free); SYM(record_tu); SYM(record_pu);
+  SYM(decoder_new); *(void**)&H.dpb_alloc = dlsym(H.lib, "de265hip_dpb_alloc_ex"); if (!H.dpb_alloc) hip_die("dlsym de265hip_dpb_alloc_ex", 0); SYM(dpb_download); SYM(recorder_new); SYM(recorder_free); SYM(record_tu); SYM(record_pu);
   SYM(record_pcm); SYM(record_slice); SYM(record_ctb); SYM(record_blk_planes); SYM(recorder_submit); SYM(picture_run);
   SYM(decoder_sync); SYM(picture_free); SYM(dpb_download_async); SYM(dpb_wait); SYM(host_alloc); SYM(host_free);
   SYM(pipeline_new); SYM(pipeline_submit); SYM(pipeline_wait); SYM(pipeline_drain); SYM(pipeline_free);
@@ -272,6 +272,13 @@ void prepare_job(Job* job, bool hip)
   for (int i=0;i<=pps.num_tile_rows && i<24;i++) P.row_bd[i] = (uint16_t)pps.rowBd[i];
   P.disable_deblocking = img->decctx->param_disable_deblocking;
   P.disable_sao = img->decctx->param_disable_sao;
+  // range extensions: what the sample paths read of sps / pps_range_extension
+  P.implicit_rdpcm_enabled_flag = sps.range_extension.implicit_rdpcm_enabled_flag;
+  P.transform_skip_rotation_enabled_flag = sps.range_extension.transform_skip_rotation_enabled_flag;
+  P.intra_smoothing_disabled_flag = sps.range_extension.intra_smoothing_disabled_flag;
+  P.cross_component_prediction_enabled_flag = pps.range_extension.cross_component_prediction_enabled_flag;
+  P.extended_precision_processing_flag = sps.range_extension.extended_precision_processing_flag;
+  P.high_precision_offsets_enabled_flag = sps.range_extension.high_precision_offsets_enabled_flag;
 
   const int w4 = (P.width+3)/4, h4 = (P.height+3)/4, nctb = sps.PicSizeInCtbsY;
   const uint8_t* scaling = sps.scaling_list_enable_flag ? (const uint8_t*)&pps.scaling_list : NULL;      // transform.cc:487-493
@@ -351,7 +358,7 @@ void build_job(Job& j)
   const double t1 = now_s();
   {                                                                 // slot allocation belongs to one thread at a time
     static std::mutex am; std::lock_guard<std::mutex> lk(am);
-    if ((rc = H.dpb_alloc(H.dec, j.slot, j.P.width, j.P.height, j.P.bit_depth_luma, j.P.bit_depth_chroma))) hip_die("dpb_alloc", rc);
+    if ((rc = H.dpb_alloc(H.dec, j.slot, j.P.width, j.P.height, j.P.bit_depth_luma, j.P.bit_depth_chroma, j.P.chroma_format_idc))) hip_die("dpb_alloc", rc);
   }
   if ((rc = H.recorder_submit(H.dec, j.slot, rec, &j.pic))) hip_die("recorder_submit", rc);
   static std::mutex pm; std::lock_guard<std::mutex> lk(pm);
@@ -505,7 +512,8 @@ bool f1_record_tu(thread_context* tctx, int x0, int y0, int nT, int cIdx, int cu
 {
   if (passive()) return false;
   const bool intra = cuPredMode == MODE_INTRA;
-  if (!intra && !cbf) return hip_mode();                          // decode_TU does nothing for it (slice.cc:3424-3488)
+  const int rsv = cIdx ? tctx->ResScaleVal : 0;                   // cross-component prediction acts on a chroma TU without coefficients too (slice.cc:3478-3487)
+  if (!intra && !cbf && !rsv) return hip_mode();                  // decode_TU does nothing for it (slice.cc:3424-3488)
   de265_image* img = tctx->img;
   const seq_parameter_set& sps = img->get_sps();
   de265hip_tu t; memset(&t,0,sizeof(t));
@@ -514,7 +522,9 @@ bool f1_record_tu(thread_context* tctx, int x0, int y0, int nT, int cIdx, int cu
   t.log2_size = (uint8_t)l2;
   t.flags = (uint8_t)((intra ? DE265HIP_TU_INTRA : 0) | (cbf ? DE265HIP_TU_CBF : 0) |
                       (tctx->transform_skip_flag[cIdx] && cbf ? DE265HIP_TU_TSKIP : 0) |
-                      (tctx->cu_transquant_bypass_flag ? DE265HIP_TU_BYPASS : 0));
+                      (tctx->cu_transquant_bypass_flag ? DE265HIP_TU_BYPASS : 0) |
+                      (!intra && cbf && tctx->explicit_rdpcm_flag ? DE265HIP_TU_EXPLICIT_RDPCM | (tctx->explicit_rdpcm_dir ? DE265HIP_TU_EXPLICIT_RDPCM_VERT : 0) : 0));
+  t.res_scale_val = (int8_t)rsv;
   if (intra) {                                         // slice.cc:3436-3451
     int m = cIdx==0 ? img->get_IntraPredMode(x0,y0) : img->get_IntraPredModeC(x0*sps.SubWidthC, y0*sps.SubHeightC);
     if (m<0 || m>=35) m = INTRA_DC;
@@ -559,8 +569,10 @@ void f1_record_pcm(thread_context* tctx, int x0, int y0, int log2CbSize)
   Rec& R = mine();
   p.sample_offset = (uint32_t)R.pcm_samples.size();
   for (int c=0;c<3;c++) {                              // the samples as read_pcm_samples_internal stored them (already << shift)
-    const int n = (1<<log2CbSize) >> (c?1:0), xx = x0 >> (c?1:0), yy = y0 >> (c?1:0), stride = img->get_image_stride(c);
-    for (int y=0;y<n;y++) for (int x=0;x<n;x++)
+    const seq_parameter_set& sps = img->get_sps();
+    const int sw = c ? sps.SubWidthC : 1, sh = c ? sps.SubHeightC : 1;
+    const int n = (1<<log2CbSize) / sw, nh = (1<<log2CbSize) / sh, xx = x0 / sw, yy = y0 / sh, stride = img->get_image_stride(c);
+    for (int y=0;y<nh;y++) for (int x=0;x<n;x++)
       R.pcm_samples.push_back(img->high_bit_depth(c) ? ((const uint16_t*)img->get_image_plane(c))[xx+x+(yy+y)*stride]
                                                       : img->get_image_plane(c)[xx+x+(yy+y)*stride]);
   }

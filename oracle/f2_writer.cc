@@ -58,6 +58,14 @@ struct Cfg {
   int dep = 0;                        /* percent: a cut point inside a slice starts a DEPENDENT slice segment (7.3.6.1, 9.3.1) */
   int scaling = 0;                    /* 1: scaling lists on, default lists (sps); 2: explicit lists in the PPS (7.3.4 scaling_list_data) */
   int dens = 50;                      /* percent: how often cbf flags are set */
+  /* range extensions: chroma format and the sample tools of sps / pps_range_extension the reference implements */
+  int chroma = 1;                     /* chroma_format_idc: 1, 2 (4:2:2), 3 (4:4:4) */
+  int xcc = 0;                        /* cross_component_prediction_enabled_flag (4:4:4) */
+  int irdpcm = 0, erdpcm = 0;         /* implicit / explicit_rdpcm_enabled_flag */
+  int rot = 0;                        /* transform_skip_rotation_enabled_flag */
+  int tskip_log2 = 2;                 /* log2_max_transform_skip_block_size */
+  int nosmooth = 0;                   /* intra_smoothing_disabled_flag */
+  int hpo = 0;                        /* high_precision_offsets_enabled_flag */
 };
 
 struct Kv { const char* k; int Cfg::* p; };
@@ -72,6 +80,8 @@ const Kv KV[] = {
   {"merge_cand",&Cfg::merge_cand},{"par_mrg",&Cfg::par_mrg},{"nref",&Cfg::nref},{"max_level",&Cfg::max_level},
   {"big_mv",&Cfg::big_mv},{"dens",&Cfg::dens},{"wpp",&Cfg::wpp},{"tile_cols",&Cfg::tile_cols},{"tile_rows",&Cfg::tile_rows},
   {"tile_uniform",&Cfg::tile_uniform},{"lf_tiles",&Cfg::lf_tiles},{"md5",&Cfg::md5},{"scaling",&Cfg::scaling},{"dep",&Cfg::dep},{"idr_period",&Cfg::idr_period},
+  {"chroma",&Cfg::chroma},{"xcc",&Cfg::xcc},{"irdpcm",&Cfg::irdpcm},{"erdpcm",&Cfg::erdpcm},{"rot",&Cfg::rot},{"tskip_log2",&Cfg::tskip_log2},
+  {"nosmooth",&Cfg::nosmooth},{"hpo",&Cfg::hpo},
 };
 
 [[noreturn]] void die(const char* msg) { fprintf(stderr, "f2_writer: %s\n", msg); exit(2); }
@@ -145,12 +155,13 @@ struct Writer {
 
   int W4, H4, ctbW, ctbH, nCtb;
   std::vector<uint8_t> ct_depth, skipf, pmode, pcmf, ipm;       /* per 4x4 block */
+  std::vector<uint8_t> ipmc, ipmc4;                             /* IntraPredModeC (4:2:2: after Table 8-3), intra_chroma_pred_mode == 4 */
+  bool rext() const { return c.chroma != 1 || c.xcc || c.irdpcm || c.erdpcm || c.rot || c.tskip_log2 > 2 || c.nosmooth || c.hpo; }
   std::vector<int> ctb_slice;                                   /* SliceAddrRS per CTB of the current picture, -1: not yet coded */
   SliceCtx S;
   struct Stats { long n_coeffs=0, abs_sum=0, n_pus=0, n_pcms=0, n_cus=0, n_resid=0; } st;   /* per picture, for the .chk sidecar */
   FILE* fchk = nullptr;
   bool qpd_coded = false;
-  int chroma_mode_cu = 0;                                       /* IntraPredModeC of the CU being coded */
 
   explicit Writer(const Cfg& cfg) : c(cfg), rng(cfg.seed) {}
 
@@ -176,6 +187,15 @@ struct Writer {
     sps->profile_tier_level_.general.set_defaults(c.bits > 8 ? Profile_Main10 : Profile_Main, 6, 2);
     sps->set_resolution(c.w, c.h);
     sps->bit_depth_luma = sps->bit_depth_chroma = c.bits;
+    sps->chroma_format_idc = c.chroma;
+    if (rext()) {
+      sps->sps_extension_present_flag = 1; sps->sps_range_extension_flag = 1;
+      sps->range_extension.transform_skip_rotation_enabled_flag = c.rot;
+      sps->range_extension.implicit_rdpcm_enabled_flag = c.irdpcm;
+      sps->range_extension.explicit_rdpcm_enabled_flag = c.erdpcm;
+      sps->range_extension.intra_smoothing_disabled_flag = c.nosmooth;
+      sps->range_extension.high_precision_offsets_enabled_flag = c.hpo;
+    }
     sps->sps_max_dec_pic_buffering[0] = 6; sps->sps_max_num_reorder_pics[0] = 4;
     sps->set_CB_log2size_range(c.log2mincb, c.log2ctb);
     sps->set_TB_log2size_range(c.log2mintb, c.log2maxtb);
@@ -208,6 +228,11 @@ struct Writer {
     pps->lists_modification_present_flag = c.lists_mod; pps->log2_parallel_merge_level = c.par_mrg;
     pps->entropy_coding_sync_enabled_flag = c.wpp;
     pps->dependent_slice_segments_enabled_flag = c.dep ? 1 : 0;
+    if (rext()) {
+      pps->pps_extension_flag = 1; pps->pps_range_extension_flag = 1;
+      pps->range_extension.log2_max_transform_skip_block_size = c.tskip_log2;
+      pps->range_extension.cross_component_prediction_enabled_flag = c.xcc;
+    }
     W4 = (c.w+3)/4; H4 = (c.h+3)/4;
     ctbW = (c.w + (1<<c.log2ctb) - 1) >> c.log2ctb; ctbH = (c.h + (1<<c.log2ctb) - 1) >> c.log2ctb; nCtb = ctbW*ctbH;
     if (c.tile_cols > 1 || c.tile_rows > 1) {
@@ -225,9 +250,23 @@ struct Writer {
     pps->set_derived_values(sps.get());
 
     nal_begin(NAL_UNIT_VPS_NUT); vps->write(&errq, hdr); hdr.add_trailing_bits(); hdr.flush_VLC(); nal_end(-1,false);
-    nal_begin(NAL_UNIT_SPS_NUT); sps->write(&errq, hdr); hdr.add_trailing_bits(); hdr.flush_VLC(); nal_end(-1,false);
+    nal_begin(NAL_UNIT_SPS_NUT); sps->write(&errq, hdr);
+    if (rext()) {                                                   /* sps.cc:421-435 + sps_range_extension::read (:1254-1264): the reference's write() stops at sps_extension_present_flag */
+      hdr.write_bit(1); hdr.write_bit(0); hdr.write_bits(0,6);       /* sps_range_extension_flag, sps_multilayer_extension_flag, sps_extension_6bits */
+      const sps_range_extension& r = sps->range_extension;
+      hdr.write_bit(r.transform_skip_rotation_enabled_flag); hdr.write_bit(0 /*transform_skip_context*/); hdr.write_bit(r.implicit_rdpcm_enabled_flag);
+      hdr.write_bit(r.explicit_rdpcm_enabled_flag); hdr.write_bit(0 /*extended_precision*/); hdr.write_bit(r.intra_smoothing_disabled_flag);
+      hdr.write_bit(r.high_precision_offsets_enabled_flag); hdr.write_bit(0 /*persistent_rice*/); hdr.write_bit(0 /*cabac_bypass_alignment*/);
+    }
+    hdr.add_trailing_bits(); hdr.flush_VLC(); nal_end(-1,false);
     nal_begin(NAL_UNIT_PPS_NUT);
     if (c.scaling == 2) write_pps_with_scaling_lists(); else pps->write(&errq, hdr, sps.get());
+    if (rext()) {                                                   /* pps.cc:503-512 + pps_range_extension::read (:47-143) */
+      hdr.write_bit(1); hdr.write_bit(0); hdr.write_bits(0,6);       /* pps_range_extension_flag, pps_multilayer_extension_flag, pps_extension_6bits */
+      if (pps->transform_skip_enabled_flag) hdr.write_uvlc(c.tskip_log2 - 2);
+      hdr.write_bit(c.xcc); hdr.write_bit(0 /*chroma_qp_offset_list_enabled_flag*/);
+      hdr.write_uvlc(0); hdr.write_uvlc(0);                          /* log2_sao_offset_scale_luma / _chroma */
+    }
     hdr.add_trailing_bits(); hdr.flush_VLC(); nal_end(-1,false);
 
   }
@@ -273,7 +312,7 @@ struct Writer {
         }
       }
     hdr.write_bit(p.lists_modification_present_flag); hdr.write_uvlc(p.log2_parallel_merge_level-2);
-    hdr.write_bit(p.slice_segment_header_extension_present_flag); hdr.write_bit(0);   /* pps_extension_flag */
+    hdr.write_bit(p.slice_segment_header_extension_present_flag); hdr.write_bit(p.pps_extension_flag);
   }
 
   /* ---------- block state ---------- */
@@ -558,8 +597,8 @@ struct Writer {
     const int nb = sps->pcm_sample_bit_depth_luma, n = 1<<log2;
     const int mode = rng.below(3), base = rng.below(1<<nb);
     for (int comp=0;comp<3;comp++) {
-      const int w = comp ? n/2 : n;
-      for (int i=0;i<w*w;i++) {
+      const int w = comp ? n/(c.chroma==3 ? 1 : 2) : n, h = comp ? n/(c.chroma==1 ? 2 : 1) : n;      /* slice.cc:4166-4170: nCS / SubWidthC x nCS / SubHeightC */
+      for (int i=0;i<w*h;i++) {
         int v = mode==0 ? rng.below(1<<nb) : mode==1 ? base : std::min((1<<nb)-1, std::max(0, base + rng.range(-3,3)));
         cab.write_bits(v, nb);
       }
@@ -601,11 +640,21 @@ struct Writer {
       fill(ipm, x,y,pb,pb, mode);
       if (k==0) mode0 = mode;
     }
-    const int cpm = rng.below(5);                                                    /* intra_chroma_pred_mode */
-    cab.write_CABAC_bit(CONTEXT_MODEL_INTRA_CHROMA_PRED_MODE, cpm!=4);
-    if (cpm!=4) cab.write_CABAC_FL_bypass(cpm, 2);
+    /* intra_chroma_pred_mode: one per CU; in 4:4:4 one per PU (slice.cc:4444-4485).  IntraPredModeC of 4:2:2 goes through
+       Table 8-3 (slice.cc:4240-4243, :4478-4480) */
     static const int tab[4] = {0,26,10,1};
-    chroma_mode_cu = cpm==4 ? mode0 : (tab[cpm]==mode0 ? 34 : tab[cpm]);
+    static const uint8_t map422[35] = { 0,1,2, 2, 2, 2, 3, 5, 7, 8,10,12,13,15,17,18,19,20, 21,22,23,23,24,24,25,25,26,27,27,28,28,29,29,30,31 };
+    for (int k=0; k<(c.chroma==3 ? npu : 1); k++) {
+      const int x = c.chroma==3 ? x0 + (k&1)*pb : x0, y = c.chroma==3 ? y0 + (k>>1)*pb : y0, sz = c.chroma==3 ? pb : n;
+      const int cpm = rng.below(5);
+      cab.write_CABAC_bit(CONTEXT_MODEL_INTRA_CHROMA_PRED_MODE, cpm!=4);
+      if (cpm!=4) cab.write_CABAC_FL_bypass(cpm, 2);
+      const int lm = at(ipm,x,y);
+      int m = cpm==4 ? lm : (tab[cpm]==lm ? 34 : tab[cpm]);
+      if (c.chroma==2) m = map422[m];
+      fill(ipmc, x,y,sz,sz, m); fill(ipmc4, x,y,sz,sz, cpm==4);
+    }
+    (void)mode0;
   }
 
   /* slice.cc:2503 */
@@ -685,10 +734,18 @@ struct Writer {
       const bool interSplit = c.depth_inter==0 && depth==0 && !intra && part != PART_2Nx2N;
       split = log2 > c.log2maxtb || (intraSplit && depth==0) || interSplit;
     }
+    /* cbf_cb / cbf_cr (slice.cc:3885-3906): bit 0 the chroma TU (4:2:2: the upper one), bit 1 the lower one of 4:2:2 */
     int cbf_cb = -1, cbf_cr = -1;
-    if (log2 > 2) {
-      if (parent_cb) { cbf_cb = rng.pct(c.dens*7/10); cab.write_CABAC_bit(CONTEXT_MODEL_CBF_CHROMA + depth, cbf_cb); }
-      if (parent_cr) { cbf_cr = rng.pct(c.dens*7/10); cab.write_CABAC_bit(CONTEXT_MODEL_CBF_CHROMA + depth, cbf_cr); }
+    if (log2 > 2 || c.chroma == 3) {
+      const bool second = c.chroma == 2 && (!split || log2 == 3);
+      if (parent_cb) {
+        cbf_cb = rng.pct(c.dens*7/10); cab.write_CABAC_bit(CONTEXT_MODEL_CBF_CHROMA + depth, cbf_cb);
+        if (second) { const int b = rng.pct(c.dens*7/10); cab.write_CABAC_bit(CONTEXT_MODEL_CBF_CHROMA + depth, b); cbf_cb |= b<<1; }
+      }
+      if (parent_cr) {
+        cbf_cr = rng.pct(c.dens*7/10); cab.write_CABAC_bit(CONTEXT_MODEL_CBF_CHROMA + depth, cbf_cr);
+        if (second) { const int b = rng.pct(c.dens*7/10); cab.write_CABAC_bit(CONTEXT_MODEL_CBF_CHROMA + depth, b); cbf_cr |= b<<1; }
+      }
     }
     if (cbf_cb < 0) cbf_cb = (depth>0 && log2==2) ? parent_cb : 0;
     if (cbf_cr < 0) cbf_cr = (depth>0 && log2==2) ? parent_cr : 0;
@@ -706,20 +763,41 @@ struct Writer {
     if (cbf_luma || cbf_cb || cbf_cr) {
       if (c.cuqpd && !qpd_coded) { code_cu_qp_delta(); qpd_coded = true; }
     }
-    if (cbf_luma) code_residual(log2, 0, intra ? scan_idx(log2, at(ipm,x0,y0), 0) : 0);
-    if (log2 > 2) {
-      if (cbf_cb) code_residual(log2-1, 1, intra ? scan_idx(log2-1, chroma_mode_cu, 1) : 0);
-      if (cbf_cr) code_residual(log2-1, 2, intra ? scan_idx(log2-1, chroma_mode_cu, 2) : 0);
+    /* transform unit (slice.cc:3549-3800): luma, then per chroma component [cross_comp_pred] + one or (4:2:2) two blocks */
+    if (cbf_luma) code_residual(log2, 0, intra ? scan_idx(log2, at(ipm,x0,y0), 0) : 0, intra, at(ipm,x0,y0));
+    const int cm = at(ipmc,x0,y0);
+    if (log2 > 2 || c.chroma == 3) {
+      const int lc = c.chroma == 3 ? log2 : log2-1;
+      const bool do_xcc = c.xcc && cbf_luma && (!intra || at(ipmc4,x0,y0));
+      for (int cIdx=1; cIdx<=2; cIdx++) {
+        const int cbf = cIdx==1 ? cbf_cb : cbf_cr;
+        if (do_xcc) code_cross_comp_pred(cIdx-1);
+        if (cbf & 1) code_residual(lc, cIdx, intra ? scan_idx(lc, cm, cIdx) : 0, intra, cm);
+        if (c.chroma == 2 && (cbf & 2)) code_residual(lc, cIdx, intra ? scan_idx(lc, cm, cIdx) : 0, intra, cm);
+      }
     } else if (blkIdx == 3) {
-      if (cbf_cb) code_residual(2, 1, intra ? scan_idx(2, chroma_mode_cu, 1) : 0);
-      if (cbf_cr) code_residual(2, 2, intra ? scan_idx(2, chroma_mode_cu, 2) : 0);
+      const int cmb = at(ipmc,xBase,yBase);
+      for (int cIdx=1; cIdx<=2; cIdx++) {
+        const int cbf = cIdx==1 ? cbf_cb : cbf_cr;
+        if (cbf & 1) code_residual(2, cIdx, intra ? scan_idx(2, cmb, cIdx) : 0, intra, cmb);
+        if (cbf & 2) code_residual(2, cIdx, intra ? scan_idx(2, cmb, cIdx) : 0, intra, cmb);
+      }
     }
   }
 
-  /* intrapred.cc:279 get_intra_scan_idx, 4:2:0 */
-  static int scan_idx(int log2, int mode, int cIdx)
+  /* slice.cc:3490-3541 read_cross_comp_pred: log2_res_scale_abs_plus1 (TU, cMax 4, one context per bin and component), sign */
+  void code_cross_comp_pred(int cIdxMinus1)
   {
-    if (log2==2 || (log2==3 && cIdx==0)) { if (mode>=6 && mode<=14) return 2; if (mode>=22 && mode<=30) return 1; }
+    const int v = rng.pct(45) ? 0 : rng.range(1,4);
+    for (int b=0;b<v;b++) cab.write_CABAC_bit(CONTEXT_MODEL_LOG2_RES_SCALE_ABS_PLUS1 + 4*cIdxMinus1 + b, 1);
+    if (v<4) cab.write_CABAC_bit(CONTEXT_MODEL_LOG2_RES_SCALE_ABS_PLUS1 + 4*cIdxMinus1 + v, 0);
+    if (v) cab.write_CABAC_bit(CONTEXT_MODEL_RES_SCALE_SIGN_FLAG + cIdxMinus1, rng.below(2));
+  }
+
+  /* intrapred.cc:279 get_intra_scan_idx */
+  int scan_idx(int log2, int mode, int cIdx) const
+  {
+    if (log2==2 || (log2==3 && (cIdx==0 || c.chroma==3))) { if (mode>=6 && mode<=14) return 2; if (mode>=22 && mode<=30) return 1; }
     return 0;
   }
 
@@ -783,7 +861,7 @@ struct Writer {
     }
   }
 
-  void code_residual(int log2, int cIdx, int scanIdx)
+  void code_residual(int log2, int cIdx, int scanIdx, bool intra, int predModeIntra)
   {
     const int n = 1<<log2;
     int16_t co[32*32];
@@ -791,7 +869,15 @@ struct Writer {
     st.n_resid++;
     for (int i=0;i<n*n;i++) if (co[i]) { st.n_coeffs++; st.abs_sum += abs(co[i]); }
     bool tskip = false;
-    if (c.tskip && !cu_bypass && log2 <= 2) { tskip = rng.pct(35); cab.write_CABAC_bit(CONTEXT_MODEL_TRANSFORM_SKIP_FLAG + (cIdx?1:0), tskip); }
+    if (c.tskip && !cu_bypass && log2 <= c.tskip_log2) { tskip = rng.pct(35); cab.write_CABAC_bit(CONTEXT_MODEL_TRANSFORM_SKIP_FLAG + (cIdx?1:0), tskip); }
+    bool explicit_rdpcm = false;                                    /* slice.cc:2937-2952 */
+    if (!intra && c.erdpcm && (tskip || cu_bypass)) {
+      explicit_rdpcm = rng.pct(50);
+      cab.write_CABAC_bit(CONTEXT_MODEL_RDPCM_FLAG + (cIdx?1:0), explicit_rdpcm);
+      if (explicit_rdpcm) cab.write_CABAC_bit(CONTEXT_MODEL_RDPCM_DIR + (cIdx?1:0), rng.below(2));
+    }
+    /* sign data hiding is off where the residual goes through RDPCM or the CU bypasses the transform (slice.cc:3294-3307) */
+    const bool no_hiding = cu_bypass || explicit_rdpcm || (intra && c.irdpcm && tskip && (predModeIntra == 10 || predModeIntra == 26));
 
     const position* subScan = get_scan_order(log2-2, scanIdx);
     const position* posScan = get_scan_order(2, scanIdx);
@@ -860,7 +946,7 @@ struct Writer {
       }
       if (firstG1>=0) cab.write_CABAC_bit(CONTEXT_MODEL_COEFF_ABS_LEVEL_GREATER2_FLAG + ctxSet + (cIdx?4:0), abs(lev[firstG1])>2);
       /* sign_data_hiding: the sign of the last (lowest-frequency) level is the parity of the sum; noise content, so it is simply left out */
-      const bool hidden = c.sdh && !cu_bypass && firstP-lastP > 3;
+      const bool hidden = c.sdh && !no_hiding && firstP-lastP > 3;
       for (int k=0;k<nc-(hidden?1:0);k++) cab.write_CABAC_bypass(lev[k]<0);
       int rice = 0;
       for (int k=0;k<nc;k++) {
@@ -1044,7 +1130,7 @@ struct Writer {
   {
     init_scan_orders();
     write_parameter_sets();
-    ct_depth.assign(W4*H4,0); skipf = pmode = pcmf = ipm = ct_depth; ctb_slice.assign(nCtb,-1);
+    ct_depth.assign(W4*H4,0); skipf = pmode = pcmf = ipm = ipmc = ipmc4 = ct_depth; ctb_slice.assign(nCtb,-1);
     fchk = fopen((c.out + ".chk").c_str(), "w");
     if (!fchk) die("cannot open .chk output");
     const std::vector<PicPlan> plan = plan_gop(c);

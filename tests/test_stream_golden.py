@@ -64,7 +64,7 @@ def test_oracle_replays_recorded_stream_pictures(fx):
         P = rp.params
         d = rp.to_desc()
         for stage, key in ((_abi.STAGE_PREFILTER, "prefilter"), (_abi.STAGE_FINAL, "final")):
-            out = pyoracle.alloc_planes(P.width, P.height, P.bit_depth_luma)
+            out = pyoracle.alloc_planes(P.width, P.height, P.bit_depth_luma, chroma_format=P.chroma_format_idc)
             pyoracle.reconstruct(d, None, dpb, out, stage)
             assert md5(out) == dg[key], "%s picture %d: %s differs from libde265's decoder" % (os.path.basename(fx), i, key)
         dpb[rp.meta["dst_slot"]] = out
@@ -115,11 +115,11 @@ def test_gpu_replays_recorded_stream_pictures_through_the_recorder_api(fx):
             rec.record_desc(d)                                   # record_slice / _ctb / _tu / _pu / _pcm / _blk_planes one by one
             slot = rp.meta["dst_slot"]                           # reference lists name libde265's DPB indices: keep them
             assert slot < _abi.MAX_DPB_SLOTS
-            dec.dpb_alloc(slot, P.width, P.height, P.bit_depth_luma)
+            dec.dpb_alloc(slot, P.width, P.height, P.bit_depth_luma, chroma_format=P.chroma_format_idc)
             pic = rec.submit(dec, slot)
             try:
                 for stage, key in ((_abi.STAGE_PREFILTER, "prefilter"), (_abi.STAGE_FINAL, "final")):
-                    dec.upload(slot, pyoracle.alloc_planes(P.width, P.height, P.bit_depth_luma))
+                    dec.upload(slot, pyoracle.alloc_planes(P.width, P.height, P.bit_depth_luma, chroma_format=P.chroma_format_idc))
                     dec.run(pic, stage)
                     dec.sync()
                     got = dec.download(slot, P.width, P.height, P.bit_depth_luma)
@@ -161,7 +161,8 @@ def test_libde265_decodes_the_bitstream_with_the_hip_back_end(fx, mode):
     for i, (rp, dg) in enumerate(fixture):
         P = rp.params
         bpp = 2 if P.bit_depth_luma > 8 else 1
-        n = (P.width * P.height + 2 * (P.width // 2) * (P.height // 2)) * bpp
+        cw, ch = P.width // (2 if P.chroma_format_idc in (1, 2) else 1), P.height // (2 if P.chroma_format_idc == 1 else 1)
+        n = (P.width * P.height + 2 * cw * ch) * bpp
         m = hashlib.md5(data[off:off + n]).hexdigest()
         off += n
         assert m == dg["final"], "%s picture %d: the HIP-backed decoder's output differs from the CPU decoder's" % (os.path.basename(fx), i)
@@ -177,6 +178,9 @@ FULL_SIZE = [
     ("1080p8_B_scaling_lists", "gop=B pics=3 w=1920 h=1080 log2ctb=5 scaling=2 seed=16"),
     ("4k10_B", "gop=B pics=4 w=3840 h=2160 bits=10 log2ctb=6 seed=13"),
     ("4k10_B_wpp", "gop=B pics=3 w=3840 h=2160 bits=10 log2ctb=6 wpp=1 slices=2 seed=15"),
+    # range-extension streams at full size
+    ("1080p8_LDB_444_xcc_rdpcm_rot", "gop=LDB pics=3 w=1920 h=1080 chroma=3 xcc=1 irdpcm=1 erdpcm=1 rot=1 tskip=1 tskip_log2=5 tqbypass=1 seed=17"),
+    ("1080p10_B_422_wp_hpo", "gop=B pics=3 w=1920 h=1080 chroma=2 bits=10 log2ctb=6 wp=1 hpo=1 irdpcm=1 erdpcm=1 rot=1 tskip=1 tskip_log2=4 nosmooth=1 slices=2 seed=18"),
 ]
 
 

@@ -47,7 +47,7 @@ def replay(dumpdir):
         rp, pre, fin = f1_stream.load_dump(os.path.join(dumpdir, fn))
         P, d = rp.params, rp.to_desc()
         for stage, want in ((_abi.STAGE_PREFILTER, pre), (_abi.STAGE_FINAL, fin)):
-            out = pyoracle.alloc_planes(P.width, P.height, P.bit_depth_luma)
+            out = pyoracle.alloc_planes(P.width, P.height, P.bit_depth_luma, chroma_format=P.chroma_format_idc)
             pyoracle.reconstruct(d, None, dpb, out, stage)
             diff = [int((a != b).sum()) for a, b in zip(out, want)]
             if any(diff):

@@ -49,6 +49,14 @@ F2_STREAMS = [
     dict(name="f2_ldb_scaling_lists_10bit", args="gop=LDB pics=3 w=192 h=128 scaling=2 bits=10 tskip=1 seed=7"),
     dict(name="f2_p_wpp_dependent_segments", args="gop=P pics=3 w=256 h=192 dep=60 wpp=1 slices=2 seed=8"),
     dict(name="f2_p_tiles_4x3", args="gop=P pics=3 w=256 h=192 log2ctb=4 log2maxtb=4 tile_cols=4 tile_rows=3 tile_uniform=0 lf_tiles=0 slices=5 seed=6"),
+    # range-extension streams (4:2:2 / 4:4:4 transform trees and chroma intra modes, cross-component prediction,
+    # implicit + explicit RDPCM, transform-skip rotation and large transform-skip blocks, intra smoothing off, high-precision
+    # weighted-prediction offsets)
+    dict(name="f4_ldb_444_xcc_rdpcm_rot", args="gop=LDB pics=4 w=192 h=128 chroma=3 xcc=1 irdpcm=1 erdpcm=1 rot=1 tskip=1 tskip_log2=5 "
+                                               "tqbypass=1 seed=21"),
+    dict(name="f4_b_422_10bit_wp_hpo", args="gop=B pics=5 w=192 h=128 chroma=2 bits=10 wp=1 hpo=1 irdpcm=1 erdpcm=1 rot=1 tskip=1 "
+                                            "tskip_log2=4 tqbypass=1 nosmooth=1 slices=2 seed=22"),
+    dict(name="f4_i_444_10bit_pcm_ctb64", args="gop=I pics=2 w=200 h=136 chroma=3 log2ctb=6 bits=10 pcm_bits=7 seed=23"),
 ]
 
 
@@ -87,7 +95,10 @@ def record(bitstream, outdir):
 
 
 def main():
+    only = set(sys.argv[1:])                                    # optional: regenerate just the named streams
     for st in STREAMS:
+        if only and st["name"] not in only:
+            continue
         with tempfile.TemporaryDirectory() as td:
             yuv, bits = os.path.join(td, "in.yuv"), os.path.join(GOLD, "stream_%s.bin" % st["name"])
             open(yuv, "wb").write(synth_yuv(st["w"], st["h"], st["frames"], st["seed"], st["noise"]))
@@ -104,6 +115,8 @@ def main():
                   sum(rp.meta["n_tus"] for rp, _ in pics), "TUs,", sum(rp.meta["n_coeffs"] for rp, _ in pics), "coefficients; fixture",
                   os.path.getsize(os.path.join(GOLD, "stream_%s.npz" % st["name"])), "B")
     for st in F2_STREAMS:
+        if only and st["name"] not in only:
+            continue
         with tempfile.TemporaryDirectory() as td:
             bits = os.path.join(GOLD, "stream_%s.bin" % st["name"])
             subprocess.check_call([os.path.join(REFDIR, "f2_writer"), "out=" + bits] + st["args"].split())
