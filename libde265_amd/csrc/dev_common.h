@@ -41,6 +41,23 @@ struct PicDev {
   int32_t wp_shift_luma, wp_shift_chroma;   // WpOffsetBdShift
 };
 
+// XCD-aware block index.  Workgroups are dealt round-robin to the 8 XCDs in dispatch order, so blocks L and L+8 share an XCD
+// and its L2.  A kernel launched as a 1-D grid of xcd_grid(gx*gy*gz) blocks calls xcd_block(): every XCD then works on ONE
+// contiguous eighth of the logical (x fastest, z slowest) grid, i.e. a band of the picture, and the rows / columns that
+// neighbouring tiles share are fetched into one L2 once instead of into several.  Speed only, never correctness.
+struct XcdBlk { int x, y, z; bool ok; };
+static inline unsigned xcd_grid(unsigned n) { return (n + 7u) & ~7u; }
+__device__ __forceinline__ XcdBlk xcd_block(unsigned gx, unsigned gy, unsigned gz)
+{
+  const unsigned n = gx * gy * gz, per = (n + 7u) >> 3;
+  const unsigned lg = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+  XcdBlk b;
+  b.ok = lg < n && (blockIdx.x >> 3) < per;
+  const unsigned plane = gx * gy, z = lg / plane, r = lg - z * plane, y = r / gx;
+  b.x = (int)(r - y * gx); b.y = (int)y; b.z = (int)z;
+  return b;
+}
+
 __device__ __forceinline__ bool intra_smooth_on(const PicDev& P, int c_idx) { return c_idx ? P.smooth_chroma != 0 : P.smooth_luma != 0; }
 
 // TU task: de265hip_tu plus the host-derived neighbour availability.

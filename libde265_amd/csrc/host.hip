@@ -126,7 +126,7 @@ struct de265hip_picture {
   uint32_t* d_slots = nullptr;
   uint32_t gen = 0;                           // runs of this picture so far (k_run flag generation)
   std::vector<int> level_start;       // level_start[l] .. level_start[l+1] in d_tus
-  int n_mc = 0, n_pcm = 0, n_tus = 0;
+  int n_mc = 0, n_mc2 = 0, n_mc_quads = 0, n_pcm = 0, n_tus = 0;   // MC tasks: n_mc2 chunks (k_mc2), then 4 * n_mc_quads blocks (k_mc_micro), then k_mc's tiles
   bool any_edges = false;
   uint32_t ref_mask = 0;              // DPB slots the picture's MC tasks read (validated when the picture is launched)
   int n_launched = 0;                 // de265hip_picture_run calls so far
@@ -141,7 +141,8 @@ int free_slot(Slot& s)
 {
   if (s.dl_done) { (void)hipEventSynchronize(s.dl_done); (void)hipEventDestroy(s.dl_done); s.dl_done = nullptr; }
   s.dl_seq = s.dl_waited = 0;
-  for (int c = 0; c < 3; c++) if (s.pl[c].ptr) { (void)hipFree(s.pl[c].ptr); s.pl[c].ptr = nullptr; }
+  if (s.pl[0].ptr) (void)hipFree(s.pl[0].ptr);            // (one allocation: the chroma planes follow the luma plane)
+  for (int c = 0; c < 3; c++) s.pl[c].ptr = nullptr;
   s.valid = false;
   return 0;
 }
@@ -150,13 +151,19 @@ int alloc_slot(Slot& s, int w, int h, int bdY, int bdC, int cf = 1)
 {
   if (s.valid && s.w == w && s.h == h && s.bdY == bdY && s.bdC == bdC && s.cf == cf) return 0;
   free_slot(s);
+  // The three planes of a picture are ONE allocation, luma first: a kernel reaches all of them through one buffer descriptor
+  // (k_mc2), and the planes of a slot always change hands together (the SAO output swap).
+  size_t off[4] = { 0, 0, 0, 0 };
   for (int c = 0; c < 3; c++) {
     int cw = c ? (cf == 3 ? w : w / 2) : w, ch = c ? (cf == 1 ? h / 2 : h) : h;
     int stride = (cw + 63) & ~63;                         // samples; rows start 128/64-byte aligned
     size_t bytes = (size_t)stride * ch * px_bytes(c ? bdC : bdY) + 256;
-    HIPCHK(hipMalloc(&s.pl[c].ptr, bytes), DE265HIP_ERROR_OUT_OF_MEMORY);
+    off[c + 1] = off[c] + ((bytes + 255) & ~(size_t)255);
     s.pl[c].stride = stride;
   }
+  void* base = nullptr;
+  HIPCHK(hipMalloc(&base, off[3]), DE265HIP_ERROR_OUT_OF_MEMORY);
+  for (int c = 0; c < 3; c++) s.pl[c].ptr = (char*)base + off[c];
   s.w = w; s.h = h; s.bdY = bdY; s.bdC = bdC; s.cf = cf; s.valid = true;
   return 0;
 }
@@ -297,7 +304,7 @@ struct BuildScratch {
   std::vector<TuTask> l0, run_tus;
   std::vector<RunTask> runs; std::vector<uint32_t> run_deps, slots;
   std::vector<int> order, newidx, count2, width; std::vector<uint8_t> micro;
-  std::vector<McTask> mcs; std::vector<PcmTask> pcms; std::vector<SaoCtb> saos;
+  std::vector<McTask> mcs, mcs2, mc_micro[17 * 17]; std::vector<int> micro_keys; std::vector<PcmTask> pcms; std::vector<SaoCtb> saos;
 };
 static thread_local BuildScratch g_scratch;
 static const int8_t k_intra_angle[35] = { 0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26,
@@ -1223,6 +1230,8 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   pt.mark("l0");
   // ---- MC tasks: resolve references, bi->uni shortcut, split into <=16x16 tiles
   std::vector<McTask>& mcs = SC.mcs; mcs.clear();
+  std::vector<McTask>& mcs2 = SC.mcs2; mcs2.clear();
+  static const int mc_paths = getenv("DE265HIP_MC_PATHS") ? atoi(getenv("DE265HIP_MC_PATHS")) : 3;   // bit 0: k_mc_micro, bit 1: k_mc2 (experiments)
   int64_t alg_mc = 0;
   for (int i = 0; i < d->n_pus; i++) {
     const de265hip_pu& pu = d->pus[i];
@@ -1258,14 +1267,64 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     const int nref = (t.slot[0] >= 0) + (t.slot[1] >= 0);
     const int64_t bppY = px_bytes(p.bit_depth_luma);
     alg_mc += ((int64_t)pu.w * pu.h + 2 * (int64_t)(pu.w / subw) * (pu.h / subh)) * bppY * (nref + 1);
-    for (int ty = 0; ty < pu.h; ty += 16)
-      for (int tx = 0; tx < pu.w; tx += 16) {
-        McTask q = t;
-        q.x = (uint16_t)(pu.x + tx); q.y = (uint16_t)(pu.y + ty);
-        q.w = (uint8_t)std::min(16, pu.w - tx); q.h = (uint8_t)std::min(16, pu.h - ty);
-        mcs.push_back(q);
+    // 4:2:0, reference blocks (filter margins included) inside the picture for every list:
+    //   PUs narrower or lower than 16 -> blocks of at most 8x8 for k_mc_micro (four blocks per wavefront, sorted by slot pair);
+    //   other PUs -> chunks of up to 32x32 for k_mc2 (one wavefront walks the chunk's 16x16 tiles).
+    // What touches the picture border, and every other chroma format, goes to k_mc as 16x16 tiles (clamped per-sample fetch).
+    auto interior = [&](int X, int Y, int w_, int h_) {
+      for (int l = 0; l < 2; l++) {
+        if (t.slot[l] < 0) continue;
+        const int xs = X + (t.mv[l][0] >> 2) - 3, ys = Y + (t.mv[l][1] >> 2) - 3;
+        const int xc = (X >> 1) + (t.mv[l][0] >> 3) - 1, yc = (Y >> 1) + (t.mv[l][1] >> 3) - 1;
+        if (!(xs >= 0 && ys >= 0 && xs + w_ + 7 <= p.width && ys + h_ + 7 <= p.height &&
+              xc >= 0 && yc >= 0 && xc + (w_ >> 1) + 3 <= (p.width >> 1) && yc + (h_ >> 1) + 3 <= (p.height >> 1))) return false;
+      }
+      return true;
+    };
+    auto tiles16 = [&](int X, int Y, int w_, int h_) {
+      for (int ty = 0; ty < h_; ty += 16)
+        for (int tx = 0; tx < w_; tx += 16) {
+          McTask q = t;
+          q.x = (uint16_t)(X + tx); q.y = (uint16_t)(Y + ty);
+          q.w = (uint8_t)std::min(16, w_ - tx); q.h = (uint8_t)std::min(16, h_ - ty);
+          mcs.push_back(q);
+        }
+    };
+    if (cf == 1 && (mc_paths & 1) && (pu.w < 16 || pu.h < 16)) {
+      const int key = (t.slot[0] + 1) * 17 + (t.slot[1] + 1);
+      for (int by = 0; by < pu.h; by += 8)
+        for (int bx = 0; bx < pu.w; bx += 8) {
+          const int w_ = std::min(8, pu.w - bx), h_ = std::min(8, pu.h - by), X = pu.x + bx, Y = pu.y + by;
+          if (!interior(X, Y, w_, h_)) { tiles16(X, Y, w_, h_); continue; }
+          McTask q = t;
+          q.x = (uint16_t)X; q.y = (uint16_t)Y; q.w = (uint8_t)w_; q.h = (uint8_t)h_;
+          if (SC.mc_micro[key].empty()) SC.micro_keys.push_back(key);
+          SC.mc_micro[key].push_back(q);
+        }
+      continue;
+    }
+    for (int cy0 = 0; cy0 < pu.h; cy0 += 32)
+      for (int cx0 = 0; cx0 < pu.w; cx0 += 32) {
+        const int cw_ = std::min(32, pu.w - cx0), ch_ = std::min(32, pu.h - cy0), X = pu.x + cx0, Y = pu.y + cy0;
+        if (cf == 1 && (mc_paths & 2) && interior(X, Y, cw_, ch_)) {
+          McTask q = t;
+          q.x = (uint16_t)X; q.y = (uint16_t)Y; q.w = (uint8_t)cw_; q.h = (uint8_t)ch_;
+          mcs2.push_back(q);
+        } else tiles16(X, Y, cw_, ch_);
       }
   }
+  // [k_mc2's chunks | k_mc_micro's blocks, four per wavefront, every four of one slot pair | k_mc's tiles]
+  pic->n_mc2 = (int)mcs2.size();
+  std::sort(SC.micro_keys.begin(), SC.micro_keys.end());
+  for (int key : SC.micro_keys) {
+    std::vector<McTask>& v = SC.mc_micro[key];
+    while (v.size() & 3) { McTask q = v.back(); q.w = q.h = 0; v.push_back(q); }      // (a block that stores nothing)
+    mcs2.insert(mcs2.end(), v.begin(), v.end());
+    v.clear();
+  }
+  SC.micro_keys.clear();
+  pic->n_mc_quads = ((int)mcs2.size() - pic->n_mc2) / 4;
+  mcs.insert(mcs.begin(), mcs2.begin(), mcs2.end());
   pic->n_mc = (int)mcs.size();
 
   pt.mark("mc");
@@ -1412,7 +1471,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
                             (size_t)d->n_ctbs * 2, (size_t)d->n_ctbs * sizeof(SaoCtb), nblk, nblk, nblk * sizeof(de265hip_motion), runs.size() * sizeof(RunTask), run_deps.size() * 4,
                             run_tus.size() * sizeof(TuTask), slots.size() * 4, l0.size() * sizeof(TuTask), 0 };
     for (int i = 0; i < 19; i++) mix(host.data() + offs[i], lens[i]);      // (only the written bytes: padding between sections is undefined)
-    const int64_t scal[] = { pic->n_workers, pic->n_batches, pic->n_l0, pic->n_l0_size[0], pic->n_l0_size[1], pic->n_l0_size[2], pic->n_l0_size[3], pic->n_mc, pic->n_pcm,
+    const int64_t scal[] = { pic->n_workers, pic->n_batches, pic->n_l0, pic->n_l0_size[0], pic->n_l0_size[1], pic->n_l0_size[2], pic->n_l0_size[3], pic->n_mc, pic->n_mc2, pic->n_mc_quads, pic->n_pcm,
                              pic->n_tus, pic->n_runs, (int64_t)n_resid, (int64_t)L.total, (int64_t)pic->any_edges, (int64_t)P.has_exempt, (int64_t)pic->run_direct, max_level, max_rl, (int64_t)sum_lvls, (int64_t)pic->n_front };
     mix(scal, sizeof(scal));
     if (!SC.l0_rext.empty()) mix(host.data() + o_l0x, SC.l0_rext.size() * sizeof(TuTask));
@@ -1553,8 +1612,12 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
     for (int s = 0; s < DE265HIP_MAX_DPB_SLOTS; s++)
       if (dec->slots[s].valid) for (int c = 0; c < 3; c++) tab.p[s][c] = dec->slots[s].pl[c];
     KTimer t(dec, DE265HIP_K_MC, 1);
-    hipLaunchKernelGGL(k_mc<PX>, dim3(((pic->n_mc + 7) / 8) * 8), dim3(64), 0, st, P, tab, d0, d1, d2, pic->d_mc, pic->d_slices,
-                       pic->n_mc);
+    const int n2 = pic->n_mc2, nq = pic->n_mc_quads, n1 = pic->n_mc - n2 - 4 * nq;
+    if (n2 || nq)
+      hipLaunchKernelGGL(k_mc_all<PX>, dim3(xcd_grid((unsigned)n1) + xcd_grid((unsigned)n2) + xcd_grid((unsigned)nq)), dim3(64), 0, st, P, tab, d0, d1, d2,
+                         pic->d_mc, pic->d_slices, n2, nq, n1);
+    else if (n1)
+      hipLaunchKernelGGL(k_mc<PX>, dim3(xcd_grid((unsigned)n1)), dim3(64), 0, st, P, tab, d0, d1, d2, pic->d_mc, pic->d_slices, n1);
     if (P.chroma_format != 1)                          // 4:2:2 / 4:4:4: k_mc predicts luma only, the chroma planes by the plain kernel
       hipLaunchKernelGGL(k_mc_chroma_any<PX>, dim3(pic->n_mc, 2), dim3(64), 0, st, P, tab, d1, d2, pic->d_mc, pic->d_slices, pic->n_mc);
   }
@@ -1695,7 +1758,8 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
         const int lswc = std::min(3, P.log2_ctb - 4), twc = 8 << lswc, thc = (64 >> lswc) * SAO_ROWS;
         const int gx = std::max((P.width + tw - 1) / tw, (P.width / 2 + twc - 1) / twc);
         const int gy = std::max((P.height + 4 * th - 1) / (4 * th), (P.height / 2 + 4 * thc - 1) / (4 * thc));
-        hipLaunchKernelGGL(k_sao_ctb<PX>, dim3(gx, gy, c420 ? 3 : 1), dim3(256), 0, st, P, d0, d1, d2, sp.pl[0], sp.pl[1], sp.pl[2], M);
+        const uint3 G = make_uint3((unsigned)gx, (unsigned)gy, c420 ? 3u : 1u);
+        hipLaunchKernelGGL(k_sao_ctb<PX>, dim3(xcd_grid(G.x * G.y * G.z)), dim3(256), 0, st, P, d0, d1, d2, sp.pl[0], sp.pl[1], sp.pl[2], M, G);
         if (!c420)
           hipLaunchKernelGGL(k_sao_chroma_any<PX>, dim3((P.cwidth + 255) / 256, P.cheight, 2), dim3(256), 0, st, P, d1, d2, sp.pl[1], sp.pl[2], M);
       }

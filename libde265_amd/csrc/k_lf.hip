@@ -801,17 +801,21 @@ void k_sao(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, PlaneRe
 // right edge fetch the one sample beyond it themselves: one divergent block of four 2-byte loads, issued together with the rows.
 template <typename PX>
 __global__ __launch_bounds__(256, SAO_WAVES)
-void k_sao_ctb(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, PlaneRef d1, PlaneRef d2, SaoMeta M)
+void k_sao_ctb(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, PlaneRef d1, PlaneRef d2, SaoMeta M, uint3 G)
 {
-  const int comp = blockIdx.z, cs = comp ? 1 : 0;
+  // (XCD-aware: the one sample a tile reads beyond its left / right edge sits in the neighbouring tile's cache line; with the
+  //  plain round-robin dispatch that line went into a second L2: the kernel fetched 3.3x the picture)
+  const XcdBlk B = xcd_block(G.x, G.y, G.z);
+  if (!B.ok) return;
+  const int comp = B.z, cs = comp ? 1 : 0;
   const int width = P.width >> cs, height = P.height >> cs;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ctbshift = P.log2_ctb - cs;
   const int lsw = min(3, ctbshift - 3);                         // log2 strips per tile row (CTB 16 chroma: one strip)
   const int sx = lane & ((1 << lsw) - 1), sy = lane >> lsw;
   const int tw = 8 << lsw, th = (64 >> lsw) * SAO_ROWS;         // tile size in samples
-  const int x0 = blockIdx.x * tw + sx * 8;
-  const int y0 = (blockIdx.y * 4 + wave) * th + sy * SAO_ROWS;
+  const int x0 = B.x * tw + sx * 8;
+  const int y0 = (B.y * 4 + wave) * th + sy * SAO_ROWS;
   const PlaneRef sp = comp == 0 ? s0 : (comp == 1 ? s1 : s2);
   const PlaneRef dp = comp == 0 ? d0 : (comp == 1 ? d1 : d2);
   const PX* src = (const PX*)sp.ptr;
@@ -954,7 +958,7 @@ template __global__ void k_lf_tile<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRe
 
 template __global__ void k_sao<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, SaoMeta);
 template __global__ void k_sao<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, SaoMeta);
-template __global__ void k_sao_ctb<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, SaoMeta);
-template __global__ void k_sao_ctb<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, SaoMeta);
+template __global__ void k_sao_ctb<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, SaoMeta, uint3);
+template __global__ void k_sao_ctb<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, SaoMeta, uint3);
 
 }  // namespace d265

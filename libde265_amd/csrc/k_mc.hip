@@ -37,6 +37,12 @@ __device__ __constant__ uint32_t c_epel_pk[8][2] = {
 typedef short mc_s2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int mc_dot2(uint32_t a, uint32_t b, int acc)
 { return __builtin_amdgcn_sdot2(__builtin_bit_cast(mc_s2, a), __builtin_bit_cast(mc_s2, b), acc, false); }
+// first term of a chain.  (The compiler picks the accumulate-in-place form v_dot2c and spends a v_mov on every chain's zero;
+// the three-address form takes the inline constant.)
+__device__ __forceinline__ int mc_dot2_first(uint32_t a, uint32_t b)
+{ int r; asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ int mc_dot2_first_s(uint32_t a, uint32_t b_uniform)
+{ int r; asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "s"(b_uniform)); return r; }
 
 #define MC_IWP 24          // LDS pitch of the staged input tile (>= 16+7)
 
@@ -164,20 +170,21 @@ template <> __device__ __forceinline__ void st2_px<uint8_t>(uint8_t* p, int a, i
 
 #define MC_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")   // one wave per workgroup
 
+#define MC_TILE_LDS (2 * 23 * MCL_P * 2 + 4 * 11 * MCC_P * 2 + 23 * MCT_P * 2)
 template <typename PX>
-__global__ __launch_bounds__(64)
-void k_mc(PicDev P, DpbTable dpb, PlaneRef d0, PlaneRef d1, PlaneRef d2,
-          const McTask* __restrict__ tasks, const de265hip_slice_params* __restrict__ slices, int n_tasks)
+__device__ __forceinline__ void mc_tile_body(const PicDev& P, const DpbTable& dpb, const PlaneRef& d0, const PlaneRef& d1, const PlaneRef& d2,
+                                             const McTask* __restrict__ tasks, const de265hip_slice_params* __restrict__ slices, int n_tasks,
+                                             unsigned bid, char* smem)
 {
-  __shared__ __attribute__((aligned(16))) uint16_t s_inL[2][23 * MCL_P];
-  __shared__ __attribute__((aligned(16))) uint16_t s_inC[2][2][11 * MCC_P];
-  __shared__ __attribute__((aligned(16))) int16_t s_tmp[23 * MCT_P];
+  uint16_t (*s_inL)[23 * MCL_P] = reinterpret_cast<uint16_t (*)[23 * MCL_P]>(smem);
+  uint16_t (*s_inC)[2][11 * MCC_P] = reinterpret_cast<uint16_t (*)[2][11 * MCC_P]>(smem + 2 * 23 * MCL_P * 2);
+  int16_t* s_tmp = reinterpret_cast<int16_t*>(smem + 2 * 23 * MCL_P * 2 + 4 * 11 * MCC_P * 2);
   const int lane = threadIdx.x;
   // XCD-aware mapping: workgroups b and b+8 share an XCD (and its L2); give every XCD one contiguous
   // eighth of the task list (tasks are in decode order, i.e. spatial neighbours) so that the
   // overlapping filter margins of neighbouring tiles hit in the same L2.  Speed only, never correctness.
   const int per = (n_tasks + 7) >> 3;
-  const int tix = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int tix = (bid & 7) * per + (bid >> 3);
   if (tix >= n_tasks) return;
   McTask t;                                         // (five dwords at a uniform address: scalar loads)
   {
@@ -468,10 +475,610 @@ void k_mc(PicDev P, DpbTable dpb, PlaneRef d0, PlaneRef d1, PlaneRef d2,
   }
 }
 
+template <typename PX>
+__global__ __launch_bounds__(64)
+void k_mc(PicDev P, DpbTable dpb, PlaneRef d0, PlaneRef d1, PlaneRef d2,
+          const McTask* __restrict__ tasks, const de265hip_slice_params* __restrict__ slices, int n_tasks)
+{
+  __shared__ __attribute__((aligned(16))) char smem[MC_TILE_LDS];
+  mc_tile_body<PX>(P, dpb, d0, d1, d2, tasks, slices, n_tasks, blockIdx.x, smem);
+}
 template __global__ void k_mc<uint8_t>(PicDev, DpbTable, PlaneRef, PlaneRef, PlaneRef, const McTask*,
                                        const de265hip_slice_params*, int);
 template __global__ void k_mc<uint16_t>(PicDev, DpbTable, PlaneRef, PlaneRef, PlaneRef, const McTask*,
                                         const de265hip_slice_params*, int);
+
+// ---------------------------------------------------------------- picture-level MC kernel, second form (4:2:0, interior tasks)
+// k_mc above is bound by instruction issue (tools/exp/pmc_mc.sh: 380 VALU + 372 SALU instructions per wavefront, the VALU
+// pipes ~90 % busy while its wavefronts are resident), not by HBM.  k_mc2 does the same arithmetic with about half the
+// instructions per tile:
+//  * a task is a PU chunk of up to 32x32 luma samples = up to four 16x16 tiles walked by ONE wavefront: task decode, mode,
+//    weights, filter taps, buffer descriptors and every per-lane address are computed once per chunk, a tile costs a few
+//    scalar offsets;
+//  * only chunks whose reference blocks (margins included) lie inside the picture come here (the host sorts the others into
+//    k_mc's list): the fetch is unconditional raw buffer loads - descriptor in scalar registers, one per-lane offset for all
+//    planes of a list, out-of-range rows read as zero instead of faulting - into an LDS tile of fixed geometry: no per-lane
+//    conditions, no 64-bit address arithmetic;
+//  * horizontal pass: one lane = 8 adjacent outputs of one row from 8 dwords of sample pairs.  Outputs that start on an
+//    even sample take 4 v_dot2 with the tap pairs (t0,t1)..(t6,t7), outputs that start on an odd sample 5 v_dot2 with
+//    (0,t0)(t1,t2)..(t7,0): no v_alignbit re-pairing of the row, whatever the parity of the block's start;
+//  * its int16 results go to LDS as halves of VERTICAL pairs, twice: (row 2q, row 2q+1) and (row 2q-1, row 2q).  The
+//    vertical pass of output row y then reads its four tap pairs ready-made - from the first copy for even y, the second
+//    for odd y - with four 16-byte LDS reads per lane and 16 v_dot2: no v_perm pair building;
+//  * stores are raw buffer stores with a per-lane offset computed once per chunk.
+// Truncations as in the reference (fallback-motion.cc:346,:377,:508-545): int16 after each pass.
+typedef unsigned int mc_v2u __attribute__((ext_vector_type(2)));
+#define M2_LP 28                      // luma input tile: 23 rows x 7 chunks of 4 samples
+#define M2_LROWS 23
+#define M2_CP 16                      // chroma input tile: 11 rows x 4 chunks
+#define M2_CROWS 11
+#define M2_PP 20                      // pair buffers: 12 pair rows x 16 columns (pitch 20 dwords: 16-byte aligned rows)
+#define M2_PR 12
+#define M2_CPP 8                      // chroma pair buffers (inside the luma ones): per plane 6 pair rows x 8 columns
+#define M2_CPR 6
+
+#define QPK(a, b) ((uint32_t)(uint16_t)(int16_t)(a) | ((uint32_t)(uint16_t)(int16_t)(b) << 16))
+#define QROW(t0, t1, t2, t3, t4, t5, t6, t7) { QPK(t0, t1), QPK(t2, t3), QPK(t4, t5), QPK(t6, t7), \
+                                               QPK(0, t0), QPK(t1, t2), QPK(t3, t4), QPK(t5, t6), QPK(t7, 0), 0, 0, 0 }
+#define EROW(t0, t1, t2, t3) { QPK(t0, t1), QPK(t2, t3), QPK(0, t0), QPK(t1, t2), QPK(t3, 0), 0, 0, 0 }
+// [fraction][0..3: pairs for an even start, 4..8: pairs for an odd start]
+__device__ __constant__ uint32_t c_qpel_eo[4][12] = {
+  QROW(0, 0, 0, 64, 0, 0, 0, 0), QROW(-1, 4, -10, 58, 17, -5, 1, 0), QROW(-1, 4, -11, 40, 40, -11, 4, -1), QROW(0, 1, -5, 17, 58, -10, 4, -1) };
+// [fraction][0..1 even start, 2..4 odd start]
+__device__ __constant__ uint32_t c_epel_eo[8][8] = {
+  EROW(0, 64, 0, 0), EROW(-2, 58, 10, -2), EROW(-4, 54, 16, -2), EROW(-6, 46, 28, -4),
+  EROW(-4, 36, 36, -4), EROW(-4, 28, 46, -6), EROW(-2, 16, 54, -4), EROW(-2, 10, 58, -2) };
+#undef QROW
+#undef EROW
+#undef QPK
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mc_rsrc(const void* base, uint32_t bytes)
+{ return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000); }
+// four samples at byte offset voff + soff of a plane, as two dwords of two 16-bit samples
+template <typename PX> __device__ __forceinline__ uint2 mc_fetch4(__amdgpu_buffer_rsrc_t r, int voff, int soff);
+template <> __device__ __forceinline__ uint2 mc_fetch4<uint16_t>(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{ const mc_v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0); return make_uint2(v.x, v.y); }
+template <> __device__ __forceinline__ uint2 mc_fetch4<uint8_t>(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+  const uint32_t v = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+  return make_uint2(__builtin_amdgcn_perm(0, v, 0x0C010C00u), __builtin_amdgcn_perm(0, v, 0x0C030C02u));
+}
+template <typename PX> __device__ __forceinline__ void mc_store4(__amdgpu_buffer_rsrc_t r, int voff, int soff, const int v[4]);
+template <> __device__ __forceinline__ void mc_store4<uint16_t>(__amdgpu_buffer_rsrc_t r, int voff, int soff, const int v[4])
+{
+  mc_v2u q; q.x = (uint32_t)v[0] | ((uint32_t)v[1] << 16); q.y = (uint32_t)v[2] | ((uint32_t)v[3] << 16);
+  __builtin_amdgcn_raw_buffer_store_b64(q, r, voff, soff, 0);
+}
+template <> __device__ __forceinline__ void mc_store4<uint8_t>(__amdgpu_buffer_rsrc_t r, int voff, int soff, const int v[4])
+{ __builtin_amdgcn_raw_buffer_store_b32((uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24), r, voff, soff, 0); }
+template <typename PX> __device__ __forceinline__ void mc_store2(__amdgpu_buffer_rsrc_t r, int voff, int soff, int a, int b);
+template <> __device__ __forceinline__ void mc_store2<uint16_t>(__amdgpu_buffer_rsrc_t r, int voff, int soff, int a, int b)
+{ __builtin_amdgcn_raw_buffer_store_b32((uint32_t)a | ((uint32_t)b << 16), r, voff, soff, 0); }
+template <> __device__ __forceinline__ void mc_store2<uint8_t>(__amdgpu_buffer_rsrc_t r, int voff, int soff, int a, int b)
+{ __builtin_amdgcn_raw_buffer_store_b16((uint16_t)(a | (b << 8)), r, voff, soff, 0); }
+
+// the 8 outputs of a horizontal 8-tap pass from the row's dwords D[0..7] = sample pairs (d0,d1)..(d14,d15); output j starts at
+// sample j + ODD.  T: 4 even-start + 5 odd-start tap pairs (scalar registers)
+template <int ODD, bool UNI>
+__device__ __forceinline__ void mc_h8(const uint32_t D[8], const uint32_t T[9], int o[8])
+{
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int q = j + ODD, i = q >> 1;
+    int a;
+    if (q & 1) {
+      a = UNI ? mc_dot2_first_s(D[i], T[4]) : mc_dot2_first(D[i], T[4]);
+#pragma unroll
+      for (int m = 1; m < 5; m++) a = mc_dot2(D[i + m], T[4 + m], a);
+    } else {
+      a = UNI ? mc_dot2_first_s(D[i], T[0]) : mc_dot2_first(D[i], T[0]);
+#pragma unroll
+      for (int m = 1; m < 4; m++) a = mc_dot2(D[i + m], T[m], a);
+    }
+    o[j] = a;
+  }
+}
+// the same for 4 outputs of a 4-tap pass from D[0..3]; T: 2 even-start + 3 odd-start pairs
+template <int ODD, bool UNI>
+__device__ __forceinline__ void mc_h4(const uint32_t D[4], const uint32_t T[5], int o[4])
+{
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int q = j + ODD, i = q >> 1;
+    int a;
+    if (q & 1) {
+      a = UNI ? mc_dot2_first_s(D[i], T[2]) : mc_dot2_first(D[i], T[2]);
+#pragma unroll
+      for (int m = 1; m < 3; m++) a = mc_dot2(D[i + m], T[2 + m], a);
+    } else {
+      a = UNI ? mc_dot2_first_s(D[i], T[0]) : mc_dot2_first(D[i], T[0]);
+      a = mc_dot2(D[i + 1], T[1], a);
+    }
+    o[j] = a;
+  }
+}
+// sample n (0..) of a row of pairs
+__device__ __forceinline__ int mc_pick(const uint32_t* D, int n) { return (int)((D[n >> 1] >> (16 * (n & 1))) & 0xFFFFu); }
+
+#define MC_CHUNK_LDS (2 * M2_LROWS * M2_LP * 2 + 4 * M2_CROWS * M2_CP * 2 + 2 * M2_PR * M2_PP * 4)
+template <typename PX>
+__device__ __forceinline__ void mc_chunk_body(const PicDev& P, const DpbTable& dpb, const PlaneRef& d0, const PlaneRef& d1, const PlaneRef& d2,
+                                              const McTask* __restrict__ tasks, const de265hip_slice_params* __restrict__ slices, int n_tasks,
+                                              unsigned bid, char* smem)
+{
+  uint16_t (*s_inL)[M2_LROWS * M2_LP] = reinterpret_cast<uint16_t (*)[M2_LROWS * M2_LP]>(smem);
+  uint16_t (*s_inC)[2][M2_CROWS * M2_CP] = reinterpret_cast<uint16_t (*)[2][M2_CROWS * M2_CP]>(smem + 2 * M2_LROWS * M2_LP * 2);
+  uint32_t* s_pair = reinterpret_cast<uint32_t*>(smem + 2 * M2_LROWS * M2_LP * 2 + 4 * M2_CROWS * M2_CP * 2);      // [first copy | second copy]
+  const int lane = threadIdx.x;
+  const int per = (n_tasks + 7) >> 3;                  // XCD-aware: see k_mc
+  const int tix = (bid & 7) * per + (bid >> 3);
+  if (tix >= n_tasks) return;
+  McTask t;
+  {
+    const uint32_t* tq = reinterpret_cast<const uint32_t*>(tasks + tix);
+    uint32_t tw[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) tw[i] = __builtin_amdgcn_readfirstlane(tq[i]);
+    __builtin_memcpy(&t, tw, sizeof(t));
+  }
+  const de265hip_slice_params* sh = &slices[t.slice_idx];
+  const bool use0 = t.slot[0] >= 0, use1 = t.slot[1] >= 0, bi = use0 && use1;
+  const int l_uni = use0 ? 0 : 1;
+  constexpr int bpp = (int)sizeof(PX);
+  int mode;                                           // motion.cc:440-620
+  if (sh->slice_type == 1) mode = P.weighted_pred ? 1 : 0;
+  else if (bi) mode = P.weighted_bipred ? 3 : 2;
+  else mode = P.weighted_bipred ? 1 : 0;
+  const int bdL = P.bd_luma, bdC = P.bd_chroma;
+  const int cH = P.height >> 1;
+
+  // ---- per list: one descriptor for the slot's three planes (one allocation, luma first: host.hip alloc_slot), per-lane
+  // fetch offsets
+  __amdgpu_buffer_rsrc_t rsR[2];
+  int sbL[2], sbC[2], ofCb[2], ofCr[2];                // row pitch in bytes; where the chroma planes start
+  // luma fetch slots lane + 64 i: row (lane >> 3) + 8 i, chunk lane & 7 (the 8th chunk of a row is fetched and dropped); the
+  // slots of a picture's DPB share one geometry, hence one pitch (checked at launch): one per-lane offset serves both lists
+  int vofL = 0, vofC = 0;
+#pragma unroll
+  for (int l = 0; l < 2; l++) {
+    if (t.slot[l] < 0) continue;
+    const PlaneRef pl = dpb.p[t.slot[l]][0], pb = dpb.p[t.slot[l]][1], pr = dpb.p[t.slot[l]][2];
+    sbL[l] = pl.stride * bpp; sbC[l] = pb.stride * bpp;
+    ofCb[l] = (int)((const char*)pb.ptr - (const char*)pl.ptr); ofCr[l] = (int)((const char*)pr.ptr - (const char*)pl.ptr);
+    rsR[l] = mc_rsrc(pl.ptr, (uint32_t)(max(ofCb[l], ofCr[l]) + sbC[l] * cH));
+    vofL = (lane >> 3) * sbL[l] + (lane & 7) * 4 * bpp;
+    vofC = (lane >> 2) * sbC[l] + (lane & 3) * 4 * bpp;
+  }
+  const int ldsL0 = (lane >> 3) * M2_LP + 4 * (lane & 7);
+
+  // weights (motion.cc:403-406, :464-473, :522-540), luma and the two chroma planes
+  const int la = (mode == 3) ? 0 : l_uni;
+  const int cp = lane >> 5;                            // chroma: lane -> plane
+  int w0 = 0, o0 = 0, w1 = 0, o1 = 0, log2WD = 1, cw0 = 0, co0 = 0, cw1 = 0, co1 = 0, clog2WD = 1;
+  if (mode == 1 || mode == 3) {
+    log2WD = sh->luma_log2_weight_denom + max(2, 14 - bdL);
+    w0 = sh->luma_weight[la][t.ref_idx[la]]; o0 = sh->luma_offset[la][t.ref_idx[la]] * (1 << P.wp_shift_luma);
+    clog2WD = sh->chroma_log2_weight_denom + max(2, 14 - bdC);
+    cw0 = sh->chroma_weight[la][t.ref_idx[la]][cp]; co0 = sh->chroma_offset[la][t.ref_idx[la]][cp] * (1 << P.wp_shift_chroma);
+    if (mode == 3) {
+      w1 = sh->luma_weight[1][t.ref_idx[1]]; o1 = sh->luma_offset[1][t.ref_idx[1]] * (1 << P.wp_shift_luma);
+      cw1 = sh->chroma_weight[1][t.ref_idx[1]][cp]; co1 = sh->chroma_offset[1][t.ref_idx[1]][cp] * (1 << P.wp_shift_chroma);
+    }
+  }
+
+  // destination: descriptors and per-lane offsets.  luma: lane -> row lane>>2, 4 columns; chroma: plane lane>>5, row, 2 columns
+  const int dsbL = d0.stride * bpp, dsbC = d1.stride * bpp;
+  const int dofCb = (int)((const char*)d1.ptr - (const char*)d0.ptr), dofCr = (int)((const char*)d2.ptr - (const char*)d0.ptr);
+  const __amdgpu_buffer_rsrc_t rdD = mc_rsrc(d0.ptr, (uint32_t)(max(dofCb, dofCr) + dsbC * cH));
+  const int ly = lane >> 2, lx4 = (lane & 3) * 4;
+  const int cy = (lane & 31) >> 2, cx2 = (lane & 3) * 2;
+  const int dvL = ly * dsbL + lx4 * bpp, dvC = cy * dsbC + cx2 * bpp + (cp ? dofCr : dofCb);
+  // horizontal pass lanes.  luma: row lane>>1 (lanes 0..45), 8 columns; chroma: plane lane>>5, row (lane&31)>>1 (< 11), 4 columns
+  const int hr = lane >> 1, hx8 = (lane & 1) * 8;
+  const int hq = lane >> 5, hcr = (lane & 31) >> 1, hx4 = (lane & 1) * 4;
+  uint16_t* const pair16 = reinterpret_cast<uint16_t*>(s_pair);
+  // where a lane's horizontal results go: first copy pair row r>>1, half r&1; second copy pair row (r+1)>>1, half (r+1)&1
+  const int peL = ((hr >> 1) * M2_PP + hx8) * 2 + (hr & 1);
+  const int poL = (M2_PR * M2_PP + ((hr + 1) >> 1) * M2_PP + hx8) * 2 + ((hr + 1) & 1);
+  const int cbase = hq * (2 * M2_CPR * M2_CPP);                         // chroma plane q: [first copy | second copy] of 6 x 8 dwords
+  const int peC = (cbase + (hcr >> 1) * M2_CPP + hx4) * 2 + (hcr & 1);
+  const int poC = (cbase + M2_CPR * M2_CPP + ((hcr + 1) >> 1) * M2_CPP + hx4) * 2 + ((hcr + 1) & 1);
+  // where a lane's vertical pass reads: output row y -> first copy from pair row y>>1 (y even), second from (y+1)>>1 (y odd)
+  const int pvL = (ly & 1) * (M2_PR * M2_PP) + ((ly + (ly & 1)) >> 1) * M2_PP + lx4;
+  const int pvC = cp * (2 * M2_CPR * M2_CPP) + (cy & 1) * (M2_CPR * M2_CPP) + ((cy + (cy & 1)) >> 1) * M2_CPP + cx2;
+
+  for (int ty = 0; ty < t.h; ty += 16)
+    for (int tx = 0; tx < t.w; tx += 16) {
+      const int tw = min(16, t.w - tx), th = min(16, t.h - ty);
+      const int X = t.x + tx, Y = t.y + ty;
+      // ---------------- fetch: every load of both lists and all planes back to back, then into LDS
+      uint2 rl[2][3], rc[2][2];
+      int oxL[2] = { 0, 0 }, oxC[2] = { 0, 0 };
+#pragma unroll
+      for (int l = 0; l < 2; l++) {
+        if (t.slot[l] < 0) continue;
+        const int xs = X + (t.mv[l][0] >> 2) - 3, ys = Y + (t.mv[l][1] >> 2) - 3;
+        oxL[l] = xs & 3;
+        const int so = ys * sbL[l] + (xs & ~3) * bpp;
+        rl[l][0] = mc_fetch4<PX>(rsR[l], vofL, so);
+        rl[l][1] = mc_fetch4<PX>(rsR[l], vofL, so + 8 * sbL[l]);
+        rl[l][2] = mc_fetch4<PX>(rsR[l], vofL, so + 16 * sbL[l]);
+        const int xc = (X >> 1) + (t.mv[l][0] >> 3) - 1, yc = (Y >> 1) + (t.mv[l][1] >> 3) - 1;
+        oxC[l] = xc & 3;
+        const int sc = yc * sbC[l] + (xc & ~3) * bpp;
+        rc[l][0] = mc_fetch4<PX>(rsR[l], vofC, sc + ofCb[l]);
+        rc[l][1] = mc_fetch4<PX>(rsR[l], vofC, sc + ofCr[l]);
+      }
+#pragma unroll
+      for (int l = 0; l < 2; l++) {
+        if (t.slot[l] < 0) continue;
+        if ((lane & 7) != 7) {
+          *reinterpret_cast<uint2*>(&s_inL[l][ldsL0]) = rl[l][0];
+          *reinterpret_cast<uint2*>(&s_inL[l][ldsL0 + 8 * M2_LP]) = rl[l][1];
+          if (lane < 8 * (M2_LROWS - 16)) *reinterpret_cast<uint2*>(&s_inL[l][ldsL0 + 16 * M2_LP]) = rl[l][2];
+        }
+        if (lane < M2_CROWS * 4) {
+          *reinterpret_cast<uint2*>(&s_inC[l][0][lane * 4]) = rc[l][0];
+          *reinterpret_cast<uint2*>(&s_inC[l][1][lane * 4]) = rc[l][1];
+        }
+      }
+      MC_LDS_SYNC();
+
+      // ---------------- luma
+      int prL[2][4];
+#pragma unroll
+      for (int l = 0; l < 2; l++) {
+        if (t.slot[l] < 0) continue;
+        int xF = t.mv[l][0] & 3, yF = t.mv[l][1] & 3;
+        const int shift1 = bdL - 8;
+        asm volatile("" : "+s"(xF), "+s"(yF));       // (tap pairs are fetched where they are used: hoisted out of the tile loop they do not fit the scalar registers)
+        if (xF == 0 && yF == 0) {
+          const uint16_t* in = &s_inL[l][(ly + 3) * M2_LP + lx4 + 3 + oxL[l]];
+#pragma unroll
+          for (int j = 0; j < 4; j++) prL[l][j] = (int16_t)(in[j] << (14 - bdL));
+          continue;
+        }
+        if (lane < 2 * M2_LROWS) {
+          const uint32_t* rowd = reinterpret_cast<const uint32_t*>(&s_inL[l][hr * M2_LP + hx8 + (oxL[l] & ~1)]);
+          uint32_t D[8];
+#pragma unroll
+          for (int m = 0; m < 8; m++) D[m] = rowd[m];
+          int o[8];
+          if (xF == 0) {
+            if (oxL[l] & 1) {
+#pragma unroll
+              for (int j = 0; j < 8; j++) o[j] = mc_pick(D, j + 4);
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; j++) o[j] = mc_pick(D, j + 3);
+            }
+          } else {
+            uint32_t T[9];
+#pragma unroll
+            for (int m = 0; m < 9; m++) T[m] = c_qpel_eo[xF][m];
+            if (oxL[l] & 1) mc_h8<1, true>(D, T, o); else mc_h8<0, true>(D, T, o);
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] >>= shift1;
+          }
+#pragma unroll
+          for (int j = 0; j < 8; j++) { pair16[peL + 2 * j] = (uint16_t)o[j]; pair16[poL + 2 * j] = (uint16_t)o[j]; }
+        }
+        MC_LDS_SYNC();
+        {
+          const int vshift = (xF == 0) ? shift1 : 6;
+          int acc[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const uint4 v = *reinterpret_cast<const uint4*>(&s_pair[pvL + j * M2_PP]);
+            const uint32_t tp = c_qpel_eo[yF][j];
+            if (j == 0) { acc[0] = mc_dot2_first_s(v.x, tp); acc[1] = mc_dot2_first_s(v.y, tp); acc[2] = mc_dot2_first_s(v.z, tp); acc[3] = mc_dot2_first_s(v.w, tp); }
+            else {
+              acc[0] = mc_dot2(v.x, tp, acc[0]); acc[1] = mc_dot2(v.y, tp, acc[1]);
+              acc[2] = mc_dot2(v.z, tp, acc[2]); acc[3] = mc_dot2(v.w, tp, acc[3]);
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 4; j++) prL[l][j] = (int16_t)(acc[j] >> vshift);
+        }
+        MC_LDS_SYNC();                               // the pair buffers are reused by the next list / chroma
+      }
+      if (ly < th && lx4 < tw) {
+        int o[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          o[j] = mc_combine<PX>(mode, bi ? prL[0][j] : (use0 ? prL[0][j] : prL[1][j]), prL[1][j], bdL, w0, o0, w1, o1, log2WD);
+        mc_store4<PX>(rdD, dvL, Y * dsbL + X * bpp, o);
+      }
+
+      // ---------------- chroma, both planes at once
+      int prC[2][2];
+#pragma unroll
+      for (int l = 0; l < 2; l++) {
+        if (t.slot[l] < 0) continue;
+        int xF = t.mv[l][0] & 7, yF = t.mv[l][1] & 7;
+        const int shift1 = bdC - 8;
+        asm volatile("" : "+s"(xF), "+s"(yF));
+        if (xF == 0 && yF == 0) {
+          const uint16_t* in = &s_inC[l][cp][(cy + 1) * M2_CP + cx2 + 1 + oxC[l]];
+          prC[l][0] = (int16_t)(in[0] << (14 - bdC)); prC[l][1] = (int16_t)(in[1] << (14 - bdC));
+          continue;
+        }
+        if ((lane & 31) < 2 * M2_CROWS) {
+          const uint32_t* rowd = reinterpret_cast<const uint32_t*>(&s_inC[l][hq][hcr * M2_CP + hx4 + (oxC[l] & ~1)]);
+          uint32_t D[4];
+#pragma unroll
+          for (int m = 0; m < 4; m++) D[m] = rowd[m];
+          int o[4];
+          if (xF == 0) {
+            if (oxC[l] & 1) {
+#pragma unroll
+              for (int j = 0; j < 4; j++) o[j] = mc_pick(D, j + 2);
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; j++) o[j] = mc_pick(D, j + 1);
+            }
+          } else {
+            uint32_t T[5];
+#pragma unroll
+            for (int m = 0; m < 5; m++) T[m] = c_epel_eo[xF][m];
+            if (oxC[l] & 1) mc_h4<1, true>(D, T, o); else mc_h4<0, true>(D, T, o);
+#pragma unroll
+            for (int j = 0; j < 4; j++) o[j] >>= shift1;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; j++) { pair16[peC + 2 * j] = (uint16_t)o[j]; pair16[poC + 2 * j] = (uint16_t)o[j]; }
+        }
+        MC_LDS_SYNC();
+        {
+          const int vshift = (xF == 0) ? shift1 : 6;
+          const uint2 v0 = *reinterpret_cast<const uint2*>(&s_pair[pvC]);
+          const uint2 v1 = *reinterpret_cast<const uint2*>(&s_pair[pvC + M2_CPP]);
+          const uint32_t q0 = c_epel_eo[yF][0], q1 = c_epel_eo[yF][1];
+          const int a0 = mc_dot2(v1.x, q1, mc_dot2_first_s(v0.x, q0));
+          const int a1 = mc_dot2(v1.y, q1, mc_dot2_first_s(v0.y, q0));
+          prC[l][0] = (int16_t)(a0 >> vshift); prC[l][1] = (int16_t)(a1 >> vshift);
+        }
+        MC_LDS_SYNC();
+      }
+      if (cy < (th >> 1) && cx2 < (tw >> 1)) {
+        const int a0 = bi ? prC[0][0] : (use0 ? prC[0][0] : prC[1][0]), a1 = bi ? prC[0][1] : (use0 ? prC[0][1] : prC[1][1]);
+        const int q0 = mc_combine<PX>(mode, a0, prC[1][0], bdC, cw0, co0, cw1, co1, clog2WD);
+        const int q1 = mc_combine<PX>(mode, a1, prC[1][1], bdC, cw0, co0, cw1, co1, clog2WD);
+        mc_store2<PX>(rdD, dvC, (Y >> 1) * dsbC + (X >> 1) * bpp, q0, q1);
+      }
+    }
+}
+
+// ---------------------------------------------------------------- picture-level MC kernel for small PUs (4:2:0, interior)
+// Half of a B picture's MC tasks are PUs of 8x8, 8x4 or 4x8 luma samples: as tiles of k_mc / k_mc2 they use 4-16 of a
+// wavefront's 64 lanes for the price of a full tile.  Here a wavefront takes FOUR blocks of at most 8x8 luma samples, one per
+// 16-lane group, through the same steps as k_mc2 (horizontal pass -> vertical pairs in LDS -> vertical pass), with everything
+// that is a scalar there - position, vector, fractions, tap pairs, weights - held per lane.  Wavefront-uniform stay: the two
+// reference slots (the host sorts the blocks by their slot pair: one buffer descriptor per list, uni / bi known) and the code
+// path: both passes always run, fraction 0 through the taps (0,0,0,64,0,..): bit-exact because 64 * s >> shift1 fits the
+// int16 intermediate and (64 * v) >> 6 = v; all four weighting modes through the explicit-weight formulas with w = 1, o = 0
+// where the slice has none ((a + 2^(s-1)) >> s and (a + b + 2^s) >> (s+1) are those formulas at log2WD = s).
+#define MM_LP 20                      // luma input: 15 rows x 5 chunks of 4 samples
+#define MM_LROWS 15
+#define MM_CP 12                      // chroma input: 2 planes x 7 rows x 3 chunks
+#define MM_CROWS 7
+#define MC_MICRO_LDS (4 * MM_LROWS * MM_LP * 2 + 8 * MM_CROWS * MM_CP * 2 + 4 * 128 * 4 + (48 + 64) * 4)
+template <typename PX>
+__device__ __forceinline__ void mc_micro_body(const PicDev& P, const DpbTable& dpb, const PlaneRef& d0, const PlaneRef& d1, const PlaneRef& d2,
+                                              const McTask* __restrict__ tasks, const de265hip_slice_params* __restrict__ slices, int n_quads,
+                                              unsigned bid, char* smem)
+{
+  uint16_t (*s_inL)[MM_LROWS * MM_LP] = reinterpret_cast<uint16_t (*)[MM_LROWS * MM_LP]>(smem);                      // 4 x 600 B
+  uint16_t (*s_inC)[2][MM_CROWS * MM_CP] = reinterpret_cast<uint16_t (*)[2][MM_CROWS * MM_CP]>(smem + 4 * MM_LROWS * MM_LP * 2);   // 4 x 336 B
+  uint32_t (*s_pair)[128] = reinterpret_cast<uint32_t (*)[128]>(smem + 4 * MM_LROWS * MM_LP * 2 + 8 * MM_CROWS * MM_CP * 2);   // per group [first copy | second copy] of 8 pair rows x 8 columns
+  // the tap tables, indexed per lane: from LDS (as loads from constant memory they were four dependent memory round trips per list)
+  uint32_t* s_tq = reinterpret_cast<uint32_t*>(smem + 4 * MM_LROWS * MM_LP * 2 + 8 * MM_CROWS * MM_CP * 2 + 4 * 128 * 4);      // [4][12]
+  uint32_t* s_te = s_tq + 48;                                                                                                  // [8][8]
+  const int lane = threadIdx.x, g = lane >> 4, gl = lane & 15;
+  const int per = (n_quads + 7) >> 3;                  // XCD-aware: see k_mc
+  const int qix = (bid & 7) * per + (bid >> 3);
+  if (qix >= n_quads) return;
+  constexpr int bpp = (int)sizeof(PX);
+  if (lane < 48) s_tq[lane] = (&c_qpel_eo[0][0])[lane];
+  s_te[lane] = (&c_epel_eo[0][0])[lane];
+  // the group's task, per lane
+  uint32_t tw[5];
+  {
+    const uint32_t* tq = reinterpret_cast<const uint32_t*>(tasks + 4 * qix + g);
+#pragma unroll
+    for (int i = 0; i < 5; i++) tw[i] = tq[i];
+  }
+  const int X = tw[0] & 0xFFFF, Y = tw[0] >> 16, W = tw[1] & 0xFF, H = (tw[1] >> 8) & 0xFF;
+  // (slots: wavefront-uniform by construction; read from the first group)
+  const int slot0 = (int8_t)(__builtin_amdgcn_readfirstlane(tw[1]) >> 16), slot1 = (int8_t)(__builtin_amdgcn_readfirstlane(tw[1]) >> 24);
+  const bool use0 = slot0 >= 0, use1 = slot1 >= 0, bi = use0 && use1;
+  const int mvx[2] = { (int16_t)(tw[2] & 0xFFFF), (int16_t)(tw[3] & 0xFFFF) }, mvy[2] = { (int16_t)(tw[2] >> 16), (int16_t)(tw[3] >> 16) };
+  const int slice_idx = tw[4] & 0xFFFF, ref0 = (int8_t)(tw[4] >> 16), ref1 = (int8_t)(tw[4] >> 24);
+  const de265hip_slice_params* sh = &slices[slice_idx];
+  const int bdL = P.bd_luma, bdC = P.bd_chroma, cH = P.height >> 1;
+  const int cpl = gl >> 3;                             // chroma: lane -> plane
+
+  // weights per lane: luma, and the lane's chroma plane
+  const int l_uni = use0 ? 0 : 1;
+  int w0 = 1, o0 = 0, w1 = 1, o1 = 0, log2WD = 14 - bdL, cw0 = 1, co0 = 0, cw1 = 1, co1 = 0, clog2WD = 14 - bdC;
+  {
+    const bool weighted = sh->slice_type == 1 ? P.weighted_pred != 0 : P.weighted_bipred != 0;
+    if (weighted) {
+      const int la = bi ? 0 : l_uni, ra = la ? ref1 : ref0;
+      log2WD = sh->luma_log2_weight_denom + max(2, 14 - bdL);
+      clog2WD = sh->chroma_log2_weight_denom + max(2, 14 - bdC);
+      w0 = sh->luma_weight[la][ra]; o0 = sh->luma_offset[la][ra] * (1 << P.wp_shift_luma);
+      cw0 = sh->chroma_weight[la][ra][cpl]; co0 = sh->chroma_offset[la][ra][cpl] * (1 << P.wp_shift_chroma);
+      if (bi) {
+        w1 = sh->luma_weight[1][ref1]; o1 = sh->luma_offset[1][ref1] * (1 << P.wp_shift_luma);
+        cw1 = sh->chroma_weight[1][ref1][cpl]; co1 = sh->chroma_offset[1][ref1][cpl] * (1 << P.wp_shift_chroma);
+      }
+    }
+  }
+
+  // destination (one descriptor: the planes of a slot are one allocation, host.hip alloc_slot)
+  const int dsbL = d0.stride * bpp, dsbC = d1.stride * bpp;
+  const int dofCb = (int)((const char*)d1.ptr - (const char*)d0.ptr), dofCr = (int)((const char*)d2.ptr - (const char*)d0.ptr);
+  const __amdgpu_buffer_rsrc_t rdD = mc_rsrc(d0.ptr, (uint32_t)(max(dofCb, dofCr) + dsbC * cH));
+  const int vr = gl >> 1, vc4 = (gl & 1) * 4;          // luma output: row, 4 columns
+  const int cy = (gl >> 1) & 3, cc2 = (gl & 1) * 2;    // chroma output: plane cpl, row, 2 columns
+  uint16_t* const pair16 = reinterpret_cast<uint16_t*>(s_pair[g]);
+  const uint32_t* const pairw = s_pair[g];
+
+  int prL[2][4], prC[2][2];
+  uint2 fl[5], fc[3];
+  int oxL = 0, oxC = 0;
+  auto issue = [&](int l) {                            // the list's reference block of this lane's group: luma row gl, chroma (plane, row)
+    const int slot = l ? slot1 : slot0;
+    const PlaneRef pl = dpb.p[slot][0], pb = dpb.p[slot][1], pr = dpb.p[slot][2];
+    const int sbL = pl.stride * bpp, sbC = pb.stride * bpp;
+    const int ofCb = (int)((const char*)pb.ptr - (const char*)pl.ptr), ofCr = (int)((const char*)pr.ptr - (const char*)pl.ptr);
+    const __amdgpu_buffer_rsrc_t rs = mc_rsrc(pl.ptr, (uint32_t)(max(ofCb, ofCr) + sbC * cH));
+    const int xs = X + (mvx[l] >> 2) - 3, ys = Y + (mvy[l] >> 2) - 3;
+    oxL = xs & 3;
+    const int vo = (ys + min(gl, MM_LROWS - 1)) * sbL + (xs & ~3) * bpp;
+#pragma unroll
+    for (int k = 0; k < 5; k++) fl[k] = mc_fetch4<PX>(rs, vo + 4 * k * bpp, 0);
+    const int xc = (X >> 1) + (mvx[l] >> 3) - 1, yc = (Y >> 1) + (mvy[l] >> 3) - 1;
+    oxC = xc & 3;
+    const int vc = (cpl ? ofCr : ofCb) + (yc + min(gl & 7, MM_CROWS - 1)) * sbC + (xc & ~3) * bpp;
+#pragma unroll
+    for (int k = 0; k < 3; k++) fc[k] = mc_fetch4<PX>(rs, vc + 4 * k * bpp, 0);
+  };
+  auto commit = [&]() {
+    if (gl < MM_LROWS) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) *reinterpret_cast<uint2*>(&s_inL[g][gl * MM_LP + 4 * k]) = fl[k];
+    }
+    if ((gl & 7) < MM_CROWS) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) *reinterpret_cast<uint2*>(&s_inC[g][cpl][(gl & 7) * MM_CP + 4 * k]) = fc[k];
+    }
+  };
+  if (use0) issue(0); else issue(1);
+#pragma unroll
+  for (int l = 0; l < 2; l++) {
+    if (l == 0 ? !use0 : !use1) continue;
+    const int oL = oxL, oC = oxC;                      // (of the block being committed)
+    commit();
+    if (l == 0 && use1) issue(1);                      // the second list's block travels while the first is filtered
+    MC_LDS_SYNC();
+    // ---- luma: horizontal pass, lane -> row gl (15 rows), 8 outputs
+    {
+      const uint32_t* th = s_tq + 12 * (mvx[l] & 3);
+      uint32_t T[9];
+#pragma unroll
+      for (int m = 0; m < 9; m++) T[m] = th[m];
+      if (gl < MM_LROWS) {
+        const uint32_t* rowd = reinterpret_cast<const uint32_t*>(&s_inL[g][gl * MM_LP + (oL & ~1)]);
+        uint32_t D[9], E[8];
+#pragma unroll
+        for (int m = 0; m < 9; m++) D[m] = rowd[m];
+        const int sa = (oL & 1) * 16;
+#pragma unroll
+        for (int m = 0; m < 8; m++) E[m] = __builtin_amdgcn_alignbit(D[m + 1], D[m], sa);
+        int o[8];
+        mc_h8<0, false>(E, T, o);
+        const int pe = ((gl >> 1) * 8) * 2 + (gl & 1), po = (64 + ((gl + 1) >> 1) * 8) * 2 + ((gl + 1) & 1);
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const uint16_t v = (uint16_t)(o[j] >> (bdL - 8)); pair16[pe + 2 * j] = v; pair16[po + 2 * j] = v; }
+      }
+    }
+    MC_LDS_SYNC();
+    {
+      const uint32_t* tv = s_tq + 12 * (mvy[l] & 3);
+      const int pv = (vr & 1) * 64 + ((vr + (vr & 1)) >> 1) * 8 + vc4;
+      int acc[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint4 v = *reinterpret_cast<const uint4*>(&pairw[pv + j * 8]);
+        const uint32_t tp = tv[j];
+        if (j == 0) { acc[0] = mc_dot2_first(v.x, tp); acc[1] = mc_dot2_first(v.y, tp); acc[2] = mc_dot2_first(v.z, tp); acc[3] = mc_dot2_first(v.w, tp); }
+        else {
+          acc[0] = mc_dot2(v.x, tp, acc[0]); acc[1] = mc_dot2(v.y, tp, acc[1]);
+          acc[2] = mc_dot2(v.z, tp, acc[2]); acc[3] = mc_dot2(v.w, tp, acc[3]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) prL[l][j] = (int16_t)(acc[j] >> 6);
+    }
+    MC_LDS_SYNC();
+    // ---- chroma: horizontal pass, lane -> plane gl>>3, row gl&7 (7 rows), 4 outputs
+    {
+      const uint32_t* th = s_te + 8 * (mvx[l] & 7);
+      uint32_t T[5];
+#pragma unroll
+      for (int m = 0; m < 5; m++) T[m] = th[m];
+      if ((gl & 7) < MM_CROWS) {
+        const int r = gl & 7;
+        const uint32_t* rowd = reinterpret_cast<const uint32_t*>(&s_inC[g][cpl][r * MM_CP + (oC & ~1)]);
+        uint32_t D[5], E[4];
+#pragma unroll
+        for (int m = 0; m < 5; m++) D[m] = rowd[m];
+        const int sa = (oC & 1) * 16;
+#pragma unroll
+        for (int m = 0; m < 4; m++) E[m] = __builtin_amdgcn_alignbit(D[m + 1], D[m], sa);
+        int o[4];
+        mc_h4<0, false>(E, T, o);
+        // per plane [first copy | second copy] of 4 pair rows x 4 columns
+        const int cb = cpl * 32;
+        const int pe = (cb + (r >> 1) * 4) * 2 + (r & 1), po = (cb + 16 + ((r + 1) >> 1) * 4) * 2 + ((r + 1) & 1);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const uint16_t v = (uint16_t)(o[j] >> (bdC - 8)); pair16[pe + 2 * j] = v; pair16[po + 2 * j] = v; }
+      }
+    }
+    MC_LDS_SYNC();
+    {
+      const uint32_t* tv = s_te + 8 * (mvy[l] & 7);
+      const int pv = cpl * 32 + (cy & 1) * 16 + ((cy + (cy & 1)) >> 1) * 4 + cc2;
+      const uint2 v0 = *reinterpret_cast<const uint2*>(&pairw[pv]);
+      const uint2 v1 = *reinterpret_cast<const uint2*>(&pairw[pv + 4]);
+      const uint32_t q0 = tv[0], q1 = tv[1];
+      prC[l][0] = (int16_t)(mc_dot2(v1.x, q1, mc_dot2_first(v0.x, q0)) >> 6);
+      prC[l][1] = (int16_t)(mc_dot2(v1.y, q1, mc_dot2_first(v0.y, q0)) >> 6);
+    }
+    MC_LDS_SYNC();                                     // the input tile and the pair buffers are reused by the next list
+  }
+  // ---- weighted sample prediction and store
+  const int maxL = (1 << bdL) - 1, maxC = (1 << bdC) - 1;
+  int ol[4], oc[2];
+  if (bi) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) ol[j] = mc_clip3(0, maxL, (prL[0][j] * w0 + prL[1][j] * w1 + ((o0 + o1 + 1) << log2WD)) >> (log2WD + 1));
+#pragma unroll
+    for (int j = 0; j < 2; j++) oc[j] = mc_clip3(0, maxC, (prC[0][j] * cw0 + prC[1][j] * cw1 + ((co0 + co1 + 1) << clog2WD)) >> (clog2WD + 1));
+  } else {
+    const int lu = l_uni;
+#pragma unroll
+    for (int j = 0; j < 4; j++) ol[j] = mc_clip3(0, maxL, ((prL[lu][j] * w0 + (1 << (log2WD - 1))) >> log2WD) + o0);
+#pragma unroll
+    for (int j = 0; j < 2; j++) oc[j] = mc_clip3(0, maxC, ((prC[lu][j] * cw0 + (1 << (clog2WD - 1))) >> clog2WD) + co0);
+  }
+  if (vr < H && vc4 < W) mc_store4<PX>(rdD, (Y + vr) * dsbL + (X + vc4) * bpp, 0, ol);
+  if (cy < (H >> 1) && cc2 < (W >> 1))
+    mc_store2<PX>(rdD, (cpl ? dofCr : dofCb) + ((Y >> 1) + cy) * dsbC + ((X >> 1) + cc2) * bpp, 0, oc[0], oc[1]);
+}
+// ---- the three forms in one launch: [k_mc's border tiles | k_mc2's chunks | k_mc_micro's quads], every segment a multiple of
+// 8 workgroups (XCD mapping).  The populations overlap instead of each launch paying its own ramp and tail; the border tiles
+// (per-sample clamped fetch: the longest single tasks) and the chunks start first, the short quads fill the tail.
+#define MC_ALL_LDS (MC_TILE_LDS > MC_CHUNK_LDS ? (MC_TILE_LDS > MC_MICRO_LDS ? MC_TILE_LDS : MC_MICRO_LDS) : (MC_CHUNK_LDS > MC_MICRO_LDS ? MC_CHUNK_LDS : MC_MICRO_LDS))
+template <typename PX>
+#ifndef MC_ALL_WAVES
+#define MC_ALL_WAVES 5
+#endif
+__global__ __launch_bounds__(64, MC_ALL_WAVES)
+void k_mc_all(PicDev P, DpbTable dpb, PlaneRef d0, PlaneRef d1, PlaneRef d2,
+              const McTask* __restrict__ tasks, const de265hip_slice_params* __restrict__ slices, int n_chunks, int n_quads, int n_tiles)
+{
+  __shared__ __attribute__((aligned(16))) char smem[MC_ALL_LDS];
+  const unsigned g1 = (n_tiles + 7u) & ~7u, g2 = (n_chunks + 7u) & ~7u;
+  const unsigned b = blockIdx.x;
+  if (b < g1) mc_tile_body<PX>(P, dpb, d0, d1, d2, tasks + n_chunks + 4 * n_quads, slices, n_tiles, b, smem);
+  else if (b < g1 + g2) mc_chunk_body<PX>(P, dpb, d0, d1, d2, tasks, slices, n_chunks, b - g1, smem);
+  else mc_micro_body<PX>(P, dpb, d0, d1, d2, tasks + n_chunks, slices, n_quads, b - g1 - g2, smem);
+}
+template __global__ void k_mc_all<uint8_t>(PicDev, DpbTable, PlaneRef, PlaneRef, PlaneRef, const McTask*, const de265hip_slice_params*, int, int, int);
+template __global__ void k_mc_all<uint16_t>(PicDev, DpbTable, PlaneRef, PlaneRef, PlaneRef, const McTask*, const de265hip_slice_params*, int, int, int);
 
 // ---- chroma prediction of one MC task for any chroma format (4:2:2 / 4:4:4 pictures; mc_chroma, motion.cc:175-273: the
 // vector scaled by 2 / SubWidthC, 2 / SubHeightC, eighth-sample fractions).  One wavefront per task and plane

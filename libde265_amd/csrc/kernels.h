@@ -53,6 +53,9 @@ template <typename PX>
 __global__ void k_mc(PicDev, DpbTable, PlaneRef, PlaneRef, PlaneRef, const McTask*,
                      const de265hip_slice_params*, int);
 template <typename PX>
+__global__ void k_mc_all(PicDev, DpbTable, PlaneRef, PlaneRef, PlaneRef, const McTask*,
+                         const de265hip_slice_params*, int, int, int);
+template <typename PX>
 __global__ void k_pcm(PicDev, PlaneRef, PlaneRef, PlaneRef, const PcmTask*, const uint16_t*);
 __global__ void k_bs(PicDev, const uint8_t*, const de265hip_motion*, uint8_t*);
 template <typename PX, bool VERT>
@@ -62,7 +65,7 @@ __global__ void k_deblock_fused(PicDev, PlaneRef, PlaneRef, PlaneRef, LfMeta);
 template <typename PX>
 __global__ void k_sao(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, SaoMeta);
 template <typename PX>
-__global__ void k_sao_ctb(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, SaoMeta);
+__global__ void k_sao_ctb(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, SaoMeta, uint3);
 #ifndef LF_TW
 #define LF_TW 128                        // tile of k_lf_tile (deblocking + SAO in one pass), luma / chroma samples alike
 #endif
