@@ -109,7 +109,7 @@ class _stdout_to_stderr:
 def product_pass(pipes, gops, stagger, steps=1):
     """`steps` steps through the product path: every picture of every stream is SUBMITTED to its decoder's pipeline
     (de265hip_pipeline_submit_desc: the library's own worker threads build it - host stage + pinned asynchronous upload -,
-    launch it in decode order and free it).  submit() blocks while 2 n_workers + 2 pictures of that decoder are between
+    launch it in decode order and free it).  submit() blocks while 4 n_workers + 4 pictures of that decoder are between
     parser and device, so every stream has its own submitting thread, as every stream of a server has its own parser
     (one thread feeding all streams would stall them all behind the one whose window is full)."""
     S, GOP = len(pipes), len(gops[0])

@@ -346,7 +346,7 @@ int  de265hip_recorder_submit(de265hip_decoder*, int dst_slot, de265hip_recorder
  * thread, several pictures at once) and de265hip_recorder_submit (= de265hip_picture_build) - and the device reconstructs the
  * pictures before those.  Pictures are LAUNCHED in submission order (a picture's kernels read the DPB slots its references were
  * launched into): de265hip_picture_run(STAGE_FINAL) + de265hip_dpb_download_async of every non-NULL `planes[c]` (pinned memory,
- * de265hip_host_alloc; strides as in de265hip_dpb_download).  submit() returns as soon as there is room (at most 2 n_workers + 2
+ * de265hip_host_alloc; strides as in de265hip_dpb_download).  submit() returns as soon as there is room (at most 4 n_workers + 4
  * pictures between parser and device); nobody waits for a picture until de265hip_pipeline_wait(ticket) - what a decoder calls
  * when the picture is about to be output or read (de265.cc:392 de265_peek_next_picture).  While a pipeline exists, run / dpb_* /
  * sync of its decoder belong to the pipeline; dpb_alloc of slots no queued picture uses is allowed.  An error of prepare, build
