@@ -115,12 +115,13 @@ struct de265hip_picture {
   uint8_t* d_bs = nullptr;
   SaoCtb* d_sao = nullptr;
   RunTask* d_runs = nullptr; uint32_t* d_deps = nullptr; uint32_t* d_sync = nullptr;
+  uint32_t* d_mbx = nullptr; uint32_t* d_mbsegs = nullptr; unsigned long long* d_mb = nullptr; int n_mailboxes = 0;   // k_run edge mailboxes
   TuTask* d_run_tus = nullptr;
   int n_l0_size[4] = { 0, 0, 0, 0 };          // TU count per size in d_l0 (sorted 32,16,8,4)
   TuTask* d_l0 = nullptr; int n_l0 = 0;       // run mode: inter residual TUs + residual-only copies of intra TUs
   TuTask* d_l0_rext = nullptr; int n_l0_rext = 0;   // ... those with a range-extension tool (k_resid_rext)
   int16_t* d_resid = nullptr;                 // precomputed residual blocks of intra TUs
-  int n_runs = 0, n_batches = 0, n_workers = 0, run_box = 64, ticket_batch = 1; size_t sync_bytes = 0;
+  int n_runs = 0, n_batches = 0, n_workers = 0, run_box = 64, ticket_batch = 1; size_t sync_bytes = 0, clear_bytes = 0;
   int n_front = 0;                            // runs [0, n_front): micro runs without producers, reconstructed by k_intra_front ahead of k_run
   bool run_direct = false;                    // k_run with one workgroup per ticket instead of persistent workers (wide pictures)
   uint32_t* d_slots = nullptr;
@@ -289,6 +290,7 @@ struct RunB {                                            // a run under construc
   int32_t n_tus, head, tail;                             // its TUs: list through BuildScratch::it_next, decode order
   int32_t n_deps, dep_head, dep_tail;                    // its producer runs: list through BuildScratch::dep_next, order of discovery
   int64_t alg;
+  int32_t foreign;                                       // some neighbour its TUs read is not written by an intra run of this picture (inter / PCM samples)
 };
 struct BuildScratch {
   std::vector<Cell> cells[3];
@@ -302,7 +304,7 @@ struct BuildScratch {
   std::vector<int> level_hist;
   std::vector<TuTask> all_tasks; std::vector<int> all_levels;                              // DE265HIP_INTRA_MODE=levels only
   std::vector<TuTask> l0, run_tus;
-  std::vector<RunTask> runs; std::vector<uint32_t> run_deps, slots;
+  std::vector<RunTask> runs; std::vector<uint32_t> run_deps, slots, mbx, mb_segs;
   std::vector<int> order, newidx, count2, width; std::vector<uint8_t> micro;
   std::vector<McTask> mcs, mcs2, mc_micro[17 * 17]; std::vector<int> micro_keys; std::vector<PcmTask> pcms; std::vector<SaoCtb> saos;
 };
@@ -892,10 +894,12 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       // (4:4:4 chroma is smoothed like luma: it takes luma's table, a superset of what it reads)
       uint64_t need = mode_deps ? needed_units(g_used_units[tu.log2_size - 2][m][c == 0 || cf == 3], mask) : mask;
       int lev = 0, llev = 0, n_prod = 0;
+      bool foreign = false;
       const int crun = cur_run[c];
       for (; need; need &= need - 1) {
         const Cell C = cells[cell[__builtin_ctzll(need)]];
         const int cr = C.run - E;                           // (< 0: no intra TU of this picture covers the cell)
+        foreign = foreign || cr < 0;
         if (cr >= 0) {
           lev = std::max(lev, (int)C.lvl);
           if (cr == crun) llev = std::max(llev, (int)C.llvl);
@@ -950,6 +954,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
         llev = 1;
       }
       RunB& R = rb[r];
+      if (foreign) R.foreign = 1;
       R.x0 = std::min(R.x0, (int)tu.x0); R.y0 = std::min(R.y0, (int)tu.y0);
       R.x1 = std::max(R.x1, tu.x0 + nT); R.y1 = std::max(R.y1, tu.y0 + nT);
       R.wx1 = std::max(R.wx1, tu.x0 + 2 * nT); R.wy1 = std::max(R.wy1, tu.y0 + 2 * nT);    // top-right / bottom-left reach
@@ -1016,7 +1021,10 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   const int micro_tus = getenv("DE265HIP_MICRO_TUS") ? std::min(16, atoi(getenv("DE265HIP_MICRO_TUS"))) : 16;   // MICRO_TUS of k_run
   int64_t sum_lvls = 0, dbg_foreign = 0, dbg_w[4] = { 0, 0, 0, 0 };
   size_t n_resid = 0;
-  int max_rl = 0, n_front = 0;
+  int max_rl = 0, n_front = 0, n_mailboxes = 0;
+  static const bool mailbox_on = getenv("DE265HIP_NO_MAILBOX") == nullptr;
+  std::vector<uint32_t>& mbx = SC.mbx; std::vector<uint32_t>& mb_segs = SC.mb_segs;      // per run: (own mailbox, first dword of its segments); the segments
+  mbx.assign(2 * rb.size(), 0xFFFFFFFFu); mb_segs.clear();
   {
     for (auto& R : rb) { int l = 0; for (int e = R.dep_head; e >= 0; e = SC.dep_next[e]) l = std::max(l, rb[SC.dep_val[e]].level); R.level = l + 1; max_rl = std::max(max_rl, R.level); }
     std::vector<int>& order = SC.order; std::vector<int>& newidx = SC.newidx;
@@ -1160,6 +1168,51 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       o.n_samples = samp;
       n_resid += (samp + 7u) & ~7u;
       for (int e = R.dep_head; e >= 0; e = SC.dep_next[e]) if (newidx[SC.dep_val[e]] >= n_front) run_deps.push_back((uint32_t)newidx[SC.dep_val[e]]);
+      // Edge mailboxes (k_run): a dense ordinary run whose every neighbour sample comes from the bottom row / right column of
+      // dense ordinary runs takes them from those runs' mailboxes - tagged packets the producer stores the moment its chain
+      // ends - instead of waiting for the flag (store drain -> flag -> poll) and then fetching its window from the picture.
+      // Its part of the deps array: [producer ids | own mailbox, once somebody reads it | segment count, segments].
+      if (mailbox_on && !micro[order[k]] && dense && !R.foreign && o.n_deps > 0 && o.n_deps == R.n_deps && o.n_deps <= 8) {
+        const int ax0 = ((int)o.x0 - 1) & ~7, wy0 = (int)o.y0 - 1, tile_p = (64 + 40 + 7) & ~7;      // RUN_TILE_P_OF(64) of k_run
+        const int cw_ = R.c ? cwid : p.width, ch_ = R.c ? chei : p.height;
+        const int wx1c = std::min((int)o.wx1, cw_), wy1c = std::min((int)o.wy1, ch_);
+        uint32_t seg[2 * 16]; int nseg = 0; bool ok = true;
+        for (int e = R.dep_head; e >= 0 && ok; e = SC.dep_next[e]) {
+          const int pk = newidx[SC.dep_val[e]];
+          const RunTask& Pq = runs[pk];
+          if ((Pq.micro & 3) != 2) { ok = false; break; }                 // producer: ordinary and dense
+          bool any = false;
+          if ((int)Pq.y0 <= wy0 && wy0 < (int)Pq.y1) {                    // the row above the box
+            const int xs = std::max((int)Pq.x0, (int)o.x0 - 1), xe = std::min((int)Pq.x1, wx1c);
+            if (xs < xe) {
+              if ((int)Pq.y1 - 1 != wy0) { ok = false; break; }
+              seg[2 * nseg] = (uint32_t)pk | ((uint32_t)(xe - xs - 1) << 24); seg[2 * nseg + 1] = (uint32_t)(xs - Pq.x0) | ((uint32_t)(xs - ax0) << 8);
+              nseg++; any = true;
+            }
+          }
+          if ((int)Pq.x0 <= (int)o.x0 - 1 && (int)o.x0 - 1 < (int)Pq.x1) {  // the column left of it
+            const int ys = std::max((int)Pq.y0, (int)o.y0), ye = std::min((int)Pq.y1, wy1c);
+            if (ys < ye) {
+              if ((int)Pq.x1 != (int)o.x0) { ok = false; break; }
+              seg[2 * nseg] = (uint32_t)pk | ((uint32_t)(ye - ys - 1) << 24) | 0x80000000u;
+              seg[2 * nseg + 1] = (uint32_t)(ys - Pq.y0) | ((uint32_t)((ys - wy0) * tile_p + ((int)o.x0 - 1 - ax0)) << 8);
+              nseg++; any = true;
+            }
+          }
+          if (!any) ok = false;
+        }
+        if (ok && nseg > 0) {
+          o.micro |= 4;
+          for (int q = 0; q < nseg; q++) {                  // producer run index -> its mailbox
+            const uint32_t pk = seg[2 * q] & 0xFFFFFFu;
+            if (!(runs[pk].micro & 8)) { runs[pk].micro |= 8; mbx[2 * pk] = (uint32_t)n_mailboxes++; }
+            seg[2 * q] = (seg[2 * q] & 0xFF000000u) | mbx[2 * pk];
+          }
+          mbx[2 * k + 1] = (uint32_t)mb_segs.size();
+          mb_segs.push_back((uint32_t)nseg);
+          mb_segs.insert(mb_segs.end(), seg, seg + 2 * nseg);
+        }
+      }
     }
   }
   pt.mark("runs");
@@ -1409,12 +1462,19 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   const size_t o_slots = L.add(slots.size() * 4);
   const size_t o_l0 = L.add(l0.size() * sizeof(TuTask));
   const size_t o_l0x = L.add(SC.l0_rext.size() * sizeof(TuTask));
+  const size_t o_mbx = L.add(n_mailboxes ? mbx.size() * 4 : 0), o_mbs = L.add(n_mailboxes ? mb_segs.size() * 4 : 0);
   const size_t upload_bytes = L.total;                 // everything above is written by the host
   // device-only scratch: boundary strengths, residual blocks, run flags (no staging, no upload)
   const size_t o_bs = L.add(nblk);
   const size_t o_resid = L.add(n_resid * 2 + 64);
   pic->sync_bytes = (2 + runs.size()) * 4;
   const size_t o_sync = L.add(pic->sync_bytes);
+  // edge mailboxes of k_run: 64 packets of (two samples, generation) per publishing run - its bottom row, then its right
+  // column; cleared with the flags (a packet counts when it carries the launch's generation)
+  const size_t mb_bytes = (size_t)n_mailboxes * 64 * 8;
+  const size_t o_mb = L.add(mb_bytes);
+  const size_t clear_bytes = L.total - o_sync;           // flags + mailboxes: one memset
+  pic->clear_bytes = clear_bytes;
   // pinned staging + pooled arena: no allocation, no host-side wait in the steady state
   int stage_idx = -1;
   uint8_t* host_base = nullptr;
@@ -1457,6 +1517,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   put(o_slots, slots.data(), slots.size() * 4);
   put(o_l0, l0.data(), l0.size() * sizeof(TuTask));
   put(o_l0x, SC.l0_rext.data(), SC.l0_rext.size() * sizeof(TuTask));
+  if (n_mailboxes) { put(o_mbx, mbx.data(), mbx.size() * 4); put(o_mbs, mb_segs.data(), mb_segs.size() * 4); }
   put(o_flags, d->blk_flags, nblk); put(o_qp, d->blk_qp_y, nblk);
   if (d->blk_motion) put(o_mot, d->blk_motion, nblk * sizeof(de265hip_motion));
   else memset(host.data() + o_mot, 0xFF, nblk * sizeof(de265hip_motion));       // ref_slot = -1 everywhere
@@ -1475,6 +1536,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
                              pic->n_tus, pic->n_runs, (int64_t)n_resid, (int64_t)L.total, (int64_t)pic->any_edges, (int64_t)P.has_exempt, (int64_t)pic->run_direct, max_level, max_rl, (int64_t)sum_lvls, (int64_t)pic->n_front };
     mix(scal, sizeof(scal));
     if (!SC.l0_rext.empty()) mix(host.data() + o_l0x, SC.l0_rext.size() * sizeof(TuTask));
+    if (n_mailboxes) { mix(host.data() + o_mbx, mbx.size() * 4); mix(host.data() + o_mbs, mb_segs.size() * 4); }
     mix(pic->level_start.data(), pic->level_start.size() * sizeof(int));
     dec->pooled_bytes = (size_t)hsh;
   }
@@ -1486,7 +1548,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     if (pic->arena_buf.used && hipStreamWaitEvent(cs, pic->arena_buf.last_use, 0) != hipSuccess) return fail(DE265HIP_ERROR_DECODING);
     if (hipEventCreateWithFlags(&pic->uploaded, hipEventDisableTiming) != hipSuccess) return fail(DE265HIP_ERROR_OUT_OF_MEMORY);
     if (hipMemcpyAsync(pic->arena, host.data(), upload_bytes, hipMemcpyHostToDevice, cs) != hipSuccess ||
-        hipMemsetAsync((uint8_t*)pic->arena + o_sync, 0, pic->sync_bytes, cs) != hipSuccess ||
+        hipMemsetAsync((uint8_t*)pic->arena + o_sync, 0, clear_bytes, cs) != hipSuccess ||
         hipEventRecord(stage_event, cs) != hipSuccess || hipEventRecord(pic->uploaded, cs) != hipSuccess)
       return fail(DE265HIP_ERROR_DECODING);
     std::lock_guard<std::mutex> lk(dec->mu);
@@ -1509,6 +1571,8 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   pic->d_run_tus = (TuTask*)(base + o_rtus); pic->d_slots = (uint32_t*)(base + o_slots); pic->d_sync = (uint32_t*)(base + o_sync);
   pic->d_l0 = (TuTask*)(base + o_l0); pic->d_resid = (int16_t*)(base + o_resid);
   pic->d_l0_rext = (TuTask*)(base + o_l0x); pic->n_l0_rext = (int)SC.l0_rext.size();
+  pic->d_mbx = n_mailboxes ? (uint32_t*)(base + o_mbx) : nullptr; pic->d_mbsegs = (uint32_t*)(base + o_mbs); pic->d_mb = (unsigned long long*)(base + o_mb);
+  pic->n_mailboxes = n_mailboxes;
 
   const int64_t Pbytes = ((int64_t)p.width * p.height + 2 * (int64_t)cwid * chei) * px_bytes(p.bit_depth_luma);
   pic->stats.n_levels = max_level + (pic->level_start[1] > 0 ? 1 : 0);
@@ -1673,10 +1737,10 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
       uint32_t base = 0, gen = 1;
       if (pic->run_direct) gen = ++pic->gen;                        // (no ticket counter at all)
       else if (pic->ticket_batch == 1) { gen = ++pic->gen; base = (gen - 1u) * (uint32_t)(pic->n_batches + pic->n_workers); }
-      else { (void)hipMemsetAsync(pic->d_sync, 0, pic->sync_bytes, st); pic->gen = 0; }
+      else { (void)hipMemsetAsync(pic->d_sync, 0, pic->clear_bytes, st); pic->gen = 0; }
       hipLaunchKernelGGL((k_run<PX, 64>), dim3(pic->run_direct ? pic->n_batches : pic->n_workers), dim3(64 * dec->run_waves), 0, st, P, d0, d1, d2,
                          pic->d_runs, pic->d_deps, pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->d_slots, pic->n_batches,
-                         pic->run_direct ? 0 : pic->ticket_batch, base, gen, dec->dbg, dec->spin_limit);
+                         pic->run_direct ? 0 : pic->ticket_batch, base, gen, dec->dbg, dec->spin_limit, pic->d_mbx, pic->d_mbsegs, pic->d_mb);
     }
   } else {
     if (nlev > 0 && pic->level_start[1] > pic->level_start[0]) {

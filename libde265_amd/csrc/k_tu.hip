@@ -1556,7 +1556,8 @@ __global__ __launch_bounds__(64 * RUN_WAVES)
 void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __restrict__ runs,
            const uint32_t* __restrict__ deps, uint32_t* sync, uint32_t* err, const TuTask* __restrict__ tasks,
            const int16_t* __restrict__ resid, const uint32_t* __restrict__ slots, int n_batches, int batch, uint32_t ticket_base,
-           uint32_t gen, int dbg, uint32_t spin_limit)
+           uint32_t gen, int dbg, uint32_t spin_limit, const uint32_t* __restrict__ mbx, const uint32_t* __restrict__ mbsegs,
+           unsigned long long* mb)
 {
   constexpr int RUN_TILE_H = RUN_TILE_H_OF(BOX), RUN_TILE_P = RUN_TILE_P_OF(BOX);
   constexpr int MAX_TUS = BOX * BOX / 16;
@@ -1654,9 +1655,37 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   const uint32_t ticket = slv[0];
   const RunTask run = load_run_task(runs, ticket);
   st.mark(0);
-  const bool has_dep = tid < (int)run.n_deps;
+  // Edge mailboxes (host.hip): a run marked 8 stores its bottom row and right column as packets (two samples | generation << 32)
+  // the moment its chain ends; a run marked 4 reads every neighbour sample from such packets instead of waiting for the
+  // producers' flags (which follow the drain of ALL their stores) and then fetching its window from the picture: one memory
+  // round trip between two dependent runs instead of three.
+  const bool mb_cons = (run.micro & 4) && !(RUN_DBG & 2048), mb_pub = (run.micro & 8) != 0;
+  uint32_t mb_own = 0, mb_seg0 = 0;
+  if (run.micro & 12) { mb_own = __builtin_amdgcn_readfirstlane(mbx[2 * ticket]); mb_seg0 = __builtin_amdgcn_readfirstlane(mbx[2 * ticket + 1]); }
+  const bool has_dep = tid < (int)run.n_deps && !mb_cons;
   uint32_t dep_id = 0;
   if (has_dep) dep_id = deps[run.dep_offset + tid];
+  // neighbour sample s of the run (s counts through its segments): packet address, which half, where it goes in the window
+  auto mb_locate = [&](int s_, const unsigned long long*& src_p, int& half, int& dst) {
+    const int nseg = (int)__builtin_amdgcn_readfirstlane(mbsegs[mb_seg0]);
+    int acc = 0;
+    src_p = nullptr;
+    for (int q = 0; q < nseg; q++) {
+      const uint32_t a = __builtin_amdgcn_readfirstlane(mbsegs[mb_seg0 + 1 + 2 * q]), b = __builtin_amdgcn_readfirstlane(mbsegs[mb_seg0 + 2 + 2 * q]);
+      const int cnt = (int)((a >> 24) & 63) + 1, off = s_ - acc;
+      if (off >= 0 && off < cnt) {
+        const bool col = a >> 31;
+        const int src = (int)(b & 63) + off;
+        src_p = mb + (size_t)(a & 0xFFFFFFu) * 64 + (col ? 32 : 0) + (src >> 1);
+        half = src & 1;
+        dst = (int)(b >> 8) + off * (col ? RUN_TILE_P : 1);
+      }
+      acc += cnt;
+    }
+    return acc;                                        // samples in all segments
+  };
+  const unsigned long long* mb_src = nullptr; int mb_half = 0, mb_dst = 0, mb_total = 0;
+  if (mb_cons) mb_total = mb_locate(tid, mb_src, mb_half, mb_dst);
 
   const int c = run.c_idx;
   const PlaneRef pr = c == 0 ? pl0 : (c == 1 ? pl1 : pl2);
@@ -1748,7 +1777,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   };
   // producers already finished (the usual case when the picture is throughput-bound): fetch the window now,
   // under the preparation of the samples, instead of after it
-  const bool early = !(RUN_DBG & 8) && (run.n_deps == 0 || __syncthreads_and(flag0 == gen));
+  const bool early = !(RUN_DBG & 8) && !mb_cons && (run.n_deps == 0 || __syncthreads_and(flag0 == gen));
   if (early) {
 #if !RUN_SC1_WINDOW
     if (run.n_deps && !(RUN_DBG & 2)) {
@@ -1770,6 +1799,21 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   st.mark(2);
   int wbase = 0;
   if (early) { window_commit(); wbase = 4 * nthr; }
+  else if (mb_cons) {
+    for (int s_ = tid; s_ < mb_total; s_ += nthr) {     // (one pass with 256 threads: at most 193 samples)
+      if (s_ != tid) mb_locate(s_, mb_src, mb_half, mb_dst);
+      if (!mb_src) continue;
+      uint32_t spins = 0;
+      unsigned long long v = __hip_atomic_load(mb_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while ((uint32_t)(v >> 32) != gen) {
+        if (spins) { if (spins < RUN_POLL_FAST_N) __builtin_amdgcn_s_sleep(RUN_POLL_FAST); else __builtin_amdgcn_s_sleep(RUN_POLL_SLOW); }
+        if (++spins > spin_limit) { atomicExch(err, 1u); break; }               // never hang the grid
+        v = __hip_atomic_load(mb_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      tile[mb_dst] = (uint16_t)(v >> (16 * mb_half));
+    }
+    wbase = nchunks;                                   // (a dense run reads nothing else from outside its box)
+  }
   else if (run.n_deps) {
     for (int i = tid; i < run.n_deps; i += nthr) {
       const uint32_t* flag = &sync[2 + (i == tid ? dep_id : deps[run.dep_offset + i])];
@@ -1917,6 +1961,16 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   // The flag is only raised after the run, so nothing is lost by storing here instead of per TU, and a
   // write-through store costs one fabric write whatever its size.
   __syncthreads();
+  if (mb_pub && tid < 64) {
+    const bool col = tid >= 32;
+    const int i = 2 * (tid & 31);
+    const int bw = (int)run.x1 - (int)run.x0, bh = (int)run.y1 - (int)run.y0;
+    if (i < (col ? bh : bw)) {
+      const int r = col ? (int)run.y0 - wy0 + i : (int)run.y1 - 1 - wy0, cx = col ? (int)run.x1 - 1 - ax0 : (int)run.x0 - ax0 + i;
+      const uint32_t a = tile[r * RUN_TILE_P + cx], b = col ? tile[(r + 1) * RUN_TILE_P + cx] : tile[r * RUN_TILE_P + cx + 1];
+      __hip_atomic_store(mb + (size_t)mb_own * 64 + tid, ((unsigned long long)gen << 32) | (b << 16) | a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   {
     PX* wplane = plane + ax0 + wy0 * stride;                             // picture address of window sample (0, 0)
     const int rows = (int)run.y1 - (int)run.y0, nch = ((int)run.x1 - ax0 + 7) >> 3;
@@ -1967,8 +2021,8 @@ template __global__ void k_tu<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, con
                                        const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
 template __global__ void k_tu<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int,
                                         const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
-template __global__ void k_run<uint8_t, 64>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, const uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t);
-template __global__ void k_run<uint16_t, 64>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, const uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t);
+template __global__ void k_run<uint8_t, 64>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, const uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t, const uint32_t*, const uint32_t*, unsigned long long*);
+template __global__ void k_run<uint16_t, 64>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*, const TuTask*, const int16_t*, const uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t, const uint32_t*, const uint32_t*, unsigned long long*);
 template __global__ void k_fn_residual<uint8_t>(int, int, int, uint8_t*, int, const int32_t*, const int16_t*);
 template __global__ void k_fn_residual<uint16_t>(int, int, int, uint16_t*, int, const int32_t*, const int16_t*);
 

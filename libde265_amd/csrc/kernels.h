@@ -45,7 +45,7 @@ __global__ void k_resid_small(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask
 #define RUN_WAVES 4          // wavefronts per run workgroup (one per SIMD of a CU); blockDim.x = 64..64*RUN_WAVES
 template <typename PX, int BOX>
 __global__ void k_run(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*,
-                      const TuTask*, const int16_t*, const uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t);
+                      const TuTask*, const int16_t*, const uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t, const uint32_t*, const uint32_t*, unsigned long long*);
 #define RUN_SPIN_LIMIT_DEFAULT (1u << 21)   // polls (~1 us each) a k_run wavefront waits for a producer's flag before the picture fails instead of hanging
 template <typename PX>
 __global__ void k_intra_front(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const TuTask*, const int16_t*, int);
