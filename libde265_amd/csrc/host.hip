@@ -127,7 +127,8 @@ struct de265hip_picture {
   uint32_t* d_slots = nullptr;
   uint32_t gen = 0;                           // runs of this picture so far (k_run flag generation)
   std::vector<int> level_start;       // level_start[l] .. level_start[l+1] in d_tus
-  int n_mc = 0, n_mc2 = 0, n_mc_quads = 0, n_pcm = 0, n_tus = 0;   // MC tasks: n_mc2 chunks (k_mc2), then 4 * n_mc_quads blocks (k_mc_micro), then k_mc's tiles
+  int n_mc = 0, n_mc2 = 0, n_mc_quads = 0, n_pcm = 0, n_tus = 0;   // MC tasks in all; of them n_mc2 chunks and 4 * n_mc_quads small blocks
+  McBands mc_bands; bool mc_all = false;                            // k_mc_all: where band x's tiles / chunks / quads are
   bool any_edges = false;
   uint32_t ref_mask = 0;              // DPB slots the picture's MC tasks read (validated when the picture is launched)
   int n_launched = 0;                 // de265hip_picture_run calls so far
@@ -306,7 +307,7 @@ struct BuildScratch {
   std::vector<TuTask> l0, run_tus;
   std::vector<RunTask> runs; std::vector<uint32_t> run_deps, slots, mbx, mb_segs;
   std::vector<int> order, newidx, count2, width; std::vector<uint8_t> micro;
-  std::vector<McTask> mcs, mcs2, mc_micro[17 * 17]; std::vector<int> micro_keys; std::vector<PcmTask> pcms; std::vector<SaoCtb> saos;
+  std::vector<McTask> mcs, mc_tiles[8], mc_chunks[8], mc_micro[8 * 17 * 17]; std::vector<int> micro_keys; std::vector<PcmTask> pcms; std::vector<SaoCtb> saos;
 };
 static thread_local BuildScratch g_scratch;
 static const int8_t k_intra_angle[35] = { 0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26,
@@ -1283,8 +1284,8 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   pt.mark("l0");
   // ---- MC tasks: resolve references, bi->uni shortcut, split into <=16x16 tiles
   std::vector<McTask>& mcs = SC.mcs; mcs.clear();
-  std::vector<McTask>& mcs2 = SC.mcs2; mcs2.clear();
   static const int mc_paths = getenv("DE265HIP_MC_PATHS") ? atoi(getenv("DE265HIP_MC_PATHS")) : 3;   // bit 0: k_mc_micro, bit 1: k_mc2 (experiments)
+  const bool mc_all = cf == 1 && mc_paths != 0;        // k_mc_all (tiles, chunks and quads in bands, one launch); else k_mc over 16x16 tiles
   int64_t alg_mc = 0;
   for (int i = 0; i < d->n_pus; i++) {
     const de265hip_pu& pu = d->pus[i];
@@ -1334,23 +1335,28 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       }
       return true;
     };
+    // band of a task: eight ranges of CTB rows, one per XCD (k_mc_all)
+    auto band_of = [&](int Y) { return mc_all ? ((Y >> lc) * 8) / g.ctbs_h : 0; };
     auto tiles16 = [&](int X, int Y, int w_, int h_) {
       for (int ty = 0; ty < h_; ty += 16)
         for (int tx = 0; tx < w_; tx += 16) {
           McTask q = t;
           q.x = (uint16_t)(X + tx); q.y = (uint16_t)(Y + ty);
           q.w = (uint8_t)std::min(16, w_ - tx); q.h = (uint8_t)std::min(16, h_ - ty);
-          mcs.push_back(q);
+          SC.mc_tiles[band_of(Y + ty)].push_back(q);
         }
     };
-    if (cf == 1 && (mc_paths & 1) && (pu.w < 16 || pu.h < 16)) {
-      const int key = (t.slot[0] + 1) * 17 + (t.slot[1] + 1);
+    // (a PU whose whole reference block lies inside the picture: so does every part of it)
+    const bool pu_interior = mc_all && interior(pu.x, pu.y, pu.w, pu.h);
+    if (mc_all && (mc_paths & 1) && (pu.w < 16 || pu.h < 16)) {
+      const int key0 = (t.slot[0] + 1) * 17 + (t.slot[1] + 1);
       for (int by = 0; by < pu.h; by += 8)
         for (int bx = 0; bx < pu.w; bx += 8) {
           const int w_ = std::min(8, pu.w - bx), h_ = std::min(8, pu.h - by), X = pu.x + bx, Y = pu.y + by;
-          if (!interior(X, Y, w_, h_)) { tiles16(X, Y, w_, h_); continue; }
+          if (!pu_interior && !interior(X, Y, w_, h_)) { tiles16(X, Y, w_, h_); continue; }
           McTask q = t;
           q.x = (uint16_t)X; q.y = (uint16_t)Y; q.w = (uint8_t)w_; q.h = (uint8_t)h_;
+          const int key = band_of(Y) * 289 + key0;
           if (SC.mc_micro[key].empty()) SC.micro_keys.push_back(key);
           SC.mc_micro[key].push_back(q);
         }
@@ -1359,25 +1365,37 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     for (int cy0 = 0; cy0 < pu.h; cy0 += 32)
       for (int cx0 = 0; cx0 < pu.w; cx0 += 32) {
         const int cw_ = std::min(32, pu.w - cx0), ch_ = std::min(32, pu.h - cy0), X = pu.x + cx0, Y = pu.y + cy0;
-        if (cf == 1 && (mc_paths & 2) && interior(X, Y, cw_, ch_)) {
+        if (mc_all && (mc_paths & 2) && (pu_interior || interior(X, Y, cw_, ch_))) {
           McTask q = t;
           q.x = (uint16_t)X; q.y = (uint16_t)Y; q.w = (uint8_t)cw_; q.h = (uint8_t)ch_;
-          mcs2.push_back(q);
+          SC.mc_chunks[band_of(Y)].push_back(q);
         } else tiles16(X, Y, cw_, ch_);
       }
   }
-  // [k_mc2's chunks | k_mc_micro's blocks, four per wavefront, every four of one slot pair | k_mc's tiles]
-  pic->n_mc2 = (int)mcs2.size();
+  // band by band: [k_mc's tiles | k_mc2's chunks | k_mc_micro's blocks, four per wavefront, every four of one slot pair]
   std::sort(SC.micro_keys.begin(), SC.micro_keys.end());
-  for (int key : SC.micro_keys) {
-    std::vector<McTask>& v = SC.mc_micro[key];
-    while (v.size() & 3) { McTask q = v.back(); q.w = q.h = 0; v.push_back(q); }      // (a block that stores nothing)
-    mcs2.insert(mcs2.end(), v.begin(), v.end());
-    v.clear();
+  {
+    McBands& B = pic->mc_bands; memset(&B, 0, sizeof(B));
+    size_t mk = 0;
+    pic->n_mc2 = pic->n_mc_quads = 0;
+    for (int b = 0; b < 8; b++) {
+      B.first[b] = (uint32_t)mcs.size();
+      B.n_tiles[b] = (uint32_t)SC.mc_tiles[b].size(); B.n_chunks[b] = (uint32_t)SC.mc_chunks[b].size();
+      mcs.insert(mcs.end(), SC.mc_tiles[b].begin(), SC.mc_tiles[b].end()); SC.mc_tiles[b].clear();
+      mcs.insert(mcs.end(), SC.mc_chunks[b].begin(), SC.mc_chunks[b].end()); SC.mc_chunks[b].clear();
+      const size_t q0 = mcs.size();
+      for (; mk < SC.micro_keys.size() && SC.micro_keys[mk] / 289 == b; mk++) {
+        std::vector<McTask>& v = SC.mc_micro[SC.micro_keys[mk]];
+        while (v.size() & 3) { McTask q = v.back(); q.w = q.h = 0; v.push_back(q); }      // (a block that stores nothing)
+        mcs.insert(mcs.end(), v.begin(), v.end());
+        v.clear();
+      }
+      B.n_quads[b] = (uint32_t)((mcs.size() - q0) / 4);
+      pic->n_mc2 += (int)B.n_chunks[b]; pic->n_mc_quads += (int)B.n_quads[b];
+    }
+    SC.micro_keys.clear();
   }
-  SC.micro_keys.clear();
-  pic->n_mc_quads = ((int)mcs2.size() - pic->n_mc2) / 4;
-  mcs.insert(mcs.begin(), mcs2.begin(), mcs2.end());
+  pic->mc_all = mc_all;
   pic->n_mc = (int)mcs.size();
 
   pt.mark("mc");
@@ -1676,12 +1694,13 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
     for (int s = 0; s < DE265HIP_MAX_DPB_SLOTS; s++)
       if (dec->slots[s].valid) for (int c = 0; c < 3; c++) tab.p[s][c] = dec->slots[s].pl[c];
     KTimer t(dec, DE265HIP_K_MC, 1);
-    const int n2 = pic->n_mc2, nq = pic->n_mc_quads, n1 = pic->n_mc - n2 - 4 * nq;
-    if (n2 || nq)
-      hipLaunchKernelGGL(k_mc_all<PX>, dim3(xcd_grid((unsigned)n1) + xcd_grid((unsigned)n2) + xcd_grid((unsigned)nq)), dim3(64), 0, st, P, tab, d0, d1, d2,
-                         pic->d_mc, pic->d_slices, n2, nq, n1);
-    else if (n1)
-      hipLaunchKernelGGL(k_mc<PX>, dim3(xcd_grid((unsigned)n1)), dim3(64), 0, st, P, tab, d0, d1, d2, pic->d_mc, pic->d_slices, n1);
+    if (pic->mc_all) {
+      const McBands& B = pic->mc_bands;
+      unsigned most = 0;
+      for (int b = 0; b < 8; b++) most = std::max(most, B.n_tiles[b] + B.n_chunks[b] + B.n_quads[b]);
+      hipLaunchKernelGGL(k_mc_all<PX>, dim3(8 * most), dim3(64), 0, st, P, tab, d0, d1, d2, pic->d_mc, pic->d_slices, B);
+    } else
+      hipLaunchKernelGGL(k_mc<PX>, dim3(xcd_grid((unsigned)pic->n_mc)), dim3(64), 0, st, P, tab, d0, d1, d2, pic->d_mc, pic->d_slices, pic->n_mc);
     if (P.chroma_format != 1)                          // 4:2:2 / 4:4:4: k_mc predicts luma only, the chroma planes by the plain kernel
       hipLaunchKernelGGL(k_mc_chroma_any<PX>, dim3(pic->n_mc, 2), dim3(64), 0, st, P, tab, d1, d2, pic->d_mc, pic->d_slices, pic->n_mc);
   }

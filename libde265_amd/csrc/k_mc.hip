@@ -173,19 +173,14 @@ template <> __device__ __forceinline__ void st2_px<uint8_t>(uint8_t* p, int a, i
 #define MC_TILE_LDS (2 * 23 * MCL_P * 2 + 4 * 11 * MCC_P * 2 + 23 * MCT_P * 2)
 template <typename PX>
 __device__ __forceinline__ void mc_tile_body(const PicDev& P, const DpbTable& dpb, const PlaneRef& d0, const PlaneRef& d1, const PlaneRef& d2,
-                                             const McTask* __restrict__ tasks, const de265hip_slice_params* __restrict__ slices, int n_tasks,
-                                             unsigned bid, char* smem)
+                                             const McTask* __restrict__ tasks, const de265hip_slice_params* __restrict__ slices,
+                                             int tix, char* smem)
 {
   uint16_t (*s_inL)[23 * MCL_P] = reinterpret_cast<uint16_t (*)[23 * MCL_P]>(smem);
   uint16_t (*s_inC)[2][11 * MCC_P] = reinterpret_cast<uint16_t (*)[2][11 * MCC_P]>(smem + 2 * 23 * MCL_P * 2);
   int16_t* s_tmp = reinterpret_cast<int16_t*>(smem + 2 * 23 * MCL_P * 2 + 4 * 11 * MCC_P * 2);
   const int lane = threadIdx.x;
-  // XCD-aware mapping: workgroups b and b+8 share an XCD (and its L2); give every XCD one contiguous
-  // eighth of the task list (tasks are in decode order, i.e. spatial neighbours) so that the
-  // overlapping filter margins of neighbouring tiles hit in the same L2.  Speed only, never correctness.
-  const int per = (n_tasks + 7) >> 3;
-  const int tix = (bid & 7) * per + (bid >> 3);
-  if (tix >= n_tasks) return;
+
   McTask t;                                         // (five dwords at a uniform address: scalar loads)
   {
     const uint32_t* tq = reinterpret_cast<const uint32_t*>(tasks + tix);
@@ -481,7 +476,13 @@ void k_mc(PicDev P, DpbTable dpb, PlaneRef d0, PlaneRef d1, PlaneRef d2,
           const McTask* __restrict__ tasks, const de265hip_slice_params* __restrict__ slices, int n_tasks)
 {
   __shared__ __attribute__((aligned(16))) char smem[MC_TILE_LDS];
-  mc_tile_body<PX>(P, dpb, d0, d1, d2, tasks, slices, n_tasks, blockIdx.x, smem);
+  // XCD-aware mapping: workgroups b and b+8 share an XCD (and its L2); give every XCD one contiguous
+  // eighth of the task list (tasks are in decode order, i.e. spatial neighbours) so that the
+  // overlapping filter margins of neighbouring tiles hit in the same L2.  Speed only, never correctness.
+  const int per = (n_tasks + 7) >> 3;
+  const int tix = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (tix >= n_tasks) return;
+  mc_tile_body<PX>(P, dpb, d0, d1, d2, tasks, slices, tix, smem);
 }
 template __global__ void k_mc<uint8_t>(PicDev, DpbTable, PlaneRef, PlaneRef, PlaneRef, const McTask*,
                                        const de265hip_slice_params*, int);
@@ -603,16 +604,14 @@ __device__ __forceinline__ int mc_pick(const uint32_t* D, int n) { return (int)(
 #define MC_CHUNK_LDS (2 * M2_LROWS * M2_LP * 2 + 4 * M2_CROWS * M2_CP * 2 + 2 * M2_PR * M2_PP * 4)
 template <typename PX>
 __device__ __forceinline__ void mc_chunk_body(const PicDev& P, const DpbTable& dpb, const PlaneRef& d0, const PlaneRef& d1, const PlaneRef& d2,
-                                              const McTask* __restrict__ tasks, const de265hip_slice_params* __restrict__ slices, int n_tasks,
-                                              unsigned bid, char* smem)
+                                              const McTask* __restrict__ tasks, const de265hip_slice_params* __restrict__ slices,
+                                              int tix, char* smem)
 {
   uint16_t (*s_inL)[M2_LROWS * M2_LP] = reinterpret_cast<uint16_t (*)[M2_LROWS * M2_LP]>(smem);
   uint16_t (*s_inC)[2][M2_CROWS * M2_CP] = reinterpret_cast<uint16_t (*)[2][M2_CROWS * M2_CP]>(smem + 2 * M2_LROWS * M2_LP * 2);
   uint32_t* s_pair = reinterpret_cast<uint32_t*>(smem + 2 * M2_LROWS * M2_LP * 2 + 4 * M2_CROWS * M2_CP * 2);      // [first copy | second copy]
   const int lane = threadIdx.x;
-  const int per = (n_tasks + 7) >> 3;                  // XCD-aware: see k_mc
-  const int tix = (bid & 7) * per + (bid >> 3);
-  if (tix >= n_tasks) return;
+
   McTask t;
   {
     const uint32_t* tq = reinterpret_cast<const uint32_t*>(tasks + tix);
@@ -865,8 +864,8 @@ __device__ __forceinline__ void mc_chunk_body(const PicDev& P, const DpbTable& d
 #define MC_MICRO_LDS (4 * MM_LROWS * MM_LP * 2 + 8 * MM_CROWS * MM_CP * 2 + 4 * 128 * 4 + (48 + 64) * 4)
 template <typename PX>
 __device__ __forceinline__ void mc_micro_body(const PicDev& P, const DpbTable& dpb, const PlaneRef& d0, const PlaneRef& d1, const PlaneRef& d2,
-                                              const McTask* __restrict__ tasks, const de265hip_slice_params* __restrict__ slices, int n_quads,
-                                              unsigned bid, char* smem)
+                                              const McTask* __restrict__ tasks, const de265hip_slice_params* __restrict__ slices,
+                                              int qix, char* smem)
 {
   uint16_t (*s_inL)[MM_LROWS * MM_LP] = reinterpret_cast<uint16_t (*)[MM_LROWS * MM_LP]>(smem);                      // 4 x 600 B
   uint16_t (*s_inC)[2][MM_CROWS * MM_CP] = reinterpret_cast<uint16_t (*)[2][MM_CROWS * MM_CP]>(smem + 4 * MM_LROWS * MM_LP * 2);   // 4 x 336 B
@@ -875,9 +874,7 @@ __device__ __forceinline__ void mc_micro_body(const PicDev& P, const DpbTable& d
   uint32_t* s_tq = reinterpret_cast<uint32_t*>(smem + 4 * MM_LROWS * MM_LP * 2 + 8 * MM_CROWS * MM_CP * 2 + 4 * 128 * 4);      // [4][12]
   uint32_t* s_te = s_tq + 48;                                                                                                  // [8][8]
   const int lane = threadIdx.x, g = lane >> 4, gl = lane & 15;
-  const int per = (n_quads + 7) >> 3;                  // XCD-aware: see k_mc
-  const int qix = (bid & 7) * per + (bid >> 3);
-  if (qix >= n_quads) return;
+
   constexpr int bpp = (int)sizeof(PX);
   if (lane < 48) s_tq[lane] = (&c_qpel_eo[0][0])[lane];
   s_te[lane] = (&c_epel_eo[0][0])[lane];
@@ -1058,27 +1055,35 @@ __device__ __forceinline__ void mc_micro_body(const PicDev& P, const DpbTable& d
   if (cy < (H >> 1) && cc2 < (W >> 1))
     mc_store2<PX>(rdD, (cpl ? dofCr : dofCb) + ((Y >> 1) + cy) * dsbC + ((X >> 1) + cc2) * bpp, 0, oc[0], oc[1]);
 }
-// ---- the three forms in one launch: [k_mc's border tiles | k_mc2's chunks | k_mc_micro's quads], every segment a multiple of
-// 8 workgroups (XCD mapping).  The populations overlap instead of each launch paying its own ramp and tail; the border tiles
-// (per-sample clamped fetch: the longest single tasks) and the chunks start first, the short quads fill the tail.
+// ---- the three forms in one launch.  The host sorts a picture's MC tasks into eight horizontal bands of CTB rows, one per
+// XCD (workgroups b and b+8 share an XCD and its L2): band x = [k_mc's border tiles | k_mc2's chunks | k_mc_micro's quads] of
+// that part of the picture, worked off by the workgroups with blockIdx & 7 == x in that order - the border tiles (per-sample
+// clamped fetch: the longest single tasks) and the chunks first, the short quads fill the tail.  Whatever form a task takes,
+// its neighbours' overlapping filter margins and the cache lines they write side by side meet in the same L2 (with the
+// tasks of one form dealt to the XCDs in list order the micro blocks - sorted by slot pair, not by position - moved 4x the
+// algorithmic bytes through the L2s).  The three populations overlap instead of each launch paying its own ramp and tail.
 #define MC_ALL_LDS (MC_TILE_LDS > MC_CHUNK_LDS ? (MC_TILE_LDS > MC_MICRO_LDS ? MC_TILE_LDS : MC_MICRO_LDS) : (MC_CHUNK_LDS > MC_MICRO_LDS ? MC_CHUNK_LDS : MC_MICRO_LDS))
-template <typename PX>
 #ifndef MC_ALL_WAVES
 #define MC_ALL_WAVES 5
 #endif
+template <typename PX>
 __global__ __launch_bounds__(64, MC_ALL_WAVES)
 void k_mc_all(PicDev P, DpbTable dpb, PlaneRef d0, PlaneRef d1, PlaneRef d2,
-              const McTask* __restrict__ tasks, const de265hip_slice_params* __restrict__ slices, int n_chunks, int n_quads, int n_tiles)
+              const McTask* __restrict__ tasks, const de265hip_slice_params* __restrict__ slices, McBands B)
 {
   __shared__ __attribute__((aligned(16))) char smem[MC_ALL_LDS];
-  const unsigned g1 = (n_tiles + 7u) & ~7u, g2 = (n_chunks + 7u) & ~7u;
-  const unsigned b = blockIdx.x;
-  if (b < g1) mc_tile_body<PX>(P, dpb, d0, d1, d2, tasks + n_chunks + 4 * n_quads, slices, n_tiles, b, smem);
-  else if (b < g1 + g2) mc_chunk_body<PX>(P, dpb, d0, d1, d2, tasks, slices, n_chunks, b - g1, smem);
-  else mc_micro_body<PX>(P, dpb, d0, d1, d2, tasks + n_chunks, slices, n_quads, b - g1 - g2, smem);
+  const unsigned x = blockIdx.x & 7u;
+  int i = (int)(blockIdx.x >> 3);
+  const McTask* t = tasks + B.first[x];
+  const int nt = (int)B.n_tiles[x], nc = (int)B.n_chunks[x], nq = (int)B.n_quads[x];
+  if (i < nt) { mc_tile_body<PX>(P, dpb, d0, d1, d2, t, slices, i, smem); return; }
+  i -= nt;
+  if (i < nc) { mc_chunk_body<PX>(P, dpb, d0, d1, d2, t + nt, slices, i, smem); return; }
+  i -= nc;
+  if (i < nq) mc_micro_body<PX>(P, dpb, d0, d1, d2, t + nt + nc, slices, i, smem);
 }
-template __global__ void k_mc_all<uint8_t>(PicDev, DpbTable, PlaneRef, PlaneRef, PlaneRef, const McTask*, const de265hip_slice_params*, int, int, int);
-template __global__ void k_mc_all<uint16_t>(PicDev, DpbTable, PlaneRef, PlaneRef, PlaneRef, const McTask*, const de265hip_slice_params*, int, int, int);
+template __global__ void k_mc_all<uint8_t>(PicDev, DpbTable, PlaneRef, PlaneRef, PlaneRef, const McTask*, const de265hip_slice_params*, McBands);
+template __global__ void k_mc_all<uint16_t>(PicDev, DpbTable, PlaneRef, PlaneRef, PlaneRef, const McTask*, const de265hip_slice_params*, McBands);
 
 // ---- chroma prediction of one MC task for any chroma format (4:2:2 / 4:4:4 pictures; mc_chroma, motion.cc:175-273: the
 // vector scaled by 2 / SubWidthC, 2 / SubHeightC, eighth-sample fractions).  One wavefront per task and plane
