@@ -1023,7 +1023,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   int64_t sum_lvls = 0, dbg_foreign = 0, dbg_w[4] = { 0, 0, 0, 0 };
   size_t n_resid = 0;
   int max_rl = 0, n_front = 0, n_mailboxes = 0;
-  static const bool mailbox_on = getenv("DE265HIP_NO_MAILBOX") == nullptr;
+  const bool mailbox_on = getenv("DE265HIP_NO_MAILBOX") == nullptr;
   std::vector<uint32_t>& mbx = SC.mbx; std::vector<uint32_t>& mb_segs = SC.mb_segs;      // per run: (own mailbox, first dword of its segments); the segments
   mbx.assign(2 * rb.size(), 0xFFFFFFFFu); mb_segs.clear();
   {
@@ -1284,7 +1284,8 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   pt.mark("l0");
   // ---- MC tasks: resolve references, bi->uni shortcut, split into <=16x16 tiles
   std::vector<McTask>& mcs = SC.mcs; mcs.clear();
-  static const int mc_paths = getenv("DE265HIP_MC_PATHS") ? atoi(getenv("DE265HIP_MC_PATHS")) : 3;   // bit 0: k_mc_micro, bit 1: k_mc2 (experiments)
+  const char* mc_env = getenv("DE265HIP_MC_PATHS");
+  const int mc_paths = mc_env ? atoi(mc_env) : 3;   // bit 0: k_mc_micro, bit 1: k_mc2 (experiments)
   const bool mc_all = cf == 1 && mc_paths != 0;        // k_mc_all (tiles, chunks and quads in bands, one launch); else k_mc over 16x16 tiles
   int64_t alg_mc = 0;
   for (int i = 0; i < d->n_pus; i++) {
