@@ -101,8 +101,9 @@ struct __attribute__((aligned(4))) McTask {   // (4-byte aligned: the kernel fet
 };
 static_assert(sizeof(McTask) == 20, "McTask layout");
 // k_mc_all: the MC tasks of band x (a range of CTB rows; XCD x) are tasks[first[x] ..): n_tiles[x] 16x16 tiles, then n_chunks[x]
-// chunks of up to 32x32, then 4 * n_quads[x] blocks of up to 8x8 (every four of one slot pair)
-struct McBands { uint32_t first[8], n_tiles[8], n_chunks[8], n_quads[8]; };
+// chunks of up to 32x32 (the host: 32x16), then 4 * n_quads[x] blocks of up to 8x8 (every four of one slot pair)
+// and the order its wavefronts take them in: n_entries[x] dwords from order_first[x] on: bit 31 a quad, bit 30 a chunk, else a tile | index in the band's list of that form
+struct McBands { uint32_t first[8], n_tiles[8], n_chunks[8], n_quads[8], order_first[8], n_entries[8]; };
 
 // Run task: a run of consecutive (decode order) intra TUs of ONE colour component that
 // one wavefront reconstructs serially with its pixel window resident in LDS.

@@ -106,7 +106,7 @@ struct de265hip_picture {
   TuTask* d_tus = nullptr;
   int16_t* d_cval = nullptr; uint16_t* d_cpos = nullptr;
   uint8_t* d_scaling = nullptr;
-  McTask* d_mc = nullptr;
+  McTask* d_mc = nullptr; uint32_t* d_mc_order = nullptr;
   PcmTask* d_pcm = nullptr; uint16_t* d_pcm_samples = nullptr;
   de265hip_slice_params* d_slices = nullptr;
   de265hip_ctb_info* d_ctbs = nullptr;
@@ -154,7 +154,7 @@ int alloc_slot(Slot& s, int w, int h, int bdY, int bdC, int cf = 1)
   if (s.valid && s.w == w && s.h == h && s.bdY == bdY && s.bdC == bdC && s.cf == cf) return 0;
   free_slot(s);
   // The three planes of a picture are ONE allocation, luma first: a kernel reaches all of them through one buffer descriptor
-  // (k_mc2), and the planes of a slot always change hands together (the SAO output swap).
+  // (the chunk form (mc_chunk_body)), and the planes of a slot always change hands together (the SAO output swap).
   size_t off[4] = { 0, 0, 0, 0 };
   for (int c = 0; c < 3; c++) {
     int cw = c ? (cf == 3 ? w : w / 2) : w, ch = c ? (cf == 1 ? h / 2 : h) : h;
@@ -307,7 +307,9 @@ struct BuildScratch {
   std::vector<TuTask> l0, run_tus;
   std::vector<RunTask> runs; std::vector<uint32_t> run_deps, slots, mbx, mb_segs;
   std::vector<int> order, newidx, count2, width; std::vector<uint8_t> micro;
-  std::vector<McTask> mcs, mc_tiles[8], mc_chunks[8], mc_micro[8 * 17 * 17]; std::vector<int> micro_keys; std::vector<PcmTask> pcms; std::vector<SaoCtb> saos;
+  std::vector<McTask> mcs, mc_tiles[8], mc_chunks[8], mc_quads[8], mc_micro[8 * 17 * 17]; std::vector<int> micro_keys;
+  std::vector<uint8_t> band_row, sub_row; std::vector<uint32_t> roww, mc_order[8 * 4 * 2], mc_order_all;   // mc_order[(band * MC_SUB + part) * 2 + (quad ? 1 : 0)]
+  std::vector<PcmTask> pcms; std::vector<SaoCtb> saos;
 };
 static thread_local BuildScratch g_scratch;
 static const int8_t k_intra_angle[35] = { 0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26,
@@ -1285,9 +1287,36 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   // ---- MC tasks: resolve references, bi->uni shortcut, split into <=16x16 tiles
   std::vector<McTask>& mcs = SC.mcs; mcs.clear();
   const char* mc_env = getenv("DE265HIP_MC_PATHS");
-  const int mc_paths = mc_env ? atoi(mc_env) : 3;   // bit 0: k_mc_micro, bit 1: k_mc2 (experiments)
+  const int mc_paths = mc_env ? atoi(mc_env) : 3;   // bit 0: the quad form (mc_micro_body), bit 1: the chunk form (mc_chunk_body) (experiments)
   const bool mc_all = cf == 1 && mc_paths != 0;        // k_mc_all (tiles, chunks and quads in bands, one launch); else k_mc over 16x16 tiles
   int64_t alg_mc = 0;
+  // k_mc_all's bands: ranges of CTB rows with about an eighth of the picture's MC work each (a wavefront per 16x16 tile of a
+  // larger PU and list, a third of that per block of a small PU): band_row[CTB row]
+  std::vector<uint32_t>& mc_order_all = SC.mc_order_all;
+  const char* ch_env = getenv("DE265HIP_MC_CHUNK_H"); const int chunk_h = ch_env ? std::max(16, atoi(ch_env) & ~15) : 16;
+  const char* sub_env = getenv("DE265HIP_MC_SUB"); const char* mix_env = getenv("DE265HIP_MC_MIX");   // (experiments)
+  const int MC_SUB = sub_env ? std::min(4, std::max(1, atoi(sub_env))) : 1, mc_mix = mix_env ? atoi(mix_env) != 0 : 1;
+  std::vector<uint8_t>& band_row = SC.band_row; band_row.assign((size_t)g.ctbs_h, 0);
+  std::vector<uint8_t>& sub_row = SC.sub_row; sub_row.assign((size_t)g.ctbs_h, 0);
+  if (mc_all) {
+    std::vector<uint32_t>& roww = SC.roww; roww.assign((size_t)g.ctbs_h, 0);
+    uint64_t total = 0;
+    for (int i = 0; i < d->n_pus; i++) {
+      const de265hip_pu& pu = d->pus[i];
+      if (pu.y >= p.height) continue;                  // (rejected below)
+      const int nl = (pu.pred_flag & 1) + ((pu.pred_flag >> 1) & 1);
+      const uint32_t wgt = (pu.w < 16 || pu.h < 16) ? (uint32_t)nl * ((pu.w + 7) >> 3) * ((pu.h + 7) >> 3)
+                                                    : 3u * nl * ((pu.w + 15) >> 4) * ((pu.h + 15) >> 4);
+      roww[pu.y >> lc] += wgt; total += wgt;
+    }
+    // (experiments: each band in MC_SUB parts of about equal work, sub_row, inside a part the chunks before the quads)
+    uint64_t acc = 0; int b = 0;
+    for (int r = 0; r < g.ctbs_h; r++) {
+      while (b < 8 * MC_SUB - 1 && acc * (8 * MC_SUB) >= total * (uint64_t)(b + 1)) b++;
+      band_row[r] = (uint8_t)(b / MC_SUB); sub_row[r] = (uint8_t)(b % MC_SUB);
+      acc += roww[r];
+    }
+  }
   for (int i = 0; i < d->n_pus; i++) {
     const de265hip_pu& pu = d->pus[i];
     if (pu.slice_idx >= d->n_slices || pu.w == 0 || pu.h == 0 || (pu.w & 3) || (pu.h & 3) || pu.w > 64 || pu.h > 64 ||
@@ -1323,8 +1352,8 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     const int64_t bppY = px_bytes(p.bit_depth_luma);
     alg_mc += ((int64_t)pu.w * pu.h + 2 * (int64_t)(pu.w / subw) * (pu.h / subh)) * bppY * (nref + 1);
     // 4:2:0, reference blocks (filter margins included) inside the picture for every list:
-    //   PUs narrower or lower than 16 -> blocks of at most 8x8 for k_mc_micro (four blocks per wavefront, sorted by slot pair);
-    //   other PUs -> chunks of up to 32x32 for k_mc2 (one wavefront walks the chunk's 16x16 tiles).
+    //   PUs narrower or lower than 16 -> blocks of at most 8x8 for the quad form (mc_micro_body) (four blocks per wavefront, sorted by slot pair);
+    //   other PUs -> chunks of up to 32x16 for the chunk form (mc_chunk_body) (one wavefront walks the chunk's 16x16 tiles).
     // What touches the picture border, and every other chroma format, goes to k_mc as 16x16 tiles (clamped per-sample fetch).
     auto interior = [&](int X, int Y, int w_, int h_) {
       for (int l = 0; l < 2; l++) {
@@ -1337,7 +1366,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       return true;
     };
     // band of a task: eight ranges of CTB rows, one per XCD (k_mc_all)
-    auto band_of = [&](int Y) { return mc_all ? ((Y >> lc) * 8) / g.ctbs_h : 0; };
+    auto band_of = [&](int Y) { return (int)band_row[Y >> lc]; };
     auto tiles16 = [&](int X, int Y, int w_, int h_) {
       for (int ty = 0; ty < h_; ty += 16)
         for (int tx = 0; tx < w_; tx += 16) {
@@ -1357,26 +1386,34 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
           if (!pu_interior && !interior(X, Y, w_, h_)) { tiles16(X, Y, w_, h_); continue; }
           McTask q = t;
           q.x = (uint16_t)X; q.y = (uint16_t)Y; q.w = (uint8_t)w_; q.h = (uint8_t)h_;
-          const int key = band_of(Y) * 289 + key0;
-          if (SC.mc_micro[key].empty()) SC.micro_keys.push_back(key);
-          SC.mc_micro[key].push_back(q);
+          // quads in decode order: a slot pair's open quad is emitted the moment its fourth block arrives (quads sorted by
+          // slot pair swept the band once per pair: 3.3x the algorithmic bytes through the L2 with two reference slots)
+          const int bnd = band_of(Y), key = bnd * 289 + key0;
+          std::vector<McTask>& v = SC.mc_micro[key];
+          if (v.empty()) SC.micro_keys.push_back(key);
+          v.push_back(q);
+          if (v.size() == 4) {
+            SC.mc_order[(bnd * MC_SUB + sub_row[Y >> lc]) * 2 + (mc_mix ? 0 : 1)].push_back(0x80000000u | (uint32_t)(SC.mc_quads[bnd].size() / 4));
+            SC.mc_quads[bnd].insert(SC.mc_quads[bnd].end(), v.begin(), v.end()); v.clear();
+          }
         }
       continue;
     }
-    for (int cy0 = 0; cy0 < pu.h; cy0 += 32)
+    for (int cy0 = 0; cy0 < pu.h; cy0 += chunk_h)
       for (int cx0 = 0; cx0 < pu.w; cx0 += 32) {
-        const int cw_ = std::min(32, pu.w - cx0), ch_ = std::min(32, pu.h - cy0), X = pu.x + cx0, Y = pu.y + cy0;
+        const int cw_ = std::min(32, pu.w - cx0), ch_ = std::min(chunk_h, pu.h - cy0), X = pu.x + cx0, Y = pu.y + cy0;
         if (mc_all && (mc_paths & 2) && (pu_interior || interior(X, Y, cw_, ch_))) {
           McTask q = t;
           q.x = (uint16_t)X; q.y = (uint16_t)Y; q.w = (uint8_t)cw_; q.h = (uint8_t)ch_;
-          SC.mc_chunks[band_of(Y)].push_back(q);
+          { const int bc = band_of(Y); SC.mc_order[(bc * MC_SUB + sub_row[Y >> lc]) * 2].push_back(0x40000000u | (uint32_t)SC.mc_chunks[bc].size()); SC.mc_chunks[bc].push_back(q); }
         } else tiles16(X, Y, cw_, ch_);
       }
   }
-  // band by band: [k_mc's tiles | k_mc2's chunks | k_mc_micro's blocks, four per wavefront, every four of one slot pair]
+  // band by band: [k_mc's tiles | the chunk form's chunks | the quad form's blocks, four per wavefront, every four of one slot pair]
   std::sort(SC.micro_keys.begin(), SC.micro_keys.end());
   {
     McBands& B = pic->mc_bands; memset(&B, 0, sizeof(B));
+    mc_order_all.clear();
     size_t mk = 0;
     pic->n_mc2 = pic->n_mc_quads = 0;
     for (int b = 0; b < 8; b++) {
@@ -1385,13 +1422,29 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       mcs.insert(mcs.end(), SC.mc_tiles[b].begin(), SC.mc_tiles[b].end()); SC.mc_tiles[b].clear();
       mcs.insert(mcs.end(), SC.mc_chunks[b].begin(), SC.mc_chunks[b].end()); SC.mc_chunks[b].clear();
       const size_t q0 = mcs.size();
-      for (; mk < SC.micro_keys.size() && SC.micro_keys[mk] / 289 == b; mk++) {
+      mcs.insert(mcs.end(), SC.mc_quads[b].begin(), SC.mc_quads[b].end()); SC.mc_quads[b].clear();
+      for (; mk < SC.micro_keys.size() && SC.micro_keys[mk] / 289 == b; mk++) {             // the quads left open
         std::vector<McTask>& v = SC.mc_micro[SC.micro_keys[mk]];
+        if (v.empty()) continue;
         while (v.size() & 3) { McTask q = v.back(); q.w = q.h = 0; v.push_back(q); }      // (a block that stores nothing)
+        SC.mc_order[(b * MC_SUB + MC_SUB - 1) * 2 + 1].push_back(0x80000000u | (uint32_t)((mcs.size() - q0) / 4));
         mcs.insert(mcs.end(), v.begin(), v.end());
         v.clear();
       }
       B.n_quads[b] = (uint32_t)((mcs.size() - q0) / 4);
+      // the band's wavefronts take the border tiles first (few, and the longest single tasks: per-sample clamped fetch), then
+      // chunks and quads mixed, in decode order: ONE sweep over the band's reference area.  Measured (4K10 B picture, two
+      // reference slots, rocprofv3 + PMC): chunks of 32x32 first, then the quads: 43.6-44.6 us but 2.7x the algorithmic bytes
+      // through the L2s (the band is swept twice and its reference area, 6 MB, does not fit the 4 MB L2); mixed in decode
+      // order: 1.75x but 48.2 us (four-tile chunks at the end of the list make the tail); chunks of 32x16 mixed: 44.2 us
+      // and 1.75x.  Hence chunks of at most two tiles.
+      B.order_first[b] = (uint32_t)mc_order_all.size();
+      for (uint32_t q = 0; q < B.n_tiles[b]; q++) mc_order_all.push_back(q);
+      for (int q = 0; q < 2 * MC_SUB; q++) {
+        std::vector<uint32_t>& v = SC.mc_order[b * 2 * MC_SUB + q];
+        mc_order_all.insert(mc_order_all.end(), v.begin(), v.end()); v.clear();
+      }
+      B.n_entries[b] = (uint32_t)mc_order_all.size() - B.order_first[b];
       pic->n_mc2 += (int)B.n_chunks[b]; pic->n_mc_quads += (int)B.n_quads[b];
     }
     SC.micro_keys.clear();
@@ -1469,7 +1522,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   const size_t o_tus = L.add(sorted.size() * sizeof(TuTask));
   const size_t o_cval = L.add((size_t)d->n_coeffs * 2), o_cpos = L.add((size_t)d->n_coeffs * 2);
   const size_t o_scal = L.add(DE265HIP_SCALING_BLOB_BYTES);
-  const size_t o_mc = L.add(mcs.size() * sizeof(McTask));
+  const size_t o_mc = L.add(mcs.size() * sizeof(McTask)), o_mco = L.add(SC.mc_order_all.size() * 4);
   const size_t o_pcm = L.add(pcms.size() * sizeof(PcmTask)), o_pcms = L.add((size_t)d->n_pcm_samples * 2);
   const size_t o_sl = L.add((size_t)d->n_slices * sizeof(de265hip_slice_params));
   const size_t o_ctb = L.add((size_t)d->n_ctbs * sizeof(de265hip_ctb_info));
@@ -1525,7 +1578,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   put(o_cval, d->coeff_val, (size_t)d->n_coeffs * 2); put(o_cpos, d->coeff_pos, (size_t)d->n_coeffs * 2);
   if (p.scaling_list_enable_flag) put(o_scal, d->scaling_factors, DE265HIP_SCALING_BLOB_BYTES);
   else memset(host.data() + o_scal, 0, DE265HIP_SCALING_BLOB_BYTES);
-  put(o_mc, mcs.data(), mcs.size() * sizeof(McTask));
+  put(o_mc, mcs.data(), mcs.size() * sizeof(McTask)); put(o_mco, SC.mc_order_all.data(), SC.mc_order_all.size() * 4);
   put(o_pcm, pcms.data(), pcms.size() * sizeof(PcmTask)); put(o_pcms, d->pcm_samples, (size_t)d->n_pcm_samples * 2);
   put(o_sl, d->slices, (size_t)d->n_slices * sizeof(de265hip_slice_params));
   put(o_ctb, d->ctbs, (size_t)d->n_ctbs * sizeof(de265hip_ctb_info));
@@ -1556,6 +1609,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     mix(scal, sizeof(scal));
     if (!SC.l0_rext.empty()) mix(host.data() + o_l0x, SC.l0_rext.size() * sizeof(TuTask));
     if (n_mailboxes) { mix(host.data() + o_mbx, mbx.size() * 4); mix(host.data() + o_mbs, mb_segs.size() * 4); }
+    mix(host.data() + o_mco, SC.mc_order_all.size() * 4);
     mix(pic->level_start.data(), pic->level_start.size() * sizeof(int));
     dec->pooled_bytes = (size_t)hsh;
   }
@@ -1577,7 +1631,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   pic->d_tus = (TuTask*)(base + o_tus);
   pic->d_cval = (int16_t*)(base + o_cval); pic->d_cpos = (uint16_t*)(base + o_cpos);
   pic->d_scaling = base + o_scal;
-  pic->d_mc = (McTask*)(base + o_mc);
+  pic->d_mc = (McTask*)(base + o_mc); pic->d_mc_order = (uint32_t*)(base + o_mco);
   pic->d_pcm = (PcmTask*)(base + o_pcm); pic->d_pcm_samples = (uint16_t*)(base + o_pcms);
   pic->d_slices = (de265hip_slice_params*)(base + o_sl);
   pic->d_ctbs = (de265hip_ctb_info*)(base + o_ctb);
@@ -1698,8 +1752,8 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
     if (pic->mc_all) {
       const McBands& B = pic->mc_bands;
       unsigned most = 0;
-      for (int b = 0; b < 8; b++) most = std::max(most, B.n_tiles[b] + B.n_chunks[b] + B.n_quads[b]);
-      hipLaunchKernelGGL(k_mc_all<PX>, dim3(8 * most), dim3(64), 0, st, P, tab, d0, d1, d2, pic->d_mc, pic->d_slices, B);
+      for (int b = 0; b < 8; b++) most = std::max(most, B.n_entries[b]);
+      hipLaunchKernelGGL(k_mc_all<PX>, dim3(8 * most), dim3(64), 0, st, P, tab, d0, d1, d2, pic->d_mc, pic->d_slices, pic->d_mc_order, B);
     } else
       hipLaunchKernelGGL(k_mc<PX>, dim3(xcd_grid((unsigned)pic->n_mc)), dim3(64), 0, st, P, tab, d0, d1, d2, pic->d_mc, pic->d_slices, pic->n_mc);
     if (P.chroma_format != 1)                          // 4:2:2 / 4:4:4: k_mc predicts luma only, the chroma planes by the plain kernel

@@ -136,10 +136,8 @@ __device__ __forceinline__ PX mc_combine(int mode, int a, int b, int bd, int w0,
   return (PX)mc_clip3(0, maxv, v);
 }
 
-// (Tried: a second kernel for tiles of at most 8x8 -- 42 % of the tasks, 12 % of the samples of the synthetic B
-//  pictures -- with four tasks per wavefront, one per 16-lane group, every task quantity per lane and both filter passes
-//  always run (fraction-0 taps {0,0,0,64,..} are bit-exact).  Bit-exact, but 71-79 us instead of 62 us per 4K B picture:
-//  without the scalar registers and wave-uniform shortcuts a packed wavefront costs about twice a plain one.)
+// (Round 2 tried a second KERNEL for tiles of at most 8x8, four per wavefront: 71-79 us instead of 62 us per 4K B picture -
+//  a launch of its own pays its own ramp and tail.  Round 3 has that form inside k_mc_all's single launch: mc_micro_body.)
 // ---------------------------------------------------------------- picture-level MC kernel
 // One wavefront per MC task.  All reference fetches of the task (2 lists x 3 planes) are
 // issued back to back as aligned 4-sample vector loads into LDS (one exposed HBM/L2 latency
@@ -491,9 +489,9 @@ template __global__ void k_mc<uint16_t>(PicDev, DpbTable, PlaneRef, PlaneRef, Pl
 
 // ---------------------------------------------------------------- picture-level MC kernel, second form (4:2:0, interior tasks)
 // k_mc above is bound by instruction issue (tools/exp/pmc_mc.sh: 380 VALU + 372 SALU instructions per wavefront, the VALU
-// pipes ~90 % busy while its wavefronts are resident), not by HBM.  k_mc2 does the same arithmetic with about half the
+// pipes ~90 % busy while its wavefronts are resident), not by HBM.  The chunk form (mc_chunk_body) does the same arithmetic with about half the
 // instructions per tile:
-//  * a task is a PU chunk of up to 32x32 luma samples = up to four 16x16 tiles walked by ONE wavefront: task decode, mode,
+//  * a task is a PU chunk of up to 32x32 luma samples (the host makes them 32x16: two 16x16 tiles) walked by ONE wavefront: task decode, mode,
 //    weights, filter taps, buffer descriptors and every per-lane address are computed once per chunk, a tile costs a few
 //    scalar offsets;
 //  * only chunks whose reference blocks (margins included) lie inside the picture come here (the host sorts the others into
@@ -849,9 +847,9 @@ __device__ __forceinline__ void mc_chunk_body(const PicDev& P, const DpbTable& d
 }
 
 // ---------------------------------------------------------------- picture-level MC kernel for small PUs (4:2:0, interior)
-// Half of a B picture's MC tasks are PUs of 8x8, 8x4 or 4x8 luma samples: as tiles of k_mc / k_mc2 they use 4-16 of a
+// Half of a B picture's MC tasks are PUs of 8x8, 8x4 or 4x8 luma samples: as tiles of k_mc / the chunk form (mc_chunk_body) they use 4-16 of a
 // wavefront's 64 lanes for the price of a full tile.  Here a wavefront takes FOUR blocks of at most 8x8 luma samples, one per
-// 16-lane group, through the same steps as k_mc2 (horizontal pass -> vertical pairs in LDS -> vertical pass), with everything
+// 16-lane group, through the same steps as the chunk form (mc_chunk_body) (horizontal pass -> vertical pairs in LDS -> vertical pass), with everything
 // that is a scalar there - position, vector, fractions, tap pairs, weights - held per lane.  Wavefront-uniform stay: the two
 // reference slots (the host sorts the blocks by their slot pair: one buffer descriptor per list, uni / bi known) and the code
 // path: both passes always run, fraction 0 through the taps (0,0,0,64,0,..): bit-exact because 64 * s >> shift1 fits the
@@ -1056,9 +1054,10 @@ __device__ __forceinline__ void mc_micro_body(const PicDev& P, const DpbTable& d
     mc_store2<PX>(rdD, (cpl ? dofCr : dofCb) + ((Y >> 1) + cy) * dsbC + ((X >> 1) + cc2) * bpp, 0, oc[0], oc[1]);
 }
 // ---- the three forms in one launch.  The host sorts a picture's MC tasks into eight horizontal bands of CTB rows, one per
-// XCD (workgroups b and b+8 share an XCD and its L2): band x = [k_mc's border tiles | k_mc2's chunks | k_mc_micro's quads] of
-// that part of the picture, worked off by the workgroups with blockIdx & 7 == x in that order - the border tiles (per-sample
-// clamped fetch: the longest single tasks) and the chunks first, the short quads fill the tail.  Whatever form a task takes,
+// XCD (workgroups b and b+8 share an XCD and its L2): band x = [k_mc's border tiles | the chunk form's chunks | the quad form's quads] of
+// that part of the picture, worked off by the workgroups with blockIdx & 7 == x in the order the host lists (`order`): the few
+// border tiles first (per-sample clamped fetch: the longest single tasks), then chunks and quads mixed in DECODE order - one
+// sweep over the band's reference area (form after form the band was swept three times: 3x the bytes).  Whatever form a task takes,
 // its neighbours' overlapping filter margins and the cache lines they write side by side meet in the same L2 (with the
 // tasks of one form dealt to the XCDs in list order the micro blocks - sorted by slot pair, not by position - moved 4x the
 // algorithmic bytes through the L2s).  The three populations overlap instead of each launch paying its own ramp and tail.
@@ -1069,21 +1068,21 @@ __device__ __forceinline__ void mc_micro_body(const PicDev& P, const DpbTable& d
 template <typename PX>
 __global__ __launch_bounds__(64, MC_ALL_WAVES)
 void k_mc_all(PicDev P, DpbTable dpb, PlaneRef d0, PlaneRef d1, PlaneRef d2,
-              const McTask* __restrict__ tasks, const de265hip_slice_params* __restrict__ slices, McBands B)
+              const McTask* __restrict__ tasks, const de265hip_slice_params* __restrict__ slices, const uint32_t* __restrict__ order, McBands B)
 {
   __shared__ __attribute__((aligned(16))) char smem[MC_ALL_LDS];
-  const unsigned x = blockIdx.x & 7u;
-  int i = (int)(blockIdx.x >> 3);
+  const unsigned x = blockIdx.x & 7u, i = blockIdx.x >> 3;
+  if (i >= B.n_entries[x]) return;
+  const uint32_t e = __builtin_amdgcn_readfirstlane(order[B.order_first[x] + i]);
   const McTask* t = tasks + B.first[x];
-  const int nt = (int)B.n_tiles[x], nc = (int)B.n_chunks[x], nq = (int)B.n_quads[x];
-  if (i < nt) { mc_tile_body<PX>(P, dpb, d0, d1, d2, t, slices, i, smem); return; }
-  i -= nt;
-  if (i < nc) { mc_chunk_body<PX>(P, dpb, d0, d1, d2, t + nt, slices, i, smem); return; }
-  i -= nc;
-  if (i < nq) mc_micro_body<PX>(P, dpb, d0, d1, d2, t + nt + nc, slices, i, smem);
+  const int nt = (int)B.n_tiles[x], nc = (int)B.n_chunks[x];
+  const int idx = (int)(e & 0x3FFFFFFFu);
+  if (e >> 31) mc_micro_body<PX>(P, dpb, d0, d1, d2, t + nt + nc, slices, idx, smem);
+  else if (e >> 30) mc_chunk_body<PX>(P, dpb, d0, d1, d2, t + nt, slices, idx, smem);
+  else mc_tile_body<PX>(P, dpb, d0, d1, d2, t, slices, idx, smem);
 }
-template __global__ void k_mc_all<uint8_t>(PicDev, DpbTable, PlaneRef, PlaneRef, PlaneRef, const McTask*, const de265hip_slice_params*, McBands);
-template __global__ void k_mc_all<uint16_t>(PicDev, DpbTable, PlaneRef, PlaneRef, PlaneRef, const McTask*, const de265hip_slice_params*, McBands);
+template __global__ void k_mc_all<uint8_t>(PicDev, DpbTable, PlaneRef, PlaneRef, PlaneRef, const McTask*, const de265hip_slice_params*, const uint32_t*, McBands);
+template __global__ void k_mc_all<uint16_t>(PicDev, DpbTable, PlaneRef, PlaneRef, PlaneRef, const McTask*, const de265hip_slice_params*, const uint32_t*, McBands);
 
 // ---- chroma prediction of one MC task for any chroma format (4:2:2 / 4:4:4 pictures; mc_chroma, motion.cc:175-273: the
 // vector scaled by 2 / SubWidthC, 2 / SubHeightC, eighth-sample fractions).  One wavefront per task and plane

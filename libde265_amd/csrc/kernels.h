@@ -54,7 +54,7 @@ __global__ void k_mc(PicDev, DpbTable, PlaneRef, PlaneRef, PlaneRef, const McTas
                      const de265hip_slice_params*, int);
 template <typename PX>
 __global__ void k_mc_all(PicDev, DpbTable, PlaneRef, PlaneRef, PlaneRef, const McTask*,
-                         const de265hip_slice_params*, McBands);
+                         const de265hip_slice_params*, const uint32_t*, McBands);
 template <typename PX>
 __global__ void k_pcm(PicDev, PlaneRef, PlaneRef, PlaneRef, const PcmTask*, const uint16_t*);
 __global__ void k_bs(PicDev, const uint8_t*, const de265hip_motion*, uint8_t*);
