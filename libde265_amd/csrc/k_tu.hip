@@ -1440,7 +1440,10 @@ __device__ __forceinline__ void micro_run(const PicDev& P, const PlaneRef& pl0, 
     const int i = 8 * (64 * u + lane);
     rres[u] = i < n_samp ? *reinterpret_cast<const uint4*>(resid + run.res_offset + i) : make_uint4(0, 0, 0, 0);
   }
-  const int nchx = (wx1 - ax0 + 7) >> 3, nrows = wy1 - wy0, nchunks = nchx * nrows;    // window: at most 41 rows x 6 chunks of 8 samples
+  // window: at most 41 rows x 6 chunks of 8 samples.  A dense run (its TUs cover its box: the usual isolated intra CU) writes
+  // every sample of the box before it reads it: only row 0 and the first chunk of the other rows are fetched (as in k_run)
+  const bool dense = run.micro & 2;
+  const int nchx = (wx1 - ax0 + 7) >> 3, nrows = wy1 - wy0, nchunks = dense ? nchx + nrows - 1 : nchx * nrows;
   const __amdgpu_buffer_rsrc_t wrs = plane_rsrc(plane);
   uint4 wv[4]; int woff[4];
   auto window_issue = [&]() {
@@ -1449,7 +1452,9 @@ __device__ __forceinline__ void micro_run(const PicDev& P, const PlaneRef& pl0, 
       const int idx = u * 64 + lane;
       woff[u] = -1;
       if (idx < nchunks) {
-        const int rr = idx / nchx, cx = idx - rr * nchx;
+        int rr, cx;
+        if (dense) { rr = idx < nchx ? 0 : idx - nchx + 1; cx = idx < nchx ? idx : 0; }
+        else { rr = idx / nchx; cx = idx - rr * nchx; }
         const int gx = ax0 + 8 * cx, gy = wy0 + rr;
         if (gx >= 0 && gy >= 0) {
 #if RUN_SC1_WINDOW
