@@ -827,7 +827,9 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     if (tu.flags & DE265HIP_TU_CBF) {
       const uint16_t* cp = d->coeff_pos + tu.coeff_offset;
       unsigned worst = 0;
-      for (int k = 0; k < tu.n_coeff; k++) worst = std::max<unsigned>(worst, cp[k]);      // (vectorises)
+      const int nc = tu.n_coeff;
+      if (nc <= 4) { for (int k = 0; k < nc; k++) worst |= cp[k]; }                        // (an OR bounds the maximum: nT*nT is a power of two)
+      else for (int k = 0; k < nc; k++) worst = std::max<unsigned>(worst, cp[k]);        // (vectorises)
       if (worst >= (unsigned)(nT * nT)) { delete pic; return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE; }
     }
     if (tu.c_idx == 0) last_luma_tu = i;
@@ -871,8 +873,8 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       const bool aT = yL > 0 && ctb_group[cx + ((yL - 1) >> lc) * g.ctbs_w] == own;
       const bool aTL = xL > 0 && yL > 0 && ctb_group[((xL - 1) >> lc) + ((yL - 1) >> lc) * g.ctbs_w] == own;
       const bool aTR = yL > 0 && (xL + nT * sbw < p.width) && ctb_group[((xL + nT * sbw) >> lc) + ((yL - 1) >> lc) * g.ctbs_w] == own;
-      int nBottom = (p.height - yL + sbh - 1) / sbh; if (nBottom > 2 * nT) nBottom = 2 * nT;
-      int nRight = (p.width - xL + sbw - 1) / sbw;   if (nRight > 2 * nT) nRight = 2 * nT;
+      int nBottom = (p.height - yL + sbh - 1) >> (sbh - 1); if (nBottom > 2 * nT) nBottom = 2 * nT;      // (sbw, sbh are 1 or 2)
+      int nRight = (p.width - xL + sbw - 1) >> (sbw - 1);   if (nRight > 2 * nT) nRight = 2 * nT;
       const int cur = zs[(xL >> lt) + (size_t)(yL >> lt) * g.tbs_w];
       const int mw = map_w[c], corner = nT >> 1;
       uint64_t mask = 0;

@@ -23,6 +23,9 @@ def cases():
     for it in range(24):
         w, h, bd, st, over = ref_sweep.mid_config(rng)
         out.append((w, h, bd, st, 61000 + it, over))
+    for it, (cf, st) in enumerate([(2, 2), (2, 0), (3, 2), (3, 0), (3, 1), (2, 1)]):          # range-extension pictures
+        out.append((416, 240, 8 + 2 * (it & 1), st, 62000 + it, dict(chroma_format=cf, cross_component_pct=30 if cf == 3 else 0, implicit_rdpcm=1,
+                                                                     explicit_rdpcm_pct=30, rotation=1, tskip_pct=20, log2_max_tskip_size=4, bypass_pct=5)))
     out.append((3840, 2160, 10, 2, 0xDE265004, {}))
     out.append((3840, 2160, 10, 0, 0xDE265005, {}))
     out.append((1920, 1080, 8, 0, 0xDE265003, dict(weighted_pred=1)))
