@@ -206,7 +206,10 @@ typedef struct de265hip_picture_desc {
   int32_t n_slices;  const de265hip_slice_params* slices;
   int32_t n_ctbs;    const de265hip_ctb_info* ctbs;      /* raster, PicSizeInCtbsY */
   int32_t n_tus;     const de265hip_tu* tus;             /* decode order */
-  int32_t n_coeffs;  const int16_t* coeff_val; const uint16_t* coeff_pos;
+  int32_t n_coeffs;  const int16_t* coeff_val; const uint16_t* coeff_pos;   /* positions x + y * nT inside the TU's block (coeffPos, slice.cc:3408-3410).
+                                   * Everything else of a descriptor is validated by de265hip_picture_build (PARAMETER_OUT_OF_RANGE); a
+                                   * position beyond its block is caught on the device behind the upload: the picture still decodes
+                                   * memory-safely and de265hip_decoder_sync returns DE265HIP_ERROR_DECODING */
   int32_t n_pus;     const de265hip_pu* pus;
   int32_t n_pcms;    const de265hip_pcm* pcms;
   int32_t n_pcm_samples; const uint16_t* pcm_samples;

@@ -812,6 +812,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   TuTask* l0p = SC.l0.data();
   SC.it.reserve(n_intra); SC.it_next.reserve(n_intra); SC.it_llev.reserve(n_intra);
   SC.it_rx.clear(); SC.it_rsv.clear(); SC.it_luma.clear(); SC.l0_rext.clear();
+  const bool host_checks_positions = dec->dry || dec->intra_levels;
   int last_luma_tu = -1;                                   // most recent luma TU record (cross-component prediction reads its residual)
   int n_tasks = 0;
   int32_t cell[33];                                        // 4x4 map cell of every available unit of the current TU
@@ -824,7 +825,9 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
         ((tu.flags & DE265HIP_TU_CBF) && ((int64_t)tu.coeff_offset + tu.n_coeff > d->n_coeffs || tu.n_coeff > nT * nT))) {
       delete pic; return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
     }
-    if (tu.flags & DE265HIP_TU_CBF) {
+    // (positions inside the TU's block: checked - and folded into the block - on the device, k_check_coeffs behind the upload;
+    //  the level-launch schedule reads the descriptor's order, not the level-0 lists that kernel walks: checked here)
+    if ((tu.flags & DE265HIP_TU_CBF) && host_checks_positions) {
       const uint16_t* cp = d->coeff_pos + tu.coeff_offset;
       unsigned worst = 0;
       const int nc = tu.n_coeff;
@@ -1624,8 +1627,15 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     if (hipEventCreateWithFlags(&pic->uploaded, hipEventDisableTiming) != hipSuccess) return fail(DE265HIP_ERROR_OUT_OF_MEMORY);
     if (hipMemcpyAsync(pic->arena, host.data(), upload_bytes, hipMemcpyHostToDevice, cs) != hipSuccess ||
         hipMemsetAsync((uint8_t*)pic->arena + o_sync, 0, clear_bytes, cs) != hipSuccess ||
-        hipEventRecord(stage_event, cs) != hipSuccess || hipEventRecord(pic->uploaded, cs) != hipSuccess)
+        hipEventRecord(stage_event, cs) != hipSuccess)
       return fail(DE265HIP_ERROR_DECODING);
+    if (!host_checks_positions) {
+      const int n_chk = (int)l0.size() + (int)SC.l0_rext.size();
+      if (n_chk > 0)
+        hipLaunchKernelGGL(k_check_coeffs, dim3((n_chk + 255) / 256), dim3(256), 0, cs, (const TuTask*)((uint8_t*)pic->arena + o_l0), (int)l0.size(),
+                           (const TuTask*)((uint8_t*)pic->arena + o_l0x), (int)SC.l0_rext.size(), (uint16_t*)((uint8_t*)pic->arena + o_cpos), dec->d_err);
+    }
+    if (hipEventRecord(pic->uploaded, cs) != hipSuccess) return fail(DE265HIP_ERROR_DECODING);
     std::lock_guard<std::mutex> lk(dec->mu);
     for (auto& b : dec->stage_pool) if (b.ptr == host_base) b.state = 2;      // reusable once `copied` has completed
   }

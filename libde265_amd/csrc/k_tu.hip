@@ -692,6 +692,26 @@ __device__ __forceinline__ void resid16_body(const PicDev& P, const PlaneRef& pl
 // k_resid_small: one wavefront per workgroup, workgroups [0, n8) an 8x8 TU each, the rest four 4x4 TUs each (one launch
 // for both small sizes; a single launch for all three made every workgroup pay the big path's 112 VGPRs and 5 KB of LDS:
 // 7.0 instead of 5.3 ms per 48 pictures with three GOP streams in flight).  tasks[] is sorted [32x32 | 16x16 | 8x8 | 4x4].
+// ---- coefficient positions, checked where they are cheap to check (de265hip_picture_build enqueues this behind the upload,
+// on the copy stream, ahead of the event every kernel of the picture waits for): a position beyond its TU's nT x nT block is
+// folded into the block and the decoder's error word is raised (de265hip_decoder_sync: DE265HIP_ERROR_DECODING), so that no
+// residual kernel ever indexes LDS out of its block.  On the host this loop cost 12 % of the host stage of a 4K B picture.
+__global__ __launch_bounds__(256)
+void k_check_coeffs(const TuTask* __restrict__ l0, int n_l0, const TuTask* __restrict__ l0x, int n_l0x, uint16_t* cpos, uint32_t* err)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_l0 + n_l0x) return;
+  const TuTask* t = i < n_l0 ? l0 + i : l0x + (i - n_l0);
+  const unsigned nS = 1u << (2 * t->log2_size), n = t->n_coeff;
+  uint16_t* p = cpos + t->coeff_offset;
+  bool bad = false;
+  for (unsigned k = 0; k < n; k++) {
+    const unsigned v = p[k];
+    if (v >= nS) { p[k] = (uint16_t)(v & (nS - 1)); bad = true; }
+  }
+  if (bad) atomicOr(err, 1u);
+}
+
 template <typename PX>
 __global__ __launch_bounds__(256, RESID_BIG_WAVES)
 void k_resid_big(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const TuTask* __restrict__ tasks, int n_wg, int n_wave,

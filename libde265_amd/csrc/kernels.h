@@ -43,6 +43,7 @@ __global__ void k_resid_small(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask
 #define RESID_SPL 4          // samples per lane of k_resid_small: RESID_SPL 8x8 TUs / 4 RESID_SPL 4x4 TUs per wavefront
 #endif
 #define RUN_WAVES 4          // wavefronts per run workgroup (one per SIMD of a CU); blockDim.x = 64..64*RUN_WAVES
+__global__ void k_check_coeffs(const TuTask*, int, const TuTask*, int, uint16_t*, uint32_t*);
 template <typename PX, int BOX>
 __global__ void k_run(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const uint32_t*, uint32_t*, uint32_t*,
                       const TuTask*, const int16_t*, const uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t, const uint32_t*, const uint32_t*, unsigned long long*);

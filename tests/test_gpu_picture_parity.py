@@ -724,6 +724,36 @@ def test_expired_dependency_wait_surfaces_as_decoding_error(monkeypatch):
         d.close()
 
 
+def test_coefficient_position_beyond_its_block_surfaces_as_decoding_error():
+    """A coefficient position outside its TU's nT x nT block (no parser of the reference produces one) is caught on the device,
+    behind the upload (k_check_coeffs): the picture decodes memory-safely (the position is folded into the block), the error word
+    is raised - de265hip_decoder_sync returns DE265_ERROR_UNSPECIFIED_DECODING_ERROR - and the next picture is fine."""
+    w, h, bd = 416, 240, 8
+    d = backend.Decoder()
+    try:
+        sp = pysynth.SynthPicture(pysynth.default_config(w, h, bd, 2, seed=1401, log2_max_tb_size=3))
+        exp = pyoracle.alloc_planes(w, h, bd)
+        pyoracle.reconstruct(sp.desc, sp.order, {}, exp)
+        dd = sp.d
+        assert dd.n_coeffs > 10
+        keep = dd.coeff_pos[5]
+        dd.coeff_pos[5] = 60000                          # every TU is at most 8x8: beyond any block
+        d.dpb_alloc(2, w, h, bd)
+        bad = d.build(2, sp.desc)                        # (not refused at build: the check travels with the upload)
+        d.run(bad, 2)
+        with pytest.raises(backend.De265HipError) as e:
+            d.sync()
+        assert e.value.code == _abi.ERROR_DECODING
+        bad.free()
+        dd.coeff_pos[5] = keep
+        good = d.build(2, sp.desc)
+        d.run(good, 2); d.sync()
+        assert all(np.array_equal(g, e_) for g, e_ in zip(d.download(2, w, h, bd), exp))
+        good.free()
+    finally:
+        d.close()
+
+
 @pytest.mark.parametrize("cf", [2, 3])
 @pytest.mark.parametrize("seed", range(6))
 def test_range_extension_pictures_against_the_oracle(seed, cf):
