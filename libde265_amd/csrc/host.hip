@@ -1143,7 +1143,17 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
           const int list = (SC.it[tix[i]].log2_size > 3 && !micro[order[k]]) ? 4 : rank[lev]++ % nwv;
           keys[i] = ((uint32_t)list << 20) | ((uint32_t)lev << 8) | (uint32_t)i;
         }
-        if (n > 1) std::sort(keys, keys + n);
+        if (n > 12) {
+          // counting sort by (list, level), stable in the decode index: the keys are unique and (list, level) has at most
+          // 5 (nl + 1) values (an all-intra 4K picture: 5 700 runs of ~40 TUs; std::sort took 2 ms of its host stage)
+          uint16_t cnt[5 * 257 + 2]; uint32_t tmp[256];
+          const int nb = 5 * (nl + 1);
+          memset(cnt, 0, (size_t)(nb + 1) * sizeof(cnt[0]));
+          for (int i = 0; i < n; i++) cnt[(keys[i] >> 20) * (nl + 1) + ((keys[i] >> 8) & 0xFFF) + 1]++;
+          for (int b = 0; b < nb; b++) cnt[b + 1] = (uint16_t)(cnt[b + 1] + cnt[b]);
+          for (int i = 0; i < n; i++) tmp[cnt[(keys[i] >> 20) * (nl + 1) + ((keys[i] >> 8) & 0xFFF)]++] = keys[i];
+          memcpy(keys, tmp, (size_t)n * sizeof(keys[0]));
+        } else if (n > 1) std::sort(keys, keys + n);
         int pos = 0;
         for (int w = 0; w < 4; w++) {
           while (pos < n && (int)(keys[pos] >> 20) <= w) { dbg_w[w]++; pos++; }
