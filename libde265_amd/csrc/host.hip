@@ -302,6 +302,7 @@ struct BuildScratch {
   std::vector<TuTask> l0_rext;                                                              // level-0 tasks of k_resid_rext
   std::vector<RunB> rb;
   std::vector<int32_t> dep_val, dep_next;
+  std::vector<uint64_t> avail_memo; int avail_memo_key = -1;                                   // availability masks by (chroma, size, position in the CTB)
   std::vector<int> level_hist;
   std::vector<TuTask> all_tasks; std::vector<int> all_levels;                              // DE265HIP_INTRA_MODE=levels only
   std::vector<TuTask> l0, run_tus;
@@ -771,6 +772,12 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   const int lc = p.log2_ctb_size, lt = p.log2_min_tb_size;
   const int* zs = g.min_tb_zs.data();
   const bool cip = p.constrained_intra_pred_flag != 0;
+  const bool one_tile = p.num_tile_columns == 1 && p.num_tile_rows == 1;
+  const int ctb_mask = (1 << lc) - 1;
+  {
+    const int mkey = lc | (lt << 4) | (cf << 8);
+    if (SC.avail_memo.size() != 2 * 4 * 16 * 16 || SC.avail_memo_key != mkey) { SC.avail_memo.assign(2 * 4 * 16 * 16, 0); SC.avail_memo_key = mkey; }
+  }
   // pre-pass: how many level-0 tasks of each size there will be - inter TUs with residual, then the residual-only copies of the
   // intra TUs: [32x32 | 16x16 | 8x8 | 4x4], inside a size the inter TUs first - so that both are written to their final place
   // Range-extension tools of a TU (D265_RX_* bits; 0 for every TU of a Main / Main10 picture): such a TU's residual is
@@ -815,7 +822,6 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   const bool host_checks_positions = dec->dry || dec->intra_levels;
   int last_luma_tu = -1;                                   // most recent luma TU record (cross-component prediction reads its residual)
   int n_tasks = 0;
-  int32_t cell[33];                                        // 4x4 map cell of every available unit of the current TU
   int prod[40];
   for (int i = 0; i < d->n_tus; i++) {
     const de265hip_tu& tu = d->tus[i];
@@ -885,17 +891,31 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
         return !cip || (d->blk_flags[((xs * sbw) >> 2) + ((ys * sbh) >> 2) * g.w4] & DE265HIP_BLK_INTRA);
       };
       auto z_ok = [&](int xs, int ys) { return zs[((xs * sbw) >> lt) + (size_t)((ys * sbh) >> lt) * g.tbs_w] <= cur; };
-      auto take = [&](int u, int xs, int ys) { mask |= 1ull << u; cell[u] = (xs >> 2) + (ys >> 2) * mw; };
-      if (aL) {
-        for (int y = nT - 1; y >= 0; y -= 4) if ((!full_z || z_ok(xB - 1, yB + y)) && intra_ok(xB - 1, yB + y)) take((2 * nT - 1 - y) >> 2, xB - 1, yB + y);
-        for (int y = nBottom - 1; y >= nT; y -= 4)
-          if (z_ok(xB - 1, yB + y) && intra_ok(xB - 1, yB + y)) take((2 * nT - 1 - y) >> 2, xB - 1, yB + y);
+      auto take = [&](int u, int, int) { mask |= 1ull << u; };
+      // 4x4 map cell of neighbour unit u (left column bottom -> top, corner, top row left -> right)
+      const int cell_l = ((xB - 1) >> 2) + ((yB >> 2) + corner - 1) * mw, cell_t = (xB >> 2) + ((yB >> 2) - 1) * mw;
+      auto cell_of = [&](int u) { return u < corner ? cell_l - u * mw : (u == corner ? cell_t - 1 : cell_t + (u - corner - 1)); };
+      // One tile, no constrained intra prediction, the four neighbouring CTBs of the TU's slice and nothing clipped by the picture:
+      // what is left is the z-scan order, a function of the TU's size and position inside its CTB - remembered per thread
+      // (filled by the general code below the first time a position is seen; an entry is never 0: the left column is there)
+      uint64_t* memo = nullptr;
+      if (one_tile && !cip && !full_z && aL && aT && aTL && aTR && yL + 2 * nT * sbh <= p.height && xL + 2 * nT * sbw <= p.width) {
+        memo = &SC.avail_memo[((((c ? 1 : 0) * 4 + (tu.log2_size - 2)) * 16 + ((yL & ctb_mask) >> 2)) * 16) + ((xL & ctb_mask) >> 2)];
+        mask = *memo;
       }
-      if (aTL && (!full_z || z_ok(xB - 1, yB - 1)) && intra_ok(xB - 1, yB - 1)) take(corner, xB - 1, yB - 1);
-      if (aT) for (int x = 0; x < nT; x += 4) if ((!full_z || z_ok(xB + x, yB - 1)) && intra_ok(xB + x, yB - 1)) take(corner + 1 + (x >> 2), xB + x, yB - 1);
-      if (aTR)
-        for (int x = nT; x < nRight; x += 4)
-          if (z_ok(xB + x, yB - 1) && intra_ok(xB + x, yB - 1)) take(corner + 1 + (x >> 2), xB + x, yB - 1);
+      if (!mask) {
+        if (aL) {
+          for (int y = nT - 1; y >= 0; y -= 4) if ((!full_z || z_ok(xB - 1, yB + y)) && intra_ok(xB - 1, yB + y)) take((2 * nT - 1 - y) >> 2, xB - 1, yB + y);
+          for (int y = nBottom - 1; y >= nT; y -= 4)
+            if (z_ok(xB - 1, yB + y) && intra_ok(xB - 1, yB + y)) take((2 * nT - 1 - y) >> 2, xB - 1, yB + y);
+        }
+        if (aTL && (!full_z || z_ok(xB - 1, yB - 1)) && intra_ok(xB - 1, yB - 1)) take(corner, xB - 1, yB - 1);
+        if (aT) for (int x = 0; x < nT; x += 4) if ((!full_z || z_ok(xB + x, yB - 1)) && intra_ok(xB + x, yB - 1)) take(corner + 1 + (x >> 2), xB + x, yB - 1);
+        if (aTR)
+          for (int x = nT; x < nRight; x += 4)
+            if (z_ok(xB + x, yB - 1) && intra_ok(xB + x, yB - 1)) take(corner + 1 + (x >> 2), xB + x, yB - 1);
+        if (memo) *memo = mask;
+      }
       t.avail = mask;
       // -- dependencies: only the units the mode reads (mode_deps), or every available unit
       const Cell* cells = SC.cells[c].data();
@@ -905,7 +925,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       bool foreign = false;
       const int crun = cur_run[c];
       for (; need; need &= need - 1) {
-        const Cell C = cells[cell[__builtin_ctzll(need)]];
+        const Cell C = cells[cell_of(__builtin_ctzll(need))];
         const int cr = C.run - E;                           // (< 0: no intra TU of this picture covers the cell)
         foreign = foreign || cr < 0;
         if (cr >= 0) {
@@ -923,7 +943,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       bool extends = r >= 0 && rb[r].ctu == ctu && rb[r].n_tus < 255;       /* RUN_MAX_TUS of k_run; positions + 1 fit a byte */
       if (extends) {
         extends = false;
-        for (uint64_t mm = mask; mm && !extends; mm &= mm - 1) extends = cells[cell[__builtin_ctzll(mm)]].run == E + r;
+        for (uint64_t mm = mask; mm && !extends; mm &= mm - 1) extends = cells[cell_of(__builtin_ctzll(mm))].run == E + r;
       }
       // A TU that cannot extend the current run but reads from exactly ONE run joins that run instead of starting its
       // own (e.g. an intra CU next to an intra CU of the neighbouring CTB, or below one decoded long ago): a hand-over
