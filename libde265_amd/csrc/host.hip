@@ -288,7 +288,7 @@ static uint64_t needed_units(uint64_t used, uint64_t avail)
 struct Cell { int32_t run; uint16_t lvl, llvl; };        // per 4x4 unit of a component: run of the intra TU covering it (-1: none), its TU level, its in-run level
 struct RunB {                                            // a run under construction
   int32_t c, ctu, x0, y0, x1, y1, wx1, wy1, level, est;  // est: run level as far as known during the scan
-  int32_t n_tus, head, tail;                             // its TUs: list through BuildScratch::it_next, decode order
+  int32_t n_tus, head, tail;                             // its TUs: list through TuTask::resid_offset of BuildScratch::it, decode order
   int32_t n_deps, dep_head, dep_tail;                    // its producer runs: list through BuildScratch::dep_next, order of discovery
   int64_t alg;
   int32_t foreign;                                       // some neighbour its TUs read is not written by an intra run of this picture (inter / PCM samples)
@@ -297,8 +297,12 @@ struct BuildScratch {
   std::vector<Cell> cells[3];
   int32_t epoch_base = 0;
   std::vector<uint32_t> ctb_group;
-  std::vector<TuTask> it; std::vector<int32_t> it_next; std::vector<uint16_t> it_llev;     // intra TUs in decode order
-  std::vector<uint8_t> it_rx; std::vector<int8_t> it_rsv; std::vector<uint64_t> it_luma;                                // ... their range-extension bits (D265_RX_*) and, for cross-component prediction, the luma TU
+  // intra TUs in decode order.  Until the runs are laid out three fields of a record carry scan state: resid_offset = the next
+  // TU of its run (-1: last), run_level = its in-run level - 1 (what the field finally holds), pad3 = its range-extension
+  // bits (D265_RX_*; cleared in the run-ordered copy)
+  std::vector<TuTask> it;
+  struct ItXcc { int32_t ti; int8_t rsv; uint64_t luma; };
+  std::vector<ItXcc> it_xcc;                                                                 // cross-component prediction: ResScaleVal and the luma TU, by ascending ti
   std::vector<TuTask> l0_rext;                                                              // level-0 tasks of k_resid_rext
   std::vector<RunB> rb;
   std::vector<int32_t> dep_val, dep_next;
@@ -757,7 +761,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   // runs: maximal intervals of the per-component intra TU sequence inside one CTB in which
   // every TU reads from the run so far (see k_run); independent TUs start a new run
   std::vector<RunB>& rb = SC.rb; rb.clear();
-  SC.it.clear(); SC.it_next.clear(); SC.it_llev.clear(); SC.dep_val.clear(); SC.dep_next.clear();
+  SC.it.clear(); SC.it_xcc.clear(); SC.dep_val.clear(); SC.dep_next.clear();
   SC.level_hist.assign(2, 0);
   SC.all_tasks.clear(); SC.all_levels.clear();
   int cur_run[3] = { -1, -1, -1 };
@@ -817,8 +821,8 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     SC.l0.resize(at);
   }
   TuTask* l0p = SC.l0.data();
-  SC.it.reserve(n_intra); SC.it_next.reserve(n_intra); SC.it_llev.reserve(n_intra);
-  SC.it_rx.clear(); SC.it_rsv.clear(); SC.it_luma.clear(); SC.l0_rext.clear();
+  SC.it.reserve(n_intra);
+  SC.l0_rext.clear();
   const bool host_checks_positions = dec->dry || dec->intra_levels;
   int last_luma_tu = -1;                                   // most recent luma TU record (cross-component prediction reads its residual)
   int n_tasks = 0;
@@ -1000,9 +1004,11 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       }
       {                                                     // the run's TUs: a list in decode order
         const int ti = (int)SC.it.size();
-        SC.it.push_back(t); SC.it_next.push_back(-1); SC.it_llev.push_back((uint16_t)llev);
-        SC.it_rx.push_back((uint8_t)(rx | rx_luma)); SC.it_rsv.push_back(tu.res_scale_val); SC.it_luma.push_back(luma_info);
-        if (R.tail >= 0) SC.it_next[R.tail] = ti; else R.head = ti;
+        t.resid_offset = 0xFFFFFFFFu; t.run_level = (uint8_t)(llev - 1); t.pad3 = (uint8_t)(rx | rx_luma);
+        SC.it.push_back(t);
+        t.resid_offset = 0; t.run_level = 0; t.pad3 = 0;     // (the level-launch schedule keeps its own copy of t below)
+        if (rx & D265_RX_XCC) SC.it_xcc.push_back(BuildScratch::ItXcc{ ti, tu.res_scale_val, luma_info });
+        if (R.tail >= 0) SC.it[R.tail].resid_offset = (uint32_t)ti; else R.head = ti;
         R.tail = ti; R.n_tus++;
       }
       {
@@ -1068,7 +1074,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     auto is_micro = [&](const RunB& R) {
       if (micro_off || R.n_tus > micro_tus || R.x1 - R.x0 > 32 || R.y1 - R.y0 > 32) return false;
       int samples = 0; bool big = false;
-      for (int ti = R.head; ti >= 0; ti = SC.it_next[ti]) {
+      for (int ti = R.head; ti >= 0; ti = (int32_t)SC.it[ti].resid_offset) {
         const TuTask& t = SC.it[ti];
         if (t.log2_size > 4) return false;
         big = big || t.log2_size == 4; samples += 1 << (2 * t.log2_size);
@@ -1117,7 +1123,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       o.x0 = (uint16_t)R.x0; o.y0 = (uint16_t)R.y0; o.x1 = (uint16_t)R.x1; o.y1 = (uint16_t)R.y1;
       o.wx1 = (uint16_t)std::min(R.wx1, R.x1 + 32); o.wy1 = (uint16_t)std::min(R.wy1, R.y1 + 32);
       int n = 0, own_samples = 0, nl = 0;
-      for (int ti = R.head; ti >= 0; ti = SC.it_next[ti]) { tix[n++] = ti; own_samples += 1 << (2 * SC.it[ti].log2_size); nl = std::max(nl, (int)SC.it_llev[ti]); }
+      for (int ti = R.head; ti >= 0; ti = (int32_t)SC.it[ti].resid_offset) { tix[n++] = ti; own_samples += 1 << (2 * SC.it[ti].log2_size); nl = std::max(nl, (int)SC.it[ti].run_level + 1); }
       // dense: the run's TUs cover its whole bounding box AND every available neighbour outside the box lies on the row
       // above it or the column left of it (two stacked CUs with an inter CU beside the upper one do not qualify: the
       // lower CU reads above-right samples from inside the box's row range)
@@ -1159,7 +1165,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
         const int nwv = micro[order[k]] ? 1 : dec->run_waves;
         const int n_epochs = nl > 0 ? nl - 1 : 0;
         for (int i = 0; i < n; i++) {
-          const int lev = SC.it_llev[tix[i]];
+          const int lev = (int)SC.it[tix[i]].run_level + 1;
           const int list = (SC.it[tix[i]].log2_size > 3 && !micro[order[k]]) ? 4 : rank[lev]++ % nwv;
           keys[i] = ((uint32_t)list << 20) | ((uint32_t)lev << 8) | (uint32_t)i;
         }
@@ -1193,14 +1199,21 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
         // behind the run record, before they have seen a single TU record
         tt.resid_offset = (uint32_t)n_resid + samp;
         tt.coeff_offset = samp; samp += 1u << (2 * tt.log2_size);
-        const int trx = SC.it_rx[ti];
+        const int trx = tt.pad3; tt.pad3 = 0;
         if ((tt.flags & DE265HIP_TU_CBF) || (trx & D265_RX_XCC)) {
-          TuTask ro = tt; ro.flags |= D265_TU_RESID_ONLY; ro.coeff_offset = coeff_offset;
-          if (trx) { ro.pad3 = (uint8_t)trx; ro.angle = SC.it_rsv[ti]; ro.avail = SC.it_luma[ti]; SC.l0_rext.push_back(ro); }
+          TuTask ro = tt; ro.flags |= D265_TU_RESID_ONLY; ro.coeff_offset = coeff_offset; ro.run_level = 0;
+          if (trx) {
+            ro.pad3 = (uint8_t)trx; ro.angle = 0; ro.avail = 0;
+            if (trx & D265_RX_XCC) {
+              const auto e = std::lower_bound(SC.it_xcc.begin(), SC.it_xcc.end(), ti, [](const BuildScratch::ItXcc& a, int v) { return a.ti < v; });
+              ro.angle = e->rsv; ro.avail = e->luma;
+            }
+            SC.l0_rext.push_back(ro);
+          }
           else l0p[ro_cur[ro.log2_size - 2]++] = ro;
           tt.flags |= DE265HIP_TU_CBF;                     // (the run kernels read the residual block whenever there is one)
         }
-        tt.run_level = (uint8_t)(SC.it_llev[ti] - 1);    // the run-ordered copy carries the TU's barrier epoch
+        // (tt.run_level: the run-ordered copy carries the TU's barrier epoch = its in-run level - 1, there since the scan)
         run_tus.push_back(tt);
       }
       o.n_samples = samp;
@@ -1289,11 +1302,11 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       struct Path { double t = 0, lv = 0, slots = 0, n16 = 0, n32 = 0; int runs = 0; };
       std::vector<Path> fin(rb.size()); Path worst;
       for (size_t i = 0; i < rb.size(); i++) {           // rb is in creation order: producers precede consumers
-        int nl = 0; for (int ti = rb[i].head; ti >= 0; ti = SC.it_next[ti]) nl = std::max(nl, (int)SC.it_llev[ti]);
+        int nl = 0; for (int ti = rb[i].head; ti >= 0; ti = (int32_t)SC.it[ti].resid_offset) nl = std::max(nl, (int)SC.it[ti].run_level + 1);
         std::vector<int> per(nl + 1, 0); int n16 = 0, n32 = 0;
-        for (int ti = rb[i].head; ti >= 0; ti = SC.it_next[ti]) {
+        for (int ti = rb[i].head; ti >= 0; ti = (int32_t)SC.it[ti].resid_offset) {
           const int l2 = SC.it[ti].log2_size;
-          if (l2 == 4) n16++; else if (l2 == 5) n32++; else per[SC.it_llev[ti]]++;
+          if (l2 == 4) n16++; else if (l2 == 5) n32++; else per[(int)SC.it[ti].run_level + 1]++;
         }
         int nslots = 0; for (int l = 1; l <= nl; l++) nslots += (per[l] + 3) / 4;
         Path st;
