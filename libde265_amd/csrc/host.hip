@@ -309,7 +309,7 @@ struct BuildScratch {
   std::vector<uint64_t> avail_memo; int avail_memo_key = -1;                                   // availability masks by (chroma, size, position in the CTB)
   std::vector<int> level_hist;
   std::vector<TuTask> all_tasks; std::vector<int> all_levels;                              // DE265HIP_INTRA_MODE=levels only
-  std::vector<TuTask> l0, run_tus;
+  std::vector<TuTask> l0, l0_inter[4], run_tus;
   std::vector<RunTask> runs; std::vector<uint32_t> run_deps, slots, mbx, mb_segs;
   std::vector<int> order, newidx, count2, width; std::vector<uint8_t> micro;
   std::vector<McTask> mcs, mc_tiles[8], mc_chunks[8], mc_quads[8], mc_micro[8 * 17 * 17]; std::vector<int> micro_keys;
@@ -806,22 +806,11 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     if (tu.c_idx && tu.res_scale_val) rx |= D265_RX_XCC;
     return rx;
   };
-  int n_inter_size[4] = { 0, 0, 0, 0 }, n_ro_size[4] = { 0, 0, 0, 0 }, n_intra = 0;
-  for (int i = 0; i < d->n_tus; i++) {
-    const de265hip_tu& tu = d->tus[i];
-    if (tu.log2_size < 2 || tu.log2_size > 5) { delete pic; return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE; }
-    if (rx_bits(tu)) { if (tu.flags & DE265HIP_TU_INTRA) n_intra++; continue; }                 // (k_resid_rext's list, not bucketed by size)
-    if (tu.flags & DE265HIP_TU_INTRA) { n_intra++; if ((tu.flags & DE265HIP_TU_CBF) && tu.n_coeff) n_ro_size[tu.log2_size - 2]++; }
-    else if (tu.flags & DE265HIP_TU_CBF) n_inter_size[tu.log2_size - 2]++;
-  }
-  size_t inter_cur[4], ro_cur[4];
-  {
-    size_t at = 0;
-    for (int k = 3; k >= 0; k--) { inter_cur[k] = at; at += n_inter_size[k]; ro_cur[k] = at; at += n_ro_size[k]; pic->n_l0_size[k] = n_inter_size[k] + n_ro_size[k]; }
-    SC.l0.resize(at);
-  }
-  TuTask* l0p = SC.l0.data();
-  SC.it.reserve(n_intra);
+  // (the inter TUs of each size are collected as they come and copied to their place behind the scan, when the number of
+  //  residual-only intra copies of each size is known: one pass over the TU records instead of two)
+  int n_ro_size[4] = { 0, 0, 0, 0 };
+  for (auto& v : SC.l0_inter) v.clear();
+  SC.it.reserve((size_t)d->n_tus);
   SC.l0_rext.clear();
   const bool host_checks_positions = dec->dry || dec->intra_levels;
   int last_luma_tu = -1;                                   // most recent luma TU record (cross-component prediction reads its residual)
@@ -829,6 +818,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   int prod[40];
   for (int i = 0; i < d->n_tus; i++) {
     const de265hip_tu& tu = d->tus[i];
+    if (tu.log2_size < 2 || tu.log2_size > 5) { delete pic; return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE; }
     const int nT = 1 << tu.log2_size;
     const int cw = tu.c_idx ? cwid : p.width, ch = tu.c_idx ? chei : p.height;
     if (tu.c_idx > 2 || (tu.x0 & 3) || (tu.y0 & 3) || tu.x0 + nT > cw || tu.y0 + nT > ch || tu.qp < 0 ||
@@ -1020,12 +1010,13 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       alg_intra += (int64_t)bpp * (4 * nT + 1) + (int64_t)bpp * nT * nT;
       R.alg += (int64_t)bpp * (4 * nT + 1) + (int64_t)bpp * nT * nT;
       if (level >= 65535) { delete pic; return DE265HIP_ERROR_NOT_IMPLEMENTED; }
+      if (!rx && (t.flags & DE265HIP_TU_CBF)) n_ro_size[tu.log2_size - 2]++;      // its residual-only copy: a level-0 task of that size
     } else if (rx) {                                        // level 0, a range-extension tool: k_resid_rext's list
       TuTask rt = t;
       rt.pad3 = (uint8_t)(rx | rx_luma); rt.angle = tu.res_scale_val; rt.avail = luma_info;
       SC.l0_rext.push_back(rt);
     } else
-      l0p[inter_cur[tu.log2_size - 2]++] = t;               // level 0: residual added into the (inter-predicted) picture
+      SC.l0_inter[tu.log2_size - 2].push_back(t);           // level 0: residual added into the (inter-predicted) picture
     if (t.flags & DE265HIP_TU_CBF)
       alg_resid += std::min<int64_t>(4 * (int64_t)t.n_coeff, 2 * (int64_t)nT * nT) +
                    ((tu.flags & DE265HIP_TU_INTRA) ? 0 : 2 * (int64_t)bpp * nT * nT);
@@ -1034,6 +1025,14 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     n_tasks++;
     if (dec->intra_levels) { SC.all_tasks.push_back(t); SC.all_levels.push_back(level); }
   }
+  size_t ro_cur[4];
+  {
+    size_t at = 0, inter_at[4];
+    for (int k = 3; k >= 0; k--) { inter_at[k] = at; at += SC.l0_inter[k].size(); ro_cur[k] = at; at += n_ro_size[k]; pic->n_l0_size[k] = (int)SC.l0_inter[k].size() + n_ro_size[k]; }
+    SC.l0.resize(at);
+    for (int k = 0; k < 4; k++) if (!SC.l0_inter[k].empty()) memcpy(SC.l0.data() + inter_at[k], SC.l0_inter[k].data(), SC.l0_inter[k].size() * sizeof(TuTask));
+  }
+  TuTask* l0p = SC.l0.data();
   pt.mark("tu_scan");
   pic->level_start.assign(SC.level_hist.begin(), SC.level_hist.begin() + max_level + 2);
   for (int l = 0; l <= max_level; l++) pic->level_start[l + 1] += pic->level_start[l];
