@@ -313,7 +313,7 @@ struct BuildScratch {
   std::vector<RunTask> runs; std::vector<uint32_t> run_deps, slots, mbx, mb_segs;
   std::vector<int> order, newidx, count2, width; std::vector<uint8_t> micro;
   std::vector<McTask> mcs, mc_tiles[8], mc_chunks[8], mc_quads[8], mc_micro[8 * 17 * 17]; std::vector<int> micro_keys;
-  std::vector<uint8_t> band_row, sub_row; std::vector<uint32_t> roww, mc_order[8 * 4 * 2], mc_order_all;   // mc_order[(band * MC_SUB + part) * 2 + (quad ? 1 : 0)]
+  std::vector<uint8_t> band_row; std::vector<uint32_t> roww, mc_order[8], mc_order_all;
   std::vector<PcmTask> pcms; std::vector<SaoCtb> saos;
 };
 static thread_local BuildScratch g_scratch;
@@ -1340,11 +1340,8 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   // k_mc_all's bands: ranges of CTB rows with about an eighth of the picture's MC work each (a wavefront per 16x16 tile of a
   // larger PU and list, a third of that per block of a small PU): band_row[CTB row]
   std::vector<uint32_t>& mc_order_all = SC.mc_order_all;
-  const char* ch_env = getenv("DE265HIP_MC_CHUNK_H"); const int chunk_h = ch_env ? std::max(16, atoi(ch_env) & ~15) : 16;
-  const char* sub_env = getenv("DE265HIP_MC_SUB"); const char* mix_env = getenv("DE265HIP_MC_MIX");   // (experiments)
-  const int MC_SUB = sub_env ? std::min(4, std::max(1, atoi(sub_env))) : 1, mc_mix = mix_env ? atoi(mix_env) != 0 : 1;
+  constexpr int chunk_h = 16;                             // chunks of 32x16: two tiles (see the order's comment below)
   std::vector<uint8_t>& band_row = SC.band_row; band_row.assign((size_t)g.ctbs_h, 0);
-  std::vector<uint8_t>& sub_row = SC.sub_row; sub_row.assign((size_t)g.ctbs_h, 0);
   if (mc_all) {
     std::vector<uint32_t>& roww = SC.roww; roww.assign((size_t)g.ctbs_h, 0);
     uint64_t total = 0;
@@ -1356,11 +1353,10 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
                                                     : 3u * nl * ((pu.w + 15) >> 4) * ((pu.h + 15) >> 4);
       roww[pu.y >> lc] += wgt; total += wgt;
     }
-    // (experiments: each band in MC_SUB parts of about equal work, sub_row, inside a part the chunks before the quads)
     uint64_t acc = 0; int b = 0;
     for (int r = 0; r < g.ctbs_h; r++) {
-      while (b < 8 * MC_SUB - 1 && acc * (8 * MC_SUB) >= total * (uint64_t)(b + 1)) b++;
-      band_row[r] = (uint8_t)(b / MC_SUB); sub_row[r] = (uint8_t)(b % MC_SUB);
+      while (b < 7 && acc * 8 >= total * (uint64_t)(b + 1)) b++;
+      band_row[r] = (uint8_t)b;
       acc += roww[r];
     }
   }
@@ -1440,7 +1436,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
           if (v.empty()) SC.micro_keys.push_back(key);
           v.push_back(q);
           if (v.size() == 4) {
-            SC.mc_order[(bnd * MC_SUB + sub_row[Y >> lc]) * 2 + (mc_mix ? 0 : 1)].push_back(0x80000000u | (uint32_t)(SC.mc_quads[bnd].size() / 4));
+            SC.mc_order[bnd].push_back(0x80000000u | (uint32_t)(SC.mc_quads[bnd].size() / 4));
             SC.mc_quads[bnd].insert(SC.mc_quads[bnd].end(), v.begin(), v.end()); v.clear();
           }
         }
@@ -1452,7 +1448,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
         if (mc_all && (mc_paths & 2) && (pu_interior || interior(X, Y, cw_, ch_))) {
           McTask q = t;
           q.x = (uint16_t)X; q.y = (uint16_t)Y; q.w = (uint8_t)cw_; q.h = (uint8_t)ch_;
-          { const int bc = band_of(Y); SC.mc_order[(bc * MC_SUB + sub_row[Y >> lc]) * 2].push_back(0x40000000u | (uint32_t)SC.mc_chunks[bc].size()); SC.mc_chunks[bc].push_back(q); }
+          { const int bc = band_of(Y); SC.mc_order[bc].push_back(0x40000000u | (uint32_t)SC.mc_chunks[bc].size()); SC.mc_chunks[bc].push_back(q); }
         } else tiles16(X, Y, cw_, ch_);
       }
   }
@@ -1474,7 +1470,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
         std::vector<McTask>& v = SC.mc_micro[SC.micro_keys[mk]];
         if (v.empty()) continue;
         while (v.size() & 3) { McTask q = v.back(); q.w = q.h = 0; v.push_back(q); }      // (a block that stores nothing)
-        SC.mc_order[(b * MC_SUB + MC_SUB - 1) * 2 + 1].push_back(0x80000000u | (uint32_t)((mcs.size() - q0) / 4));
+        SC.mc_order[b].push_back(0x80000000u | (uint32_t)((mcs.size() - q0) / 4));
         mcs.insert(mcs.end(), v.begin(), v.end());
         v.clear();
       }
@@ -1487,10 +1483,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       // and 1.75x.  Hence chunks of at most two tiles.
       B.order_first[b] = (uint32_t)mc_order_all.size();
       for (uint32_t q = 0; q < B.n_tiles[b]; q++) mc_order_all.push_back(q);
-      for (int q = 0; q < 2 * MC_SUB; q++) {
-        std::vector<uint32_t>& v = SC.mc_order[b * 2 * MC_SUB + q];
-        mc_order_all.insert(mc_order_all.end(), v.begin(), v.end()); v.clear();
-      }
+      mc_order_all.insert(mc_order_all.end(), SC.mc_order[b].begin(), SC.mc_order[b].end()); SC.mc_order[b].clear();
       B.n_entries[b] = (uint32_t)mc_order_all.size() - B.order_first[b];
       pic->n_mc2 += (int)B.n_chunks[b]; pic->n_mc_quads += (int)B.n_quads[b];
     }
