@@ -916,15 +916,16 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       // (4:4:4 chroma is smoothed like luma: it takes luma's table, a superset of what it reads)
       uint64_t need = mode_deps ? needed_units(g_used_units[tu.log2_size - 2][m][c == 0 || cf == 3], mask) : mask;
       int lev = 0, llev = 0, n_prod = 0;
-      bool foreign = false;
+      bool foreign = false, reads_cur = false;
       const int crun = cur_run[c];
+      const uint64_t need0 = need;
       for (; need; need &= need - 1) {
         const Cell C = cells[cell_of(__builtin_ctzll(need))];
         const int cr = C.run - E;                           // (< 0: no intra TU of this picture covers the cell)
         foreign = foreign || cr < 0;
         if (cr >= 0) {
           lev = std::max(lev, (int)C.lvl);
-          if (cr == crun) llev = std::max(llev, (int)C.llvl);
+          if (cr == crun) { llev = std::max(llev, (int)C.llvl); reads_cur = true; }
           bool seen = false;
           for (int q = 0; q < n_prod; q++) seen = seen || prod[q] == cr;
           if (!seen) prod[n_prod++] = cr;
@@ -935,9 +936,9 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       // decided on the FULL neighbourhood, so that an all-intra CTB stays one run per component) ...
       int r = crun;
       bool extends = r >= 0 && rb[r].ctu == ctu && rb[r].n_tus < 255;       /* RUN_MAX_TUS of k_run; positions + 1 fit a byte */
-      if (extends) {
+      if (extends && !reads_cur) {                          // (a needed unit of the current run settles it: the needed units are available ones)
         extends = false;
-        for (uint64_t mm = mask; mm && !extends; mm &= mm - 1) extends = cells[cell_of(__builtin_ctzll(mm))].run == E + r;
+        for (uint64_t mm = mask & ~need0; mm && !extends; mm &= mm - 1) extends = cells[cell_of(__builtin_ctzll(mm))].run == E + r;
       }
       // A TU that cannot extend the current run but reads from exactly ONE run joins that run instead of starting its
       // own (e.g. an intra CU next to an intra CU of the neighbouring CTB, or below one decoded long ago): a hand-over
