@@ -312,7 +312,8 @@ struct BuildScratch {
   std::vector<TuTask> l0, l0_inter[4], run_tus;
   std::vector<RunTask> runs; std::vector<uint32_t> run_deps, slots, mbx, mb_segs;
   std::vector<int> order, newidx, count2, width; std::vector<uint8_t> micro;
-  std::vector<McTask> mcs, mc_tiles[8], mc_chunks[8], mc_quads[8], mc_micro[8 * 17 * 17]; std::vector<int> micro_keys;
+  struct QuadPend { McTask t[4]; int n = 0; };                                               // a slot pair's open quad (k_mc_all)
+  std::vector<McTask> mcs, mc_tiles[8], mc_chunks[8], mc_quads[8]; QuadPend mc_pend[8 * 17 * 17]; std::vector<int> micro_keys;
   std::vector<uint8_t> band_row; std::vector<uint32_t> roww, mc_order[8], mc_order_all;
   std::vector<PcmTask> pcms; std::vector<SaoCtb> saos;
 };
@@ -1341,6 +1342,10 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   // k_mc_all's bands: ranges of CTB rows with about an eighth of the picture's MC work each (a wavefront per 16x16 tile of a
   // larger PU and list, a third of that per block of a small PU): band_row[CTB row]
   std::vector<uint32_t>& mc_order_all = SC.mc_order_all;
+  // (a build that failed half way through its PUs may have left lists of its own behind)
+  for (int key : SC.micro_keys) SC.mc_pend[key].n = 0;
+  SC.micro_keys.clear();
+  for (int b = 0; b < 8; b++) { SC.mc_tiles[b].clear(); SC.mc_chunks[b].clear(); SC.mc_quads[b].clear(); SC.mc_order[b].clear(); }
   constexpr int chunk_h = 16;                             // chunks of 32x16: two tiles (see the order's comment below)
   std::vector<uint8_t>& band_row = SC.band_row; band_row.assign((size_t)g.ctbs_h, 0);
   if (mc_all) {
@@ -1433,12 +1438,12 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
           // quads in decode order: a slot pair's open quad is emitted the moment its fourth block arrives (quads sorted by
           // slot pair swept the band once per pair: 3.3x the algorithmic bytes through the L2 with two reference slots)
           const int bnd = band_of(Y), key = bnd * 289 + key0;
-          std::vector<McTask>& v = SC.mc_micro[key];
-          if (v.empty()) SC.micro_keys.push_back(key);
-          v.push_back(q);
-          if (v.size() == 4) {
+          BuildScratch::QuadPend& v = SC.mc_pend[key];
+          if (v.n == 0) SC.micro_keys.push_back(key);
+          v.t[v.n++] = q;
+          if (v.n == 4) {
             SC.mc_order[bnd].push_back(0x80000000u | (uint32_t)(SC.mc_quads[bnd].size() / 4));
-            SC.mc_quads[bnd].insert(SC.mc_quads[bnd].end(), v.begin(), v.end()); v.clear();
+            SC.mc_quads[bnd].insert(SC.mc_quads[bnd].end(), v.t, v.t + 4); v.n = 0;
           }
         }
       continue;
@@ -1468,12 +1473,12 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       const size_t q0 = mcs.size();
       mcs.insert(mcs.end(), SC.mc_quads[b].begin(), SC.mc_quads[b].end()); SC.mc_quads[b].clear();
       for (; mk < SC.micro_keys.size() && SC.micro_keys[mk] / 289 == b; mk++) {             // the quads left open
-        std::vector<McTask>& v = SC.mc_micro[SC.micro_keys[mk]];
-        if (v.empty()) continue;
-        while (v.size() & 3) { McTask q = v.back(); q.w = q.h = 0; v.push_back(q); }      // (a block that stores nothing)
+        BuildScratch::QuadPend& v = SC.mc_pend[SC.micro_keys[mk]];
+        if (v.n == 0) continue;
+        while (v.n < 4) { v.t[v.n] = v.t[v.n - 1]; v.t[v.n].w = v.t[v.n].h = 0; v.n++; }  // (a block that stores nothing)
         SC.mc_order[b].push_back(0x80000000u | (uint32_t)((mcs.size() - q0) / 4));
-        mcs.insert(mcs.end(), v.begin(), v.end());
-        v.clear();
+        mcs.insert(mcs.end(), v.t, v.t + 4);
+        v.n = 0;
       }
       B.n_quads[b] = (uint32_t)((mcs.size() - q0) / 4);
       // the band's wavefronts take the border tiles first (few, and the longest single tasks: per-sample clamped fetch), then
