@@ -30,9 +30,12 @@
  * PUs/PCM/metadata in luma samples.  ChromaArrayType 1 (4:2:0), 2 (4:2:2) and 3 (4:4:4) are supported, with the
  * range-extension sample tools the reference implements: cross-component prediction, implicit and
  * explicit RDPCM, transform-skip rotation, transform skip beyond 4x4, intra smoothing switched off, chroma smoothing
- * in 4:4:4.  Monochrome (0) and extended_precision_processing return DE265_ERROR_NOT_IMPLEMENTED_YET (the reference's
- * inter path reads chroma planes a monochrome picture does not have, motion.cc:302-305, and its transform path hard-codes
- * extended_precision_processing_flag = 0, transform.cc:535).
+ * in 4:4:4.  Monochrome (0) is supported for pictures WITHOUT prediction units (all-intra): the two chroma planes of such
+ * a picture are empty (uploads / downloads of them are no-ops, a TU record with c_idx > 0 is out of range, a PCM block
+ * carries n*n samples).  Monochrome with prediction units and extended_precision_processing return
+ * DE265_ERROR_NOT_IMPLEMENTED_YET (the reference's inter path addresses chroma planes whatever the format,
+ * motion.cc:296-305, which a monochrome picture does not have, and its transform path hard-codes
+ * extended_precision_processing_flag = 0, transform.cc:535: nothing defined to match).
  */
 #ifndef DE265_HIP_H
 #define DE265_HIP_H

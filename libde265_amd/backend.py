@@ -276,6 +276,8 @@ class Decoder:
 
     def _chroma_dims(self, slot, w, h):
         cf = lib().de265hip_dpb_chroma_format(self._h, slot)
+        if cf == 0:
+            return (0, 0)                      # monochrome: empty chroma planes
         return (w if cf == 3 else w // 2, h // 2 if cf == 1 else h)
 
     def dpb_info(self, slot):

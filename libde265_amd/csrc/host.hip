@@ -32,10 +32,10 @@ namespace {
 
 struct Slot {
   PlaneRef pl[3] = {};
-  int w = 0, h = 0, bdY = 0, bdC = 0, cf = 1;      // cf: chroma_format_idc (1, 2, 3)
+  int w = 0, h = 0, bdY = 0, bdC = 0, cf = 1;      // cf: chroma_format_idc (0: monochrome, empty chroma planes)
   bool valid = false;
-  int cw() const { return cf == 3 ? w : w / 2; }      // chroma plane size (SubWidthC / SubHeightC, sps.cc:540-552)
-  int ch() const { return cf == 1 ? h / 2 : h; }
+  int cw() const { return cf == 0 ? 0 : cf == 3 ? w : w / 2; }      // chroma plane size (SubWidthC / SubHeightC, sps.cc:540-552)
+  int ch() const { return cf == 0 ? 0 : cf == 1 ? h / 2 : h; }
   // de265hip_dpb_download_async: recorded on the output stream behind the slot's latest copy-out; whoever writes the
   // slot next (a new picture, an upload) or frees it waits for it.  dl_seq counts the copy-outs (dpb_wait compares it).
   hipEvent_t dl_done = nullptr;
@@ -158,6 +158,7 @@ int alloc_slot(Slot& s, int w, int h, int bdY, int bdC, int cf = 1)
   size_t off[4] = { 0, 0, 0, 0 };
   for (int c = 0; c < 3; c++) {
     int cw = c ? (cf == 3 ? w : w / 2) : w, ch = c ? (cf == 1 ? h / 2 : h) : h;
+    if (c && cf == 0) cw = ch = 0;                        // monochrome: the two chroma planes are empty (image.cc:301-306)
     int stride = (cw + 63) & ~63;                         // samples; rows start 128/64-byte aligned
     size_t bytes = (size_t)stride * ch * px_bytes(c ? bdC : bdY) + 256;
     off[c + 1] = off[c] + ((bytes + 255) & ~(size_t)255);
@@ -491,7 +492,7 @@ int de265hip_dpb_alloc(de265hip_decoder* d, int slot, int width, int height, int
 int de265hip_dpb_alloc_ex(de265hip_decoder* d, int slot, int width, int height, int bdY, int bdC, int chroma_format_idc)
 {
   if (!d || slot < 0 || slot >= DE265HIP_MAX_DPB_SLOTS) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
-  if (chroma_format_idc < 1 || chroma_format_idc > 3) return DE265HIP_ERROR_NOT_IMPLEMENTED;
+  if (chroma_format_idc < 0 || chroma_format_idc > 3) return DE265HIP_ERROR_NOT_IMPLEMENTED;
   if (width <= 0 || height <= 0 || (width & 7) || (height & 7) || bdY < 8 || bdY > 12 || bdC < 8 || bdC > 12)
     return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   if ((bdY > 8) != (bdC > 8)) return DE265HIP_ERROR_NOT_IMPLEMENTED;
@@ -513,6 +514,7 @@ int de265hip_dpb_upload(de265hip_decoder* d, int slot, int c, const void* src, p
 {
   Slot* s; int w, h; size_t bpp;
   int rc = plane_geom(d, slot, c, &s, &w, &h, &bpp); if (rc) return rc;
+  if (w == 0 || h == 0) return DE265HIP_OK;               // (a chroma plane of a monochrome picture)
   if (s->dl_done && s->dl_waited != s->dl_seq) HIPCHK(hipEventSynchronize(s->dl_done), DE265HIP_ERROR_DECODING);
   HIPCHK(hipStreamSynchronize(d->stream), DE265HIP_ERROR_DECODING);
   HIPCHK(hipMemcpy2D(s->pl[c].ptr, s->pl[c].stride * bpp, src, (size_t)stride_bytes, w * bpp, h, hipMemcpyHostToDevice),
@@ -525,6 +527,7 @@ int de265hip_dpb_download(de265hip_decoder* d, int slot, int c, void* dst, ptrdi
   Slot* s; int w, h; size_t bpp;
   int rc = plane_geom(d, slot, c, &s, &w, &h, &bpp); if (rc) return rc;
   HIPCHK(hipStreamSynchronize(d->stream), DE265HIP_ERROR_DECODING);
+  if (w == 0 || h == 0) return DE265HIP_OK;
   HIPCHK(hipMemcpy2D(dst, (size_t)stride_bytes, s->pl[c].ptr, s->pl[c].stride * bpp, w * bpp, h, hipMemcpyDeviceToHost),
          DE265HIP_ERROR_DECODING);
   return 0;
@@ -545,6 +548,7 @@ int de265hip_dpb_download_async(de265hip_decoder* d, int slot, int c, void* dst,
 {
   Slot* s; int w, h; size_t bpp;
   int rc = plane_geom(d, slot, c, &s, &w, &h, &bpp); if (rc) return rc;
+  if (w == 0 || h == 0) return DE265HIP_OK;               // (a chroma plane of a monochrome picture)
   std::lock_guard<std::mutex> lk(d->mu);
   if (!d->out_stream) {
     HIPCHK(hipStreamCreateWithFlags(&d->out_stream, hipStreamNonBlocking), DE265HIP_ERROR_DECODING);
@@ -636,6 +640,7 @@ int de265hip_dpb_copy(de265hip_decoder* sd, int ss, de265hip_decoder* dd, int ds
   for (int c = 0; c < 3 && !rc; c++) {
     const int h = c ? S.ch() : S.h;
     const size_t bytes = (size_t)S.pl[c].stride * h * px_bytes(c ? S.bdC : S.bdY);      // same pitch on both sides (alloc_slot)
+    if (!bytes) continue;
     hipError_t e = sd->device == dd->device
       ? hipMemcpyAsync(D.pl[c].ptr, S.pl[c].ptr, bytes, hipMemcpyDeviceToDevice, sd->stream)
       : hipMemcpyPeerAsync(D.pl[c].ptr, dd->device, S.pl[c].ptr, sd->device, bytes, sd->stream);
@@ -667,9 +672,11 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   if (!dec || !d || !out) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   *out = nullptr;
   const de265hip_pic_params& p = d->params;
-  // monochrome: the reference's inter path reads chroma planes a monochrome picture does not have (motion.cc:302-305);
-  // extended precision: its transform path hard-codes extended_precision_processing_flag = 0 (transform.cc:535)
-  if (p.chroma_format_idc < 1 || p.chroma_format_idc > 3 || p.extended_precision_processing_flag) return DE265HIP_ERROR_NOT_IMPLEMENTED;
+  // extended precision: the reference's transform path hard-codes extended_precision_processing_flag = 0 (transform.cc:535)
+  if (p.chroma_format_idc < 0 || p.chroma_format_idc > 3 || p.extended_precision_processing_flag) return DE265HIP_ERROR_NOT_IMPLEMENTED;
+  // monochrome: pictures without prediction units only - the reference's inter path addresses the chroma planes whatever
+  // the format (motion.cc:296-305), which a monochrome picture does not have: no defined result to match
+  if (p.chroma_format_idc == 0 && d->n_pus) return DE265HIP_ERROR_NOT_IMPLEMENTED;
   if (p.cross_component_prediction_enabled_flag && p.chroma_format_idc != 3) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   if ((p.bit_depth_luma > 8) != (p.bit_depth_chroma > 8)) return DE265HIP_ERROR_NOT_IMPLEMENTED;
   if (p.bit_depth_luma < 8 || p.bit_depth_luma > 12 || p.bit_depth_chroma < 8 || p.bit_depth_chroma > 12 ||
@@ -728,8 +735,8 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   P.weighted_pred = p.weighted_pred_flag; P.weighted_bipred = p.weighted_bipred_flag;
   P.cb_qp_offset = p.pic_cb_qp_offset; P.cr_qp_offset = p.pic_cr_qp_offset;
   P.lf_across_tiles = p.loop_filter_across_tiles_enabled_flag; P.scaling_list = p.scaling_list_enable_flag;
-  const int cf = p.chroma_format_idc, subw = cf == 3 ? 1 : 2, subh = cf == 1 ? 2 : 1;      // SubWidthC, SubHeightC
-  const int cwid = p.width / subw, chei = p.height / subh;
+  const int cf = p.chroma_format_idc, subw = (cf == 3 || cf == 0) ? 1 : 2, subh = cf == 1 ? 2 : 1;      // SubWidthC, SubHeightC
+  const int cwid = cf ? p.width / subw : 0, chei = cf ? p.height / subh : 0;          // (monochrome: no chroma samples; a TU with c_idx > 0 is out of range)
   P.chroma_format = cf; P.csw = subw - 1; P.csh = subh - 1; P.cwidth = cwid; P.cheight = chei;
   P.smooth_luma = !p.intra_smoothing_disabled_flag; P.smooth_chroma = !p.intra_smoothing_disabled_flag && cf == 3;
   P.implicit_rdpcm = p.implicit_rdpcm_enabled_flag; P.xcc_enabled = p.cross_component_prediction_enabled_flag;
@@ -1505,7 +1512,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     const de265hip_pcm& pc = d->pcms[i];
     const int n = 1 << pc.log2_cb_size;
     if (pc.log2_cb_size < 3 || pc.log2_cb_size > 5 || (pc.x0 & 7) || (pc.y0 & 7) || pc.x0 + n > p.width ||
-        pc.y0 + n > p.height || (int64_t)pc.sample_offset + n * n + 2 * (n / subw) * (n / subh) > d->n_pcm_samples) {
+        pc.y0 + n > p.height || (int64_t)pc.sample_offset + n * n + (cf ? 2 * (n / subw) * (n / subh) : 0) > d->n_pcm_samples) {
       delete pic; return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
     }
     PcmTask t; t.x0 = pc.x0; t.y0 = pc.y0; t.log2_cb_size = pc.log2_cb_size; t.sample_offset = pc.sample_offset;
@@ -1918,7 +1925,7 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
       KTimer t(dec, DE265HIP_K_DEBLOCK_V, 1);
       const int nbx = (P.width + 3) / 8 + 1, nby = (P.height + 3) / 8 + 1;
       hipLaunchKernelGGL((k_deblock_fused<PX>), dim3((nbx + 255) / 256, nby, c420 ? 3 : 1), dim3(256), 0, st, P, d0, d1, d2, M);
-      if (!c420)
+      if (!c420 && P.chroma_format)
         for (int vertical = 1; vertical >= 0; vertical--) {       // vertical edges of the whole plane before any horizontal one
           const int xi = (vertical ? 2 : 1) << P.csw, yi = (vertical ? 1 : 2) << P.csh;
           hipLaunchKernelGGL((k_deblock_chroma_any<PX>), dim3(((P.w4 + xi - 1) / xi + 255) / 256, (P.h4 + yi - 1) / yi, 2), dim3(256), 0, st,
@@ -1951,7 +1958,7 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
         const int gy = std::max((P.height + 4 * th - 1) / (4 * th), (P.height / 2 + 4 * thc - 1) / (4 * thc));
         const uint3 G = make_uint3((unsigned)gx, (unsigned)gy, c420 ? 3u : 1u);
         hipLaunchKernelGGL(k_sao_ctb<PX>, dim3(xcd_grid(G.x * G.y * G.z)), dim3(256), 0, st, P, d0, d1, d2, sp.pl[0], sp.pl[1], sp.pl[2], M, G);
-        if (!c420)
+        if (!c420 && P.chroma_format)
           hipLaunchKernelGGL(k_sao_chroma_any<PX>, dim3((P.cwidth + 255) / 256, P.cheight, 2), dim3(256), 0, st, P, d1, d2, sp.pl[1], sp.pl[2], M);
       }
     }
@@ -2178,7 +2185,7 @@ int de265hip_record_pcm(de265hip_recorder* r, int x0, int y0, int log2_cb_size, 
   p.sample_offset = (uint32_t)r->pcm_samples.size();
   const int n = 1 << log2_cb_size;
   const int rcf = r->d.params.chroma_format_idc;
-  r->pcm_samples.insert(r->pcm_samples.end(), samples, samples + n * n + 2 * (n / (rcf == 3 ? 1 : 2)) * (n / (rcf == 1 ? 2 : 1)));
+  r->pcm_samples.insert(r->pcm_samples.end(), samples, samples + n * n + (rcf ? 2 * (n / (rcf == 3 ? 1 : 2)) * (n / (rcf == 1 ? 2 : 1)) : 0));
   r->pcms.push_back(p);
   return DE265HIP_OK;
 }

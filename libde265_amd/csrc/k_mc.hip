@@ -1145,7 +1145,8 @@ void k_pcm(PicDev P, PlaneRef d0, PlaneRef d1, PlaneRef d2, const PcmTask* __res
   const int n = 1 << t.log2_cb_size;
   const uint16_t* s = samples + t.sample_offset;
   const PlaneRef dsts[3] = { d0, d1, d2 };
-  for (int comp = 0; comp < 3; comp++) {
+  const int ncomp = P.chroma_format ? 3 : 1;                 // (monochrome: luma samples only, slice.cc:4200)
+  for (int comp = 0; comp < ncomp; comp++) {
     const int w = comp ? n >> P.csw : n, h = comp ? n >> P.csh : n;
     const int x0 = comp ? t.x0 >> P.csw : t.x0, y0 = comp ? t.y0 >> P.csh : t.y0;
     PX* dst = (PX*)dsts[comp].ptr;

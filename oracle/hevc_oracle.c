@@ -89,6 +89,7 @@ typedef struct octx {
   int* tile_id;                /* TileIdRS, pps.cc:646-660 */
   int sw, sh;                  /* SubWidthC, SubHeightC (sps.cc:540-552) */
   int cw, chh;                 /* chroma plane width / height */
+  int ncomp;                   /* 1: monochrome */
   int32_t* residual_luma;      /* thread_context::residual_luma (decctx.h): the last luma TU's residual, read by cross_comp_pred */
 } octx;
 
@@ -118,12 +119,15 @@ static int octx_init(octx* c, const de265hip_picture_desc* d, oracle_image* img,
 {
   const de265hip_pic_params* P = &d->params;
   memset(c, 0, sizeof(*c));
-  if (P->chroma_format_idc < 1 || P->chroma_format_idc > 3 || P->extended_precision_processing_flag) return DE265HIP_ERROR_NOT_IMPLEMENTED;
+  /* monochrome: intra pictures only (the reference's inter path reads chroma planes a monochrome picture does not have, motion.cc:302-305) */
+  if (P->chroma_format_idc < 0 || P->chroma_format_idc > 3 || P->extended_precision_processing_flag) return DE265HIP_ERROR_NOT_IMPLEMENTED;
+  if (P->chroma_format_idc == 0 && d->n_pus > 0) return DE265HIP_ERROR_NOT_IMPLEMENTED;
   if (P->num_tile_columns < 1 || P->num_tile_rows < 1 ||
       P->num_tile_columns > 20 || P->num_tile_rows > 22) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   c->d = d; c->img = img; c->dpb = dpb;
-  c->sw = P->chroma_format_idc == 3 ? 1 : 2; c->sh = P->chroma_format_idc == 1 ? 2 : 1;
-  c->cw = P->width / c->sw; c->chh = P->height / c->sh;
+  c->sw = (P->chroma_format_idc == 3 || P->chroma_format_idc == 0) ? 1 : 2; c->sh = P->chroma_format_idc == 1 ? 2 : 1;   /* SubWidthC, SubHeightC (sps.cc:540-552) */
+  c->ncomp = P->chroma_format_idc == 0 ? 1 : 3;
+  c->cw = c->ncomp == 1 ? 0 : P->width / c->sw; c->chh = c->ncomp == 1 ? 0 : P->height / c->sh;
   c->residual_luma = (int32_t*)calloc(32 * 32, sizeof(int32_t));
   int ctb = 1 << P->log2_ctb_size;
   c->ctbs_w = (P->width + ctb - 1) >> P->log2_ctb_size;
@@ -371,7 +375,7 @@ static int hi_depth(const de265hip_pic_params* P) { return P->bit_depth_luma > 8
 
 static int check_params(const de265hip_pic_params* P)
 {
-  if (P->chroma_format_idc < 1 || P->chroma_format_idc > 3 || P->extended_precision_processing_flag) return DE265HIP_ERROR_NOT_IMPLEMENTED;
+  if (P->chroma_format_idc < 0 || P->chroma_format_idc > 3 || P->extended_precision_processing_flag) return DE265HIP_ERROR_NOT_IMPLEMENTED;
   if ((P->bit_depth_luma > 8) != (P->bit_depth_chroma > 8)) return DE265HIP_ERROR_NOT_IMPLEMENTED;
   if (P->bit_depth_luma < 8 || P->bit_depth_luma > 12 || P->bit_depth_chroma < 8 ||
       P->bit_depth_chroma > 12) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
@@ -395,8 +399,8 @@ static void do_deblock(const octx* c)
     for (int pass = 0; pass < 2; pass++) {
       int vertical = pass == 0;
       derive_bs(c, vertical, bs);
-      if (hi_depth(&c->d->params)) { deblock_luma_16(c, vertical, bs); deblock_chroma_16(c, vertical, bs); }
-      else { deblock_luma_8(c, vertical, bs); deblock_chroma_8(c, vertical, bs); }
+      if (hi_depth(&c->d->params)) { deblock_luma_16(c, vertical, bs); if (c->ncomp == 3) deblock_chroma_16(c, vertical, bs); }      /* deblock.cc:977, :1034 */
+      else { deblock_luma_8(c, vertical, bs); if (c->ncomp == 3) deblock_chroma_8(c, vertical, bs); }
     }
   free(bs);
 }

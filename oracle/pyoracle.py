@@ -98,6 +98,8 @@ def make_image(planes):
 def alloc_planes(width, height, bit_depth, fill=None, chroma_format=1):
     dt = np.uint16 if bit_depth > 8 else np.uint8
     cw, ch = width // (1 if chroma_format == 3 else 2), height // (2 if chroma_format == 1 else 1)
+    if chroma_format == 0:
+        cw, ch = 0, 0                                  # monochrome: empty chroma planes
     shapes = [(height, width), (ch, cw), (ch, cw)]
     if fill is None:
         return [np.zeros(s, dt) for s in shapes]

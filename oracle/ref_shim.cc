@@ -90,7 +90,7 @@ struct ref_picture {
   std::vector<de265_image*> refs;
   std::vector<slice_segment_header*> shdrs;
   thread_context* tctx;
-  int w, h, bytes, cw, ch;
+  int w, h, bytes, cw, ch, ncomp = 3;
 
   ref_picture() : dctx(NULL), sctx(NULL), img(NULL), tctx(NULL) {}
   ~ref_picture() {
@@ -140,6 +140,10 @@ static int build_headers(ref_picture& R, const de265hip_pic_params& P, const uin
   sps->range_extension.intra_smoothing_disabled_flag = P.intra_smoothing_disabled_flag;
   sps->range_extension.high_precision_offsets_enabled_flag = P.high_precision_offsets_enabled_flag;
   if (sps->compute_derived_values(true) != DE265_OK) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  // monochrome: sps.cc:40-41 tabulate SubWidthC/SubHeightC as -1 for chroma_format_idc 0 and image.cc:314-317
+  // asserts they equal 1, so an assert-enabled build of the reference (this one) aborts on such a stream while a
+  // release build goes on.  No luma path reads the two fields; give them the value alloc_image expects.
+  if (P.chroma_format_idc == 0) { sps->SubWidthC = 1; sps->SubHeightC = 1; }
 
   pps->set_defaults();
   pps->sps = sps;
@@ -296,9 +300,15 @@ static int setup(ref_picture& R, const de265hip_picture_desc* d, const oracle_im
                  const uint8_t* cb_log2_size, const uint8_t* cb_part_mode, const uint8_t* tu_split)
 {
   const de265hip_pic_params& P = d->params;
-  if (P.chroma_format_idc < 1 || P.chroma_format_idc > 3 || P.extended_precision_processing_flag) return DE265HIP_ERROR_NOT_IMPLEMENTED;
-  const enum de265_chroma chroma = P.chroma_format_idc == 1 ? de265_chroma_420 : (P.chroma_format_idc == 2 ? de265_chroma_422 : de265_chroma_444);
-  const int cw = P.width / (P.chroma_format_idc == 3 ? 1 : 2), ch = P.height / (P.chroma_format_idc == 1 ? 2 : 1);
+  if (P.chroma_format_idc < 0 || P.chroma_format_idc > 3 || P.extended_precision_processing_flag) return DE265HIP_ERROR_NOT_IMPLEMENTED;
+  // monochrome: the reference's motion compensation addresses the chroma planes whatever the format
+  // (motion.cc:296-305), so only pictures without prediction units have a defined result there
+  if (P.chroma_format_idc == 0 && d->n_pus) return DE265HIP_ERROR_NOT_IMPLEMENTED;
+  const enum de265_chroma chroma = P.chroma_format_idc == 0 ? de265_chroma_mono : P.chroma_format_idc == 1 ? de265_chroma_420 :
+                                   (P.chroma_format_idc == 2 ? de265_chroma_422 : de265_chroma_444);
+  const int cw = P.chroma_format_idc == 0 ? 0 : P.width / (P.chroma_format_idc == 3 ? 1 : 2);
+  const int ch = P.chroma_format_idc == 0 ? 0 : P.height / (P.chroma_format_idc == 1 ? 2 : 1);
+  R.ncomp = P.chroma_format_idc == 0 ? 1 : 3;
   int rc = build_headers(R, P, d->scaling_factors);
   if (rc) return rc;
   R.w = P.width; R.h = P.height; R.bytes = P.bit_depth_luma>8 ? 2 : 1;
@@ -312,7 +322,7 @@ static int setup(ref_picture& R, const de265hip_picture_desc* d, const oracle_im
   R.img->set_headers(R.vps,R.sps,R.pps);
   R.img->integrity = INTEGRITY_CORRECT;      // dpb.cc new_image(); any reference-side complaint lowers it
   if (cur)
-    for (int c=0;c<3;c++)
+    for (int c=0;c<R.ncomp;c++)
       copy_in(R.img,c,cur->plane[c],cur->stride[c], c?cw:P.width, c?ch:P.height, R.bytes);
   if (dpb)
     for (int s=0;s<DE265HIP_MAX_DPB_SLOTS;s++) {
@@ -321,7 +331,7 @@ static int setup(ref_picture& R, const de265hip_picture_desc* d, const oracle_im
       if (r->alloc_image(P.width,P.height,chroma,R.sps,false,R.dctx,NULL,0,NULL,false) != DE265_OK)
         { delete r; return DE265HIP_ERROR_OUT_OF_MEMORY; }
       r->PicState = UsedForShortTermReference;
-      for (int c=0;c<3;c++)
+      for (int c=0;c<R.ncomp;c++)
         copy_in(r,c,dpb[s].plane[c],dpb[s].stride[c], c?cw:P.width, c?ch:P.height, R.bytes);
       R.refs.push_back(r);
       R.sctx->slots[s] = r;
@@ -395,7 +405,7 @@ static void do_pcm(ref_picture& R, const de265hip_picture_desc* d, int i)
   const de265hip_pcm& p = d->pcms[i];
   const uint16_t* s = d->pcm_samples + p.sample_offset;
   const int sw = R.sps->SubWidthC, sh = R.sps->SubHeightC;
-  for (int c=0;c<3;c++) {
+  for (int c=0;c<R.ncomp;c++) {
     int nw = (1<<p.log2_cb_size) / (c?sw:1), nh = (1<<p.log2_cb_size) / (c?sh:1);
     int x0 = p.x0 / (c?sw:1), y0 = p.y0 / (c?sh:1);
     int stride = R.img->get_image_stride(c);
@@ -443,7 +453,7 @@ int ref_reconstruct(const de265hip_picture_desc* d, const uint32_t* order, int n
   // decctx.cc:1859-1883 run_postprocessing_filters_sequential
   if (last_stage >= DE265HIP_STAGE_DEBLOCKED && !d->params.disable_deblocking) apply_deblocking_filter(R.img);
   if (last_stage >= DE265HIP_STAGE_FINAL && !d->params.disable_sao) apply_sample_adaptive_offset_sequential(R.img);
-  for (int c=0;c<3;c++)
+  for (int c=0;c<R.ncomp;c++)
     copy_out(R.img,c,img->plane[c],img->stride[c], c?R.cw:R.w, c?R.ch:R.h, R.bytes);
   if (out_deblk) {
     int w4 = (R.w+3)/4, h4 = (R.h+3)/4;

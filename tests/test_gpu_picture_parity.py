@@ -105,13 +105,15 @@ def test_empty_picture_and_errors(dec):
     pic.free()
     d.n_tus = n_tus
     # unsupported / invalid parameters surface as de265_error codes, never as a fallback
-    # what is still refused of the range extensions: monochrome (the reference's inter path has no chroma planes to read) and
-    # extended_precision_processing (the reference hard-codes it off)
-    d.params.chroma_format_idc = 0
+    # what is still refused of the range extensions: monochrome pictures WITH prediction units (the reference's inter path has
+    # no chroma planes to read there: no defined result) and extended_precision_processing (the reference hard-codes it off)
+    spb = pysynth.SynthPicture(pysynth.default_config(w, h, bd, 0, seed=2))
+    assert spb.d.n_pus > 0
+    spb.d.params.chroma_format_idc = 0
     with pytest.raises(backend.De265HipError) as e:
-        dec.build(2, sp.desc)
+        dec.build(2, spb.desc)
     assert e.value.code == _abi.ERROR_NOT_IMPLEMENTED
-    d.params.chroma_format_idc = 1
+    spb.close()
     d.params.extended_precision_processing_flag = 1
     with pytest.raises(backend.De265HipError) as e:
         dec.build(2, sp.desc)
@@ -750,6 +752,48 @@ def test_coefficient_position_beyond_its_block_surfaces_as_decoding_error():
         d.run(good, 2); d.sync()
         assert all(np.array_equal(g, e_) for g, e_ in zip(d.download(2, w, h, bd), exp))
         good.free()
+    finally:
+        d.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_monochrome_intra_pictures_against_the_oracle(seed):
+    """chroma_format_idc 0: intra pictures (the kind the reference has a defined result for), every stage, every bit depth, with
+    tiles / slices / PCM / transform skip / bypass / scaling lists / implicit RDPCM / rotation drawn at random.  The two chroma
+    planes of such a picture are empty on both sides; a TU record with c_idx > 0 is out of range."""
+    rng = np.random.default_rng([seed, 0, 78])
+    w, h = [(208, 120), (352, 288), (416, 240), (832, 480)][seed % 4]
+    bd = [8, 10, 12, 9][seed % 4]
+    over = dict(monochrome=1, tskip_pct=int(rng.integers(0, 50)), bypass_pct=int(rng.integers(0, 20)), pcm_pct=int(rng.integers(0, 15)),
+                implicit_rdpcm=int(rng.integers(0, 2)), rotation=int(rng.integers(0, 2)), log2_max_tskip_size=int(rng.integers(2, 6)),
+                intra_smoothing_disabled=int(rng.integers(0, 2)), scaling_list=int(rng.integers(0, 3)), n_slices=int(rng.integers(1, 4)),
+                lf_across_slices_pct=50, log2_ctb_size=int(rng.choice([4, 5, 6])), big_coeff_pct=int(rng.choice([0, 3])),
+                constrained_intra_pred=int(rng.integers(0, 2)), pcm_loop_filter_disable=int(rng.integers(0, 2)),
+                tile_cols=int(rng.integers(1, 4)), tile_rows=int(rng.integers(1, 3)), lf_across_tiles=int(rng.integers(0, 2)))
+    if over["log2_ctb_size"] == 4:
+        over["log2_max_tb_size"] = 4
+    sp = pysynth.SynthPicture(pysynth.default_config(w, h, bd, 2, seed=5200 + seed, **over))
+    assert sp.d.params.chroma_format_idc == 0 and sp.d.n_pus == 0
+    d = backend.Decoder()
+    try:
+        d.dpb_alloc(2, w, h, bd, chroma_format=0)
+        pic = d.build(2, sp.desc)
+        for stage in (0, 1, 2):
+            init = pysynth.fill_planes(w, h, bd, 999, 0)
+            assert init[1].size == 0 and init[2].size == 0
+            exp = [p.copy() for p in init]
+            pyoracle.reconstruct(sp.desc, sp.order, {}, exp, last_stage=stage)
+            d.upload(2, init); d.run(pic, stage); d.sync()
+            got = d.download(2, w, h, bd)
+            assert got[1].shape == (0, 0) and got[2].shape == (0, 0)
+            bad = np.argwhere(got[0] != exp[0])
+            assert bad.size == 0, "seed %d stage %d: %d mismatches, first at %s (%s)" % (seed, stage, len(bad), tuple(bad[0]), over)
+        pic.free()
+        # a chroma TU in a monochrome picture is refused
+        sp.d.tus[0].c_idx = 1
+        with pytest.raises(backend.De265HipError) as e:
+            d.build(2, sp.desc)
+        assert e.value.code == _abi.ERROR_PARAMETER_OUT_OF_RANGE
     finally:
         d.close()
 

@@ -60,6 +60,36 @@ def test_generator_is_deterministic_and_covers_features():
     assert {4, 8, 12, 16, 32, 64} <= widths or {8, 16, 32, 64} <= widths
 
 
+def test_monochrome_intra_pictures_and_what_is_refused():
+    """chroma_format_idc 0: the generator emits luma records only, PCM blocks carry n*n samples, both checkers decode it into a
+    luma plane next to two EMPTY chroma planes, and a monochrome picture with prediction units is refused by both (the
+    reference's inter path addresses chroma planes whatever the format, motion.cc:296-305: no defined result)."""
+    w, h = 208, 120
+    sp = pysynth.SynthPicture(pysynth.default_config(w, h, 10, 2, seed=31, monochrome=1, pcm_pct=20, tskip_pct=20, n_slices=2))
+    d = sp.d
+    assert d.params.chroma_format_idc == 0 and d.n_pus == 0 and d.n_pcms > 0
+    assert all(d.tus[i].c_idx == 0 for i in range(d.n_tus))
+    assert d.n_pcm_samples == sum((1 << d.pcms[i].log2_cb_size) ** 2 for i in range(d.n_pcms))
+    out = pyoracle.alloc_planes(w, h, 10, chroma_format=0)
+    assert out[1].shape == (0, 0) and out[2].shape == (0, 0)
+    pre = [p.copy() for p in out]
+    pyoracle.reconstruct(sp.desc, sp.order, {}, pre, last_stage=_abi.STAGE_PREFILTER)
+    fin = [p.copy() for p in out]
+    pyoracle.reconstruct(sp.desc, sp.order, {}, fin)
+    assert not np.array_equal(pre[0], fin[0]) and fin[0].max() < 1024
+    # the product's host stage (no device needed) accepts it ...
+    assert backend.lib().de265hip_debug_build_host_only(sp.desc, 1) == 0
+    # ... and both refuse monochrome with prediction units
+    sp2 = pysynth.SynthPicture(pysynth.default_config(w, h, 8, 0, seed=32, monochrome=1))
+    assert sp2.d.n_pus > 0
+    with pytest.raises(RuntimeError):
+        pyoracle.reconstruct(sp2.desc, sp2.order, {}, pyoracle.alloc_planes(w, h, 8, chroma_format=0))
+    assert backend.lib().de265hip_debug_build_host_only(sp2.desc, 1) == _abi.ERROR_NOT_IMPLEMENTED
+    # a chroma TU record in a monochrome picture is out of range
+    d.tus[0].c_idx = 1
+    assert backend.lib().de265hip_debug_build_host_only(sp.desc, 1) == _abi.ERROR_PARAMETER_OUT_OF_RANGE
+
+
 def test_disable_flags_and_stages():
     sp, refs = make(416, 240, 8, 0, 5)
     pre = recon(sp, refs, _abi.STAGE_PREFILTER)

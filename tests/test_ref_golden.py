@@ -146,7 +146,7 @@ def dec():
 
 def _gpu_picture_digests(dec, case):
     sp, refs, init = ref_cases.make_picture(case)
-    w, h, bd, cf = case["w"], case["h"], case["bd"], case.get("chroma_format", 1)
+    w, h, bd, cf = case["w"], case["h"], case["bd"], 0 if case.get("monochrome") else case.get("chroma_format", 1)
     for s, pl in refs.items():
         dec.dpb_alloc(s, w, h, bd, chroma_format=cf)
         dec.upload(s, pl)

@@ -34,7 +34,7 @@ class SynthConfig(C.Structure):
         ("amp", C.c_int32), ("split_bias", C.c_int32),
         ("chroma_format", C.c_int32), ("cross_component_pct", C.c_int32), ("implicit_rdpcm", C.c_int32),
         ("explicit_rdpcm_pct", C.c_int32), ("rotation", C.c_int32), ("intra_smoothing_disabled", C.c_int32),
-        ("log2_max_tskip_size", C.c_int32), ("high_precision_offsets", C.c_int32),
+        ("log2_max_tskip_size", C.c_int32), ("high_precision_offsets", C.c_int32), ("monochrome", C.c_int32),
     ]
 
 
@@ -141,6 +141,8 @@ class SynthPicture:
 
 def chroma_dims(width, height, chroma_format=1):
     """(w, h) of a chroma plane: SubWidthC / SubHeightC of sps.cc:540-552"""
+    if chroma_format == 0:
+        return (0, 0)                                   # monochrome: no chroma planes
     return (width // (2 if chroma_format in (1, 2) else 1), height // (2 if chroma_format == 1 else 1))
 
 

@@ -99,6 +99,15 @@ PICTURE_CASES = [
          explicit_rdpcm_pct=50, rotation=1, log2_max_tskip_size=5, intra_smoothing_disabled=1, intra_pct=40, scaling_list=1),
     dict(name="1080p10_B_444_rext", w=1920, h=1080, bd=10, st=0, seed=3011, chroma_format=3, tskip_pct=20, bypass_pct=5,
          implicit_rdpcm=1, explicit_rdpcm_pct=30, rotation=1, log2_max_tskip_size=5, cross_component_pct=40),
+    # monochrome (chroma_format_idc 0), intra pictures: the only kind the reference has a defined result for
+    # (its inter path addresses chroma planes whatever the format, motion.cc:296-305)
+    dict(name="cif8_I_mono", w=352, h=288, bd=8, st=2, seed=3101, monochrome=1),
+    dict(name="cif10_I_mono_features", w=352, h=288, bd=10, st=2, seed=3102, monochrome=1, pcm_loop_filter_disable=1, scaling_list=1,
+         n_slices=3, lf_across_slices_pct=50, **_F),
+    dict(name="wvga12_I_mono_tiles_rext", w=832, h=480, bd=12, st=2, seed=3103, monochrome=1, tile_cols=3, tile_rows=2, slice_per_tile=1,
+         lf_across_tiles=0, lf_across_slices_pct=0, tskip_pct=40, bypass_pct=15, pcm_pct=5, implicit_rdpcm=1, rotation=1,
+         log2_max_tskip_size=5, intra_smoothing_disabled=1),
+    dict(name="1080p8_I_mono", w=1920, h=1080, bd=8, st=2, seed=3104, monochrome=1, constrained_intra_pred=1),
 ]
 # three cases whose final planes are stored in full (tests/golden/ref_small_pictures.npz)
 FULL_PICTURE_CASES = ["qcif8_I", "qcif10_B", "ctb16_12_B"]
@@ -117,7 +126,7 @@ def make_picture(c):
     over = {k: v for k, v in c.items() if k not in ("name", "w", "h", "bd", "st", "seed")}
     sp = pysynth.SynthPicture(pysynth.default_config(c["w"], c["h"], c["bd"], c["st"], seed=c["seed"], **over))
     s = c["seed"] & 0xFFFF
-    cf = c.get("chroma_format", 1)
+    cf = 0 if c.get("monochrome") else c.get("chroma_format", 1)
     refs = {0: pysynth.fill_planes(c["w"], c["h"], c["bd"], s + 1, cf), 1: pysynth.fill_planes(c["w"], c["h"], c["bd"], s + 2, cf)}
     init = pysynth.fill_planes(c["w"], c["h"], c["bd"], s + 3, cf)
     return sp, refs, init

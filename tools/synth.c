@@ -217,7 +217,9 @@ static void gen_ttree(synth_picture* s, int x0, int y0, int xBase, int yBase, in
   int n_before = s->tus.n;
   emit_tu(s, x0, y0, log2, 0, cbfY, lmode, 0);
   int luma_cbf = s->tus.n > n_before && (s->tus.p[s->tus.n - 1].flags & DE265HIP_TU_CBF) && s->tus.p[s->tus.n - 1].c_idx == 0;
-  if (s->cf == 3) {
+  if (s->cf == 0) {
+    /* monochrome: no chroma TUs */
+  } else if (s->cf == 3) {
     /* 4:4:4: chroma TUs of the luma TU's size, cross-component prediction when the luma TU has coefficients and the CU is
      * inter or its chroma mode is derived (intra_chroma_pred_mode 4), slice.cc:3672-3684 */
     int elig = g->cross_component_pct > 0 && luma_cbf && (!s->cur_intra || s->cu_chroma_derived[pidx]);
@@ -324,7 +326,7 @@ static void gen_cu(synth_picture* s, int x0, int y0, int log2Cb)
     pc.x0 = (uint16_t)x0; pc.y0 = (uint16_t)y0; pc.log2_cb_size = (uint8_t)log2Cb;
     pc.sample_offset = (uint32_t)s->pcm_samples.n;
     int pcm_bits = g->bit_depth - rnd_int(r, 0, 2);
-    int n = cb*cb + 2*(cb/s->sw)*(cb/s->sh);
+    int n = cb*cb + (s->cf ? 2*(cb/s->sw)*(cb/s->sh) : 0);
     for (int i = 0; i < n; i++)
       VPUSH(s->pcm_samples, (uint16_t)(rnd_int(r, 0, (1 << pcm_bits) - 1) << (g->bit_depth - pcm_bits)));
     VPUSH(s->order, ORD_PCM | (uint32_t)s->pcms.n);
@@ -426,11 +428,11 @@ synth_picture* synth_generate(const synth_config* cfg)
   de265hip_pic_params* P = &s->desc.params;
   P->width = g->width; P->height = g->height;
   P->bit_depth_luma = P->bit_depth_chroma = g->bit_depth;
-  s->cf = g->chroma_format ? g->chroma_format : 1;
+  s->cf = g->monochrome ? 0 : (g->chroma_format ? g->chroma_format : 1);
   /* 4:4:4 with scaling lists: no 32x32 TUs.  The reference indexes ScalingFactor_Size3[matrixID] with matrixID up to 5 for a
    * 32x32 chroma TU although the array holds two matrices (transform.cc:487-493, sps.h:57): undefined, nothing to be pinned to. */
   if (s->cf == 3 && g->scaling_list && s->cfg.log2_max_tb_size > 4) s->cfg.log2_max_tb_size = 4;
-  s->sw = s->cf == 3 ? 1 : 2; s->sh = s->cf == 1 ? 2 : 1;
+  s->sw = (s->cf == 3 || s->cf == 0) ? 1 : 2; s->sh = s->cf == 1 ? 2 : 1;
   P->chroma_format_idc = s->cf;
   P->implicit_rdpcm_enabled_flag = g->implicit_rdpcm;
   P->transform_skip_rotation_enabled_flag = g->rotation;

@@ -56,6 +56,7 @@ typedef struct synth_config {
   int32_t intra_smoothing_disabled;
   int32_t log2_max_tskip_size;  /* 0 -> 2; transform skip on TUs up to this size (tskip_pct applies) */
   int32_t high_precision_offsets;
+  int32_t monochrome;           /* chroma_format_idc 0 (intra pictures only: the reference's inter path has no defined behaviour without chroma planes) */
 } synth_config;
 
 typedef struct synth_picture synth_picture;
