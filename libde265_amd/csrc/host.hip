@@ -307,6 +307,10 @@ struct BuildScratch {
   std::vector<TuTask> l0_rext;                                                              // level-0 tasks of k_resid_rext
   std::vector<RunB> rb;
   std::vector<int32_t> dep_val, dep_next;
+  // Cr mirrors Cb (tu_scan): what the scan decided for a Cb TU, waiting for the Cr TU of the same place; Cb run -> its Cr run
+  struct CbScan { uint16_t x0, y0; uint8_t log2, mode, kind, foreign; int32_t run, level, llev, n_prod; uint64_t mask; int32_t prod[40]; };
+  CbScan cbq[4];
+  std::vector<int32_t> mirror;
   std::vector<uint64_t> avail_memo; int avail_memo_key = -1;                                   // availability masks by (chroma, size, position in the CTB)
   std::vector<int> level_hist;
   std::vector<TuTask> all_tasks; std::vector<int> all_levels;                              // DE265HIP_INTRA_MODE=levels only
@@ -319,6 +323,7 @@ struct BuildScratch {
   std::vector<PcmTask> pcms; std::vector<SaoCtb> saos;
 };
 static thread_local BuildScratch g_scratch;
+static thread_local bool g_no_cr_mirror = false;         // set while a build is repeated without the Cb -> Cr shortcut of its TU scan
 static const int8_t k_intra_angle[35] = { 0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26,
                                           -32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };
 static const int16_t k_inv_angle[15] = { -4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096 };
@@ -822,6 +827,15 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   SC.l0_rext.clear();
   const bool host_checks_positions = dec->dry || dec->intra_levels;
   int last_luma_tu = -1;                                   // most recent luma TU record (cross-component prediction reads its residual)
+  // Cr mirrors Cb: the Cr TU of an intra CU sits at its Cb TU's place with its size and mode, and - by induction over the
+  // decode order - among Cr neighbours that are the images of the Cb TU's neighbours: availability, needed units, levels and
+  // the run decision of the Cb TU hold for it (run ids through SC.mirror), and the Cr cell map is never consulted.  A
+  // descriptor that breaks the pattern (a Cr intra TU without its Cb twin right before it, or the other way round) makes the
+  // build start over without the shortcut.  DE265HIP_NO_CR_MIRROR=1: always the long way (the arenas are identical).
+  const bool cr_mirror = cf != 0 && !g_no_cr_mirror && getenv("DE265HIP_NO_CR_MIRROR") == nullptr;
+  int cbq_head = 0, cbq_n = 0;
+  bool mirror_broken = false;
+  SC.mirror.clear();
   int n_tasks = 0;
   int prod[40];
   for (int i = 0; i < d->n_tus; i++) {
@@ -879,6 +893,25 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       // (a 4:2:2 chroma TU covers a 2:1 luma area: the shortcut for the left / top neighbours is not taken there)
       const bool full_z = c != 0 && cf == 2;
       const int cx = xL >> lc, cy = yL >> lc, ctu = cx + cy * g.ctbs_w;
+      const int mw = map_w[c], corner = nT >> 1;
+      uint64_t mask = 0;
+      int lev = 0, llev = 0, n_prod = 0;
+      bool foreign = false;
+      int r = -1, kind = 2;                                 // kind: 0 extends the current run of its component, 1 joins run r, 2 starts a run
+      const Cell* cells = SC.cells[c].data();
+      bool mirrored = false;
+      if (cr_mirror && c != 1 && (c == 0 ? cbq_n != 0 : cbq_n == 0)) { mirror_broken = true; break; }      // a Cb TU left without its Cr TU / a Cr TU without its Cb TU
+      if (cr_mirror && c == 2) {
+        const BuildScratch::CbScan& q = SC.cbq[cbq_head];
+        if (q.x0 != tu.x0 || q.y0 != tu.y0 || q.log2 != tu.log2_size || q.mode != tu.intra_mode) { mirror_broken = true; break; }
+        mask = q.mask; lev = q.level - 1; llev = q.llev; foreign = q.foreign != 0; kind = q.kind; n_prod = q.n_prod;
+        for (int k2 = 0; k2 < n_prod; k2++) { prod[k2] = SC.mirror[q.prod[k2]]; if (prod[k2] < 0) mirror_broken = true; }
+        r = kind == 0 ? cur_run[2] : (kind == 1 ? SC.mirror[q.run] : -1);
+        if ((kind != 2 && r < 0) || mirror_broken) { mirror_broken = true; break; }
+        cbq_head = (cbq_head + 1) & 3; cbq_n--;
+        mirrored = true;
+      }
+      if (!mirrored) {
       const uint32_t own = ctb_group[ctu];
       const bool aL = xL > 0 && ctb_group[((xL - 1) >> lc) + cy * g.ctbs_w] == own;
       const bool aT = yL > 0 && ctb_group[cx + ((yL - 1) >> lc) * g.ctbs_w] == own;
@@ -887,8 +920,6 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       int nBottom = (p.height - yL + sbh - 1) >> (sbh - 1); if (nBottom > 2 * nT) nBottom = 2 * nT;      // (sbw, sbh are 1 or 2)
       int nRight = (p.width - xL + sbw - 1) >> (sbw - 1);   if (nRight > 2 * nT) nRight = 2 * nT;
       const int cur = zs[(xL >> lt) + (size_t)(yL >> lt) * g.tbs_w];
-      const int mw = map_w[c], corner = nT >> 1;
-      uint64_t mask = 0;
       auto intra_ok = [&](int xs, int ys) {                 // constrained_intra_pred: only samples of intra CUs (intrapred.cc:612-615)
         return !cip || (d->blk_flags[((xs * sbw) >> 2) + ((ys * sbh) >> 2) * g.w4] & DE265HIP_BLK_INTRA);
       };
@@ -918,13 +949,10 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
             if (z_ok(xB + x, yB - 1) && intra_ok(xB + x, yB - 1)) take(corner + 1 + (x >> 2), xB + x, yB - 1);
         if (memo) *memo = mask;
       }
-      t.avail = mask;
       // -- dependencies: only the units the mode reads (mode_deps), or every available unit
-      const Cell* cells = SC.cells[c].data();
       // (4:4:4 chroma is smoothed like luma: it takes luma's table, a superset of what it reads)
       uint64_t need = mode_deps ? needed_units(g_used_units[tu.log2_size - 2][m][c == 0 || cf == 3], mask) : mask;
-      int lev = 0, llev = 0, n_prod = 0;
-      bool foreign = false, reads_cur = false;
+      bool reads_cur = false;
       const int crun = cur_run[c];
       const uint64_t need0 = need;
       for (; need; need &= need - 1) {
@@ -939,10 +967,10 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
           if (!seen) prod[n_prod++] = cr;
         }
       }
-      level = lev + 1; llev += 1;
+      llev += 1;
       // -- which run: the current one of its component if the TU lies in the same CTB and reads from it (the run structure is
       // decided on the FULL neighbourhood, so that an all-intra CTB stays one run per component) ...
-      int r = crun;
+      r = crun;
       bool extends = r >= 0 && rb[r].ctu == ctu && rb[r].n_tus < 255;       /* RUN_MAX_TUS of k_run; positions + 1 fit a byte */
       if (extends && !reads_cur) {                          // (a needed unit of the current run settles it: the needed units are available ones)
         extends = false;
@@ -975,14 +1003,27 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
           if (lx + 1 <= 250) { r = x; llev = lx + 1; merged = true; }
         }
       }
-      if (!extends && !merged) {
+      kind = extends ? 0 : (merged ? 1 : 2);
+      }                                                     // (!mirrored)
+      t.avail = mask;
+      level = lev + 1;
+      if (kind == 2) {
         r = (int)rb.size();
         RunB nr; memset(&nr, 0, sizeof(nr));
         nr.c = c; nr.ctu = ctu; nr.x0 = tu.x0; nr.y0 = tu.y0; nr.x1 = tu.x0 + nT; nr.y1 = tu.y0 + nT; nr.est = 1;
         nr.head = nr.tail = -1; nr.dep_head = nr.dep_tail = -1;
         rb.push_back(nr);
+        SC.mirror.push_back(-1);
         cur_run[c] = r;
         llev = 1;
+        if (mirrored) SC.mirror[SC.cbq[(cbq_head + 3) & 3].run] = r;      // (the entry just taken)
+      }
+      if (cr_mirror && c == 1) {                            // remember what was decided, for the Cr TU of this place
+        if (cbq_n == 4) { mirror_broken = true; break; }
+        BuildScratch::CbScan& q = SC.cbq[(cbq_head + cbq_n) & 3]; cbq_n++;
+        q.x0 = tu.x0; q.y0 = tu.y0; q.log2 = tu.log2_size; q.mode = tu.intra_mode; q.kind = (uint8_t)kind; q.foreign = foreign;
+        q.run = r; q.level = level; q.llev = llev; q.n_prod = n_prod; q.mask = mask;
+        for (int k2 = 0; k2 < n_prod; k2++) q.prod[k2] = prod[k2];
       }
       RunB& R = rb[r];
       if (foreign) R.foreign = 1;
@@ -1010,7 +1051,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
         if (R.tail >= 0) SC.it[R.tail].resid_offset = (uint32_t)ti; else R.head = ti;
         R.tail = ti; R.n_tus++;
       }
-      {
+      if (!(cr_mirror && c == 2)) {                         // (nothing reads the Cr map while Cr mirrors Cb)
         Cell* wc = SC.cells[c].data();
         const Cell v{ E + r, (uint16_t)level, (uint16_t)llev };
         for (int y = tu.y0 >> 2; y < (tu.y0 + nT) >> 2; y++)
@@ -1033,6 +1074,13 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     SC.level_hist[level + 1]++;
     n_tasks++;
     if (dec->intra_levels) { SC.all_tasks.push_back(t); SC.all_levels.push_back(level); }
+  }
+  if (cr_mirror && (mirror_broken || cbq_n != 0)) {         // not the pattern the shortcut relies on: once more, the long way
+    delete pic;
+    g_no_cr_mirror = true;
+    const int rc2 = de265hip_picture_build(dec, dst_slot, d, out);
+    g_no_cr_mirror = false;
+    return rc2;
   }
   size_t ro_cur[4];
   {
@@ -1326,8 +1374,9 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       }
       fprintf(stderr, "de265hip chain: %lld barrier epochs in all runs; TUs per wavefront %lld %lld %lld %lld\n",
               (long long)dbg_foreign, (long long)dbg_w[0], (long long)dbg_w[1], (long long)dbg_w[2], (long long)dbg_w[3]);
-      fprintf(stderr, "de265hip crit: est %.0f us; on the longest path %d runs, %.0f in-run levels, %.0f TU slots, %.0f 16x16 and %.0f 32x32 TUs\n",
-              worst.t, worst.runs, worst.lv, worst.slots, worst.n16, worst.n32);
+      fprintf(stderr, "de265hip crit: est %.0f us; on the longest path %d runs, %.0f in-run levels, %.0f TU slots, %.0f 16x16 and %.0f 32x32 TUs; "
+              "longest TU-to-TU dependency chain of the picture: %d TUs\n",
+              worst.t, worst.runs, worst.lv, worst.slots, worst.n16, worst.n32, max_level);
     }
     // tickets per draw: 1 (DE265HIP_TICKET_BATCH for experiments: several per draw relieve the single device-scope
     // counter, ~12 ns per add, but serialise dependants: +46 % at 4 on a 4K B picture)

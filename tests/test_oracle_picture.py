@@ -90,6 +90,38 @@ def test_monochrome_intra_pictures_and_what_is_refused():
     assert backend.lib().de265hip_debug_build_host_only(sp.desc, 1) == _abi.ERROR_PARAMETER_OUT_OF_RANGE
 
 
+def test_host_stage_cr_shortcut_and_its_fallback(monkeypatch):
+    """The TU scan of de265hip_picture_build takes a Cr intra TU's availability / levels / run from its Cb twin; a descriptor
+    without that pattern (here: a Cr TU whose mode differs from its Cb TU's, and a Cb TU whose Cr TU is missing) is built the
+    long way.  Either way the uploaded arena is the one the long way builds (FNV hash of everything the device would get)."""
+    Lh = backend.lib()
+
+    def both(desc):
+        monkeypatch.delenv("DE265HIP_NO_CR_MIRROR", raising=False)
+        rc_a = Lh.de265hip_debug_build_host_only(desc, 1); a = Lh.de265hip_debug_last_build_hash()
+        monkeypatch.setenv("DE265HIP_NO_CR_MIRROR", "1")
+        rc_b = Lh.de265hip_debug_build_host_only(desc, 1); b = Lh.de265hip_debug_last_build_hash()
+        monkeypatch.delenv("DE265HIP_NO_CR_MIRROR")
+        return rc_a, a, rc_b, b
+
+    for st, cf in ((2, 1), (0, 1), (2, 2), (0, 3)):
+        sp = pysynth.SynthPicture(pysynth.default_config(416, 240, 8, st, seed=90 + st + cf, chroma_format=cf, tskip_pct=20, n_slices=2))
+        d = sp.d
+        rc_a, a, rc_b, b = both(sp.desc)
+        assert rc_a == 0 and rc_b == 0 and a == b
+        cr = [i for i in range(d.n_tus) if d.tus[i].c_idx == 2 and (d.tus[i].flags & _abi.TU_INTRA)]
+        assert cr
+        k = cr[len(cr) // 2]
+        d.tus[k].intra_mode = (d.tus[k].intra_mode + 7) % 35          # no longer its Cb twin's mode
+        rc_a, a2, rc_b, b2 = both(sp.desc)
+        assert rc_a == 0 and rc_b == 0 and a2 == b2 and a2 != a
+        d.tus[k].intra_mode = (d.tus[k].intra_mode - 7) % 35
+        d.tus[k].flags &= ~_abi.TU_INTRA & 0xFF                        # the Cb TU before it is left alone
+        rc_a, a3, rc_b, b3 = both(sp.desc)
+        assert rc_a == rc_b and a3 == b3
+        sp.close()
+
+
 def test_disable_flags_and_stages():
     sp, refs = make(416, 240, 8, 0, 5)
     pre = recon(sp, refs, _abi.STAGE_PREFILTER)
