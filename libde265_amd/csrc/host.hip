@@ -314,7 +314,11 @@ struct BuildScratch {
   std::vector<uint64_t> avail_memo; int avail_memo_key = -1;                                   // availability masks by (chroma, size, position in the CTB)
   std::vector<int> level_hist;
   std::vector<TuTask> all_tasks; std::vector<int> all_levels;                              // DE265HIP_INTRA_MODE=levels only
-  std::vector<TuTask> l0, l0_inter[4], run_tus;
+  std::vector<TuTask> l0, run_tus;
+  // level-0 tasks of the plain inter TUs by size: raw arrays with room for every TU record of the picture (no growth test per TU)
+  struct TaskBuf { TuTask* p = nullptr; size_t cap = 0, n = 0; ~TaskBuf() { free(p); }
+                   bool ensure(size_t c) { if (c <= cap) return true; free(p); p = (TuTask*)malloc(c * sizeof(TuTask)); cap = p ? c : 0; return p != nullptr; } };
+  TaskBuf l0_inter[4];
   std::vector<RunTask> runs; std::vector<uint32_t> run_deps, slots, mbx, mb_segs;
   std::vector<int> order, newidx, count2, width; std::vector<uint8_t> micro;
   struct QuadPend { McTask t[4]; int n = 0; };                                               // a slot pair's open quad (k_mc_all)
@@ -822,7 +826,11 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   // (the inter TUs of each size are collected as they come and copied to their place behind the scan, when the number of
   //  residual-only intra copies of each size is known: one pass over the TU records instead of two)
   int n_ro_size[4] = { 0, 0, 0, 0 };
-  for (auto& v : SC.l0_inter) v.clear();
+  for (auto& v : SC.l0_inter) { v.n = 0; if (!v.ensure((size_t)d->n_tus + 1)) { delete pic; return DE265HIP_ERROR_OUT_OF_MEMORY; } }
+  static_assert(sizeof(de265hip_tu) == 16 && offsetof(de265hip_tu, n_coeff) == offsetof(TuTask, n_coeff) && offsetof(de265hip_tu, coeff_offset) == offsetof(TuTask, coeff_offset) &&
+                offsetof(de265hip_tu, qp) == offsetof(TuTask, qp) && offsetof(de265hip_tu, res_scale_val) == offsetof(TuTask, run_level) && offsetof(de265hip_tu, flags) == offsetof(TuTask, flags),
+                "a TU record is the first half of its task");
+  int64_t n_plain = 0;                                     // level-0 tasks of plain inter TUs (added to the level histogram behind the loop)
   SC.it.reserve((size_t)d->n_tus);
   SC.l0_rext.clear();
   const bool host_checks_positions = dec->dry || dec->intra_levels;
@@ -843,8 +851,9 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     if (tu.log2_size < 2 || tu.log2_size > 5) { delete pic; return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE; }
     const int nT = 1 << tu.log2_size;
     const int cw = tu.c_idx ? cwid : p.width, ch = tu.c_idx ? chei : p.height;
-    if (tu.c_idx > 2 || (tu.x0 & 3) || (tu.y0 & 3) || tu.x0 + nT > cw || tu.y0 + nT > ch || tu.qp < 0 ||
-        ((tu.flags & DE265HIP_TU_CBF) && ((int64_t)tu.coeff_offset + tu.n_coeff > d->n_coeffs || tu.n_coeff > nT * nT))) {
+    // (one test of the OR of the conditions instead of a branch per condition)
+    if ((unsigned)(tu.c_idx > 2) | (unsigned)((tu.x0 | tu.y0) & 3) | (unsigned)(tu.x0 + nT > cw) | (unsigned)(tu.y0 + nT > ch) | (unsigned)(tu.qp < 0) |
+        (unsigned)((tu.flags & DE265HIP_TU_CBF) && (((int64_t)tu.coeff_offset + tu.n_coeff > d->n_coeffs) | (tu.n_coeff > nT * nT)))) {
       delete pic; return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
     }
     // (positions inside the TU's block: checked - and folded into the block - on the device, k_check_coeffs behind the upload;
@@ -858,6 +867,18 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       if (worst >= (unsigned)(nT * nT)) { delete pic; return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE; }
     }
     if (tu.c_idx == 0) last_luma_tu = i;
+    if (!(tu.flags & (DE265HIP_TU_INTRA | DE265HIP_TU_TSKIP | DE265HIP_TU_BYPASS | DE265HIP_TU_EXPLICIT_RDPCM)) && !tu.res_scale_val) {
+      // a plain inter TU (most TUs of a picture with inter PUs): its level-0 task is the record itself plus sixteen zero bytes
+      if (!(tu.flags & DE265HIP_TU_CBF)) continue;                                   // nothing to reconstruct
+      BuildScratch::TaskBuf& v = SC.l0_inter[tu.log2_size - 2];
+      TuTask& t = v.p[v.n++];
+      memcpy(&t, &tu, 16); memset((uint8_t*)&t + 16, 0, 16);
+      if (tu.n_coeff == 0) t.flags &= (uint8_t)~DE265HIP_TU_CBF;
+      else alg_resid += std::min<int64_t>(4 * (int64_t)tu.n_coeff, 2 * (int64_t)nT * nT) + 2 * (int64_t)px_bytes(tu.c_idx ? p.bit_depth_chroma : p.bit_depth_luma) * nT * nT;
+      n_plain++; n_tasks++;
+      if (dec->intra_levels) { SC.all_tasks.push_back(t); SC.all_levels.push_back(0); }
+      continue;
+    }
     const int rx = rx_bits(tu);
     if (!(tu.flags & (DE265HIP_TU_INTRA | DE265HIP_TU_CBF)) && !(rx & D265_RX_XCC)) continue;       // nothing to reconstruct
     // cross-component prediction: the luma TU of the same position and size comes right before the chroma TUs (4:4:4,
@@ -1066,7 +1087,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       rt.pad3 = (uint8_t)(rx | rx_luma); rt.angle = tu.res_scale_val; rt.avail = luma_info;
       SC.l0_rext.push_back(rt);
     } else
-      SC.l0_inter[tu.log2_size - 2].push_back(t);           // level 0: residual added into the (inter-predicted) picture
+      { BuildScratch::TaskBuf& v = SC.l0_inter[tu.log2_size - 2]; v.p[v.n++] = t; }      // level 0: residual added into the (inter-predicted) picture
     if (t.flags & DE265HIP_TU_CBF)
       alg_resid += std::min<int64_t>(4 * (int64_t)t.n_coeff, 2 * (int64_t)nT * nT) +
                    ((tu.flags & DE265HIP_TU_INTRA) ? 0 : 2 * (int64_t)bpp * nT * nT);
@@ -1082,12 +1103,13 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     g_no_cr_mirror = false;
     return rc2;
   }
+  SC.level_hist[1] += (int)n_plain;
   size_t ro_cur[4];
   {
     size_t at = 0, inter_at[4];
-    for (int k = 3; k >= 0; k--) { inter_at[k] = at; at += SC.l0_inter[k].size(); ro_cur[k] = at; at += n_ro_size[k]; pic->n_l0_size[k] = (int)SC.l0_inter[k].size() + n_ro_size[k]; }
+    for (int k = 3; k >= 0; k--) { inter_at[k] = at; at += SC.l0_inter[k].n; ro_cur[k] = at; at += n_ro_size[k]; pic->n_l0_size[k] = (int)SC.l0_inter[k].n + n_ro_size[k]; }
     SC.l0.resize(at);
-    for (int k = 0; k < 4; k++) if (!SC.l0_inter[k].empty()) memcpy(SC.l0.data() + inter_at[k], SC.l0_inter[k].data(), SC.l0_inter[k].size() * sizeof(TuTask));
+    for (int k = 0; k < 4; k++) if (SC.l0_inter[k].n) memcpy(SC.l0.data() + inter_at[k], SC.l0_inter[k].p, SC.l0_inter[k].n * sizeof(TuTask));
   }
   TuTask* l0p = SC.l0.data();
   pt.mark("tu_scan");
