@@ -106,6 +106,25 @@ class _stdout_to_stderr:
         os.close(self._saved)
 
 
+def host_cores():
+    """CPUs this process may keep busy: its affinity mask, capped by the CPU bandwidth quota of its cgroup (a container with
+    256 visible CPUs and cpu.max = "1600000 100000" has 16: threads beyond the quota are throttled, all of them at once)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]           # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:                                                                        # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def product_pass(pipes, gops, stagger, steps=1):
     """`steps` steps through the product path: every picture of every stream is SUBMITTED to its decoder's pipeline
     (de265hip_pipeline_submit_desc: the library's own worker threads build it - host stage + pinned asynchronous upload -,
@@ -139,7 +158,7 @@ def cpu_baseline(gops, decs, W, H, BD, GOP, full=True):
     import pyoracle
     import pyref
     kind = "reference" if pyref.available() else "port"
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
 
     def decode_gop(g):
         planes = {}
@@ -355,7 +374,7 @@ def main():
 
     # ---- (2) the product path, THE TIMED REGION of this bench: every picture built, launched and freed through the C ABI
     elapsed, ktimes, product = replay_elapsed, ktimes_replay, None
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     if not args.no_host_inclusive:
         nthr = args.host_threads if args.host_threads > 0 else max(1, min(16, cores // max(1, world)))
         per = max(1, min(16, nthr // S))                 # worker threads of each decoder's pipeline
