@@ -207,6 +207,9 @@ def main():
     ap.add_argument("--gop", type=int, default=16)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DE265HIP_BENCH_STREAMS", "3")),
                     help="independent closed GOPs decoded concurrently per GPU (one decoder/HIP stream each)")
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("DE265HIP_BENCH_LANES", "1")),
+                    help="picture-level concurrency inside each decoder (de265hip_decoder_set_lanes): independent pictures of ONE "
+                         "stream on up to 4 HIP streams (the closed GOPs of a stream overlap at their boundaries)")
     ap.add_argument("--no-stagger", dest="stagger", action="store_false",
                     help="start all GOP streams at their I picture in lockstep instead of phase-shifted")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -310,6 +313,8 @@ def main():
     for s_i in range(S):
         g = make_gop(pysynth, farm, W, H, BD, GOP, farm.gop_seed(CONFIG_ID, rank, s_i))
         d = backend.Decoder(device=local_rank)
+        if args.lanes > 1:
+            d.set_lanes(args.lanes)
         for k in range(GOP):
             d.dpb_alloc(k, W, H, BD)
         gops.append(g); decs.append(d)
@@ -523,7 +528,7 @@ def main():
                                    "%d independent GOP(s) in flight per GPU, all stages on device"
                                    % (W, H, BD, GOP, GOP - 1, S),
                        "timed_region": region,
-                       "gop": GOP, "streams_per_gpu": S, "pictures_per_step": GOP * S,
+                       "gop": GOP, "streams_per_gpu": S, "lanes_per_decoder": args.lanes, "pictures_per_step": GOP * S,
                        "host_threads": product["host_threads"] if product else 0, "host_cores_available": cores,
                        "events_in_timed_region": "every kernel" if args.events == "all" else "dominant kernel (%s) only" % dom,
                        "parallelism": "%d gop stream(s) x %d gpu(s)" % (S, world)},

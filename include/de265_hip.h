@@ -259,6 +259,14 @@ int  de265hip_device_count(void);
  * decoder_sync() of one decoder belong to one thread at a time. */
 int  de265hip_decoder_new(de265hip_decoder** out, int device);
 void de265hip_decoder_free(de265hip_decoder*);
+/* Lanes: picture-level concurrency inside one decoder (the reference has none: decctx.cc:904-910 "TODO ... frame-parallel
+ * decoding").  With n_lanes > 1 (at most 4) pictures that do not depend on each other - hierarchical-B pictures of one
+ * layer, the first pictures of the next closed GOP - are enqueued on different HIP streams; the calls stay the same
+ * and stay in decode order (de265hip_picture_run / the pipeline), the device work is ordered by what the pictures' DPB
+ * slots say: a picture waits for the pictures it references, and for every picture that still reads or writes the slot
+ * it is decoded into.  Default 1 (DE265HIP_LANES overrides it when the decoder is created); each extra lane holds one more
+ * spare picture in device memory.  Call it between pictures (it synchronises the decoder). */
+int  de265hip_decoder_set_lanes(de265hip_decoder*, int n_lanes);
 /* Allocate (or re-use) DPB slot `slot` for a picture of this geometry. */
 int  de265hip_dpb_alloc(de265hip_decoder*, int slot, int width, int height,
                         int bit_depth_luma, int bit_depth_chroma);

@@ -17,7 +17,7 @@ SO_PATH = os.environ.get("DE265HIP_SO") or os.path.join(_HERE, "libde265_hip.so"
 # every symbol include/de265_hip.h declares (tests/test_abi.py checks the .so exports them all)
 EXPORTS = [
     "de265hip_version", "de265hip_device_count",
-    "de265hip_decoder_new", "de265hip_decoder_free",
+    "de265hip_decoder_new", "de265hip_decoder_free", "de265hip_decoder_set_lanes",
     "de265hip_dpb_alloc", "de265hip_dpb_alloc_ex", "de265hip_dpb_chroma_format", "de265hip_dpb_upload", "de265hip_dpb_download", "de265hip_dpb_plane", "de265hip_dpb_info",
     "de265hip_dpb_copy", "de265hip_dpb_download_async", "de265hip_dpb_wait", "de265hip_host_alloc", "de265hip_host_free",
     "de265hip_pipeline_new", "de265hip_pipeline_submit", "de265hip_pipeline_submit_desc", "de265hip_pipeline_wait", "de265hip_pipeline_drain", "de265hip_pipeline_free",
@@ -88,6 +88,7 @@ def lib():
     L.de265hip_picture_build.argtypes = [vp, i32, pp(_abi.PictureDesc), pp(vp)]
     L.de265hip_picture_run.argtypes = [vp, vp, i32]
     L.de265hip_decoder_sync.argtypes = [vp]
+    L.de265hip_decoder_set_lanes.argtypes = [vp, i32]
     L.de265hip_picture_free.argtypes = [vp]
     L.de265hip_picture_free.restype = None
     L.de265hip_decode_picture.argtypes = [vp, i32, pp(_abi.PictureDesc)]
@@ -340,6 +341,10 @@ class Decoder:
 
     def run(self, pic, last_stage=_abi.STAGE_FINAL):
         _chk(lib().de265hip_picture_run(self._h, pic._h, last_stage), "picture_run")
+
+    def set_lanes(self, n_lanes):
+        """Picture-level concurrency inside this decoder: independent pictures on up to 4 HIP streams (de265_hip.h)."""
+        _chk(lib().de265hip_decoder_set_lanes(self._h, n_lanes), "decoder_set_lanes")
 
     def sync(self):
         _chk(lib().de265hip_decoder_sync(self._h), "decoder_sync")

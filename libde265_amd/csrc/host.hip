@@ -40,7 +40,18 @@ struct Slot {
   // slot next (a new picture, an upload) or frees it waits for it.  dl_seq counts the copy-outs (dpb_wait compares it).
   hipEvent_t dl_done = nullptr;
   uint64_t dl_seq = 0, dl_waited = 0;
+  // Lanes (de265hip_decoder_set_lanes > 1): who wrote the slot's picture and who reads it, as events on the lanes' streams.
+  // written: recorded behind the picture that was decoded into the slot (writer_lane >= 0) or behind a copy into it from
+  // another decoder (kForeignWriter: every lane waits for it); read_done[l]: behind the latest picture of lane l that
+  // references the slot's present content.  A writer waits for all of them, a reader for `written`.
+  hipEvent_t written = nullptr;
+  int writer_lane = -1;                            // -1: nobody the device has to wait for (empty, or written by a synchronous upload)
+  uint64_t written_seq = 0;                        // launch number of the writing picture (lane choice)
+  hipEvent_t read_done[4] = { nullptr, nullptr, nullptr, nullptr };
+  bool rd_valid[4] = { false, false, false, false };
 };
+constexpr int kMaxLanes = 4;
+constexpr int kForeignWriter = -2;
 
 struct PendingEvent { int kid; hipEvent_t a, b; };
 
@@ -67,7 +78,18 @@ struct de265hip_decoder {
   std::vector<StageBuf> stage_pool;
   size_t pooled_bytes = 0;
   Slot slots[DE265HIP_MAX_DPB_SLOTS];
-  Slot spare;                         // SAO output target, swapped with the decoded slot
+  Slot spare;                         // SAO output target, swapped with the decoded slot (lane 0's)
+  // Lanes: pictures of ONE decoder that do not depend on each other run on different HIP streams (hierarchical-B pictures of
+  // one layer, the next closed GOP's first pictures); the reference decodes its pictures strictly one after the other
+  // (decctx.cc:904-910).  Lane 0 is `stream` / `spare`; lanes 1.. have a stream and a spare picture of their own.
+  // Launch order stays decode order; what orders the device work are the slots' events (Slot::written / read_done).
+  int n_lanes = 1;
+  hipStream_t lane_stream[kMaxLanes] = { nullptr, nullptr, nullptr, nullptr };
+  Slot lane_spare[kMaxLanes];         // [0] unused (lane 0's is `spare`)
+  hipEvent_t lane_fence[kMaxLanes] = { nullptr, nullptr, nullptr, nullptr };   // scratch events ("everything lane l has queued so far")
+  uint64_t lane_tail_seq[kMaxLanes] = { 0, 0, 0, 0 };   // launch number of the lane's latest picture
+  uint64_t launch_seq = 0;
+  hipStream_t cur_stream = nullptr;   // the stream of the picture being launched (KTimer)
   uint32_t* d_err = nullptr;          // set by a kernel whose bounded spin expired
   int run_waves = RUN_WAVES;          // DE265HIP_RUN_WAVES: wavefronts per run workgroup (experiments)
   bool resid_one_launch = true;       // DE265HIP_RESID_ONE_LAUNCH=0: 8x8 / 4x4 residual TUs in their own launch (k_resid_small)
@@ -100,8 +122,9 @@ struct de265hip_picture {
   void* arena = nullptr;              // one (pooled) device allocation for all command buffers
   size_t arena_bytes = 0;
   ArenaBuf arena_buf;                 // the pool entry behind `arena`
-  hipEvent_t uploaded = nullptr;      // recorded on the copy stream behind the upload; the first run waits for it on the decoder's stream
-  bool upload_waited = false;
+  hipEvent_t uploaded = nullptr;      // recorded on the copy stream behind the upload; the first run on a lane waits for it on that lane's stream
+  uint32_t upload_waited = 0;         // bit l: lane l has waited
+  int lane = 0;                       // the lane of its latest launch (its arena's last use is recorded there)
   // device pointers into the arena
   TuTask* d_tus = nullptr;
   int16_t* d_cval = nullptr; uint16_t* d_cpos = nullptr;
@@ -143,6 +166,10 @@ int free_slot(Slot& s)
 {
   if (s.dl_done) { (void)hipEventSynchronize(s.dl_done); (void)hipEventDestroy(s.dl_done); s.dl_done = nullptr; }
   s.dl_seq = s.dl_waited = 0;
+  // (hipFree below waits for the device: nobody is left to wait for)
+  if (s.written) { (void)hipEventDestroy(s.written); s.written = nullptr; }
+  for (int l = 0; l < kMaxLanes; l++) { if (s.read_done[l]) { (void)hipEventDestroy(s.read_done[l]); s.read_done[l] = nullptr; } s.rd_valid[l] = false; }
+  s.writer_lane = -1; s.written_seq = 0;
   if (s.pl[0].ptr) (void)hipFree(s.pl[0].ptr);            // (one allocation: the chroma planes follow the luma plane)
   for (int c = 0; c < 3; c++) s.pl[c].ptr = nullptr;
   s.valid = false;
@@ -169,6 +196,36 @@ int alloc_slot(Slot& s, int w, int h, int bdY, int bdC, int cf = 1)
   for (int c = 0; c < 3; c++) s.pl[c].ptr = (char*)base + off[c];
   s.w = w; s.h = h; s.bdY = bdY; s.bdC = bdC; s.cf = cf; s.valid = true;
   return 0;
+}
+
+// ---- lanes
+hipStream_t lane_st(de265hip_decoder* d, int l) { return l == 0 ? d->stream : d->lane_stream[l]; }
+Slot& lane_sp(de265hip_decoder* d, int l) { return l == 0 ? d->spare : d->lane_spare[l]; }
+
+hipError_t sync_all_lanes(de265hip_decoder* d)
+{
+  hipError_t rc = hipSuccess;
+  for (int l = 0; l < d->n_lanes; l++) { const hipError_t e = hipStreamSynchronize(lane_st(d, l)); if (e != hipSuccess) rc = e; }
+  return rc;
+}
+
+// `st` continues behind everything the decoder's lanes have queued so far (st may be a lane of this decoder or any other stream)
+bool wait_for_all_lanes(de265hip_decoder* d, hipStream_t st)
+{
+  for (int l = 0; l < d->n_lanes; l++) {
+    hipStream_t ls = lane_st(d, l);
+    if (ls == st) continue;
+    if (!d->lane_fence[l] && hipEventCreateWithFlags(&d->lane_fence[l], hipEventDisableTiming) != hipSuccess) return false;
+    if (hipEventRecord(d->lane_fence[l], ls) != hipSuccess || hipStreamWaitEvent(st, d->lane_fence[l], 0) != hipSuccess) return false;
+  }
+  return true;
+}
+
+// the host (a synchronous upload) or a full synchronisation has made the slot's content final: nobody is left to wait for
+void slot_settled(Slot& s)
+{
+  s.writer_lane = -1;
+  for (int l = 0; l < kMaxLanes; l++) s.rd_valid[l] = false;
 }
 
 struct Geometry {
@@ -364,10 +421,10 @@ void destroy_arena(ArenaBuf& a)
 }
 
 // hand an arena back: reusable once everything enqueued on the decoder's stream so far has run
-void release_arena(de265hip_decoder* dec, ArenaBuf a)
+void release_arena(de265hip_decoder* dec, ArenaBuf a, hipStream_t last_stream = nullptr)
 {
   if (!a.ptr) return;
-  if (hipEventRecord(a.last_use, dec->stream) != hipSuccess || dec->pooled_bytes + a.bytes > kPoolLimitBytes) { destroy_arena(a); return; }
+  if (hipEventRecord(a.last_use, last_stream ? last_stream : dec->stream) != hipSuccess || dec->pooled_bytes + a.bytes > kPoolLimitBytes) { destroy_arena(a); return; }
   a.used = true;
   dec->pooled_bytes += a.bytes;
   dec->free_arenas.push_back(a);
@@ -458,7 +515,23 @@ int de265hip_decoder_new(de265hip_decoder** out, int device)
   if (const char* e = getenv("DE265HIP_RESID_ONE_LAUNCH")) d->resid_one_launch = atoi(e) != 0;
   if (const char* e = getenv("DE265HIP_TEST_SPIN_LIMIT")) d->spin_limit = (uint32_t)std::max(1, atoi(e));
   if (const char* rw = getenv("DE265HIP_RUN_WAVES")) d->run_waves = std::min(RUN_WAVES, std::max(1, atoi(rw)));
+  if (const char* e = getenv("DE265HIP_LANES")) {
+    const int rc = de265hip_decoder_set_lanes(d, atoi(e));
+    if (rc) { de265hip_decoder_free(d); return rc; }
+  }
   *out = d;
+  return DE265HIP_OK;
+}
+
+int de265hip_decoder_set_lanes(de265hip_decoder* d, int n_lanes)
+{
+  if (!d || n_lanes < 1 || n_lanes > kMaxLanes) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  std::lock_guard<std::mutex> lk(d->mu);
+  HIPCHK(sync_all_lanes(d), DE265HIP_ERROR_DECODING);                 // (a change takes effect between pictures)
+  for (auto& s : d->slots) slot_settled(s);
+  for (int l = 1; l < n_lanes; l++)
+    if (!d->lane_stream[l]) HIPCHK(hipStreamCreateWithFlags(&d->lane_stream[l], hipStreamNonBlocking), DE265HIP_ERROR_INIT_FAILED);
+  d->n_lanes = n_lanes;
   return DE265HIP_OK;
 }
 
@@ -469,7 +542,7 @@ void de265hip_decoder_free(de265hip_decoder* d)
 {
   if (!d) return;
   (void)hipStreamSynchronize(d->copy_stream);
-  (void)hipStreamSynchronize(d->stream);
+  (void)sync_all_lanes(d);
   if (d->out_stream) { (void)hipStreamSynchronize(d->out_stream); (void)hipStreamDestroy(d->out_stream); }
   if (d->out_fence) (void)hipEventDestroy(d->out_fence);
   {
@@ -489,6 +562,8 @@ void de265hip_decoder_free(de265hip_decoder* d)
   for (auto& e : d->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& s : d->slots) free_slot(s);
   free_slot(d->spare);
+  for (int l = 1; l < kMaxLanes; l++) { free_slot(d->lane_spare[l]); if (d->lane_stream[l]) (void)hipStreamDestroy(d->lane_stream[l]); }
+  for (int l = 0; l < kMaxLanes; l++) if (d->lane_fence[l]) (void)hipEventDestroy(d->lane_fence[l]);
   if (d->d_err) (void)hipFree(d->d_err);
   (void)hipStreamDestroy(d->copy_stream);
   (void)hipStreamDestroy(d->stream);
@@ -525,7 +600,8 @@ int de265hip_dpb_upload(de265hip_decoder* d, int slot, int c, const void* src, p
   int rc = plane_geom(d, slot, c, &s, &w, &h, &bpp); if (rc) return rc;
   if (w == 0 || h == 0) return DE265HIP_OK;               // (a chroma plane of a monochrome picture)
   if (s->dl_done && s->dl_waited != s->dl_seq) HIPCHK(hipEventSynchronize(s->dl_done), DE265HIP_ERROR_DECODING);
-  HIPCHK(hipStreamSynchronize(d->stream), DE265HIP_ERROR_DECODING);
+  HIPCHK(sync_all_lanes(d), DE265HIP_ERROR_DECODING);
+  slot_settled(*s);
   HIPCHK(hipMemcpy2D(s->pl[c].ptr, s->pl[c].stride * bpp, src, (size_t)stride_bytes, w * bpp, h, hipMemcpyHostToDevice),
          DE265HIP_ERROR_DECODING);
   return 0;
@@ -535,7 +611,7 @@ int de265hip_dpb_download(de265hip_decoder* d, int slot, int c, void* dst, ptrdi
 {
   Slot* s; int w, h; size_t bpp;
   int rc = plane_geom(d, slot, c, &s, &w, &h, &bpp); if (rc) return rc;
-  HIPCHK(hipStreamSynchronize(d->stream), DE265HIP_ERROR_DECODING);
+  HIPCHK(sync_all_lanes(d), DE265HIP_ERROR_DECODING);
   if (w == 0 || h == 0) return DE265HIP_OK;
   HIPCHK(hipMemcpy2D(dst, (size_t)stride_bytes, s->pl[c].ptr, s->pl[c].stride * bpp, w * bpp, h, hipMemcpyDeviceToHost),
          DE265HIP_ERROR_DECODING);
@@ -565,8 +641,12 @@ int de265hip_dpb_download_async(de265hip_decoder* d, int slot, int c, void* dst,
   }
   if (!s->dl_done) HIPCHK(hipEventCreateWithFlags(&s->dl_done, hipEventDisableTiming), DE265HIP_ERROR_DECODING);
   // behind everything enqueued on the decoder's stream so far (the picture's kernels), but not in FRONT of what comes next
-  HIPCHK(hipEventRecord(d->out_fence, d->stream), DE265HIP_ERROR_DECODING);
-  HIPCHK(hipStreamWaitEvent(d->out_stream, d->out_fence, 0), DE265HIP_ERROR_DECODING);
+  if (d->n_lanes > 1) {                                   // (lanes: behind the picture that was decoded into the slot)
+    if (s->writer_lane != -1 && s->written) HIPCHK(hipStreamWaitEvent(d->out_stream, s->written, 0), DE265HIP_ERROR_DECODING);
+  } else {
+    HIPCHK(hipEventRecord(d->out_fence, d->stream), DE265HIP_ERROR_DECODING);
+    HIPCHK(hipStreamWaitEvent(d->out_stream, d->out_fence, 0), DE265HIP_ERROR_DECODING);
+  }
   // rows that are contiguous on both sides leave as ONE linear DMA: enqueueing a pitched copy costs the host about 2 us per row
   // (4.3 ms for the three planes of a 4K picture, tools/exp/e2e_profile.sh), more than the whole host stage can afford
   if ((size_t)stride_bytes == w * bpp && s->pl[c].stride * bpp == w * bpp)
@@ -639,8 +719,14 @@ int de265hip_dpb_copy(de265hip_decoder* sd, int ss, de265hip_decoder* dd, int ds
   // The copy runs on the SOURCE decoder's stream.  It must also come behind what the destination decoder has already
   // enqueued - pictures that still read the slot's old content as a reference, or write it - and behind a copy-out of
   // that old content (de265hip_dpb_download_async): overwriting a live reference slot is what an open-GOP hand-over does.
+  // (lanes: behind everything EVERY lane of either decoder has queued - the copy is a synchronisation point of both)
   if (sd != dd) {
-    if (hipEventRecord(ev, dd->stream) != hipSuccess || hipStreamWaitEvent(sd->stream, ev, 0) != hipSuccess) rc = DE265HIP_ERROR_DECODING;
+    std::lock_guard<std::mutex> lk(dd->mu);
+    if (!wait_for_all_lanes(dd, sd->stream)) rc = DE265HIP_ERROR_DECODING;
+  }
+  if (sd->n_lanes > 1) {
+    std::lock_guard<std::mutex> lk(sd->mu);
+    if (!wait_for_all_lanes(sd, sd->stream)) rc = DE265HIP_ERROR_DECODING;
   }
   {
     std::lock_guard<std::mutex> lk(dd->mu);
@@ -658,6 +744,20 @@ int de265hip_dpb_copy(de265hip_decoder* sd, int ss, de265hip_decoder* dd, int ds
   if (!rc && (hipEventRecord(ev, sd->stream) != hipSuccess || hipStreamWaitEvent(dd->stream, ev, 0) != hipSuccess))
     rc = DE265HIP_ERROR_DECODING;
   (void)hipEventDestroy(ev);            // (released once it has completed)
+  if (!rc && dd->n_lanes > 1) {         // the destination's other lanes learn of the copy through the slot's `written` event
+    std::lock_guard<std::mutex> lk(dd->mu);
+    if (!D.written && hipEventCreateWithFlags(&D.written, hipEventDisableTiming) != hipSuccess) rc = DE265HIP_ERROR_OUT_OF_MEMORY;
+    if (!rc && hipEventRecord(D.written, sd->stream) != hipSuccess) rc = DE265HIP_ERROR_DECODING;
+    D.writer_lane = kForeignWriter; D.written_seq = ++dd->launch_seq;
+    for (int l = 0; l < kMaxLanes; l++) D.rd_valid[l] = false;
+  }
+  if (!rc && sd->n_lanes > 1) {         // and the source's lanes that the copy (on its lane 0) reads the slot
+    std::lock_guard<std::mutex> lk(sd->mu);
+    Slot& S2 = sd->slots[ss];
+    if (!S2.read_done[0] && hipEventCreateWithFlags(&S2.read_done[0], hipEventDisableTiming) != hipSuccess) rc = DE265HIP_ERROR_OUT_OF_MEMORY;
+    if (!rc && hipEventRecord(S2.read_done[0], sd->stream) != hipSuccess) rc = DE265HIP_ERROR_DECODING;
+    if (!rc) S2.rd_valid[0] = true;
+  }
   return rc;
 }
 
@@ -669,7 +769,7 @@ void de265hip_picture_free(de265hip_picture* p)
     dec->live.erase(std::remove(dec->live.begin(), dec->live.end(), p), dec->live.end());
     // no synchronisation: the arena goes back to the pool behind an event on the decoder's stream, and its next
     // upload waits for that event on the copy stream
-    release_arena(dec, p->arena_buf);
+    release_arena(dec, p->arena_buf, lane_st(dec, p->lane));     // (its launches on other lanes precede the latest one: they wrote the same slot)
     if (p->uploaded) (void)hipEventDestroy(p->uploaded);
   }
   delete p;
@@ -1836,9 +1936,9 @@ struct KTimer {
   KTimer(de265hip_decoder* dec, int k, int n_launches) : d(dec), kid(k), on((dec->profiling >> k) & 1u)
   {
     d->launches[kid] += n_launches;
-    if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, d->stream); }
+    if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, d->cur_stream); }
   }
-  ~KTimer() { if (on) { (void)hipEventRecord(b, d->stream); d->pending.push_back({ kid, a, b }); } }
+  ~KTimer() { if (on) { (void)hipEventRecord(b, d->cur_stream); d->pending.push_back({ kid, a, b }); } }
 };
 
 template <typename PX>
@@ -1848,13 +1948,25 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
   // are swapped with the spare's below: all under the decoder's lock, which the build threads take for slot / pool work.
   std::lock_guard<std::mutex> lk(dec->mu);
   Slot& dst = dec->slots[pic->dst_slot];
+  // ---- lane of this launch: the lane whose latest picture is the reference this picture was decoded after (it simply follows
+  // it in stream order); a picture without such a predecessor - no references at all, or references that other pictures have
+  // followed already - goes to the lane that was given work longest ago and overlaps with what the other lanes are doing.
+  int lane = 0;
+  if (dec->n_lanes > 1) {
+    uint64_t newest = 0; int wl = -1;
+    for (int s = 0; s < DE265HIP_MAX_DPB_SLOTS; s++)
+      if (((pic->ref_mask >> s) & 1u) && dec->slots[s].writer_lane >= 0 && dec->slots[s].written_seq >= newest) { newest = dec->slots[s].written_seq; wl = dec->slots[s].writer_lane; }
+    if (wl >= 0 && wl < dec->n_lanes && dec->lane_tail_seq[wl] == newest) lane = wl;
+    else for (int l = 1; l < dec->n_lanes; l++) if (dec->lane_tail_seq[l] < dec->lane_tail_seq[lane]) lane = l;
+  }
+  Slot& spare = lane_sp(dec, lane);
   {
     // Geometry is the PICTURE's (recorded at build): the destination and the spare are (re)allocated now, in launch order -
     // a change of picture size with pictures of the old size still queued is therefore safe (everything launched before has
     // the old planes, hipFree waits for it) - and every reference must hold a picture of this geometry by now.
     const de265hip_pic_params& pp = pic->params;
     int rc = alloc_slot(dst, pp.width, pp.height, pp.bit_depth_luma, pp.bit_depth_chroma, pp.chroma_format_idc);
-    if (!rc) rc = alloc_slot(dec->spare, pp.width, pp.height, pp.bit_depth_luma, pp.bit_depth_chroma, pp.chroma_format_idc);
+    if (!rc) rc = alloc_slot(spare, pp.width, pp.height, pp.bit_depth_luma, pp.bit_depth_chroma, pp.chroma_format_idc);
     if (rc) return rc;
     for (int s = 0; s < DE265HIP_MAX_DPB_SLOTS; s++)
       if ((pic->ref_mask >> s) & 1u) {
@@ -1864,13 +1976,47 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
       }
   }
   pic->n_launched++;
-  hipStream_t st = dec->stream;
+  hipStream_t st = lane_st(dec, lane);
+  dec->cur_stream = st;
+  pic->lane = lane;
   // a copy-out of the picture this slot held before must have left (de265hip_dpb_download_async)
   if (dst.dl_done && dst.dl_waited != dst.dl_seq && hipStreamWaitEvent(st, dst.dl_done, 0) != hipSuccess) return DE265HIP_ERROR_DECODING;
-  if (!pic->upload_waited) {            // the command buffers arrive on the copy stream
+  if (!((pic->upload_waited >> lane) & 1u)) {            // the command buffers arrive on the copy stream
     if (hipStreamWaitEvent(st, pic->uploaded, 0) != hipSuccess) return DE265HIP_ERROR_DECODING;
-    pic->upload_waited = true;
+    pic->upload_waited |= 1u << lane;
   }
+  if (dec->n_lanes > 1) {
+    // the pictures this one reads (on other lanes), and - for the slot it overwrites - the picture that wrote it and every
+    // picture that still reads it
+    for (int s = 0; s < DE265HIP_MAX_DPB_SLOTS; s++)
+      if ((pic->ref_mask >> s) & 1u) {
+        const Slot& r = dec->slots[s];
+        if ((r.writer_lane >= 0 && r.writer_lane != lane) || r.writer_lane == kForeignWriter)
+          if (hipStreamWaitEvent(st, r.written, 0) != hipSuccess) return DE265HIP_ERROR_DECODING;
+      }
+    if ((dst.writer_lane >= 0 && dst.writer_lane != lane) || dst.writer_lane == kForeignWriter)
+      if (hipStreamWaitEvent(st, dst.written, 0) != hipSuccess) return DE265HIP_ERROR_DECODING;
+    for (int l = 0; l < dec->n_lanes; l++)
+      if (l != lane && dst.rd_valid[l] && hipStreamWaitEvent(st, dst.read_done[l], 0) != hipSuccess) return DE265HIP_ERROR_DECODING;
+  }
+  // behind the picture's last kernel: it has written its slot and read its references
+  auto lanes_epilogue = [&]() -> bool {
+    if (dec->n_lanes == 1) return true;
+    const uint64_t seq = ++dec->launch_seq;
+    dec->lane_tail_seq[lane] = seq;
+    if (!dst.written && hipEventCreateWithFlags(&dst.written, hipEventDisableTiming) != hipSuccess) return false;
+    if (hipEventRecord(dst.written, st) != hipSuccess) return false;
+    dst.writer_lane = lane; dst.written_seq = seq;
+    for (int l = 0; l < kMaxLanes; l++) dst.rd_valid[l] = false;
+    for (int s = 0; s < DE265HIP_MAX_DPB_SLOTS; s++)
+      if ((pic->ref_mask >> s) & 1u) {
+        Slot& r = dec->slots[s];
+        if (!r.read_done[lane] && hipEventCreateWithFlags(&r.read_done[lane], hipEventDisableTiming) != hipSuccess) return false;
+        if (hipEventRecord(r.read_done[lane], st) != hipSuccess) return false;
+        r.rd_valid[lane] = true;
+      }
+    return true;
+  };
   PicDev P = pic->P;
   P.dbg = dec->dbg;
   const PlaneRef d0 = dst.pl[0], d1 = dst.pl[1], d2 = dst.pl[2];
@@ -1970,7 +2116,7 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
   const bool c420 = P.chroma_format == 1;           // (4:2:2 / 4:4:4: luma through the tuned kernels, the chroma planes through k_*_chroma_any)
   const bool lf_tile = want_sao && dec->lf_tile && !dec->separate_bs && !dec->two_pass_deblock && c420;
   if (lf_tile) {
-    Slot& sp = dec->spare;
+    Slot& sp = spare;
     LfMeta LM{ pic->d_flags, pic->d_qp, nullptr, pic->d_motion, pic->d_ctbs, pic->d_slices };
     SaoMeta SM{ pic->d_flags, pic->d_sao };
     {
@@ -1979,7 +2125,7 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
                          P, d0, d1, d2, sp.pl[0], sp.pl[1], sp.pl[2], LM, SM, want_deblock ? 1 : 0);
     }
     for (int c = 0; c < 3; c++) std::swap(dst.pl[c], sp.pl[c]);      // output picture now lives in the slot
-    if (hipGetLastError() != hipSuccess) return DE265HIP_ERROR_DECODING;
+    if (!lanes_epilogue() || hipGetLastError() != hipSuccess) return DE265HIP_ERROR_DECODING;
     return DE265HIP_OK;
   }
   if (want_deblock) {
@@ -2014,7 +2160,7 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
     }
   }
   if (last_stage >= DE265HIP_STAGE_FINAL && !pic->params.disable_sao && pic->params.sample_adaptive_offset_enabled_flag) {
-    Slot& sp = dec->spare;
+    Slot& sp = spare;
     SaoMeta M{ pic->d_flags, pic->d_sao };
     {
       KTimer t(dec, DE265HIP_K_SAO, 1);
@@ -2035,7 +2181,7 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
     }
     for (int c = 0; c < 3; c++) std::swap(dst.pl[c], sp.pl[c]);      // output picture now lives in the slot
   }
-  if (hipGetLastError() != hipSuccess) return DE265HIP_ERROR_DECODING;
+  if (!lanes_epilogue() || hipGetLastError() != hipSuccess) return DE265HIP_ERROR_DECODING;
   return DE265HIP_OK;
 }
 
@@ -2053,7 +2199,7 @@ int de265hip_picture_run(de265hip_decoder* dec, de265hip_picture* pic, int last_
 int de265hip_decoder_sync(de265hip_decoder* dec)
 {
   if (!dec) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
-  HIPCHK(hipStreamSynchronize(dec->stream), DE265HIP_ERROR_DECODING);
+  HIPCHK(sync_all_lanes(dec), DE265HIP_ERROR_DECODING);
   uint32_t err = 0;                     // a dependency wait that expired (k_run): results are not trustworthy
   HIPCHK(hipMemcpy(&err, dec->d_err, 4, hipMemcpyDeviceToHost), DE265HIP_ERROR_DECODING);
   if (dec->dbg & 16) {                  // diagnostic build switch: dump and clear the phase stamps
@@ -2090,7 +2236,7 @@ int de265hip_get_kernel_times(de265hip_decoder* dec, double ms[DE265HIP_K_COUNT]
                               int64_t launches[DE265HIP_K_COUNT], int reset)
 {
   if (!dec) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
-  HIPCHK(hipStreamSynchronize(dec->stream), DE265HIP_ERROR_DECODING);
+  HIPCHK(sync_all_lanes(dec), DE265HIP_ERROR_DECODING);
   for (auto& e : dec->pending) {
     float t = 0;
     if (hipEventElapsedTime(&t, e.a, e.b) == hipSuccess) dec->ms[e.kid] += t;

@@ -756,6 +756,66 @@ def test_coefficient_position_beyond_its_block_surfaces_as_decoding_error():
         d.close()
 
 
+# decode order of two hierarchical GOPs: (slice type, reference slots, destination slot).  Pictures 4 / 5, 6 and 7 / 8 of the
+# first GOP do not depend on each other; the second GOP re-uses the slots of the first while its last pictures still read them
+_DAG = [(2, [], 0), (1, [0], 1), (0, [0, 1], 2), (0, [0, 2], 3), (0, [0, 3], 4), (0, [3, 2], 5), (0, [2, 1], 6), (0, [2, 6], 7), (0, [6, 1], 8),
+        (2, [], 0), (1, [0], 3), (0, [0, 3], 2), (0, [0, 2], 4), (0, [2, 3], 5), (0, [4, 5], 1), (1, [1], 6)]
+
+
+_DAG_CACHE = {}
+
+
+def _dag_pictures(w, h, bd):
+    """The DAG's pictures and what the oracle makes of them, decoded one after the other (once per session)."""
+    if (w, h, bd) not in _DAG_CACHE:
+        sps, exp, planes = [], [], {}
+        for k, (st, refs, dst) in enumerate(_DAG):
+            over = dict(ref_slots=refs) if refs else {}
+            sp = pysynth.SynthPicture(pysynth.default_config(w, h, bd, st, seed=7100 + k, intra_pct=25, n_slices=2, weighted_pred=k & 1, **over))
+            out = pysynth.fill_planes(w, h, bd, 50 + k)            # (every sample of a picture is covered by a PU, an intra TU or a PCM block: what it starts from does not show)
+            pyoracle.reconstruct(sp.desc, sp.order, {s: planes[s] for s in refs}, out)
+            planes[dst] = out
+            sps.append(sp); exp.append([p.copy() for p in out])
+        _DAG_CACHE[(w, h, bd)] = (sps, exp)
+    return _DAG_CACHE[(w, h, bd)]
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 4])
+def test_lanes_overlap_independent_pictures_and_keep_the_result(lanes):
+    """Picture-level concurrency inside one decoder (de265hip_decoder_set_lanes): the pictures of a reference DAG are launched in
+    decode order without any host-side wait in between, each copied out asynchronously right behind its launch; every picture
+    must come out as the oracle decodes it one after the other - whatever overlaps on the device.  Covers read-after-write
+    (references decoded on another lane), write-after-read and write-after-write on re-used slots, and the copy-out.
+    (Full HD pictures, and the all-intra one queued several times first: the device is still busy with it when the host has
+    queued the others, so a missing wait shows - checked by taking the waits out.)"""
+    w, h, bd = 1920, 1080, 10
+    d = backend.Decoder()
+    try:
+        d.set_lanes(lanes)
+        sps, exp = _dag_pictures(w, h, bd)
+        for s in set(x[2] for x in _DAG):
+            d.dpb_alloc(s, w, h, bd)
+        pics = [d.build(dst, sp.desc) for sp, (_, _, dst) in zip(sps, _DAG)]
+        for rep in range(2):                                   # (the second pass re-runs the same picture objects: the replay of bench.py)
+            handles = []
+            for _ in range(6):                                  # (the all-intra picture a few times: the device falls behind the host)
+                d.run(pics[0], 2)
+            for pic, (_, _, dst) in zip(pics, _DAG):
+                d.run(pic, 2)
+                handles.append(d.download_async(dst, w, h, bd))
+            d.sync()
+            for k, hd in enumerate(handles):
+                got = hd.wait()
+                for c in range(3):
+                    bad = np.argwhere(got[c] != exp[k][c])
+                    assert bad.size == 0, "lanes %d pass %d picture %d comp %d: %d mismatches, first at %s" % (lanes, rep, k, c, len(bad), tuple(bad[0]))
+                hd.free()
+        for pic in pics:
+            pic.free()
+    finally:
+        d.close()
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_monochrome_intra_pictures_against_the_oracle(seed):
     """chroma_format_idc 0: intra pictures (the kind the reference has a defined result for), every stage, every bit depth, with
