@@ -601,7 +601,7 @@ int de265hip_dpb_upload(de265hip_decoder* d, int slot, int c, const void* src, p
   if (w == 0 || h == 0) return DE265HIP_OK;               // (a chroma plane of a monochrome picture)
   if (s->dl_done && s->dl_waited != s->dl_seq) HIPCHK(hipEventSynchronize(s->dl_done), DE265HIP_ERROR_DECODING);
   HIPCHK(sync_all_lanes(d), DE265HIP_ERROR_DECODING);
-  slot_settled(*s);
+  { std::lock_guard<std::mutex> lk(d->mu); slot_settled(*s); }
   HIPCHK(hipMemcpy2D(s->pl[c].ptr, s->pl[c].stride * bpp, src, (size_t)stride_bytes, w * bpp, h, hipMemcpyHostToDevice),
          DE265HIP_ERROR_DECODING);
   return 0;
@@ -1851,7 +1851,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     if (!host_checks_positions) {
       const int n_chk = (int)l0.size() + (int)SC.l0_rext.size();
       if (n_chk > 0)
-        hipLaunchKernelGGL(k_check_coeffs, dim3((n_chk + 255) / 256), dim3(256), 0, cs, (const TuTask*)((uint8_t*)pic->arena + o_l0), (int)l0.size(),
+        hipLaunchKernelGGL(k_check_coeffs, dim3((n_chk + 15) / 16), dim3(256), 0, cs, (const TuTask*)((uint8_t*)pic->arena + o_l0), (int)l0.size(),
                            (const TuTask*)((uint8_t*)pic->arena + o_l0x), (int)SC.l0_rext.size(), (uint16_t*)((uint8_t*)pic->arena + o_cpos), dec->d_err);
     }
     if (hipEventRecord(pic->uploaded, cs) != hipSuccess) return fail(DE265HIP_ERROR_DECODING);

@@ -699,13 +699,14 @@ __device__ __forceinline__ void resid16_body(const PicDev& P, const PlaneRef& pl
 __global__ __launch_bounds__(256)
 void k_check_coeffs(const TuTask* __restrict__ l0, int n_l0, const TuTask* __restrict__ l0x, int n_l0x, uint16_t* cpos, uint32_t* err)
 {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  // sixteen lanes per TU, striding its list (a thread per TU walked up to 1024 positions alone: 138 us per 4K picture)
+  const int i = (blockIdx.x * 256 + threadIdx.x) >> 4, sub = threadIdx.x & 15;
   if (i >= n_l0 + n_l0x) return;
   const TuTask* t = i < n_l0 ? l0 + i : l0x + (i - n_l0);
   const unsigned nS = 1u << (2 * t->log2_size), n = t->n_coeff;
   uint16_t* p = cpos + t->coeff_offset;
   bool bad = false;
-  for (unsigned k = 0; k < n; k++) {
+  for (unsigned k = sub; k < n; k += 16) {
     const unsigned v = p[k];
     if (v >= nS) { p[k] = (uint16_t)(v & (nS - 1)); bad = true; }
   }

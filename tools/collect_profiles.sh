@@ -11,6 +11,7 @@ mkdir -p $out
 export TMPDIR=/tmp
 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
 python3 bench.py --streams 1 --no-cpu-baseline --no-host-inclusive --no-e2e > $out/bench_1stream.json 2> $out/bench_1stream.err
+python3 bench.py --streams 1 --lanes 2 --no-cpu-baseline --no-host-inclusive --no-e2e > $out/bench_1stream_2lanes.json 2> $out/bench_1stream_2lanes.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats3 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-inclusive --no-e2e \
   > $out/bench_under_rocprof_3streams.json 2> $out/stats3.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1 -- python3 bench.py --streams 1 --steps 3 --warmup 1 --no-cpu-baseline --no-host-inclusive --no-e2e \
