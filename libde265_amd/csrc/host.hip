@@ -376,7 +376,7 @@ struct BuildScratch {
   struct TaskBuf { TuTask* p = nullptr; size_t cap = 0, n = 0; ~TaskBuf() { free(p); }
                    bool ensure(size_t c) { if (c <= cap) return true; free(p); p = (TuTask*)malloc(c * sizeof(TuTask)); cap = p ? c : 0; return p != nullptr; } };
   TaskBuf l0_inter[4];
-  std::vector<RunTask> runs; std::vector<uint32_t> run_deps, slots, mbx, mb_segs;
+  std::vector<RunTask> runs; std::vector<uint32_t> run_deps, slots, mbx, mb_segs, mb_owner;
   std::vector<int> order, newidx, count2, width; std::vector<uint8_t> micro;
   struct QuadPend { McTask t[4]; int n = 0; };                                               // a slot pair's open quad (k_mc_all)
   std::vector<McTask> mcs, mc_tiles[8], mc_chunks[8], mc_quads[8]; QuadPend mc_pend[8 * 17 * 17]; std::vector<int> micro_keys;
@@ -1236,7 +1236,12 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   int max_rl = 0, n_front = 0, n_mailboxes = 0;
   const bool mailbox_on = getenv("DE265HIP_NO_MAILBOX") == nullptr;
   std::vector<uint32_t>& mbx = SC.mbx; std::vector<uint32_t>& mb_segs = SC.mb_segs;      // per run: (own mailbox, first dword of its segments); the segments
-  mbx.assign(2 * rb.size(), 0xFFFFFFFFu); mb_segs.clear();
+  mbx.assign(3 * rb.size(), 0xFFFFFFFFu); mb_segs.clear(); SC.mb_owner.clear();      // (+ first dword of its packets' ready epochs, phased hand-over)
+  // Phased hand-over between luma runs (DE265HIP_NO_MB_PHASES=1: off): a publishing run stores each packet behind the barrier
+  // epoch that completes the TU under it (its table of ready epochs), and a reading run fetches each neighbour sample at the
+  // latest of at most four points of its chain that still precedes the first TU needing it - the right column's upper half
+  // of the CTB to the left is there when that CTB is half done, its own lower half needs the lower half only later.
+  const bool mb_phases = mailbox_on && getenv("DE265HIP_NO_MB_PHASES") == nullptr;
   {
     for (auto& R : rb) { int l = 0; for (int e = R.dep_head; e >= 0; e = SC.dep_next[e]) l = std::max(l, rb[SC.dep_val[e]].level); R.level = l + 1; max_rl = std::max(max_rl, R.level); }
     std::vector<int>& order = SC.order; std::vector<int>& newidx = SC.newidx;
@@ -1434,12 +1439,137 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
           o.micro |= 4;
           for (int q = 0; q < nseg; q++) {                  // producer run index -> its mailbox
             const uint32_t pk = seg[2 * q] & 0xFFFFFFu;
-            if (!(runs[pk].micro & 8)) { runs[pk].micro |= 8; mbx[2 * pk] = (uint32_t)n_mailboxes++; }
-            seg[2 * q] = (seg[2 * q] & 0xFF000000u) | mbx[2 * pk];
+            if (!(runs[pk].micro & 8)) {
+              runs[pk].micro |= 8; mbx[3 * pk] = (uint32_t)n_mailboxes++; SC.mb_owner.push_back(pk);
+              if (mb_phases && runs[pk].c_idx == 0) {       // its packets' ready epochs: 32 of the bottom row, 32 of the right column
+                const RunTask& Pq = runs[pk];
+                const Cell* pc = SC.cells[0].data(); const int mw0 = map_w[0];
+                uint8_t rdy[64];
+                for (int i = 0; i < 32; i++) {
+                  const int xr = (int)Pq.x0 + 2 * i, yc = (int)Pq.y0 + 2 * i;
+                  rdy[i] = xr < (int)Pq.x1 ? (uint8_t)(pc[(xr >> 2) + (size_t)(((int)Pq.y1 - 1) >> 2) * mw0].llvl - 1) : 255;
+                  rdy[32 + i] = yc < (int)Pq.y1 ? (uint8_t)(pc[(((int)Pq.x1 - 1) >> 2) + (size_t)(yc >> 2) * mw0].llvl - 1) : 255;
+                }
+                // at most three store points before the end of the chain (quantiles of the distinct ready epochs): a packet
+                // goes out at the first of them that is not before its ready epoch, the rest when the chain ends (255)
+                bool seen_r[256]; memset(seen_r, 0, sizeof(seen_r));
+                for (int i = 0; i < 64; i++) seen_r[rdy[i]] = true;
+                uint8_t rv[256]; int nrv = 0;
+                for (int v = 0; v < (int)Pq.n_lvls && v < 255; v++) if (seen_r[v]) rv[nrv++] = (uint8_t)v;      // (epoch n_lvls is the end)
+                uint8_t pubs[4] = { 255, 255, 255, 255 };
+                const int n_pub = std::min(3, nrv);
+                for (int j = 0; j < n_pub; j++) pubs[j] = rv[((j + 1) * nrv) / n_pub - 1];
+                for (int i = 0; i < 64; i++) {
+                  uint8_t qv = 255;
+                  for (int j = n_pub - 1; j >= 0; j--) if (rdy[i] <= pubs[j]) qv = pubs[j];
+                  rdy[i] = qv;
+                }
+                mbx[3 * pk + 2] = (uint32_t)mb_segs.size();
+                mb_segs.resize(mb_segs.size() + 17);
+                memcpy(&mb_segs[mb_segs.size() - 17], rdy, 64);
+                mb_segs[mb_segs.size() - 1] = (uint32_t)pubs[0] | ((uint32_t)pubs[1] << 8) | ((uint32_t)pubs[2] << 16) | (255u << 24);
+              }
+            }
+            seg[2 * q] = (seg[2 * q] & 0xFF000000u) | mbx[3 * pk];
           }
-          mbx[2 * k + 1] = (uint32_t)mb_segs.size();
-          mb_segs.push_back((uint32_t)nseg);
-          mb_segs.insert(mb_segs.end(), seg, seg + 2 * nseg);
+          // -- when is each neighbour sample first needed?  Only TUs on the box's left column / top row read outside it (dense run)
+          uint8_t need_row[256], need_col[256];               // by x - (x0 - 1) / y - y0; 255: never read
+          uint32_t sub[2 * 48]; uint8_t sub_g[48]; int nsub = 0;
+          uint8_t polls[4] = { 0, 0, 0, 0 }; int n_groups = 1;
+          bool phased = mb_phases && R.c == 0 && nl >= 4;
+          if (phased) {
+            memset(need_row, 255, sizeof(need_row)); memset(need_col, 255, sizeof(need_col));
+            for (int i = 0; i < n; i++) {
+              const TuTask& tt = SC.it[tix[i]];
+              const int xB = tt.x0, yB = tt.y0;
+              if (xB != R.x0 && yB != R.y0) continue;
+              const int nT = 1 << tt.log2_size, corner = nT >> 1, m = tt.intra_mode < 35 ? tt.intra_mode : 1;
+              const uint8_t ep = tt.run_level;
+              uint64_t need = mode_deps ? needed_units(g_used_units[tt.log2_size - 2][m][1], tt.avail) : tt.avail;
+              for (; need; need &= need - 1) {
+                const int u = __builtin_ctzll(need);
+                if (u < corner) {
+                  if (xB != R.x0) continue;
+                  const int yb = yB + 2 * nT - 4 * u - 4 - R.y0;
+                  for (int q = 0; q < 4; q++) if (yb + q >= 0 && yb + q < 256) need_col[yb + q] = std::min(need_col[yb + q], ep);
+                } else if (u == corner) {
+                  if (yB == R.y0) { const int xi = xB - R.x0; if (xi >= 0 && xi < 256) need_row[xi] = std::min(need_row[xi], ep); }   // (x = xB - 1)
+                  else if (xB == R.x0) { const int yi = yB - 1 - R.y0; if (yi >= 0 && yi < 256) need_col[yi] = std::min(need_col[yi], ep); }
+                } else {
+                  if (yB != R.y0) continue;
+                  const int xb = xB + 4 * (u - corner - 1) - (R.x0 - 1);
+                  for (int q = 0; q < 4; q++) if (xb + q >= 0 && xb + q < 256) need_row[xb + q] = std::min(need_row[xb + q], ep);
+                }
+              }
+            }
+            // the samples' need epochs -> at most four poll points (quantiles of the distinct values)
+            bool seen[256]; memset(seen, 0, sizeof(seen));
+            auto need_of = [&](int q, int off) -> int {
+              const bool col = seg[2 * q] >> 31;
+              const int src = (int)(seg[2 * q + 1] & 63) + off;
+              const RunTask& Pq = runs[SC.mb_owner[seg[2 * q] & 0xFFFFFFu]];
+              return col ? need_col[(int)Pq.y0 + src - R.y0] : need_row[(int)Pq.x0 + src - (R.x0 - 1)];
+            };
+            for (int q = 0; q < nseg; q++) { const int cnt = (int)((seg[2 * q] >> 24) & 63) + 1; for (int off = 0; off < cnt; off++) seen[need_of(q, off)] = true; }
+            uint8_t vals[256]; int nv = 0;
+            for (int v = 0; v < 255; v++) if (seen[v]) vals[nv++] = (uint8_t)v;
+            if (nv < 2) phased = false;
+            else {
+              n_groups = std::min(4, nv);
+              for (int g2 = 0; g2 < n_groups; g2++) polls[g2] = vals[(g2 * nv) / n_groups];
+              // sub-segments of one group each (samples nobody reads are left out)
+              for (int q = 0; q < nseg && phased; q++) {
+                const int cnt = (int)((seg[2 * q] >> 24) & 63) + 1;
+                const bool col = seg[2 * q] >> 31;
+                int start = -1, g_cur = -1;
+                for (int off = 0; off <= cnt; off++) {
+                  int g2 = -1;
+                  if (off < cnt) { const int v = need_of(q, off); if (v != 255) { g2 = 0; while (g2 + 1 < n_groups && polls[g2 + 1] <= v) g2++; } }
+                  if (g2 != g_cur) {
+                    if (g_cur >= 0) {
+                      if (nsub == 48) { phased = false; break; }
+                      const int len = off - start;
+                      sub[2 * nsub] = (seg[2 * q] & 0x80FFFFFFu) | ((uint32_t)(len - 1) << 24);
+                      sub[2 * nsub + 1] = ((seg[2 * q + 1] & 63u) + (uint32_t)start) | (((seg[2 * q + 1] >> 8) + (uint32_t)(start * (col ? tile_p : 1))) << 8);
+                      sub_g[nsub++] = (uint8_t)g_cur;
+                    }
+                    start = off; g_cur = g2;
+                  }
+                }
+              }
+            }
+          }
+          mbx[3 * k + 1] = (uint32_t)mb_segs.size();
+          if (phased && nsub > 0) {
+            int ends[4] = { 0, 0, 0, 0 }, tot = 0;
+            const size_t at = mb_segs.size();
+            mb_segs.resize(at + 3 + 2 * (size_t)nsub);
+            size_t w = at + 3;
+            for (int g2 = 0; g2 < n_groups; g2++) {
+              for (int q = 0; q < nsub; q++) if (sub_g[q] == g2) { mb_segs[w++] = sub[2 * q]; mb_segs[w++] = sub[2 * q + 1]; tot += (int)((sub[2 * q] >> 24) & 63) + 1; }
+              ends[g2] = tot;
+            }
+            if (tot > 255) {                               // (cannot happen with 64x64 boxes: <= 193 neighbour samples)
+              mb_segs.resize(at); phased = false;
+            } else {
+              for (int g2 = n_groups; g2 < 4; g2++) { ends[g2] = tot; polls[g2] = 255; }
+              mb_segs[at] = (uint32_t)nsub | ((uint32_t)n_groups << 8);
+              mb_segs[at + 1] = (uint32_t)ends[0] | ((uint32_t)ends[1] << 8) | ((uint32_t)ends[2] << 16) | ((uint32_t)ends[3] << 24);
+              mb_segs[at + 2] = (uint32_t)polls[0] | ((uint32_t)polls[1] << 8) | ((uint32_t)polls[2] << 16) | ((uint32_t)polls[3] << 24);
+            }
+          }
+          if (getenv("DE265HIP_PRINT_PHASES") && R.c == 0 && k % 97 == 0) {
+            fprintf(stderr, "run %zu (%d,%d) nl %d phased %d groups %d polls %d %d %d %d nsub %d | need_col:", k, (int)o.x0, (int)o.y0, nl, (int)phased, n_groups, polls[0], polls[1], polls[2], polls[3], nsub);
+            if (phased) { for (int q = 0; q < 96; q += 4) fprintf(stderr, " %d", need_col[q]); fprintf(stderr, " | need_row:"); for (int q = 0; q < 100; q += 4) fprintf(stderr, " %d", need_row[q]); }
+            fprintf(stderr, "\n");
+            for (int q = 0; q < nseg; q++) { const uint32_t mid = seg[2 * q] & 0xFFFFFFu; const uint32_t ro = mbx[3 * SC.mb_owner[mid] + 2];
+              if (ro != 0xFFFFFFFFu) { const uint8_t* rd = (const uint8_t*)&mb_segs[ro]; fprintf(stderr, "   producer %u nl %d ready row:", SC.mb_owner[mid], (int)runs[SC.mb_owner[mid]].n_lvls + 1); for (int i = 0; i < 32; i += 2) fprintf(stderr, " %d", rd[i]); fprintf(stderr, " col:"); for (int i = 32; i < 64; i += 2) fprintf(stderr, " %d", rd[i]); fprintf(stderr, "\n"); } }
+          }
+          if (!(phased && nsub > 0)) {
+            mb_segs.push_back((uint32_t)nseg | (1u << 8));
+            mb_segs.push_back(0); mb_segs.push_back(0);      // (one group: everything at the start)
+            mb_segs.insert(mb_segs.end(), seg, seg + 2 * nseg);
+          }
         }
       }
     }

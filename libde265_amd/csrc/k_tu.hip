@@ -1686,18 +1686,34 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   // producers' flags (which follow the drain of ALL their stores) and then fetching its window from the picture: one memory
   // round trip between two dependent runs instead of three.
   const bool mb_cons = (run.micro & 4) && !(RUN_DBG & 2048), mb_pub = (run.micro & 8) != 0;
-  uint32_t mb_own = 0, mb_seg0 = 0;
-  if (run.micro & 12) { mb_own = __builtin_amdgcn_readfirstlane(mbx[2 * ticket]); mb_seg0 = __builtin_amdgcn_readfirstlane(mbx[2 * ticket + 1]); }
+  uint32_t mb_own = 0, mb_seg0 = 0, mb_rdy0 = 0xFFFFFFFFu;
+  if (run.micro & 12) {
+    mb_own = __builtin_amdgcn_readfirstlane(mbx[3 * ticket]); mb_seg0 = __builtin_amdgcn_readfirstlane(mbx[3 * ticket + 1]);
+    mb_rdy0 = __builtin_amdgcn_readfirstlane(mbx[3 * ticket + 2]);
+  }
+  // Phased hand-over (host.hip): a publishing run with a table of ready epochs stores each packet behind the barrier epoch
+  // that completes the TU under it; a reading run with several sample groups fetches group g > 0 at poll epoch g of its chain
+  // (group 0 before the chain), prefetched at the start.
+  uint32_t mb_ready = 255;                                   // this thread's packet (tid < 64): the epoch whose barrier completes it
+  if (mb_pub && mb_rdy0 != 0xFFFFFFFFu && tid < 64) mb_ready = (mbsegs[mb_rdy0 + (tid >> 2)] >> (8 * (tid & 3))) & 0xFF;
+  const bool mb_pub_phased = mb_pub && mb_rdy0 != 0xFFFFFFFFu;
+  uint32_t mb_pubs = 0xFFFFFFFFu;                            // its store points (epochs, ascending; 255: none)
+  if (mb_pub_phased) mb_pubs = __builtin_amdgcn_readfirstlane(mbsegs[mb_rdy0 + 16]);
+  uint32_t mb_ends = 0, mb_polls = 0; int mb_ngroups = 1;
+  if (mb_cons) {
+    mb_ngroups = (int)((__builtin_amdgcn_readfirstlane(mbsegs[mb_seg0]) >> 8) & 0xFF);
+    mb_ends = __builtin_amdgcn_readfirstlane(mbsegs[mb_seg0 + 1]); mb_polls = __builtin_amdgcn_readfirstlane(mbsegs[mb_seg0 + 2]);
+  }
   const bool has_dep = tid < (int)run.n_deps && !mb_cons;
   uint32_t dep_id = 0;
   if (has_dep) dep_id = deps[run.dep_offset + tid];
   // neighbour sample s of the run (s counts through its segments): packet address, which half, where it goes in the window
   auto mb_locate = [&](int s_, const unsigned long long*& src_p, int& half, int& dst) {
-    const int nseg = (int)__builtin_amdgcn_readfirstlane(mbsegs[mb_seg0]);
+    const int nseg = (int)(__builtin_amdgcn_readfirstlane(mbsegs[mb_seg0]) & 0xFF);
     int acc = 0;
     src_p = nullptr;
     for (int q = 0; q < nseg; q++) {
-      const uint32_t a = __builtin_amdgcn_readfirstlane(mbsegs[mb_seg0 + 1 + 2 * q]), b = __builtin_amdgcn_readfirstlane(mbsegs[mb_seg0 + 2 + 2 * q]);
+      const uint32_t a = __builtin_amdgcn_readfirstlane(mbsegs[mb_seg0 + 3 + 2 * q]), b = __builtin_amdgcn_readfirstlane(mbsegs[mb_seg0 + 4 + 2 * q]);
       const int cnt = (int)((a >> 24) & 63) + 1, off = s_ - acc;
       if (off >= 0 && off < cnt) {
         const bool col = a >> 31;
@@ -1824,9 +1840,17 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
     run_prepare_sample<RUN_TILE_P>(s, s_task, s_own, s_res, s_ctl, s_ex, s_mine, CONST_ADDR);
   st.mark(2);
   int wbase = 0;
+  bool mb_phased = false; int mb_grp = 0; unsigned long long mb_v = 0;
   if (early) { window_commit(); wbase = 4 * nthr; }
   else if (mb_cons) {
-    for (int s_ = tid; s_ < mb_total; s_ += nthr) {     // (one pass with 256 threads: at most 193 samples)
+    // (several groups only when every sample has a thread of its own: the later groups' packets stay in registers)
+    mb_phased = mb_ngroups > 1 && mb_total <= nthr;
+    const int g0_end = mb_phased ? (int)(mb_ends & 0xFF) : mb_total;
+    if (mb_phased && tid >= g0_end && tid < mb_total && mb_src) {
+      mb_grp = 1 + (tid >= (int)((mb_ends >> 8) & 0xFF)) + (tid >= (int)((mb_ends >> 16) & 0xFF));
+      mb_v = __hip_atomic_load(mb_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (looked at when its poll epoch comes)
+    }
+    for (int s_ = tid; s_ < g0_end; s_ += nthr) {       // (one pass with 256 threads: at most 193 samples)
       if (s_ != tid) mb_locate(s_, mb_src, mb_half, mb_dst);
       if (!mb_src) continue;
       uint32_t spins = 0;
@@ -1874,6 +1898,16 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   for (int base = wbase; base < nchunks; base += 4 * nthr) { window_issue(base, nthr, tid); window_commit(); }
   __syncthreads();
   st.mark(4);
+  auto mb_publish = [&]() {                              // this thread's packet (tid < 64): two samples of the bottom row / right column
+    const bool col = tid >= 32;
+    const int i = 2 * (tid & 31);
+    const int bw = (int)run.x1 - (int)run.x0, bh = (int)run.y1 - (int)run.y0;
+    if (i < (col ? bh : bw)) {
+      const int r = col ? (int)run.y0 - wy0 + i : (int)run.y1 - 1 - wy0, cx = col ? (int)run.x1 - 1 - ax0 : (int)run.x0 - ax0 + i;
+      const uint32_t a = tile[r * RUN_TILE_P + cx], b = col ? tile[(r + 1) * RUN_TILE_P + cx] : tile[r * RUN_TILE_P + cx + 1];
+      __hip_atomic_store(mb + (size_t)mb_own * 64 + tid, ((unsigned long long)gen << 32) | (b << 16) | a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
 
   // ---- the dependency chain.  Each wavefront walks its own list of the run's TUs (the host's list schedule keeps
   // a z-scan chain on one wavefront and moves independent branches to the others).  A TU whose producers all come
@@ -1919,7 +1953,26 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
     // The own TUs are walked in a tight inner loop over the common kind (angular, not smoothed, 4x4 / 8x8: spelled out
     // with as few instructions as possible, the chain costs about a dozen cycles per instruction) that drops out to the
     // general code for one TU of any other kind: the compiler then lays the common path out contiguously.
+    int mb_next = 1;                                                     // next sample group to fetch (phased readers)
+    // (one scalar compare per epoch and kind of event: the epoch of the next fetch / the next store point, -1: none)
+    int mb_poll_at = (mb_phased && mb_ngroups > 1) ? (int)((mb_polls >> 8) & 0xFF) : -1;
+    int mb_pub_at = (mb_pubs & 0xFF) == 255 ? -1 : (int)(mb_pubs & 0xFF);
     for (int epoch = 0;; epoch++) {
+      if (epoch == mb_poll_at) {
+        // the neighbour samples first read by TUs of this epoch (and later ones): their packets were requested before the chain
+        if (mb_grp == mb_next) {
+          uint32_t spins = 0;
+          while ((uint32_t)(mb_v >> 32) != gen) {
+            if (spins) { if (spins < RUN_POLL_FAST_N) __builtin_amdgcn_s_sleep(RUN_POLL_FAST); else __builtin_amdgcn_s_sleep(RUN_POLL_SLOW); }
+            if (++spins > spin_limit) { atomicExch(err, 1u); break; }               // never hang the grid
+            mb_v = __hip_atomic_load(mb_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          tile[mb_dst] = (uint16_t)(mb_v >> (16 * mb_half));
+        }
+        mb_next++;
+        mb_poll_at = mb_next < mb_ngroups ? (int)((mb_polls >> (8 * mb_next)) & 0xFF) : -1;
+        RUN_LDS_BARRIER();
+      }
       while (c_lvl == epoch) {
         const uint32_t c0 = __builtin_amdgcn_readfirstlane(rc.x), c1 = __builtin_amdgcn_readfirstlane(rc.y);
         const int log2 = __builtin_amdgcn_readfirstlane((int)((rc.w >> 27) & 7));
@@ -1977,6 +2030,11 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
       if (epoch >= n_epochs) break;
       RUN_LDS_BARRIER();
       if (RUN_DBG & 128) RUN_LDS_BARRIER();
+      if (epoch == mb_pub_at) {                                         // a store point: the packets completed since the last one (tid < 64)
+        if (mb_ready == (uint32_t)epoch) mb_publish();
+        mb_pubs >>= 8;
+        mb_pub_at = (mb_pubs & 0xFF) == 255 ? -1 : (int)(mb_pubs & 0xFF);
+      }
     }
 #undef RUN_CHAIN_HEAD
 #undef RUN_CHAIN_NEXT
@@ -1987,16 +2045,7 @@ void k_run(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __
   // The flag is only raised after the run, so nothing is lost by storing here instead of per TU, and a
   // write-through store costs one fabric write whatever its size.
   __syncthreads();
-  if (mb_pub && tid < 64) {
-    const bool col = tid >= 32;
-    const int i = 2 * (tid & 31);
-    const int bw = (int)run.x1 - (int)run.x0, bh = (int)run.y1 - (int)run.y0;
-    if (i < (col ? bh : bw)) {
-      const int r = col ? (int)run.y0 - wy0 + i : (int)run.y1 - 1 - wy0, cx = col ? (int)run.x1 - 1 - ax0 : (int)run.x0 - ax0 + i;
-      const uint32_t a = tile[r * RUN_TILE_P + cx], b = col ? tile[(r + 1) * RUN_TILE_P + cx] : tile[r * RUN_TILE_P + cx + 1];
-      __hip_atomic_store(mb + (size_t)mb_own * 64 + tid, ((unsigned long long)gen << 32) | (b << 16) | a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
+  if (mb_pub && tid < 64 && (!mb_pub_phased || mb_ready == 255 || (RUN_DBG & 4))) mb_publish();      // (the packets no earlier epoch has stored)
   {
     PX* wplane = plane + ax0 + wy0 * stride;                             // picture address of window sample (0, 0)
     const int rows = (int)run.y1 - (int)run.y0, nch = ((int)run.x1 - ax0 + 7) >> 3;
