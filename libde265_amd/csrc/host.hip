@@ -376,7 +376,7 @@ struct BuildScratch {
   struct TaskBuf { TuTask* p = nullptr; size_t cap = 0, n = 0; ~TaskBuf() { free(p); }
                    bool ensure(size_t c) { if (c <= cap) return true; free(p); p = (TuTask*)malloc(c * sizeof(TuTask)); cap = p ? c : 0; return p != nullptr; } };
   TaskBuf l0_inter[4];
-  std::vector<RunTask> runs; std::vector<uint32_t> run_deps, slots, mbx, mb_segs, mb_owner;
+  std::vector<RunTask> runs; std::vector<uint32_t> run_deps, slots, mbx, mb_segs, mb_owner; std::vector<uint8_t> rdy_tab;
   std::vector<int> order, newidx, count2, width; std::vector<uint8_t> micro;
   struct QuadPend { McTask t[4]; int n = 0; };                                               // a slot pair's open quad (k_mc_all)
   std::vector<McTask> mcs, mc_tiles[8], mc_chunks[8], mc_quads[8]; QuadPend mc_pend[8 * 17 * 17]; std::vector<int> micro_keys;
@@ -1326,6 +1326,28 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
           if (kmin < corner && (tt.avail >> (corner + 1 + kmin)) & ((1ull << (corner - kmin)) - 1ull)) dense = false;
         }
       }
+      // Phased hand-over: every dense ordinary luma run leaves the ready epochs of its edge packets behind (the epoch of the TU
+      // under each pair of samples of its bottom row and right column), for the runs that will read its mailbox.
+      // (Tried on top of it: moving the TUs that read the column left of the box to their as-late-as-possible level, from the
+      //  run's TU-to-TU edges, so that the run asks for the left neighbour's last samples later in its chain: 4K all-intra
+      //  picture 1.62 -> 1.56 ms, but 5 ms more host time per such picture - the edges cost as much as the scan; not kept.)
+      if (mb_phases && dense && !micro[order[k]] && R.c == 0 && R.x1 - R.x0 <= 64 && R.y1 - R.y0 <= 64) {
+        uint8_t umap[256];
+        for (int i = 0; i < n; i++) {
+          const TuTask& tt = SC.it[tix[i]];
+          const int u0x = (tt.x0 - R.x0) >> 2, u0y = (tt.y0 - R.y0) >> 2, nu = 1 << (tt.log2_size - 2);
+          if (u0y + nu - 1 == ((R.y1 - 1 - R.y0) >> 2) || u0x + nu - 1 == ((R.x1 - 1 - R.x0) >> 2))      // (only the bottom row and the right column are looked up)
+            for (int yy = 0; yy < nu; yy++) memset(&umap[(u0y + yy) * 16 + u0x], i, (size_t)nu);
+        }
+        if (SC.rdy_tab.size() < 64 * rb.size()) SC.rdy_tab.resize(64 * rb.size());
+        uint8_t* rdy = &SC.rdy_tab[64 * k];
+        const int uyb = (R.y1 - 1 - R.y0) >> 2, uxr = (R.x1 - 1 - R.x0) >> 2;
+        for (int i = 0; i < 32; i++) {
+          const int xr = R.x0 + 2 * i, yc = R.y0 + 2 * i;
+          rdy[i] = xr < R.x1 ? SC.it[tix[umap[uyb * 16 + ((xr - R.x0) >> 2)]]].run_level : 255;
+          rdy[32 + i] = yc < R.y1 ? SC.it[tix[umap[((yc - R.y0) >> 2) * 16 + uxr]]].run_level : 255;
+        }
+      }
       o.c_idx = (uint8_t)R.c; o.micro = (uint8_t)(micro[order[k]] | (dense ? 2 : 0)); o.n_tus = (uint16_t)n;
       o.first_tu = (uint32_t)run_tus.size(); o.dep_offset = (uint32_t)run_deps.size();
       { int nd = 0; for (int e = R.dep_head; e >= 0; e = SC.dep_next[e]) nd += newidx[SC.dep_val[e]] >= n_front; o.n_deps = (uint16_t)nd; }
@@ -1443,19 +1465,17 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
               runs[pk].micro |= 8; mbx[3 * pk] = (uint32_t)n_mailboxes++; SC.mb_owner.push_back(pk);
               if (mb_phases && runs[pk].c_idx == 0) {       // its packets' ready epochs: 32 of the bottom row, 32 of the right column
                 const RunTask& Pq = runs[pk];
-                const Cell* pc = SC.cells[0].data(); const int mw0 = map_w[0];
                 uint8_t rdy[64];
-                for (int i = 0; i < 32; i++) {
-                  const int xr = (int)Pq.x0 + 2 * i, yc = (int)Pq.y0 + 2 * i;
-                  rdy[i] = xr < (int)Pq.x1 ? (uint8_t)(pc[(xr >> 2) + (size_t)(((int)Pq.y1 - 1) >> 2) * mw0].llvl - 1) : 255;
-                  rdy[32 + i] = yc < (int)Pq.y1 ? (uint8_t)(pc[(((int)Pq.x1 - 1) >> 2) + (size_t)(yc >> 2) * mw0].llvl - 1) : 255;
-                }
+                memcpy(rdy, &SC.rdy_tab[64 * (size_t)pk], 64);   // (left behind when the run was laid out, above)
                 // at most three store points before the end of the chain (quantiles of the distinct ready epochs): a packet
                 // goes out at the first of them that is not before its ready epoch, the rest when the chain ends (255)
-                bool seen_r[256]; memset(seen_r, 0, sizeof(seen_r));
-                for (int i = 0; i < 64; i++) seen_r[rdy[i]] = true;
+                uint64_t seen_r[4] = { 0, 0, 0, 0 };
+                for (int i = 0; i < 64; i++) seen_r[rdy[i] >> 6] |= 1ull << (rdy[i] & 63);
                 uint8_t rv[256]; int nrv = 0;
-                for (int v = 0; v < (int)Pq.n_lvls && v < 255; v++) if (seen_r[v]) rv[nrv++] = (uint8_t)v;      // (epoch n_lvls is the end)
+                for (int wd = 0; wd < 4; wd++) for (uint64_t mm = seen_r[wd]; mm; mm &= mm - 1) {
+                  const int v = 64 * wd + __builtin_ctzll(mm);
+                  if (v < (int)Pq.n_lvls && v < 255) rv[nrv++] = (uint8_t)v;                                     // (epoch n_lvls is the end)
+                }
                 uint8_t pubs[4] = { 255, 255, 255, 255 };
                 const int n_pub = std::min(3, nrv);
                 for (int j = 0; j < n_pub; j++) pubs[j] = rv[((j + 1) * nrv) / n_pub - 1];
@@ -1478,7 +1498,10 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
           uint8_t polls[4] = { 0, 0, 0, 0 }; int n_groups = 1;
           bool phased = mb_phases && R.c == 0 && nl >= 4;
           if (phased) {
-            memset(need_row, 255, sizeof(need_row)); memset(need_col, 255, sizeof(need_col));
+            // (kept per 4-sample unit - a unit's samples are read together - and spread over the sample arrays at the end;
+            //  row unit j: x0 + 4j .. + 3, the corner x0 - 1 on its own; column unit j: y0 + 4j .. + 3)
+            uint8_t nru[40], ncu[40], ncorner = 255;
+            memset(nru, 255, sizeof(nru)); memset(ncu, 255, sizeof(ncu));
             for (int i = 0; i < n; i++) {
               const TuTask& tt = SC.it[tix[i]];
               const int xB = tt.x0, yB = tt.y0;
@@ -1490,51 +1513,53 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
                 const int u = __builtin_ctzll(need);
                 if (u < corner) {
                   if (xB != R.x0) continue;
-                  const int yb = yB + 2 * nT - 4 * u - 4 - R.y0;
-                  for (int q = 0; q < 4; q++) if (yb + q >= 0 && yb + q < 256) need_col[yb + q] = std::min(need_col[yb + q], ep);
+                  const int j = (yB + 2 * nT - 4 * u - 4 - R.y0) >> 2;
+                  if (j >= 0 && j < 40) ncu[j] = std::min(ncu[j], ep);
                 } else if (u == corner) {
-                  if (yB == R.y0) { const int xi = xB - R.x0; if (xi >= 0 && xi < 256) need_row[xi] = std::min(need_row[xi], ep); }   // (x = xB - 1)
-                  else if (xB == R.x0) { const int yi = yB - 1 - R.y0; if (yi >= 0 && yi < 256) need_col[yi] = std::min(need_col[yi], ep); }
+                  if (yB == R.y0) { if (xB == R.x0) ncorner = std::min(ncorner, ep); else { const int j = (xB - 1 - R.x0) >> 2; if (j < 40) nru[j] = std::min(nru[j], ep); } }
+                  else if (xB == R.x0) { const int j = (yB - 1 - R.y0) >> 2; if (j >= 0 && j < 40) ncu[j] = std::min(ncu[j], ep); }
                 } else {
                   if (yB != R.y0) continue;
-                  const int xb = xB + 4 * (u - corner - 1) - (R.x0 - 1);
-                  for (int q = 0; q < 4; q++) if (xb + q >= 0 && xb + q < 256) need_row[xb + q] = std::min(need_row[xb + q], ep);
+                  const int j = (xB + 4 * (u - corner - 1) - R.x0) >> 2;
+                  if (j >= 0 && j < 40) nru[j] = std::min(nru[j], ep);
                 }
               }
             }
+            need_row[0] = ncorner;
+            for (int j = 0; j < 40; j++) { memset(need_row + 1 + 4 * j, nru[j], 4); memset(need_col + 4 * j, ncu[j], 4); }
             // the samples' need epochs -> at most four poll points (quantiles of the distinct values)
-            bool seen[256]; memset(seen, 0, sizeof(seen));
-            auto need_of = [&](int q, int off) -> int {
-              const bool col = seg[2 * q] >> 31;
-              const int src = (int)(seg[2 * q + 1] & 63) + off;
+            const uint8_t* nbase[16];                          // per segment: need epoch of its first sample
+            uint64_t seen[4] = { 0, 0, 0, 0 };
+            for (int q = 0; q < nseg; q++) {
               const RunTask& Pq = runs[SC.mb_owner[seg[2 * q] & 0xFFFFFFu]];
-              return col ? need_col[(int)Pq.y0 + src - R.y0] : need_row[(int)Pq.x0 + src - (R.x0 - 1)];
-            };
-            for (int q = 0; q < nseg; q++) { const int cnt = (int)((seg[2 * q] >> 24) & 63) + 1; for (int off = 0; off < cnt; off++) seen[need_of(q, off)] = true; }
+              const int src = (int)(seg[2 * q + 1] & 63), cnt = (int)((seg[2 * q] >> 24) & 63) + 1;
+              nbase[q] = (seg[2 * q] >> 31) ? need_col + ((int)Pq.y0 + src - R.y0) : need_row + ((int)Pq.x0 + src - (R.x0 - 1));
+              for (int off = 0; off < cnt; off++) { const uint8_t v = nbase[q][off]; seen[v >> 6] |= 1ull << (v & 63); }
+            }
+            seen[3] &= ~(1ull << 63);                          // (255: never read)
             uint8_t vals[256]; int nv = 0;
-            for (int v = 0; v < 255; v++) if (seen[v]) vals[nv++] = (uint8_t)v;
+            for (int wd = 0; wd < 4; wd++) for (uint64_t mm = seen[wd]; mm; mm &= mm - 1) vals[nv++] = (uint8_t)(64 * wd + __builtin_ctzll(mm));
             if (nv < 2) phased = false;
             else {
               n_groups = std::min(4, nv);
               for (int g2 = 0; g2 < n_groups; g2++) polls[g2] = vals[(g2 * nv) / n_groups];
+              uint8_t grp_of[256];                              // need epoch -> group (255 -> none)
+              { int g2 = 0; for (int v = 0; v < 255; v++) { while (g2 + 1 < n_groups && polls[g2 + 1] <= v) g2++; grp_of[v] = (uint8_t)g2; } grp_of[255] = 255; }
               // sub-segments of one group each (samples nobody reads are left out)
               for (int q = 0; q < nseg && phased; q++) {
                 const int cnt = (int)((seg[2 * q] >> 24) & 63) + 1;
                 const bool col = seg[2 * q] >> 31;
-                int start = -1, g_cur = -1;
-                for (int off = 0; off <= cnt; off++) {
-                  int g2 = -1;
-                  if (off < cnt) { const int v = need_of(q, off); if (v != 255) { g2 = 0; while (g2 + 1 < n_groups && polls[g2 + 1] <= v) g2++; } }
-                  if (g2 != g_cur) {
-                    if (g_cur >= 0) {
-                      if (nsub == 48) { phased = false; break; }
-                      const int len = off - start;
-                      sub[2 * nsub] = (seg[2 * q] & 0x80FFFFFFu) | ((uint32_t)(len - 1) << 24);
-                      sub[2 * nsub + 1] = ((seg[2 * q + 1] & 63u) + (uint32_t)start) | (((seg[2 * q + 1] >> 8) + (uint32_t)(start * (col ? tile_p : 1))) << 8);
-                      sub_g[nsub++] = (uint8_t)g_cur;
-                    }
-                    start = off; g_cur = g2;
+                int start = 0, g_cur = grp_of[nbase[q][0]];
+                for (int off = 1; off <= cnt; off++) {
+                  const int g2 = off < cnt ? grp_of[nbase[q][off]] : 254;
+                  if (g2 == g_cur) continue;
+                  if (g_cur != 255) {
+                    if (nsub == 48) { phased = false; break; }
+                    sub[2 * nsub] = (seg[2 * q] & 0x80FFFFFFu) | ((uint32_t)(off - start - 1) << 24);
+                    sub[2 * nsub + 1] = ((seg[2 * q + 1] & 63u) + (uint32_t)start) | (((seg[2 * q + 1] >> 8) + (uint32_t)(start * (col ? tile_p : 1))) << 8);
+                    sub_g[nsub++] = (uint8_t)g_cur;
                   }
+                  start = off; g_cur = g2;
                 }
               }
             }
