@@ -36,7 +36,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_h_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_i_pmc_traffic.json")
 PMC_KERNEL = {"intra": ["k_run<unsigned short, 64>"], "mc": ["k_mc<unsigned short>"], "sao": ["k_sao_ctb<unsigned short>"],
               "deblock_v": ["k_deblock_fused<unsigned short>"],   # both directions in one kernel, reported under deblock_v
               "resid": ["k_resid_big<unsigned short>"]}     # all sizes in one launch

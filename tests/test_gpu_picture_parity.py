@@ -353,10 +353,10 @@ def test_recorder_submit_matches_oracle(dec):
                                  {"DE265HIP_MICRO_TUS": "4"}, {"DE265HIP_TICKET_BATCH": "4"}, {"DE265HIP_SEPARATE_BS": "1"},
                                  {"DE265HIP_TWO_PASS_DEBLOCK": "1"}, {"DE265HIP_MICRO16": "0"}, {"DE265HIP_RESID16_BIG": "1"}, {"DE265HIP_RESID_ONE_LAUNCH": "0"},
                                  {"DE265HIP_LF_TILE": "1"}, {"DE265HIP_NO_MERGE": "1"}, {"DE265HIP_RUN_DIRECT": "1"}, {"DE265HIP_SAO_STRIPS": "1"},
-                                 {"DE265HIP_NO_MAILBOX": "1"}, {"DE265HIP_NO_FRONT": "1"}, {"DE265HIP_MC_PATHS": "0"}, {"DE265HIP_MC_PATHS": "1"},
+                                 {"DE265HIP_NO_MAILBOX": "1"}, {"DE265HIP_NO_MB_PHASES": "1"}, {"DE265HIP_NO_FRONT": "1"}, {"DE265HIP_MC_PATHS": "0"}, {"DE265HIP_MC_PATHS": "1"},
                                  {"DE265HIP_MC_PATHS": "2"}])
 def test_run_kernel_schedule_variants(env):
-    """k_run's schedule knobs (wavefronts per workgroup, micro runs on/off, tickets per draw, edge mailboxes, front runs) and the forms MC tasks
+    """k_run's schedule knobs (wavefronts per workgroup, micro runs on/off, tickets per draw, edge mailboxes with and without the phased hand-over, front runs) and the forms MC tasks
     take (round 2's tiles only, + quads of small blocks, + chunks) only change who does what when: every variant is bit-exact against the oracle."""
     import os
     from libde265_amd import backend
@@ -368,6 +368,7 @@ def test_run_kernel_schedule_variants(env):
         run_case(d2, 352, 288, 8, 0, seed=92, stages=(2,), tskip_pct=10, scaling_list=1, constrained_intra_pred=1)
         run_case(d2, 512, 320, 10, 0, seed=93, stages=(2,), intra_pct=60, split_bias=80)
         run_case(d2, 448, 256, 10, 2, seed=94, stages=(2,), split_bias=40)            # all-intra, big TUs: dense CTB runs (edge mailboxes)
+        run_case(d2, 1024, 576, 10, 2, seed=95, stages=(2,), split_bias=70, strong_intra_smoothing=0)      # many CTBs side by side: the phased hand-over at work
     finally:
         d2.close()
         for k, v in old.items():
