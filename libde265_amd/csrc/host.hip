@@ -798,6 +798,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   if (p.scaling_list_enable_flag && !d->scaling_factors) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   if (dst_slot < 0 || dst_slot >= DE265HIP_MAX_DPB_SLOTS) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   int rc = 0;
+  PhaseTimer pt;
   if (!dec->dry) {
     // Builds run ahead of launches (de265hip_pipeline_*, several host threads): a slot or the spare that already holds
     // planes of ANOTHER geometry may still be read or written by pictures that are built but not launched yet, so it is
@@ -812,8 +813,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     if (!rc && (!dec->spare.valid || !pending)) rc = alloc_slot(dec->spare, p.width, p.height, p.bit_depth_luma, p.bit_depth_chroma, p.chroma_format_idc);
   }
   if (rc) return rc;
-
-  PhaseTimer pt;
+  pt.mark("slots");
   // CtbAddrRStoTS / TileIdRS / MinTbAddrZS depend on the picture size, CTB / min TB size and the tile grid only: the same for
   // every picture of a sequence.  One cached copy per host thread (4K: 522 240 z-scan addresses, 4 ms to compute).
   struct GeoKey { int32_t w, h, lc, lt, nc, nr; uint16_t cb[24], rb[24]; };
