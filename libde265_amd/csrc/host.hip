@@ -1332,7 +1332,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       //  run's TU-to-TU edges, so that the run asks for the left neighbour's last samples later in its chain: 4K all-intra
       //  picture 1.62 -> 1.56 ms, but 5 ms more host time per such picture - the edges cost as much as the scan; not kept.)
       if (mb_phases && dense && !micro[order[k]] && R.c == 0 && R.x1 - R.x0 <= 64 && R.y1 - R.y0 <= 64) {
-        uint8_t umap[256];
+        uint8_t umap[256]; memset(umap, 255, sizeof(umap));      // (255: no TU - a malformed description may leave holes in a box whose sample count adds up)
         for (int i = 0; i < n; i++) {
           const TuTask& tt = SC.it[tix[i]];
           const int u0x = (tt.x0 - R.x0) >> 2, u0y = (tt.y0 - R.y0) >> 2, nu = 1 << (tt.log2_size - 2);
@@ -1344,8 +1344,8 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
         const int uyb = (R.y1 - 1 - R.y0) >> 2, uxr = (R.x1 - 1 - R.x0) >> 2;
         for (int i = 0; i < 32; i++) {
           const int xr = R.x0 + 2 * i, yc = R.y0 + 2 * i;
-          rdy[i] = xr < R.x1 ? SC.it[tix[umap[uyb * 16 + ((xr - R.x0) >> 2)]]].run_level : 255;
-          rdy[32 + i] = yc < R.y1 ? SC.it[tix[umap[((yc - R.y0) >> 2) * 16 + uxr]]].run_level : 255;
+          { const int ui = umap[uyb * 16 + ((xr - R.x0) >> 2)]; rdy[i] = (xr < R.x1 && ui < n) ? SC.it[tix[ui]].run_level : 255; }
+          { const int ui = umap[((yc - R.y0) >> 2) * 16 + uxr]; rdy[32 + i] = (yc < R.y1 && ui < n) ? SC.it[tix[ui]].run_level : 255; }
         }
       }
       o.c_idx = (uint8_t)R.c; o.micro = (uint8_t)(micro[order[k]] | (dense ? 2 : 0)); o.n_tus = (uint16_t)n;

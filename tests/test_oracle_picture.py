@@ -90,6 +90,17 @@ def test_monochrome_intra_pictures_and_what_is_refused():
     assert backend.lib().de265hip_debug_build_host_only(sp.desc, 1) == _abi.ERROR_PARAMETER_OUT_OF_RANGE
 
 
+def test_host_stage_survives_corrupted_descriptions():
+    """tools/fuzz_desc.py: random corruptions of valid picture descriptions - wild values and values that pass every range
+    check (moved, resized, duplicated TUs, arbitrary flags and modes) - come back from the host stage as an error code or as a
+    normal build, never as a crash.  (The same under an address-sanitizer build of the host code: see the tool's header;
+    1 800 descriptions without a report.)"""
+    import fuzz_desc
+    codes = fuzz_desc.run(20261004, 120)
+    assert set(codes) <= {0, _abi.ERROR_PARAMETER_OUT_OF_RANGE, _abi.ERROR_NOT_IMPLEMENTED, _abi.ERROR_OUT_OF_MEMORY}, codes
+    assert codes.get(0, 0) > 10 and codes.get(_abi.ERROR_PARAMETER_OUT_OF_RANGE, 0) > 10
+
+
 def test_host_stage_cr_shortcut_and_its_fallback(monkeypatch):
     """The TU scan of de265hip_picture_build takes a Cr intra TU's availability / levels / run from its Cb twin; a descriptor
     without that pattern (here: a Cr TU whose mode differs from its Cb TU's, and a Cb TU whose Cr TU is missing) is built the
