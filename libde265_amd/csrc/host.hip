@@ -1332,20 +1332,14 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       //  run's TU-to-TU edges, so that the run asks for the left neighbour's last samples later in its chain: 4K all-intra
       //  picture 1.62 -> 1.56 ms, but 5 ms more host time per such picture - the edges cost as much as the scan; not kept.)
       if (mb_phases && dense && !micro[order[k]] && R.c == 0 && R.x1 - R.x0 <= 64 && R.y1 - R.y0 <= 64) {
-        uint8_t umap[256]; memset(umap, 255, sizeof(umap));      // (255: no TU - a malformed description may leave holes in a box whose sample count adds up)
-        for (int i = 0; i < n; i++) {
-          const TuTask& tt = SC.it[tix[i]];
-          const int u0x = (tt.x0 - R.x0) >> 2, u0y = (tt.y0 - R.y0) >> 2, nu = 1 << (tt.log2_size - 2);
-          if (u0y + nu - 1 == ((R.y1 - 1 - R.y0) >> 2) || u0x + nu - 1 == ((R.x1 - 1 - R.x0) >> 2))      // (only the bottom row and the right column are looked up)
-            for (int yy = 0; yy < nu; yy++) memset(&umap[(u0y + yy) * 16 + u0x], i, (size_t)nu);
-        }
         if (SC.rdy_tab.size() < 64 * rb.size()) SC.rdy_tab.resize(64 * rb.size());
         uint8_t* rdy = &SC.rdy_tab[64 * k];
-        const int uyb = (R.y1 - 1 - R.y0) >> 2, uxr = (R.x1 - 1 - R.x0) >> 2;
-        for (int i = 0; i < 32; i++) {
-          const int xr = R.x0 + 2 * i, yc = R.y0 + 2 * i;
-          { const int ui = umap[uyb * 16 + ((xr - R.x0) >> 2)]; rdy[i] = (xr < R.x1 && ui < n) ? SC.it[tix[ui]].run_level : 255; }
-          { const int ui = umap[((yc - R.y0) >> 2) * 16 + uxr]; rdy[32 + i] = (yc < R.y1 && ui < n) ? SC.it[tix[ui]].run_level : 255; }
+        memset(rdy, 255, 64);                              // (255: no packet there - or, in a malformed description, no TU under it)
+        for (int i = 0; i < n; i++) {
+          const TuTask& tt = SC.it[tix[i]];
+          const int nT = 1 << tt.log2_size;
+          if (tt.y0 + nT == R.y1) memset(rdy + ((tt.x0 - R.x0) >> 1), tt.run_level, (size_t)(nT >> 1));             // packets of the bottom row under this TU
+          if (tt.x0 + nT == R.x1) memset(rdy + 32 + ((tt.y0 - R.y0) >> 1), tt.run_level, (size_t)(nT >> 1));        // ... of the right column beside it
         }
       }
       o.c_idx = (uint8_t)R.c; o.micro = (uint8_t)(micro[order[k]] | (dense ? 2 : 0)); o.n_tus = (uint16_t)n;
@@ -1543,15 +1537,15 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
             else {
               n_groups = std::min(4, nv);
               for (int g2 = 0; g2 < n_groups; g2++) polls[g2] = vals[(g2 * nv) / n_groups];
-              uint8_t grp_of[256];                              // need epoch -> group (255 -> none)
-              { int g2 = 0; for (int v = 0; v < 255; v++) { while (g2 + 1 < n_groups && polls[g2 + 1] <= v) g2++; grp_of[v] = (uint8_t)g2; } grp_of[255] = 255; }
+              const int p1 = n_groups > 1 ? polls[1] : 256, p2 = n_groups > 2 ? polls[2] : 256, p3 = n_groups > 3 ? polls[3] : 256;
+              auto grp_of_v = [&](int v) { return v == 255 ? 255 : (v >= p1) + (v >= p2) + (v >= p3); };      // need epoch -> group (255: nobody reads it)
               // sub-segments of one group each (samples nobody reads are left out)
               for (int q = 0; q < nseg && phased; q++) {
                 const int cnt = (int)((seg[2 * q] >> 24) & 63) + 1;
                 const bool col = seg[2 * q] >> 31;
-                int start = 0, g_cur = grp_of[nbase[q][0]];
+                int start = 0, g_cur = grp_of_v(nbase[q][0]);
                 for (int off = 1; off <= cnt; off++) {
-                  const int g2 = off < cnt ? grp_of[nbase[q][off]] : 254;
+                  const int g2 = off < cnt ? grp_of_v(nbase[q][off]) : 254;
                   if (g2 == g_cur) continue;
                   if (g_cur != 255) {
                     if (nsub == 48) { phased = false; break; }
