@@ -516,7 +516,7 @@ int de265hip_decoder_new(de265hip_decoder** out, int device)
   if (const char* e = getenv("DE265HIP_TEST_SPIN_LIMIT")) d->spin_limit = (uint32_t)std::max(1, atoi(e));
   if (const char* rw = getenv("DE265HIP_RUN_WAVES")) d->run_waves = std::min(RUN_WAVES, std::max(1, atoi(rw)));
   if (const char* e = getenv("DE265HIP_LANES")) {
-    const int rc = de265hip_decoder_set_lanes(d, atoi(e));
+    const int rc = de265hip_decoder_set_lanes(d, std::min(kMaxLanes, std::max(1, atoi(e))));
     if (rc) { de265hip_decoder_free(d); return rc; }
   }
   *out = d;
