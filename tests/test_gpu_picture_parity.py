@@ -792,6 +792,10 @@ def test_lanes_overlap_independent_pictures_and_keep_the_result(lanes):
     w, h, bd = 1920, 1080, 10
     d = backend.Decoder()
     try:
+        for bad in (0, 5, -1):
+            with pytest.raises(backend.De265HipError) as e:
+                d.set_lanes(bad)
+            assert e.value.code == _abi.ERROR_PARAMETER_OUT_OF_RANGE
         d.set_lanes(lanes)
         sps, exp = _dag_pictures(w, h, bd)
         for s in set(x[2] for x in _DAG):
