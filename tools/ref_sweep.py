@@ -1,7 +1,8 @@
 """Build-container sweep: CPU restatement (oracle/) against the COMPILED REFERENCE (oracle/_ref) on random
 synthetic pictures, every stage, plus edge flags and boundary strengths.  Usage:
-    python tools/ref_sweep.py [seed] [n_small] [n_mid]
-Prints one line per mismatching case and a summary; exit code 1 on any mismatch."""
+    python tools/ref_sweep.py [seed] [n_small] [n_mid] [n_formats]
+n_formats: that many more small / mid-size pictures in the other chroma formats - 4:2:2 and 4:4:4 with the range-extension sample
+tools drawn at random, monochrome intra pictures.  Prints one line per mismatching case and a summary; exit code 1 on any mismatch."""
 import os
 import sys
 
@@ -65,13 +66,28 @@ def mid_config(rng):
     return w, h, bd, st, over
 
 
-def compare(w, h, bd, st, seed, over, stages=(0, 1, 2)):
+def format_config(rng, it):
+    """A small (two of three) or mid-size configuration in another chroma format."""
+    w, h, bd, st, over = mid_config(rng) if it % 3 == 2 else small_config(rng, it)
+    cf = int(rng.choice([0, 2, 2, 3, 3]))
+    over.update(tskip_pct=int(rng.choice([0, 20, 40])), implicit_rdpcm=int(rng.integers(0, 2)), rotation=int(rng.integers(0, 2)),
+                log2_max_tskip_size=int(rng.integers(2, 6)), intra_smoothing_disabled=int(rng.integers(0, 2)))
+    if cf == 0:
+        st = 2
+        over.update(monochrome=1)
+    else:
+        over.update(chroma_format=cf, explicit_rdpcm_pct=int(rng.choice([0, 50])), high_precision_offsets=int(rng.integers(0, 2)),
+                    cross_component_pct=int(rng.choice([0, 60])) if cf == 3 else 0)
+    return w, h, bd, st, over, cf
+
+
+def compare(w, h, bd, st, seed, over, stages=(0, 1, 2), cf=1):
     """Returns a list of mismatch descriptions (empty = identical)."""
     cfg = pysynth.default_config(w, h, bd, st, seed=seed, **over)
     sp = pysynth.SynthPicture(cfg)
     structure = sp.structure()
-    refs = {0: pysynth.fill_planes(w, h, bd, 100 + seed), 1: pysynth.fill_planes(w, h, bd, 200 + seed)}
-    init = pysynth.fill_planes(w, h, bd, 999)
+    refs = {} if cf == 0 else {0: pysynth.fill_planes(w, h, bd, 100 + seed, cf), 1: pysynth.fill_planes(w, h, bd, 200 + seed, cf)}
+    init = pysynth.fill_planes(w, h, bd, 999, cf)
     bad = []
     for stage in stages:
         a = [p.copy() for p in init]
@@ -128,6 +144,19 @@ def main():
             print("MID %d: %dx%d bd=%d st=%d %r" % (it, w, h, bd, st, over))
             for b in bad:
                 print("   ", b)
+    n_fmt = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    count = {0: 0, 2: 0, 3: 0}
+    for it in range(n_fmt):
+        w, h, bd, st, over, cf = format_config(rng, it)
+        bad = compare(w, h, bd, st, 13000 + seed * 100000 + it, over, cf=cf)
+        count[cf] += 1
+        if bad:
+            fails += 1
+            print("FORMAT %d: %dx%d bd=%d st=%d %r" % (it, w, h, bd, st, over))
+            for b in bad:
+                print("   ", b)
+    if n_fmt:
+        print("other formats: %d monochrome, %d 4:2:2, %d 4:4:4 pictures" % (count[0], count[2], count[3]))
     print("ref_sweep seed %d: %d small + %d mid pictures, %d with mismatches" % (seed, n_small, n_mid, fails))
     return 1 if fails else 0
 
