@@ -36,8 +36,12 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_i_pmc_traffic.json")
-PMC_KERNEL = {"intra": ["k_run<unsigned short, 64>"], "mc": ["k_mc<unsigned short>"], "sao": ["k_sao_ctb<unsigned short>"],
+PMC_FILE = os.path.join(ROOT, "profiles", os.environ.get("DE265HIP_PMC_FILE", "r04_pmc_traffic.json"))
+PMC_FALLBACK = os.path.join(ROOT, "profiles", "r03_i_pmc_traffic.json")
+# kernel id of the C ABI (de265hip_get_kernel_times) -> the kernels rocprofv3 names under it (tests/test_bench_launcher.py checks
+# every name against the kernels the library really holds)
+PMC_KERNEL = {"intra": ["k_run<unsigned short, 64>"], "intra_front": ["k_intra_front<unsigned short>"],
+              "mc": ["k_mc_all<unsigned short>"], "sao": ["k_sao_ctb<unsigned short>"],
               "deblock_v": ["k_deblock_fused<unsigned short>"],   # both directions in one kernel, reported under deblock_v
               "resid": ["k_resid_big<unsigned short>"]}     # all sizes in one launch
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
@@ -47,11 +51,13 @@ ALG_KEY = {"mc": "alg_bytes_mc", "resid": "alg_bytes_resid", "intra": "alg_bytes
            "deblock_v": "alg_bytes_deblock", "deblock_h": "alg_bytes_deblock", "sao": "alg_bytes_sao"}
 
 
-def make_gop(pysynth, farm, width, height, bit_depth, gop, seed):
+def make_gop(pysynth, farm, width, height, bit_depth, gop, seed, chroma_format=1):
     """Picture k is decoded into DPB slot k; B pictures reference slots k-1 and k-2 (farm.gop_plan)."""
     pics = []
     for k, (slice_type, refs) in enumerate(farm.gop_plan(gop)):
         over = dict(ref_slots=refs, weighted_pred=1 if (k % 10) == 5 else 0) if refs else {}
+        if chroma_format != 1:
+            over["chroma_format"] = chroma_format
         pics.append(pysynth.SynthPicture(pysynth.default_config(width, height, bit_depth, slice_type,
                                                                 seed=seed + k, **over)))
     return pics
@@ -106,26 +112,66 @@ class _stdout_to_stderr:
         os.close(self._saved)
 
 
-def host_cores():
-    """CPUs this process may keep busy: its affinity mask, capped by the CPU bandwidth quota of its cgroup (a container with
-    256 visible CPUs and cpu.max = "1600000 100000" has 16: threads beyond the quota are throttled, all of them at once)."""
+def host_cores(world=1, pinned=False):
+    """CPUs THIS RANK may keep busy: its affinity mask (its own share of it when the ranks are not pinned apart), capped by its
+    share of the CPU bandwidth quota of the job's cgroup (a container with 256 visible CPUs and cpu.max = "1600000 100000" has
+    16: threads beyond the quota are throttled, all of them at once - and all ranks of a node share that quota)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if not pinned:
+        n = max(1, n // max(1, world))
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]           # cgroup v2
         if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
+            n = min(n, max(1, int(int(quota) / int(period)) // max(1, world)))
     except (OSError, ValueError):
         try:                                                                        # cgroup v1
             quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
             period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
             if quota > 0 and period > 0:
-                n = min(n, max(1, quota // period))
+                n = min(n, max(1, (quota // period) // max(1, world)))
         except (OSError, ValueError):
             pass
     return n
 
 
-def product_pass(pipes, gops, stagger, steps=1):
+def pin_rank_to_its_cores(local_rank, world):
+    """Before the first GPU call of a rank process: restrict it (and every thread it starts later: the library's pipeline workers,
+    the submitters) to its share of the CPUs this job may use, so that N ranks on one node do not migrate over each other's
+    cores and caches.  The share comes from the NUMA node of the rank's GPU where /sys tells (the ranks whose GPUs hang off one
+    node split that node's CPUs), else from an even split of the affinity mask.  Returns (cpus, numa_node or None)."""
+    if not hasattr(os, "sched_setaffinity"):
+        return None, None
+    allowed = sorted(os.sched_getaffinity(0))
+    if world <= 1 or len(allowed) < 2 * world:
+        return None, None                                   # (nothing to split: the rank keeps the whole mask)
+    node = None
+    try:                                                    # GPU -> PCI device -> NUMA node (no HIP call: sysfs only)
+        cards = sorted(d for d in os.listdir("/sys/class/drm") if d.startswith("card") and d[4:].isdigit()
+                       and os.path.exists("/sys/class/drm/%s/device/numa_node" % d))
+        if local_rank < len(cards):
+            node = int(open("/sys/class/drm/%s/device/numa_node" % cards[local_rank]).read())
+            nodes = [int(open("/sys/class/drm/%s/device/numa_node" % c).read()) for c in cards[:world]]
+            if node >= 0:
+                cpus = set()
+                for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+                    a, _, b = part.partition("-")
+                    cpus.update(range(int(a), int(b or a) + 1))
+                mine = [c for c in allowed if c in cpus]
+                peers = [r for r in range(world) if nodes[r] == node]
+                if len(mine) >= 2 * len(peers):
+                    k = peers.index(local_rank)
+                    share = mine[k * len(mine) // len(peers):(k + 1) * len(mine) // len(peers)]
+                    os.sched_setaffinity(0, share)
+                    return share, node
+            node = None
+    except (OSError, ValueError, IndexError):
+        node = None
+    share = allowed[local_rank * len(allowed) // world:(local_rank + 1) * len(allowed) // world]
+    os.sched_setaffinity(0, share)
+    return share, node
+
+
+def product_pass(pipes, gops, stagger, steps=1, pinned=None):
     """`steps` steps through the product path: every picture of every stream is SUBMITTED to its decoder's pipeline
     (de265hip_pipeline_submit_desc: the library's own worker threads build it - host stage + pinned asynchronous upload -,
     launch it in decode order and free it).  submit() blocks while 4 n_workers + 4 pictures of that decoder are between
@@ -134,10 +180,25 @@ def product_pass(pipes, gops, stagger, steps=1):
     S, GOP = len(pipes), len(gops[0])
 
     def feed(s_i):
+        # with_copy_out: every picture leaves through de265hip_dpb_download_async into pinned host planes (a ring per stream: the
+        # ticket that used a buffer before is waited for before it is handed out again - what a player's output queue does)
+        ring = pinned[s_i] if pinned else None
+        tickets = [None] * (len(ring) if ring else 0)
+        n = 0
         for _ in range(steps):
             for j in range(GOP):
                 k = (j + s_i * (GOP // S)) % GOP if stagger else j
-                pipes[s_i].submit_desc(k, gops[s_i][k].desc)
+                if ring:
+                    b = n % len(ring)
+                    if tickets[b] is not None:
+                        pipes[s_i].wait(tickets[b])
+                    tickets[b] = pipes[s_i].submit_desc(k, gops[s_i][k].desc, ring[b])
+                    n += 1
+                else:
+                    pipes[s_i].submit_desc(k, gops[s_i][k].desc)
+        for t in tickets:
+            if t is not None:
+                pipes[s_i].wait(t)
 
     if S == 1:
         feed(0)
@@ -146,7 +207,7 @@ def product_pass(pipes, gops, stagger, steps=1):
         list(pool.map(feed, range(S)))
 
 
-def cpu_baseline(gops, decs, W, H, BD, GOP, full=True):
+def cpu_baseline(gops, decs, W, H, BD, GOP, full=True, CF=1):
     """libde265's own pixel-reconstruction path on this box's host cores, next to the GPU number (a reported baseline, not
     the target).  kind "reference": the compiled reference (oracle/_ref/libde265_ref.so: libde265's decoder sources built
     with plain g++, scalar fallback DSP -- what the reference itself runs for 10-bit, x86/sse.cc:67-100 overrides 8-bit
@@ -163,7 +224,7 @@ def cpu_baseline(gops, decs, W, H, BD, GOP, full=True):
     def decode_gop(g):
         planes = {}
         for k in range(GOP):
-            out = pyoracle.alloc_planes(W, H, BD)
+            out = pyoracle.alloc_planes(W, H, BD, chroma_format=CF)
             if kind == "reference":
                 pyref.reconstruct(g[k].desc, g[k].order, planes, out, g[k].structure())
             else:
@@ -204,6 +265,11 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--bit-depth", type=int, default=10)
+    ap.add_argument("--chroma-format", type=int, default=1, choices=[1, 2, 3],
+                    help="chroma_format_idc of the workload: 1 = 4:2:0 (the headline), 2 = 4:2:2, 3 = 4:4:4 (range extensions, SURVEY 8 f4)")
+    ap.add_argument("--no-copy-out", action="store_true",
+                    help="skip the with_copy_out leg (product path with every picture copied out to pinned host memory)")
+    ap.add_argument("--no-affinity", action="store_true", help="N > 1: do not pin the rank to its share of the host's CPUs")
     ap.add_argument("--gop", type=int, default=16)
     ap.add_argument("--streams", type=int, default=int(os.environ.get("DE265HIP_BENCH_STREAMS", "3")),
                     help="independent closed GOPs decoded concurrently per GPU (one decoder/HIP stream each)")
@@ -242,6 +308,8 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
+    # host placement BEFORE anything touches the GPU (and before the threads of torch / the library exist): this rank's cores
+    cpus, numa = (None, None) if args.no_affinity else pin_rank_to_its_cores(rank if args.single_device else local_rank, world)
     if args.dry_run:
         if os.environ.get("DE265HIP_BENCH_FAIL_RANK") == str(rank):     # (launcher test: a rank that dies early)
             raise SystemExit(3)
@@ -280,9 +348,30 @@ def main():
             dist.all_gather(allv, me)
             open_gop = {"handoffs": world - 1, "ms_per_handoff": round(1e3 * t_x / (world - 1), 3),
                         "checksum_ok": all(int(allv[r + 1][1]) == int(allv[r][0]) for r in range(world - 1))}
+        # every rank's share of the host, gathered: a SCALE record can then be read as host-bound or not
+        cores = host_cores(world, pinned=cpus is not None)
+        nthr = args.host_threads if args.host_threads > 0 else max(1, min(16, cores))
+        shares = [(len(cpus) if cpus else None, nthr)]
+        if world > 1:
+            import torch
+            t_ = torch.tensor([len(cpus) if cpus else -1, nthr], dtype=torch.int64)
+            allv = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(allv, t_)
+            shares = [(int(v[0]) if int(v[0]) >= 0 else None, int(v[1])) for v in allv]
+        disjoint = None
+        if world > 1 and cpus:
+            import torch
+            mask = torch.zeros(4096, dtype=torch.int64)
+            mask[torch.tensor(cpus)] = 1
+            dist.all_reduce(mask)
+            disjoint = bool(int(mask.max()) <= 1)
         if rank == 0:
             print(json.dumps({"metric": "decoded frames/sec (4K Main10)", "value": None, "unit": "frames/s", "n_gpus": world,
                               "steps": args.steps, "warmup": args.warmup, "dry_run": True, "units_all_ranks": units,
+                              "config": {"chroma_format": args.chroma_format, "host_threads_per_rank": [s_[1] for s_ in shares],
+                                         "rank_cpus": [s_[0] for s_ in shares], "rank_cpu_sets_disjoint": disjoint,
+                                         "device_replay_over_value": None},
+                              "with_copy_out": None if args.no_copy_out else {"value": None},
                               "open_gop": open_gop, "ms_per_step": round(1e3 * elapsed / max(1, args.steps), 3)}))
         if world > 1:
             dist.destroy_process_group()
@@ -308,15 +397,17 @@ def main():
                 dist.barrier()              # (gloo connects lazily: its banner comes with the first collective)
     red_dev = "cuda" if args.backend == "nccl" else "cpu"
 
-    W, H, BD, GOP, S = args.width, args.height, args.bit_depth, args.gop, max(1, args.streams)
+    W, H, BD, GOP, S, CF = args.width, args.height, args.bit_depth, args.gop, max(1, args.streams), args.chroma_format
+    if args.open_gop and GOP >= backend._abi.MAX_DPB_SLOTS:
+        raise SystemExit("bench.py: --open-gop needs a free DPB slot beside the GOP's %d (at most %d slots)" % (GOP, backend._abi.MAX_DPB_SLOTS))
     gops, decs, pics = [], [], []
     for s_i in range(S):
-        g = make_gop(pysynth, farm, W, H, BD, GOP, farm.gop_seed(CONFIG_ID, rank, s_i))
+        g = make_gop(pysynth, farm, W, H, BD, GOP, farm.gop_seed(CONFIG_ID, rank, s_i), CF)
         d = backend.Decoder(device=local_rank)
         if args.lanes > 1:
             d.set_lanes(args.lanes)
         for k in range(GOP):
-            d.dpb_alloc(k, W, H, BD)
+            d.dpb_alloc(k, W, H, BD, chroma_format=CF)
         gops.append(g); decs.append(d)
         pics.append([d.build(k, g[k].desc) for k in range(GOP)])  # inputs now resident in HBM
     gop, dec = gops[0], decs[0]
@@ -379,9 +470,9 @@ def main():
 
     # ---- (2) the product path, THE TIMED REGION of this bench: every picture built, launched and freed through the C ABI
     elapsed, ktimes, product = replay_elapsed, ktimes_replay, None
-    cores = host_cores()
+    cores = host_cores(world, pinned=cpus is not None)   # this rank's share
     if not args.no_host_inclusive:
-        nthr = args.host_threads if args.host_threads > 0 else max(1, min(16, cores // max(1, world)))
+        nthr = args.host_threads if args.host_threads > 0 else max(1, min(16, cores))
         per = max(1, min(16, nthr // S))                 # worker threads of each decoder's pipeline
         for ps in pics:                                  # the prebuilt pictures go back to the pools
             for p_ in ps:
@@ -407,6 +498,37 @@ def main():
         ktimes = collect()
         for d in decs:
             d.set_profiling(False)
+        # ---- (2b) the same product path with every decoded picture DELIVERED: copied out through de265hip_dpb_download_async
+        # into pinned host planes inside the timed region (what de265_get_image_plane hands an application), PCIe included
+        copy_out = None
+        if not args.no_copy_out:
+            ring_n = 4
+            rings = [[backend.PinnedPlanes(W, H, BD, chroma_format=CF) for _ in range(ring_n)] for _ in range(S)]
+            product_pass(pipes, gops, args.stagger, pinned=rings)
+            drain()
+            tm = farm.RankTimer(dist, sync, device=red_dev)
+            tm.start()
+            product_pass(pipes, gops, args.stagger, steps=args.steps, pinned=rings)
+            drain()
+            t_co = tm.stop()
+            pic_bytes = sum(p_.nbytes for p_ in rings[0][0].planes)
+            copy_out = {"value": round(world * args.steps * GOP * S / t_co, 2), "unit": "frames/s",
+                        "ms_per_step": round(1e3 * t_co / args.steps, 3), "bytes_per_picture": int(pic_bytes),
+                        "d2h_GBs": round(world * args.steps * GOP * S * pic_bytes / 1e9 / t_co, 2),
+                        "what": "product path + de265hip_dpb_download_async of every picture into pinned host planes (ring of %d per "
+                                "stream, the ticket that held a buffer is waited for before its reuse), inside the timed region" % ring_n}
+            # the last picture each stream delivered must be the one the device holds
+            import numpy as _np
+            ok = True
+            for s_i in range(S):
+                k_last = ((GOP - 1) + s_i * (GOP // S)) % GOP if args.stagger else GOP - 1
+                got = decs[s_i].download(k_last, W, H, BD)
+                b = (args.steps * GOP - 1) % ring_n
+                ok = ok and all(_np.array_equal(g_, e_) for g_, e_ in zip(got, rings[s_i][b].planes))
+            copy_out["delivered_equals_dpb"] = bool(ok)
+            for r_ in rings:
+                for pp2 in r_:
+                    pp2.free()
         for pp_ in pipes:
             pp_.close()
         # one host thread: stream 0 alone through a one-worker pipeline
@@ -417,19 +539,21 @@ def main():
         t1 = time.perf_counter() - t1
         one.close()
         product = {"host_threads": per * S, "workers_per_decoder": per, "host_cores_available": cores,
-                   "value_1_host_thread": round(GOP / t1, 2),
+                   "host_threads_per_rank": per * S, "rank_cpus": len(cpus) if cpus else None, "rank_numa_node": numa,
+                   "value_1_host_thread": round(GOP / t1, 2), "with_copy_out": copy_out,
                    "what": "de265hip_pipeline_submit_desc per picture: the library's worker threads run de265hip_picture_build (host stage + "
                            "pinned asynchronous upload), launch in decode order (de265hip_picture_run) and free; decoded pictures stay in the "
                            "device-resident DPB (no copy-out in the timed region)"}
         pics = [[d.build(k, g[k].desc) for k in range(GOP)] for d, g in zip(decs, gops)]   # (for the isolated pass below)
+        stats = [p.stats() for ps in pics for p in ps]
 
     # ---- (3) open-GOP hand-off, timed separately from `value`: the last picture of a GOP of rank r
     # goes to rank r + 1 (DPB slot GOP, beside the receiver's own GOP).  RCCL point-to-point on the DPB planes with
     # --backend nccl; a gloo rehearsal stages through the host (gloo sends CPU tensors only).
     open_gop = None
     if args.open_gop and world > 1:
-        slot_in = GOP if GOP < 20 else 19
-        decs[0].dpb_alloc(slot_in, W, H, BD)
+        slot_in = GOP                                     # (a free slot beside the GOP's: checked at start-up)
+        decs[0].dpb_alloc(slot_in, W, H, BD, chroma_format=CF)
         sync()
         tm = farm.RankTimer(dist, sync, device=red_dev)
         tm.start()
@@ -439,7 +563,7 @@ def main():
             else:
                 farm.exchange_reference_picture_host(dist, decs[0], GOP - 1, slot_in, r, r + 1, rank, W, H, BD)
         t_x = tm.stop()
-        nbytes = W * H * 3 // 2 * (2 if BD > 8 else 1)
+        nbytes = sum(r_ * c_ for r_, c_ in farm.plane_shapes(W, H, CF)) * (2 if BD > 8 else 1)
         open_gop = {"handoffs": world - 1, "ms_per_handoff": round(1e3 * t_x / (world - 1), 3), "bytes_per_picture": nbytes,
                     "GBs": round(nbytes / 1e9 / (t_x / (world - 1)), 2), "transport": "rccl p2p on DPB planes" if args.backend == "nccl" else "gloo via host (rehearsal)",
                     "checksum_ok": farm.check_handoff(dist, decs[0], GOP - 1, slot_in, rank, world, W, H, BD, device=red_dev)}
@@ -474,8 +598,8 @@ def main():
         # for gfx950 (MI355X_MICROARCH.md, HBM).  Only valid for the default 4K 10-bit workload.
         traffic = None
         try:
-            if (W, H, BD, GOP) == (3840, 2160, 10, 16) and dom in PMC_KERNEL:
-                pk = json.load(open(PMC_FILE))["kernels"]
+            if (W, H, BD, GOP, CF) == (3840, 2160, 10, 16, 1) and dom in PMC_KERNEL:
+                pk = json.load(open(PMC_FILE if os.path.exists(PMC_FILE) else PMC_FALLBACK))["kernels"]
                 traffic = int(sum((2 * pk[k]["fetch_kb_per_launch"] + pk[k]["write_kb_per_launch"]) * 1024
                                   for k in PMC_KERNEL[dom]))
         except Exception:
@@ -513,7 +637,7 @@ def main():
         cpu = None
         parity = "not checked"
         if not args.no_cpu_baseline:
-            cpu, parity = cpu_baseline(gops, decs, W, H, BD, GOP, full=(world == 1))
+            cpu, parity = cpu_baseline(gops, decs, W, H, BD, GOP, full=(world == 1), CF=CF)
         if product is not None:
             region = ("product path: every picture of the step goes build -> run -> free through the C ABI inside the timed region "
                       "(%d host threads in the library's pipelines); device_replay is the device alone" % product["host_threads"])
@@ -524,16 +648,20 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u16" if BD > 8 else "u8", "data": "synthetic",
-            "config": {"workload": "%dx%d %d-bit 4:2:0 random-access closed GOPs of %d pictures (1 I + %d B, 2 refs), "
+            "config": {"workload": "%dx%d %d-bit %s random-access closed GOPs of %d pictures (1 I + %d B, 2 refs), "
                                    "%d independent GOP(s) in flight per GPU, all stages on device"
-                                   % (W, H, BD, GOP, GOP - 1, S),
+                                   % (W, H, BD, {1: "4:2:0", 2: "4:2:2", 3: "4:4:4"}[CF], GOP, GOP - 1, S),
                        "timed_region": region,
                        "gop": GOP, "streams_per_gpu": S, "lanes_per_decoder": args.lanes, "pictures_per_step": GOP * S,
                        "host_threads": product["host_threads"] if product else 0, "host_cores_available": cores,
+                       "host_threads_per_rank": product["host_threads_per_rank"] if product else 0,
+                       "device_replay_over_value": round(device_replay["value"] / fps, 2) if fps > 0 else None,
+                       "bound": ("host (the device alone sustains %.1fx this rate)" % (device_replay["value"] / fps)
+                                 if device_replay["value"] > 1.15 * fps else "device") if product else "device replay",
                        "events_in_timed_region": "every kernel" if args.events == "all" else "dominant kernel (%s) only" % dom,
                        "parallelism": "%d gop stream(s) x %d gpu(s)" % (S, world)},
             "roofline": roofline, "roofline_aggregate": aggregate, "cpu_baseline": cpu, "device_replay": device_replay,
-            "product_path": product, "open_gop": open_gop, "parity_vs_reference": parity, "kernels": kernels,
+            "product_path": product, "with_copy_out": product["with_copy_out"] if product else None, "open_gop": open_gop, "parity_vs_reference": parity, "kernels": kernels,
             "kernels_isolated": kernels_iso,
         }
         print(json.dumps(line))

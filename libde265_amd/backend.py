@@ -209,10 +209,12 @@ class Pipeline:
 class PinnedPlanes:
     """three planes in de265hip_host_alloc memory (numpy views in .planes), for asynchronous copy-outs"""
 
-    def __init__(self, width, height, bit_depth):
+    def __init__(self, width, height, bit_depth, chroma_format=1):
         dt = np.uint16 if bit_depth > 8 else np.uint8
         self.ptrs, self.planes, self.strides = [], [], []
-        for sh in [(height, width), (height // 2, width // 2), (height // 2, width // 2)]:
+        cw = 0 if chroma_format == 0 else (width if chroma_format == 3 else width // 2)      # SubWidthC / SubHeightC (sps.cc:540-552)
+        ch = 0 if chroma_format == 0 else (height // 2 if chroma_format == 1 else height)
+        for sh in [(height, width), (ch, cw), (ch, cw)]:
             nbytes = sh[0] * sh[1] * np.dtype(dt).itemsize
             ptr = lib().de265hip_host_alloc(nbytes)
             if not ptr:

@@ -87,24 +87,44 @@ class _DevPlane:
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
 
-def dpb_plane_tensors(dec, slot):
-    """Zero-copy torch uint8 views (pitch x rows, padding included) of the three planes of a decoder's DPB slot
-    (de265hip_dpb_plane).  The caller orders access: dec.sync() before another stream reads them, and
-    torch.cuda.synchronize() (or an event) before the decoder's kernels read what torch wrote."""
-    import torch          # (import torch before the first libde265_hip.so call in such a process: tests/conftest.py)
+def plane_rows(dec, slot):
+    """Rows of the three planes of a DPB slot: the chroma planes follow the slot's chroma_format_idc
+    (de265hip_dpb_chroma_format; SubHeightC is 2 for 4:2:0 only, a monochrome slot has empty chroma planes)."""
     w, h, _, _ = dec.dpb_info(slot)
+    _, ch = dec._chroma_dims(slot, w, h)
+    return [h, ch, ch]
+
+
+def dpb_plane_tensors(dec, slot):
+    """Zero-copy torch uint8 views (pitch x rows, padding included) of the planes of a decoder's DPB slot
+    (de265hip_dpb_plane); empty planes (monochrome chroma) are left out.  The caller orders access: dec.sync() before
+    another stream reads them, and torch.cuda.synchronize() (or an event) before the decoder's kernels read what torch wrote."""
+    import torch          # (import torch before the first libde265_hip.so call in such a process: tests/conftest.py)
     views = []
-    for c in range(3):
+    for c, rows in enumerate(plane_rows(dec, slot)):
         ptr, stride_bytes = dec.plane(slot, c)
-        rows = h // 2 if c else h
-        views.append(torch.as_tensor(_DevPlane(ptr, stride_bytes * rows), device="cuda"))
+        if rows:
+            views.append(torch.as_tensor(_DevPlane(ptr, stride_bytes * rows), device="cuda"))
     return views
+
+
+def dpb_slot_tensor(dec, slot):
+    """The whole slot as ONE zero-copy uint8 view: a slot is one device allocation, luma first, so a picture
+    crosses xGMI in one message instead of three.  Two slots of the same geometry (size, bit depths, chroma format) have the
+    same layout, whichever decoder or rank owns them."""
+    import torch
+    rows = plane_rows(dec, slot)
+    p0, _ = dec.plane(slot, 0)
+    last = max(c for c in range(3) if rows[c])
+    pl, sl = dec.plane(slot, last)
+    return torch.as_tensor(_DevPlane(p0, pl + sl * rows[last] - p0), device="cuda")
 
 
 def send_reference_picture_dpb(dist, dec, slot, src, dst, rank):
     """Open-GOP exchange between ranks on the planes where they live: rank `src` sends DPB slot `slot` of its decoder
-    to rank `dst` (RCCL point-to-point over xGMI, 24.9 MB per 4K Main10 picture), which receives into the same slot of
-    its own decoder (already dpb_alloc'ed to the same geometry).  No host staging, no collective for the other ranks."""
+    to rank `dst` (RCCL point-to-point over xGMI, one message per picture: 24.9 MB at 4K Main10 4:2:0), which receives into
+    the same slot of its own decoder (already dpb_alloc'ed to the same geometry, chroma format included).  No host staging,
+    no collective for the other ranks."""
     import torch
     if rank not in (src, dst):
         return
@@ -112,11 +132,11 @@ def send_reference_picture_dpb(dist, dec, slot, src, dst, rank):
     # enqueued (pictures that still read the slot's old content as a reference, a copy-out of it) is done before RCCL,
     # which runs on torch's stream, overwrites the slot
     dec.sync()
-    for t in dpb_plane_tensors(dec, slot):
-        if rank == src:
-            dist.send(t, dst=dst)
-        else:
-            dist.recv(t, src=src)
+    t = dpb_slot_tensor(dec, slot)
+    if rank == src:
+        dist.send(t, dst=dst)
+    else:
+        dist.recv(t, src=src)
     torch.cuda.synchronize()                         # received planes are in place before the decoder's stream reads them
 
 
@@ -125,8 +145,7 @@ def broadcast_reference_picture_dpb(dist, dec, slot, src, rank, group=None):
     prefer send_reference_picture_dpb to the actual consumers when they are few)."""
     import torch
     dec.sync()                                       # (sender: picture finished; receivers: nothing queued still uses the slot)
-    for t in dpb_plane_tensors(dec, slot):
-        dist.broadcast(t, src=src, group=group)
+    dist.broadcast(dpb_slot_tensor(dec, slot), src=src, group=group)
     torch.cuda.synchronize()
 
 
@@ -137,12 +156,21 @@ def exchange_reference_picture_dpb(dist, dec, src_slot, dst_slot, src, dst, rank
     if rank not in (src, dst):
         return
     dec.sync()                                       # sender: the picture is finished; receiver: nothing queued still uses the slot
-    for t in dpb_plane_tensors(dec, src_slot if rank == src else dst_slot):
-        if rank == src:
-            dist.send(t, dst=dst)
-        else:
-            dist.recv(t, src=src)
+    t = dpb_slot_tensor(dec, src_slot if rank == src else dst_slot)
+    if rank == src:
+        dist.send(t, dst=dst)
+    else:
+        dist.recv(t, src=src)
     torch.cuda.synchronize()
+
+
+def plane_shapes(width, height, chroma_format=1):
+    """(rows, columns) of the three planes of a picture: SubWidthC / SubHeightC by chroma_format_idc (sps.cc:540-552)."""
+    if chroma_format == 0:
+        return [(height, width), (0, 0), (0, 0)]
+    cw = width if chroma_format == 3 else width // 2
+    ch = height // 2 if chroma_format == 1 else height
+    return [(height, width), (ch, cw), (ch, cw)]
 
 
 def exchange_reference_picture_host(dist, dec, src_slot, dst_slot, src, dst, rank, width, height, bit_depth):
@@ -152,13 +180,16 @@ def exchange_reference_picture_host(dist, dec, src_slot, dst_slot, src, dst, ran
     import torch
     if rank == src:
         for p in dec.download(src_slot, width, height, bit_depth):
-            dist.send(torch.from_numpy(np.ascontiguousarray(p).view(np.uint8).reshape(-1)), dst=dst)
+            if p.size:                                   # (monochrome: the empty chroma planes are not sent)
+                dist.send(torch.from_numpy(np.ascontiguousarray(p).view(np.uint8).reshape(-1)), dst=dst)
     elif rank == dst:
         dt = np.uint16 if bit_depth > 8 else np.uint8
         planes = []
-        for (h, w) in ((height, width), (height // 2, width // 2), (height // 2, width // 2)):
+        cw, ch = dec._chroma_dims(dst_slot, width, height)      # (the receiving slot was dpb_alloc'ed with the sender's chroma format)
+        for (h, w) in ((height, width), (ch, cw), (ch, cw)):
             buf = torch.empty(h * w * np.dtype(dt).itemsize, dtype=torch.uint8)
-            dist.recv(buf, src=src)
+            if h * w:
+                dist.recv(buf, src=src)
             planes.append(buf.numpy().view(dt).reshape(h, w))
         dec.upload(dst_slot, planes)
 

@@ -59,3 +59,40 @@ def test_open_gop_leg_hands_the_last_picture_to_the_next_rank():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.splitlines()[-1])
     assert out["n_gpus"] == 3 and out["open_gop"]["handoffs"] == 2 and out["open_gop"]["checksum_ok"] is True
+
+
+def test_new_switches_and_per_rank_host_placement():
+    """--chroma-format, the with_copy_out leg and the per-rank host placement: the line names the
+    chroma format, carries a with_copy_out object unless --no-copy-out, and says how many host threads and CPUs every rank has;
+    ranks that were pinned apart hold disjoint CPU sets."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--dry-run", "--chroma-format", "3"], env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.splitlines()[-1])
+    cfg = out["config"]
+    assert cfg["chroma_format"] == 3 and "device_replay_over_value" in cfg
+    assert len(cfg["host_threads_per_rank"]) == 2 and all(t >= 1 for t in cfg["host_threads_per_rank"])
+    assert out["with_copy_out"] is not None
+    if len(os.sched_getaffinity(0)) >= 4:                     # enough CPUs to split between two ranks
+        assert cfg["rank_cpu_sets_disjoint"] is True and all(c and c >= 2 for c in cfg["rank_cpus"])
+    r = subprocess.run([sys.executable, BENCH, "--steps", "2", "--dry-run", "--no-copy-out", "--no-affinity"], env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.splitlines()[-1])
+    assert out["with_copy_out"] is None and out["config"]["chroma_format"] == 1 and out["config"]["rank_cpus"] == [None]
+
+
+def test_pmc_kernel_names_are_kernels_of_the_library():
+    """bench.py maps kernel ids to the names rocprofv3 prints (roofline.traffic is looked up under them): every name must be a
+    kernel the built library really holds (round 2 and 3 each had one stale name here)."""
+    import re
+    sys.path.insert(0, ROOT)
+    import bench
+    from libde265_amd import backend
+    blob = open(backend.SO_PATH, "rb").read()
+    for kid, names in bench.PMC_KERNEL.items():
+        for n in names:
+            base = re.match(r"(k_[a-z0-9_]+)<", n).group(1)
+            assert re.search(rb"_ZN4d265" + str(len(base)).encode() + base.encode() + rb"I", blob), (kid, n)
+    from libde265_amd import _abi
+    assert set(bench.PMC_KERNEL) <= set(_abi.K_NAMES)

@@ -80,3 +80,70 @@ def test_two_rank_gop_farm():
     assert len({g for g, _ in d0 + d1}) == 4 and len({s for _, s in d0 + d1}) == 4   # different GOPs, different content
     assert s1 == s0 == d0[-1][1]                                 # rank 1 received rank 0's last picture
     assert dep0 == dep1                                          # dependent picture decodes identically on both
+
+
+class _StubDecoder:
+    """What exchange_reference_picture_host needs of a decoder, on numpy planes (no GPU): download, upload, _chroma_dims."""
+
+    def __init__(self, chroma_format):
+        self.cf, self.slots = chroma_format, {}
+
+    def _chroma_dims(self, slot, w, h):
+        if self.cf == 0:
+            return (0, 0)
+        return (w if self.cf == 3 else w // 2, h // 2 if self.cf == 1 else h)
+
+    def download(self, slot, w, h, bd):
+        return self.slots[slot]
+
+    def upload(self, slot, planes):
+        self.slots[slot] = [p.copy() for p in planes]
+
+
+def _handoff_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from libde265_amd import farm
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = True
+    W, H = 64, 48
+    for cf, bd in ((1, 8), (2, 10), (3, 10), (3, 8), (0, 8)):
+        dec = _StubDecoder(cf)
+        shapes = farm.plane_shapes(W, H, cf)
+        dt = np.uint16 if bd > 8 else np.uint8
+        rng = np.random.default_rng(100 * cf + bd)           # both ranks draw the same picture; only rank 0 keeps it
+        planes = [rng.integers(0, 1 << bd, sh, dtype=dt) for sh in shapes]
+        if rank == 0:
+            dec.slots[3] = planes
+        farm.exchange_reference_picture_host(dist, dec, 3, 5, 0, 1, rank, W, H, bd)
+        if rank == 1:
+            got = dec.slots[5]
+            ok = ok and [g.shape for g in got] == [tuple(sh) for sh in shapes]
+            ok = ok and all(np.array_equal(g, e) for g, e in zip(got, planes))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_handoff_of_every_chroma_format():
+    """The open-GOP hand-over takes its plane geometry from the slot's chroma format (4:2:2 and 4:4:4 chroma planes are as
+    high as the luma plane; a monochrome slot has none): every format arrives whole on the receiving rank."""
+    import torch.multiprocessing as mp
+    from libde265_amd import farm
+    assert farm.plane_shapes(64, 48, 1) == [(48, 64), (24, 32), (24, 32)]
+    assert farm.plane_shapes(64, 48, 2) == [(48, 64), (48, 32), (48, 32)]
+    assert farm.plane_shapes(64, 48, 3) == [(48, 64), (48, 64), (48, 64)]
+    assert farm.plane_shapes(64, 48, 0) == [(48, 64), (0, 0), (0, 0)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_handoff_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]

@@ -468,6 +468,44 @@ def test_reference_picture_exchange_on_dpb_planes(dec):
         d2.close()
 
 
+@pytest.mark.parametrize("cf", [2, 3, 0])
+def test_reference_picture_exchange_of_other_chroma_formats(cf):
+    """The hand-over views follow the slot's chroma format (4:2:2 / 4:4:4 chroma planes are as high as the luma plane, a
+    monochrome slot has none): the planes of a slot, and the slot as ONE message (farm.dpb_slot_tensor), arrive whole."""
+    import torch
+    from libde265_amd import backend, farm
+    w, h, bd = 352, 288, 10
+    pl = pysynth.fill_planes(w, h, bd, 31 + cf)
+    shapes = farm.plane_shapes(w, h, cf)
+    planes = [np.ascontiguousarray(np.resize(p, sh)) if sh[0] else np.zeros((0, 0), p.dtype) for p, sh in zip([pl[0], pl[1], pl[2]], shapes)]
+    a, b = backend.Decoder(), backend.Decoder()
+    try:
+        for d in (a, b):
+            for s in (1, 2):
+                d.dpb_alloc(s, w, h, bd, chroma_format=cf)
+        a.upload(1, planes)
+        assert farm.plane_rows(a, 1) == [sh[0] for sh in shapes]
+        src, dst = farm.dpb_plane_tensors(a, 1), farm.dpb_plane_tensors(b, 1)
+        assert len(src) == (1 if cf == 0 else 3)
+        a.sync()
+        for x, y in zip(src, dst):
+            assert x.numel() == y.numel()
+            y.copy_(x)
+        one_src, one_dst = farm.dpb_slot_tensor(a, 1), farm.dpb_slot_tensor(b, 2)      # the whole slot in one message
+        assert one_src.numel() == one_dst.numel() >= sum(t.numel() for t in src)
+        one_dst.copy_(one_src)
+        torch.cuda.synchronize()
+        for s in (1, 2):
+            got = b.download(s, w, h, bd)
+            assert [g.shape for g in got] == [tuple(sh) for sh in shapes]
+            assert all(np.array_equal(g, e) for g, e in zip(got, planes))
+        pp = backend.PinnedPlanes(w, h, bd, chroma_format=cf)
+        assert [p.shape for p in pp.planes] == [tuple(sh) for sh in shapes]
+        pp.free()
+    finally:
+        a.close(); b.close()
+
+
 def test_concurrent_builds_on_one_decoder(dec):
     """de265hip_picture_build / _free from several host threads on ONE decoder (include/de265_hip.h THREADS; what
     bench.py's host_inclusive leg does): the pools and the live list are shared, every picture still comes out right."""
