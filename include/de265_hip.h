@@ -384,6 +384,16 @@ int  de265hip_debug_build_host_only(const de265hip_picture_desc*, int reps);
 /* FNV-1a hash over everything the last de265hip_debug_build_host_only of this thread would have uploaded (regression
  * net for changes to the host stage: tools/exp/build_hash.py). */
 uint64_t de265hip_debug_last_build_hash(void);
+/* mode 0: the round-3 host scan of the TU records; 1: the host's part of a build with the device-side scan (scan_core.h); 2: the
+ * same plus the CPU rehearsal of the scan's passes.  keep: the last picture, its arena in host memory (de265hip_debug_picture_*,
+ * de265hip_picture_free). */
+int  de265hip_debug_build_host_only_ex(const de265hip_picture_desc*, int reps, int mode, de265hip_picture** keep);
+/* Test entry points: fault injection (a run other runs wait for is left out of the pictures built from now on; spin_limit
+ * bounds k_run's dependency waits, 0 = default), and read-back of a picture's run-side structures (offsets and counts, then
+ * bytes of its arena) for tests/test_scan_equivalence.py. */
+int  de265hip_debug_fault_injection(de265hip_decoder*, int drop_producer, uint32_t spin_limit);
+int  de265hip_debug_picture_layout(de265hip_picture*, int64_t out[32]);
+int  de265hip_debug_picture_read(de265hip_picture*, int64_t offset, int64_t bytes, void* dst);
 
 /* Introspection used by bench/tests */
 typedef struct de265hip_picture_stats {

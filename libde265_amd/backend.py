@@ -21,7 +21,8 @@ EXPORTS = [
     "de265hip_dpb_alloc", "de265hip_dpb_alloc_ex", "de265hip_dpb_chroma_format", "de265hip_dpb_upload", "de265hip_dpb_download", "de265hip_dpb_plane", "de265hip_dpb_info",
     "de265hip_dpb_copy", "de265hip_dpb_download_async", "de265hip_dpb_wait", "de265hip_host_alloc", "de265hip_host_free",
     "de265hip_pipeline_new", "de265hip_pipeline_submit", "de265hip_pipeline_submit_desc", "de265hip_pipeline_wait", "de265hip_pipeline_drain", "de265hip_pipeline_free",
-    "de265hip_debug_build_host_only", "de265hip_debug_last_build_hash",
+    "de265hip_debug_build_host_only", "de265hip_debug_last_build_hash", "de265hip_debug_build_host_only_ex",
+    "de265hip_debug_fault_injection", "de265hip_debug_picture_layout", "de265hip_debug_picture_read",
     "de265hip_picture_build", "de265hip_picture_run", "de265hip_decoder_sync", "de265hip_picture_free",
     "de265hip_decode_picture", "de265hip_picture_get_stats",
     "de265hip_set_profiling", "de265hip_get_kernel_times", "de265hip_derive_edge_flags", "de265hip_intra_used_units",
@@ -83,6 +84,10 @@ def lib():
     L.de265hip_pipeline_free.argtypes = [vp]
     L.de265hip_pipeline_free.restype = None
     L.de265hip_debug_build_host_only.argtypes = [pp(_abi.PictureDesc), i32]
+    L.de265hip_debug_build_host_only_ex.argtypes = [pp(_abi.PictureDesc), i32, i32, pp(vp)]
+    L.de265hip_debug_fault_injection.argtypes = [vp, i32, C.c_uint32]
+    L.de265hip_debug_picture_layout.argtypes = [vp, pp(C.c_int64)]
+    L.de265hip_debug_picture_read.argtypes = [vp, C.c_int64, C.c_int64, vp]
     L.de265hip_debug_last_build_hash.restype = C.c_uint64
     L.de265hip_debug_last_build_hash.argtypes = []
     L.de265hip_picture_build.argtypes = [vp, i32, pp(_abi.PictureDesc), pp(vp)]

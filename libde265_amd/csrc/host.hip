@@ -15,7 +15,10 @@
 #include <mutex>
 #include <chrono>
 
+#include <deque>
+
 #include "kernels.h"
+#include "scan.h"
 
 using namespace d265;
 
@@ -40,6 +43,7 @@ struct Slot {
   // slot next (a new picture, an upload) or frees it waits for it.  dl_seq counts the copy-outs (dpb_wait compares it).
   hipEvent_t dl_done = nullptr;
   uint64_t dl_seq = 0, dl_waited = 0;
+  int err_idx = -1; uint64_t err_seq = 0;          // error-ring entry of the picture last decoded into the slot
   // Lanes (de265hip_decoder_set_lanes > 1): who wrote the slot's picture and who reads it, as events on the lanes' streams.
   // written: recorded behind the picture that was decoded into the slot (writer_lane >= 0) or behind a copy into it from
   // another decoder (kForeignWriter: every lane waits for it); read_done[l]: behind the latest picture of lane l that
@@ -58,7 +62,8 @@ struct PendingEvent { int kid; hipEvent_t a, b; };
 // Pooled device arena of one picture's command buffers.  last_use: recorded on the decoder's stream when the
 // picture that used the arena is freed; the next upload into it waits for that event on the copy stream (no
 // host-side synchronisation, no hipMalloc / hipFree per picture -- both stall every stream of the process).
-struct ArenaBuf { void* ptr = nullptr; size_t bytes = 0; hipEvent_t last_use = nullptr; bool used = false; };
+struct ArenaBuf { void* ptr = nullptr; size_t bytes = 0; hipEvent_t last_use = nullptr; bool used = false;
+                  int64_t epoch = -1; };       // epoch: the decoder's generation epoch the arena was last cleared in (-1: never)
 // Pinned staging buffer the host stage assembles the command buffers in.  copied: recorded on the copy stream
 // behind the upload; the buffer is handed out again once it has completed.
 struct StageBuf { void* ptr = nullptr; size_t bytes = 0; hipEvent_t copied = nullptr; int state = 0; };   // state: 0 idle, 1 being filled by a host thread, 2 upload in flight
@@ -90,7 +95,27 @@ struct de265hip_decoder {
   uint64_t lane_tail_seq[kMaxLanes] = { 0, 0, 0, 0 };   // launch number of the lane's latest picture
   uint64_t launch_seq = 0;
   hipStream_t cur_stream = nullptr;   // the stream of the picture being launched (KTimer)
-  uint32_t* d_err = nullptr;          // set by a kernel whose bounded spin expired
+  uint32_t* d_err = nullptr;          // diagnostic builds only (phase stamps of k_run)
+  // Per-picture error words (a k_run dependency wait that expired, a coefficient position beyond its block): a ring of device
+  // words, and beside it a ring of pinned host records the device-side scan of a picture reports into (ScanCounts).  A picture
+  // takes an entry at build and hands it back when it is freed; entries are re-used first in, first out, so the word of a
+  // picture that was freed right behind its launch (the pipeline does) still stands when its ticket is waited for.
+  static constexpr int kRing = 4096;
+  uint32_t* d_err_ring = nullptr;
+  ScanCounts* h_ring = nullptr;
+  std::deque<int> ring_free;
+  uint64_t ring_owner[kRing] = {};    // sequence number of the picture that holds / last held the entry
+  uint64_t ring_seq = 0;
+  std::vector<std::pair<int, uint64_t>> launched_err;      // (entry, owner) of the pictures launched since the last de265hip_decoder_sync
+  // k_run's flags and mailbox packets carry the generation number of their launch; the decoder never hands a number out twice
+  // (arena_epoch counts the wrap-arounds: an arena of an older epoch is cleared before its next use)
+  uint32_t gen_tag = 0;
+  int64_t arena_epoch = 0;
+  bool dev_scan = true;               // the TU scan as kernels behind the upload (scan_core.h); DE265HIP_HOST_SCAN=1: the round-3 host scan
+  bool dry_scan = false;              // dry decoders only: run the passes on the host (the CPU rehearsal of tests/test_scan_equivalence.py)
+  uint64_t* d_used_units = nullptr;   // g_used_units on the device
+  bool drop_producer = false;         // fault injection (de265hip_debug_fault_injection; tests only)
+  int building = 0;                   // de265hip_picture_build calls in progress (their pictures are not in `live` yet)
   int run_waves = RUN_WAVES;          // DE265HIP_RUN_WAVES: wavefronts per run workgroup (experiments)
   bool resid_one_launch = true;       // DE265HIP_RESID_ONE_LAUNCH=0: 8x8 / 4x4 residual TUs in their own launch (k_resid_small)
   bool resid16_big = false;           // DE265HIP_RESID16_BIG: 16x16 residual TUs by 4-wavefront workgroups (k_resid_big) instead of one wavefront
@@ -103,10 +128,10 @@ struct de265hip_decoder {
   bool separate_bs = false;           // DE265HIP_SEPARATE_BS: bS by its own kernel instead of inside the deblocking kernels
   int dbg = 0;                        // DE265HIP_DEBUG: timing-only ablations of k_run (results invalid)
   bool intra_levels = false;          // DE265HIP_INTRA_MODE=levels: one launch per dependency level
-  // Fault injection for the one device-side failure mode the design admits (tests/test_gpu_picture_parity.py): a picture
-  // built while DE265HIP_TEST_DROP_PRODUCER is set leaves one run that other runs wait for out of its ticket list, so that
-  // run's flag is never raised; DE265HIP_TEST_SPIN_LIMIT (read when the decoder is created) bounds the waits so that they
-  // expire within milliseconds instead of seconds.
+  // Fault injection for the one device-side failure mode the design admits (tests/test_gpu_picture_parity.py), through an
+  // explicit test entry point only (de265hip_debug_fault_injection; no environment switch makes a decoder fail): a picture
+  // built while drop_producer is set leaves one run that other runs wait for out of its ticket list, so that run's flag is
+  // never raised; spin_limit bounds the waits so that they expire within milliseconds instead of seconds.
   uint32_t spin_limit = RUN_SPIN_LIMIT_DEFAULT;
   uint32_t profiling = 0;             // bit k: launches of kernel id k are bracketed by hipEvents
   std::vector<PendingEvent> pending;
@@ -156,6 +181,16 @@ struct de265hip_picture {
   uint32_t ref_mask = 0;              // DPB slots the picture's MC tasks read (validated when the picture is launched)
   int n_launched = 0;                 // de265hip_picture_run calls so far
   de265hip_picture_stats stats = {};
+  // device-side scan (scan_core.h): its parameters, buffers, and the counts the passes report (pinned ring entry)
+  bool dev_scan = false, scan_pending = false;
+  int scan_rc = 0;
+  ScanParams SP; ScanLayout SL; ScanBufs SB;
+  uint32_t cap_resid = 0;
+  uint32_t* d_front_idx = nullptr;    // the front runs' ids (device-side scan: run records are not sorted)
+  int ring_idx = -1; uint64_t ring_seq = 0;
+  ScanCounts h_counts_dry;            // (dry decoders: no ring)
+  std::vector<uint8_t> dry_arena;     // (dry decoders: the arena in host memory)
+  int64_t o_layout[16] = {};          // de265hip_debug_picture_layout
 };
 
 namespace {
@@ -230,7 +265,7 @@ void slot_settled(Slot& s)
 
 struct Geometry {
   int ctbs_w, ctbs_h, w4, h4, tbs_w, tbs_h;
-  std::vector<int> rs2ts;
+  std::vector<int> rs2ts, ts2rs;
   std::vector<uint16_t> tile_id;
   std::vector<int> min_tb_zs;
 };
@@ -245,7 +280,7 @@ int make_geometry(const de265hip_pic_params& p, Geometry& g)
   const int dl = p.log2_ctb_size - p.log2_min_tb_size;
   g.tbs_w = g.ctbs_w << dl; g.tbs_h = g.ctbs_h << dl;
   const int n = g.ctbs_w * g.ctbs_h;
-  g.rs2ts.assign(n, 0); g.tile_id.assign(n, 0);
+  g.rs2ts.assign(n, 0); g.ts2rs.assign(n, 0); g.tile_id.assign(n, 0);
   const int nc = p.num_tile_columns, nr = p.num_tile_rows;
   if (p.col_bd[0] != 0 || p.row_bd[0] != 0 || p.col_bd[nc] != g.ctbs_w || p.row_bd[nr] != g.ctbs_h)
     return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
@@ -255,6 +290,7 @@ int make_geometry(const de265hip_pic_params& p, Geometry& g)
       if (p.col_bd[i + 1] <= p.col_bd[i] || p.row_bd[j + 1] <= p.row_bd[j]) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
       for (int y = p.row_bd[j]; y < p.row_bd[j + 1]; y++)
         for (int x = p.col_bd[i]; x < p.col_bd[i + 1]; x++) {
+          g.ts2rs[ts] = y * g.ctbs_w + x;
           g.rs2ts[y * g.ctbs_w + x] = ts++;                // tiles in raster order, CTBs raster inside a tile
           g.tile_id[y * g.ctbs_w + x] = (uint16_t)tid;
         }
@@ -504,6 +540,14 @@ int de265hip_decoder_new(de265hip_decoder** out, int device)
   HIPCHK(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking), DE265HIP_ERROR_INIT_FAILED);
   HIPCHK(hipMalloc((void**)&d->d_err, 256), DE265HIP_ERROR_OUT_OF_MEMORY);
   HIPCHK(hipMemset(d->d_err, 0, 256), DE265HIP_ERROR_INIT_FAILED);
+  HIPCHK(hipMalloc((void**)&d->d_err_ring, de265hip_decoder::kRing * 4), DE265HIP_ERROR_OUT_OF_MEMORY);
+  HIPCHK(hipMemset(d->d_err_ring, 0, de265hip_decoder::kRing * 4), DE265HIP_ERROR_INIT_FAILED);
+  HIPCHK(hipHostMalloc((void**)&d->h_ring, de265hip_decoder::kRing * sizeof(ScanCounts), hipHostMallocDefault), DE265HIP_ERROR_OUT_OF_MEMORY);
+  for (int i = 0; i < de265hip_decoder::kRing; i++) d->ring_free.push_back(i);
+  ensure_used_units();
+  HIPCHK(hipMalloc((void**)&d->d_used_units, sizeof(g_used_units)), DE265HIP_ERROR_OUT_OF_MEMORY);
+  HIPCHK(hipMemcpy(d->d_used_units, g_used_units, sizeof(g_used_units), hipMemcpyHostToDevice), DE265HIP_ERROR_INIT_FAILED);
+  if (const char* e = getenv("DE265HIP_HOST_SCAN")) d->dev_scan = atoi(e) == 0;
   const char* mode = getenv("DE265HIP_INTRA_MODE");
   d->intra_levels = mode && !strcmp(mode, "levels");
   if (const char* dbg = getenv("DE265HIP_DEBUG")) d->dbg = atoi(dbg);
@@ -513,7 +557,6 @@ int de265hip_decoder_new(de265hip_decoder** out, int device)
   if (const char* e = getenv("DE265HIP_LF_TILE")) d->lf_tile = atoi(e) != 0;
   if (const char* e = getenv("DE265HIP_RESID16_BIG")) d->resid16_big = atoi(e) != 0;
   if (const char* e = getenv("DE265HIP_RESID_ONE_LAUNCH")) d->resid_one_launch = atoi(e) != 0;
-  if (const char* e = getenv("DE265HIP_TEST_SPIN_LIMIT")) d->spin_limit = (uint32_t)std::max(1, atoi(e));
   if (const char* rw = getenv("DE265HIP_RUN_WAVES")) d->run_waves = std::min(RUN_WAVES, std::max(1, atoi(rw)));
   if (const char* e = getenv("DE265HIP_LANES")) {
     const int rc = de265hip_decoder_set_lanes(d, std::min(kMaxLanes, std::max(1, atoi(e))));
@@ -565,6 +608,9 @@ void de265hip_decoder_free(de265hip_decoder* d)
   for (int l = 1; l < kMaxLanes; l++) { free_slot(d->lane_spare[l]); if (d->lane_stream[l]) (void)hipStreamDestroy(d->lane_stream[l]); }
   for (int l = 0; l < kMaxLanes; l++) if (d->lane_fence[l]) (void)hipEventDestroy(d->lane_fence[l]);
   if (d->d_err) (void)hipFree(d->d_err);
+  if (d->d_err_ring) (void)hipFree(d->d_err_ring);
+  if (d->h_ring) (void)hipHostFree(d->h_ring);
+  if (d->d_used_units) (void)hipFree(d->d_used_units);
   (void)hipStreamDestroy(d->copy_stream);
   (void)hipStreamDestroy(d->stream);
   delete d;
@@ -665,8 +711,12 @@ int de265hip_dpb_wait(de265hip_decoder* d, int slot)
   hipEvent_t ev; uint64_t seq;
   { std::lock_guard<std::mutex> lk(d->mu); Slot& s = d->slots[slot]; ev = s.dl_done; seq = s.dl_seq; if (!ev || s.dl_waited == seq) return 0; }
   HIPCHK(hipEventSynchronize(ev), DE265HIP_ERROR_DECODING);        // outside the lock: another thread may be enqueueing the next picture
-  uint32_t err = 0;                                                 // as de265hip_decoder_sync: a k_run dependency wait that expired
-  HIPCHK(hipMemcpy(&err, d->d_err, 4, hipMemcpyDeviceToHost), DE265HIP_ERROR_DECODING);
+  // the error word of the picture that was decoded into the slot (a k_run dependency wait that expired): its own word, so a
+  // failure of a picture built ahead - or launched behind it - never lands on this one
+  uint32_t err = 0;
+  int eidx = -1;
+  { std::lock_guard<std::mutex> lk(d->mu); Slot& s = d->slots[slot]; if (s.err_idx >= 0 && d->ring_owner[s.err_idx] == s.err_seq) eidx = s.err_idx; }
+  if (eidx >= 0) HIPCHK(hipMemcpy(&err, d->d_err_ring + eidx, 4, hipMemcpyDeviceToHost), DE265HIP_ERROR_DECODING);
   { std::lock_guard<std::mutex> lk(d->mu); Slot& s = d->slots[slot]; if (s.dl_seq == seq) s.dl_waited = seq; }
   return err ? DE265HIP_ERROR_DECODING : 0;
 }
@@ -770,15 +820,29 @@ void de265hip_picture_free(de265hip_picture* p)
     // no synchronisation: the arena goes back to the pool behind an event on the decoder's stream, and its next
     // upload waits for that event on the copy stream
     release_arena(dec, p->arena_buf, lane_st(dec, p->lane));     // (its launches on other lanes precede the latest one: they wrote the same slot)
+    if (p->ring_idx >= 0) dec->ring_free.push_back(p->ring_idx);   // (first in, first out: its error word stands for thousands of pictures to come)
     if (p->uploaded) (void)hipEventDestroy(p->uploaded);
   }
   delete p;
 }
 
+static int finish_scan(de265hip_picture* pic);
+static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hip_picture_desc* d, de265hip_picture** out);
+
 int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_picture_desc* d,
                            de265hip_picture** out)
 {
   if (!dec || !d || !out) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  // builds in progress are counted: a picture joins `live` only at the end of its build, and until then the geometry guard
+  // of another worker's build must still see it (a change of picture size between consecutive submissions)
+  { std::lock_guard<std::mutex> lk(dec->mu); dec->building++; }
+  const int rc = picture_build_impl(dec, dst_slot, d, out);
+  { std::lock_guard<std::mutex> lk(dec->mu); dec->building--; }
+  return rc;
+}
+
+static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hip_picture_desc* d, de265hip_picture** out)
+{
   *out = nullptr;
   const de265hip_pic_params& p = d->params;
   // extended precision: the reference's transform path hard-codes extended_precision_processing_flag = 0 (transform.cc:535)
@@ -807,7 +871,8 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     // a picture exist once it is built (de265hip_dpb_plane / upload of its initial content).
     // With no picture waiting for its first launch nothing can be disturbed either (the synchronous build -> upload -> run use).
     std::lock_guard<std::mutex> lk(dec->mu);
-    bool pending = false;
+    // (a picture joins `live` only at the END of its build: builds in progress on other pipeline workers count as pending too)
+    bool pending = dec->building > 1;                  // (this build is one of them)
     for (const de265hip_picture* q : dec->live) pending = pending || q->n_launched == 0;
     if (!dec->slots[dst_slot].valid || !pending) rc = alloc_slot(dec->slots[dst_slot], p.width, p.height, p.bit_depth_luma, p.bit_depth_chroma, p.chroma_format_idc);
     if (!rc && (!dec->spare.valid || !pending)) rc = alloc_slot(dec->spare, p.width, p.height, p.bit_depth_luma, p.bit_depth_chroma, p.chroma_format_idc);
@@ -855,13 +920,32 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   if (dec->intra_levels && rext_tools) { delete pic; return DE265HIP_ERROR_NOT_IMPLEMENTED; }   // (the level-launch schedule knows the Main tools only)
 
   pt.mark("geometry");
+  // ---- Where the TU records are scanned.  Default: on the DEVICE, behind the upload (scan_core.h / k_scan.hip: availability,
+  // needed units, runs, in-run levels, run edges, task lists as kernels with one thread per TU / CTB / run) - the host copies
+  // the raw records into the staging buffer and is done.  The round-3 host scan below stays for the level-launch parity
+  // schedule (DE265HIP_INTRA_MODE=levels), as the A/B switch DE265HIP_HOST_SCAN=1, and as the reference the equivalence tests
+  // hold the passes to (tests/test_scan_equivalence.py).
+  BuildScratch& SC = g_scratch;
+  const bool dev_scan = dec->dev_scan && !dec->intra_levels;
+  int max_level = 0, max_rl = 0, n_front = 0, n_mailboxes = 0;
+  int64_t alg_resid = 0, alg_intra = 0, alg_intra_front = 0, sum_lvls = 0;
+  size_t n_resid = 0;
+  std::vector<TuTask> sorted;
+  std::vector<RunTask>& runs = SC.runs; std::vector<uint32_t>& run_deps = SC.run_deps; std::vector<uint32_t>& slots = SC.slots;
+  std::vector<TuTask>& run_tus = SC.run_tus;
+  std::vector<uint32_t>& mbx = SC.mbx; std::vector<uint32_t>& mb_segs = SC.mb_segs;
+  runs.clear(); run_deps.clear(); slots.clear(); run_tus.clear(); mbx.clear(); mb_segs.clear(); SC.l0.clear(); SC.l0_rext.clear();
+  const int lc = p.log2_ctb_size, lt = p.log2_min_tb_size;
+  const bool host_checks_positions = dec->dry || dec->intra_levels;
+  pic->level_start.assign(2, 0);
+  if (!dev_scan) {
   // dependencies between intra TUs from the units each mode reads (DE265HIP_NO_MODE_DEPS: from every available unit)
   const bool mode_deps = getenv("DE265HIP_NO_MODE_DEPS") == nullptr;
   const bool merge_runs = getenv("DE265HIP_NO_MERGE") == nullptr;
   ensure_used_units();
   // ---- TU scan: tasks, intra availability, dependency levels, runs.  One linear pass over the TU records on flat,
   // reused arrays (BuildScratch): no allocation and no page fault in the steady state.
-  BuildScratch& SC = g_scratch;
+  // (SC: hoisted above)
   const int map_w[3] = { g.w4, (cwid + 3) / 4, (cwid + 3) / 4 };
   const int map_h[3] = { g.h4, (chei + 3) / 4, (chei + 3) / 4 };
   // The cell maps are not cleared per picture (6 MB at 4K): a cell counts only if its run id is of THIS build - ids start at
@@ -873,8 +957,8 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   }
   const int32_t E = SC.epoch_base;                     // a cell's run id r (>= 0) is stored as E + r
   SC.epoch_base = E + d->n_tus + 1;                    // (the next build's ids lie above everything this one can write, even if it fails half way)
-  int max_level = 0;
-  int64_t alg_resid = 0, alg_intra = 0, alg_intra_front = 0;
+  max_level = 0;
+  alg_resid = 0; alg_intra = 0; alg_intra_front = 0;
   // runs: maximal intervals of the per-component intra TU sequence inside one CTB in which
   // every TU reads from the run so far (see k_run); independent TUs start a new run
   std::vector<RunB>& rb = SC.rb; rb.clear();
@@ -890,7 +974,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   SC.ctb_group.resize((size_t)d->n_ctbs);
   for (int a = 0; a < d->n_ctbs; a++) SC.ctb_group[a] = (uint32_t)d->ctbs[a].slice_addr_rs | ((uint32_t)g.tile_id[a] << 16);
   const uint32_t* ctb_group = SC.ctb_group.data();
-  const int lc = p.log2_ctb_size, lt = p.log2_min_tb_size;
+  // (lc, lt: hoisted above)
   const int* zs = g.min_tb_zs.data();
   const bool cip = p.constrained_intra_pred_flag != 0;
   const bool one_tile = p.num_tile_columns == 1 && p.num_tile_rows == 1;
@@ -933,7 +1017,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   int64_t n_plain = 0;                                     // level-0 tasks of plain inter TUs (added to the level histogram behind the loop)
   SC.it.reserve((size_t)d->n_tus);
   SC.l0_rext.clear();
-  const bool host_checks_positions = dec->dry || dec->intra_levels;
+  // (host_checks_positions: hoisted above)
   int last_luma_tu = -1;                                   // most recent luma TU record (cross-component prediction reads its residual)
   // Cr mirrors Cb: the Cr TU of an intra CU sits at its Cb TU's place with its size and mode, and - by induction over the
   // decode order - among Cr neighbours that are the images of the Cb TU's neighbours: availability, needed units, levels and
@@ -1113,7 +1197,9 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
         const RunB& X = rb[x];
         const int bw = std::max(X.x1, tu.x0 + nT) - std::min(X.x0, (int)tu.x0);
         const int bh = std::max(X.y1, tu.y0 + nT) - std::min(X.y0, (int)tu.y0);
-        if (X.c == c && X.n_tus < 255 && bw <= run_box && bh <= run_box) {
+        // (round 4: only a run of the TU's own CTB - a run then lives inside one CTB, and what a CTB's TUs join is decided
+        //  from that CTB's records alone: the device-side scan works the CTBs off independently)
+        if (X.c == c && X.ctu == ctu && X.n_tus < 255 && bw <= run_box && bh <= run_box) {
           // in-run level: behind everything of X it reads; the needed cells are not kept: every cell of X the TU's
           // neighbourhood touches is a safe upper bound
           int lx = 0;
@@ -1199,7 +1285,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   if (cr_mirror && (mirror_broken || cbq_n != 0)) {         // not the pattern the shortcut relies on: once more, the long way
     delete pic;
     g_no_cr_mirror = true;
-    const int rc2 = de265hip_picture_build(dec, dst_slot, d, out);
+    const int rc2 = picture_build_impl(dec, dst_slot, d, out);
     g_no_cr_mirror = false;
     return rc2;
   }
@@ -1216,7 +1302,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   pic->level_start.assign(SC.level_hist.begin(), SC.level_hist.begin() + max_level + 2);
   for (int l = 0; l <= max_level; l++) pic->level_start[l + 1] += pic->level_start[l];
   // the level-sorted task array is only needed by the level-launch schedule (DE265HIP_INTRA_MODE=levels)
-  std::vector<TuTask> sorted;
+  // (sorted: hoisted above)
   if (dec->intra_levels) {
     sorted.resize(SC.all_tasks.size());
     std::vector<int> cursor(pic->level_start.begin(), pic->level_start.end() - 1);
@@ -1225,17 +1311,17 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   pic->n_tus = n_tasks;
 
   // ---- runs in dependency (ticket) order: producers first
-  std::vector<RunTask>& runs = SC.runs; std::vector<uint32_t>& run_deps = SC.run_deps; std::vector<uint32_t>& slots = SC.slots;
-  std::vector<TuTask>& run_tus = SC.run_tus;
-  runs.clear(); run_deps.clear(); slots.clear(); run_tus.clear(); run_tus.reserve(SC.it.size());
+  // (runs, run_deps, slots, run_tus: hoisted above)
+
+  run_tus.reserve(SC.it.size());
   const bool micro_off = getenv("DE265HIP_NO_MICRO") != nullptr;
   const bool no_dense = getenv("DE265HIP_NO_DENSE") != nullptr;    // (not per run: getenv walks the whole environment)
   const int micro_tus = getenv("DE265HIP_MICRO_TUS") ? std::min(16, atoi(getenv("DE265HIP_MICRO_TUS"))) : 16;   // MICRO_TUS of k_run
-  int64_t sum_lvls = 0, dbg_foreign = 0, dbg_w[4] = { 0, 0, 0, 0 };
-  size_t n_resid = 0;
-  int max_rl = 0, n_front = 0, n_mailboxes = 0;
+  int64_t dbg_foreign = 0, dbg_w[4] = { 0, 0, 0, 0 };
+
+
   const bool mailbox_on = getenv("DE265HIP_NO_MAILBOX") == nullptr;
-  std::vector<uint32_t>& mbx = SC.mbx; std::vector<uint32_t>& mb_segs = SC.mb_segs;      // per run: (own mailbox, first dword of its segments); the segments
+  // (mbx, mb_segs: hoisted above)  per run: (own mailbox, first dword of its segments); the segments
   mbx.assign(3 * rb.size(), 0xFFFFFFFFu); mb_segs.clear(); SC.mb_owner.clear();      // (+ first dword of its packets' ready epochs, phased hand-over)
   // Phased hand-over between luma runs (DE265HIP_NO_MB_PHASES=1: off): a publishing run stores each packet behind the barrier
   // epoch that completes the TU under it (its table of ready epochs), and a reading run fetches each neighbour sample at the
@@ -1293,7 +1379,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       }
     }
     while (slots.size() % RUN_TICKET_SLOTS) slots.push_back(0xFFFFFFFFu);
-    if (getenv("DE265HIP_TEST_DROP_PRODUCER")) {         // fault injection: the first run somebody depends on is never executed
+    if (dec->drop_producer) {                            // fault injection (de265hip_debug_fault_injection): the first run somebody depends on is never executed
       int victim = -1;
       for (size_t i = 0; i < rb.size() && victim < 0; i++)
         for (int e = rb[i].dep_head; e >= 0; e = SC.dep_next[e]) if (victim < 0 && newidx[SC.dep_val[e]] >= n_front) victim = newidx[SC.dep_val[e]];
@@ -1654,6 +1740,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     const char* benv = getenv("DE265HIP_TICKET_BATCH");
     pic->ticket_batch = benv ? std::max(1, std::min(64, atoi(benv))) : 1;
   }
+  }                                                     // (!dev_scan)
   // level-0 launch of run mode: inter TUs with residual, then the residual-only intra TUs, largest first
   // [32x32 | 16x16 | 8x8 | 4x4]: both were written to their place above
   std::vector<TuTask>& l0 = SC.l0;
@@ -1892,7 +1979,8 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   pt.mark("pcm_sao_scan");
   // ---- one arena, one upload
   ArenaLayout L;
-  const size_t o_tus = L.add(sorted.size() * sizeof(TuTask));
+  // (device-side scan: the raw TU records travel instead of the level-0 / run-ordered task arrays the host used to derive)
+  const size_t o_tus = L.add(dev_scan ? (size_t)d->n_tus * sizeof(de265hip_tu) : sorted.size() * sizeof(TuTask));
   const size_t o_cval = L.add((size_t)d->n_coeffs * 2), o_cpos = L.add((size_t)d->n_coeffs * 2);
   const size_t o_scal = L.add(DE265HIP_SCALING_BLOB_BYTES);
   const size_t o_mc = L.add(mcs.size() * sizeof(McTask)), o_mco = L.add(SC.mc_order_all.size() * 4);
@@ -1908,24 +1996,53 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   const size_t o_l0 = L.add(l0.size() * sizeof(TuTask));
   const size_t o_l0x = L.add(SC.l0_rext.size() * sizeof(TuTask));
   const size_t o_mbx = L.add(n_mailboxes ? mbx.size() * 4 : 0), o_mbs = L.add(n_mailboxes ? mb_segs.size() * 4 : 0);
+  const size_t o_grp = L.add(dev_scan ? (size_t)d->n_ctbs * 4 : 0), o_rs2ts = L.add(dev_scan ? (size_t)d->n_ctbs * 4 : 0), o_ts2rs = L.add(dev_scan ? (size_t)d->n_ctbs * 4 : 0);
   const size_t upload_bytes = L.total;                 // everything above is written by the host
   // device-only scratch: boundary strengths, residual blocks, run flags (no staging, no upload)
   const size_t o_bs = L.add(nblk);
-  const size_t o_resid = L.add(n_resid * 2 + 64);
-  pic->sync_bytes = (2 + runs.size()) * 4;
+  // Device-side scan: what the passes will find is not known here, so its lists get room for the most a picture of this size
+  // and this many TU records can ask for (address space in 288 GB of HBM; none of it is uploaded or cleared): a residual
+  // sample per picture sample, a run per TU record, a producer entry per needed neighbour unit (<= nT + 1 per TU: 5 / 16 per
+  // sample of a 4x4 TU), eight slots per ticket.  Mailboxes are an optimisation: a run beyond their number does without.
+  ScanParams& SP = pic->SP; memset(&SP, 0, sizeof(SP));
+  const int64_t total_samples = (int64_t)p.width * p.height + 2 * (int64_t)cwid * chei;
+  const uint32_t cap_resid = (uint32_t)std::min<int64_t>(total_samples, 0x7FFFFF00);
+  if (dev_scan) {
+    SP.width = p.width; SP.height = p.height; SP.cwid = cwid; SP.chei = chei; SP.subw = subw; SP.subh = subh; SP.lc = lc; SP.lt = lt; SP.cf = cf;
+    SP.ctbs_w = g.ctbs_w; SP.ctbs_h = g.ctbs_h; SP.n_ctbs = d->n_ctbs;
+    for (int c = 0; c < 3; c++) { SP.map_w[c] = c ? (cwid + 3) / 4 : g.w4; SP.map_h[c] = c ? (chei + 3) / 4 : g.h4; }
+    SP.n_tus = d->n_tus; SP.n_coeffs = d->n_coeffs; SP.bppY = (int)px_bytes(p.bit_depth_luma); SP.bppC = (int)px_bytes(p.bit_depth_chroma);
+    const bool mailbox_on = getenv("DE265HIP_NO_MAILBOX") == nullptr;
+    SP.flags = (p.constrained_intra_pred_flag ? SCANF_CIP : 0) | (getenv("DE265HIP_NO_MODE_DEPS") ? 0 : SCANF_MODE_DEPS) | (getenv("DE265HIP_NO_MERGE") ? 0 : SCANF_MERGE) |
+               (mailbox_on ? SCANF_MAILBOX : 0) | ((mailbox_on && !getenv("DE265HIP_NO_MB_PHASES")) ? SCANF_MB_PHASES : 0) | (getenv("DE265HIP_NO_MICRO") ? SCANF_MICRO_OFF : 0) |
+               (getenv("DE265HIP_NO_DENSE") ? SCANF_NO_DENSE : 0) | ((!getenv("DE265HIP_MICRO16") || atoi(getenv("DE265HIP_MICRO16")) != 0) ? SCANF_MICRO16 : 0) |
+               (getenv("DE265HIP_NO_FRONT") ? SCANF_FRONT_OFF : 0) | (p.implicit_rdpcm_enabled_flag ? SCANF_IMPLICIT_RDPCM : 0) |
+               (p.transform_skip_rotation_enabled_flag ? SCANF_ROTATION : 0) | (dec->drop_producer ? SCANF_DROP_PRODUCER : 0) | SCANF_CHECK_POS;
+    SP.micro_tus = getenv("DE265HIP_MICRO_TUS") ? std::min(16, atoi(getenv("DE265HIP_MICRO_TUS"))) : 16;
+    SP.run_waves = dec->run_waves;
+    SP.cap_runs = (uint32_t)d->n_tus;
+    SP.cap_deps = (uint32_t)std::min<int64_t>(33 * (int64_t)d->n_tus, 5 * total_samples / 16 + d->n_tus) + 64;
+    SP.cap_mb = (uint32_t)std::min<int64_t>(d->n_tus, 6 * (int64_t)d->n_ctbs + 64);
+    SP.cap_segs = SP.cap_mb * 40 + 64;
+    SP.cap_slots = 16u * (uint32_t)d->n_tus + 64;
+  }
+  const size_t o_resid = L.add((dev_scan ? (size_t)cap_resid : n_resid) * 2 + 64);
+  pic->sync_bytes = (2 + (dev_scan ? (size_t)d->n_tus : runs.size())) * 4;
   const size_t o_sync = L.add(pic->sync_bytes);
   // edge mailboxes of k_run: 64 packets of (two samples, generation) per publishing run - its bottom row, then its right
-  // column; cleared with the flags (a packet counts when it carries the launch's generation)
-  const size_t mb_bytes = (size_t)n_mailboxes * 64 * 8;
+  // column.  Flags and packets carry the generation number of their LAUNCH, a number the decoder never hands out twice, so
+  // neither is cleared between pictures: an arena is cleared once, when it is allocated.
+  const size_t mb_bytes = (size_t)(dev_scan ? SP.cap_mb : (uint32_t)n_mailboxes) * 64 * 8;
   const size_t o_mb = L.add(mb_bytes);
-  const size_t clear_bytes = L.total - o_sync;           // flags + mailboxes: one memset
+  const size_t clear_bytes = L.total - o_sync;           // flags + mailboxes (experiments that clear them per launch)
   pic->clear_bytes = clear_bytes;
+  ScanLayout& SL = pic->SL;
+  if (dev_scan) L.total = SL.plan(SP, L.total);
   // pinned staging + pooled arena: no allocation, no host-side wait in the steady state
   int stage_idx = -1;
   uint8_t* host_base = nullptr;
   hipEvent_t stage_event = nullptr;
-  std::vector<uint8_t> dry_stage;
-  if (dec->dry) { dry_stage.resize(upload_bytes); host_base = dry_stage.data(); }
+  if (dec->dry) { pic->dry_arena.assign((dev_scan && dec->dry_scan) ? L.total : upload_bytes, 0); host_base = pic->dry_arena.data(); }
   else {
     std::lock_guard<std::mutex> lk(dec->mu);
     rc = acquire_stage(dec, upload_bytes, &stage_idx);
@@ -1934,6 +2051,10 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
       rc = acquire_arena(dec, L.total, &pic->arena_buf);
       if (rc) dec->stage_pool[stage_idx].state = 0;
     }
+    if (!rc) {
+      if (dec->ring_free.empty()) { rc = DE265HIP_ERROR_OUT_OF_MEMORY; dec->stage_pool[stage_idx].state = 0; release_arena(dec, pic->arena_buf); }
+      else { pic->ring_idx = dec->ring_free.front(); dec->ring_free.pop_front(); pic->ring_seq = ++dec->ring_seq; dec->ring_owner[pic->ring_idx] = pic->ring_seq; }
+    }
   }
   if (rc) { delete pic; return rc; }
   // (a failure below hands both back)
@@ -1941,13 +2062,15 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     std::lock_guard<std::mutex> lk(dec->mu);
     for (auto& b : dec->stage_pool) if (b.ptr == host_base) b.state = 0;
     release_arena(dec, pic->arena_buf);
+    if (pic->ring_idx >= 0) dec->ring_free.push_back(pic->ring_idx);
     if (pic->uploaded) (void)hipEventDestroy(pic->uploaded);
     delete pic;
     return code;
   };
   struct HostView { uint8_t* p; uint8_t* data() const { return p; } } host{ host_base };
   auto put = [&](size_t off, const void* src, size_t bytes) { if (bytes && src) memcpy(host.data() + off, src, bytes); };
-  put(o_tus, sorted.data(), sorted.size() * sizeof(TuTask));
+  if (dev_scan) put(o_tus, d->tus, (size_t)d->n_tus * sizeof(de265hip_tu));
+  else put(o_tus, sorted.data(), sorted.size() * sizeof(TuTask));
   put(o_cval, d->coeff_val, (size_t)d->n_coeffs * 2); put(o_cpos, d->coeff_pos, (size_t)d->n_coeffs * 2);
   if (p.scaling_list_enable_flag) put(o_scal, d->scaling_factors, DE265HIP_SCALING_BLOB_BYTES);
   else memset(host.data() + o_scal, 0, DE265HIP_SCALING_BLOB_BYTES);
@@ -1966,9 +2089,27 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   put(o_flags, d->blk_flags, nblk); put(o_qp, d->blk_qp_y, nblk);
   if (d->blk_motion) put(o_mot, d->blk_motion, nblk * sizeof(de265hip_motion));
   else memset(host.data() + o_mot, 0xFF, nblk * sizeof(de265hip_motion));       // ref_slot = -1 everywhere
+  if (dev_scan) {
+    // CTBs of one slice and tile share a group word (the availability tests of intrapred.cc:486-508 compare exactly these two)
+    uint32_t* grp = (uint32_t*)(host.data() + o_grp);
+    for (int a = 0; a < d->n_ctbs; a++) grp[a] = (uint32_t)d->ctbs[a].slice_addr_rs | ((uint32_t)g.tile_id[a] << 16);
+    put(o_rs2ts, g.rs2ts.data(), (size_t)d->n_ctbs * 4); put(o_ts2rs, g.ts2rs.data(), (size_t)d->n_ctbs * 4);
+  }
 
   pt.mark("staging");
-  if (dec->dry && !getenv("DE265HIP_DRY_NO_HASH")) { // FNV-1a over everything the device would receive (tools/exp/build_hash.py)
+  pic->arena = dec->dry ? (void*)host_base : pic->arena_buf.ptr;
+  pic->arena_bytes = L.total;
+  uint8_t* base = (uint8_t*)pic->arena;
+  ScanBufs& SB = pic->SB; memset(&SB, 0, sizeof(SB));
+  if (dev_scan) {
+    SB.tus = (const de265hip_tu*)(base + o_tus); SB.ctb_group = (const uint32_t*)(base + o_grp); SB.rs2ts = (const int32_t*)(base + o_rs2ts);
+    SB.ts2rs = (const int32_t*)(base + o_ts2rs); SB.blk_flags = base + o_flags; SB.coeff_pos = (uint16_t*)(base + o_cpos);
+    SB.used_units = dec->dry ? &g_used_units[0][0][0] : dec->d_used_units;
+    SL.bind(base, SB);
+    pic->cap_resid = cap_resid;
+    if (dec->dry && dec->dry_scan) scan_host_run(SP, SB, SL, base, cap_resid);      // the CPU rehearsal of the passes (tests only)
+  }
+  if (dec->dry && !getenv("DE265HIP_DRY_NO_HASH") && !dev_scan) { // FNV-1a over everything the device would receive (tools/exp/build_hash.py)
     uint64_t hsh = 1469598103934665603ull;
     auto mix = [&](const void* ptr, size_t n) { const uint8_t* b = (const uint8_t*)ptr; for (size_t i = 0; i < n; i++) { hsh ^= b[i]; hsh *= 1099511628211ull; } };
     const size_t offs[] = { o_tus, o_cval, o_cpos, o_scal, o_mc, o_pcm, o_pcms, o_sl, o_ctb, o_tile, o_sao, o_flags, o_qp, o_mot, o_runs, o_rdeps, o_rtus, o_slots, o_l0, upload_bytes };
@@ -1986,28 +2127,38 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
     mix(pic->level_start.data(), pic->level_start.size() * sizeof(int));
     dec->pooled_bytes = (size_t)hsh;
   }
-  pic->arena = pic->arena_buf.ptr;
-  pic->arena_bytes = L.total;
   if (!dec->dry) {
     hipStream_t cs = dec->copy_stream;
     // a recycled arena may still be read by kernels of the picture that had it before
     if (pic->arena_buf.used && hipStreamWaitEvent(cs, pic->arena_buf.last_use, 0) != hipSuccess) return fail(DE265HIP_ERROR_DECODING);
     if (hipEventCreateWithFlags(&pic->uploaded, hipEventDisableTiming) != hipSuccess) return fail(DE265HIP_ERROR_OUT_OF_MEMORY);
+    // a fresh arena (or one from before the generation numbers wrapped) is cleared once: flags and mailbox packets of later
+    // pictures in it are told apart by their generation
+    if (pic->arena_buf.epoch != dec->arena_epoch) {
+      if (hipMemsetAsync(pic->arena, 0, pic->arena_buf.bytes, cs) != hipSuccess) return fail(DE265HIP_ERROR_DECODING);
+      pic->arena_buf.epoch = dec->arena_epoch;
+    } else if (hipMemsetAsync((uint8_t*)pic->arena + o_sync, 0, 8, cs) != hipSuccess) return fail(DE265HIP_ERROR_DECODING);      // (the ticket counter)
     if (hipMemcpyAsync(pic->arena, host.data(), upload_bytes, hipMemcpyHostToDevice, cs) != hipSuccess ||
-        hipMemsetAsync((uint8_t*)pic->arena + o_sync, 0, clear_bytes, cs) != hipSuccess ||
+        hipMemsetAsync(dec->d_err_ring + pic->ring_idx, 0, 4, cs) != hipSuccess ||
         hipEventRecord(stage_event, cs) != hipSuccess)
       return fail(DE265HIP_ERROR_DECODING);
-    if (!host_checks_positions) {
+    if (dev_scan) {
+      // the passes of the scan, then their counts on the way back to the host (pinned; de265hip_picture_run reads them)
+      if (scan_enqueue(cs, SP, SB, SL, base, cap_resid) != hipSuccess ||
+          hipMemcpyAsync(dec->h_ring + pic->ring_idx, SB.counts, sizeof(ScanCounts), hipMemcpyDeviceToHost, cs) != hipSuccess)
+        return fail(DE265HIP_ERROR_DECODING);
+      pic->scan_pending = true;
+    } else if (!host_checks_positions) {
       const int n_chk = (int)l0.size() + (int)SC.l0_rext.size();
       if (n_chk > 0)
         hipLaunchKernelGGL(k_check_coeffs, dim3((n_chk + 15) / 16), dim3(256), 0, cs, (const TuTask*)((uint8_t*)pic->arena + o_l0), (int)l0.size(),
-                           (const TuTask*)((uint8_t*)pic->arena + o_l0x), (int)SC.l0_rext.size(), (uint16_t*)((uint8_t*)pic->arena + o_cpos), dec->d_err);
+                           (const TuTask*)((uint8_t*)pic->arena + o_l0x), (int)SC.l0_rext.size(), (uint16_t*)((uint8_t*)pic->arena + o_cpos), dec->d_err_ring + pic->ring_idx);
     }
     if (hipEventRecord(pic->uploaded, cs) != hipSuccess) return fail(DE265HIP_ERROR_DECODING);
     std::lock_guard<std::mutex> lk(dec->mu);
     for (auto& b : dec->stage_pool) if (b.ptr == host_base) b.state = 2;      // reusable once `copied` has completed
   }
-  uint8_t* base = (uint8_t*)pic->arena;
+  pic->dev_scan = dev_scan;
   pic->d_tus = (TuTask*)(base + o_tus);
   pic->d_cval = (int16_t*)(base + o_cval); pic->d_cpos = (uint16_t*)(base + o_cpos);
   pic->d_scaling = base + o_scal;
@@ -2020,12 +2171,27 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   pic->d_flags = base + o_flags; pic->d_qp = (int8_t*)(base + o_qp);
   pic->d_motion = (de265hip_motion*)(base + o_mot);
   pic->d_bs = base + o_bs;
-  pic->d_runs = (RunTask*)(base + o_runs); pic->d_deps = (uint32_t*)(base + o_rdeps);
-  pic->d_run_tus = (TuTask*)(base + o_rtus); pic->d_slots = (uint32_t*)(base + o_slots); pic->d_sync = (uint32_t*)(base + o_sync);
-  pic->d_l0 = (TuTask*)(base + o_l0); pic->d_resid = (int16_t*)(base + o_resid);
-  pic->d_l0_rext = (TuTask*)(base + o_l0x); pic->n_l0_rext = (int)SC.l0_rext.size();
-  pic->d_mbx = n_mailboxes ? (uint32_t*)(base + o_mbx) : nullptr; pic->d_mbsegs = (uint32_t*)(base + o_mbs); pic->d_mb = (unsigned long long*)(base + o_mb);
-  pic->n_mailboxes = n_mailboxes;
+  pic->d_sync = (uint32_t*)(base + o_sync); pic->d_resid = (int16_t*)(base + o_resid);
+  pic->d_mb = (unsigned long long*)(base + o_mb);
+  if (dev_scan) {
+    pic->d_runs = SB.runs; pic->d_deps = SB.deps; pic->d_run_tus = SB.run_tus; pic->d_slots = SB.slots;
+    pic->d_l0 = SB.l0; pic->d_l0_rext = SB.l0x; pic->d_mbx = SB.mbx; pic->d_mbsegs = SB.mb_segs; pic->d_front_idx = SB.front_idx;
+    pic->n_mailboxes = (int)SP.cap_mb;
+    pic->o_layout[0] = (int64_t)SL.o_runs; pic->o_layout[1] = (int64_t)SL.o_run_tus; pic->o_layout[2] = (int64_t)SL.o_deps; pic->o_layout[3] = (int64_t)SL.o_slots;
+    pic->o_layout[4] = (int64_t)SL.o_l0; pic->o_layout[5] = (int64_t)SL.o_l0x; pic->o_layout[6] = (int64_t)SL.o_mbx; pic->o_layout[7] = (int64_t)SL.o_mb_segs;
+    pic->o_layout[8] = (int64_t)SL.o_front; pic->o_layout[9] = (int64_t)SL.o_run_ntus; pic->o_layout[10] = (int64_t)SL.o_run_nall; pic->o_layout[11] = (int64_t)SL.o_run_level;
+    pic->o_layout[12] = (int64_t)SL.o_counts;
+  } else {
+    pic->d_runs = (RunTask*)(base + o_runs); pic->d_deps = (uint32_t*)(base + o_rdeps);
+    pic->d_run_tus = (TuTask*)(base + o_rtus); pic->d_slots = (uint32_t*)(base + o_slots);
+    pic->d_l0 = (TuTask*)(base + o_l0);
+    pic->d_l0_rext = (TuTask*)(base + o_l0x); pic->n_l0_rext = (int)SC.l0_rext.size();
+    pic->d_mbx = n_mailboxes ? (uint32_t*)(base + o_mbx) : nullptr; pic->d_mbsegs = (uint32_t*)(base + o_mbs);
+    pic->n_mailboxes = n_mailboxes;
+    pic->o_layout[0] = (int64_t)o_runs; pic->o_layout[1] = (int64_t)o_rtus; pic->o_layout[2] = (int64_t)o_rdeps; pic->o_layout[3] = (int64_t)o_slots;
+    pic->o_layout[4] = (int64_t)o_l0; pic->o_layout[5] = (int64_t)o_l0x; pic->o_layout[6] = n_mailboxes ? (int64_t)o_mbx : -1; pic->o_layout[7] = (int64_t)o_mbs;
+    for (int q = 8; q < 13; q++) pic->o_layout[q] = -1;
+  }
 
   const int64_t Pbytes = ((int64_t)p.width * p.height + 2 * (int64_t)cwid * chei) * px_bytes(p.bit_depth_luma);
   pic->stats.n_levels = max_level + (pic->level_start[1] > 0 ? 1 : 0);
@@ -2037,6 +2203,7 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
   pic->stats.alg_bytes_intra_front = alg_intra_front; pic->stats.n_front_runs = pic->n_front;
   pic->stats.alg_bytes_deblock = pic->any_edges ? 2 * Pbytes : 0;       // one read + one write
   pic->stats.alg_bytes_sao = p.sample_adaptive_offset_enabled_flag ? 2 * Pbytes + 16 * (int64_t)d->n_ctbs : 0;
+  if (dec->dry && dev_scan && dec->dry_scan) { pic->h_counts_dry = *SB.counts; pic->scan_pending = true; (void)finish_scan(pic); }
   if (!dec->dry) {
     std::lock_guard<std::mutex> lk(dec->mu);
     dec->live.push_back(pic);
@@ -2051,27 +2218,115 @@ int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_p
 // and without any HIP call (staging into plain memory, nothing uploaded).  Returns the build's return code.
 static thread_local uint64_t g_last_build_hash = 0;
 uint64_t de265hip_debug_last_build_hash(void) { return g_last_build_hash; }
-int de265hip_debug_build_host_only(const de265hip_picture_desc* d, int reps)
+int de265hip_debug_build_host_only(const de265hip_picture_desc* d, int reps) { return de265hip_debug_build_host_only_ex(d, reps, 0, nullptr); }
+
+// mode 0: the round-3 host scan; 1: the host's part of a build with the device-side scan (what the product spends on a host
+// core: validation, MC tasks, staging); 2: the same plus the CPU rehearsal of the passes (the equivalence tests).
+// keep != nullptr: the last picture is handed out (an orphan of a dry decoder: de265hip_debug_picture_layout / _read work on
+// its host-memory arena; de265hip_picture_free).
+int de265hip_debug_build_host_only_ex(const de265hip_picture_desc* d, int reps, int mode, de265hip_picture** keep)
 {
-  if (!d) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  if (!d || mode < 0 || mode > 2) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  if (keep) *keep = nullptr;
   de265hip_decoder* dec = new de265hip_decoder();
-  dec->dry = true;
+  dec->dry = true; dec->dev_scan = mode != 0; dec->dry_scan = mode == 2;
+  if (getenv("DE265HIP_TEST_DROP_PRODUCER")) dec->drop_producer = true;      // (dry decoders only: the equivalence test of the fault injection)
   for (auto& sl : dec->slots) { sl.valid = true; sl.w = d->params.width; sl.h = d->params.height; sl.bdY = d->params.bit_depth_luma; sl.bdC = d->params.bit_depth_chroma; sl.cf = d->params.chroma_format_idc; }
   int rc = 0;
   for (int i = 0; i < reps && !rc; i++) {
     de265hip_picture* pic = nullptr;
     rc = de265hip_picture_build(dec, DE265HIP_MAX_DPB_SLOTS - 1, d, &pic);
     g_last_build_hash = (uint64_t)dec->pooled_bytes;
-    delete pic;
+    if (pic && !rc && mode == 2) rc = pic->scan_rc;
+    if (keep && pic && i == reps - 1 && !rc) { pic->dec = nullptr; *keep = pic; }
+    else delete pic;
   }
   for (auto& sl : dec->slots) sl.valid = false;
   delete dec;
   return rc;
 }
 
+static int finish_scan(de265hip_picture* pic)
+{
+  if (!pic->scan_pending) return pic->scan_rc;
+  de265hip_decoder* dec = pic->dec;
+  if (!dec) return pic->scan_rc = DE265HIP_ERROR_DECODING;       // (an orphan: its device side is gone)
+  const ScanCounts* K = &pic->h_counts_dry;
+  if (!dec->dry) {
+    if (hipEventSynchronize(pic->uploaded) != hipSuccess) return pic->scan_rc = DE265HIP_ERROR_DECODING;
+    K = dec->h_ring + pic->ring_idx;
+  }
+  pic->scan_pending = false;
+  if (K->status) return pic->scan_rc = (int)K->status;
+  pic->n_l0 = 0;
+  for (int k = 0; k < 4; k++) { pic->n_l0_size[k] = (int)K->n_l0_size[k]; pic->n_l0 += (int)K->n_l0_size[k]; }
+  pic->n_l0_rext = (int)K->n_l0_rext;
+  pic->n_runs = (int)K->n_runs; pic->n_front = (int)K->n_front; pic->n_batches = (int)K->n_batches; pic->n_tus = (int)K->n_tasks;
+  {
+    // worker count = widest dependency level (more workers would only wait), within [64, 2 per CU] (see the host scan)
+    const char* wenv = getenv("DE265HIP_RUN_WORKERS");
+    const int cap = wenv ? atoi(wenv) : 512;
+    const char* menv = getenv("DE265HIP_RUN_WORKER_PCT");
+    const int pct = menv ? atoi(menv) : 125;
+    pic->n_workers = std::min(pic->n_batches, std::max(64, std::min(cap, (int)((int64_t)K->widest * pct / 100))));
+    const char* denv = getenv("DE265HIP_RUN_DIRECT");
+    pic->run_direct = denv ? atoi(denv) != 0 : false;
+    const char* benv = getenv("DE265HIP_TICKET_BATCH");
+    pic->ticket_batch = benv ? std::max(1, std::min(64, atoi(benv))) : 1;
+  }
+  pic->stats.n_tu_tasks = pic->n_tus; pic->stats.n_runs = pic->n_runs; pic->stats.n_run_levels = (int)K->max_rl;
+  pic->stats.n_in_run_levels = (int32_t)K->sum_lvls; pic->stats.n_levels = 0;
+  pic->stats.alg_bytes_resid = (int64_t)K->alg_resid; pic->stats.alg_bytes_intra = (int64_t)(K->alg_intra - K->alg_intra_front);
+  pic->stats.alg_bytes_intra_front = (int64_t)K->alg_intra_front; pic->stats.n_front_runs = pic->n_front;
+  return pic->scan_rc = 0;
+}
+
+/* ---- debug / test entry points (not part of the decoding interface) ---- */
+// fault injection for the one device-side failure mode the design admits (tests/test_gpu_picture_parity.py): pictures built
+// while drop_producer is set leave one run that other runs wait for out of their ticket lists; spin_limit bounds k_run's
+// dependency waits so that they expire within milliseconds (0: the default)
+int de265hip_debug_fault_injection(de265hip_decoder* dec, int drop_producer, uint32_t spin_limit)
+{
+  if (!dec) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  std::lock_guard<std::mutex> lk(dec->mu);
+  dec->drop_producer = drop_producer != 0;
+  dec->spin_limit = spin_limit ? spin_limit : RUN_SPIN_LIMIT_DEFAULT;
+  return 0;
+}
+
+// where a picture's run-side structures lie in its arena, and the counts that go with them (tests/test_scan_equivalence.py
+// reads both scans' arenas back and compares them run by run).  out[0..12]: offsets of runs, run_tus, deps, slots, l0, l0x, mbx,
+// mb_segs, front_idx, run_ntus, run_nall, run_level, counts (-1: not there); out[13..]: dev_scan, n_runs, n_front, n_batches,
+// n_l0_size[0..3], n_l0_rext, number of run records to look at, arena bytes
+int de265hip_debug_picture_layout(de265hip_picture* pic, int64_t out[32])
+{
+  if (!pic || !out) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  if (const int rc = finish_scan(pic)) return rc;
+  for (int i = 0; i < 13; i++) out[i] = pic->o_layout[i];
+  out[13] = pic->dev_scan; out[14] = pic->n_runs; out[15] = pic->n_front; out[16] = pic->n_batches;
+  for (int k = 0; k < 4; k++) out[17 + k] = pic->n_l0_size[k];
+  out[21] = pic->n_l0_rext;
+  out[22] = pic->dev_scan ? (int64_t)pic->SP.cap_runs : pic->n_runs;
+  out[23] = (int64_t)pic->arena_bytes;
+  out[24] = pic->n_workers;
+  return 0;
+}
+
+// bytes [offset, offset + bytes) of the picture's arena into dst (a device picture: after its passes have completed)
+int de265hip_debug_picture_read(de265hip_picture* pic, int64_t offset, int64_t bytes, void* dst)
+{
+  if (!pic || !dst || offset < 0 || bytes < 0 || (size_t)(offset + bytes) > pic->arena_bytes) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  if (!pic->dry_arena.empty()) { memcpy(dst, pic->dry_arena.data() + offset, (size_t)bytes); return 0; }
+  if (!pic->dec || !pic->arena) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  if (pic->uploaded) HIPCHK(hipEventSynchronize(pic->uploaded), DE265HIP_ERROR_DECODING);
+  HIPCHK(hipMemcpy(dst, (const uint8_t*)pic->arena + offset, (size_t)bytes, hipMemcpyDeviceToHost), DE265HIP_ERROR_DECODING);
+  return 0;
+}
+
 int de265hip_picture_get_stats(const de265hip_picture* p, de265hip_picture_stats* s)
 {
   if (!p || !s) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  (void)finish_scan(const_cast<de265hip_picture*>(p));      // (device-side scan: the counts behind some of the figures)
   *s = p->stats;
   return 0;
 }
@@ -2125,6 +2380,8 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
       }
   }
   pic->n_launched++;
+  dst.err_idx = pic->ring_idx; dst.err_seq = pic->ring_seq;
+  dec->launched_err.emplace_back(pic->ring_idx, pic->ring_seq);
   hipStream_t st = lane_st(dec, lane);
   dec->cur_stream = st;
   pic->lane = lane;
@@ -2226,7 +2483,7 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
     if (pic->n_front > 0) {                                         // the runs nobody has to wait for: one small workgroup each
       KTimer t(dec, DE265HIP_K_INTRA_FRONT, 1);
       hipLaunchKernelGGL(k_intra_front<PX>, dim3(pic->n_front), dim3(64), 0, st, P, d0, d1, d2, pic->d_runs, pic->d_run_tus, pic->d_resid,
-                         pic->n_front);
+                         pic->n_front, pic->d_front_idx);
     }
     if (pic->n_batches > 0) {
       KTimer t(dec, DE265HIP_K_INTRA, 1);
@@ -2234,12 +2491,18 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
       // ticket beyond the last batch, so run g starts at ticket g * (n_batches + n_workers), and a flag is "raised"
       // when it holds the run's generation number (cleared once, at build).  Several tickets per draw (experiment)
       // make the count depend on the schedule: clear instead.
-      uint32_t base = 0, gen = 1;
-      if (pic->run_direct) gen = ++pic->gen;                        // (no ticket counter at all)
-      else if (pic->ticket_batch == 1) { gen = ++pic->gen; base = (gen - 1u) * (uint32_t)(pic->n_batches + pic->n_workers); }
-      else { (void)hipMemsetAsync(pic->d_sync, 0, pic->clear_bytes, st); pic->gen = 0; }
+      // The generation number of this launch: decoder-wide, never handed out twice - flags and mailbox packets left in the arena
+      // by earlier launches, of this picture or of the one that had the arena before, carry smaller numbers and are never
+      // cleared.  (On wrap-around every arena is cleared before its next use: arena_epoch.)
+      uint32_t base = 0;
+      if (++dec->gen_tag == 0) { dec->gen_tag = 1; dec->arena_epoch++; }
+      if (pic->arena_buf.epoch != dec->arena_epoch) { (void)hipMemsetAsync(pic->d_sync, 0, pic->clear_bytes, st); pic->arena_buf.epoch = dec->arena_epoch; pic->gen = 0; }
+      const uint32_t gen = dec->gen_tag;
+      if (pic->run_direct) pic->gen++;                              // (no ticket counter at all)
+      else if (pic->ticket_batch == 1) base = (pic->gen++) * (uint32_t)(pic->n_batches + pic->n_workers);
+      else { (void)hipMemsetAsync(pic->d_sync, 0, 8, st); }
       hipLaunchKernelGGL((k_run<PX, 64>), dim3(pic->run_direct ? pic->n_batches : pic->n_workers), dim3(64 * dec->run_waves), 0, st, P, d0, d1, d2,
-                         pic->d_runs, pic->d_deps, pic->d_sync, dec->d_err, pic->d_run_tus, pic->d_resid, pic->d_slots, pic->n_batches,
+                         pic->d_runs, pic->d_deps, pic->d_sync, (dec->dbg & 16) ? dec->d_err : dec->d_err_ring + pic->ring_idx, pic->d_run_tus, pic->d_resid, pic->d_slots, pic->n_batches,
                          pic->run_direct ? 0 : pic->ticket_batch, base, gen, dec->dbg, dec->spin_limit, pic->d_mbx, pic->d_mbsegs, pic->d_mb);
     }
   } else {
@@ -2341,6 +2604,9 @@ extern "C" {
 int de265hip_picture_run(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
 {
   if (!dec || !pic || pic->dec != dec || last_stage < 0 || last_stage > 2) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  // device-side scan: its counts (task list sizes, tickets, front runs) and its verdict on the records arrive with the event
+  // behind the passes - long since complete when the builds run ahead of the launches (the pipeline); outside the decoder's lock
+  if (const int rc = finish_scan(pic)) return rc;
   if (pic->P.bd_luma > 8) return run_picture<uint16_t>(dec, pic, last_stage);
   return run_picture<uint8_t>(dec, pic, last_stage);
 }
@@ -2349,8 +2615,22 @@ int de265hip_decoder_sync(de265hip_decoder* dec)
 {
   if (!dec) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   HIPCHK(sync_all_lanes(dec), DE265HIP_ERROR_DECODING);
-  uint32_t err = 0;                     // a dependency wait that expired (k_run): results are not trustworthy
-  HIPCHK(hipMemcpy(&err, dec->d_err, 4, hipMemcpyDeviceToHost), DE265HIP_ERROR_DECODING);
+  // a dependency wait that expired (k_run) in any picture launched since the last call: results are not trustworthy
+  uint32_t err = 0;
+  {
+    std::vector<std::pair<int, uint64_t>> chk;
+    { std::lock_guard<std::mutex> lk(dec->mu); chk.swap(dec->launched_err); }
+    if (!chk.empty()) {
+      std::vector<uint32_t> ring(de265hip_decoder::kRing);
+      HIPCHK(hipMemcpy(ring.data(), dec->d_err_ring, ring.size() * 4, hipMemcpyDeviceToHost), DE265HIP_ERROR_DECODING);
+      for (auto& e : chk)
+        if (ring[e.first]) {
+          err = 1;
+          std::lock_guard<std::mutex> lk(dec->mu);
+          if (dec->ring_owner[e.first] == e.second) (void)hipMemset(dec->d_err_ring + e.first, 0, 4);      // reported once
+        }
+    }
+  }
   if (dec->dbg & 16) {                  // diagnostic build switch: dump and clear the phase stamps
     uint32_t st[16];
     HIPCHK(hipMemcpy(st, dec->d_err + 8, sizeof(st), hipMemcpyDeviceToHost), DE265HIP_ERROR_DECODING);
@@ -2359,7 +2639,7 @@ int de265hip_decoder_sync(de265hip_decoder* dec)
             st[7], st[6] / n, st[0] / n, st[1] / n, st[2] / n, st[3] / n, st[4] / n, st[5] / n);
     (void)hipMemset(dec->d_err + 8, 0, sizeof(st));
   }
-  if (err) { (void)hipMemset(dec->d_err, 0, 4); return DE265HIP_ERROR_DECODING; }
+  if (err) return DE265HIP_ERROR_DECODING;
   return 0;
 }
 

@@ -1556,15 +1556,17 @@ __device__ __forceinline__ void micro_run(const PicDev& P, const PlaneRef& pl0, 
 template <typename PX>
 __global__ __launch_bounds__(64)
 void k_intra_front(PicDev P, PlaneRef pl0, PlaneRef pl1, PlaneRef pl2, const RunTask* __restrict__ runs,
-                   const TuTask* __restrict__ tasks, const int16_t* __restrict__ resid, int n)
+                   const TuTask* __restrict__ tasks, const int16_t* __restrict__ resid, int n, const uint32_t* __restrict__ front_idx)
 {
   __shared__ __attribute__((aligned(16))) uint16_t mt[MICRO_SLICE];
   __shared__ __attribute__((aligned(16))) int16_t mres[MICRO_RES];
   if ((int)blockIdx.x >= n) return;
-  micro_run<PX, true>(P, pl0, pl1, pl2, runs, nullptr, nullptr, nullptr, tasks, resid, mt, mres, blockIdx.x, threadIdx.x, 0u, 0, 0u);
+  // (front_idx: the front runs' ids when the run records are not sorted - the device-side scan; else they are runs [0, n))
+  const uint32_t r = front_idx ? __builtin_amdgcn_readfirstlane(front_idx[blockIdx.x]) : blockIdx.x;
+  micro_run<PX, true>(P, pl0, pl1, pl2, runs, nullptr, nullptr, nullptr, tasks, resid, mt, mres, r, threadIdx.x, 0u, 0, 0u);
 }
-template __global__ void k_intra_front<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const TuTask*, const int16_t*, int);
-template __global__ void k_intra_front<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const TuTask*, const int16_t*, int);
+template __global__ void k_intra_front<uint8_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const TuTask*, const int16_t*, int, const uint32_t*);
+template __global__ void k_intra_front<uint16_t>(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const TuTask*, const int16_t*, int, const uint32_t*);
 
 
 // Ticket draw on the scalar unit (s_atomic_add ... glc returns the old value through lgkmcnt): unlike a vector

@@ -49,7 +49,7 @@ __global__ void k_run(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, cons
                       const TuTask*, const int16_t*, const uint32_t*, int, int, uint32_t, uint32_t, int, uint32_t, const uint32_t*, const uint32_t*, unsigned long long*);
 #define RUN_SPIN_LIMIT_DEFAULT (1u << 21)   // polls (~1 us each) a k_run wavefront waits for a producer's flag before the picture fails instead of hanging
 template <typename PX>
-__global__ void k_intra_front(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const TuTask*, const int16_t*, int);
+__global__ void k_intra_front(PicDev, PlaneRef, PlaneRef, PlaneRef, const RunTask*, const TuTask*, const int16_t*, int, const uint32_t*);
 template <typename PX>
 __global__ void k_mc(PicDev, DpbTable, PlaneRef, PlaneRef, PlaneRef, const McTask*,
                      const de265hip_slice_params*, int);
