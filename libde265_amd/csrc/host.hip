@@ -1036,7 +1036,8 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
     const int nT = 1 << tu.log2_size;
     const int cw = tu.c_idx ? cwid : p.width, ch = tu.c_idx ? chei : p.height;
     // (one test of the OR of the conditions instead of a branch per condition)
-    if ((unsigned)(tu.c_idx > 2) | (unsigned)((tu.x0 | tu.y0) & 3) | (unsigned)(tu.x0 + nT > cw) | (unsigned)(tu.y0 + nT > ch) | (unsigned)(tu.qp < 0) |
+    if ((unsigned)(tu.c_idx > 2) | (unsigned)((tu.x0 | tu.y0) & (nT - 1)) | (unsigned)(tu.x0 + nT > cw) | (unsigned)(tu.y0 + nT > ch) | (unsigned)(tu.qp < 0) |
+        (unsigned)(((nT * (tu.c_idx ? subw : 1)) >> lc) > 1) | (unsigned)(((nT * (tu.c_idx ? subh : 1)) >> lc) > 1) |      // (a quadtree leaf: aligned to its size, inside one CTB)
         (unsigned)((tu.flags & DE265HIP_TU_CBF) && (((int64_t)tu.coeff_offset + tu.n_coeff > d->n_coeffs) | (tu.n_coeff > nT * nT)))) {
       delete pic; return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
     }

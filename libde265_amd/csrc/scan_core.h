@@ -203,6 +203,8 @@ SCAN_FN bool scan_tu_valid(const ScanParams& P, const de265hip_tu& tu)
   const int nT = 1 << tu.log2_size;
   const int cw = tu.c_idx ? P.cwid : P.width, ch = tu.c_idx ? P.chei : P.height;
   if (tu.c_idx > 2 || ((tu.x0 | tu.y0) & 3) || tu.x0 + nT > cw || tu.y0 + nT > ch || tu.qp < 0) return false;
+  // a transform block is a leaf of a quadtree: aligned to its size, inside one CTB (the CTB pass keeps a CTB's cells in LDS)
+  if (((tu.x0 | tu.y0) & (nT - 1)) || ((nT * (tu.c_idx ? P.subw : 1)) >> P.lc) > 1 || ((nT * (tu.c_idx ? P.subh : 1)) >> P.lc) > 1) return false;
   if ((tu.flags & DE265HIP_TU_CBF) && ((int64_t)tu.coeff_offset + tu.n_coeff > P.n_coeffs || tu.n_coeff > nT * nT)) return false;
   return true;
 }

@@ -120,9 +120,14 @@ def test_empty_picture_and_errors(dec):
     assert e.value.code == _abi.ERROR_NOT_IMPLEMENTED
     d.params.extended_precision_processing_flag = 0
     d.tus[0].x0 = 4000
-    with pytest.raises(backend.De265HipError) as e:
-        dec.build(2, sp.desc)
+    with pytest.raises(backend.De265HipError) as e:      # (a malformed TU record: found by the device-side scan, reported when
+        bad = dec.build(2, sp.desc)                      #  the picture is launched - or asked for its statistics)
+        try:
+            dec.run(bad, 2)
+        finally:
+            bad.free()
     assert e.value.code == _abi.ERROR_PARAMETER_OUT_OF_RANGE
+    dec.sync()
     # the host mirror refuses planes that do not match what the slot holds (the C entry point trusts its caller)
     assert dec.dpb_info(2) == (w, h, bd, bd)
     with pytest.raises(ValueError):
@@ -951,7 +956,11 @@ def test_monochrome_intra_pictures_against_the_oracle(seed):
         # a chroma TU in a monochrome picture is refused
         sp.d.tus[0].c_idx = 1
         with pytest.raises(backend.De265HipError) as e:
-            d.build(2, sp.desc)
+            bad = d.build(2, sp.desc)
+            try:
+                d.run(bad, 2)
+            finally:
+                bad.free()
         assert e.value.code == _abi.ERROR_PARAMETER_OUT_OF_RANGE
     finally:
         d.close()

@@ -17,6 +17,9 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
 import pysynth  # noqa: E402
 from libde265_amd import backend, _abi  # noqa: E402
 
+MODE = int(os.environ.get("FUZZ_MODE", "0"))
+
+
 def run(seed, N):
     """-> {return code: count} over N corrupted descriptions"""
     L = backend.lib()
@@ -103,7 +106,7 @@ def run(seed, N):
                 elif f == 1: d.n_pcm_samples = int(rng.integers(0, max(1, d.n_pcm_samples)))
                 elif f == 2: d.n_ctbs = int(rng.integers(0, n_ctbs + 1))
                 else: d.n_slices = int(rng.integers(0, n_slices + 1))                # (fewer than the CTBs / PUs refer to)
-        rc = L.de265hip_debug_build_host_only(sp.desc, 1)
+        rc = L.de265hip_debug_build_host_only_ex(sp.desc, 1, MODE, None)      # FUZZ_MODE=2: the passes of scan_core.h (CPU rehearsal)
         codes[rc] = codes.get(rc, 0) + 1
         sp.close()
     return codes
