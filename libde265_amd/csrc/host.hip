@@ -265,7 +265,7 @@ void slot_settled(Slot& s)
 
 struct Geometry {
   int ctbs_w, ctbs_h, w4, h4, tbs_w, tbs_h;
-  std::vector<int> rs2ts, ts2rs;
+  std::vector<int> rs2ts, ts2rs, diag_order;      // diag_order: the CTBs by (x + 2y, y) (scan_core.h "tickets")
   std::vector<uint16_t> tile_id;
   std::vector<int> min_tb_zs;
 };
@@ -295,6 +295,9 @@ int make_geometry(const de265hip_pic_params& p, Geometry& g)
           g.tile_id[y * g.ctbs_w + x] = (uint16_t)tid;
         }
     }
+  g.diag_order.resize(n);
+  for (int i = 0; i < n; i++) g.diag_order[i] = i;
+  { const int cw = g.ctbs_w; std::stable_sort(g.diag_order.begin(), g.diag_order.end(), [cw](int a, int b) { return a % cw + 2 * (a / cw) < b % cw + 2 * (b / cw); }); }
   g.min_tb_zs.assign((size_t)g.tbs_w * g.tbs_h, 0);
   for (int y = 0; y < g.tbs_h; y++)
     for (int x = 0; x < g.tbs_w; x++) {
@@ -1998,6 +2001,7 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
   const size_t o_l0x = L.add(SC.l0_rext.size() * sizeof(TuTask));
   const size_t o_mbx = L.add(n_mailboxes ? mbx.size() * 4 : 0), o_mbs = L.add(n_mailboxes ? mb_segs.size() * 4 : 0);
   const size_t o_grp = L.add(dev_scan ? (size_t)d->n_ctbs * 4 : 0), o_rs2ts = L.add(dev_scan ? (size_t)d->n_ctbs * 4 : 0), o_ts2rs = L.add(dev_scan ? (size_t)d->n_ctbs * 4 : 0);
+  const size_t o_dorder = L.add(dev_scan ? (size_t)d->n_ctbs * 4 : 0);
   const size_t upload_bytes = L.total;                 // everything above is written by the host
   // device-only scratch: boundary strengths, residual blocks, run flags (no staging, no upload)
   const size_t o_bs = L.add(nblk);
@@ -2095,6 +2099,7 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
     uint32_t* grp = (uint32_t*)(host.data() + o_grp);
     for (int a = 0; a < d->n_ctbs; a++) grp[a] = (uint32_t)d->ctbs[a].slice_addr_rs | ((uint32_t)g.tile_id[a] << 16);
     put(o_rs2ts, g.rs2ts.data(), (size_t)d->n_ctbs * 4); put(o_ts2rs, g.ts2rs.data(), (size_t)d->n_ctbs * 4);
+    put(o_dorder, g.diag_order.data(), (size_t)d->n_ctbs * 4);
   }
 
   pt.mark("staging");
@@ -2104,7 +2109,7 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
   ScanBufs& SB = pic->SB; memset(&SB, 0, sizeof(SB));
   if (dev_scan) {
     SB.tus = (const de265hip_tu*)(base + o_tus); SB.ctb_group = (const uint32_t*)(base + o_grp); SB.rs2ts = (const int32_t*)(base + o_rs2ts);
-    SB.ts2rs = (const int32_t*)(base + o_ts2rs); SB.blk_flags = base + o_flags; SB.coeff_pos = (uint16_t*)(base + o_cpos);
+    SB.ts2rs = (const int32_t*)(base + o_ts2rs); SB.ctb_order = (const int32_t*)(base + o_dorder); SB.blk_flags = base + o_flags; SB.coeff_pos = (uint16_t*)(base + o_cpos);
     SB.used_units = dec->dry ? &g_used_units[0][0][0] : dec->d_used_units;
     SL.bind(base, SB);
     pic->cap_resid = cap_resid;

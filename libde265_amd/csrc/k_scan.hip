@@ -2,6 +2,8 @@
 // records on the decoder's copy stream) and, from the same functions compiled for the host, the CPU rehearsal the equivalence
 // tests run without a GPU.  Integer / byte work on a few megabytes of records: no LDS tiling to speak of, no MFMA; the passes
 // are latency chains of a lone thread per unit, and there are thousands of units.
+#include <vector>
+
 #include "scan.h"
 
 namespace d265 {
@@ -72,11 +74,32 @@ void k_scan_prefix(ScanParams P, ScanBufs B, uint32_t cap_resid)
   }
 }
 
-// ---- wave-level helpers (wave64)
-__device__ __forceinline__ int wave_max_i(int v) { for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64)); return v; }
-__device__ __forceinline__ int wave_min_i(int v) { for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64)); return v; }
-__device__ __forceinline__ uint32_t wave_sum_u(uint32_t v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64); return v; }
+// ---- wave-level helpers (wave64).  Reductions by DPP row shifts + row broadcasts (no LDS round trip: a __shfl is a
+// ds_bpermute, ~100 cycles, and six of them in a row make a reduction cost more than everything else in a step of the CTB pass)
+__device__ __forceinline__ int wave_max_i(int v)          // (of non-negative values; the result in every lane)
+{
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true));   // row_shr:1
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true));   // row_shr:2
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true));   // row_shr:4
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true));   // row_shr:8
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true));   // row_bcast:15
+  v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true));   // row_bcast:31
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ uint32_t wave_sum_u(uint32_t x)
+{
+  int v = (int)x;
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);
+  return (uint32_t)__builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_min_i(int v) { return 0x7FFFFFFF - wave_max_i(0x7FFFFFFF - v); }      // (v >= 0)
 __device__ __forceinline__ uint64_t lanes_below(int lane) { return lane ? (~0ull >> (64 - lane)) : 0ull; }
+#define WAVE_ORDER() asm volatile("" ::: "memory")        // single-wavefront workgroups: LDS executes a wavefront's operations in order; only the compiler must not move them
 
 // The CTB pass, one WAVEFRONT per CTB (scan_core.h scan_ctb is the same pass as one thread's loop: the CPU rehearsal; the
 // equivalence test holds this kernel to it).  What is sequential - which run a TU joins depends on the TUs before it - runs
@@ -154,9 +177,9 @@ void k_scan_ctbs(ScanParams P, ScanBufs B)
     const uint32_t pos = (uint32_t)tu.x0 | ((uint32_t)tu.y0 << 16), shape = (uint32_t)tu.log2_size | ((uint32_t)tu.c_idx << 8);
     for (uint64_t im = __ballot(cls == 3); im; im &= im - 1) {
       const int src = __builtin_ctzll(im);
-      const uint32_t pos_u = __shfl(pos, src, 64), shape_u = __shfl(shape, src, 64);
-      const uint64_t mask = ((uint64_t)(uint32_t)__shfl((int)(av >> 32), src, 64) << 32) | (uint32_t)__shfl((int)av, src, 64);
-      const uint64_t need0 = ((uint64_t)(uint32_t)__shfl((int)(nd >> 32), src, 64) << 32) | (uint32_t)__shfl((int)nd, src, 64);
+      const uint32_t pos_u = __builtin_amdgcn_readlane(pos, src), shape_u = __builtin_amdgcn_readlane(shape, src);
+      const uint64_t mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(av >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)av, src);
+      const uint64_t need0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(nd >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)nd, src);
       const int xB = pos_u & 0xFFFF, yB = pos_u >> 16, log2 = shape_u & 0xFF, c = shape_u >> 8, nT = 1 << log2, corner = nT >> 1;
       const int sw = c ? P.subw : 1, sh = c ? P.subh : 1;
       const int ox4 = (cx0 / sw) >> 2, oy4 = (cy0 / sh) >> 2;
@@ -182,7 +205,7 @@ void k_scan_ctbs(ScanParams P, ScanBufs B)
       const uint64_t loc_m = __ballot(in_need && local);
       const bool reads_cur = __ballot(in_need && local && vrun == crun) != 0;
       int llev = wave_max_i((in_need && local && vrun == crun) ? vlev : 0) + 1;
-      const int p0 = loc_m ? __shfl(vrun, __builtin_ctzll(loc_m), 64) : -1;
+      const int p0 = loc_m ? __builtin_amdgcn_readlane(vrun, __builtin_ctzll(loc_m)) : -1;
       const bool multi = __ballot(in_need && local && vrun != p0) != 0;
       int r = crun;
       bool extends = r >= 0 && s_ntus[r] < 255;
@@ -199,14 +222,15 @@ void k_scan_ctbs(ScanParams P, ScanBufs B)
         if (lx + 1 <= 250) { r = p0; llev = lx + 1; merged = true; }
       }
       if (!extends && !merged) { r = n_local++; cur_run[c] = r; llev = 1; }
-      __syncthreads();                                   // (every lane has read s_ntus and the window)
+      WAVE_ORDER();                                      // (every lane has read s_ntus and the window)
       if (lane == 0) {
         s_ntus[r]++;
         B.tu_info[base + src] = (uint32_t)r | ((uint32_t)llev << 16) | (foreign ? SCAN_TI_FOREIGN : 0u) | SCAN_TI_INTRA;
+        B.tu_run[base + src] = ibase + (uint32_t)r;
       }
       const int n4 = nT >> 2;
       if (lane < n4 * n4) W[(wy0 + lane / n4 + 1) * SCW_W + (wx0 + lane % n4 + 1)] = (uint32_t)r | ((uint32_t)llev << 16) | (1u << 31);
-      __syncthreads();
+      WAVE_ORDER();
     }
   }
   // ---- the CTB's runs: sizes, CTB, a place in the run list
@@ -217,33 +241,41 @@ void k_scan_ctbs(ScanParams P, ScanBufs B)
 }
 
 // The run pass, one WAVEFRONT per run (persistent: a fixed grid walks the run list).  scan_core.h scan_run is the same pass as
-// one thread's loop.
+// one thread's loop.  A run is a chain of dependent global round trips if written naively (record -> CTB -> TU words -> TU
+// records -> cells -> their TUs' runs ..., ~50 of them: 100 us per run); here the run's TU records, masks and words are fetched
+// ONCE into LDS (a lane each), every later step works on LDS, and the producers are resolved in two batched round trips
+// (all needed cells, then the run ids behind them) into a hash set in LDS.
 #define SCR_MAX 256
+#define SCR_CAND (64 * 33)
 __global__ __launch_bounds__(64)
 void k_scan_runs1(ScanParams P, ScanBufs B)
 {
   __shared__ int tix[SCR_MAX];
+  __shared__ uint4 s_rec[SCR_MAX];                     // the TU records (de265hip_tu, 16 bytes)
+  __shared__ uint64_t s_need[SCR_MAX], s_av[SCR_MAX];
   __shared__ uint32_t keys[SCR_MAX], sorted[SCR_MAX], s_samp[SCR_MAX + 1];
-  __shared__ uint8_t s_lev[SCR_MAX], s_coll[SCR_MAX], s_l2[SCR_MAX], s_rdy[64];
-  __shared__ uint32_t s_tab[512];
-  __shared__ uint32_t s_nd;
+  __shared__ uint8_t s_lev[SCR_MAX], s_coll[SCR_MAX], s_rdy[64];
+  __shared__ uint32_t s_tab[512], s_cand[SCR_CAND];
+  __shared__ uint32_t s_nd, s_ncand;
   const int lane = threadIdx.x;
   if (B.counts->status) return;
   const uint32_t n_listed = B.counts->n_listed;
   uint32_t cls_start[4];
   for (int k = 0; k < 4; k++) cls_start[k] = scan_l0_class_start(B.counts->n_l0_size, k);
+  auto rec_of = [&](int k) -> de265hip_tu { de265hip_tu t; const uint4 v = s_rec[k]; __builtin_memcpy(&t, &v, 16); return t; };
   for (uint32_t qrun = blockIdx.x; qrun < n_listed; qrun += gridDim.x) {
     const uint32_t s = B.run_list[qrun];
     const int rs = (int)B.run_rs[s];
     const ScanCtb& C = B.ctb[rs];
     const int r = (int)(s - C.intra_base);
+    const uint32_t c_first = C.first_tu, c_end = C.end_tu;
     // ---- its TUs (decode order), and what the runs before it in this CTB take of the CTB's lists
     int n = 0;
     uint32_t n_before = 0, samp_before = 0, ro_before[4] = { 0, 0, 0, 0 }, rext_ro_before = 0;
-    for (uint32_t base = C.first_tu; base < C.end_tu; base += 64) {
+    for (uint32_t base = c_first; base < c_end; base += 64) {
       const uint32_t i = base + lane;
       uint32_t ti = 0;
-      if (i < C.end_tu) ti = B.tu_info[i];
+      if (i < c_end) ti = B.tu_info[i];
       const bool intra = ti & SCAN_TI_INTRA;
       const int rr = (int)SCAN_TI_RUN(ti);
       if (intra && rr < r) {
@@ -254,30 +286,35 @@ void k_scan_runs1(ScanParams P, ScanBufs B)
         if (cbf || (rx & D265_RX_XCC)) { if (rx) rext_ro_before++; else ro_before[tu.log2_size - 2]++; }
       }
       const uint64_t m = __ballot(intra && rr == r);
-      if (intra && rr == r) { const int k = n + __popcll(m & lanes_below(lane)); if (k < SCR_MAX) tix[k] = (int)i; }
+      if (intra && rr == r) { const int k = n + __popcll(m & lanes_below(lane)); if (k < SCR_MAX) { tix[k] = (int)i; s_lev[k] = (uint8_t)SCAN_TI_LLEV(ti); s_coll[k] = (ti & SCAN_TI_FOREIGN) ? 1 : 0; } }
       n += __popcll(m);
     }
     n_before = wave_sum_u(n_before); samp_before = wave_sum_u(samp_before); rext_ro_before = wave_sum_u(rext_ro_before);
     for (int k = 0; k < 4; k++) ro_before[k] = wave_sum_u(ro_before[k]);
-    __syncthreads();
+    WAVE_ORDER();
     if (n == 0 || n > 255 || n != (int)B.run_ntus[s]) { if (lane == 0) scan_fail(B, DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE); return; }
+    // ---- the run's records into LDS, a lane each (the only time they are read from memory)
+    bool foreign = false;
+    for (int k = lane; k < n; k += 64) {
+      const int i = tix[k];
+      s_rec[k] = *reinterpret_cast<const uint4*>(B.tus + i);
+      s_need[k] = B.tu_need[i]; s_av[k] = B.tu_avail[i];
+      foreign = foreign || s_coll[k];
+    }
+    WAVE_ORDER();
     // ---- box, window reach, samples, levels: every lane its TUs (k = lane, lane + 64, ..), then across the lanes
     int x0 = 1 << 30, y0 = 1 << 30, x1 = 0, y1 = 0, wx1 = 0, wy1 = 0, nl = 0, c = 0;
-    uint32_t own_samples = 0, cand = 0;
-    bool foreign = false, big = false, too_big = false;
+    uint32_t own_samples = 0;
+    bool big = false, too_big = false;
     for (int k = lane; k < n; k += 64) {
-      const de265hip_tu tu = B.tus[tix[k]];
-      const uint32_t ti = B.tu_info[tix[k]];
+      const de265hip_tu tu = rec_of(k);
       const int nT = 1 << tu.log2_size;
       c = tu.c_idx;
       x0 = min(x0, (int)tu.x0); y0 = min(y0, (int)tu.y0); x1 = max(x1, tu.x0 + nT); y1 = max(y1, tu.y0 + nT);
       wx1 = max(wx1, tu.x0 + 2 * nT); wy1 = max(wy1, tu.y0 + 2 * nT);
       own_samples += (uint32_t)(nT * nT);
-      nl = max(nl, (int)SCAN_TI_LLEV(ti));
-      foreign = foreign || (ti & SCAN_TI_FOREIGN);
+      nl = max(nl, (int)s_lev[k]);
       big = big || tu.log2_size == 4; too_big = too_big || tu.log2_size > 4;
-      s_lev[k] = (uint8_t)SCAN_TI_LLEV(ti); s_l2[k] = tu.log2_size;
-      cand += (uint32_t)__popcll(B.tu_need[tix[k]]);
     }
     x0 = wave_min_i(x0); y0 = wave_min_i(y0); x1 = wave_max_i(x1); y1 = wave_max_i(y1); wx1 = wave_max_i(wx1); wy1 = wave_max_i(wy1);
     nl = wave_max_i(nl); c = wave_max_i(c);
@@ -297,8 +334,8 @@ void k_scan_runs1(ScanParams P, ScanBufs B)
     if (dense) {
       bool bad = false;
       for (int k = lane; k < n; k += 64) {
-        const de265hip_tu tu = B.tus[tix[k]];
-        const uint64_t avail = B.tu_avail[tix[k]];
+        const de265hip_tu tu = rec_of(k);
+        const uint64_t avail = s_av[k];
         const int nT = 1 << tu.log2_size, xB = tu.x0, yB = tu.y0, corner = nT >> 1;
         if (xB > x0 && yB + 2 * nT > y1) {
           int umax = (yB + 2 * nT - 1 - y1) >> 2; if (umax > corner - 1) umax = corner - 1;
@@ -322,19 +359,19 @@ void k_scan_runs1(ScanParams P, ScanBufs B)
     uint32_t mb_id = 0xFFFFFFFFu;
     if ((P.flags & SCANF_MAILBOX) && !micro && dense) {
       if (lane == 0) mb_id = atomicAdd(&B.counts->n_mailboxes, 1u);
-      mb_id = __shfl(mb_id, 0, 64);
+      mb_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)mb_id);
       if (mb_id >= P.cap_mb) mb_id = 0xFFFFFFFFu;            // (beyond the mailboxes there are: the run does without)
       else if ((P.flags & SCANF_MB_PHASES) && c == 0 && x1 - x0 <= 64 && y1 - y0 <= 64) {
         s_rdy[lane] = 255;
-        __syncthreads();
+        WAVE_ORDER();
         for (int k = lane; k < n; k += 64) {
-          const de265hip_tu tu = B.tus[tix[k]];
+          const de265hip_tu tu = rec_of(k);
           const int nT = 1 << tu.log2_size;
           const uint8_t ep = (uint8_t)(s_lev[k] - 1);
           if (tu.y0 + nT == y1) for (int q = 0; q < (nT >> 1); q++) s_rdy[((tu.x0 - x0) >> 1) + q] = ep;
           if (tu.x0 + nT == x1) for (int q = 0; q < (nT >> 1); q++) s_rdy[32 + ((tu.y0 - y0) >> 1) + q] = ep;
         }
-        __syncthreads();
+        WAVE_ORDER();
         B.rdy_tab[64 * (size_t)mb_id + lane] = s_rdy[lane];
       }
     }
@@ -343,15 +380,16 @@ void k_scan_runs1(ScanParams P, ScanBufs B)
     // ---- chain order: list (wavefront, or 4 = collective) | in-run level | decode index; the rank of a TU inside its level
     // counts the non-collective TUs of that level before it
     const int nwv = micro ? 1 : P.run_waves;
-    for (int k = lane; k < n; k += 64) s_coll[k] = (B.tus[tix[k]].log2_size > 3 && !micro) ? 1 : 0;
-    __syncthreads();
+    WAVE_ORDER();
+    for (int k = lane; k < n; k += 64) s_coll[k] = (rec_of(k).log2_size > 3 && !micro) ? 1 : 0;
+    WAVE_ORDER();
     for (int k = lane; k < n; k += 64) {
       int rank = 0;
       for (int q = 0; q < k; q++) rank += (s_lev[q] == s_lev[k] && !s_coll[q]) ? 1 : 0;
       const int list = s_coll[k] ? 4 : rank % nwv;
       keys[k] = ((uint32_t)list << 20) | ((uint32_t)s_lev[k] << 8) | (uint32_t)k;
     }
-    __syncthreads();
+    WAVE_ORDER();
     int we[4] = { 0, 0, 0, 0 };
     for (int k = lane; k < n; k += 64) {
       int posn = 0;
@@ -361,11 +399,18 @@ void k_scan_runs1(ScanParams P, ScanBufs B)
     }
     for (int w = 0; w < 4; w++) o.wave_end[w] = (uint16_t)wave_sum_u((uint32_t)we[w]);
     o.n_lvls = (uint16_t)(nl > 0 ? nl - 1 : 0);
-    __syncthreads();
-    // ---- sample offsets in chain order (exclusive prefix of the TU sizes)
-    if (lane == 0) { uint32_t acc = 0; for (int oi = 0; oi < n; oi++) { s_samp[oi] = acc; acc += 1u << (2 * s_l2[sorted[oi] & 0xFFu]); } s_samp[n] = acc; }
-    __syncthreads();
-    o.n_samples = s_samp[n];
+    WAVE_ORDER();
+    // ---- sample offsets in chain order (exclusive prefix of the TU sizes): a lane's four entries, then across the lanes
+    {
+      uint32_t sz[4], mine = 0;
+      for (int j = 0; j < 4; j++) { const int oi = 4 * lane + j; sz[j] = oi < n ? 1u << (2 * rec_of((int)(sorted[oi] & 0xFFu)).log2_size) : 0u; mine += sz[j]; }
+      uint32_t incl = mine;                                    // inclusive scan over the lanes (Hillis-Steele on ds_bpermute: six steps, once per run)
+      for (int off = 1; off < 64; off <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, off, 64); if (lane >= off) incl += v; }
+      uint32_t acc = incl - mine;
+      for (int j = 0; j < 4; j++) { const int oi = 4 * lane + j; if (oi <= n && oi < SCR_MAX + 1) s_samp[oi] = acc; acc += sz[j]; }
+      o.n_samples = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    WAVE_ORDER();
     // ---- the run-ordered TU records + the residual-only copies (level-0 tasks), a lane per TU, 64 at a time
     uint32_t ro_at[4] = { 0, 0, 0, 0 }, rext_at = 0;
     for (int ob = 0; ob < n; ob += 64) {
@@ -376,13 +421,14 @@ void k_scan_runs1(ScanParams P, ScanBufs B)
       int trx = 0, i = 0; bool ro_on = false;
       uint32_t coeff_offset = 0;
       if (have) {
-        i = tix[sorted[oi] & 0xFFu];
-        tu = B.tus[i];
+        const int k = (int)(sorted[oi] & 0xFFu);
+        i = tix[k];
+        tu = rec_of(k);
         tt = scan_task_of(tu);
         const int m = tu.intra_mode < 35 ? tu.intra_mode : 1;
         tt.angle = (int8_t)scan_intra_angle(m); tt.inv_angle = (int16_t)scan_inv_angle(m);
-        tt.avail = B.tu_avail[i];
-        tt.run_level = (uint8_t)(SCAN_TI_LLEV(B.tu_info[i]) - 1);
+        tt.avail = s_av[k];
+        tt.run_level = (uint8_t)(s_lev[k] - 1);
         coeff_offset = tt.coeff_offset;
         tt.resid_offset = o.res_offset + s_samp[oi];
         tt.coeff_offset = s_samp[oi];
@@ -416,40 +462,52 @@ void k_scan_runs1(ScanParams P, ScanBufs B)
         B.run_tus[o.first_tu + (uint32_t)oi] = tt;
       }
     }
-    // ---- producers: every needed unit of every TU -> the run behind its cell; each run once (a hash set in LDS: the cells a
-    // run inside one CTB can need number fewer than its slots)
+    // ---- producers: the cells of every needed unit of every TU (64 TUs at a time, a lane each, into a list), then - a lane
+    // per list entry, all loads of a step in flight together - the TU behind the cell and the run behind the TU; each run
+    // once: a hash set in LDS (the cells a run inside one CTB can need number fewer than its slots)
     for (int q = lane; q < 512; q += 64) s_tab[q] = 0xFFFFFFFFu;
     if (lane == 0) s_nd = 0;
-    __syncthreads();
     {
       const int mw = P.map_w[c];
-      for (int k = lane; k < n; k += 64) {
-        const de265hip_tu tu = B.tus[tix[k]];
-        for (uint64_t need = B.tu_need[tix[k]]; need; need &= need - 1) {
-          const ScanCell v = B.cell[c][scan_cell_of(__builtin_ctzll(need), tu.x0, tu.y0, 1 << tu.log2_size, mw)];
-          if ((uint32_t)v == 0) continue;
-          const uint32_t j = (uint32_t)v - 1;
-          const uint32_t tj = B.tu_info[j];
-          if (!(tj & SCAN_TI_INTRA)) continue;
-          const uint32_t ps = B.ctb[scan_tu_ctb(P, B.tus[j])].intra_base + SCAN_TI_RUN(tj);
-          if (ps == s) continue;
-          uint32_t hsh = (ps * 2654435761u) >> 23;
-          for (int probe = 0; probe < 512; probe++, hsh = (hsh + 1) & 511) {
-            const uint32_t old = atomicCAS(&s_tab[hsh], 0xFFFFFFFFu, ps);
-            if (old == 0xFFFFFFFFu) { atomicAdd(&s_nd, 1u); break; }
-            if (old == ps) break;
+      const ScanCell* cells = B.cell[c];
+      for (int kb = 0; kb < n; kb += 64) {
+        if (lane == 0) s_ncand = 0;
+        WAVE_ORDER();
+        const int k = kb + lane;
+        if (k < n) {
+          const de265hip_tu tu = rec_of(k);
+          for (uint64_t need = s_need[k]; need; need &= need - 1)
+            s_cand[atomicAdd(&s_ncand, 1u)] = (uint32_t)scan_cell_of(__builtin_ctzll(need), tu.x0, tu.y0, 1 << tu.log2_size, mw);
+        }
+        WAVE_ORDER();
+        const uint32_t nc = s_ncand;
+        for (uint32_t q0 = 0; q0 < nc; q0 += 256) {
+          uint32_t j[4], ps[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { const uint32_t q = q0 + 64 * u + lane; j[u] = q < nc ? (uint32_t)cells[s_cand[q]] : 0u; }
+#pragma unroll
+          for (int u = 0; u < 4; u++) ps[u] = j[u] ? B.tu_run[j[u] - 1] : s;
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            if (ps[u] == s) continue;
+            uint32_t hsh = (ps[u] * 2654435761u) >> 23;
+            for (int probe = 0; probe < 512; probe++, hsh = (hsh + 1) & 511) {
+              const uint32_t old = atomicCAS(&s_tab[hsh], 0xFFFFFFFFu, ps[u]);
+              if (old == 0xFFFFFFFFu) { atomicAdd(&s_nd, 1u); break; }
+              if (old == ps[u]) break;
+            }
           }
         }
+        WAVE_ORDER();
       }
     }
-    __syncthreads();
+    WAVE_ORDER();
     const uint32_t nd = s_nd;
-    (void)cand;
     if (nd > 500) { if (lane == 0) scan_fail(B, DE265HIP_ERROR_NOT_IMPLEMENTED); return; }
     if (nd) {
       uint32_t at = 0;
       if (lane == 0) at = atomicAdd(&B.counts->n_deps_alloc, nd);
-      at = __shfl(at, 0, 64);
+      at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
       if (at + nd > P.cap_deps) { if (lane == 0) scan_fail(B, DE265HIP_ERROR_NOT_IMPLEMENTED); return; }
       o.dep_offset = at;
       uint32_t w = 0;
@@ -471,149 +529,164 @@ void k_scan_runs1(ScanParams P, ScanBufs B)
     }
     if (front) {
       // algorithmic bytes of the front runs (bench: roofline of k_intra_front)
-      unsigned long long alg = 0;
-      const unsigned long long bpp = (unsigned long long)(c ? P.bppC : P.bppY);
-      for (int k = lane; k < n; k += 64) { const unsigned long long nT = 1ull << B.tus[tix[k]].log2_size; alg += bpp * (4 * nT + 1) + bpp * nT * nT; }
-      for (int off = 32; off > 0; off >>= 1) alg += __shfl_xor(alg, off, 64);
+      uint32_t alg = 0;
+      const uint32_t bpp = (uint32_t)(c ? P.bppC : P.bppY);
+      for (int k = lane; k < n; k += 64) { const uint32_t nT = 1u << rec_of(k).log2_size; alg += bpp * (4 * nT + 1) + bpp * nT * nT; }
+      alg = wave_sum_u(alg);
       if (lane == 0) scan_add64(&B.counts->alg_intra_front, alg);
     }
-    __syncthreads();
+    WAVE_ORDER();
   }
 }
 
-// the two later run passes: a thread per listed run (scan_core.h scan_run2 / scan_run3)
-template <int PASS>
+// The second run pass, a wavefront per run: the run's chain-ordered TU records are staged in LDS by all lanes, then ONE lane
+// runs scan_run2 on them (producers that are front runs leave the list; mailbox segments and need epochs of a reader).  The
+// logic is a few thousand scalar steps on ~40 records: not worth spreading over lanes, but on records in LDS it takes ~15 us
+// instead of the ~500 us a thread took that fetched them one by one from memory next to 63 others doing the same.
 __global__ __launch_bounds__(64)
-void k_scan_runs(ScanParams P, ScanBufs B)
+void k_scan_runs2(ScanParams P, ScanBufs B)
+{
+  __shared__ TuTask s_tus[SCR_MAX];
+  const int lane = threadIdx.x;
+  if (B.counts->status) return;
+  const uint32_t n_listed = B.counts->n_listed;
+  for (uint32_t qrun = blockIdx.x; qrun < n_listed; qrun += gridDim.x) {
+    const uint32_t s = B.run_list[qrun];
+    const RunTask* R = B.runs + s;
+    const uint32_t mic = R->micro, n = R->n_tus, first = R->first_tu;
+    const uint32_t n_all = B.run_nall[s] & 0x7FFFFFFFu;
+    const bool foreign = B.run_nall[s] >> 31;
+    // (only a run that can become a mailbox reader looks at its TU records)
+    const bool cand = (P.flags & SCANF_MAILBOX) && !(mic & 1) && (mic & 2) && !foreign && n_all > 0 && n_all <= 8 && n <= SCR_MAX;
+    if (cand) {
+      const uint4* src = reinterpret_cast<const uint4*>(B.run_tus + first);
+      uint4* dst = reinterpret_cast<uint4*>(s_tus);
+      for (uint32_t q = lane; q < 2 * n; q += 64) dst[q] = src[q];
+    }
+    WAVE_ORDER();
+    if (lane == 0) scan_run2(P, B, s, cand ? s_tus : nullptr);
+    WAVE_ORDER();
+  }
+}
+
+// the third run pass: a thread per listed run (scan_core.h scan_run3)
+__global__ __launch_bounds__(64)
+void k_scan_runs3(ScanParams P, ScanBufs B)
 {
   const uint32_t q = blockIdx.x * 64 + threadIdx.x;
   if (B.counts->status || q >= B.counts->n_listed) return;
-  const uint32_t s = B.run_list[q];
-  if (PASS == 2) scan_run2(P, B, s);
-  else scan_run3(P, B, s);
+  scan_run3(P, B, B.run_list[q]);
 }
 
-// run levels (longest producer chain), ticket slots in level order - one workgroup
-#define SCO_NMAX 12288                   // runs / producer entries the LDS fast path of the level rounds holds
-#define SCO_DMAX 40960
-#define SCO_LDS_BYTES ((3 * SCO_NMAX + SCO_DMAX) * 2)
-__global__ __launch_bounds__(1024)
+// coefficient positions inside their TU's block (de265hip_picture_build's job on the host until round 3): sixteen lanes per TU
+// record, striding its list; a position beyond the block is folded into it and the picture fails
+__global__ __launch_bounds__(256)
+void k_scan_check_pos(ScanParams P, ScanBufs B)
+{
+  const int i = (blockIdx.x * 256 + threadIdx.x) >> 4, sub = threadIdx.x & 15;
+  if (i >= P.n_tus) return;
+  const de265hip_tu tu = B.tus[i];
+  if (!(tu.flags & DE265HIP_TU_CBF) || !scan_tu_valid(P, tu)) return;
+  const unsigned nS = 1u << (2 * tu.log2_size), n = tu.n_coeff;
+  uint16_t* p = B.coeff_pos + tu.coeff_offset;
+  bool bad = false;
+  for (unsigned k = sub; k < n; k += 16) {
+    const unsigned v = p[k];
+    if (v >= nS) { p[k] = (uint16_t)(v & (nS - 1)); bad = true; }
+  }
+  if (bad) scan_fail(B, DE265HIP_ERROR_DECODING);
+}
+
+// Ticket slots (scan_core.h "tickets"), one workgroup: the CTBs in ctb_order are dealt to the threads in contiguous chunks; how
+// a chunk's runs fill tickets depends on how full the open ticket is when the chunk begins, so every thread first computes its
+// chunk's effect for each of the eight possible fill states (a table), the tables are composed by a prefix scan (composition
+// of such tables is associative), and every thread then walks its chunk again from its true start state and writes the slots.
+#define SCO_THREADS 256
+__global__ __launch_bounds__(SCO_THREADS)
 void k_scan_order(ScanParams P, ScanBufs B, uint32_t cap_levels)
 {
-  __shared__ int s_changed;
-  __shared__ uint32_t s_max, s_cnt;
+  __shared__ uint32_t tab[2][SCO_THREADS][RUN_TICKET_SLOTS];       // per chunk and fill state at its start: tickets it opens | fill state at its end << 28
+  __shared__ uint32_t s_diag[4096];
+  __shared__ uint32_t s_widest, s_ready, s_ndiag;
   const int tid = threadIdx.x;
   ScanCounts& K = *B.counts;
   if (K.status) return;
-  const uint32_t n = K.n_listed;
-  if (tid == 0) { s_max = 1; s_cnt = 0; }
+  const int n = P.n_ctbs, chunk = (n + SCO_THREADS - 1) / SCO_THREADS;
+  const int t0 = min(n, tid * chunk), t1 = min(n, t0 + chunk);
+  const uint32_t victim = K.victim;
+  const int n_diag = P.ctbs_w + 2 * P.ctbs_h;
+  uint32_t* diag = n_diag <= 4096 ? s_diag : B.lvl_cnt;          // ticketed runs per anti-diagonal (for the worker count)
+  if ((uint32_t)n_diag > 5 * cap_levels) { if (tid == 0) scan_fail(B, DE265HIP_ERROR_NOT_IMPLEMENTED); return; }
+  for (int q = tid; q < n_diag; q += SCO_THREADS) diag[q] = 0;
+  if (tid == 0) { s_widest = 0; s_ready = 0; s_ndiag = 0; }
   __syncthreads();
-  // Levels by monotone relaxation: one more level is final after every round.  Fast path: everything a round touches in LDS -
-  // the levels by position in the run list, every run's producers as list positions (a picture's ~6 000 runs with their
-  // ~20 000 producer entries: the rounds of an all-intra 4K picture, 126 of them, took 10 us each on the arrays in global
-  // memory, dependent L2 round trips; 0.3 us on LDS).  A picture beyond the LDS arrays takes the global-memory rounds.
-  extern __shared__ uint16_t dyn[];
-  uint16_t* lev = dyn; uint16_t* doff = lev + SCO_NMAX; uint16_t* dna = doff + SCO_NMAX; uint16_t* dpos = dna + SCO_NMAX;
-  bool fast = n <= SCO_NMAX;
-  if (fast) {
-    for (uint32_t q = tid; q < n; q += 1024) B.run_level[B.run_list[q]] = q;        // (for now: a run's position in the list)
-    __syncthreads();
-    uint32_t tot = 0;
-    for (uint32_t q = tid; q < n; q += 1024) tot += B.run_nall[B.run_list[q]] & 0x7FFFFFFFu;
-    atomicAdd(&s_cnt, tot);
-    __syncthreads();
-    fast = s_cnt <= SCO_DMAX;
-    __syncthreads();
-    if (tid == 0) s_cnt = 0;
-    __syncthreads();
-  }
-  if (fast) {
-    for (uint32_t q = tid; q < n; q += 1024) {
-      const uint32_t s = B.run_list[q];
-      const uint32_t na = B.run_nall[s] & 0x7FFFFFFFu;
-      const uint32_t* dl = B.deps + B.runs[s].dep_offset;
-      const uint32_t o = atomicAdd(&s_cnt, na);
-      lev[q] = 1; doff[q] = (uint16_t)o; dna[q] = (uint16_t)na;
-      for (uint32_t d = 0; d < na; d++) dpos[o + d] = (uint16_t)B.run_level[dl[d]];
+  // ---- phase 1: the chunk's table
+  ScanTicketState st[RUN_TICKET_SLOTS];
+  for (int o = 0; o < RUN_TICKET_SLOTS; o++) { st[o].tickets = 0; st[o].fill = (uint32_t)o; }
+  uint32_t ready = 0;
+  for (int t = t0; t < t1; t++) {
+    const int rs = B.ctb_order[t];
+    const ScanCtb& C = B.ctb[rs];
+    const uint32_t nr = C.n_runs, ib = C.intra_base;
+    uint32_t cnt = 0;
+    for (uint32_t r = 0; r < nr; r++) {
+      const uint32_t s = ib + r;
+      const uint32_t mic = B.runs[s].micro;
+      if ((mic & RUN_MICRO_FRONT) || s == victim) continue;
+      uint32_t tk, sl;
+      for (int o = 0; o < RUN_TICKET_SLOTS; o++) scan_ticket_step(st[o], mic & 1, &tk, &sl);
+      cnt++;
+      if (B.runs[s].n_deps == 0) ready++;
     }
-    __syncthreads();
-    for (;;) {
-      if (tid == 0) s_changed = 0;
-      __syncthreads();
-      bool ch = false;
-      for (uint32_t q = tid; q < n; q += 1024) {
-        const uint32_t o = doff[q], na = dna[q];
-        uint32_t l = 1;
-        for (uint32_t d = 0; d < na; d++) { const uint32_t pl = (uint32_t)lev[dpos[o + d]] + 1; l = pl > l ? pl : l; }
-        if (l != lev[q]) { lev[q] = (uint16_t)l; ch = true; }
+    if (cnt) atomicAdd(&diag[rs % P.ctbs_w + 2 * (rs / P.ctbs_w)], cnt);
+  }
+  if (ready) atomicAdd(&s_ready, ready);
+  for (int o = 0; o < RUN_TICKET_SLOTS; o++) tab[0][tid][o] = st[o].tickets | (st[o].fill << 28);
+  __syncthreads();
+  // ---- phase 2: inclusive prefix composition (Hillis-Steele): tab[i] := tab[i - off] then tab[i]
+  int cur = 0;
+  for (int off = 1; off < SCO_THREADS; off <<= 1) {
+    for (int o = 0; o < RUN_TICKET_SLOTS; o++) {
+      uint32_t v = tab[cur][tid][o];
+      if (tid >= off) {
+        const uint32_t a = tab[cur][tid - off][o];               // the earlier chunks from state o ...
+        const uint32_t bb = tab[cur][tid][a >> 28];              // ... then this one from where they end
+        v = ((a & 0x0FFFFFFFu) + (bb & 0x0FFFFFFFu)) | (bb & 0xF0000000u);
       }
-      if (ch) s_changed = 1;
-      __syncthreads();
-      const int again = s_changed;
-      __syncthreads();
-      if (!again) break;
+      tab[cur ^ 1][tid][o] = v;
     }
-    for (uint32_t q = tid; q < n; q += 1024) B.run_level[B.run_list[q]] = lev[q];
+    cur ^= 1;
     __syncthreads();
-  } else {
-  for (uint32_t q = tid; q < n; q += 1024) B.run_level[B.run_list[q]] = 1;
+  }
+  // the state this chunk starts from: what all chunks before it make of (0 tickets, closed)
+  ScanTicketState me = { 0, 0 };
+  if (tid > 0) { const uint32_t v = tab[cur][tid - 1][0]; me.tickets = v & 0x0FFFFFFFu; me.fill = v >> 28; }
+  const uint32_t total = tab[cur][SCO_THREADS - 1][0] & 0x0FFFFFFFu;
+  if ((unsigned long long)total * RUN_TICKET_SLOTS > P.cap_slots) { if (tid == 0) scan_fail(B, DE265HIP_ERROR_NOT_IMPLEMENTED); return; }
+  for (uint32_t q = tid; q < total * RUN_TICKET_SLOTS; q += SCO_THREADS) B.slots[q] = 0xFFFFFFFFu;
+  uint32_t w = 0, nd = 0;
+  for (int q = tid; q < n_diag; q += SCO_THREADS) { w = max(w, diag[q]); nd += diag[q] ? 1 : 0; }
+  atomicMax(&s_widest, w); atomicAdd(&s_ndiag, nd);
   __syncthreads();
-  for (;;) {
-    if (tid == 0) s_changed = 0;
-    __syncthreads();
-    bool ch = false;
-    for (uint32_t q = tid; q < n; q += 1024) {
-      const uint32_t s = B.run_list[q];
-      const uint32_t na = B.run_nall[s] & 0x7FFFFFFFu;
-      const uint32_t* dl = B.deps + B.runs[s].dep_offset;
-      uint32_t l = 1;
-      for (uint32_t d = 0; d < na; d++) {
-        const uint32_t pl = __hip_atomic_load(&B.run_level[dl[d]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1;
-        l = pl > l ? pl : l;
-      }
-      if (l != B.run_level[s]) { __hip_atomic_store(&B.run_level[s], l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); ch = true; }
+  // ---- phase 3: the slots
+  for (int t = t0; t < t1; t++) {
+    const int rs = B.ctb_order[t];
+    const ScanCtb& C = B.ctb[rs];
+    const uint32_t nr = C.n_runs, ib = C.intra_base;
+    for (uint32_t r = 0; r < nr; r++) {
+      const uint32_t s = ib + r;
+      const uint32_t mic = B.runs[s].micro;
+      if ((mic & RUN_MICRO_FRONT) || s == victim) continue;
+      uint32_t tk, sl;
+      scan_ticket_step(me, mic & 1, &tk, &sl);
+      B.slots[tk * RUN_TICKET_SLOTS + sl] = (mic & 1) ? (s | 0x80000000u) : s;
     }
-    if (ch) s_changed = 1;
-    __syncthreads();
-    const int again = s_changed;
-    __syncthreads();
-    if (!again) break;
   }
-  }
-  uint32_t mx = 1;
-  for (uint32_t q = tid; q < n; q += 1024) mx = max(mx, B.run_level[B.run_list[q]]);
-  atomicMax(&s_max, mx);
-  __syncthreads();
-  const uint32_t max_rl = n ? s_max : 0;
-  if (max_rl + 2 > cap_levels) { if (tid == 0) scan_fail(B, DE265HIP_ERROR_NOT_IMPLEMENTED); return; }
-  // per level: micro runs, ordinary runs (front runs and the fault-injection victim take no ticket)
-  uint32_t* nm = B.lvl_cnt; uint32_t* no = nm + cap_levels; uint32_t* cm = no + cap_levels; uint32_t* co = cm + cap_levels; uint32_t* tb = co + cap_levels;
-  for (uint32_t l = tid; l < max_rl + 2; l += 1024) { nm[l] = no[l] = cm[l] = co[l] = 0; }
-  __syncthreads();
-  for (uint32_t q = tid; q < n; q += 1024) {
-    const uint32_t s = B.run_list[q];
-    const uint32_t mic = B.runs[s].micro;
-    if ((mic & RUN_MICRO_FRONT) || s == K.victim) continue;
-    atomicAdd((mic & 1) ? &nm[B.run_level[s]] : &no[B.run_level[s]], 1u);
-  }
-  __syncthreads();
   if (tid == 0) {
-    uint32_t at = 0, widest = 0;
-    for (uint32_t l = 0; l < max_rl + 2; l++) { tb[l] = at; at += (nm[l] + RUN_TICKET_SLOTS - 1) / RUN_TICKET_SLOTS + no[l]; widest = max(widest, nm[l] + no[l]); }
-    K.n_batches = at; K.widest = widest; K.max_rl = max_rl;
-    if ((unsigned long long)at * RUN_TICKET_SLOTS > P.cap_slots) scan_fail(B, DE265HIP_ERROR_NOT_IMPLEMENTED);
-  }
-  __syncthreads();
-  if (K.status) return;
-  const uint32_t n_slots = K.n_batches * RUN_TICKET_SLOTS;
-  for (uint32_t q = tid; q < n_slots; q += 1024) B.slots[q] = 0xFFFFFFFFu;
-  __syncthreads();
-  for (uint32_t q = tid; q < n; q += 1024) {
-    const uint32_t s = B.run_list[q];
-    const uint32_t mic = B.runs[s].micro, l = B.run_level[s];
-    if ((mic & RUN_MICRO_FRONT) || s == K.victim) continue;
-    if (mic & 1) B.slots[tb[l] * RUN_TICKET_SLOTS + atomicAdd(&cm[l], 1u)] = s | 0x80000000u;
-    else B.slots[(tb[l] + (nm[l] + RUN_TICKET_SLOTS - 1) / RUN_TICKET_SLOTS + atomicAdd(&co[l], 1u)) * RUN_TICKET_SLOTS] = s;
+    K.n_batches = total;
+    // workers: as many runs as can be in flight together - an anti-diagonal of the picture, or the runs that wait for nothing
+    K.widest = max(s_widest, s_ready);
+    K.max_rl = s_ndiag;
   }
 }
 
@@ -629,7 +702,7 @@ size_t ScanLayout::plan(const ScanParams& P, size_t at)
   o_counts = add(sizeof(ScanCounts));
   o_run_ntus = add(nr);
   clear_end = at;
-  o_tu_avail = add(nt * 8); o_tu_need = add(nt * 8); o_tu_info = add(nt * 4);
+  o_tu_avail = add(nt * 8); o_tu_need = add(nt * 8); o_tu_info = add(nt * 4); o_tu_run = add(nt * 4);
   o_run_rs = add(nr * 4); o_run_nall = add(nr * 4); o_run_level = add(nr * 4); o_run_list = add(nr * 4); o_pub_flag = add(nr);
   o_rdy_tab = add((size_t)P.cap_mb * 64);
   cap_levels = (uint32_t)nr + 2;
@@ -647,7 +720,7 @@ void ScanLayout::bind(uint8_t* base, ScanBufs& B) const
   for (int c = 0; c < 3; c++) B.cell[c] = (ScanCell*)(base + o_cell[c]);
   B.counts = (ScanCounts*)(base + o_counts);
   B.run_ntus = base + o_run_ntus;
-  B.tu_avail = (uint64_t*)(base + o_tu_avail); B.tu_need = (uint64_t*)(base + o_tu_need); B.tu_info = (uint32_t*)(base + o_tu_info);
+  B.tu_avail = (uint64_t*)(base + o_tu_avail); B.tu_need = (uint64_t*)(base + o_tu_need); B.tu_info = (uint32_t*)(base + o_tu_info); B.tu_run = (uint32_t*)(base + o_tu_run);
   B.run_rs = (uint32_t*)(base + o_run_rs); B.run_nall = (uint32_t*)(base + o_run_nall); B.run_level = (uint32_t*)(base + o_run_level);
   B.run_list = (uint32_t*)(base + o_run_list); B.pub_flag = base + o_pub_flag; B.rdy_tab = base + o_rdy_tab;
   B.lvl_cnt = (uint32_t*)(base + o_lvl_cnt);
@@ -661,19 +734,19 @@ hipError_t scan_enqueue(hipStream_t st, const ScanParams& P, const ScanBufs& B, 
 {
   hipError_t e = hipMemsetAsync(base + L.clear_begin, 0, L.clear_end - L.clear_begin, st);
   if (e != hipSuccess) return e;
-  if (P.n_tus > 0) hipLaunchKernelGGL(k_scan_tus, dim3((P.n_tus + 255) / 256), dim3(256), 0, st, P, B);
+  if (P.n_tus > 0) {
+    ScanParams Pt = P; Pt.flags &= ~SCANF_CHECK_POS;             // (the positions have a kernel of their own: sixteen lanes per TU)
+    hipLaunchKernelGGL(k_scan_tus, dim3((P.n_tus + 255) / 256), dim3(256), 0, st, Pt, B);
+    if (P.flags & SCANF_CHECK_POS) hipLaunchKernelGGL(k_scan_check_pos, dim3((P.n_tus + 15) / 16), dim3(256), 0, st, P, B);
+  }
   hipLaunchKernelGGL(k_scan_prefix, dim3(1), dim3(1024), 0, st, P, B, cap_resid);
   if (P.n_tus > 0) {
     hipLaunchKernelGGL(k_scan_ctbs, dim3(P.n_ctbs), dim3(64), 0, st, P, B);
-    // (the number of runs is only known on the device: a fixed grid of wavefronts walks the run list; the thread-per-run passes
-    //  are launched for the most runs the CTB grid has seen ... which the host does not know either: for one run per intra TU)
+    // (the number of runs is only known on the device: fixed grids of wavefronts walk the run list)
     hipLaunchKernelGGL(k_scan_runs1, dim3(4096), dim3(64), 0, st, P, B);
-    const unsigned g = (unsigned)((P.cap_runs + 63) / 64);
-    hipLaunchKernelGGL(k_scan_runs<2>, dim3(g), dim3(64), 0, st, P, B);
-    if (P.flags & SCANF_MAILBOX) hipLaunchKernelGGL(k_scan_runs<3>, dim3(g), dim3(64), 0, st, P, B);
-    static const hipError_t lds_ok = hipFuncSetAttribute((const void*)k_scan_order, hipFuncAttributeMaxDynamicSharedMemorySize, SCO_LDS_BYTES);
-    if (lds_ok != hipSuccess) return lds_ok;
-    hipLaunchKernelGGL(k_scan_order, dim3(1), dim3(1024), SCO_LDS_BYTES, st, P, B, L.cap_levels);
+    hipLaunchKernelGGL(k_scan_runs2, dim3(4096), dim3(64), 0, st, P, B);
+    if (P.flags & SCANF_MAILBOX) hipLaunchKernelGGL(k_scan_runs3, dim3((unsigned)((P.cap_runs + 63) / 64)), dim3(64), 0, st, P, B);
+    hipLaunchKernelGGL(k_scan_order, dim3(1), dim3(SCO_THREADS), 0, st, P, B, L.cap_levels);
   }
   return hipGetLastError();
 }
@@ -708,40 +781,33 @@ void scan_host_run(const ScanParams& P, const ScanBufs& B, const ScanLayout& L, 
   for (uint32_t s = 0; s < K.n_intra; s++) scan_run2(P, B, s);
   if (P.flags & SCANF_MAILBOX) for (uint32_t s = 0; s < K.n_intra; s++) scan_run3(P, B, s);
   if (K.status) return;
-  // scan_order, serially
-  const uint32_t n = K.n_listed;
-  for (uint32_t q = 0; q < n; q++) B.run_level[B.run_list[q]] = 1;
-  for (bool again = true; again;) {
-    again = false;
-    for (uint32_t q = 0; q < n; q++) {
-      const uint32_t s = B.run_list[q], na = B.run_nall[s] & 0x7FFFFFFFu;
-      const uint32_t* dl = B.deps + B.runs[s].dep_offset;
-      uint32_t l = 1;
-      for (uint32_t d = 0; d < na; d++) l = std::max(l, B.run_level[dl[d]] + 1);
-      if (l != B.run_level[s]) { B.run_level[s] = l; again = true; }
+  // scan_order, serially: the CTBs by (anti-diagonal, row), their runs in order of creation
+  {
+    ScanTicketState st = { 0, 0 };
+    const int n_diag = P.ctbs_w + 2 * P.ctbs_h;
+    std::vector<uint32_t> diag((size_t)n_diag, 0);
+    uint32_t ready = 0;
+    struct Placed { uint32_t s, ticket, slot; };
+    std::vector<Placed> placed;
+    for (int t = 0; t < P.n_ctbs; t++) {
+      const int rs = B.ctb_order[t];
+      const ScanCtb& C = B.ctb[rs];
+      for (uint32_t r = 0; r < C.n_runs; r++) {
+        const uint32_t s = C.intra_base + r, mic = B.runs[s].micro;
+        if ((mic & RUN_MICRO_FRONT) || s == K.victim) continue;
+        uint32_t tk, sl;
+        scan_ticket_step(st, mic & 1, &tk, &sl);
+        placed.push_back({ (mic & 1) ? (s | 0x80000000u) : s, tk, sl });
+        diag[rs % P.ctbs_w + 2 * (rs / P.ctbs_w)]++;
+        if (B.runs[s].n_deps == 0) ready++;
+      }
     }
-  }
-  uint32_t max_rl = 0;
-  for (uint32_t q = 0; q < n; q++) max_rl = std::max(max_rl, B.run_level[B.run_list[q]]);
-  const uint32_t cap_levels = L.cap_levels;
-  if (max_rl + 2 > cap_levels) { scan_fail(B, DE265HIP_ERROR_NOT_IMPLEMENTED); return; }
-  uint32_t* nm = B.lvl_cnt; uint32_t* no = nm + cap_levels; uint32_t* cm = no + cap_levels; uint32_t* co = cm + cap_levels; uint32_t* tb = co + cap_levels;
-  for (uint32_t l = 0; l < max_rl + 2; l++) nm[l] = no[l] = cm[l] = co[l] = 0;
-  for (uint32_t q = 0; q < n; q++) {
-    const uint32_t s = B.run_list[q], mic = B.runs[s].micro;
-    if ((mic & RUN_MICRO_FRONT) || s == K.victim) continue;
-    ((mic & 1) ? nm : no)[B.run_level[s]]++;
-  }
-  uint32_t at = 0, widest = 0;
-  for (uint32_t l = 0; l < max_rl + 2; l++) { tb[l] = at; at += (nm[l] + RUN_TICKET_SLOTS - 1) / RUN_TICKET_SLOTS + no[l]; widest = std::max(widest, nm[l] + no[l]); }
-  K.n_batches = at; K.widest = widest; K.max_rl = max_rl;
-  if ((unsigned long long)at * RUN_TICKET_SLOTS > P.cap_slots) { scan_fail(B, DE265HIP_ERROR_NOT_IMPLEMENTED); return; }
-  for (uint32_t q = 0; q < at * RUN_TICKET_SLOTS; q++) B.slots[q] = 0xFFFFFFFFu;
-  for (uint32_t q = 0; q < n; q++) {
-    const uint32_t s = B.run_list[q], mic = B.runs[s].micro, l = B.run_level[s];
-    if ((mic & RUN_MICRO_FRONT) || s == K.victim) continue;
-    if (mic & 1) B.slots[tb[l] * RUN_TICKET_SLOTS + cm[l]++] = s | 0x80000000u;
-    else B.slots[(tb[l] + (nm[l] + RUN_TICKET_SLOTS - 1) / RUN_TICKET_SLOTS + co[l]++) * RUN_TICKET_SLOTS] = s;
+    uint32_t widest = ready, ndiag = 0;
+    for (uint32_t v : diag) { widest = std::max(widest, v); ndiag += v ? 1 : 0; }
+    K.n_batches = st.tickets; K.widest = widest; K.max_rl = ndiag;
+    if ((unsigned long long)st.tickets * RUN_TICKET_SLOTS > P.cap_slots) { scan_fail(B, DE265HIP_ERROR_NOT_IMPLEMENTED); return; }
+    for (uint32_t q = 0; q < st.tickets * RUN_TICKET_SLOTS; q++) B.slots[q] = 0xFFFFFFFFu;
+    for (const Placed& pl : placed) B.slots[pl.ticket * RUN_TICKET_SLOTS + pl.slot] = pl.s;
   }
 }
 

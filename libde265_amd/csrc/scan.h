@@ -11,7 +11,7 @@ namespace d265 {
 struct ScanLayout {
   size_t clear_begin = 0, clear_end = 0;             // cleared at every build: CTB counters, cell maps, counts, run sizes
   size_t o_ctb = 0, o_cell[3] = { 0, 0, 0 }, o_counts = 0, o_run_ntus = 0;
-  size_t o_tu_avail = 0, o_tu_need = 0, o_tu_info = 0, o_run_rs = 0, o_run_nall = 0, o_run_level = 0, o_run_list = 0, o_pub_flag = 0;
+  size_t o_tu_avail = 0, o_tu_need = 0, o_tu_info = 0, o_tu_run = 0, o_run_rs = 0, o_run_nall = 0, o_run_level = 0, o_run_list = 0, o_pub_flag = 0;
   size_t o_rdy_tab = 0, o_lvl_cnt = 0, o_l0 = 0, o_l0x = 0, o_runs = 0, o_run_tus = 0, o_deps = 0, o_slots = 0, o_front = 0, o_mbx = 0, o_mb_segs = 0;
   uint32_t cap_levels = 0;
   size_t plan(const ScanParams& P, size_t at);        // lays the buffers out from offset `at`; returns the end

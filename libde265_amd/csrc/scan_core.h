@@ -15,7 +15,7 @@
 //   scan_run     per run         run record, its TUs in chain order, residual-only tasks, producer list
 //   scan_run2    per run         producers that are front runs leave the list; mailbox segments and need epochs of a reader
 //   scan_run3    per run         a run somebody reads through its mailbox: ready epochs of its packets
-//   scan_order   (one workgroup) run levels, ticket slots
+//   scan_order   (one workgroup) ticket slots: the runs in a topological order that needs no graph walk (below)
 //
 // A run is identified by its SPARSE id: (first intra TU of its CTB in the compacted intra order) + (its number inside the
 // CTB, in order of creation).  Ids grow in decode order, so a producer's id is smaller than its readers'.  Run records,
@@ -77,11 +77,12 @@ typedef unsigned long long ScanCell;
 
 struct ScanBufs {
   // inputs (uploaded)
-  const de265hip_tu* tus; const uint32_t* ctb_group; const int32_t* rs2ts; const int32_t* ts2rs; const uint8_t* blk_flags;
+  const de265hip_tu* tus; const uint32_t* ctb_group; const int32_t* rs2ts; const int32_t* ts2rs; const int32_t* ctb_order; const uint8_t* blk_flags;
   const uint64_t* used_units;          // [4][35][2]: neighbour units a TU of that size / mode / (luma-like smoothing) reads
   uint16_t* coeff_pos;                 // (positions beyond a TU's block are folded into it, k_check_coeffs' job in round 3)
   // scratch
   ScanCtb* ctb; ScanCell* cell[3]; uint64_t* tu_avail; uint64_t* tu_need; uint32_t* tu_info;
+  uint32_t* tu_run;                    // sparse id of the run of an intra TU (scan_ctb)
   uint8_t* run_ntus; uint32_t* run_rs; uint32_t* run_nall; uint32_t* run_level; uint32_t* run_list; uint8_t* pub_flag; uint8_t* rdy_tab;
   uint32_t* lvl_cnt;                   // scan_order: 4 x (levels + 2) counters
   // outputs (what the reconstruction kernels read)
@@ -480,12 +481,34 @@ SCAN_FN void scan_ctb(const ScanParams& P, const ScanBufs& B, int rs)
     }
     B.run_ntus[C.intra_base + r]++;
     B.tu_info[i] = (uint32_t)r | ((uint32_t)llev << 16) | (foreign ? SCAN_TI_FOREIGN : 0u) | SCAN_TI_INTRA;
+    B.tu_run[i] = C.intra_base + (uint32_t)r;
     const ScanCell hi = (ScanCell)((uint32_t)r | ((uint32_t)llev << 16) | (1u << 31)) << 32;
     for (int y = yB >> 2; y < (yB + nT) >> 2; y++)
       for (int x = xB >> 2; x < (xB + nT) >> 2; x++) cells[x + (size_t)y * mw] = hi | (uint32_t)(i + 1);
   }
   C.n_runs = (uint32_t)n_local;
   scan_add(&B.counts->n_runs, (uint32_t)n_local);
+}
+
+// ------------------------------------------------------------------------------------------------ tickets
+// k_run's workers draw tickets in slot order and a run may only wait for runs in earlier tickets (or in lower slots of its own
+// ticket: the wavefront of slot q works slot q + 4 off after it).  Round 3 ordered the runs by their level in the run graph
+// (longest producer chain: a propagation over the whole graph).  No walk is needed: a run reads from runs of its own CTB
+// created before it and from runs of the CTBs to the left, above-left, above and above-right - all of which lie on smaller
+// anti-diagonals x + 2y - so (anti-diagonal of the CTB, CTB, number inside the CTB) is a topological order, and the runs of
+// one anti-diagonal are exactly the ones the wavefront of an all-intra picture has ready together.  ctb_order lists the CTBs
+// by (x + 2y, y); walking it, micro runs fill the open ticket slot by slot, an ordinary run closes it and takes one alone.
+struct ScanTicketState { uint32_t tickets, fill; };    // tickets opened so far; slots taken in the last one (0: it is closed / full)
+SCAN_FN void scan_ticket_step(ScanTicketState& st, bool micro, uint32_t* ticket, uint32_t* slot)
+{
+  if (micro) {
+    if (st.fill == 0) st.tickets++;
+    *ticket = st.tickets - 1; *slot = st.fill;
+    st.fill = (st.fill + 1) % RUN_TICKET_SLOTS;
+  } else {
+    st.tickets++; st.fill = 0;
+    *ticket = st.tickets - 1; *slot = 0;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ pass 4: per run
@@ -657,7 +680,7 @@ SCAN_FN void scan_run(const ScanParams& P, const ScanBufs& B, uint32_t s)
         const uint32_t j = (uint32_t)v - 1;
         const uint32_t tj = B.tu_info[j];
         if (!(tj & SCAN_TI_INTRA)) continue;
-        const uint32_t ps = B.ctb[scan_tu_ctb(P, B.tus[j])].intra_base + SCAN_TI_RUN(tj);
+        const uint32_t ps = B.tu_run[j];
         if (ps == s) continue;
         bool seen = false;
         for (uint32_t q = 0; q < nd && !seen; q++) seen = dl[q] == ps;
@@ -689,8 +712,9 @@ SCAN_FN void scan_run(const ScanParams& P, const ScanBufs& B, uint32_t s)
 // producers that are front runs leave the list (the kernel boundary orders them); a dense ordinary run whose every neighbour
 // sample comes from the bottom row / right column of dense ordinary runs takes them from those runs' mailboxes: its segment
 // list and - phased hand-over - when each neighbour sample is first needed (host.hip, round 3: "Edge mailboxes")
-SCAN_FN void scan_run2(const ScanParams& P, const ScanBufs& B, uint32_t s)
+SCAN_FN void scan_run2(const ScanParams& P, const ScanBufs& B, uint32_t s, const TuTask* own_tus = nullptr)
 {
+  // (own_tus: the run's TU records where the caller has staged them - LDS on the device -, else they are read from run_tus)
   if (B.counts->status || B.run_ntus[s] == 0) return;
   RunTask o = B.runs[s];
   const uint32_t n_all = B.run_nall[s] & 0x7FFFFFFFu;
@@ -755,7 +779,7 @@ SCAN_FN void scan_run2(const ScanParams& P, const ScanBufs& B, uint32_t s)
         uint8_t nru[40], ncu[40], ncorner = 255;
         for (int q = 0; q < 40; q++) { nru[q] = 255; ncu[q] = 255; }
         for (int k = 0; k < n; k++) {
-          const TuTask tt = B.run_tus[o.first_tu + (uint32_t)k];
+          const TuTask tt = own_tus ? own_tus[k] : B.run_tus[o.first_tu + (uint32_t)k];
           const int xB = tt.x0, yB = tt.y0;
           if (xB != (int)o.x0 && yB != (int)o.y0) continue;
           const int nT = 1 << tt.log2_size, corner = nT >> 1, m = tt.intra_mode < 35 ? tt.intra_mode : 1;
