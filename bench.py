@@ -63,6 +63,20 @@ def make_gop(pysynth, farm, width, height, bit_depth, gop, seed, chroma_format=1
     return pics
 
 
+def hand_over_motion_plane(gops, yes):
+    """The frame-level interface takes the per-4x4 motion plane of a picture (what the deblocking's boundary strengths read) either
+    ready-made (de265hip_picture_desc::blk_motion, 6.2 MB per 4K picture, as libde265 keeps it) or not at all (NULL): the
+    device then makes it from the PU records, which are handed over anyway.  The bench hands no plane over (--motion-plane: it
+    does); the CPU baseline, which reads the plane, gets it back."""
+    import ctypes as C
+    from libde265_amd import _abi
+    for g in gops:
+        for sp in g:
+            if not hasattr(sp, "_motion_ptr"):
+                sp._motion_ptr = C.cast(sp.d.blk_motion, C.c_void_p).value
+            sp.d.blk_motion = C.cast(sp._motion_ptr, C.POINTER(_abi.Motion)) if yes else None
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) BEFORE this process
     touches the GPU, rank 0's stdout is ours (the one JSON line), exit with the worst return code."""
@@ -267,6 +281,8 @@ def main():
     ap.add_argument("--bit-depth", type=int, default=10)
     ap.add_argument("--chroma-format", type=int, default=1, choices=[1, 2, 3],
                     help="chroma_format_idc of the workload: 1 = 4:2:0 (the headline), 2 = 4:2:2, 3 = 4:4:4 (range extensions, SURVEY 8 f4)")
+    ap.add_argument("--motion-plane", action="store_true",
+                    help="hand the flattened per-4x4 motion plane over with every picture (default: the device makes it from the PU records)")
     ap.add_argument("--no-copy-out", action="store_true",
                     help="skip the with_copy_out leg (product path with every picture copied out to pinned host memory)")
     ap.add_argument("--no-affinity", action="store_true", help="N > 1: do not pin the rank to its share of the host's CPUs")
@@ -408,6 +424,7 @@ def main():
             d.set_lanes(args.lanes)
         for k in range(GOP):
             d.dpb_alloc(k, W, H, BD, chroma_format=CF)
+        hand_over_motion_plane([g], args.motion_plane)
         gops.append(g); decs.append(d)
         pics.append([d.build(k, g[k].desc) for k in range(GOP)])  # inputs now resident in HBM
     gop, dec = gops[0], decs[0]
@@ -637,6 +654,7 @@ def main():
         cpu = None
         parity = "not checked"
         if not args.no_cpu_baseline:
+            hand_over_motion_plane(gops, True)                # (the reference reads the plane)
             cpu, parity = cpu_baseline(gops, decs, W, H, BD, GOP, full=(world == 1), CF=CF)
         if product is not None:
             region = ("product path: every picture of the step goes build -> run -> free through the C ABI inside the timed region "
@@ -652,6 +670,7 @@ def main():
                                    "%d independent GOP(s) in flight per GPU, all stages on device"
                                    % (W, H, BD, {1: "4:2:0", 2: "4:2:2", 3: "4:4:4"}[CF], GOP, GOP - 1, S),
                        "timed_region": region,
+                       "motion_plane": "handed over (6.2 MB per 4K picture)" if args.motion_plane else "made on the device from the PU records (blk_motion = NULL)",
                        "gop": GOP, "streams_per_gpu": S, "lanes_per_decoder": args.lanes, "pictures_per_step": GOP * S,
                        "host_threads": product["host_threads"] if product else 0, "host_cores_available": cores,
                        "host_threads_per_rank": product["host_threads_per_rank"] if product else 0,

@@ -219,7 +219,8 @@ typedef struct de265hip_picture_desc {
   /* metadata planes, ceil(W/4) x ceil(H/4), row-major */
   const uint8_t* blk_flags;
   const int8_t*  blk_qp_y;
-  const de265hip_motion* blk_motion;  /* may be NULL when no inter CU exists */
+  const de265hip_motion* blk_motion;  /* may be NULL: the plane is then made on the device from the PU records (mv, RefPicList entry of
+                                         the PU's slice as DPB slot; units no PU covers: no reference) - 12x fewer bytes to hand over */
 } de265hip_picture_desc;
 
 typedef struct de265hip_decoder de265hip_decoder;

@@ -75,6 +75,13 @@ struct de265hip_decoder {
   bool dry = false;                   // de265hip_debug_build_host_only: the host stage without any HIP call (profiling on a CPU box)
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;  // uploads of command buffers (de265hip_picture_build), overlapping the kernels of earlier pictures
+  // Round 4: a picture's upload is followed by the kernels of its scan (k_scan.hip), latency chains of ~0.5 ms that hardly
+  // occupy the device: the builds of one decoder take turns on a few copy streams, so that the upload and the scan of
+  // consecutive pictures overlap (DE265HIP_COPY_STREAMS, default 3; [0] is copy_stream)
+  static constexpr int kMaxCopyStreams = 8;
+  hipStream_t copy_streams[kMaxCopyStreams] = {};
+  int n_copy_streams = 1;
+  uint64_t copy_turn = 0;
   hipStream_t out_stream = nullptr;   // de265hip_dpb_download_async: decoded pictures leave on their own stream, behind an event of `stream`
   hipEvent_t out_fence = nullptr;
   std::mutex mu;                      // guards live, the two pools and slot allocation: build()/free() may come from several host threads
@@ -541,6 +548,10 @@ int de265hip_decoder_new(de265hip_decoder** out, int device)
   HIPCHK(hipGetDevice(&d->device), DE265HIP_ERROR_INIT_FAILED);
   HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking), DE265HIP_ERROR_INIT_FAILED);
   HIPCHK(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking), DE265HIP_ERROR_INIT_FAILED);
+  d->copy_streams[0] = d->copy_stream;
+  d->n_copy_streams = 3;
+  if (const char* e = getenv("DE265HIP_COPY_STREAMS")) d->n_copy_streams = std::min((int)de265hip_decoder::kMaxCopyStreams, std::max(1, atoi(e)));
+  for (int i = 1; i < d->n_copy_streams; i++) HIPCHK(hipStreamCreateWithFlags(&d->copy_streams[i], hipStreamNonBlocking), DE265HIP_ERROR_INIT_FAILED);
   HIPCHK(hipMalloc((void**)&d->d_err, 256), DE265HIP_ERROR_OUT_OF_MEMORY);
   HIPCHK(hipMemset(d->d_err, 0, 256), DE265HIP_ERROR_INIT_FAILED);
   HIPCHK(hipMalloc((void**)&d->d_err_ring, de265hip_decoder::kRing * 4), DE265HIP_ERROR_OUT_OF_MEMORY);
@@ -587,7 +598,7 @@ int de265hip_decoder_set_lanes(de265hip_decoder* d, int n_lanes)
 void de265hip_decoder_free(de265hip_decoder* d)
 {
   if (!d) return;
-  (void)hipStreamSynchronize(d->copy_stream);
+  for (int i = 0; i < d->n_copy_streams; i++) if (d->copy_streams[i]) (void)hipStreamSynchronize(d->copy_streams[i]);
   (void)sync_all_lanes(d);
   if (d->out_stream) { (void)hipStreamSynchronize(d->out_stream); (void)hipStreamDestroy(d->out_stream); }
   if (d->out_fence) (void)hipEventDestroy(d->out_fence);
@@ -614,7 +625,7 @@ void de265hip_decoder_free(de265hip_decoder* d)
   if (d->d_err_ring) (void)hipFree(d->d_err_ring);
   if (d->h_ring) (void)hipHostFree(d->h_ring);
   if (d->d_used_units) (void)hipFree(d->d_used_units);
-  (void)hipStreamDestroy(d->copy_stream);
+  for (int i = 0; i < d->n_copy_streams; i++) if (d->copy_streams[i]) (void)hipStreamDestroy(d->copy_streams[i]);
   (void)hipStreamDestroy(d->stream);
   delete d;
 }
@@ -1993,7 +2004,11 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
   const size_t o_ctb = L.add((size_t)d->n_ctbs * sizeof(de265hip_ctb_info));
   const size_t o_tile = L.add((size_t)d->n_ctbs * 2);
   const size_t o_sao = L.add((size_t)d->n_ctbs * sizeof(SaoCtb));
-  const size_t o_flags = L.add(nblk), o_qp = L.add(nblk), o_mot = L.add(nblk * sizeof(de265hip_motion));
+  // the motion plane travels when the host hands one over; without one (blk_motion == NULL) it is made on the device from the
+  // PU records, which travel instead (k_motion_from_pus; no PUs: "no reference" everywhere, a device memset)
+  const bool mot_given = d->blk_motion != nullptr;
+  const size_t o_flags = L.add(nblk), o_qp = L.add(nblk), o_mot_up = L.add(mot_given ? nblk * sizeof(de265hip_motion) : 0);
+  const size_t o_pus = L.add(mot_given ? 0 : (size_t)d->n_pus * sizeof(de265hip_pu));
   const size_t o_runs = L.add(runs.size() * sizeof(RunTask)), o_rdeps = L.add(run_deps.size() * 4);
   const size_t o_rtus = L.add(run_tus.size() * sizeof(TuTask));
   const size_t o_slots = L.add(slots.size() * 4);
@@ -2005,6 +2020,7 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
   const size_t upload_bytes = L.total;                 // everything above is written by the host
   // device-only scratch: boundary strengths, residual blocks, run flags (no staging, no upload)
   const size_t o_bs = L.add(nblk);
+  const size_t o_mot = mot_given ? o_mot_up : L.add(nblk * sizeof(de265hip_motion));
   // Device-side scan: what the passes will find is not known here, so its lists get room for the most a picture of this size
   // and this many TU records can ask for (address space in 288 GB of HBM; none of it is uploaded or cleared): a residual
   // sample per picture sample, a run per TU record, a producer entry per needed neighbour unit (<= nT + 1 per TU: 5 / 16 per
@@ -2035,8 +2051,7 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
   pic->sync_bytes = (2 + (dev_scan ? (size_t)d->n_tus : runs.size())) * 4;
   const size_t o_sync = L.add(pic->sync_bytes);
   // edge mailboxes of k_run: 64 packets of (two samples, generation) per publishing run - its bottom row, then its right
-  // column.  Flags and packets carry the generation number of their LAUNCH, a number the decoder never hands out twice, so
-  // neither is cleared between pictures: an arena is cleared once, when it is allocated.
+  // column; cleared with the flags at build (a packet counts when it carries its launch's generation)
   const size_t mb_bytes = (size_t)(dev_scan ? SP.cap_mb : (uint32_t)n_mailboxes) * 64 * 8;
   const size_t o_mb = L.add(mb_bytes);
   const size_t clear_bytes = L.total - o_sync;           // flags + mailboxes (experiments that clear them per launch)
@@ -2092,8 +2107,8 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
   put(o_l0x, SC.l0_rext.data(), SC.l0_rext.size() * sizeof(TuTask));
   if (n_mailboxes) { put(o_mbx, mbx.data(), mbx.size() * 4); put(o_mbs, mb_segs.data(), mb_segs.size() * 4); }
   put(o_flags, d->blk_flags, nblk); put(o_qp, d->blk_qp_y, nblk);
-  if (d->blk_motion) put(o_mot, d->blk_motion, nblk * sizeof(de265hip_motion));
-  else memset(host.data() + o_mot, 0xFF, nblk * sizeof(de265hip_motion));       // ref_slot = -1 everywhere
+  if (mot_given) put(o_mot, d->blk_motion, nblk * sizeof(de265hip_motion));
+  else put(o_pus, d->pus, (size_t)d->n_pus * sizeof(de265hip_pu));
   if (dev_scan) {
     // CTBs of one slice and tile share a group word (the availability tests of intrapred.cc:486-508 compare exactly these two)
     uint32_t* grp = (uint32_t*)(host.data() + o_grp);
@@ -2121,7 +2136,7 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
     const size_t offs[] = { o_tus, o_cval, o_cpos, o_scal, o_mc, o_pcm, o_pcms, o_sl, o_ctb, o_tile, o_sao, o_flags, o_qp, o_mot, o_runs, o_rdeps, o_rtus, o_slots, o_l0, upload_bytes };
     const size_t lens[] = { sorted.size() * sizeof(TuTask), (size_t)d->n_coeffs * 2, (size_t)d->n_coeffs * 2, (size_t)DE265HIP_SCALING_BLOB_BYTES, mcs.size() * sizeof(McTask),
                             pcms.size() * sizeof(PcmTask), (size_t)d->n_pcm_samples * 2, (size_t)d->n_slices * sizeof(de265hip_slice_params), (size_t)d->n_ctbs * sizeof(de265hip_ctb_info),
-                            (size_t)d->n_ctbs * 2, (size_t)d->n_ctbs * sizeof(SaoCtb), nblk, nblk, nblk * sizeof(de265hip_motion), runs.size() * sizeof(RunTask), run_deps.size() * 4,
+                            (size_t)d->n_ctbs * 2, (size_t)d->n_ctbs * sizeof(SaoCtb), nblk, nblk, mot_given ? nblk * sizeof(de265hip_motion) : (size_t)0, runs.size() * sizeof(RunTask), run_deps.size() * 4,
                             run_tus.size() * sizeof(TuTask), slots.size() * 4, l0.size() * sizeof(TuTask), 0 };
     for (int i = 0; i < 19; i++) mix(host.data() + offs[i], lens[i]);      // (only the written bytes: padding between sections is undefined)
     const int64_t scal[] = { pic->n_workers, pic->n_batches, pic->n_l0, pic->n_l0_size[0], pic->n_l0_size[1], pic->n_l0_size[2], pic->n_l0_size[3], pic->n_mc, pic->n_mc2, pic->n_mc_quads, pic->n_pcm,
@@ -2134,20 +2149,26 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
     dec->pooled_bytes = (size_t)hsh;
   }
   if (!dec->dry) {
-    hipStream_t cs = dec->copy_stream;
+    hipStream_t cs;
+    { std::lock_guard<std::mutex> lk(dec->mu); cs = dec->copy_streams[dec->copy_turn++ % (uint64_t)dec->n_copy_streams]; }
     // a recycled arena may still be read by kernels of the picture that had it before
     if (pic->arena_buf.used && hipStreamWaitEvent(cs, pic->arena_buf.last_use, 0) != hipSuccess) return fail(DE265HIP_ERROR_DECODING);
     if (hipEventCreateWithFlags(&pic->uploaded, hipEventDisableTiming) != hipSuccess) return fail(DE265HIP_ERROR_OUT_OF_MEMORY);
-    // a fresh arena (or one from before the generation numbers wrapped) is cleared once: flags and mailbox packets of later
-    // pictures in it are told apart by their generation
-    if (pic->arena_buf.epoch != dec->arena_epoch) {
-      if (hipMemsetAsync(pic->arena, 0, pic->arena_buf.bytes, cs) != hipSuccess) return fail(DE265HIP_ERROR_DECODING);
-      pic->arena_buf.epoch = dec->arena_epoch;
-    } else if (hipMemsetAsync((uint8_t*)pic->arena + o_sync, 0, 8, cs) != hipSuccess) return fail(DE265HIP_ERROR_DECODING);      // (the ticket counter)
+    // k_run's ticket counter, run flags and mailbox packets start from zero: a pooled arena held another picture's buffers at
+    // these offsets before, and ANY bit pattern there could pass for a raised flag of some launch generation (round 4 tried to
+    // do without this clear, the generations being unique per decoder: a mid-size picture in a recycled arena came out wrong)
+    if (hipMemsetAsync((uint8_t*)pic->arena + o_sync, 0, clear_bytes, cs) != hipSuccess) return fail(DE265HIP_ERROR_DECODING);
+    pic->arena_buf.epoch = dec->arena_epoch;
     if (hipMemcpyAsync(pic->arena, host.data(), upload_bytes, hipMemcpyHostToDevice, cs) != hipSuccess ||
         hipMemsetAsync(dec->d_err_ring + pic->ring_idx, 0, 4, cs) != hipSuccess ||
         hipEventRecord(stage_event, cs) != hipSuccess)
       return fail(DE265HIP_ERROR_DECODING);
+    if (!mot_given) {
+      if (hipMemsetAsync((uint8_t*)pic->arena + o_mot, 0xFF, nblk * sizeof(de265hip_motion), cs) != hipSuccess) return fail(DE265HIP_ERROR_DECODING);
+      if (d->n_pus > 0)
+        hipLaunchKernelGGL(k_motion_from_pus, dim3(d->n_pus), dim3(64), 0, cs, P, (const de265hip_pu*)((uint8_t*)pic->arena + o_pus), d->n_pus,
+                           (const de265hip_slice_params*)((uint8_t*)pic->arena + o_sl), d->n_slices, (de265hip_motion*)((uint8_t*)pic->arena + o_mot));
+    }
     if (dev_scan) {
       // the passes of the scan, then their counts on the way back to the host (pinned; de265hip_picture_run reads them)
       if (scan_enqueue(cs, SP, SB, SL, base, cap_resid) != hipSuccess ||

@@ -51,6 +51,33 @@ __device__ __forceinline__ int bs_motion(const de265hip_motion& mP, const de265h
   return d00 && d01;
 }
 
+// The per-4x4 motion plane from the PU records (what image.h pb_info holds and derive_boundaryStrength reads, deblock.cc:295-304:
+// motion vectors and reference pictures as DPB slots): a host that does not flatten its motion into de265hip_picture_desc::
+// blk_motion (NULL) leaves it to this kernel - 0.5 MB of PU records cross PCIe instead of a 6.2 MB plane per 4K picture, and
+// the read-out on the host goes away.  One wavefront per PU; the plane was set to "no reference" (0xFF) before.
+__global__ __launch_bounds__(64)
+void k_motion_from_pus(PicDev P, const de265hip_pu* __restrict__ pus, int n_pus, const de265hip_slice_params* __restrict__ slices,
+                       int n_slices, de265hip_motion* __restrict__ motion)
+{
+  const int i = blockIdx.x;
+  if (i >= n_pus) return;
+  const de265hip_pu pu = pus[i];
+  if (pu.slice_idx >= n_slices) return;
+  de265hip_motion m;
+  for (int l = 0; l < 2; l++) {
+    const bool on = (pu.pred_flag >> l) & 1;
+    const int ri = pu.ref_idx[l];
+    m.ref_slot[l] = (on && ri >= 0 && ri < DE265HIP_MAX_REFS) ? slices[pu.slice_idx].ref_pic_list[l][ri] : (int8_t)-1;
+    m.mv[l][0] = on ? pu.mv[l][0] : (int16_t)0; m.mv[l][1] = on ? pu.mv[l][1] : (int16_t)0;
+  }
+  m.pad[0] = m.pad[1] = 0;
+  const int bw = pu.w >> 2, bh = pu.h >> 2;
+  for (int q = threadIdx.x; q < bw * bh; q += 64) {
+    const int x = (pu.x >> 2) + q % bw, y = (pu.y >> 2) + q / bw;
+    if (x < P.w4 && y < P.h4) motion[x + y * P.w4] = m;
+  }
+}
+
 // bS of the edge on the left (VERT) / top side of unit idx (derive_boundaryStrength, deblock.cc:241-375), fused into
 // the deblocking kernels: the motion records are only fetched for inter/inter edges without coded residual.
 // chroma_only: only bS == 2 matters (deblock.cc:763), no motion needed.

@@ -601,11 +601,11 @@ void k_scan_check_pos(ScanParams P, ScanBufs B)
 // a chunk's runs fill tickets depends on how full the open ticket is when the chunk begins, so every thread first computes its
 // chunk's effect for each of the eight possible fill states (a table), the tables are composed by a prefix scan (composition
 // of such tables is associative), and every thread then walks its chunk again from its true start state and writes the slots.
-#define SCO_THREADS 256
+#define SCO_THREADS 1024
 __global__ __launch_bounds__(SCO_THREADS)
 void k_scan_order(ScanParams P, ScanBufs B, uint32_t cap_levels)
 {
-  __shared__ uint32_t tab[2][SCO_THREADS][RUN_TICKET_SLOTS];       // per chunk and fill state at its start: tickets it opens | fill state at its end << 28
+  __shared__ uint32_t tab[SCO_THREADS][RUN_TICKET_SLOTS];          // per chunk and fill state at its start: tickets it opens | fill state at its end << 28
   __shared__ uint32_t s_diag[4096];
   __shared__ uint32_t s_widest, s_ready, s_ndiag;
   const int tid = threadIdx.x;
@@ -641,27 +641,27 @@ void k_scan_order(ScanParams P, ScanBufs B, uint32_t cap_levels)
     if (cnt) atomicAdd(&diag[rs % P.ctbs_w + 2 * (rs / P.ctbs_w)], cnt);
   }
   if (ready) atomicAdd(&s_ready, ready);
-  for (int o = 0; o < RUN_TICKET_SLOTS; o++) tab[0][tid][o] = st[o].tickets | (st[o].fill << 28);
+  for (int o = 0; o < RUN_TICKET_SLOTS; o++) tab[tid][o] = st[o].tickets | (st[o].fill << 28);
   __syncthreads();
   // ---- phase 2: inclusive prefix composition (Hillis-Steele): tab[i] := tab[i - off] then tab[i]
-  int cur = 0;
   for (int off = 1; off < SCO_THREADS; off <<= 1) {
+    uint32_t v[RUN_TICKET_SLOTS];
     for (int o = 0; o < RUN_TICKET_SLOTS; o++) {
-      uint32_t v = tab[cur][tid][o];
+      v[o] = tab[tid][o];
       if (tid >= off) {
-        const uint32_t a = tab[cur][tid - off][o];               // the earlier chunks from state o ...
-        const uint32_t bb = tab[cur][tid][a >> 28];              // ... then this one from where they end
-        v = ((a & 0x0FFFFFFFu) + (bb & 0x0FFFFFFFu)) | (bb & 0xF0000000u);
+        const uint32_t a = tab[tid - off][o];                    // the earlier chunks from state o ...
+        const uint32_t bb = tab[tid][a >> 28];                   // ... then this one from where they end
+        v[o] = ((a & 0x0FFFFFFFu) + (bb & 0x0FFFFFFFu)) | (bb & 0xF0000000u);
       }
-      tab[cur ^ 1][tid][o] = v;
     }
-    cur ^= 1;
+    __syncthreads();
+    for (int o = 0; o < RUN_TICKET_SLOTS; o++) tab[tid][o] = v[o];
     __syncthreads();
   }
   // the state this chunk starts from: what all chunks before it make of (0 tickets, closed)
   ScanTicketState me = { 0, 0 };
-  if (tid > 0) { const uint32_t v = tab[cur][tid - 1][0]; me.tickets = v & 0x0FFFFFFFu; me.fill = v >> 28; }
-  const uint32_t total = tab[cur][SCO_THREADS - 1][0] & 0x0FFFFFFFu;
+  if (tid > 0) { const uint32_t v = tab[tid - 1][0]; me.tickets = v & 0x0FFFFFFFu; me.fill = v >> 28; }
+  const uint32_t total = tab[SCO_THREADS - 1][0] & 0x0FFFFFFFu;
   if ((unsigned long long)total * RUN_TICKET_SLOTS > P.cap_slots) { if (tid == 0) scan_fail(B, DE265HIP_ERROR_NOT_IMPLEMENTED); return; }
   for (uint32_t q = tid; q < total * RUN_TICKET_SLOTS; q += SCO_THREADS) B.slots[q] = 0xFFFFFFFFu;
   uint32_t w = 0, nd = 0;

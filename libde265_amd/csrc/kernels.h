@@ -59,6 +59,7 @@ __global__ void k_mc_all(PicDev, DpbTable, PlaneRef, PlaneRef, PlaneRef, const M
 template <typename PX>
 __global__ void k_pcm(PicDev, PlaneRef, PlaneRef, PlaneRef, const PcmTask*, const uint16_t*);
 __global__ void k_bs(PicDev, const uint8_t*, const de265hip_motion*, uint8_t*);
+__global__ void k_motion_from_pus(PicDev, const de265hip_pu*, int, const de265hip_slice_params*, int, de265hip_motion*);
 template <typename PX, bool VERT>
 __global__ void k_deblock(PicDev, PlaneRef, PlaneRef, PlaneRef, LfMeta);
 template <typename PX>

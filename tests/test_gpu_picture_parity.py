@@ -20,14 +20,20 @@ def dec():
     d.close()
 
 
-def run_case(dec, w, h, bd, slice_type, seed, stages=(0, 1, 2), **over):
+def run_case(dec, w, h, bd, slice_type, seed, stages=(0, 1, 2), drop_motion_plane=False, **over):
     cfg = pysynth.default_config(w, h, bd, slice_type, seed=seed, **over)
     sp = pysynth.SynthPicture(cfg)
     refs = {0: pysynth.fill_planes(w, h, bd, 100 + seed), 1: pysynth.fill_planes(w, h, bd, 200 + seed)}
     for slot, pl in refs.items():
         dec.dpb_alloc(slot, w, h, bd)
         dec.upload(slot, pl)
+    if drop_motion_plane:                                # the device makes the plane from the PU records (blk_motion = NULL);
+        import ctypes as C                               # the oracle keeps reading the generator's
+        keep = C.cast(sp.d.blk_motion, C.c_void_p).value
+        sp.d.blk_motion = None
     pic = dec.build(2, sp.desc)
+    if drop_motion_plane:
+        sp.d.blk_motion = C.cast(keep, C.POINTER(_abi.Motion))
     try:
         for stage in stages:
             # start both sides from the same garbage so untouched samples compare equal
@@ -79,6 +85,17 @@ def test_strong_smoothing_decision_samples_are_dependencies(dec):
     run_case(dec, 1416, 536, 10, 1, seed=9045, stages=(0,), log2_ctb_size=5, log2_max_tb_size=5, log2_min_tb_size=3,
              intra_pct=40, tskip_pct=20, bypass_pct=0, pcm_pct=0, scaling_list=0, constrained_intra_pred=0,
              strong_intra_smoothing=1, weighted_pred=1, n_slices=4, split_bias=0, cbf_pct=60, mv_sigma_qpel=12)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_motion_plane_made_on_the_device_from_the_pu_records(dec, seed):
+    """de265hip_picture_desc::blk_motion = NULL: the boundary strengths of the deblocking read a motion plane the device derives
+    from the PU records (k_motion_from_pus) - same picture as with the generator's plane, which the oracle reads.  P and B
+    pictures, several slices (each with its own reference lists), AMP partitions, intra CUs in between, large vectors."""
+    st = 1 if seed % 3 == 0 else 0
+    run_case(dec, 416 + 64 * (seed % 2), 240, 8 if seed % 2 else 10, st, seed=600 + seed, stages=(1, 2), drop_motion_plane=True,
+             n_slices=1 + seed % 4, amp=seed & 1, intra_pct=[0, 15, 50][seed % 3], cbf_pct=[0, 30, 100][seed % 3], bi_pct=[0, 60, 100][(seed + 1) % 3],
+             mv_sigma_qpel=[2, 12, 60][seed % 3], weighted_pred=seed & 1, sao=0)
 
 
 def test_1080p_b_picture(dec):
