@@ -380,6 +380,14 @@ int  de265hip_pipeline_wait(de265hip_pipeline*, uint64_t ticket);
 int  de265hip_pipeline_drain(de265hip_pipeline*);          /* every submitted picture launched, finished and copied out */
 void de265hip_pipeline_free(de265hip_pipeline*);           /* drains first */
 
+/* de265hip_picture_build in two steps, for a host that wants every HIP call of a decoder issued by ONE of its threads (the
+ * pipeline does: many threads calling into the HIP runtime for one device queue up behind its locks).  _build_host: the host
+ * stage only - validation, MC tasks, staging into pinned memory -, on any thread; _enqueue: the upload and the kernels that
+ * prepare the picture on the device (the scan of the TU records), before de265hip_picture_run (which calls it itself if nobody
+ * has).  A picture that was built but never enqueued may be freed. */
+int  de265hip_picture_build_host(de265hip_decoder*, int dst_slot, const de265hip_picture_desc*, de265hip_picture** out);
+int  de265hip_picture_enqueue(de265hip_picture*);
+
 /* Profiling aid: the host stage of de265hip_picture_build `reps` times, without a GPU and without any HIP call. */
 int  de265hip_debug_build_host_only(const de265hip_picture_desc*, int reps);
 /* FNV-1a hash over everything the last de265hip_debug_build_host_only of this thread would have uploaded (regression

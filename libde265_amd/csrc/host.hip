@@ -195,6 +195,15 @@ struct de265hip_picture {
   uint32_t cap_resid = 0;
   uint32_t* d_front_idx = nullptr;    // the front runs' ids (device-side scan: run records are not sorted)
   int ring_idx = -1; uint64_t ring_seq = 0;
+  // what de265hip_picture_enqueue needs of the build (the device work of a build - upload, scan - may be issued later and by
+  // another thread than the host stage: the pipeline issues every HIP call of a decoder from one thread)
+  struct Enq {
+    bool pending = false;
+    uint8_t* host_base = nullptr; size_t upload_bytes = 0; hipEvent_t stage_event = nullptr;
+    size_t o_sync = 0, clear_bytes = 0, o_mot = 0, o_pus = 0, o_sl = 0, o_l0 = 0, o_l0x = 0, o_cpos = 0, nblk = 0;
+    bool mot_given = true, check_on_device = false;
+    int n_pus = 0, n_slices = 0, n_l0chk = 0, n_l0xchk = 0;
+  } enq;
   ScanCounts h_counts_dry;            // (dry decoders: no ring)
   std::vector<uint8_t> dry_arena;     // (dry decoders: the arena in host memory)
   int64_t o_layout[16] = {};          // de265hip_debug_picture_layout
@@ -556,7 +565,8 @@ int de265hip_decoder_new(de265hip_decoder** out, int device)
   HIPCHK(hipMemset(d->d_err, 0, 256), DE265HIP_ERROR_INIT_FAILED);
   HIPCHK(hipMalloc((void**)&d->d_err_ring, de265hip_decoder::kRing * 4), DE265HIP_ERROR_OUT_OF_MEMORY);
   HIPCHK(hipMemset(d->d_err_ring, 0, de265hip_decoder::kRing * 4), DE265HIP_ERROR_INIT_FAILED);
-  HIPCHK(hipHostMalloc((void**)&d->h_ring, de265hip_decoder::kRing * sizeof(ScanCounts), hipHostMallocDefault), DE265HIP_ERROR_OUT_OF_MEMORY);
+  HIPCHK(hipHostMalloc((void**)&d->h_ring, de265hip_decoder::kRing * sizeof(ScanCounts), hipHostMallocMapped | hipHostMallocCoherent), DE265HIP_ERROR_OUT_OF_MEMORY);
+  memset(d->h_ring, 0, de265hip_decoder::kRing * sizeof(ScanCounts));
   for (int i = 0; i < de265hip_decoder::kRing; i++) d->ring_free.push_back(i);
   ensure_used_units();
   HIPCHK(hipMalloc((void**)&d->d_used_units, sizeof(g_used_units)), DE265HIP_ERROR_OUT_OF_MEMORY);
@@ -835,12 +845,14 @@ void de265hip_picture_free(de265hip_picture* p)
     // upload waits for that event on the copy stream
     release_arena(dec, p->arena_buf, lane_st(dec, p->lane));     // (its launches on other lanes precede the latest one: they wrote the same slot)
     if (p->ring_idx >= 0) dec->ring_free.push_back(p->ring_idx);   // (first in, first out: its error word stands for thousands of pictures to come)
+    if (p->enq.pending) for (auto& b : dec->stage_pool) if (b.ptr == p->enq.host_base) b.state = 0;      // (built, never enqueued)
     if (p->uploaded) (void)hipEventDestroy(p->uploaded);
   }
   delete p;
 }
 
 static int finish_scan(de265hip_picture* pic);
+static thread_local bool g_defer_enqueue = false;        // de265hip_picture_build_host: the build stops before its HIP calls
 static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hip_picture_desc* d, de265hip_picture** out);
 
 int de265hip_picture_build(de265hip_decoder* dec, int dst_slot, const de265hip_picture_desc* d,
@@ -2149,41 +2161,12 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
     dec->pooled_bytes = (size_t)hsh;
   }
   if (!dec->dry) {
-    hipStream_t cs;
-    { std::lock_guard<std::mutex> lk(dec->mu); cs = dec->copy_streams[dec->copy_turn++ % (uint64_t)dec->n_copy_streams]; }
-    // a recycled arena may still be read by kernels of the picture that had it before
-    if (pic->arena_buf.used && hipStreamWaitEvent(cs, pic->arena_buf.last_use, 0) != hipSuccess) return fail(DE265HIP_ERROR_DECODING);
-    if (hipEventCreateWithFlags(&pic->uploaded, hipEventDisableTiming) != hipSuccess) return fail(DE265HIP_ERROR_OUT_OF_MEMORY);
-    // k_run's ticket counter, run flags and mailbox packets start from zero: a pooled arena held another picture's buffers at
-    // these offsets before, and ANY bit pattern there could pass for a raised flag of some launch generation (round 4 tried to
-    // do without this clear, the generations being unique per decoder: a mid-size picture in a recycled arena came out wrong)
-    if (hipMemsetAsync((uint8_t*)pic->arena + o_sync, 0, clear_bytes, cs) != hipSuccess) return fail(DE265HIP_ERROR_DECODING);
-    pic->arena_buf.epoch = dec->arena_epoch;
-    if (hipMemcpyAsync(pic->arena, host.data(), upload_bytes, hipMemcpyHostToDevice, cs) != hipSuccess ||
-        hipMemsetAsync(dec->d_err_ring + pic->ring_idx, 0, 4, cs) != hipSuccess ||
-        hipEventRecord(stage_event, cs) != hipSuccess)
-      return fail(DE265HIP_ERROR_DECODING);
-    if (!mot_given) {
-      if (hipMemsetAsync((uint8_t*)pic->arena + o_mot, 0xFF, nblk * sizeof(de265hip_motion), cs) != hipSuccess) return fail(DE265HIP_ERROR_DECODING);
-      if (d->n_pus > 0)
-        hipLaunchKernelGGL(k_motion_from_pus, dim3(d->n_pus), dim3(64), 0, cs, P, (const de265hip_pu*)((uint8_t*)pic->arena + o_pus), d->n_pus,
-                           (const de265hip_slice_params*)((uint8_t*)pic->arena + o_sl), d->n_slices, (de265hip_motion*)((uint8_t*)pic->arena + o_mot));
-    }
-    if (dev_scan) {
-      // the passes of the scan, then their counts on the way back to the host (pinned; de265hip_picture_run reads them)
-      if (scan_enqueue(cs, SP, SB, SL, base, cap_resid) != hipSuccess ||
-          hipMemcpyAsync(dec->h_ring + pic->ring_idx, SB.counts, sizeof(ScanCounts), hipMemcpyDeviceToHost, cs) != hipSuccess)
-        return fail(DE265HIP_ERROR_DECODING);
-      pic->scan_pending = true;
-    } else if (!host_checks_positions) {
-      const int n_chk = (int)l0.size() + (int)SC.l0_rext.size();
-      if (n_chk > 0)
-        hipLaunchKernelGGL(k_check_coeffs, dim3((n_chk + 15) / 16), dim3(256), 0, cs, (const TuTask*)((uint8_t*)pic->arena + o_l0), (int)l0.size(),
-                           (const TuTask*)((uint8_t*)pic->arena + o_l0x), (int)SC.l0_rext.size(), (uint16_t*)((uint8_t*)pic->arena + o_cpos), dec->d_err_ring + pic->ring_idx);
-    }
-    if (hipEventRecord(pic->uploaded, cs) != hipSuccess) return fail(DE265HIP_ERROR_DECODING);
-    std::lock_guard<std::mutex> lk(dec->mu);
-    for (auto& b : dec->stage_pool) if (b.ptr == host_base) b.state = 2;      // reusable once `copied` has completed
+    de265hip_picture::Enq& E = pic->enq;
+    E.pending = true; E.host_base = host_base; E.upload_bytes = upload_bytes; E.stage_event = stage_event;
+    E.o_sync = o_sync; E.clear_bytes = clear_bytes; E.o_mot = o_mot; E.o_pus = o_pus; E.o_sl = o_sl; E.o_l0 = o_l0; E.o_l0x = o_l0x; E.o_cpos = o_cpos;
+    E.nblk = nblk; E.mot_given = mot_given; E.check_on_device = !dev_scan && !host_checks_positions;
+    E.n_pus = d->n_pus; E.n_slices = d->n_slices; E.n_l0chk = (int)l0.size(); E.n_l0xchk = (int)SC.l0_rext.size();
+    pic->cap_resid = cap_resid;
   }
   pic->dev_scan = dev_scan;
   pic->d_tus = (TuTask*)(base + o_tus);
@@ -2235,10 +2218,78 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
     std::lock_guard<std::mutex> lk(dec->mu);
     dec->live.push_back(pic);
   }
-  pt.mark("upload");
+  pt.mark("host");
+  if (!dec->dry && !g_defer_enqueue) {
+    const int erc = de265hip_picture_enqueue(pic);
+    if (erc) { de265hip_picture_free(pic); return erc; }
+  }
+  pt.mark("enqueue");
   pt.done();
   *out = pic;
   return DE265HIP_OK;
+}
+
+// The device side of a build: the upload of the staged command buffers, the kernels that work on the raw records behind it (the
+// scan of the TU records, the motion plane), on one of the decoder's copy streams.  de265hip_picture_build calls it itself;
+// de265hip_picture_build_host leaves it to the caller, who may be another thread: the pipeline issues ALL HIP calls of a
+// decoder from one thread (fifteen workers calling into the HIP runtime for the same device spent three quarters of their
+// builds waiting for its locks: builds of 1.7 ms took 6.5 ms, round 4).
+int de265hip_picture_enqueue(de265hip_picture* pic)
+{
+  if (!pic || !pic->dec) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  de265hip_picture::Enq& E = pic->enq;
+  if (!E.pending) return DE265HIP_OK;
+  de265hip_decoder* dec = pic->dec;
+  hipStream_t cs;
+  { std::lock_guard<std::mutex> lk(dec->mu); cs = dec->copy_streams[dec->copy_turn++ % (uint64_t)dec->n_copy_streams]; }
+  uint8_t* base = (uint8_t*)pic->arena;
+  // a recycled arena may still be read by kernels of the picture that had it before
+  if (pic->arena_buf.used) HIPCHK(hipStreamWaitEvent(cs, pic->arena_buf.last_use, 0), DE265HIP_ERROR_DECODING);
+  HIPCHK(hipEventCreateWithFlags(&pic->uploaded, hipEventDisableTiming), DE265HIP_ERROR_OUT_OF_MEMORY);
+  // k_run's ticket counter, run flags and mailbox packets start from zero: a pooled arena held another picture's buffers at
+  // these offsets before, and ANY bit pattern there could pass for a raised flag of some launch generation (round 4 tried to
+  // do without this clear, the generations being unique per decoder: a mid-size picture in a recycled arena came out wrong).
+  // With the device-side scan its own cleared buffers follow the mailboxes: one memset for both.
+  const size_t clear_to = pic->dev_scan ? pic->SL.clear_end : E.o_sync + E.clear_bytes;
+  HIPCHK(hipMemsetAsync(base + E.o_sync, 0, clear_to - E.o_sync, cs), DE265HIP_ERROR_DECODING);
+  HIPCHK(hipMemcpyAsync(base, E.host_base, E.upload_bytes, hipMemcpyHostToDevice, cs), DE265HIP_ERROR_DECODING);
+  HIPCHK(hipEventRecord(E.stage_event, cs), DE265HIP_ERROR_DECODING);
+  {
+    std::lock_guard<std::mutex> lk(dec->mu);
+    for (auto& b : dec->stage_pool) if (b.ptr == E.host_base) b.state = 2;      // reusable once `copied` has completed
+  }
+  E.pending = false;
+  if (!E.mot_given) {
+    HIPCHK(hipMemsetAsync(base + E.o_mot, 0xFF, E.nblk * sizeof(de265hip_motion), cs), DE265HIP_ERROR_DECODING);
+    if (E.n_pus > 0)
+      hipLaunchKernelGGL(k_motion_from_pus, dim3(E.n_pus), dim3(64), 0, cs, pic->P, (const de265hip_pu*)(base + E.o_pus), E.n_pus,
+                         (const de265hip_slice_params*)(base + E.o_sl), E.n_slices, (de265hip_motion*)(base + E.o_mot));
+  }
+  if (pic->dev_scan) {
+    // the passes of the scan; the last of them writes the counts into the picture's pinned ring entry and raises its ready word
+    // (system-scope stores: no copy, no event for the host to wait on - de265hip_picture_run polls the word)
+    ScanCounts* hc = dec->h_ring + pic->ring_idx;
+    __atomic_store_n(&hc->ready, 0u, __ATOMIC_RELEASE);
+    pic->SB.host_counts = hc; pic->SB.err_word = dec->d_err_ring + pic->ring_idx; pic->SB.ready_tag = (uint32_t)pic->ring_seq | 0x80000000u;
+    HIPCHK(scan_enqueue(cs, pic->SP, pic->SB, pic->SL, base, pic->cap_resid), DE265HIP_ERROR_DECODING);
+    pic->scan_pending = true;
+  } else {
+    HIPCHK(hipMemsetAsync(dec->d_err_ring + pic->ring_idx, 0, 4, cs), DE265HIP_ERROR_DECODING);
+    if (E.check_on_device && E.n_l0chk + E.n_l0xchk > 0)
+      hipLaunchKernelGGL(k_check_coeffs, dim3((E.n_l0chk + E.n_l0xchk + 15) / 16), dim3(256), 0, cs, (const TuTask*)(base + E.o_l0), E.n_l0chk,
+                         (const TuTask*)(base + E.o_l0x), E.n_l0xchk, (uint16_t*)(base + E.o_cpos), dec->d_err_ring + pic->ring_idx);
+  }
+  HIPCHK(hipEventRecord(pic->uploaded, cs), DE265HIP_ERROR_DECODING);
+  return DE265HIP_OK;
+}
+
+// de265hip_picture_build without its device side (see de265hip_picture_enqueue)
+int de265hip_picture_build_host(de265hip_decoder* dec, int dst_slot, const de265hip_picture_desc* d, de265hip_picture** out)
+{
+  g_defer_enqueue = true;
+  const int rc = de265hip_picture_build(dec, dst_slot, d, out);
+  g_defer_enqueue = false;
+  return rc;
 }
 
 // Profiling aid (tools/time_build.py --host-only): the host stage of de265hip_picture_build `reps` times without a GPU
@@ -2280,8 +2331,18 @@ static int finish_scan(de265hip_picture* pic)
   if (!dec) return pic->scan_rc = DE265HIP_ERROR_DECODING;       // (an orphan: its device side is gone)
   const ScanCounts* K = &pic->h_counts_dry;
   if (!dec->dry) {
-    if (hipEventSynchronize(pic->uploaded) != hipSuccess) return pic->scan_rc = DE265HIP_ERROR_DECODING;
+    if (pic->enq.pending) { const int erc = de265hip_picture_enqueue(pic); if (erc) return pic->scan_rc = erc; }
     K = dec->h_ring + pic->ring_idx;
+    // the last pass stores the counts into this pinned record and then its ready word (system scope): normally long since there
+    const uint32_t tag = (uint32_t)pic->ring_seq | 0x80000000u;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0; __atomic_load_n(&K->ready, __ATOMIC_ACQUIRE) != tag; spins++) {
+      if ((spins & 255) == 255) {
+        if (hipEventQuery(pic->uploaded) == hipSuccess && __atomic_load_n(&K->ready, __ATOMIC_ACQUIRE) != tag) return pic->scan_rc = DE265HIP_ERROR_DECODING;   // (passes done, no word: a fault)
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) return pic->scan_rc = DE265HIP_ERROR_DECODING;
+      }
+      __builtin_ia32_pause();
+    }
   }
   pic->scan_pending = false;
   if (K->status) return pic->scan_rc = (int)K->status;
@@ -2345,6 +2406,7 @@ int de265hip_debug_picture_read(de265hip_picture* pic, int64_t offset, int64_t b
   if (!pic || !dst || offset < 0 || bytes < 0 || (size_t)(offset + bytes) > pic->arena_bytes) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   if (!pic->dry_arena.empty()) { memcpy(dst, pic->dry_arena.data() + offset, (size_t)bytes); return 0; }
   if (!pic->dec || !pic->arena) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  if (pic->enq.pending) { const int erc = de265hip_picture_enqueue(pic); if (erc) return erc; }
   if (pic->uploaded) HIPCHK(hipEventSynchronize(pic->uploaded), DE265HIP_ERROR_DECODING);
   HIPCHK(hipMemcpy(dst, (const uint8_t*)pic->arena + offset, (size_t)bytes, hipMemcpyDeviceToHost), DE265HIP_ERROR_DECODING);
   return 0;
@@ -2633,6 +2695,7 @@ int de265hip_picture_run(de265hip_decoder* dec, de265hip_picture* pic, int last_
   if (!dec || !pic || pic->dec != dec || last_stage < 0 || last_stage > 2) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   // device-side scan: its counts (task list sizes, tickets, front runs) and its verdict on the records arrive with the event
   // behind the passes - long since complete when the builds run ahead of the launches (the pipeline); outside the decoder's lock
+  if (pic->enq.pending) { const int erc = de265hip_picture_enqueue(pic); if (erc) return erc; }
   if (const int rc = finish_scan(pic)) return rc;
   if (pic->P.bd_luma > 8) return run_picture<uint16_t>(dec, pic, last_stage);
   return run_picture<uint8_t>(dec, pic, last_stage);

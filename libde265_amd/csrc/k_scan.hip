@@ -13,8 +13,10 @@ __global__ __launch_bounds__(256)
 void k_scan_tus(ScanParams P, ScanBufs B)
 {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0 && B.err_word) *B.err_word = 0;                  // (the picture's kernels that may raise it come behind the scan)
   ScanTuSums S = { 0, 0, 0, 0, 0 };
-  if (i < P.n_tus) scan_tu(P, B, i, S);
+  ScanParams Pt = P; Pt.flags &= ~SCANF_CHECK_POS;            // (the positions: below, sixteen lanes per TU)
+  if (i < P.n_tus) scan_tu(Pt, B, i, S);
   // one atomic per wavefront and sum
   unsigned long long v[3] = { S.alg_resid, S.alg_intra, S.n_isamp };
   uint32_t w[2] = { S.n_tasks, S.n_intra };
@@ -28,6 +30,26 @@ void k_scan_tus(ScanParams P, ScanBufs B)
   if ((threadIdx.x & 63) == 0) {
     scan_add64(&B.counts->alg_resid, v[0]); scan_add64(&B.counts->alg_intra, v[1]); scan_add64(&B.counts->n_isamp, v[2]);
     if (w[0]) atomicAdd(&B.counts->n_tasks, w[0]);
+  }
+  // coefficient positions inside their TU's block (de265hip_picture_build's job on the host until round 3): the workgroup's 256
+  // records sixteen at a time, sixteen lanes striding each list (a thread walking its own list alone took 7x as long); a
+  // position beyond the block is folded into it and the picture fails
+  if (P.flags & SCANF_CHECK_POS) {
+    const int sub = threadIdx.x & 15;
+    bool bad = false;
+    for (int g = 0; g < 16; g++) {
+      const int j = blockIdx.x * 256 + g * 16 + (threadIdx.x >> 4);
+      if (j >= P.n_tus) break;
+      const de265hip_tu tu = B.tus[j];
+      if (!(tu.flags & DE265HIP_TU_CBF) || !scan_tu_valid(P, tu)) continue;
+      const unsigned nS = 1u << (2 * tu.log2_size), n = tu.n_coeff;
+      uint16_t* p = B.coeff_pos + tu.coeff_offset;
+      for (unsigned k = sub; k < n; k += 16) {
+        const unsigned q = p[k];
+        if (q >= nS) { p[k] = (uint16_t)(q & (nS - 1)); bad = true; }
+      }
+    }
+    if (bad) scan_fail(B, DE265HIP_ERROR_DECODING);
   }
 }
 
@@ -67,6 +89,7 @@ void k_scan_prefix(ScanParams P, ScanBufs B, uint32_t cap_resid)
   }
   __syncthreads();
   if (tid == 0) {
+    if (P.n_tus == 0 && B.err_word) *B.err_word = 0;
     scan_prefix_finish_totals(B, tot);
     B.counts->victim = 0xFFFFFFFFu;
     // (overlapping intra TUs - a malformed description - could ask for more residual samples than the picture has)
@@ -569,41 +592,33 @@ void k_scan_runs2(ScanParams P, ScanBufs B)
   }
 }
 
-// the third run pass: a thread per listed run (scan_core.h scan_run3)
-__global__ __launch_bounds__(64)
-void k_scan_runs3(ScanParams P, ScanBufs B)
-{
-  const uint32_t q = blockIdx.x * 64 + threadIdx.x;
-  if (B.counts->status || q >= B.counts->n_listed) return;
-  scan_run3(P, B, B.run_list[q]);
-}
-
-// coefficient positions inside their TU's block (de265hip_picture_build's job on the host until round 3): sixteen lanes per TU
-// record, striding its list; a position beyond the block is folded into it and the picture fails
-__global__ __launch_bounds__(256)
-void k_scan_check_pos(ScanParams P, ScanBufs B)
-{
-  const int i = (blockIdx.x * 256 + threadIdx.x) >> 4, sub = threadIdx.x & 15;
-  if (i >= P.n_tus) return;
-  const de265hip_tu tu = B.tus[i];
-  if (!(tu.flags & DE265HIP_TU_CBF) || !scan_tu_valid(P, tu)) return;
-  const unsigned nS = 1u << (2 * tu.log2_size), n = tu.n_coeff;
-  uint16_t* p = B.coeff_pos + tu.coeff_offset;
-  bool bad = false;
-  for (unsigned k = sub; k < n; k += 16) {
-    const unsigned v = p[k];
-    if (v >= nS) { p[k] = (uint16_t)(v & (nS - 1)); bad = true; }
-  }
-  if (bad) scan_fail(B, DE265HIP_ERROR_DECODING);
-}
-
 // Ticket slots (scan_core.h "tickets"), one workgroup: the CTBs in ctb_order are dealt to the threads in contiguous chunks; how
 // a chunk's runs fill tickets depends on how full the open ticket is when the chunk begins, so every thread first computes its
 // chunk's effect for each of the eight possible fill states (a table), the tables are composed by a prefix scan (composition
 // of such tables is associative), and every thread then walks its chunk again from its true start state and writes the slots.
 #define SCO_THREADS 1024
+__device__ void scan_order_body(const ScanParams& P, const ScanBufs& B, uint32_t cap_levels);
 __global__ __launch_bounds__(SCO_THREADS)
 void k_scan_order(ScanParams P, ScanBufs B, uint32_t cap_levels)
+{
+  // the third run pass first (a thread per listed run, scan_core.h scan_run3: the runs somebody reads through their mailbox)
+  if (!B.counts->status && (P.flags & SCANF_MAILBOX)) {
+    const uint32_t n = B.counts->n_listed;
+    for (uint32_t q = threadIdx.x; q < n; q += SCO_THREADS) scan_run3(P, B, B.run_list[q]);
+  }
+  __threadfence();
+  __syncthreads();
+  scan_order_body(P, B, cap_levels);
+  // ---- the scan's verdict and counts to the host: into the picture's pinned record, then its ready word (system scope)
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x < sizeof(ScanCounts) / 4 - 2 && B.host_counts)
+    reinterpret_cast<volatile uint32_t*>(B.host_counts)[threadIdx.x] = reinterpret_cast<volatile uint32_t*>(B.counts)[threadIdx.x];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0 && B.host_counts) __hip_atomic_store(&B.host_counts->ready, B.ready_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ void scan_order_body(const ScanParams& P, const ScanBufs& B, uint32_t cap_levels)
 {
   __shared__ uint32_t tab[SCO_THREADS][RUN_TICKET_SLOTS];          // per chunk and fill state at its start: tickets it opens | fill state at its end << 28
   __shared__ uint32_t s_diag[4096];
@@ -732,22 +747,16 @@ void ScanLayout::bind(uint8_t* base, ScanBufs& B) const
 // ------------------------------------------------------------------------------------------------ enqueue
 hipError_t scan_enqueue(hipStream_t st, const ScanParams& P, const ScanBufs& B, const ScanLayout& L, uint8_t* base, uint32_t cap_resid)
 {
-  hipError_t e = hipMemsetAsync(base + L.clear_begin, 0, L.clear_end - L.clear_begin, st);
-  if (e != hipSuccess) return e;
-  if (P.n_tus > 0) {
-    ScanParams Pt = P; Pt.flags &= ~SCANF_CHECK_POS;             // (the positions have a kernel of their own: sixteen lanes per TU)
-    hipLaunchKernelGGL(k_scan_tus, dim3((P.n_tus + 255) / 256), dim3(256), 0, st, Pt, B);
-    if (P.flags & SCANF_CHECK_POS) hipLaunchKernelGGL(k_scan_check_pos, dim3((P.n_tus + 15) / 16), dim3(256), 0, st, P, B);
-  }
+  (void)base;                                                   // (the caller has cleared [clear_begin, clear_end) with the run flags)
+  if (P.n_tus > 0) hipLaunchKernelGGL(k_scan_tus, dim3((P.n_tus + 255) / 256), dim3(256), 0, st, P, B);
   hipLaunchKernelGGL(k_scan_prefix, dim3(1), dim3(1024), 0, st, P, B, cap_resid);
   if (P.n_tus > 0) {
     hipLaunchKernelGGL(k_scan_ctbs, dim3(P.n_ctbs), dim3(64), 0, st, P, B);
     // (the number of runs is only known on the device: fixed grids of wavefronts walk the run list)
     hipLaunchKernelGGL(k_scan_runs1, dim3(4096), dim3(64), 0, st, P, B);
     hipLaunchKernelGGL(k_scan_runs2, dim3(4096), dim3(64), 0, st, P, B);
-    if (P.flags & SCANF_MAILBOX) hipLaunchKernelGGL(k_scan_runs3, dim3((unsigned)((P.cap_runs + 63) / 64)), dim3(64), 0, st, P, B);
-    hipLaunchKernelGGL(k_scan_order, dim3(1), dim3(SCO_THREADS), 0, st, P, B, L.cap_levels);
   }
+  hipLaunchKernelGGL(k_scan_order, dim3(1), dim3(SCO_THREADS), 0, st, P, B, L.cap_levels);      // (always: it reports to the host)
   return hipGetLastError();
 }
 

@@ -2,7 +2,7 @@
 //
 // The reference overlaps parsing and reconstruction with a thread pool inside one picture (decctx.cc:976-1178: WPP rows / tiles /
 // slices as tasks).  With the reconstruction on the device, what has to overlap is: the host parser on picture n+1, the host stage
-// of this library (recorder -> de265hip_picture_build: availability replay, run construction, staging, upload) for pictures
+// of this library (recorder -> de265hip_picture_build_host: validation, MC tasks, staging) for pictures
 // n, n-1, .. on worker threads, and the kernels + copy-out of the pictures before those on the device.  A pipeline owns the worker
 // threads and the ordering rule: pictures are BUILT concurrently and LAUNCHED in submission order (a picture's kernels read the
 // DPB slots its references were launched into).  Host-only code: no kernel lives here.
@@ -37,30 +37,34 @@ struct de265hip_pipeline {
   de265hip_decoder* dec = nullptr;
   int n_workers = 1;
   std::vector<std::thread> th;
+  std::thread launcher_th;
   std::mutex mu;
-  std::condition_variable cv;
+  std::condition_variable cv;                   // submit / wait / drain
+  std::condition_variable cv_launch;            // the launcher: a picture has been built
   std::deque<PipeJob> q;                        // submitted, not yet taken by a worker
   std::map<uint64_t, int> slot_of;              // launched, copy-out possibly still in flight: ticket -> slot
   std::map<uint64_t, int> failed;               // ticket -> error of prepare / build / run
-  struct Built { PipeJob job; de265hip_picture* pic; int rc; };
+  struct Built { PipeJob job; de265hip_picture* pic; int rc; bool enqueued; };
   std::map<uint64_t, Built> ready;              // built (or failed), waiting for their turn to be launched
-  bool launching = false;                       // a worker is launching the ready pictures, in order
   uint64_t next_ticket = 0, next_launch = 0;    // tickets are handed out and launched in submission order
   int in_flight = 0;                            // queued or being built, not yet launched
   int window = 4;                               // bound of in_flight (submit blocks)
   bool stop = false;
-  // DE265HIP_PIPE_TIMING=1: where the workers' time goes (seconds, summed over workers; printed when the pipeline is freed)
+  // DE265HIP_PIPE_TIMING=1: where the threads' time goes (seconds, summed; printed when the pipeline is freed)
   bool timing = false;
-  double t_idle = 0, t_build = 0, t_turn = 0, t_launch = 0, t_free = 0; long n_jobs = 0;
+  double t_idle = 0, t_build = 0, t_enqueue = 0, t_launch = 0, t_lidle = 0; long n_jobs = 0;
 };
 
 namespace {
 
+double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// A worker: the HOST stage of its pictures, concurrently with the other workers' (prepare -> recorder, de265hip_picture_build_host:
+// validation, MC tasks, staging into pinned memory).  No HIP call that touches a stream: those are the launcher's.
 void worker(de265hip_pipeline* p)
 {
   for (;;) {
     PipeJob j;
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
     {
       std::unique_lock<std::mutex> lk(p->mu);
@@ -69,52 +73,69 @@ void worker(de265hip_pipeline* p)
       j = p->q.front(); p->q.pop_front();
     }
     const double t1 = now();
-    // host stage, concurrently with the other workers' pictures
     de265hip_recorder* rec = nullptr;
     de265hip_picture* pic = nullptr;
     int rc = 0;
-    if (j.desc) rc = de265hip_picture_build(p->dec, j.slot, j.desc, &pic);
+    if (j.desc) rc = de265hip_picture_build_host(p->dec, j.slot, j.desc, &pic);
     else {
       rc = j.prepare(j.user, &rec);
       if (!rc && !rec) rc = DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
-      if (!rc) rc = de265hip_recorder_submit(p->dec, j.slot, rec, &pic);
+      if (!rc) rc = de265hip_picture_build_host(p->dec, j.slot, de265hip_recorder_desc(rec), &pic);
       if (rec) de265hip_recorder_free(rec);
     }
     const double t2 = now();
-    // Device stage, in submission order (also when the picture failed: the turn must pass on).  The worker leaves its picture
-    // with the built ones and goes back to work; whoever finds the next picture to be launched among them - and nobody
-    // launching - launches every picture whose turn has come.  (Workers that WAITED for their turn held one picture each:
-    // with an expensive picture at the head, every other worker idled behind it after building a single picture.)
-    double t_l = 0;
+    {
+      std::lock_guard<std::mutex> lk(p->mu);
+      p->ready[j.ticket] = de265hip_pipeline::Built{ j, pic, rc, false };
+      if (p->timing) { p->t_idle += t1 - t0; p->t_build += t2 - t1; p->n_jobs++; }
+    }
+    p->cv_launch.notify_one();
+  }
+}
+
+// The launcher: the ONE thread that talks to the HIP runtime for this pipeline's decoder.  Round 3 let whichever worker finished
+// a build enqueue its upload and launch the pictures whose turn had come; with the device-side scan a build issues a dozen HIP
+// calls and fifteen workers calling into the runtime for one device spent three quarters of their builds waiting for its
+// locks (builds of 1.7 ms took 6.5 ms).  Pictures are ENQUEUED (upload + scan of their records) as soon as they are built, in
+// any order, and LAUNCHED in submission order (also when a picture failed: the turn must pass on).
+void launcher(de265hip_pipeline* p)
+{
+  for (;;) {
+    de265hip_pipeline::Built todo; bool have_enq = false, have_launch = false; uint64_t enq_ticket = 0;
+    const double t0 = now();
     {
       std::unique_lock<std::mutex> lk(p->mu);
-      p->ready[j.ticket] = de265hip_pipeline::Built{ j, pic, rc };
-      if (!p->launching) {
-        p->launching = true;
-        for (auto it = p->ready.find(p->next_launch); it != p->ready.end(); it = p->ready.find(p->next_launch)) {
-          de265hip_pipeline::Built b = it->second;
-          p->ready.erase(it);
-          lk.unlock();
-          const double ta = now();
-          int r = b.rc;
-          if (!r) r = de265hip_picture_run(p->dec, b.pic, DE265HIP_STAGE_FINAL);
-          for (int c = 0; c < 3 && !r; c++)
-            if (b.job.plane[c]) r = de265hip_dpb_download_async(p->dec, b.job.slot, c, b.job.plane[c], b.job.stride[c]);
-          if (b.pic) de265hip_picture_free(b.pic);          // never waits (de265_hip.h LIFETIME)
-          t_l += now() - ta;
-          lk.lock();
-          if (r) p->failed[b.job.ticket] = r; else p->slot_of[b.job.ticket] = b.job.slot;
-          p->next_launch++; p->in_flight--;
-          p->cv.notify_all();
-        }
-        p->launching = false;
+      for (;;) {
+        auto it = p->ready.find(p->next_launch);
+        if (it != p->ready.end() && (it->second.enqueued || it->second.rc || !it->second.pic)) { todo = it->second; p->ready.erase(it); have_launch = true; break; }
+        for (auto& kv : p->ready) if (!kv.second.enqueued && !kv.second.rc && kv.second.pic) { todo = kv.second; enq_ticket = kv.first; have_enq = true; break; }
+        if (have_enq) break;
+        if (p->stop) return;
+        p->cv_launch.wait(lk);
       }
     }
-    const double t3 = now(), t4 = t3;
-    if (p->timing) {
-      const double t5 = now();
+    const double t1 = now();
+    if (have_enq) {
+      const int rc = de265hip_picture_enqueue(todo.pic);
       std::lock_guard<std::mutex> lk(p->mu);
-      p->t_idle += t1 - t0; p->t_build += t2 - t1; p->t_turn += t3 - t2 - t_l; p->t_launch += t_l; p->t_free += t5 - t4; p->n_jobs++;
+      auto it = p->ready.find(enq_ticket);
+      if (it != p->ready.end()) { it->second.enqueued = true; if (rc) it->second.rc = rc; }
+      if (p->timing) { p->t_lidle += t1 - t0; p->t_enqueue += now() - t1; }
+      continue;
+    }
+    if (have_launch) {
+      int r = todo.rc;
+      if (!r) r = de265hip_picture_run(p->dec, todo.pic, DE265HIP_STAGE_FINAL);
+      for (int c = 0; c < 3 && !r; c++)
+        if (todo.job.plane[c]) r = de265hip_dpb_download_async(p->dec, todo.job.slot, c, todo.job.plane[c], todo.job.stride[c]);
+      if (todo.pic) de265hip_picture_free(todo.pic);          // never waits (de265_hip.h LIFETIME)
+      {
+        std::lock_guard<std::mutex> lk(p->mu);
+        if (r) p->failed[todo.job.ticket] = r; else p->slot_of[todo.job.ticket] = todo.job.slot;
+        p->next_launch++; p->in_flight--;
+        if (p->timing) { p->t_lidle += t1 - t0; p->t_launch += now() - t1; }
+      }
+      p->cv.notify_all();
     }
   }
 }
@@ -132,6 +153,7 @@ int de265hip_pipeline_new(de265hip_pipeline** out, de265hip_decoder* dec, int n_
   p->window = 4 * n_workers + 4;
   if (const char* w = getenv("DE265HIP_PIPE_WINDOW")) p->window = std::max(1, atoi(w));
   for (int i = 0; i < n_workers; i++) p->th.emplace_back(worker, p);
+  p->launcher_th = std::thread(launcher, p);
   *out = p;
   return 0;
 }
@@ -216,12 +238,13 @@ void de265hip_pipeline_free(de265hip_pipeline* p)
   if (!p) return;
   (void)de265hip_pipeline_drain(p);
   { std::lock_guard<std::mutex> lk(p->mu); p->stop = true; }
-  p->cv.notify_all();
+  p->cv.notify_all(); p->cv_launch.notify_all();
   for (auto& t : p->th) t.join();
+  p->launcher_th.join();
   if (p->timing && p->n_jobs)
-    fprintf(stderr, "de265hip pipeline: %ld pictures, %d workers; ms per picture: idle %.2f build %.2f wait-for-turn %.2f launch %.2f free %.2f\n",
-            p->n_jobs, p->n_workers, 1e3 * p->t_idle / p->n_jobs, 1e3 * p->t_build / p->n_jobs, 1e3 * p->t_turn / p->n_jobs,
-            1e3 * p->t_launch / p->n_jobs, 1e3 * p->t_free / p->n_jobs);
+    fprintf(stderr, "de265hip pipeline: %ld pictures, %d workers + 1 launcher; ms per picture: workers idle %.2f build (host stage) %.2f | launcher idle %.2f enqueue (upload + scan) %.2f launch %.2f\n",
+            p->n_jobs, p->n_workers, 1e3 * p->t_idle / p->n_jobs, 1e3 * p->t_build / p->n_jobs, 1e3 * p->t_lidle / p->n_jobs,
+            1e3 * p->t_enqueue / p->n_jobs, 1e3 * p->t_launch / p->n_jobs);
   delete p;
 }
 

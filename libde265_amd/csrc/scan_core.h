@@ -69,6 +69,7 @@ struct ScanCounts {
   uint32_t n_deps_alloc, n_segs_alloc, n_tasks, victim, sum_lvls, n_intra;
   uint32_t n_listed;                   // runs in run_list
   unsigned long long alg_resid, alg_intra, alg_intra_front, n_isamp;
+  uint32_t ready, pad1;                // (the host's copy only) the tag of the build, stored after everything else
 };
 
 // a 4x4 cell of a component: low word = index + 1 of the intra TU record covering it (0: none; scan_tu),
@@ -89,6 +90,9 @@ struct ScanBufs {
   TuTask* l0; TuTask* l0x; RunTask* runs; TuTask* run_tus; uint32_t* deps; uint32_t* slots; uint32_t* front_idx;
   uint32_t* mbx; uint32_t* mb_segs;
   ScanCounts* counts;
+  ScanCounts* host_counts;             // the picture's pinned record on the host (device-visible): written by the last pass
+  uint32_t* err_word;                  // the picture's error word (k_run, coefficient positions): cleared by the first pass
+  uint32_t ready_tag;
 };
 
 // tu_info word of an intra TU
