@@ -31,6 +31,12 @@ import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
 
+# The ROCm runtime maps HIP streams onto a few hardware queues (4 by default), round-robin in order of creation; streams that
+# share a queue run their kernels one after the other.  Three decoders with a kernel stream and two copy streams each would
+# put all three kernel streams on one queue: eight queues keep them apart ("host placement").  Must be set
+# before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
     if p not in sys.path:
@@ -489,7 +495,9 @@ def main():
     elapsed, ktimes, product = replay_elapsed, ktimes_replay, None
     cores = host_cores(world, pinned=cpus is not None)   # this rank's share
     if not args.no_host_inclusive:
-        nthr = args.host_threads if args.host_threads > 0 else max(1, min(16, cores))
+        # threads of this rank: per GOP stream one submitter (this script's: the "parser"), one launcher (the library's: every HIP
+        # call of the decoder) and `per` workers (the library's: the host stage of the builds); --host-threads counts the workers
+        nthr = args.host_threads if args.host_threads > 0 else max(S, min(9, cores - 2 * S - 1))
         per = max(1, min(16, nthr // S))                 # worker threads of each decoder's pipeline
         for ps in pics:                                  # the prebuilt pictures go back to the pools
             for p_ in ps:
@@ -555,12 +563,13 @@ def main():
         product_pass([one], gops[:1], False); one.drain()
         t1 = time.perf_counter() - t1
         one.close()
-        product = {"host_threads": per * S, "workers_per_decoder": per, "host_cores_available": cores,
-                   "host_threads_per_rank": per * S, "rank_cpus": len(cpus) if cpus else None, "rank_numa_node": numa,
+        product = {"host_threads": per * S + S, "workers_per_decoder": per, "launcher_threads": S, "host_cores_available": cores,
+                   "host_threads_per_rank": per * S + S, "rank_cpus": len(cpus) if cpus else None, "rank_numa_node": numa,
                    "value_1_host_thread": round(GOP / t1, 2), "with_copy_out": copy_out,
-                   "what": "de265hip_pipeline_submit_desc per picture: the library's worker threads run de265hip_picture_build (host stage + "
-                           "pinned asynchronous upload), launch in decode order (de265hip_picture_run) and free; decoded pictures stay in the "
-                           "device-resident DPB (no copy-out in the timed region)"}
+                   "what": "de265hip_pipeline_submit_desc per picture: the library's worker threads run the host stage of the build (validation, "
+                           "MC tasks, staging, pinned upload), its launcher thread enqueues the device-side scan of the TU records, launches in "
+                           "decode order (de265hip_picture_run) and frees; decoded pictures stay in the device-resident DPB (no copy-out in "
+                           "the timed region)"}
         pics = [[d.build(k, g[k].desc) for k in range(GOP)] for d, g in zip(decs, gops)]   # (for the isolated pass below)
         stats = [p.stats() for ps in pics for p in ps]
 

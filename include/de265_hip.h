@@ -387,6 +387,8 @@ void de265hip_pipeline_free(de265hip_pipeline*);           /* drains first */
  * has).  A picture that was built but never enqueued may be freed. */
 int  de265hip_picture_build_host(de265hip_decoder*, int dst_slot, const de265hip_picture_desc*, de265hip_picture** out);
 int  de265hip_picture_enqueue(de265hip_picture*);
+int  de265hip_picture_enqueue_batch(de265hip_picture** pics, int n);   /* pictures of ONE decoder: their scans share their kernel launches */
+int  de265hip_picture_ready(de265hip_picture*);     /* 1: de265hip_picture_run will not wait for the device side of the build; 0: not yet */
 
 /* Profiling aid: the host stage of de265hip_picture_build `reps` times, without a GPU and without any HIP call. */
 int  de265hip_debug_build_host_only(const de265hip_picture_desc*, int reps);

@@ -23,7 +23,7 @@ EXPORTS = [
     "de265hip_pipeline_new", "de265hip_pipeline_submit", "de265hip_pipeline_submit_desc", "de265hip_pipeline_wait", "de265hip_pipeline_drain", "de265hip_pipeline_free",
     "de265hip_debug_build_host_only", "de265hip_debug_last_build_hash", "de265hip_debug_build_host_only_ex",
     "de265hip_debug_fault_injection", "de265hip_debug_picture_layout", "de265hip_debug_picture_read",
-    "de265hip_picture_build", "de265hip_picture_build_host", "de265hip_picture_enqueue", "de265hip_picture_run", "de265hip_decoder_sync", "de265hip_picture_free",
+    "de265hip_picture_build", "de265hip_picture_build_host", "de265hip_picture_enqueue", "de265hip_picture_enqueue_batch", "de265hip_picture_ready", "de265hip_picture_run", "de265hip_decoder_sync", "de265hip_picture_free",
     "de265hip_decode_picture", "de265hip_picture_get_stats",
     "de265hip_set_profiling", "de265hip_get_kernel_times", "de265hip_derive_edge_flags", "de265hip_intra_used_units",
     "de265hip_recorder_new", "de265hip_recorder_free", "de265hip_record_tu", "de265hip_record_pu",
@@ -93,6 +93,8 @@ def lib():
     L.de265hip_picture_build.argtypes = [vp, i32, pp(_abi.PictureDesc), pp(vp)]
     L.de265hip_picture_build_host.argtypes = [vp, i32, pp(_abi.PictureDesc), pp(vp)]
     L.de265hip_picture_enqueue.argtypes = [vp]
+    L.de265hip_picture_ready.argtypes = [vp]
+    L.de265hip_picture_enqueue_batch.argtypes = [pp(vp), i32]
     L.de265hip_picture_run.argtypes = [vp, vp, i32]
     L.de265hip_decoder_sync.argtypes = [vp]
     L.de265hip_decoder_set_lanes.argtypes = [vp, i32]

@@ -63,10 +63,11 @@ struct PendingEvent { int kid; hipEvent_t a, b; };
 // picture that used the arena is freed; the next upload into it waits for that event on the copy stream (no
 // host-side synchronisation, no hipMalloc / hipFree per picture -- both stall every stream of the process).
 struct ArenaBuf { void* ptr = nullptr; size_t bytes = 0; hipEvent_t last_use = nullptr; bool used = false;
-                  int64_t epoch = -1; };       // epoch: the decoder's generation epoch the arena was last cleared in (-1: never)
+                  int64_t epoch = -1;          // epoch: the decoder's generation epoch the arena was last cleared in (-1: never)
+                  uint64_t release_seq = 0; }; // the decoder's count of released arenas when this one came back to the pool
 // Pinned staging buffer the host stage assembles the command buffers in.  copied: recorded on the copy stream
 // behind the upload; the buffer is handed out again once it has completed.
-struct StageBuf { void* ptr = nullptr; size_t bytes = 0; hipEvent_t copied = nullptr; int state = 0; };   // state: 0 idle, 1 being filled by a host thread, 2 upload in flight
+struct StageBuf { void* ptr = nullptr; size_t bytes = 0; hipEvent_t copied = nullptr; int state = 0; uint64_t owner = 0; };   // state: 0 idle, 1 being filled by a host thread, 2 upload in flight
 
 }  // namespace
 
@@ -82,12 +83,20 @@ struct de265hip_decoder {
   hipStream_t copy_streams[kMaxCopyStreams] = {};
   int n_copy_streams = 1;
   uint64_t copy_turn = 0;
+  // ... and the uploads of a pipeline's builds go out from the worker that staged them, on upload streams of their own:
+  // hipMemcpyAsync of a few megabytes of pinned memory holds its caller for about as long as the copy takes (140 us, at times
+  // milliseconds): issued by the launcher it was most of what the launcher did
+  hipStream_t upload_streams[2] = {};
+  uint64_t upload_turn = 0;
   hipStream_t out_stream = nullptr;   // de265hip_dpb_download_async: decoded pictures leave on their own stream, behind an event of `stream`
   hipEvent_t out_fence = nullptr;
   std::mutex mu;                      // guards live, the two pools and slot allocation: build()/free() may come from several host threads
   std::vector<de265hip_picture*> live;        // pictures built on this decoder and not yet freed (decoder_free orphans them)
   std::vector<ArenaBuf> free_arenas;
+  std::deque<ArenaBuf> cooling;                 // released, their last user's kernels possibly still running (reap_arenas)
+  uint64_t arena_releases = 0;                  // arenas handed back so far (acquire_arena: how long ago was this one released?)
   std::vector<StageBuf> stage_pool;
+  std::vector<hipEvent_t> free_events;          // `uploaded` events of freed pictures (no create / destroy per picture)
   size_t pooled_bytes = 0;
   Slot slots[DE265HIP_MAX_DPB_SLOTS];
   Slot spare;                         // SAO output target, swapped with the decoded slot (lane 0's)
@@ -123,6 +132,8 @@ struct de265hip_decoder {
   uint64_t* d_used_units = nullptr;   // g_used_units on the device
   bool drop_producer = false;         // fault injection (de265hip_debug_fault_injection; tests only)
   int building = 0;                   // de265hip_picture_build calls in progress (their pictures are not in `live` yet)
+  double t_scan_wait = 0, t_run = 0, t_enq = 0; long n_scan_wait = 0;
+  double t_sec[8] = {}, t_sec_max[8] = {}; long n_sec = 0;      // DE265HIP_PIPE_TIMING: sections of de265hip_picture_enqueue_batch      // DE265HIP_PIPE_TIMING: seconds the launches waited for scans / spent enqueueing
   int run_waves = RUN_WAVES;          // DE265HIP_RUN_WAVES: wavefronts per run workgroup (experiments)
   bool resid_one_launch = true;       // DE265HIP_RESID_ONE_LAUNCH=0: 8x8 / 4x4 residual TUs in their own launch (k_resid_small)
   bool resid16_big = false;           // DE265HIP_RESID16_BIG: 16x16 residual TUs by 4-wavefront workgroups (k_resid_big) instead of one wavefront
@@ -198,7 +209,7 @@ struct de265hip_picture {
   // what de265hip_picture_enqueue needs of the build (the device work of a build - upload, scan - may be issued later and by
   // another thread than the host stage: the pipeline issues every HIP call of a decoder from one thread)
   struct Enq {
-    bool pending = false;
+    bool pending = false, uploaded_by_builder = false;
     uint8_t* host_base = nullptr; size_t upload_bytes = 0; hipEvent_t stage_event = nullptr;
     size_t o_sync = 0, clear_bytes = 0, o_mot = 0, o_pus = 0, o_sl = 0, o_l0 = 0, o_l0x = 0, o_cpos = 0, nblk = 0;
     bool mot_given = true, check_on_device = false;
@@ -447,13 +458,37 @@ static const int16_t k_inv_angle[15] = { -4096, -1638, -910, -630, -482, -390, -
 // ---- pools (caller holds dec->mu)
 constexpr size_t kPoolLimitBytes = (size_t)24 << 30;      // free arenas kept for reuse (of 288 GB of HBM)
 
+// Arenas whose last user has finished on the device move from `cooling` to the free list (caller holds dec->mu).  The only
+// place that asks the runtime (hipEventQuery): called by whoever issues the decoder's HIP calls anyway (enqueue, run), and by
+// acquire_arena when the free list has nothing to offer.
+void reap_arenas(de265hip_decoder* dec)
+{
+  for (size_t i = 0; i < dec->cooling.size();) {
+    if (hipEventQuery(dec->cooling[i].last_use) == hipSuccess) {
+      ArenaBuf a = dec->cooling[i];
+      a.used = false;                                    // (nothing left to wait for: its next upload starts at once)
+      dec->free_arenas.push_back(a);
+      dec->cooling.erase(dec->cooling.begin() + i);
+    } else if (++i >= 4) break;                          // (they finish roughly in order: no need to ask about all of them)
+  }
+}
+
 int acquire_arena(de265hip_decoder* dec, size_t bytes, ArenaBuf* out)
 {
-  int best = -1;
-  for (size_t i = 0; i < dec->free_arenas.size(); i++) {
-    const ArenaBuf& a = dec->free_arenas[i];
-    if (a.bytes >= bytes && a.bytes <= 4 * bytes + ((size_t)8 << 20) && (best < 0 || a.bytes < dec->free_arenas[best].bytes)) best = (int)i;
-  }
+  // Only arenas that are KNOWN to be free (reap_arenas): an arena taken back while its last picture's kernels were still
+  // queued made the new picture's upload - and every upload and scan queued behind it on those streams - wait on the device
+  // for that picture's whole reconstruction (round 4: uploads of 0.14 ms completed 1-2 ms after they were issued, and a
+  // decoder's scans came in at 800 per second whatever was done to them).  The pool grows to what is in flight plus what cools.
+  auto pick = [&]() {
+    int best = -1;
+    for (size_t i = 0; i < dec->free_arenas.size(); i++) {
+      const ArenaBuf& a = dec->free_arenas[i];
+      if (a.bytes >= bytes && a.bytes <= 4 * bytes + ((size_t)8 << 20) && (best < 0 || a.bytes < dec->free_arenas[best].bytes)) best = (int)i;
+    }
+    return best;
+  };
+  int best = pick();
+  if (best < 0 && !dec->cooling.empty()) { reap_arenas(dec); best = pick(); }
   if (best >= 0) {
     *out = dec->free_arenas[best];
     dec->free_arenas.erase(dec->free_arenas.begin() + best);
@@ -480,18 +515,31 @@ void release_arena(de265hip_decoder* dec, ArenaBuf a, hipStream_t last_stream = 
 {
   if (!a.ptr) return;
   if (hipEventRecord(a.last_use, last_stream ? last_stream : dec->stream) != hipSuccess || dec->pooled_bytes + a.bytes > kPoolLimitBytes) { destroy_arena(a); return; }
-  a.used = true;
+  a.used = true; a.release_seq = ++dec->arena_releases;
   dec->pooled_bytes += a.bytes;
-  dec->free_arenas.push_back(a);
+  dec->cooling.push_back(a);
+  reap_arenas(dec);
 }
 
 int acquire_stage(de265hip_decoder* dec, size_t bytes, int* index)
 {
-  int best = -1;
-  for (size_t i = 0; i < dec->stage_pool.size(); i++) {
-    StageBuf& b = dec->stage_pool[i];
-    if (b.state == 2 && hipEventQuery(b.copied) == hipSuccess) b.state = 0;
-    if (b.state == 0 && b.bytes >= bytes && (best < 0 || b.bytes < dec->stage_pool[best].bytes)) best = (int)i;
+  // Called by the threads that run the host stage of a build (the pipeline's workers): in the steady state WITHOUT a HIP call -
+  // whoever learns that an upload has completed (de265hip_picture_run, when the picture's scan has reported) marks its buffer
+  // idle.  Only when no idle buffer is large enough are the buffers with an upload in flight asked through their events
+  // (round 4: every worker queried every buffer's event on every build, two dozen calls into the HIP runtime that queued up
+  //  behind its locks with the launcher's).
+  auto pick = [&]() {
+    int best = -1;
+    for (size_t i = 0; i < dec->stage_pool.size(); i++) {
+      StageBuf& b = dec->stage_pool[i];
+      if (b.state == 0 && b.bytes >= bytes && (best < 0 || b.bytes < dec->stage_pool[best].bytes)) best = (int)i;
+    }
+    return best;
+  };
+  int best = pick();
+  if (best < 0) {
+    for (auto& b : dec->stage_pool) if (b.state == 2 && hipEventQuery(b.copied) == hipSuccess) b.state = 0;
+    best = pick();
   }
   if (best < 0) {
     // recycle an idle buffer that is too small rather than growing without bound
@@ -508,7 +556,7 @@ int acquire_stage(de265hip_decoder* dec, size_t bytes, int* index)
     dec->stage_pool.push_back(b);
     best = (int)dec->stage_pool.size() - 1;
   }
-  dec->stage_pool[best].state = 1;
+  dec->stage_pool[best].state = 1; dec->stage_pool[best].owner = 0;
   *index = best;
   return 0;
 }
@@ -558,9 +606,10 @@ int de265hip_decoder_new(de265hip_decoder** out, int device)
   HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking), DE265HIP_ERROR_INIT_FAILED);
   HIPCHK(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking), DE265HIP_ERROR_INIT_FAILED);
   d->copy_streams[0] = d->copy_stream;
-  d->n_copy_streams = 3;
+  d->n_copy_streams = 2;
   if (const char* e = getenv("DE265HIP_COPY_STREAMS")) d->n_copy_streams = std::min((int)de265hip_decoder::kMaxCopyStreams, std::max(1, atoi(e)));
   for (int i = 1; i < d->n_copy_streams; i++) HIPCHK(hipStreamCreateWithFlags(&d->copy_streams[i], hipStreamNonBlocking), DE265HIP_ERROR_INIT_FAILED);
+  for (int i = 0; i < 2; i++) HIPCHK(hipStreamCreateWithFlags(&d->upload_streams[i], hipStreamNonBlocking), DE265HIP_ERROR_INIT_FAILED);
   HIPCHK(hipMalloc((void**)&d->d_err, 256), DE265HIP_ERROR_OUT_OF_MEMORY);
   HIPCHK(hipMemset(d->d_err, 0, 256), DE265HIP_ERROR_INIT_FAILED);
   HIPCHK(hipMalloc((void**)&d->d_err_ring, de265hip_decoder::kRing * 4), DE265HIP_ERROR_OUT_OF_MEMORY);
@@ -608,6 +657,16 @@ int de265hip_decoder_set_lanes(de265hip_decoder* d, int n_lanes)
 void de265hip_decoder_free(de265hip_decoder* d)
 {
   if (!d) return;
+  if (getenv("DE265HIP_PIPE_TIMING") && d->n_scan_wait)
+    fprintf(stderr, "de265hip decoder: %ld launches; ms per picture: waiting for the scan %.3f, run_picture (kernel launches) %.3f\n",
+            d->n_scan_wait, 1e3 * d->t_scan_wait / d->n_scan_wait, 1e3 * d->t_run / d->n_scan_wait);
+  if (getenv("DE265HIP_PIPE_TIMING") && d->n_sec) {
+    static const char* nm[8] = { "wait-arena-event", "event-pool", "memset", "memcpy-h2d", "stage-event", "motion+clear", "scan-launches", "uploaded-events" };
+    fprintf(stderr, "de265hip enqueue sections, us per picture (max of one call):");
+    for (int k = 0; k < 8; k++) fprintf(stderr, " %s %.1f (%.0f)", nm[k], 1e6 * d->t_sec[k] / d->n_sec, 1e6 * d->t_sec_max[k]);
+    fprintf(stderr, "\n");
+  }
+  for (int i = 0; i < 2; i++) if (d->upload_streams[i]) (void)hipStreamSynchronize(d->upload_streams[i]);
   for (int i = 0; i < d->n_copy_streams; i++) if (d->copy_streams[i]) (void)hipStreamSynchronize(d->copy_streams[i]);
   (void)sync_all_lanes(d);
   if (d->out_stream) { (void)hipStreamSynchronize(d->out_stream); (void)hipStreamDestroy(d->out_stream); }
@@ -623,8 +682,12 @@ void de265hip_decoder_free(de265hip_decoder* d)
     d->live.clear();
     for (auto& a : d->free_arenas) destroy_arena(a);
     d->free_arenas.clear();
+    for (auto& a : d->cooling) destroy_arena(a);
+    d->cooling.clear();
     for (auto& b : d->stage_pool) { if (b.ptr) (void)hipHostFree(b.ptr); if (b.copied) (void)hipEventDestroy(b.copied); }
     d->stage_pool.clear();
+    for (hipEvent_t e : d->free_events) (void)hipEventDestroy(e);
+    d->free_events.clear();
   }
   for (auto& e : d->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& s : d->slots) free_slot(s);
@@ -636,6 +699,7 @@ void de265hip_decoder_free(de265hip_decoder* d)
   if (d->h_ring) (void)hipHostFree(d->h_ring);
   if (d->d_used_units) (void)hipFree(d->d_used_units);
   for (int i = 0; i < d->n_copy_streams; i++) if (d->copy_streams[i]) (void)hipStreamDestroy(d->copy_streams[i]);
+  for (int i = 0; i < 2; i++) if (d->upload_streams[i]) (void)hipStreamDestroy(d->upload_streams[i]);
   (void)hipStreamDestroy(d->stream);
   delete d;
 }
@@ -845,8 +909,8 @@ void de265hip_picture_free(de265hip_picture* p)
     // upload waits for that event on the copy stream
     release_arena(dec, p->arena_buf, lane_st(dec, p->lane));     // (its launches on other lanes precede the latest one: they wrote the same slot)
     if (p->ring_idx >= 0) dec->ring_free.push_back(p->ring_idx);   // (first in, first out: its error word stands for thousands of pictures to come)
-    if (p->enq.pending) for (auto& b : dec->stage_pool) if (b.ptr == p->enq.host_base) b.state = 0;      // (built, never enqueued)
-    if (p->uploaded) (void)hipEventDestroy(p->uploaded);
+    if (p->enq.pending && !p->enq.uploaded_by_builder) for (auto& b : dec->stage_pool) if (b.ptr == p->enq.host_base && b.owner == p->ring_seq) b.state = 0;      // (built, never enqueued)
+    if (p->uploaded) { if (dec->free_events.size() < 256) dec->free_events.push_back(p->uploaded); else (void)hipEventDestroy(p->uploaded); }
   }
   delete p;
 }
@@ -2085,7 +2149,8 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
     }
     if (!rc) {
       if (dec->ring_free.empty()) { rc = DE265HIP_ERROR_OUT_OF_MEMORY; dec->stage_pool[stage_idx].state = 0; release_arena(dec, pic->arena_buf); }
-      else { pic->ring_idx = dec->ring_free.front(); dec->ring_free.pop_front(); pic->ring_seq = ++dec->ring_seq; dec->ring_owner[pic->ring_idx] = pic->ring_seq; }
+      else { pic->ring_idx = dec->ring_free.front(); dec->ring_free.pop_front(); pic->ring_seq = ++dec->ring_seq; dec->ring_owner[pic->ring_idx] = pic->ring_seq;
+             dec->stage_pool[stage_idx].owner = pic->ring_seq; }
     }
   }
   if (rc) { delete pic; return rc; }
@@ -2219,6 +2284,19 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
     dec->live.push_back(pic);
   }
   pt.mark("host");
+  if (!dec->dry && g_defer_enqueue) {
+    // (a pipeline's build: the upload goes out from this thread, on an upload stream; the launcher's copy stream waits for it)
+    de265hip_picture::Enq& E = pic->enq;
+    hipStream_t us;
+    { std::lock_guard<std::mutex> lk(dec->mu); us = dec->upload_streams[dec->upload_turn++ & 1]; }
+    bool ok = !pic->arena_buf.used || hipStreamWaitEvent(us, pic->arena_buf.last_use, 0) == hipSuccess;
+    ok = ok && hipMemcpyAsync(pic->arena, E.host_base, E.upload_bytes, hipMemcpyHostToDevice, us) == hipSuccess;
+    ok = ok && hipEventRecord(E.stage_event, us) == hipSuccess;
+    if (!ok) { de265hip_picture_free(pic); return DE265HIP_ERROR_DECODING; }
+    E.uploaded_by_builder = true;
+    std::lock_guard<std::mutex> lk(dec->mu);
+    for (auto& b : dec->stage_pool) if (b.ptr == E.host_base && b.owner == pic->ring_seq) b.state = 2;
+  }
   if (!dec->dry && !g_defer_enqueue) {
     const int erc = de265hip_picture_enqueue(pic);
     if (erc) { de265hip_picture_free(pic); return erc; }
@@ -2234,53 +2312,98 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
 // de265hip_picture_build_host leaves it to the caller, who may be another thread: the pipeline issues ALL HIP calls of a
 // decoder from one thread (fifteen workers calling into the HIP runtime for the same device spent three quarters of their
 // builds waiting for its locks: builds of 1.7 ms took 6.5 ms, round 4).
-int de265hip_picture_enqueue(de265hip_picture* pic)
+int de265hip_picture_enqueue(de265hip_picture* pic) { return de265hip_picture_enqueue_batch(&pic, 1); }
+
+// The same for several pictures of ONE decoder at once (at most SCAN_BATCH are scanned per set of launches; more are taken in
+// turns): their uploads go out one after the other on one copy stream, the passes of their scans run as one batch behind them.
+int de265hip_picture_enqueue_batch(de265hip_picture** pics, int n)
 {
-  if (!pic || !pic->dec) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
-  de265hip_picture::Enq& E = pic->enq;
-  if (!E.pending) return DE265HIP_OK;
-  de265hip_decoder* dec = pic->dec;
-  hipStream_t cs;
-  { std::lock_guard<std::mutex> lk(dec->mu); cs = dec->copy_streams[dec->copy_turn++ % (uint64_t)dec->n_copy_streams]; }
-  uint8_t* base = (uint8_t*)pic->arena;
-  // a recycled arena may still be read by kernels of the picture that had it before
-  if (pic->arena_buf.used) HIPCHK(hipStreamWaitEvent(cs, pic->arena_buf.last_use, 0), DE265HIP_ERROR_DECODING);
-  HIPCHK(hipEventCreateWithFlags(&pic->uploaded, hipEventDisableTiming), DE265HIP_ERROR_OUT_OF_MEMORY);
-  // k_run's ticket counter, run flags and mailbox packets start from zero: a pooled arena held another picture's buffers at
-  // these offsets before, and ANY bit pattern there could pass for a raised flag of some launch generation (round 4 tried to
-  // do without this clear, the generations being unique per decoder: a mid-size picture in a recycled arena came out wrong).
-  // With the device-side scan its own cleared buffers follow the mailboxes: one memset for both.
-  const size_t clear_to = pic->dev_scan ? pic->SL.clear_end : E.o_sync + E.clear_bytes;
-  HIPCHK(hipMemsetAsync(base + E.o_sync, 0, clear_to - E.o_sync, cs), DE265HIP_ERROR_DECODING);
-  HIPCHK(hipMemcpyAsync(base, E.host_base, E.upload_bytes, hipMemcpyHostToDevice, cs), DE265HIP_ERROR_DECODING);
-  HIPCHK(hipEventRecord(E.stage_event, cs), DE265HIP_ERROR_DECODING);
-  {
-    std::lock_guard<std::mutex> lk(dec->mu);
-    for (auto& b : dec->stage_pool) if (b.ptr == E.host_base) b.state = 2;      // reusable once `copied` has completed
+  if (!pics || n < 1) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  for (int i = 0; i < n; i++) if (!pics[i] || !pics[i]->dec || pics[i]->dec != pics[0]->dec) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  de265hip_decoder* dec = pics[0]->dec;
+  for (int i0 = 0; i0 < n; i0 += SCAN_BATCH) {
+    const int m = std::min(SCAN_BATCH, n - i0);
+    hipStream_t cs;
+    { std::lock_guard<std::mutex> lk(dec->mu); cs = dec->copy_streams[dec->copy_turn++ % (uint64_t)dec->n_copy_streams]; reap_arenas(dec); }
+    ScanBatch J; J.n = 0; J.pad = 0;
+    de265hip_picture* done[SCAN_BATCH]; int n_done = 0;
+    auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tl = tnow();
+    auto sec = [&](int k) { const double t = tnow(); dec->t_sec[k] += t - tl; if (t - tl > dec->t_sec_max[k]) dec->t_sec_max[k] = t - tl; tl = t; };
+    for (int i = i0; i < i0 + m; i++) {
+      de265hip_picture* pic = pics[i];
+      de265hip_picture::Enq& E = pic->enq;
+      if (!E.pending) continue;
+      uint8_t* base = (uint8_t*)pic->arena;
+      // a recycled arena may still be read by kernels of the picture that had it before
+      tl = tnow();
+      if (pic->arena_buf.used) HIPCHK(hipStreamWaitEvent(cs, pic->arena_buf.last_use, 0), DE265HIP_ERROR_DECODING);
+      sec(0);
+      {
+        std::lock_guard<std::mutex> lk(dec->mu);
+        if (!dec->free_events.empty()) { pic->uploaded = dec->free_events.back(); dec->free_events.pop_back(); }
+      }
+      if (!pic->uploaded) HIPCHK(hipEventCreateWithFlags(&pic->uploaded, hipEventDisableTiming), DE265HIP_ERROR_OUT_OF_MEMORY);
+      // k_run's ticket counter, run flags and mailbox packets start from zero: a pooled arena held another picture's buffers
+      // at these offsets before, and ANY bit pattern there could pass for a raised flag of some launch generation (round 4
+      // tried to do without this clear, the generations being unique per decoder: a mid-size picture in a recycled arena came
+      // out wrong).  With the device-side scan its own cleared buffers follow the mailboxes: one memset for both.
+      const size_t clear_to = pic->dev_scan ? pic->SL.clear_end : E.o_sync + E.clear_bytes;
+      sec(1);
+      HIPCHK(hipMemsetAsync(base + E.o_sync, 0, clear_to - E.o_sync, cs), DE265HIP_ERROR_DECODING);
+      sec(2);
+      if (E.uploaded_by_builder) HIPCHK(hipStreamWaitEvent(cs, E.stage_event, 0), DE265HIP_ERROR_DECODING);      // (the builder's thread sent it)
+      else {
+        HIPCHK(hipMemcpyAsync(base, E.host_base, E.upload_bytes, hipMemcpyHostToDevice, cs), DE265HIP_ERROR_DECODING);
+        sec(3);
+        HIPCHK(hipEventRecord(E.stage_event, cs), DE265HIP_ERROR_DECODING);
+        std::lock_guard<std::mutex> lk(dec->mu);
+        for (auto& b : dec->stage_pool) if (b.ptr == E.host_base && b.owner == pic->ring_seq) b.state = 2;      // reusable once `copied` has completed
+      }
+      E.pending = false;
+      sec(4);
+      if (!E.mot_given) {
+        HIPCHK(hipMemsetAsync(base + E.o_mot, 0xFF, E.nblk * sizeof(de265hip_motion), cs), DE265HIP_ERROR_DECODING);
+        if (E.n_pus > 0)
+          hipLaunchKernelGGL(k_motion_from_pus, dim3((E.n_pus + 15) / 16), dim3(256), 0, cs, pic->P, (const de265hip_pu*)(base + E.o_pus), E.n_pus,
+                             (const de265hip_slice_params*)(base + E.o_sl), E.n_slices, (de265hip_motion*)(base + E.o_mot));
+      }
+      if (pic->dev_scan) {
+        // the last pass of the scan writes the counts into the picture's pinned ring entry and raises its ready word (system-
+        // scope stores: no copy, no event for the host to wait on - de265hip_picture_run polls the word)
+        ScanCounts* hc = dec->h_ring + pic->ring_idx;
+        __atomic_store_n(&hc->ready, 0u, __ATOMIC_RELEASE);
+        pic->SB.host_counts = hc; pic->SB.err_word = dec->d_err_ring + pic->ring_idx; pic->SB.ready_tag = (uint32_t)pic->ring_seq | 0x80000000u;
+        ScanJob& jb = J.job[J.n++];
+        jb.P = pic->SP; jb.B = pic->SB; jb.cap_resid = pic->cap_resid; jb.cap_levels = pic->SL.cap_levels;
+        pic->scan_pending = true;
+      } else {
+        HIPCHK(hipMemsetAsync(dec->d_err_ring + pic->ring_idx, 0, 4, cs), DE265HIP_ERROR_DECODING);
+        if (E.check_on_device && E.n_l0chk + E.n_l0xchk > 0)
+          hipLaunchKernelGGL(k_check_coeffs, dim3((E.n_l0chk + E.n_l0xchk + 15) / 16), dim3(256), 0, cs, (const TuTask*)(base + E.o_l0), E.n_l0chk,
+                             (const TuTask*)(base + E.o_l0x), E.n_l0xchk, (uint16_t*)(base + E.o_cpos), dec->d_err_ring + pic->ring_idx);
+      }
+      done[n_done++] = pic;
+      sec(5);
+    }
+    tl = tnow();
+    if (J.n) HIPCHK(scan_enqueue_batch(cs, J), DE265HIP_ERROR_DECODING);
+    sec(6);
+    for (int i = 0; i < n_done; i++) HIPCHK(hipEventRecord(done[i]->uploaded, cs), DE265HIP_ERROR_DECODING);
+    sec(7); dec->n_sec += n_done;
   }
-  E.pending = false;
-  if (!E.mot_given) {
-    HIPCHK(hipMemsetAsync(base + E.o_mot, 0xFF, E.nblk * sizeof(de265hip_motion), cs), DE265HIP_ERROR_DECODING);
-    if (E.n_pus > 0)
-      hipLaunchKernelGGL(k_motion_from_pus, dim3(E.n_pus), dim3(64), 0, cs, pic->P, (const de265hip_pu*)(base + E.o_pus), E.n_pus,
-                         (const de265hip_slice_params*)(base + E.o_sl), E.n_slices, (de265hip_motion*)(base + E.o_mot));
-  }
-  if (pic->dev_scan) {
-    // the passes of the scan; the last of them writes the counts into the picture's pinned ring entry and raises its ready word
-    // (system-scope stores: no copy, no event for the host to wait on - de265hip_picture_run polls the word)
-    ScanCounts* hc = dec->h_ring + pic->ring_idx;
-    __atomic_store_n(&hc->ready, 0u, __ATOMIC_RELEASE);
-    pic->SB.host_counts = hc; pic->SB.err_word = dec->d_err_ring + pic->ring_idx; pic->SB.ready_tag = (uint32_t)pic->ring_seq | 0x80000000u;
-    HIPCHK(scan_enqueue(cs, pic->SP, pic->SB, pic->SL, base, pic->cap_resid), DE265HIP_ERROR_DECODING);
-    pic->scan_pending = true;
-  } else {
-    HIPCHK(hipMemsetAsync(dec->d_err_ring + pic->ring_idx, 0, 4, cs), DE265HIP_ERROR_DECODING);
-    if (E.check_on_device && E.n_l0chk + E.n_l0xchk > 0)
-      hipLaunchKernelGGL(k_check_coeffs, dim3((E.n_l0chk + E.n_l0xchk + 15) / 16), dim3(256), 0, cs, (const TuTask*)(base + E.o_l0), E.n_l0chk,
-                         (const TuTask*)(base + E.o_l0x), E.n_l0xchk, (uint16_t*)(base + E.o_cpos), dec->d_err_ring + pic->ring_idx);
-  }
-  HIPCHK(hipEventRecord(pic->uploaded, cs), DE265HIP_ERROR_DECODING);
   return DE265HIP_OK;
+}
+
+// Has the device side of the picture's build reported (the scan of its records: de265hip_picture_run would not wait)?  1 yes,
+// 0 not yet, < 0 never will (not enqueued).  For a launcher that has other work to do meanwhile.
+int de265hip_picture_ready(de265hip_picture* pic)
+{
+  if (!pic || !pic->dec) return -1;
+  if (pic->enq.pending) return -1;
+  if (!pic->scan_pending || pic->dec->dry) return 1;
+  const ScanCounts* K = pic->dec->h_ring + pic->ring_idx;
+  return __atomic_load_n(&K->ready, __ATOMIC_ACQUIRE) == ((uint32_t)pic->ring_seq | 0x80000000u) ? 1 : 0;
 }
 
 // de265hip_picture_build without its device side (see de265hip_picture_enqueue)
@@ -2336,12 +2459,20 @@ static int finish_scan(de265hip_picture* pic)
     // the last pass stores the counts into this pinned record and then its ready word (system scope): normally long since there
     const uint32_t tag = (uint32_t)pic->ring_seq | 0x80000000u;
     const auto t0 = std::chrono::steady_clock::now();
+    struct Acc { de265hip_decoder* d; std::chrono::steady_clock::time_point t; ~Acc() { d->t_scan_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); d->n_scan_wait++; } } acc{ dec, t0 };
     for (uint32_t spins = 0; __atomic_load_n(&K->ready, __ATOMIC_ACQUIRE) != tag; spins++) {
       if ((spins & 255) == 255) {
         if (hipEventQuery(pic->uploaded) == hipSuccess && __atomic_load_n(&K->ready, __ATOMIC_ACQUIRE) != tag) return pic->scan_rc = DE265HIP_ERROR_DECODING;   // (passes done, no word: a fault)
         if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) return pic->scan_rc = DE265HIP_ERROR_DECODING;
       }
       __builtin_ia32_pause();
+    }
+    // (the scan ran behind the upload on the same stream: the staging buffer is free)
+    if (pic->enq.host_base) {
+      std::lock_guard<std::mutex> lk(dec->mu);
+      // (only while the buffer is still this picture's: the event path of acquire_stage may have handed it to another one since)
+      for (auto& b : dec->stage_pool) if (b.ptr == pic->enq.host_base && b.state == 2 && b.owner == pic->ring_seq) b.state = 0;
+      pic->enq.host_base = nullptr;
     }
   }
   pic->scan_pending = false;
@@ -2697,8 +2828,10 @@ int de265hip_picture_run(de265hip_decoder* dec, de265hip_picture* pic, int last_
   // behind the passes - long since complete when the builds run ahead of the launches (the pipeline); outside the decoder's lock
   if (pic->enq.pending) { const int erc = de265hip_picture_enqueue(pic); if (erc) return erc; }
   if (const int rc = finish_scan(pic)) return rc;
-  if (pic->P.bd_luma > 8) return run_picture<uint16_t>(dec, pic, last_stage);
-  return run_picture<uint8_t>(dec, pic, last_stage);
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rrc = pic->P.bd_luma > 8 ? run_picture<uint16_t>(dec, pic, last_stage) : run_picture<uint8_t>(dec, pic, last_stage);
+  dec->t_run += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return rrc;
 }
 
 int de265hip_decoder_sync(de265hip_decoder* dec)

@@ -55,11 +55,13 @@ __device__ __forceinline__ int bs_motion(const de265hip_motion& mP, const de265h
 // motion vectors and reference pictures as DPB slots): a host that does not flatten its motion into de265hip_picture_desc::
 // blk_motion (NULL) leaves it to this kernel - 0.5 MB of PU records cross PCIe instead of a 6.2 MB plane per 4K picture, and
 // the read-out on the host goes away.  One wavefront per PU; the plane was set to "no reference" (0xFF) before.
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(256)
 void k_motion_from_pus(PicDev P, const de265hip_pu* __restrict__ pus, int n_pus, const de265hip_slice_params* __restrict__ slices,
                        int n_slices, de265hip_motion* __restrict__ motion)
 {
-  const int i = blockIdx.x;
+  // sixteen lanes per PU, sixteen PUs per workgroup (a workgroup per PU was 33 000 one-wavefront workgroups per 4K picture: the
+  // dispatcher's time, not the kernel's)
+  const int i = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
   if (i >= n_pus) return;
   const de265hip_pu pu = pus[i];
   if (pu.slice_idx >= n_slices) return;
@@ -72,7 +74,7 @@ void k_motion_from_pus(PicDev P, const de265hip_pu* __restrict__ pus, int n_pus,
   }
   m.pad[0] = m.pad[1] = 0;
   const int bw = pu.w >> 2, bh = pu.h >> 2;
-  for (int q = threadIdx.x; q < bw * bh; q += 64) {
+  for (int q = sub; q < bw * bh; q += 16) {
     const int x = (pu.x >> 2) + q % bw, y = (pu.y >> 2) + q / bw;
     if (x < P.w4 && y < P.h4) motion[x + y * P.w4] = m;
   }

@@ -10,8 +10,10 @@ namespace d265 {
 
 // ------------------------------------------------------------------------------------------------ device kernels
 __global__ __launch_bounds__(256)
-void k_scan_tus(ScanParams P, ScanBufs B)
+void k_scan_tus(ScanBatch J)
 {
+  if (blockIdx.y >= (unsigned)J.n) return;
+  const ScanParams& P = J.job[blockIdx.y].P; const ScanBufs& B = J.job[blockIdx.y].B;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i == 0 && B.err_word) *B.err_word = 0;                  // (the picture's kernels that may raise it come behind the scan)
   ScanTuSums S = { 0, 0, 0, 0, 0 };
@@ -56,8 +58,11 @@ void k_scan_tus(ScanParams P, ScanBufs B)
 // exclusive prefix over the CTBs in tile-scan (decode) order of the seven per-CTB counts, by one workgroup: every thread sums
 // a contiguous chunk of CTBs, the workgroup scans the 1024 chunk sums in LDS, every thread writes its chunk's bases
 __global__ __launch_bounds__(1024)
-void k_scan_prefix(ScanParams P, ScanBufs B, uint32_t cap_resid)
+void k_scan_prefix(ScanBatch J)
 {
+  if (blockIdx.y >= (unsigned)J.n) return;
+  const ScanParams& P = J.job[blockIdx.y].P; const ScanBufs& B = J.job[blockIdx.y].B;
+  const uint32_t cap_resid = J.job[blockIdx.y].cap_resid;
   __shared__ uint32_t sums[7][1024];
   __shared__ uint32_t tot[7];
   const int tid = threadIdx.x, n = P.n_ctbs, chunk = (n + 1023) / 1024;
@@ -134,12 +139,14 @@ __device__ __forceinline__ uint64_t lanes_below(int lane) { return lane ? (~0ull
 #define SCW_H 17                         // window rows:    cell y in [-1, 15]
 #define SCW_NONLOCAL 0x40000000u         // an intra TU of another CTB covers the cell
 __global__ __launch_bounds__(64)
-void k_scan_ctbs(ScanParams P, ScanBufs B)
+void k_scan_ctbs(ScanBatch J)
 {
+  if (blockIdx.y >= (unsigned)J.n) return;
+  const ScanParams& P = J.job[blockIdx.y].P; const ScanBufs& B = J.job[blockIdx.y].B;
   __shared__ uint32_t win[3][SCW_W * SCW_H];
   __shared__ uint8_t s_ntus[768];
   const int rs = blockIdx.x, lane = threadIdx.x;
-  if (B.counts->status) return;
+  if (rs >= P.n_ctbs || B.counts->status) return;
   ScanCtb& C = B.ctb[rs];
   const uint32_t first = C.first_tu, end = C.end_tu, seen = C.seen, n_intra = C.n_intra, ibase = C.intra_base;
   if (seen == 0) { if (lane == 0) C.n_runs = 0; return; }
@@ -269,10 +276,12 @@ void k_scan_ctbs(ScanParams P, ScanBufs B)
 // ONCE into LDS (a lane each), every later step works on LDS, and the producers are resolved in two batched round trips
 // (all needed cells, then the run ids behind them) into a hash set in LDS.
 #define SCR_MAX 256
-#define SCR_CAND (64 * 33)
+#define SCR_CAND (16 * 33)
 __global__ __launch_bounds__(64)
-void k_scan_runs1(ScanParams P, ScanBufs B)
+void k_scan_runs1(ScanBatch J)
 {
+  if (blockIdx.y >= (unsigned)J.n) return;
+  const ScanParams& P = J.job[blockIdx.y].P; const ScanBufs& B = J.job[blockIdx.y].B;
   __shared__ int tix[SCR_MAX];
   __shared__ uint4 s_rec[SCR_MAX];                     // the TU records (de265hip_tu, 16 bytes)
   __shared__ uint64_t s_need[SCR_MAX], s_av[SCR_MAX];
@@ -493,11 +502,11 @@ void k_scan_runs1(ScanParams P, ScanBufs B)
     {
       const int mw = P.map_w[c];
       const ScanCell* cells = B.cell[c];
-      for (int kb = 0; kb < n; kb += 64) {
+      for (int kb = 0; kb < n; kb += 16) {
         if (lane == 0) s_ncand = 0;
         WAVE_ORDER();
         const int k = kb + lane;
-        if (k < n) {
+        if (lane < 16 && k < n) {
           const de265hip_tu tu = rec_of(k);
           for (uint64_t need = s_need[k]; need; need &= need - 1)
             s_cand[atomicAdd(&s_ncand, 1u)] = (uint32_t)scan_cell_of(__builtin_ctzll(need), tu.x0, tu.y0, 1 << tu.log2_size, mw);
@@ -567,8 +576,10 @@ void k_scan_runs1(ScanParams P, ScanBufs B)
 // logic is a few thousand scalar steps on ~40 records: not worth spreading over lanes, but on records in LDS it takes ~15 us
 // instead of the ~500 us a thread took that fetched them one by one from memory next to 63 others doing the same.
 __global__ __launch_bounds__(64)
-void k_scan_runs2(ScanParams P, ScanBufs B)
+void k_scan_runs2(ScanBatch J)
 {
+  if (blockIdx.y >= (unsigned)J.n) return;
+  const ScanParams& P = J.job[blockIdx.y].P; const ScanBufs& B = J.job[blockIdx.y].B;
   __shared__ TuTask s_tus[SCR_MAX];
   const int lane = threadIdx.x;
   if (B.counts->status) return;
@@ -599,8 +610,11 @@ void k_scan_runs2(ScanParams P, ScanBufs B)
 #define SCO_THREADS 1024
 __device__ void scan_order_body(const ScanParams& P, const ScanBufs& B, uint32_t cap_levels);
 __global__ __launch_bounds__(SCO_THREADS)
-void k_scan_order(ScanParams P, ScanBufs B, uint32_t cap_levels)
+void k_scan_order(ScanBatch J)
 {
+  if (blockIdx.y >= (unsigned)J.n) return;
+  const ScanParams& P = J.job[blockIdx.y].P; const ScanBufs& B = J.job[blockIdx.y].B;
+  const uint32_t cap_levels = J.job[blockIdx.y].cap_levels;
   // the third run pass first (a thread per listed run, scan_core.h scan_run3: the runs somebody reads through their mailbox)
   if (!B.counts->status && (P.flags & SCANF_MAILBOX)) {
     const uint32_t n = B.counts->n_listed;
@@ -631,7 +645,6 @@ __device__ void scan_order_body(const ScanParams& P, const ScanBufs& B, uint32_t
   const uint32_t victim = K.victim;
   const int n_diag = P.ctbs_w + 2 * P.ctbs_h;
   uint32_t* diag = n_diag <= 4096 ? s_diag : B.lvl_cnt;          // ticketed runs per anti-diagonal (for the worker count)
-  if ((uint32_t)n_diag > 5 * cap_levels) { if (tid == 0) scan_fail(B, DE265HIP_ERROR_NOT_IMPLEMENTED); return; }
   for (int q = tid; q < n_diag; q += SCO_THREADS) diag[q] = 0;
   if (tid == 0) { s_widest = 0; s_ready = 0; s_ndiag = 0; }
   __syncthreads();
@@ -721,7 +734,7 @@ size_t ScanLayout::plan(const ScanParams& P, size_t at)
   o_run_rs = add(nr * 4); o_run_nall = add(nr * 4); o_run_level = add(nr * 4); o_run_list = add(nr * 4); o_pub_flag = add(nr);
   o_rdy_tab = add((size_t)P.cap_mb * 64);
   cap_levels = (uint32_t)nr + 2;
-  o_lvl_cnt = add((size_t)cap_levels * 5 * 4);
+  o_lvl_cnt = add(std::max((size_t)cap_levels * 5, (size_t)(P.ctbs_w + 2 * P.ctbs_h)) * 4);      // (scan_order: a counter per CTB anti-diagonal)
   o_l0 = add(nt * sizeof(TuTask)); o_l0x = add(nt * sizeof(TuTask));
   o_runs = add(nr * sizeof(RunTask)); o_run_tus = add(nt * sizeof(TuTask));
   o_deps = add((size_t)P.cap_deps * 4); o_slots = add((size_t)P.cap_slots * 4); o_front = add(nr * 4);
@@ -745,19 +758,34 @@ void ScanLayout::bind(uint8_t* base, ScanBufs& B) const
 }
 
 // ------------------------------------------------------------------------------------------------ enqueue
+// The passes for a BATCH of pictures in one set of launches (grid.y = picture): the scan is a chain of six dependent kernels,
+// each a latency chain that leaves most of the device idle, two of them single workgroups; launched per picture, a decoder's
+// scans and the reconstruction kernels of the other streams kept queueing behind each other (round 4: 2 100 pictures/s whatever
+// the number of copy streams).  A batch pays the chain once.
+hipError_t scan_enqueue_batch(hipStream_t st, const ScanBatch& J)
+{
+  int max_tus = 0, max_ctbs = 0;
+  for (int i = 0; i < J.n; i++) { max_tus = std::max(max_tus, J.job[i].P.n_tus); max_ctbs = std::max(max_ctbs, J.job[i].P.n_ctbs); }
+  const unsigned ny = (unsigned)J.n;
+  if (max_tus > 0) hipLaunchKernelGGL(k_scan_tus, dim3((max_tus + 255) / 256, ny), dim3(256), 0, st, J);
+  hipLaunchKernelGGL(k_scan_prefix, dim3(1, ny), dim3(1024), 0, st, J);
+  if (max_tus > 0) {
+    hipLaunchKernelGGL(k_scan_ctbs, dim3(max_ctbs, ny), dim3(64), 0, st, J);
+    // (the number of runs is only known on the device: fixed grids of wavefronts walk the run lists)
+    static const int run_grid = getenv("DE265HIP_SCAN_RUN_GRID") ? atoi(getenv("DE265HIP_SCAN_RUN_GRID")) : 1024;
+    hipLaunchKernelGGL(k_scan_runs1, dim3(run_grid, ny), dim3(64), 0, st, J);
+    hipLaunchKernelGGL(k_scan_runs2, dim3(run_grid, ny), dim3(64), 0, st, J);
+  }
+  hipLaunchKernelGGL(k_scan_order, dim3(1, ny), dim3(SCO_THREADS), 0, st, J);      // (always: it reports to the host)
+  return hipGetLastError();
+}
+
 hipError_t scan_enqueue(hipStream_t st, const ScanParams& P, const ScanBufs& B, const ScanLayout& L, uint8_t* base, uint32_t cap_resid)
 {
-  (void)base;                                                   // (the caller has cleared [clear_begin, clear_end) with the run flags)
-  if (P.n_tus > 0) hipLaunchKernelGGL(k_scan_tus, dim3((P.n_tus + 255) / 256), dim3(256), 0, st, P, B);
-  hipLaunchKernelGGL(k_scan_prefix, dim3(1), dim3(1024), 0, st, P, B, cap_resid);
-  if (P.n_tus > 0) {
-    hipLaunchKernelGGL(k_scan_ctbs, dim3(P.n_ctbs), dim3(64), 0, st, P, B);
-    // (the number of runs is only known on the device: fixed grids of wavefronts walk the run list)
-    hipLaunchKernelGGL(k_scan_runs1, dim3(4096), dim3(64), 0, st, P, B);
-    hipLaunchKernelGGL(k_scan_runs2, dim3(4096), dim3(64), 0, st, P, B);
-  }
-  hipLaunchKernelGGL(k_scan_order, dim3(1), dim3(SCO_THREADS), 0, st, P, B, L.cap_levels);      // (always: it reports to the host)
-  return hipGetLastError();
+  (void)base;
+  ScanBatch J; J.n = 1;
+  J.job[0].P = P; J.job[0].B = B; J.job[0].cap_resid = cap_resid; J.job[0].cap_levels = L.cap_levels;
+  return scan_enqueue_batch(st, J);
 }
 
 // ------------------------------------------------------------------------------------------------ the CPU rehearsal

@@ -8,6 +8,7 @@
 // DPB slots its references were launched into).  Host-only code: no kernel lives here.
 #include "../../include/de265_hip.h"
 
+#include <array>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -29,6 +30,7 @@ struct PipeJob {
   const de265hip_picture_desc* desc = nullptr;  // de265hip_pipeline_submit_desc: a ready-made description instead of prepare()
   void* plane[3] = { nullptr, nullptr, nullptr };
   ptrdiff_t stride[3] = { 0, 0, 0 };
+  double t_sub = 0;
 };
 
 }  // namespace
@@ -44,14 +46,16 @@ struct de265hip_pipeline {
   std::deque<PipeJob> q;                        // submitted, not yet taken by a worker
   std::map<uint64_t, int> slot_of;              // launched, copy-out possibly still in flight: ticket -> slot
   std::map<uint64_t, int> failed;               // ticket -> error of prepare / build / run
-  struct Built { PipeJob job; de265hip_picture* pic; int rc; bool enqueued; };
+  struct Built { PipeJob job; de265hip_picture* pic; int rc; bool enqueued; double t_sub, t_b0, t_b1, t_enq, t_ready; };
+  std::vector<std::array<double, 8>> trace;     // DE265HIP_PIPE_TRACE: per picture: ticket, submitted, build start / end, enqueued, launch start / end
   std::map<uint64_t, Built> ready;              // built (or failed), waiting for their turn to be launched
   uint64_t next_ticket = 0, next_launch = 0;    // tickets are handed out and launched in submission order
   int in_flight = 0;                            // queued or being built, not yet launched
   int window = 4;                               // bound of in_flight (submit blocks)
+  int batch = 2;                                // pictures enqueued together (their scans share their launches)
   bool stop = false;
   // DE265HIP_PIPE_TIMING=1: where the threads' time goes (seconds, summed; printed when the pipeline is freed)
-  bool timing = false;
+  bool timing = false, tracing = false;
   double t_idle = 0, t_build = 0, t_enqueue = 0, t_launch = 0, t_lidle = 0; long n_jobs = 0;
 };
 
@@ -86,7 +90,7 @@ void worker(de265hip_pipeline* p)
     const double t2 = now();
     {
       std::lock_guard<std::mutex> lk(p->mu);
-      p->ready[j.ticket] = de265hip_pipeline::Built{ j, pic, rc, false };
+      p->ready[j.ticket] = de265hip_pipeline::Built{ j, pic, rc, false, j.t_sub, t1, t2, 0, 0 };
       if (p->timing) { p->t_idle += t1 - t0; p->t_build += t2 - t1; p->n_jobs++; }
     }
     p->cv_launch.notify_one();
@@ -100,26 +104,48 @@ void worker(de265hip_pipeline* p)
 // any order, and LAUNCHED in submission order (also when a picture failed: the turn must pass on).
 void launcher(de265hip_pipeline* p)
 {
+  int held = 0;                                  // rounds a partial batch has been held back
   for (;;) {
-    de265hip_pipeline::Built todo; bool have_enq = false, have_launch = false; uint64_t enq_ticket = 0;
+    de265hip_pipeline::Built todo; bool have_enq = false, have_launch = false;
+    de265hip_picture* enq_pic[8]; uint64_t enq_tk[8]; int n_enq = 0;
     const double t0 = now();
     {
       std::unique_lock<std::mutex> lk(p->mu);
       for (;;) {
+        if (p->tracing) for (auto& kv : p->ready) if (kv.second.enqueued && kv.second.pic && kv.second.t_ready == 0 && de265hip_picture_ready(kv.second.pic) == 1) kv.second.t_ready = now();
+        // uploads and scans first: they run ahead of the launches on the copy streams (a picture launched right behind its
+        // enqueue makes the launcher wait for its scan, ~0.5 ms of device latency)
+        // (as many as a batch of the scan takes, DE265HIP_PIPE_BATCH, default 2: their passes share their kernel launches; a batch
+        //  is only held back for more pictures while the picture whose turn it is has been enqueued)
+        n_enq = 0;
+        for (auto& kv : p->ready) if (!kv.second.enqueued && !kv.second.rc && kv.second.pic && n_enq < p->batch) { enq_pic[n_enq] = kv.second.pic; enq_tk[n_enq++] = kv.first; }
+        if (n_enq) {
+          auto nx = p->ready.find(p->next_launch);
+          const bool next_waits_for_us = nx == p->ready.end() || !nx->second.enqueued;
+          if (n_enq >= p->batch || next_waits_for_us || p->in_flight <= n_enq || held > 3) { have_enq = true; held = 0; break; }
+          held++;
+        }
         auto it = p->ready.find(p->next_launch);
-        if (it != p->ready.end() && (it->second.enqueued || it->second.rc || !it->second.pic)) { todo = it->second; p->ready.erase(it); have_launch = true; break; }
-        for (auto& kv : p->ready) if (!kv.second.enqueued && !kv.second.rc && kv.second.pic) { todo = kv.second; enq_ticket = kv.first; have_enq = true; break; }
-        if (have_enq) break;
+        if (it != p->ready.end()) {
+          // its turn - if its scan has reported (or it failed: the turn passes on).  The launcher never blocks on a scan while
+          // pictures may arrive that want enqueueing: a launcher that waited 0.9 ms for picture n's scan enqueued picture n + 1
+          // only then, and no two scans ever overlapped (round 4: 1 000 pictures/s per decoder whatever the copy streams)
+          if (it->second.rc || !it->second.pic || de265hip_picture_ready(it->second.pic) != 0) { todo = it->second; p->ready.erase(it); have_launch = true; break; }
+          p->cv_launch.wait_for(lk, std::chrono::microseconds(20));
+          continue;
+        }
         if (p->stop) return;
         p->cv_launch.wait(lk);
       }
     }
     const double t1 = now();
     if (have_enq) {
-      const int rc = de265hip_picture_enqueue(todo.pic);
+      const int rc = de265hip_picture_enqueue_batch(enq_pic, n_enq);
       std::lock_guard<std::mutex> lk(p->mu);
-      auto it = p->ready.find(enq_ticket);
-      if (it != p->ready.end()) { it->second.enqueued = true; if (rc) it->second.rc = rc; }
+      for (int i = 0; i < n_enq; i++) {
+        auto it = p->ready.find(enq_tk[i]);
+        if (it != p->ready.end()) { it->second.enqueued = true; it->second.t_enq = now(); if (rc) it->second.rc = rc; }
+      }
       if (p->timing) { p->t_lidle += t1 - t0; p->t_enqueue += now() - t1; }
       continue;
     }
@@ -134,6 +160,7 @@ void launcher(de265hip_pipeline* p)
         if (r) p->failed[todo.job.ticket] = r; else p->slot_of[todo.job.ticket] = todo.job.slot;
         p->next_launch++; p->in_flight--;
         if (p->timing) { p->t_lidle += t1 - t0; p->t_launch += now() - t1; }
+        if (p->tracing) p->trace.push_back({ (double)todo.job.ticket, todo.t_sub, todo.t_b0, todo.t_b1, todo.t_enq, t1, now(), todo.t_ready });
       }
       p->cv.notify_all();
     }
@@ -149,9 +176,11 @@ int de265hip_pipeline_new(de265hip_pipeline** out, de265hip_decoder* dec, int n_
   if (!out || !dec || n_workers < 1 || n_workers > 16) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   de265hip_pipeline* p = new (std::nothrow) de265hip_pipeline();
   if (!p) return DE265HIP_ERROR_OUT_OF_MEMORY;
-  p->dec = dec; p->n_workers = n_workers; p->timing = getenv("DE265HIP_PIPE_TIMING") != nullptr;
+  p->dec = dec; p->n_workers = n_workers; p->timing = getenv("DE265HIP_PIPE_TIMING") != nullptr; p->tracing = getenv("DE265HIP_PIPE_TRACE") != nullptr;
   p->window = 4 * n_workers + 4;
   if (const char* w = getenv("DE265HIP_PIPE_WINDOW")) p->window = std::max(1, atoi(w));
+  if (const char* b = getenv("DE265HIP_PIPE_BATCH")) p->batch = std::min(8, std::max(1, atoi(b)));
+  p->window = std::max(p->window, 3 * p->batch + 2);
   for (int i = 0; i < n_workers; i++) p->th.emplace_back(worker, p);
   p->launcher_th = std::thread(launcher, p);
   *out = p;
@@ -172,7 +201,7 @@ static int pipeline_submit_job(de265hip_pipeline* p, int dst_slot, de265hip_prep
     // others need that many cheaper ones behind it to stay busy (measured, 3 x 5 workers, 4K10 GOPs of 1 I + 15 B: window 12
     // -> workers idle 2.7-3.4 ms per picture, 1 040-1 070 pictures/s; 24 -> 0.5-0.9 ms, 1 307; 40 -> 1 291)
     p->cv.wait(lk, [&] { return p->in_flight < p->window; });
-    j.ticket = p->next_ticket++;
+    j.ticket = p->next_ticket++; j.t_sub = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     p->in_flight++;
     p->q.push_back(j);
   }
@@ -245,6 +274,7 @@ void de265hip_pipeline_free(de265hip_pipeline* p)
     fprintf(stderr, "de265hip pipeline: %ld pictures, %d workers + 1 launcher; ms per picture: workers idle %.2f build (host stage) %.2f | launcher idle %.2f enqueue (upload + scan) %.2f launch %.2f\n",
             p->n_jobs, p->n_workers, 1e3 * p->t_idle / p->n_jobs, 1e3 * p->t_build / p->n_jobs, 1e3 * p->t_lidle / p->n_jobs,
             1e3 * p->t_enqueue / p->n_jobs, 1e3 * p->t_launch / p->n_jobs);
+  if (p->tracing) for (auto& r : p->trace) fprintf(stderr, "pipetrace %p %.0f %.6f %.6f %.6f %.6f %.6f %.6f %.6f\n", (void*)p, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
   delete p;
 }
 

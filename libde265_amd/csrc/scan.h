@@ -18,6 +18,11 @@ struct ScanLayout {
   void bind(uint8_t* base, ScanBufs& B) const;        // the pointers of the scratch / output buffers (inputs are the caller's)
 };
 
+// up to SCAN_BATCH pictures whose passes share their launches (kernel arguments by value: < 4 KB)
+#define SCAN_BATCH 4
+struct ScanJob { ScanParams P; ScanBufs B; uint32_t cap_resid, cap_levels; };
+struct ScanBatch { int n; int pad; ScanJob job[SCAN_BATCH]; };
+hipError_t scan_enqueue_batch(hipStream_t st, const ScanBatch& J);
 hipError_t scan_enqueue(hipStream_t st, const ScanParams& P, const ScanBufs& B, const ScanLayout& L, uint8_t* base, uint32_t cap_resid);
 void scan_host_run(const ScanParams& P, const ScanBufs& B, const ScanLayout& L, uint8_t* base, uint32_t cap_resid);
 
