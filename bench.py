@@ -684,7 +684,9 @@ def main():
                        "host_threads": product["host_threads"] if product else 0, "host_cores_available": cores,
                        "host_threads_per_rank": product["host_threads_per_rank"] if product else 0,
                        "device_replay_over_value": round(device_replay["value"] / fps, 2) if fps > 0 else None,
-                       "bound": ("host (the device alone sustains %.1fx this rate)" % (device_replay["value"] / fps)
+                       "bound": ("not the reconstruction kernels (replayed alone they sustain %.1fx this rate): the build of a picture - host "
+                                 "stage on the worker threads, then the device-side scan of its records, which shares the device with the "
+                                 "reconstruction" % (device_replay["value"] / fps)
                                  if device_replay["value"] > 1.15 * fps else "device") if product else "device replay",
                        "events_in_timed_region": "every kernel" if args.events == "all" else "dominant kernel (%s) only" % dom,
                        "parallelism": "%d gop stream(s) x %d gpu(s)" % (S, world)},

@@ -772,7 +772,9 @@ hipError_t scan_enqueue_batch(hipStream_t st, const ScanBatch& J)
   if (max_tus > 0) {
     hipLaunchKernelGGL(k_scan_ctbs, dim3(max_ctbs, ny), dim3(64), 0, st, J);
     // (the number of runs is only known on the device: fixed grids of wavefronts walk the run lists)
-    static const int run_grid = getenv("DE265HIP_SCAN_RUN_GRID") ? atoi(getenv("DE265HIP_SCAN_RUN_GRID")) : 1024;
+    // (512 wavefronts: with 128 / 256 / 512 / 1024 the product path of the bench made 1 860 / 2 310 / 2 630 / 2 380 pictures/s -
+    //  fewer leave the run passes' latency chains too long, more crowd the reconstruction kernels of the other streams)
+    static const int run_grid = getenv("DE265HIP_SCAN_RUN_GRID") ? atoi(getenv("DE265HIP_SCAN_RUN_GRID")) : 512;
     hipLaunchKernelGGL(k_scan_runs1, dim3(run_grid, ny), dim3(64), 0, st, J);
     hipLaunchKernelGGL(k_scan_runs2, dim3(run_grid, ny), dim3(64), 0, st, J);
   }
