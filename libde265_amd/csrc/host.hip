@@ -16,6 +16,8 @@
 #include <chrono>
 
 #include <deque>
+#include <array>
+#include <map>
 
 #include "kernels.h"
 #include "scan.h"
@@ -82,6 +84,7 @@ struct de265hip_decoder {
   static constexpr int kMaxCopyStreams = 8;
   hipStream_t copy_streams[kMaxCopyStreams] = {};
   int n_copy_streams = 1;
+  int prio_low = 0, prio_high = 0;                  // stream priorities (de265hip_decoder_new)
   uint64_t copy_turn = 0;
   // ... and the uploads of a pipeline's builds go out from the worker that staged them, on upload streams of their own:
   // hipMemcpyAsync of a few megabytes of pinned memory holds its caller for about as long as the copy takes (140 us, at times
@@ -106,6 +109,9 @@ struct de265hip_decoder {
   // Launch order stays decode order; what orders the device work are the slots' events (Slot::written / read_done).
   int n_lanes = 1;
   hipStream_t lane_stream[kMaxLanes] = { nullptr, nullptr, nullptr, nullptr };
+  bool lane_pooled[kMaxLanes] = { false, false, false, false };
+  int kstream_index = -1;             // which of the process's pooled kernel streams `stream` is (-1: the decoder's own)
+  bool streams_pooled = false;        // copy and upload streams from the process's pools as well
   Slot lane_spare[kMaxLanes];         // [0] unused (lane 0's is `spare`)
   hipEvent_t lane_fence[kMaxLanes] = { nullptr, nullptr, nullptr, nullptr };   // scratch events ("everything lane l has queued so far")
   uint64_t lane_tail_seq[kMaxLanes] = { 0, 0, 0, 0 };   // launch number of the lane's latest picture
@@ -574,6 +580,76 @@ struct PhaseTimer {
   void done() { if (on) fprintf(stderr, "de265hip build:%s\n", buf); }
 };
 
+// Kernel streams of the process, four per device, created BACK TO BACK the first time a decoder asks: the device has four
+// dispatch pipes, a hardware queue is bound to pipe (number of the queue in order of creation) % 4 whatever its priority, and a
+// pipe dispatches one kernel at a time - a kernel of many workgroups keeps it for as long as it runs (tools/exp/pipeprobe.hip:
+// a one-workgroup kernel behind a 40 000-workgroup grid finishes after 30 us from another pipe, after 415 us from the same).
+// Two decoders whose kernel streams met on one pipe cost a third of the device: replay of three GOP streams 5 200 instead of
+// 7 050 pictures/s, decided by how many other streams had been created in between (round 4).  Four streams created in a row
+// sit on four different pipes; decoder k of the process works on stream k % 4 (more than four decoders share: they would
+// share a pipe anyway).  DE265HIP_OWN_STREAMS=1: every decoder creates its own, as before.
+constexpr int kKernelStreams = 4;
+// The copy streams (upload of a picture's records, the scan kernels behind it: priority high) and the upload streams (priority
+// low) come from pools of the process too, four and two per device: every HIP stream may cost a hardware queue, and beyond
+// some 16 hardware queues in the process the device's scheduler time-slices them - three decoders with three copy streams each
+// and the priority pools of their own (4 + 9 + 6 + 3 streams) ran at 5 to 300 pictures/s instead of 2 500 (round 4,
+// tools/exp/r4b_window.sh).  Copy-out streams stay per decoder (created when first used).
+constexpr int kScanStreams = 4, kUploadStreams = 2;
+struct DeviceStreams {
+  hipStream_t kernel[kKernelStreams] = {}, scan[kScanStreams] = {}, upload[kUploadStreams] = {};
+  int next_kernel = 0, next_scan = 0, next_upload = 0;
+  bool ok = false;
+};
+static std::mutex g_streams_mu;
+static std::map<int, DeviceStreams> g_streams;
+static bool own_streams()
+{
+  static const bool own = getenv("DE265HIP_OWN_STREAMS") && atoi(getenv("DE265HIP_OWN_STREAMS"));
+  return own;
+}
+// (caller holds g_streams_mu)
+static DeviceStreams* device_streams(int device)
+{
+  auto it = g_streams.find(device);
+  if (it == g_streams.end()) {
+    DeviceStreams D;
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return nullptr;      // (numerically: lowest, greatest priority)
+    if (const char* e = getenv("DE265HIP_FLAT_PRIORITIES")) if (atoi(e)) lo = hi = 0;
+    bool ok = true;
+    for (int i = 0; i < kKernelStreams && ok; i++) ok = hipStreamCreateWithPriority(&D.kernel[i], hipStreamNonBlocking, 0) == hipSuccess;      // back to back: four pipes
+    for (int i = 0; i < kScanStreams && ok; i++) ok = hipStreamCreateWithPriority(&D.scan[i], hipStreamNonBlocking, hi) == hipSuccess;
+    for (int i = 0; i < kUploadStreams && ok; i++) ok = hipStreamCreateWithPriority(&D.upload[i], hipStreamNonBlocking, lo) == hipSuccess;
+    if (!ok) return nullptr;                             // (leaves what was created: the process is about to fail anyway)
+    D.ok = true;
+    it = g_streams.emplace(device, D).first;
+  }
+  return &it->second;
+}
+static hipStream_t pooled_kernel_stream(int device, int* index, bool fixed = false)
+{
+  if (own_streams()) return nullptr;
+  std::lock_guard<std::mutex> lk(g_streams_mu);
+  DeviceStreams* D = device_streams(device);
+  if (!D) return nullptr;
+  if (!fixed) *index = D->next_kernel++ % kKernelStreams;
+  return D->kernel[*index];
+}
+static hipStream_t pooled_scan_stream(int device)
+{
+  if (own_streams()) return nullptr;
+  std::lock_guard<std::mutex> lk(g_streams_mu);
+  DeviceStreams* D = device_streams(device);
+  return D ? D->scan[D->next_scan++ % kScanStreams] : nullptr;
+}
+static hipStream_t pooled_upload_stream(int device)
+{
+  if (own_streams()) return nullptr;
+  std::lock_guard<std::mutex> lk(g_streams_mu);
+  DeviceStreams* D = device_streams(device);
+  return D ? D->upload[D->next_upload++ % kUploadStreams] : nullptr;
+}
+
 struct ArenaLayout {
   size_t total = 0;
   size_t add(size_t bytes) { size_t o = total; total = (total + bytes + 255) & ~(size_t)255; return o; }
@@ -603,13 +679,32 @@ int de265hip_decoder_new(de265hip_decoder** out, int device)
   de265hip_decoder* d = new (std::nothrow) de265hip_decoder();
   if (!d) return DE265HIP_ERROR_OUT_OF_MEMORY;
   HIPCHK(hipGetDevice(&d->device), DE265HIP_ERROR_INIT_FAILED);
-  HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking), DE265HIP_ERROR_INIT_FAILED);
-  HIPCHK(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking), DE265HIP_ERROR_INIT_FAILED);
-  d->copy_streams[0] = d->copy_stream;
-  d->n_copy_streams = 2;
+  // Three kinds of streams, three priorities - the runtime keeps a pool of hardware queues PER priority (GPU_MAX_HW_QUEUES
+  // each), and hands a new stream the least used queue of its pool.  With every stream at the default priority a decoder's
+  // kernel stream shared its hardware queue - or its dispatch pipe - with some other decoder's, or not, depending on how many
+  // copy streams had been created before it: device replay of three GOP streams 4 550 / 5 190 / 7 080 pictures/s for 4 / 2 / 1
+  // copy streams per decoder (round 4, tools/exp/r4b_replay_streams.sh).  Now the streams come from the process's pools
+  // (DeviceStreams above): kernel streams (and lanes) at the default priority, the copy streams (scan of the TU records:
+  // short, latency-bound kernels the launches wait for) high, the upload and copy-out streams low.
+  int prio_lo = 0, prio_hi = 0;
+  HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi), DE265HIP_ERROR_INIT_FAILED);      // (numerically: lowest, greatest)
+  d->prio_low = prio_lo; d->prio_high = prio_hi;
+  if (const char* e = getenv("DE265HIP_FLAT_PRIORITIES")) if (atoi(e)) d->prio_low = d->prio_high = 0;
+  d->stream = pooled_kernel_stream(d->device, &d->kstream_index);
+  if (!d->stream) { d->kstream_index = -1; HIPCHK(hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, 0), DE265HIP_ERROR_INIT_FAILED); }
+  d->n_copy_streams = 4;               // (pooled: every decoder takes turns on all four; 2 / 3 / 4: 2 570 / 2 770 / 2 900 pictures/s, three decoders)
   if (const char* e = getenv("DE265HIP_COPY_STREAMS")) d->n_copy_streams = std::min((int)de265hip_decoder::kMaxCopyStreams, std::max(1, atoi(e)));
-  for (int i = 1; i < d->n_copy_streams; i++) HIPCHK(hipStreamCreateWithFlags(&d->copy_streams[i], hipStreamNonBlocking), DE265HIP_ERROR_INIT_FAILED);
-  for (int i = 0; i < 2; i++) HIPCHK(hipStreamCreateWithFlags(&d->upload_streams[i], hipStreamNonBlocking), DE265HIP_ERROR_INIT_FAILED);
+  d->streams_pooled = d->kstream_index >= 0;
+  if (d->streams_pooled) d->n_copy_streams = std::min(d->n_copy_streams, kScanStreams);
+  for (int i = 0; i < d->n_copy_streams; i++) {
+    if (d->streams_pooled) d->copy_streams[i] = pooled_scan_stream(d->device);
+    else HIPCHK(hipStreamCreateWithPriority(&d->copy_streams[i], hipStreamNonBlocking, d->prio_high), DE265HIP_ERROR_INIT_FAILED);
+  }
+  d->copy_stream = d->copy_streams[0];
+  for (int i = 0; i < 2; i++) {
+    if (d->streams_pooled) d->upload_streams[i] = pooled_upload_stream(d->device);
+    else HIPCHK(hipStreamCreateWithPriority(&d->upload_streams[i], hipStreamNonBlocking, d->prio_low), DE265HIP_ERROR_INIT_FAILED);
+  }
   HIPCHK(hipMalloc((void**)&d->d_err, 256), DE265HIP_ERROR_OUT_OF_MEMORY);
   HIPCHK(hipMemset(d->d_err, 0, 256), DE265HIP_ERROR_INIT_FAILED);
   HIPCHK(hipMalloc((void**)&d->d_err_ring, de265hip_decoder::kRing * 4), DE265HIP_ERROR_OUT_OF_MEMORY);
@@ -646,7 +741,11 @@ int de265hip_decoder_set_lanes(de265hip_decoder* d, int n_lanes)
   HIPCHK(sync_all_lanes(d), DE265HIP_ERROR_DECODING);                 // (a change takes effect between pictures)
   for (auto& s : d->slots) slot_settled(s);
   for (int l = 1; l < n_lanes; l++)
-    if (!d->lane_stream[l]) HIPCHK(hipStreamCreateWithFlags(&d->lane_stream[l], hipStreamNonBlocking), DE265HIP_ERROR_INIT_FAILED);
+    if (!d->lane_stream[l]) {
+      // (a lane takes the pool's next kernel stream - another dispatch pipe - when the decoder's own came from the pool)
+      if (d->kstream_index >= 0) { int ix = (d->kstream_index + l) % kKernelStreams; d->lane_stream[l] = pooled_kernel_stream(d->device, &ix, true); d->lane_pooled[l] = d->lane_stream[l] != nullptr; }
+      if (!d->lane_stream[l]) HIPCHK(hipStreamCreateWithPriority(&d->lane_stream[l], hipStreamNonBlocking, 0), DE265HIP_ERROR_INIT_FAILED);
+    }
   d->n_lanes = n_lanes;
   return DE265HIP_OK;
 }
@@ -692,15 +791,17 @@ void de265hip_decoder_free(de265hip_decoder* d)
   for (auto& e : d->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& s : d->slots) free_slot(s);
   free_slot(d->spare);
-  for (int l = 1; l < kMaxLanes; l++) { free_slot(d->lane_spare[l]); if (d->lane_stream[l]) (void)hipStreamDestroy(d->lane_stream[l]); }
+  for (int l = 1; l < kMaxLanes; l++) { free_slot(d->lane_spare[l]); if (d->lane_stream[l] && !d->lane_pooled[l]) (void)hipStreamDestroy(d->lane_stream[l]); }
   for (int l = 0; l < kMaxLanes; l++) if (d->lane_fence[l]) (void)hipEventDestroy(d->lane_fence[l]);
   if (d->d_err) (void)hipFree(d->d_err);
   if (d->d_err_ring) (void)hipFree(d->d_err_ring);
   if (d->h_ring) (void)hipHostFree(d->h_ring);
   if (d->d_used_units) (void)hipFree(d->d_used_units);
-  for (int i = 0; i < d->n_copy_streams; i++) if (d->copy_streams[i]) (void)hipStreamDestroy(d->copy_streams[i]);
-  for (int i = 0; i < 2; i++) if (d->upload_streams[i]) (void)hipStreamDestroy(d->upload_streams[i]);
-  (void)hipStreamDestroy(d->stream);
+  if (!d->streams_pooled) {
+    for (int i = 0; i < d->n_copy_streams; i++) if (d->copy_streams[i]) (void)hipStreamDestroy(d->copy_streams[i]);
+    for (int i = 0; i < 2; i++) if (d->upload_streams[i]) (void)hipStreamDestroy(d->upload_streams[i]);
+  }
+  if (d->kstream_index < 0) (void)hipStreamDestroy(d->stream);      // (a pooled kernel stream lives as long as the process)
   delete d;
 }
 
@@ -770,7 +871,7 @@ int de265hip_dpb_download_async(de265hip_decoder* d, int slot, int c, void* dst,
   if (w == 0 || h == 0) return DE265HIP_OK;               // (a chroma plane of a monochrome picture)
   std::lock_guard<std::mutex> lk(d->mu);
   if (!d->out_stream) {
-    HIPCHK(hipStreamCreateWithFlags(&d->out_stream, hipStreamNonBlocking), DE265HIP_ERROR_DECODING);
+    HIPCHK(hipStreamCreateWithPriority(&d->out_stream, hipStreamNonBlocking, d->prio_low), DE265HIP_ERROR_DECODING);
     HIPCHK(hipEventCreateWithFlags(&d->out_fence, hipEventDisableTiming), DE265HIP_ERROR_DECODING);
   }
   if (!s->dl_done) HIPCHK(hipEventCreateWithFlags(&s->dl_done, hipEventDisableTiming), DE265HIP_ERROR_DECODING);
