@@ -2426,7 +2426,13 @@ int de265hip_picture_enqueue_batch(de265hip_picture** pics, int n)
     const int m = std::min(SCAN_BATCH, n - i0);
     hipStream_t cs;
     { std::lock_guard<std::mutex> lk(dec->mu); cs = dec->copy_streams[dec->copy_turn++ % (uint64_t)dec->n_copy_streams]; reap_arenas(dec); }
-    ScanBatch J; J.n = 0; J.pad = 0;
+    static const int prefix_tail = getenv("DE265HIP_SCAN_PREFIX_TAIL") ? atoi(getenv("DE265HIP_SCAN_PREFIX_TAIL")) : 0;
+    static const int own_prep = getenv("DE265HIP_OWN_PREP") ? atoi(getenv("DE265HIP_OWN_PREP")) : 1;
+    // (pad = 1: the last workgroup of the per-TU pass to finish computes the per-CTB bases instead of a launch of its own.  Off:
+    //  every workgroup has to publish its counts with an agent-scope fence first, and 400 of those per picture - each writes the
+    //  L2 back, the other kernels' dirty lines included - cost more than the launch: 2 500 against 3 060 pictures/s, round 4)
+    ScanBatch J; J.n = 0; J.pad = prefix_tail;
+    PrepBatch PJ; PJ.n = 0; PJ.pad = 0;
     de265hip_picture* done[SCAN_BATCH]; int n_done = 0;
     auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tl = tnow();
@@ -2451,7 +2457,6 @@ int de265hip_picture_enqueue_batch(de265hip_picture** pics, int n)
       // out wrong).  With the device-side scan its own cleared buffers follow the mailboxes: one memset for both.
       const size_t clear_to = pic->dev_scan ? pic->SL.clear_end : E.o_sync + E.clear_bytes;
       sec(1);
-      HIPCHK(hipMemsetAsync(base + E.o_sync, 0, clear_to - E.o_sync, cs), DE265HIP_ERROR_DECODING);
       sec(2);
       if (E.uploaded_by_builder) HIPCHK(hipStreamWaitEvent(cs, E.stage_event, 0), DE265HIP_ERROR_DECODING);      // (the builder's thread sent it)
       else {
@@ -2463,11 +2468,13 @@ int de265hip_picture_enqueue_batch(de265hip_picture** pics, int n)
       }
       E.pending = false;
       sec(4);
-      if (!E.mot_given) {
-        HIPCHK(hipMemsetAsync(base + E.o_mot, 0xFF, E.nblk * sizeof(de265hip_motion), cs), DE265HIP_ERROR_DECODING);
-        if (E.n_pus > 0)
-          hipLaunchKernelGGL(k_motion_from_pus, dim3((E.n_pus + 15) / 16), dim3(256), 0, cs, pic->P, (const de265hip_pu*)(base + E.o_pus), E.n_pus,
-                             (const de265hip_slice_params*)(base + E.o_sl), E.n_slices, (de265hip_motion*)(base + E.o_mot));
+      // the cleared region and the motion plane: one launch each for the whole batch, behind the waits of all its pictures
+      {
+        PrepJob& q = PJ.job[PJ.n++];
+        q.zero = base + E.o_sync; q.zero_bytes = clear_to - E.o_sync;
+        q.ff = E.mot_given ? nullptr : base + E.o_mot; q.ff_bytes = E.mot_given ? 0 : E.nblk * sizeof(de265hip_motion);
+        q.pus = (const de265hip_pu*)(base + E.o_pus); q.slices = (const de265hip_slice_params*)(base + E.o_sl); q.motion = (de265hip_motion*)(base + E.o_mot);
+        q.n_pus = E.mot_given ? 0 : E.n_pus; q.n_slices = E.n_slices; q.w4 = pic->P.w4; q.h4 = pic->P.h4;
       }
       if (pic->dev_scan) {
         // the last pass of the scan writes the counts into the picture's pinned ring entry and raises its ready word (system-
@@ -2488,6 +2495,16 @@ int de265hip_picture_enqueue_batch(de265hip_picture** pics, int n)
       sec(5);
     }
     tl = tnow();
+    if (own_prep) HIPCHK(prep_enqueue_batch(cs, PJ), DE265HIP_ERROR_DECODING);
+    else for (int i = 0; i < PJ.n; i++) {
+      const PrepJob& q = PJ.job[i];
+      HIPCHK(hipMemsetAsync(q.zero, 0, q.zero_bytes, cs), DE265HIP_ERROR_DECODING);
+      if (q.ff) {
+        HIPCHK(hipMemsetAsync(q.ff, 0xFF, q.ff_bytes, cs), DE265HIP_ERROR_DECODING);
+        PicDev Pm; memset(&Pm, 0, sizeof(Pm)); Pm.w4 = q.w4; Pm.h4 = q.h4;
+        if (q.n_pus > 0) hipLaunchKernelGGL(k_motion_from_pus, dim3((q.n_pus + 15) / 16), dim3(256), 0, cs, Pm, q.pus, q.n_pus, q.slices, q.n_slices, q.motion);
+      }
+    }
     if (J.n) HIPCHK(scan_enqueue_batch(cs, J), DE265HIP_ERROR_DECODING);
     sec(6);
     for (int i = 0; i < n_done; i++) HIPCHK(hipEventRecord(done[i]->uploaded, cs), DE265HIP_ERROR_DECODING);

@@ -9,99 +9,6 @@
 namespace d265 {
 
 // ------------------------------------------------------------------------------------------------ device kernels
-__global__ __launch_bounds__(256)
-void k_scan_tus(ScanBatch J)
-{
-  if (blockIdx.y >= (unsigned)J.n) return;
-  const ScanParams& P = J.job[blockIdx.y].P; const ScanBufs& B = J.job[blockIdx.y].B;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i == 0 && B.err_word) *B.err_word = 0;                  // (the picture's kernels that may raise it come behind the scan)
-  ScanTuSums S = { 0, 0, 0, 0, 0 };
-  ScanParams Pt = P; Pt.flags &= ~SCANF_CHECK_POS;            // (the positions: below, sixteen lanes per TU)
-  if (i < P.n_tus) scan_tu(Pt, B, i, S);
-  // one atomic per wavefront and sum
-  unsigned long long v[3] = { S.alg_resid, S.alg_intra, S.n_isamp };
-  uint32_t w[2] = { S.n_tasks, S.n_intra };
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-    for (int k = 0; k < 3; k++) v[k] += __shfl_down(v[k], off, 64);
-#pragma unroll
-    for (int k = 0; k < 2; k++) w[k] += __shfl_down(w[k], off, 64);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    scan_add64(&B.counts->alg_resid, v[0]); scan_add64(&B.counts->alg_intra, v[1]); scan_add64(&B.counts->n_isamp, v[2]);
-    if (w[0]) atomicAdd(&B.counts->n_tasks, w[0]);
-  }
-  // coefficient positions inside their TU's block (de265hip_picture_build's job on the host until round 3): the workgroup's 256
-  // records sixteen at a time, sixteen lanes striding each list (a thread walking its own list alone took 7x as long); a
-  // position beyond the block is folded into it and the picture fails
-  if (P.flags & SCANF_CHECK_POS) {
-    const int sub = threadIdx.x & 15;
-    bool bad = false;
-    for (int g = 0; g < 16; g++) {
-      const int j = blockIdx.x * 256 + g * 16 + (threadIdx.x >> 4);
-      if (j >= P.n_tus) break;
-      const de265hip_tu tu = B.tus[j];
-      if (!(tu.flags & DE265HIP_TU_CBF) || !scan_tu_valid(P, tu)) continue;
-      const unsigned nS = 1u << (2 * tu.log2_size), n = tu.n_coeff;
-      uint16_t* p = B.coeff_pos + tu.coeff_offset;
-      for (unsigned k = sub; k < n; k += 16) {
-        const unsigned q = p[k];
-        if (q >= nS) { p[k] = (uint16_t)(q & (nS - 1)); bad = true; }
-      }
-    }
-    if (bad) scan_fail(B, DE265HIP_ERROR_DECODING);
-  }
-}
-
-// exclusive prefix over the CTBs in tile-scan (decode) order of the seven per-CTB counts, by one workgroup: every thread sums
-// a contiguous chunk of CTBs, the workgroup scans the 1024 chunk sums in LDS, every thread writes its chunk's bases
-__global__ __launch_bounds__(1024)
-void k_scan_prefix(ScanBatch J)
-{
-  if (blockIdx.y >= (unsigned)J.n) return;
-  const ScanParams& P = J.job[blockIdx.y].P; const ScanBufs& B = J.job[blockIdx.y].B;
-  const uint32_t cap_resid = J.job[blockIdx.y].cap_resid;
-  __shared__ uint32_t sums[7][1024];
-  __shared__ uint32_t tot[7];
-  const int tid = threadIdx.x, n = P.n_ctbs, chunk = (n + 1023) / 1024;
-  const int t0 = tid * chunk, t1 = min(n, t0 + chunk);
-  uint32_t acc[7] = { 0, 0, 0, 0, 0, 0, 0 };
-  for (int t = t0; t < t1; t++) {
-    const ScanCtb& C = B.ctb[B.ts2rs[t]];
-    for (int k = 0; k < 4; k++) acc[k] += C.n_inter[k] + C.n_ro[k];
-    acc[4] += C.n_rext_inter + C.n_rext_ro; acc[5] += C.n_intra; acc[6] += C.n_isamp;
-  }
-  for (int k = 0; k < 7; k++) sums[k][tid] = acc[k];
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {                 // inclusive Hillis-Steele scan of the chunk sums
-    uint32_t v[7];
-    for (int k = 0; k < 7; k++) v[k] = tid >= off ? sums[k][tid - off] : 0u;
-    __syncthreads();
-    for (int k = 0; k < 7; k++) sums[k][tid] += v[k];
-    __syncthreads();
-  }
-  if (tid == 1023) for (int k = 0; k < 7; k++) tot[k] = sums[k][1023];
-  uint32_t base[7];
-  for (int k = 0; k < 7; k++) base[k] = sums[k][tid] - acc[k];
-  for (int t = t0; t < t1; t++) {
-    ScanCtb& C = B.ctb[B.ts2rs[t]];
-    for (int k = 0; k < 4; k++) { C.l0_base[k] = base[k]; base[k] += C.n_inter[k] + C.n_ro[k]; }
-    C.rext_base = base[4]; base[4] += C.n_rext_inter + C.n_rext_ro;
-    C.intra_base = base[5]; base[5] += C.n_intra;
-    C.isamp_base = base[6]; base[6] += C.n_isamp;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    if (P.n_tus == 0 && B.err_word) *B.err_word = 0;
-    scan_prefix_finish_totals(B, tot);
-    B.counts->victim = 0xFFFFFFFFu;
-    // (overlapping intra TUs - a malformed description - could ask for more residual samples than the picture has)
-    if (tot[6] > cap_resid || tot[5] > P.cap_runs) scan_fail(B, DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE);
-  }
-}
-
 // ---- wave-level helpers (wave64).  Reductions by DPP row shifts + row broadcasts (no LDS round trip: a __shfl is a
 // ds_bpermute, ~100 cycles, and six of them in a row make a reduction cost more than everything else in a step of the CTB pass)
 __device__ __forceinline__ int wave_max_i(int v)          // (of non-negative values; the result in every lane)
@@ -128,6 +35,257 @@ __device__ __forceinline__ uint32_t wave_sum_u(uint32_t x)
 __device__ __forceinline__ int wave_min_i(int v) { return 0x7FFFFFFF - wave_max_i(0x7FFFFFFF - v); }      // (v >= 0)
 __device__ __forceinline__ uint64_t lanes_below(int lane) { return lane ? (~0ull >> (64 - lane)) : 0ull; }
 #define WAVE_ORDER() asm volatile("" ::: "memory")        // single-wavefront workgroups: LDS executes a wavefront's operations in order; only the compiler must not move them
+
+template <int NT> __device__ void scan_prefix_body(const ScanParams& P, const ScanBufs& B, uint32_t cap_resid);
+
+// The per-TU pass on the device.  scan_core.h scan_tu is the same pass as plain code (the CPU rehearsal); what differs here:
+// - the availability mask in closed form.  scan_tu asks MinTbAddrZS for every below-left and above-right unit (a dependent
+//   load each, up to 33 in a row: 90 us for a kernel of 100 000 threads).  The below-left units of a TU all lie in ONE block
+//   of the TU's size, aligned like it, and so do the above-right ones; aligned blocks of equal size cover disjoint ranges of
+//   the z-scan order, so one comparison settles a whole block (4:2:2 chroma blocks are not square in luma: those TUs take
+//   scan_tu's loops);
+// - the per-CTB counts by one atomic per counter, CTB and wavefront (the records of a CTB are contiguous: a wavefront sees one
+//   or two CTBs) instead of one to three per TU.
+__device__ __forceinline__ void scan_tu_dev(const ScanParams& P, const ScanBufs& B, int i, bool have, uint32_t& alg_resid, uint32_t& alg_intra, uint32_t& n_tasks)
+{
+  const int lane = threadIdx.x & 63;
+  int cls = 0, rx = 0, ctu = -1;
+  de265hip_tu tu; memset(&tu, 0, sizeof(tu));
+  bool fail_range = false;
+  if (have) {
+    tu = B.tus[i];
+    B.tu_info[i] = 0;                                    // (scan_ctb fills the words of the intra TUs)
+    if (!scan_tu_valid(P, tu)) { fail_range = true; have = false; }
+  }
+  if (have) {
+    ctu = scan_tu_ctb(P, tu);
+    // -- where the record array enters a CTB
+    int prev = -1;
+    if (i > 0) { const de265hip_tu q = B.tus[i - 1]; if (scan_tu_valid(P, q)) prev = scan_tu_ctb(P, q); }
+    if (i == 0 || prev != ctu) {
+      atomicAdd(&B.ctb[ctu].seen, 1u);
+      B.ctb[ctu].first_tu = (uint32_t)i;
+      if (prev >= 0) B.ctb[prev].end_tu = (uint32_t)i;
+    }
+    if (i == P.n_tus - 1) B.ctb[ctu].end_tu = (uint32_t)P.n_tus;
+    cls = scan_tu_class(P, B, tu, &rx);
+    if ((rx & D265_RX_XCC) && cls != 0) { uint64_t li; int rl; if (!scan_xcc_luma(P, B, i, &li, &rl)) { fail_range = true; cls = 0; } }
+  }
+  if (__ballot(fail_range) != 0 && fail_range) scan_fail(B, DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE);
+  const int nT = 1 << tu.log2_size, c = tu.c_idx;
+  const bool cbf = (tu.flags & DE265HIP_TU_CBF) && tu.n_coeff;
+  const bool ro = cls == 3 && (cbf || (rx & D265_RX_XCC));
+  if (cls != 0) {
+    const uint32_t bpp = (uint32_t)(c ? P.bppC : P.bppY);
+    const uint32_t coef_bytes = cbf ? (4u * tu.n_coeff < 2u * nT * nT ? 4u * tu.n_coeff : 2u * nT * nT) : 0u;
+    n_tasks++;
+    if (cls != 3) { if (cbf) alg_resid += coef_bytes + 2 * bpp * nT * nT; }
+    else { alg_resid += coef_bytes; alg_intra += bpp * (4 * nT + 1) + bpp * nT * nT; }
+  }
+  // -- the per-CTB counts: the lanes of one CTB together
+  for (uint64_t todo = __ballot(cls != 0); todo;) {
+    const int lead = __builtin_ctzll(todo);
+    const int lctu = __builtin_amdgcn_readlane(ctu, lead);
+    const bool same = cls != 0 && ctu == lctu;
+    todo &= ~__ballot(same);
+    uint32_t n_inter[4], n_intra_k[4], n_ro[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      n_inter[k] = (uint32_t)__popcll(__ballot(same && cls == 1 && tu.log2_size == k + 2));
+      n_intra_k[k] = (uint32_t)__popcll(__ballot(same && cls == 3 && tu.log2_size == k + 2));
+      n_ro[k] = (uint32_t)__popcll(__ballot(same && ro && !rx && tu.log2_size == k + 2));
+    }
+    const uint32_t n_rext_inter = (uint32_t)__popcll(__ballot(same && cls == 2)), n_rext_ro = (uint32_t)__popcll(__ballot(same && ro && rx));
+    if (lane == lead) {
+      ScanCtb& C = B.ctb[lctu];
+      const uint32_t ni = n_intra_k[0] + n_intra_k[1] + n_intra_k[2] + n_intra_k[3];
+#pragma unroll
+      for (int k = 0; k < 4; k++) { if (n_inter[k]) atomicAdd(&C.n_inter[k], n_inter[k]); if (n_ro[k]) atomicAdd(&C.n_ro[k], n_ro[k]); }
+      if (n_rext_inter) atomicAdd(&C.n_rext_inter, n_rext_inter);
+      if (n_rext_ro) atomicAdd(&C.n_rext_ro, n_rext_ro);
+      if (ni) { atomicAdd(&C.n_intra, ni); atomicAdd(&C.n_isamp, 16 * n_intra_k[0] + 64 * n_intra_k[1] + 256 * n_intra_k[2] + 1024 * n_intra_k[3]); }
+    }
+  }
+  if (cls != 3) return;
+  // -- an intra TU: neighbour availability (8.4.4.2.2; intrapred.cc:437-527 preproc, :577-688 fill_from_image) as a unit bit mask
+  const int sbw = c ? P.subw : 1, sbh = c ? P.subh : 1;
+  const int xB = tu.x0, yB = tu.y0, xL = xB * sbw, yL = yB * sbh;
+  uint64_t mask = 0;
+  if (c != 0 && P.cf == 2) {
+    // (4:2:2 chroma: scan_tu's loops, every unit its own comparison)
+    const int cx = xL >> P.lc, cy = yL >> P.lc;
+    const int corner = nT >> 1, w4 = (P.width + 3) >> 2;
+    const uint32_t own = B.ctb_group[ctu];
+    const bool aL = xL > 0 && B.ctb_group[((xL - 1) >> P.lc) + cy * P.ctbs_w] == own;
+    const bool aT = yL > 0 && B.ctb_group[cx + ((yL - 1) >> P.lc) * P.ctbs_w] == own;
+    const bool aTL = xL > 0 && yL > 0 && B.ctb_group[((xL - 1) >> P.lc) + ((yL - 1) >> P.lc) * P.ctbs_w] == own;
+    const bool aTR = yL > 0 && (xL + nT * sbw < P.width) && B.ctb_group[((xL + nT * sbw) >> P.lc) + ((yL - 1) >> P.lc) * P.ctbs_w] == own;
+    int nBottom = (P.height - yL + sbh - 1) >> (sbh - 1); if (nBottom > 2 * nT) nBottom = 2 * nT;
+    int nRight = (P.width - xL + sbw - 1) >> (sbw - 1);   if (nRight > 2 * nT) nRight = 2 * nT;
+    const int cur = scan_zs(P, B, xL >> P.lt, yL >> P.lt);
+    const bool cip = P.flags & SCANF_CIP;
+    auto intra_ok = [&](int xs, int ys) { return !cip || (B.blk_flags[((xs * sbw) >> 2) + ((ys * sbh) >> 2) * w4] & DE265HIP_BLK_INTRA); };
+    auto z_ok = [&](int xs, int ys) { return scan_zs(P, B, (xs * sbw) >> P.lt, (ys * sbh) >> P.lt) <= cur; };
+    if (aL) for (int y = nBottom - 1; y >= 0; y -= 4) if (z_ok(xB - 1, yB + y) && intra_ok(xB - 1, yB + y)) mask |= 1ull << ((2 * nT - 1 - y) >> 2);
+    if (aTL && z_ok(xB - 1, yB - 1) && intra_ok(xB - 1, yB - 1)) mask |= 1ull << corner;
+    if (aT || aTR) for (int x = 0; x < nRight; x += 4) if ((x < nT ? aT : aTR) && z_ok(xB + x, yB - 1) && intra_ok(xB + x, yB - 1)) mask |= 1ull << (corner + 1 + (x >> 2));
+  } else {
+    const int S = nT * sbw;                              // the TU in luma samples (square)
+    const int cx = xL >> P.lc, cy = yL >> P.lc, lc = P.lc, cw = P.ctbs_w;
+    const int corner = nT >> 1, q4 = nT >> 2;
+    const bool hasL = xL > 0, hasT = yL > 0, hasR = xL + S < P.width;
+    // the neighbouring CTBs' groups (slice address + tile) and - for the two blocks that may come later in z-scan order - their
+    // place in it: all loads up front, none depends on another
+    const int ctbL = ((xL - 1) >> lc) + cy * cw, ctbT = cx + ((yL - 1) >> lc) * cw, ctbTL = ((xL - 1) >> lc) + ((yL - 1) >> lc) * cw, ctbTR = ((xL + S) >> lc) + ((yL - 1) >> lc) * cw;
+    const int ctbBL = ((xL - 1) >> lc) + ((yL + S) >> lc) * cw;
+    int nBottom = (P.height - yL + sbh - 1) >> (sbh - 1); if (nBottom > 2 * nT) nBottom = 2 * nT;      // (sbw, sbh are 1 or 2)
+    int nRight = (P.width - xL + sbw - 1) >> (sbw - 1);   if (nRight > 2 * nT) nRight = 2 * nT;
+    const bool wantBL = hasL && nBottom > nT;
+    const uint32_t own = B.ctb_group[ctu];
+    const uint32_t gL = hasL ? B.ctb_group[ctbL] : ~own, gT = hasT ? B.ctb_group[ctbT] : ~own, gTL = (hasL && hasT) ? B.ctb_group[ctbTL] : ~own;
+    const uint32_t gTR = (hasT && hasR) ? B.ctb_group[ctbTR] : ~own;
+    const int dl = lc - P.lt;
+    const int tsC = B.rs2ts[ctu], tsBL = wantBL ? B.rs2ts[ctbBL] : 0, tsTR = (hasT && hasR) ? B.rs2ts[ctbTR] : 0;
+    auto morton = [&](int xtb, int ytb) { int v = 0; for (int b2 = 0; b2 < dl; b2++) v |= (((xtb >> b2) & 1) << (2 * b2)) | (((ytb >> b2) & 1) << (2 * b2 + 1)); return v; };
+    const int cur = (tsC << (2 * dl)) | morton(xL >> P.lt, yL >> P.lt);
+    const bool aL = hasL && gL == own, aT = hasT && gT == own, aTL = hasL && hasT && gTL == own, aTR = hasT && hasR && gTR == own;
+    const bool zBL = wantBL && ((tsBL << (2 * dl)) | morton((xL - sbw) >> P.lt, (yL + S) >> P.lt)) <= cur;
+    const bool zTR = aTR && ((tsTR << (2 * dl)) | morton((xL + S) >> P.lt, (yL - sbh) >> P.lt)) <= cur;
+    auto bits = [](int lo, int hi) -> uint64_t { return hi > lo ? ((hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull)) : 0ull; };      // [lo, hi)
+    if (aL) {
+      mask |= bits(q4, corner);                                              // beside the TU
+      if (zBL) mask |= bits((2 * nT - nBottom) >> 2, q4);                    // below-left, as far as the picture goes
+    }
+    if (aTL) mask |= 1ull << corner;
+    if (aT) mask |= bits(corner + 1, corner + 1 + q4);
+    if (zTR && nRight > nT) mask |= bits(corner + 1 + q4, corner + 1 + (nRight >> 2));
+    if ((P.flags & SCANF_CIP) && mask) {
+      // constrained_intra_pred: only samples of intra CUs (intrapred.cc:612-615)
+      const int w4 = (P.width + 3) >> 2;
+      uint64_t keep = 0;
+      for (uint64_t mm = mask; mm; mm &= mm - 1) {
+        const int u = __builtin_ctzll(mm);
+        const int xs = u < corner ? xB - 1 : (u == corner ? xB - 1 : xB + 4 * (u - corner - 1));
+        const int ys = u < corner ? yB + 2 * nT - 1 - 4 * u : yB - 1;
+        if (B.blk_flags[((xs * sbw) >> 2) + ((ys * sbh) >> 2) * w4] & DE265HIP_BLK_INTRA) keep |= 1ull << u;
+      }
+      mask = keep;
+    }
+  }
+  // -- dependencies: only the units the mode reads (4:4:4 chroma is smoothed like luma: it takes luma's table, a superset)
+  const int m = tu.intra_mode < 35 ? tu.intra_mode : 1;
+  const uint64_t need = (P.flags & SCANF_MODE_DEPS) ? scan_needed_units(B.used_units[((tu.log2_size - 2) * 35 + m) * 2 + ((c == 0 || P.cf == 3) ? 1 : 0)], mask) : mask;
+  B.tu_avail[i] = mask; B.tu_need[i] = need;
+  // -- the cells it covers
+  const int mw = P.map_w[c];
+  ScanCell* cells = B.cell[c];
+  for (int y = yB >> 2; y < (yB + nT) >> 2; y++)
+    for (int x = xB >> 2; x < (xB + nT) >> 2; x++) cells[x + (size_t)y * mw] = (ScanCell)(uint32_t)(i + 1);
+}
+
+__global__ __launch_bounds__(256)
+void k_scan_tus(ScanBatch J)
+{
+  if (blockIdx.y >= (unsigned)J.n) return;
+  const ScanParams& P = J.job[blockIdx.y].P; const ScanBufs& B = J.job[blockIdx.y].B;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0 && B.err_word) *B.err_word = 0;                  // (the picture's kernels that may raise it come behind the scan)
+  uint32_t alg_resid = 0, alg_intra = 0, n_tasks = 0;
+  scan_tu_dev(P, B, i, i < P.n_tus, alg_resid, alg_intra, n_tasks);
+  // one atomic per wavefront and sum
+  alg_resid = wave_sum_u(alg_resid); alg_intra = wave_sum_u(alg_intra); n_tasks = wave_sum_u(n_tasks);
+  if ((threadIdx.x & 63) == 0) {
+    scan_add64(&B.counts->alg_resid, alg_resid); scan_add64(&B.counts->alg_intra, alg_intra);
+    if (n_tasks) atomicAdd(&B.counts->n_tasks, n_tasks);
+  }
+  // coefficient positions inside their TU's block (de265hip_picture_build's job on the host until round 3): the workgroup's 256
+  // records sixteen at a time, sixteen lanes striding each list (a thread walking its own list alone took 7x as long); a
+  // position beyond the block is folded into it and the picture fails
+  if (P.flags & SCANF_CHECK_POS) {
+    const int sub = threadIdx.x & 15;
+    bool bad = false;
+    for (int g = 0; g < 16; g++) {
+      const int j = blockIdx.x * 256 + g * 16 + (threadIdx.x >> 4);
+      if (j >= P.n_tus) break;
+      const de265hip_tu tu = B.tus[j];
+      if (!(tu.flags & DE265HIP_TU_CBF) || !scan_tu_valid(P, tu)) continue;
+      const unsigned nS = 1u << (2 * tu.log2_size), n = tu.n_coeff;
+      uint16_t* p = B.coeff_pos + tu.coeff_offset;
+      for (unsigned k = sub; k < n; k += 16) {
+        const unsigned q = p[k];
+        if (q >= nS) { p[k] = (uint16_t)(q & (nS - 1)); bad = true; }
+      }
+    }
+    if (bad) scan_fail(B, DE265HIP_ERROR_DECODING);
+  }
+  // ---- the last workgroup of this picture to get here computes the per-CTB bases (scan_prefix): every workgroup publishes its
+  // counts (agent-scope fence), then takes a number
+  if (P.n_tus == 0 || !J.pad) return;
+  __shared__ uint32_t s_last;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(&B.counts->pad1, 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  scan_prefix_body<256>(P, B, J.job[blockIdx.y].cap_resid);
+}
+
+// exclusive prefix over the CTBs in tile-scan (decode) order of the seven per-CTB counts, by one workgroup of NT threads: every
+// thread sums a contiguous chunk of CTBs, the workgroup scans the chunk sums in LDS, every thread writes its chunk's bases.
+// Run by the LAST workgroup of k_scan_tus to finish (a launch of its own until round 4's second half: 16 us alone, 60-150 us
+// next to the reconstruction kernels, on a chain that everything behind it waits for).
+template <int NT>
+__device__ void scan_prefix_body(const ScanParams& P, const ScanBufs& B, uint32_t cap_resid)
+{
+  __shared__ uint32_t sums[7][NT];
+  __shared__ uint32_t tot[7];
+  const int tid = threadIdx.x, n = P.n_ctbs, chunk = (n + NT - 1) / NT;
+  const int t0 = min(n, tid * chunk), t1 = min(n, t0 + chunk);
+  uint32_t acc[7] = { 0, 0, 0, 0, 0, 0, 0 };
+  for (int t = t0; t < t1; t++) {
+    const ScanCtb& C = B.ctb[B.ts2rs[t]];
+    for (int k = 0; k < 4; k++) acc[k] += C.n_inter[k] + C.n_ro[k];
+    acc[4] += C.n_rext_inter + C.n_rext_ro; acc[5] += C.n_intra; acc[6] += C.n_isamp;
+  }
+  for (int k = 0; k < 7; k++) sums[k][tid] = acc[k];
+  __syncthreads();
+  for (int off = 1; off < NT; off <<= 1) {                   // inclusive Hillis-Steele scan of the chunk sums
+    uint32_t v[7];
+    for (int k = 0; k < 7; k++) v[k] = tid >= off ? sums[k][tid - off] : 0u;
+    __syncthreads();
+    for (int k = 0; k < 7; k++) sums[k][tid] += v[k];
+    __syncthreads();
+  }
+  if (tid == NT - 1) for (int k = 0; k < 7; k++) tot[k] = sums[k][NT - 1];
+  uint32_t base[7];
+  for (int k = 0; k < 7; k++) base[k] = sums[k][tid] - acc[k];
+  for (int t = t0; t < t1; t++) {
+    ScanCtb& C = B.ctb[B.ts2rs[t]];
+    for (int k = 0; k < 4; k++) { C.l0_base[k] = base[k]; base[k] += C.n_inter[k] + C.n_ro[k]; }
+    C.rext_base = base[4]; base[4] += C.n_rext_inter + C.n_rext_ro;
+    C.intra_base = base[5]; base[5] += C.n_intra;
+    C.isamp_base = base[6]; base[6] += C.n_isamp;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    scan_prefix_finish_totals(B, tot);
+    B.counts->victim = 0xFFFFFFFFu;
+    // (overlapping intra TUs - a malformed description - could ask for more residual samples than the picture has)
+    if (tot[6] > cap_resid || tot[5] > P.cap_runs) scan_fail(B, DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE);
+  }
+}
+
+// a picture without TU records: the bases (all zero) and the totals still have to be written
+__global__ __launch_bounds__(256)
+void k_scan_prefix(ScanBatch J)
+{
+  if (blockIdx.y >= (unsigned)J.n) return;
+  const ScanParams& P = J.job[blockIdx.y].P; const ScanBufs& B = J.job[blockIdx.y].B;
+  if (P.n_tus != 0 && J.pad) return;                         // (done by its k_scan_tus)
+  if (threadIdx.x == 0 && B.err_word) *B.err_word = 0;
+  scan_prefix_body<256>(P, B, J.job[blockIdx.y].cap_resid);
+}
 
 // The CTB pass, one WAVEFRONT per CTB (scan_core.h scan_ctb is the same pass as one thread's loop: the CPU rehearsal; the
 // equivalence test holds this kernel to it).  What is sequential - which run a TU joins depends on the TUs before it - runs
@@ -263,6 +421,20 @@ void k_scan_ctbs(ScanBatch J)
       WAVE_ORDER();
     }
   }
+  // ---- the run behind every cell of this CTB that an intra TU covers: sparse id + 1 into the cell's high word (what the run
+  // pass resolves producers from: one load per needed unit)
+  WAVE_ORDER();
+  for (int c = 0; c < (P.cf ? 3 : 1); c++) {
+    const int sw = c ? P.subw : 1, sh = c ? P.subh : 1, mw = P.map_w[c], mh = P.map_h[c];
+    const int ox4 = (cx0 / sw) >> 2, oy4 = (cy0 / sh) >> 2;
+    const int cw4 = ((1 << P.lc) / sw) >> 2, ch4 = ((1 << P.lc) / sh) >> 2;          // the CTB in cells of this component
+    for (int q = lane; q < cw4 * ch4; q += 64) {
+      const int wx = q % cw4, wy = q / cw4;
+      const uint32_t v = win[c][(wy + 1) * SCW_W + (wx + 1)];
+      if ((v >> 31) && ox4 + wx < mw && oy4 + wy < mh)
+        reinterpret_cast<uint32_t*>(&B.cell[c][(ox4 + wx) + (size_t)(oy4 + wy) * mw])[1] = ibase + (v & 0xFFFFu) + 1u;
+    }
+  }
   // ---- the CTB's runs: sizes, CTB, a place in the run list
   uint32_t at = 0;
   if (lane == 0) { C.n_runs = (uint32_t)n_local; atomicAdd(&B.counts->n_runs, (uint32_t)n_local); at = atomicAdd(&B.counts->n_listed, (uint32_t)n_local); }
@@ -270,302 +442,352 @@ void k_scan_ctbs(ScanBatch J)
   for (int q = lane; q < n_local; q += 64) { B.run_ntus[ibase + q] = s_ntus[q]; B.run_rs[ibase + q] = (uint32_t)rs; B.run_list[at + q] = ibase + (uint32_t)q; }
 }
 
-// The run pass, one WAVEFRONT per run (persistent: a fixed grid walks the run list).  scan_core.h scan_run is the same pass as
-// one thread's loop.  A run is a chain of dependent global round trips if written naively (record -> CTB -> TU words -> TU
-// records -> cells -> their TUs' runs ..., ~50 of them: 100 us per run); here the run's TU records, masks and words are fetched
-// ONCE into LDS (a lane each), every later step works on LDS, and the producers are resolved in two batched round trips
-// (all needed cells, then the run ids behind them) into a hash set in LDS.
-#define SCR_MAX 256
-#define SCR_CAND (16 * 33)
+// inclusive prefix sum over the lanes of the wavefront (Hillis-Steele inside each row of 16 by DPP row shifts, then the row
+// totals by row broadcasts: lanes a row mask leaves out add the `old` operand, zero)
+__device__ __forceinline__ uint32_t wave_scan_incl_u(uint32_t x)
+{
+  int v = (int)x;
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);
+  return (uint32_t)v;
+}
+
+// The run pass, one WAVEFRONT per CTB: all runs of the CTB together (scan_core.h scan_run is the same pass as one thread's loop
+// over one run).  Round 4's first form gave every run a wavefront of its own: ~2 200 instructions of fixed cost per run -
+// reductions, sorts, a hash table - for runs of two or three TUs, 19 M wavefront instructions per 4K B picture, as much as the
+// picture's motion compensation.  Here the work follows the CTB's intra TUs (a lane each, 64 at a time): per-run sums by LDS
+// atomics into a table of the CTB's runs (64 runs at a time: a tile), a TU's place in its run's chain order by counting the
+// TUs of its run that sort before it (two loops over the CTB's TUs in LDS), the producers by one load per needed unit (the
+// cell's high word: the sparse id of the run that covers it, left there by the CTB pass) into one hash set per tile.
+#define SR_TMAX 768                      // intra TUs of a CTB (k_scan_ctbs refuses more)
+#define SR_HASH 1024
+enum { RF_FOREIGN = 1, RF_BIG = 2, RF_TOO_BIG = 4, RF_BAD = 8, RF_DENSE0 = 16, RF_MICRO = 32, RF_DENSE = 64, RF_MB = 128, RF_PHASED = 256 };
 __global__ __launch_bounds__(64)
 void k_scan_runs1(ScanBatch J)
 {
   if (blockIdx.y >= (unsigned)J.n) return;
   const ScanParams& P = J.job[blockIdx.y].P; const ScanBufs& B = J.job[blockIdx.y].B;
-  __shared__ int tix[SCR_MAX];
-  __shared__ uint4 s_rec[SCR_MAX];                     // the TU records (de265hip_tu, 16 bytes)
-  __shared__ uint64_t s_need[SCR_MAX], s_av[SCR_MAX];
-  __shared__ uint32_t keys[SCR_MAX], sorted[SCR_MAX], s_samp[SCR_MAX + 1];
-  __shared__ uint8_t s_lev[SCR_MAX], s_coll[SCR_MAX], s_rdy[64];
-  __shared__ uint32_t s_tab[512], s_cand[SCR_CAND];
-  __shared__ uint32_t s_nd, s_ncand;
-  const int lane = threadIdx.x;
-  if (B.counts->status) return;
-  const uint32_t n_listed = B.counts->n_listed;
-  uint32_t cls_start[4];
-  for (int k = 0; k < 4; k++) cls_start[k] = scan_l0_class_start(B.counts->n_l0_size, k);
-  auto rec_of = [&](int k) -> de265hip_tu { de265hip_tu t; const uint4 v = s_rec[k]; __builtin_memcpy(&t, &v, 16); return t; };
-  for (uint32_t qrun = blockIdx.x; qrun < n_listed; qrun += gridDim.x) {
-    const uint32_t s = B.run_list[qrun];
-    const int rs = (int)B.run_rs[s];
-    const ScanCtb& C = B.ctb[rs];
-    const int r = (int)(s - C.intra_base);
-    const uint32_t c_first = C.first_tu, c_end = C.end_tu;
-    // ---- its TUs (decode order), and what the runs before it in this CTB take of the CTB's lists
-    int n = 0;
-    uint32_t n_before = 0, samp_before = 0, ro_before[4] = { 0, 0, 0, 0 }, rext_ro_before = 0;
-    for (uint32_t base = c_first; base < c_end; base += 64) {
-      const uint32_t i = base + lane;
-      uint32_t ti = 0;
-      if (i < c_end) ti = B.tu_info[i];
-      const bool intra = ti & SCAN_TI_INTRA;
-      const int rr = (int)SCAN_TI_RUN(ti);
-      if (intra && rr < r) {
+  __shared__ uint32_t s_w[SR_TMAX];                    // per intra TU of the CTB (decode order): run | level << 10 | (log2 - 2) << 18 | residual-only task << 20 | rext << 21 | foreign << 22
+  __shared__ uint32_t s_key[SR_TMAX];                  // list << 20 | level << 8 | number inside its run
+  __shared__ uint16_t s_ix[SR_TMAX];                   // its record, relative to the CTB's first
+  // the tile's runs
+  __shared__ uint32_t r_x0[64], r_y0[64], r_x1[64], r_y1[64], r_wx1[64], r_wy1[64], r_n[64], r_samp[64], r_nl[64], r_fl[64], r_c[64];
+  __shared__ uint32_t r_ro[4][64], r_rx[64], r_alg[64], r_cnt[5][64], r_nd[64], r_fill[64];
+  __shared__ uint32_t r_first[64], r_res[64], r_robase[4][64], r_rxbase[64], r_depoff[64], r_mb[64];
+  __shared__ uint32_t s_tab[SR_HASH];
+  __shared__ uint8_t s_rdy[64];
+  const int rs = blockIdx.x, lane = threadIdx.x;
+  if (rs >= P.n_ctbs || B.counts->status) return;
+  const ScanCtb& C = B.ctb[rs];
+  const uint32_t n_runs = C.n_runs;
+  if (n_runs == 0) return;
+  const uint32_t first = C.first_tu, end = C.end_tu, ibase = C.intra_base, isamp_base = C.isamp_base, rext_base = C.rext_base, n_rext_inter = C.n_rext_inter;
+  uint32_t l0_at[4];                                   // where the residual-only copies of this CTB's intra TUs start, per size class
+  for (int k = 0; k < 4; k++) l0_at[k] = scan_l0_class_start(B.counts->n_l0_size, k) + C.l0_base[k] + C.n_inter[k];
+  const uint32_t pflags = P.flags;
+  const int micro_tus = P.micro_tus, run_waves = P.run_waves;
+  if (end - first > 65535u || n_runs > SR_TMAX) { if (lane == 0) scan_fail(B, DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE); return; }
+  // ---- the CTB's intra TUs, compacted (decode order)
+  int T = 0;
+  for (uint32_t base = first; base < end; base += 64) {
+    const uint32_t i = base + lane;
+    const uint32_t ti = i < end ? B.tu_info[i] : 0u;
+    const bool intra = ti & SCAN_TI_INTRA;
+    const uint64_t m = __ballot(intra);
+    if (intra) {
+      const int t = T + __popcll(m & lanes_below(lane));
+      if (t < SR_TMAX) {
         const de265hip_tu tu = B.tus[i];
-        const int rx = scan_rx_bits(P, B, tu);
-        const bool cbf = (tu.flags & DE265HIP_TU_CBF) && tu.n_coeff;
-        n_before++; samp_before += 1u << (2 * tu.log2_size);
-        if (cbf || (rx & D265_RX_XCC)) { if (rx) rext_ro_before++; else ro_before[tu.log2_size - 2]++; }
+        const int trx = scan_rx_bits(P, B, tu);
+        const bool ro = ((tu.flags & DE265HIP_TU_CBF) && tu.n_coeff) || (trx & D265_RX_XCC);
+        s_ix[t] = (uint16_t)(i - first);
+        s_w[t] = SCAN_TI_RUN(ti) | (SCAN_TI_LLEV(ti) << 10) | ((uint32_t)(tu.log2_size - 2) << 18) | (ro ? 1u << 20 : 0u) | (trx ? 1u << 21 : 0u) | ((ti & SCAN_TI_FOREIGN) ? 1u << 22 : 0u);
       }
-      const uint64_t m = __ballot(intra && rr == r);
-      if (intra && rr == r) { const int k = n + __popcll(m & lanes_below(lane)); if (k < SCR_MAX) { tix[k] = (int)i; s_lev[k] = (uint8_t)SCAN_TI_LLEV(ti); s_coll[k] = (ti & SCAN_TI_FOREIGN) ? 1 : 0; } }
-      n += __popcll(m);
     }
-    n_before = wave_sum_u(n_before); samp_before = wave_sum_u(samp_before); rext_ro_before = wave_sum_u(rext_ro_before);
-    for (int k = 0; k < 4; k++) ro_before[k] = wave_sum_u(ro_before[k]);
+    T += __popcll(m);
+  }
+  if (T > SR_TMAX) { if (lane == 0) scan_fail(B, DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE); return; }
+  WAVE_ORDER();
+  uint32_t carry_n = 0, carry_samp = 0, carry_ro[4] = { 0, 0, 0, 0 }, carry_rx = 0;
+  for (uint32_t r0 = 0; r0 < n_runs; r0 += 64) {
+    const uint32_t n_tile = n_runs - r0 < 64u ? n_runs - r0 : 64u;
+    const bool have_run = (uint32_t)lane < n_tile;
+    const uint32_t s = ibase + r0 + (uint32_t)lane;                      // the sparse id of this lane's run
+    // ---- per-run sums
+    r_x0[lane] = 0xFFFFu; r_y0[lane] = 0xFFFFu; r_x1[lane] = 0; r_y1[lane] = 0; r_wx1[lane] = 0; r_wy1[lane] = 0; r_n[lane] = 0; r_samp[lane] = 0;
+    r_nl[lane] = 0; r_fl[lane] = 0; r_c[lane] = 0; r_rx[lane] = 0; r_alg[lane] = 0; r_nd[lane] = 0; r_fill[lane] = 0;
+    for (int k = 0; k < 4; k++) r_ro[k][lane] = 0;
+    for (int k = 0; k < 5; k++) r_cnt[k][lane] = 0;
+    for (int q = lane; q < SR_HASH; q += 64) s_tab[q] = 0xFFFFFFFFu;
     WAVE_ORDER();
-    if (n == 0 || n > 255 || n != (int)B.run_ntus[s]) { if (lane == 0) scan_fail(B, DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE); return; }
-    // ---- the run's records into LDS, a lane each (the only time they are read from memory)
-    bool foreign = false;
-    for (int k = lane; k < n; k += 64) {
-      const int i = tix[k];
-      s_rec[k] = *reinterpret_cast<const uint4*>(B.tus + i);
-      s_need[k] = B.tu_need[i]; s_av[k] = B.tu_avail[i];
-      foreign = foreign || s_coll[k];
+    for (int cb = 0; cb < T; cb += 64) {
+      const int t = cb + lane;
+      if (t >= T) continue;
+      const uint32_t w = s_w[t], jj = (w & 1023u) - r0;
+      if (jj >= 64u) continue;
+      const de265hip_tu tu = B.tus[first + s_ix[t]];
+      const uint32_t nT = 1u << tu.log2_size, bpp = (uint32_t)(tu.c_idx ? P.bppC : P.bppY);
+      atomicMin(&r_x0[jj], (uint32_t)tu.x0); atomicMin(&r_y0[jj], (uint32_t)tu.y0);
+      atomicMax(&r_x1[jj], tu.x0 + nT); atomicMax(&r_y1[jj], tu.y0 + nT); atomicMax(&r_wx1[jj], tu.x0 + 2 * nT); atomicMax(&r_wy1[jj], tu.y0 + 2 * nT);
+      atomicAdd(&r_n[jj], 1u); atomicAdd(&r_samp[jj], nT * nT); atomicMax(&r_nl[jj], (w >> 10) & 0xFFu); atomicMax(&r_c[jj], (uint32_t)tu.c_idx);
+      atomicAdd(&r_alg[jj], bpp * (4 * nT + 1) + bpp * nT * nT);
+      const uint32_t fl = ((w >> 22) & 1u ? RF_FOREIGN : 0u) | (tu.log2_size == 4 ? RF_BIG : 0u) | (tu.log2_size > 4 ? RF_TOO_BIG : 0u);
+      if (fl) atomicOr(&r_fl[jj], fl);
+      if ((w >> 20) & 1u) { if ((w >> 21) & 1u) atomicAdd(&r_rx[jj], 1u); else atomicAdd(&r_ro[tu.log2_size - 2][jj], 1u); }
     }
     WAVE_ORDER();
-    // ---- box, window reach, samples, levels: every lane its TUs (k = lane, lane + 64, ..), then across the lanes
-    int x0 = 1 << 30, y0 = 1 << 30, x1 = 0, y1 = 0, wx1 = 0, wy1 = 0, nl = 0, c = 0;
-    uint32_t own_samples = 0;
-    bool big = false, too_big = false;
-    for (int k = lane; k < n; k += 64) {
-      const de265hip_tu tu = rec_of(k);
-      const int nT = 1 << tu.log2_size;
-      c = tu.c_idx;
-      x0 = min(x0, (int)tu.x0); y0 = min(y0, (int)tu.y0); x1 = max(x1, tu.x0 + nT); y1 = max(y1, tu.y0 + nT);
-      wx1 = max(wx1, tu.x0 + 2 * nT); wy1 = max(wy1, tu.y0 + 2 * nT);
-      own_samples += (uint32_t)(nT * nT);
-      nl = max(nl, (int)s_lev[k]);
-      big = big || tu.log2_size == 4; too_big = too_big || tu.log2_size > 4;
-    }
-    x0 = wave_min_i(x0); y0 = wave_min_i(y0); x1 = wave_max_i(x1); y1 = wave_max_i(y1); wx1 = wave_max_i(wx1); wy1 = wave_max_i(wy1);
-    nl = wave_max_i(nl); c = wave_max_i(c);
-    own_samples = wave_sum_u(own_samples);
-    foreign = __ballot(foreign) != 0; big = __ballot(big) != 0; too_big = __ballot(too_big) != 0;
-    if (nl > 256 || nl - 1 > 255) { if (lane == 0) scan_fail(B, DE265HIP_ERROR_NOT_IMPLEMENTED); return; }
-    bool micro = !(P.flags & SCANF_MICRO_OFF) && n <= P.micro_tus && x1 - x0 <= 32 && y1 - y0 <= 32 && !too_big;
-    if (micro && big) {
-      if (!(P.flags & SCANF_MICRO16) || own_samples > 1024) micro = false;
+    // ---- a lane per run: class
+    int x0 = (int)r_x0[lane], y0 = (int)r_y0[lane], x1 = (int)r_x1[lane], y1 = (int)r_y1[lane], wx1 = (int)r_wx1[lane], wy1 = (int)r_wy1[lane];
+    const int n = (int)r_n[lane], own_samples = (int)r_samp[lane], nl = (int)r_nl[lane], c = (int)r_c[lane];
+    uint32_t fl = r_fl[lane];
+    if (__ballot(have_run && (n == 0 || n > 255 || n != (int)B.run_ntus[have_run ? s : ibase])) != 0) { if (lane == 0) scan_fail(B, DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE); return; }
+    if (__ballot(have_run && nl > 256) != 0) { if (lane == 0) scan_fail(B, DE265HIP_ERROR_NOT_IMPLEMENTED); return; }
+    bool micro = have_run && !(pflags & SCANF_MICRO_OFF) && n <= micro_tus && x1 - x0 <= 32 && y1 - y0 <= 32 && !(fl & RF_TOO_BIG);
+    if (micro && (fl & RF_BIG)) {
+      if (!(pflags & SCANF_MICRO16) || own_samples > 1024) micro = false;
       else {
         const int ax0 = (x0 - 1) & ~7, wxc = wx1 < x1 + 32 ? wx1 : x1 + 32, wyc = wy1 < y1 + 32 ? wy1 : y1 + 32;
         const int cols = wxc - ax0, rows = wyc - (y0 - 1);
         micro = cols <= 56 && rows <= 41 && ((cols + 7) >> 3) * rows <= 256;
       }
     }
-    bool dense = (int)own_samples == (x1 - x0) * (y1 - y0) && !(P.flags & SCANF_NO_DENSE);
-    if (dense) {
-      bool bad = false;
-      for (int k = lane; k < n; k += 64) {
-        const de265hip_tu tu = rec_of(k);
-        const uint64_t avail = s_av[k];
-        const int nT = 1 << tu.log2_size, xB = tu.x0, yB = tu.y0, corner = nT >> 1;
-        if (xB > x0 && yB + 2 * nT > y1) {
-          int umax = (yB + 2 * nT - 1 - y1) >> 2; if (umax > corner - 1) umax = corner - 1;
+    const bool dense0 = have_run && own_samples == (x1 - x0) * (y1 - y0) && !(pflags & SCANF_NO_DENSE);
+    r_fl[lane] = fl | (micro ? RF_MICRO : 0u) | (dense0 ? RF_DENSE0 : 0u);
+    WAVE_ORDER();
+    // dense: every available neighbour outside the box lies on the row above it or the column left of it (a lane per TU)
+    if (__ballot(dense0) != 0) {
+      for (int cb = 0; cb < T; cb += 64) {
+        const int t = cb + lane;
+        if (t >= T) continue;
+        const uint32_t w = s_w[t], jj = (w & 1023u) - r0;
+        if (jj >= 64u || !(r_fl[jj] & RF_DENSE0)) continue;
+        const uint32_t i = first + s_ix[t];
+        const de265hip_tu tu = B.tus[i];
+        const uint64_t avail = B.tu_avail[i];
+        const int nT = 1 << tu.log2_size, xB = tu.x0, yB = tu.y0, corner = nT >> 1, bx0 = (int)r_x0[jj], by0 = (int)r_y0[jj], bx1 = (int)r_x1[jj], by1 = (int)r_y1[jj];
+        bool bad = false;
+        if (xB > bx0 && yB + 2 * nT > by1) {
+          int umax = (yB + 2 * nT - 1 - by1) >> 2; if (umax > corner - 1) umax = corner - 1;
           if (avail & ((2ull << umax) - 1ull)) bad = true;
         }
-        if (yB > y0 && xB + 2 * nT > x1) {
-          int kmin = (x1 - xB) >> 2; if (kmin < 0) kmin = 0;
+        if (yB > by0 && xB + 2 * nT > bx1) {
+          int kmin = (bx1 - xB) >> 2; if (kmin < 0) kmin = 0;
           if (kmin < corner && ((avail >> (corner + 1 + kmin)) & ((1ull << (corner - kmin)) - 1ull))) bad = true;
         }
+        if (bad) atomicOr(&r_fl[jj], (uint32_t)RF_BAD);
       }
-      dense = __ballot(bad) == 0;
+      WAVE_ORDER();
     }
-    RunTask o;
-    o.x0 = (uint16_t)x0; o.y0 = (uint16_t)y0; o.x1 = (uint16_t)x1; o.y1 = (uint16_t)y1;
-    o.wx1 = (uint16_t)(wx1 < x1 + 32 ? wx1 : x1 + 32); o.wy1 = (uint16_t)(wy1 < y1 + 32 ? wy1 : y1 + 32);
-    o.c_idx = (uint8_t)c; o.micro = (uint8_t)((micro ? 1 : 0) | (dense ? 2 : 0)); o.n_tus = (uint16_t)n;
-    o.first_tu = C.intra_base + n_before;
-    o.res_offset = C.isamp_base + samp_before;
-    o.dep_offset = 0; o.n_deps = 0;
-    // ---- mailbox of an ordinary dense run; ready epochs of its edge packets
+    fl = r_fl[lane];
+    const bool dense = dense0 && !(fl & RF_BAD);
+    // ---- what the runs before it take of the CTB's lists: prefix over the runs (three packed sums), carried across tiles
+    const uint32_t pa = have_run ? ((uint32_t)n | ((uint32_t)own_samples << 16)) : 0u;
+    const uint32_t pb = have_run ? (r_ro[0][lane] | (r_ro[1][lane] << 10) | (r_ro[2][lane] << 20)) : 0u;
+    const uint32_t pc = have_run ? (r_ro[3][lane] | (r_rx[lane] << 16)) : 0u;
+    const uint32_t ia = wave_scan_incl_u(pa), ib = wave_scan_incl_u(pb), ic = wave_scan_incl_u(pc);
+    const uint32_t ea = ia - pa, eb = ib - pb, ec = ic - pc;
+    const uint32_t first_tu = ibase + carry_n + (ea & 0xFFFFu), res_offset = isamp_base + carry_samp + (ea >> 16);
+    r_first[lane] = first_tu; r_res[lane] = res_offset;
+    r_robase[0][lane] = l0_at[0] + carry_ro[0] + (eb & 1023u); r_robase[1][lane] = l0_at[1] + carry_ro[1] + ((eb >> 10) & 1023u);
+    r_robase[2][lane] = l0_at[2] + carry_ro[2] + ((eb >> 20) & 1023u); r_robase[3][lane] = l0_at[3] + carry_ro[3] + (ec & 0xFFFFu);
+    r_rxbase[lane] = rext_base + n_rext_inter + carry_rx + (ec >> 16);
+    {
+      const uint32_t ta = (uint32_t)__builtin_amdgcn_readlane((int)ia, 63), tb = (uint32_t)__builtin_amdgcn_readlane((int)ib, 63), tc = (uint32_t)__builtin_amdgcn_readlane((int)ic, 63);
+      carry_n += ta & 0xFFFFu; carry_samp += ta >> 16; carry_ro[0] += tb & 1023u; carry_ro[1] += (tb >> 10) & 1023u; carry_ro[2] += (tb >> 20) & 1023u;
+      carry_ro[3] += tc & 0xFFFFu; carry_rx += tc >> 16;
+    }
+    // ---- mailbox of an ordinary dense run
     uint32_t mb_id = 0xFFFFFFFFu;
-    if ((P.flags & SCANF_MAILBOX) && !micro && dense) {
-      if (lane == 0) mb_id = atomicAdd(&B.counts->n_mailboxes, 1u);
-      mb_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)mb_id);
-      if (mb_id >= P.cap_mb) mb_id = 0xFFFFFFFFu;            // (beyond the mailboxes there are: the run does without)
-      else if ((P.flags & SCANF_MB_PHASES) && c == 0 && x1 - x0 <= 64 && y1 - y0 <= 64) {
-        s_rdy[lane] = 255;
-        WAVE_ORDER();
-        for (int k = lane; k < n; k += 64) {
-          const de265hip_tu tu = rec_of(k);
-          const int nT = 1 << tu.log2_size;
-          const uint8_t ep = (uint8_t)(s_lev[k] - 1);
-          if (tu.y0 + nT == y1) for (int q = 0; q < (nT >> 1); q++) s_rdy[((tu.x0 - x0) >> 1) + q] = ep;
-          if (tu.x0 + nT == x1) for (int q = 0; q < (nT >> 1); q++) s_rdy[32 + ((tu.y0 - y0) >> 1) + q] = ep;
-        }
-        WAVE_ORDER();
-        B.rdy_tab[64 * (size_t)mb_id + lane] = s_rdy[lane];
-      }
-    }
-    if (lane < 3) B.mbx[3 * (size_t)s + lane] = lane == 0 ? mb_id : 0xFFFFFFFFu;
-    if (lane == 0) B.pub_flag[s] = 0;
-    // ---- chain order: list (wavefront, or 4 = collective) | in-run level | decode index; the rank of a TU inside its level
-    // counts the non-collective TUs of that level before it
-    const int nwv = micro ? 1 : P.run_waves;
-    WAVE_ORDER();
-    for (int k = lane; k < n; k += 64) s_coll[k] = (rec_of(k).log2_size > 3 && !micro) ? 1 : 0;
-    WAVE_ORDER();
-    for (int k = lane; k < n; k += 64) {
-      int rank = 0;
-      for (int q = 0; q < k; q++) rank += (s_lev[q] == s_lev[k] && !s_coll[q]) ? 1 : 0;
-      const int list = s_coll[k] ? 4 : rank % nwv;
-      keys[k] = ((uint32_t)list << 20) | ((uint32_t)s_lev[k] << 8) | (uint32_t)k;
-    }
-    WAVE_ORDER();
-    int we[4] = { 0, 0, 0, 0 };
-    for (int k = lane; k < n; k += 64) {
-      int posn = 0;
-      for (int q = 0; q < n; q++) posn += keys[q] < keys[k] ? 1 : 0;
-      sorted[posn] = keys[k];
-      for (int w = 0; w < 4; w++) we[w] += (int)(keys[k] >> 20) <= w ? 1 : 0;
-    }
-    for (int w = 0; w < 4; w++) o.wave_end[w] = (uint16_t)wave_sum_u((uint32_t)we[w]);
-    o.n_lvls = (uint16_t)(nl > 0 ? nl - 1 : 0);
-    WAVE_ORDER();
-    // ---- sample offsets in chain order (exclusive prefix of the TU sizes): a lane's four entries, then across the lanes
+    bool phased = false;
     {
-      uint32_t sz[4], mine = 0;
-      for (int j = 0; j < 4; j++) { const int oi = 4 * lane + j; sz[j] = oi < n ? 1u << (2 * rec_of((int)(sorted[oi] & 0xFFu)).log2_size) : 0u; mine += sz[j]; }
-      uint32_t incl = mine;                                    // inclusive scan over the lanes (Hillis-Steele on ds_bpermute: six steps, once per run)
-      for (int off = 1; off < 64; off <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, off, 64); if (lane >= off) incl += v; }
-      uint32_t acc = incl - mine;
-      for (int j = 0; j < 4; j++) { const int oi = 4 * lane + j; if (oi <= n && oi < SCR_MAX + 1) s_samp[oi] = acc; acc += sz[j]; }
-      o.n_samples = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      const bool want = have_run && (pflags & SCANF_MAILBOX) && !micro && dense;
+      const uint64_t wm = __ballot(want);
+      if (wm) {
+        uint32_t at = 0;
+        if (lane == 0) at = atomicAdd(&B.counts->n_mailboxes, (uint32_t)__popcll(wm));
+        at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+        if (want) {
+          mb_id = at + (uint32_t)__popcll(wm & lanes_below(lane));
+          if (mb_id >= P.cap_mb) mb_id = 0xFFFFFFFFu;        // (beyond the mailboxes there are: the run does without)
+          else phased = (pflags & SCANF_MB_PHASES) && c == 0 && x1 - x0 <= 64 && y1 - y0 <= 64;
+        }
+      }
     }
+    r_mb[lane] = mb_id;
+    r_fl[lane] = fl | (dense ? RF_DENSE : 0u) | (phased ? RF_PHASED : 0u);
     WAVE_ORDER();
-    // ---- the run-ordered TU records + the residual-only copies (level-0 tasks), a lane per TU, 64 at a time
-    uint32_t ro_at[4] = { 0, 0, 0, 0 }, rext_at = 0;
-    for (int ob = 0; ob < n; ob += 64) {
-      const int oi = ob + lane;
-      const bool have = oi < n;
-      TuTask tt; memset(&tt, 0, sizeof(tt));
-      de265hip_tu tu; memset(&tu, 0, sizeof(tu));
-      int trx = 0, i = 0; bool ro_on = false;
-      uint32_t coeff_offset = 0;
-      if (have) {
-        const int k = (int)(sorted[oi] & 0xFFu);
-        i = tix[k];
-        tu = rec_of(k);
-        tt = scan_task_of(tu);
-        const int m = tu.intra_mode < 35 ? tu.intra_mode : 1;
-        tt.angle = (int8_t)scan_intra_angle(m); tt.inv_angle = (int16_t)scan_inv_angle(m);
-        tt.avail = s_av[k];
-        tt.run_level = (uint8_t)(s_lev[k] - 1);
-        coeff_offset = tt.coeff_offset;
-        tt.resid_offset = o.res_offset + s_samp[oi];
-        tt.coeff_offset = s_samp[oi];
-        trx = scan_rx_bits(P, B, tu);
-        ro_on = (tt.flags & DE265HIP_TU_CBF) || (trx & D265_RX_XCC);
-      }
-      for (int k = 0; k < 4; k++) {
-        const bool mine = have && ro_on && !trx && tt.log2_size == k + 2;
-        const uint64_t m = __ballot(mine);
-        if (mine) {
-          TuTask ro = tt; ro.flags |= D265_TU_RESID_ONLY; ro.coeff_offset = coeff_offset; ro.run_level = 0;
-          B.l0[cls_start[k] + C.l0_base[k] + C.n_inter[k] + ro_before[k] + ro_at[k] + __popcll(m & lanes_below(lane))] = ro;
-        }
-        ro_at[k] += __popcll(m);
-      }
-      {
-        const bool mine = have && ro_on && trx;
-        const uint64_t m = __ballot(mine);
-        if (mine) {
-          TuTask ro = tt; ro.flags |= D265_TU_RESID_ONLY; ro.coeff_offset = coeff_offset; ro.run_level = 0;
-          uint64_t luma_info = 0; int rx_luma = 0;
-          if (trx & D265_RX_XCC) scan_xcc_luma(P, B, i, &luma_info, &rx_luma);
-          ro.pad3 = (uint8_t)(trx | rx_luma); ro.angle = 0; ro.avail = 0;
-          if (trx & D265_RX_XCC) { ro.angle = tu.res_scale_val; ro.avail = luma_info; }
-          B.l0x[C.rext_base + C.n_rext_inter + rext_ro_before + rext_at + __popcll(m & lanes_below(lane))] = ro;
-        }
-        rext_at += __popcll(m);
-      }
-      if (have) {
-        if (ro_on) tt.flags |= DE265HIP_TU_CBF;              // (the run kernels read the residual block whenever there is one)
-        B.run_tus[o.first_tu + (uint32_t)oi] = tt;
-      }
-    }
-    // ---- producers: the cells of every needed unit of every TU (64 TUs at a time, a lane each, into a list), then - a lane
-    // per list entry, all loads of a step in flight together - the TU behind the cell and the run behind the TU; each run
-    // once: a hash set in LDS (the cells a run inside one CTB can need number fewer than its slots)
-    for (int q = lane; q < 512; q += 64) s_tab[q] = 0xFFFFFFFFu;
-    if (lane == 0) s_nd = 0;
-    {
-      const int mw = P.map_w[c];
-      const ScanCell* cells = B.cell[c];
-      for (int kb = 0; kb < n; kb += 16) {
-        if (lane == 0) s_ncand = 0;
-        WAVE_ORDER();
-        const int k = kb + lane;
-        if (lane < 16 && k < n) {
-          const de265hip_tu tu = rec_of(k);
-          for (uint64_t need = s_need[k]; need; need &= need - 1)
-            s_cand[atomicAdd(&s_ncand, 1u)] = (uint32_t)scan_cell_of(__builtin_ctzll(need), tu.x0, tu.y0, 1 << tu.log2_size, mw);
-        }
-        WAVE_ORDER();
-        const uint32_t nc = s_ncand;
-        for (uint32_t q0 = 0; q0 < nc; q0 += 256) {
-          uint32_t j[4], ps[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) { const uint32_t q = q0 + 64 * u + lane; j[u] = q < nc ? (uint32_t)cells[s_cand[q]] : 0u; }
-#pragma unroll
-          for (int u = 0; u < 4; u++) ps[u] = j[u] ? B.tu_run[j[u] - 1] : s;
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            if (ps[u] == s) continue;
-            uint32_t hsh = (ps[u] * 2654435761u) >> 23;
-            for (int probe = 0; probe < 512; probe++, hsh = (hsh + 1) & 511) {
-              const uint32_t old = atomicCAS(&s_tab[hsh], 0xFFFFFFFFu, ps[u]);
-              if (old == 0xFFFFFFFFu) { atomicAdd(&s_nd, 1u); break; }
-              if (old == ps[u]) break;
-            }
+    // ---- chain order.  First loop: the TU's number inside its run (decode order) and its rank among the non-collective TUs of
+    // its in-run level before it -> its list; second loop: how many TUs of its run sort before it, their samples, and how many
+    // residual-only copies of its class
+    for (int cb = 0; cb < T; cb += 64) {
+      const int t = cb + lane;
+      uint32_t key = 0xFFFFFFFFu;
+      const uint32_t w = t < T ? s_w[t] : 0xFFFFFFFFu, jj = (w & 1023u) - r0;
+      const bool mine = t < T && jj < 64u;
+      const bool rmicro = mine && (r_fl[mine ? jj : 0] & RF_MICRO);
+      if (__ballot(mine) != 0) {
+        uint32_t k_in = 0, rank = 0;
+        const int u_end = cb + 64 < T ? cb + 64 : T;
+        for (int u = 0; u < u_end; u++) {
+          const uint32_t wu = s_w[u];
+          if (u < t && ((wu ^ w) & 1023u) == 0) {
+            k_in++;
+            const bool coll_u = ((wu >> 18) & 3u) > 1u && !rmicro;
+            if (((wu ^ w) & (0xFFu << 10)) == 0 && !coll_u) rank++;
           }
         }
-        WAVE_ORDER();
+        if (mine) {
+          const bool coll = ((w >> 18) & 3u) > 1u && !rmicro;
+          const uint32_t list = coll ? 4u : rank % (uint32_t)(rmicro ? 1 : run_waves);
+          key = (list << 20) | (((w >> 10) & 0xFFu) << 8) | k_in;
+          atomicAdd(&r_cnt[list][jj], 1u);
+        }
+      }
+      if (t < T) s_key[t] = mine ? key : 0xFFFFFFFFu;
+    }
+    WAVE_ORDER();
+    for (int cb = 0; cb < T; cb += 64) {
+      const int t = cb + lane;
+      const uint32_t w = t < T ? s_w[t] : 0xFFFFFFFFu, jj = (w & 1023u) - r0;
+      const bool mine = t < T && jj < 64u;
+      if (__ballot(mine) == 0) continue;
+      const uint32_t key = mine ? s_key[t] : 0u;
+      uint32_t pos = 0, samp = 0, ro_rank = 0;
+      for (int u = 0; u < T; u++) {
+        const uint32_t wu = s_w[u], ku = s_key[u];
+        if (((wu ^ w) & 1023u) == 0 && ku < key) {
+          pos++; samp += 16u << (2 * ((wu >> 18) & 3u));
+          // the same list of residual-only tasks: both with a range-extension tool, or both without and of one size
+          if (((wu >> 20) & 1u) && ((wu ^ w) & (1u << 21)) == 0 && (((w >> 21) & 1u) || ((wu ^ w) & (3u << 18)) == 0)) ro_rank++;
+        }
+      }
+      if (!mine) continue;
+      // ---- the run-ordered TU record + the residual-only copy (level-0 task)
+      const uint32_t i = first + s_ix[t];
+      const de265hip_tu tu = B.tus[i];
+      TuTask tt = scan_task_of(tu);
+      const int m = tu.intra_mode < 35 ? tu.intra_mode : 1;
+      tt.angle = (int8_t)scan_intra_angle(m); tt.inv_angle = (int16_t)scan_inv_angle(m);
+      tt.avail = B.tu_avail[i];
+      tt.run_level = (uint8_t)(((w >> 10) & 0xFFu) - 1);
+      const uint32_t coeff_offset = tt.coeff_offset;
+      tt.resid_offset = r_res[jj] + samp;
+      tt.coeff_offset = samp;
+      if ((w >> 20) & 1u) {
+        TuTask ro = tt; ro.flags |= D265_TU_RESID_ONLY; ro.coeff_offset = coeff_offset; ro.run_level = 0;
+        if ((w >> 21) & 1u) {
+          const int trx = scan_rx_bits(P, B, tu);
+          uint64_t luma_info = 0; int rx_luma = 0;
+          if (trx & D265_RX_XCC) scan_xcc_luma(P, B, (int)i, &luma_info, &rx_luma);
+          ro.pad3 = (uint8_t)(trx | rx_luma); ro.angle = 0; ro.avail = 0;
+          if (trx & D265_RX_XCC) { ro.angle = tu.res_scale_val; ro.avail = luma_info; }
+          B.l0x[r_rxbase[jj] + ro_rank] = ro;
+        } else B.l0[r_robase[tu.log2_size - 2][jj] + ro_rank] = ro;
+        tt.flags |= DE265HIP_TU_CBF;                      // (the run kernels read the residual block whenever there is one)
+      }
+      B.run_tus[r_first[jj] + pos] = tt;
+      // ---- its producers: the run behind every needed unit (the high word of the cell: sparse id + 1, k_scan_ctbs), each
+      // (run, producer) pair once
+      const ScanCell* cells = B.cell[tu.c_idx];
+      const int mw = P.map_w[tu.c_idx], nT = 1 << tu.log2_size;
+      const uint32_t own = ibase + (w & 1023u);
+      for (uint64_t need = B.tu_need[i]; need;) {
+        uint32_t ps[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          ps[q] = 0;
+          if (need) { ps[q] = (uint32_t)(cells[scan_cell_of(__builtin_ctzll(need), tu.x0, tu.y0, nT, mw)] >> 32); need &= need - 1; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          if (ps[q] == 0 || ps[q] - 1 == own) continue;
+          const uint32_t e = (jj << 24) | (ps[q] - 1);
+          uint32_t hsh = (e * 2654435761u) >> 22;
+          int probe = 0;
+          for (; probe < SR_HASH; probe++, hsh = (hsh + 1) & (SR_HASH - 1)) {
+            const uint32_t old = atomicCAS(&s_tab[hsh], 0xFFFFFFFFu, e);
+            if (old == 0xFFFFFFFFu) { atomicAdd(&r_nd[jj], 1u); break; }
+            if (old == e) break;
+          }
+          if (probe == SR_HASH) scan_fail(B, DE265HIP_ERROR_NOT_IMPLEMENTED);
+        }
       }
     }
     WAVE_ORDER();
-    const uint32_t nd = s_nd;
-    if (nd > 500) { if (lane == 0) scan_fail(B, DE265HIP_ERROR_NOT_IMPLEMENTED); return; }
-    if (nd) {
+    if (B.counts->status) return;
+    // ---- the producer lists: room from the pool (one request per tile), the table's entries to their runs
+    const uint32_t nd = have_run ? r_nd[lane] : 0u;
+    {
+      const uint32_t incl = wave_scan_incl_u(nd), total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
       uint32_t at = 0;
-      if (lane == 0) at = atomicAdd(&B.counts->n_deps_alloc, nd);
-      at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
-      if (at + nd > P.cap_deps) { if (lane == 0) scan_fail(B, DE265HIP_ERROR_NOT_IMPLEMENTED); return; }
-      o.dep_offset = at;
-      uint32_t w = 0;
-      for (int qb = 0; qb < 512; qb += 64) {
-        const uint32_t e = s_tab[qb + lane];
-        const uint64_t m = __ballot(e != 0xFFFFFFFFu);
-        if (e != 0xFFFFFFFFu) B.deps[at + w + __popcll(m & lanes_below(lane))] = e;
-        w += __popcll(m);
+      if (total) {
+        if (lane == 0) at = atomicAdd(&B.counts->n_deps_alloc, total);
+        at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+        if (at + total > P.cap_deps) { if (lane == 0) scan_fail(B, DE265HIP_ERROR_NOT_IMPLEMENTED); return; }
       }
+      r_depoff[lane] = at + incl - nd;
+      WAVE_ORDER();
+      if (total)
+        for (int q = lane; q < SR_HASH; q += 64) {
+          const uint32_t e = s_tab[q];
+          if (e == 0xFFFFFFFFu) continue;
+          const uint32_t jj = e >> 24;
+          B.deps[r_depoff[jj] + atomicAdd(&r_fill[jj], 1u)] = e & 0xFFFFFFu;
+        }
     }
-    o.n_deps = (uint16_t)nd;
-    const bool front = micro && nd == 0 && !(P.flags & SCANF_FRONT_OFF);
-    if (front) o.micro |= RUN_MICRO_FRONT;
-    if (lane == 0) {
-      B.run_nall[s] = nd | (foreign ? 0x80000000u : 0u);
-      atomicAdd(&B.counts->sum_lvls, (uint32_t)nl);
-      if (front) B.front_idx[atomicAdd(&B.counts->n_front, 1u)] = s;
+    // ---- ready epochs of the edge packets of a run that publishes in phases (a luma run of at most 64 x 64, dense)
+    for (uint64_t pm = __ballot(phased); pm; pm &= pm - 1) {
+      const int jj = __builtin_ctzll(pm);
+      const int bx0 = (int)r_x0[jj], by0 = (int)r_y0[jj], bx1 = (int)r_x1[jj], by1 = (int)r_y1[jj];
+      s_rdy[lane] = 255;
+      WAVE_ORDER();
+      for (int cb = 0; cb < T; cb += 64) {
+        const int t = cb + lane;
+        if (t >= T) continue;
+        const uint32_t w = s_w[t];
+        if ((w & 1023u) - r0 != (uint32_t)jj) continue;
+        const de265hip_tu tu = B.tus[first + s_ix[t]];
+        const int nT = 1 << tu.log2_size;
+        const uint8_t ep = (uint8_t)(((w >> 10) & 0xFFu) - 1);
+        if (tu.y0 + nT == by1) for (int q = 0; q < (nT >> 1); q++) s_rdy[((tu.x0 - bx0) >> 1) + q] = ep;
+        if (tu.x0 + nT == bx1) for (int q = 0; q < (nT >> 1); q++) s_rdy[32 + ((tu.y0 - by0) >> 1) + q] = ep;
+      }
+      WAVE_ORDER();
+      B.rdy_tab[64 * (size_t)r_mb[jj] + lane] = s_rdy[lane];
+      WAVE_ORDER();
+    }
+    // ---- the run records
+    const bool front = have_run && micro && nd == 0 && !(pflags & SCANF_FRONT_OFF);
+    if (have_run) {
+      RunTask o;
+      o.x0 = (uint16_t)x0; o.y0 = (uint16_t)y0; o.x1 = (uint16_t)x1; o.y1 = (uint16_t)y1;
+      o.wx1 = (uint16_t)(wx1 < x1 + 32 ? wx1 : x1 + 32); o.wy1 = (uint16_t)(wy1 < y1 + 32 ? wy1 : y1 + 32);
+      o.c_idx = (uint8_t)c; o.micro = (uint8_t)((micro ? 1 : 0) | (dense ? 2 : 0) | (front ? RUN_MICRO_FRONT : 0)); o.n_tus = (uint16_t)n;
+      o.first_tu = first_tu; o.res_offset = res_offset;
+      o.dep_offset = nd ? r_depoff[lane] : 0u; o.n_deps = (uint16_t)nd;
+      uint32_t acc = 0;
+      for (int wv = 0; wv < 4; wv++) { acc += r_cnt[wv][lane]; o.wave_end[wv] = (uint16_t)acc; }
+      o.n_lvls = (uint16_t)(nl > 0 ? nl - 1 : 0);
+      o.n_samples = (uint32_t)own_samples;
       B.runs[s] = o;
+      B.mbx[3 * (size_t)s] = mb_id; B.mbx[3 * (size_t)s + 1] = 0xFFFFFFFFu; B.mbx[3 * (size_t)s + 2] = 0xFFFFFFFFu;
+      B.pub_flag[s] = 0;
+      B.run_nall[s] = nd | ((fl & RF_FOREIGN) ? 0x80000000u : 0u);
     }
-    if (front) {
-      // algorithmic bytes of the front runs (bench: roofline of k_intra_front)
-      uint32_t alg = 0;
-      const uint32_t bpp = (uint32_t)(c ? P.bppC : P.bppY);
-      for (int k = lane; k < n; k += 64) { const uint32_t nT = 1u << rec_of(k).log2_size; alg += bpp * (4 * nT + 1) + bpp * nT * nT; }
-      alg = wave_sum_u(alg);
-      if (lane == 0) scan_add64(&B.counts->alg_intra_front, alg);
+    {
+      const uint64_t fm = __ballot(front);
+      uint32_t at = 0;
+      if (fm) {
+        if (lane == 0) at = atomicAdd(&B.counts->n_front, (uint32_t)__popcll(fm));
+        at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+        if (front) B.front_idx[at + (uint32_t)__popcll(fm & lanes_below(lane))] = s;
+      }
+      const uint32_t alg = wave_sum_u(front ? r_alg[lane] : 0u), lv = wave_sum_u(have_run ? (uint32_t)nl : 0u);
+      if (lane == 0) { if (alg) scan_add64(&B.counts->alg_intra_front, alg); atomicAdd(&B.counts->sum_lvls, lv); }
     }
     WAVE_ORDER();
   }
@@ -575,6 +797,7 @@ void k_scan_runs1(ScanBatch J)
 // runs scan_run2 on them (producers that are front runs leave the list; mailbox segments and need epochs of a reader).  The
 // logic is a few thousand scalar steps on ~40 records: not worth spreading over lanes, but on records in LDS it takes ~15 us
 // instead of the ~500 us a thread took that fetched them one by one from memory next to 63 others doing the same.
+#define SCR_MAX 256
 __global__ __launch_bounds__(64)
 void k_scan_runs2(ScanBatch J)
 {
@@ -620,15 +843,14 @@ void k_scan_order(ScanBatch J)
     const uint32_t n = B.counts->n_listed;
     for (uint32_t q = threadIdx.x; q < n; q += SCO_THREADS) scan_run3(P, B, B.run_list[q]);
   }
-  __threadfence();
+  // (one workgroup, one CU: what its threads have stored is visible to each other behind a barrier.  An agent-scope fence here -
+  //  __threadfence() - writes the whole L2 back, the reconstruction kernels' dirty lines included, once per wavefront: round 4)
   __syncthreads();
   scan_order_body(P, B, cap_levels);
   // ---- the scan's verdict and counts to the host: into the picture's pinned record, then its ready word (system scope)
-  __threadfence();
   __syncthreads();
   if (threadIdx.x < sizeof(ScanCounts) / 4 - 2 && B.host_counts)
-    reinterpret_cast<volatile uint32_t*>(B.host_counts)[threadIdx.x] = reinterpret_cast<volatile uint32_t*>(B.counts)[threadIdx.x];
-  __threadfence_system();
+    __hip_atomic_store(reinterpret_cast<uint32_t*>(B.host_counts) + threadIdx.x, reinterpret_cast<const uint32_t*>(B.counts)[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __syncthreads();
   if (threadIdx.x == 0 && B.host_counts) __hip_atomic_store(&B.host_counts->ready, B.ready_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -718,6 +940,65 @@ __device__ void scan_order_body(const ScanParams& P, const ScanBufs& B, uint32_t
   }
 }
 
+// ------------------------------------------------------------------------------------------------ before the passes
+__global__ __launch_bounds__(256)
+void k_build_prep(PrepBatch J)
+{
+  if (blockIdx.y >= (unsigned)J.n) return;
+  const PrepJob& Q = J.job[blockIdx.y];
+  const unsigned long long step = (unsigned long long)gridDim.x * 256 * 16, first = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 16;
+  {
+    uint4* z = reinterpret_cast<uint4*>(Q.zero);
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    for (unsigned long long at = first; at < Q.zero_bytes; at += step) z[at >> 4] = zero;
+  }
+  if (Q.ff) {
+    uint4* f = reinterpret_cast<uint4*>(Q.ff);
+    const uint4 ones = make_uint4(~0u, ~0u, ~0u, ~0u);
+    const unsigned long long whole = Q.ff_bytes & ~15ull;
+    for (unsigned long long at = first; at < whole; at += step) f[at >> 4] = ones;
+    if (blockIdx.x == 0 && threadIdx.x < (Q.ff_bytes & 15ull)) Q.ff[whole + threadIdx.x] = 0xFF;
+  }
+}
+
+// the motion planes of the batch's pictures from their PU records (k_lf.hip k_motion_from_pus, the same body): sixteen lanes per
+// PU, sixteen PUs per workgroup
+__global__ __launch_bounds__(256)
+void k_motion_batch(PrepBatch J)
+{
+  if (blockIdx.y >= (unsigned)J.n) return;
+  const PrepJob& Q = J.job[blockIdx.y];
+  const int i = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+  if (i >= Q.n_pus) return;
+  const de265hip_pu pu = Q.pus[i];
+  if (pu.slice_idx >= Q.n_slices) return;
+  de265hip_motion m;
+  for (int l = 0; l < 2; l++) {
+    const bool on = (pu.pred_flag >> l) & 1;
+    const int ri = pu.ref_idx[l];
+    m.ref_slot[l] = (on && ri >= 0 && ri < DE265HIP_MAX_REFS) ? Q.slices[pu.slice_idx].ref_pic_list[l][ri] : (int8_t)-1;
+    m.mv[l][0] = on ? pu.mv[l][0] : (int16_t)0; m.mv[l][1] = on ? pu.mv[l][1] : (int16_t)0;
+  }
+  m.pad[0] = m.pad[1] = 0;
+  const int bw = pu.w >> 2, bh = pu.h >> 2;
+  for (int q = sub; q < bw * bh; q += 16) {
+    const int x = (pu.x >> 2) + q % bw, y = (pu.y >> 2) + q / bw;
+    if (x < Q.w4 && y < Q.h4) Q.motion[x + y * Q.w4] = m;
+  }
+}
+
+hipError_t prep_enqueue_batch(hipStream_t st, const PrepBatch& J)
+{
+  if (J.n <= 0) return hipSuccess;
+  unsigned long long most = 0; int most_pus = 0;
+  for (int i = 0; i < J.n; i++) { most = std::max(most, std::max(J.job[i].zero_bytes, J.job[i].ff ? J.job[i].ff_bytes : 0ull)); most_pus = std::max(most_pus, J.job[i].ff ? J.job[i].n_pus : 0); }
+  // (a thread stores 16 bytes per step; 2048 workgroups at most: a grid that is resident at once)
+  const unsigned blocks = (unsigned)std::min<unsigned long long>(2048, (most + 256 * 16 - 1) / (256 * 16));
+  if (blocks) hipLaunchKernelGGL(k_build_prep, dim3(blocks, (unsigned)J.n), dim3(256), 0, st, J);
+  if (most_pus > 0) hipLaunchKernelGGL(k_motion_batch, dim3((most_pus + 15) / 16, (unsigned)J.n), dim3(256), 0, st, J);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ layout
 size_t ScanLayout::plan(const ScanParams& P, size_t at)
 {
@@ -768,14 +1049,16 @@ hipError_t scan_enqueue_batch(hipStream_t st, const ScanBatch& J)
   for (int i = 0; i < J.n; i++) { max_tus = std::max(max_tus, J.job[i].P.n_tus); max_ctbs = std::max(max_ctbs, J.job[i].P.n_ctbs); }
   const unsigned ny = (unsigned)J.n;
   if (max_tus > 0) hipLaunchKernelGGL(k_scan_tus, dim3((max_tus + 255) / 256, ny), dim3(256), 0, st, J);
-  hipLaunchKernelGGL(k_scan_prefix, dim3(1, ny), dim3(1024), 0, st, J);
+  bool any_empty = false;
+  for (int i = 0; i < J.n; i++) any_empty = any_empty || J.job[i].P.n_tus == 0;
+  if (any_empty || !J.pad) hipLaunchKernelGGL(k_scan_prefix, dim3(1, ny), dim3(256), 0, st, J);
   if (max_tus > 0) {
     hipLaunchKernelGGL(k_scan_ctbs, dim3(max_ctbs, ny), dim3(64), 0, st, J);
     // (the number of runs is only known on the device: fixed grids of wavefronts walk the run lists)
     // (512 wavefronts: with 128 / 256 / 512 / 1024 the product path of the bench made 1 860 / 2 310 / 2 630 / 2 380 pictures/s -
     //  fewer leave the run passes' latency chains too long, more crowd the reconstruction kernels of the other streams)
     static const int run_grid = getenv("DE265HIP_SCAN_RUN_GRID") ? atoi(getenv("DE265HIP_SCAN_RUN_GRID")) : 512;
-    hipLaunchKernelGGL(k_scan_runs1, dim3(run_grid, ny), dim3(64), 0, st, J);
+    hipLaunchKernelGGL(k_scan_runs1, dim3(max_ctbs, ny), dim3(64), 0, st, J);        // (a wavefront per CTB)
     hipLaunchKernelGGL(k_scan_runs2, dim3(run_grid, ny), dim3(64), 0, st, J);
   }
   hipLaunchKernelGGL(k_scan_order, dim3(1, ny), dim3(SCO_THREADS), 0, st, J);      // (always: it reports to the host)
@@ -785,7 +1068,7 @@ hipError_t scan_enqueue_batch(hipStream_t st, const ScanBatch& J)
 hipError_t scan_enqueue(hipStream_t st, const ScanParams& P, const ScanBufs& B, const ScanLayout& L, uint8_t* base, uint32_t cap_resid)
 {
   (void)base;
-  ScanBatch J; J.n = 1;
+  ScanBatch J; J.n = 1; J.pad = 0;
   J.job[0].P = P; J.job[0].B = B; J.job[0].cap_resid = cap_resid; J.job[0].cap_levels = L.cap_levels;
   return scan_enqueue_batch(st, J);
 }

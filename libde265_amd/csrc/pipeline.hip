@@ -52,11 +52,12 @@ struct de265hip_pipeline {
   uint64_t next_ticket = 0, next_launch = 0;    // tickets are handed out and launched in submission order
   int in_flight = 0;                            // queued or being built, not yet launched
   int window = 4;                               // bound of in_flight (submit blocks)
-  int batch = 2;                                // pictures enqueued together (their scans share their launches)
+  int batch = 4;                                // pictures enqueued together at most (their scans share their launches)
+  int chains = 2;                               // scans in flight at most (each a chain of kernels over up to `batch` pictures)
   bool stop = false;
   // DE265HIP_PIPE_TIMING=1: where the threads' time goes (seconds, summed; printed when the pipeline is freed)
   bool timing = false, tracing = false;
-  double t_idle = 0, t_build = 0, t_enqueue = 0, t_launch = 0, t_lidle = 0; long n_jobs = 0;
+  double t_idle = 0, t_build = 0, t_enqueue = 0, t_launch = 0, t_lidle = 0, t_chain = 0; long n_jobs = 0, n_chains = 0;
 };
 
 namespace {
@@ -104,7 +105,9 @@ void worker(de265hip_pipeline* p)
 // any order, and LAUNCHED in submission order (also when a picture failed: the turn must pass on).
 void launcher(de265hip_pipeline* p)
 {
-  int held = 0;                                  // rounds a partial batch has been held back
+  // pictures of the chains (upload + scan launched together) whose scans have not reported yet: the last picture of each
+  std::vector<de265hip_picture*> open_chains;
+  std::vector<double> open_since;
   for (;;) {
     de265hip_pipeline::Built todo; bool have_enq = false, have_launch = false;
     de265hip_picture* enq_pic[8]; uint64_t enq_tk[8]; int n_enq = 0;
@@ -113,27 +116,32 @@ void launcher(de265hip_pipeline* p)
       std::unique_lock<std::mutex> lk(p->mu);
       for (;;) {
         if (p->tracing) for (auto& kv : p->ready) if (kv.second.enqueued && kv.second.pic && kv.second.t_ready == 0 && de265hip_picture_ready(kv.second.pic) == 1) kv.second.t_ready = now();
-        // uploads and scans first: they run ahead of the launches on the copy streams (a picture launched right behind its
-        // enqueue makes the launcher wait for its scan, ~0.5 ms of device latency)
-        // (as many as a batch of the scan takes, DE265HIP_PIPE_BATCH, default 2: their passes share their kernel launches; a batch
-        //  is only held back for more pictures while the picture whose turn it is has been enqueued)
+        for (size_t i = 0; i < open_chains.size();)
+          if (de265hip_picture_ready(open_chains[i]) != 0) {
+            if (p->timing) p->t_chain += now() - open_since[i];
+            open_chains.erase(open_chains.begin() + i); open_since.erase(open_since.begin() + i);
+          } else i++;
+        // Uploads and scans first: they run ahead of the launches on the copy streams.  The scan of a picture is a chain of
+        // six dependent kernels, ~0.6 ms alone and 1-2 ms next to the reconstruction kernels, whatever the number of pictures
+        // it works on (grid.y = picture), and the device runs only so many chains at once (four scan streams per device): what
+        // counts is pictures per chain.  So a decoder keeps at most `chains` (DE265HIP_PIPE_CHAINS, default 2) in flight and
+        // hands the next one every picture that has been built meanwhile (up to DE265HIP_PIPE_BATCH): one picture at once when
+        // the device is idle, full batches when the scans are what everybody waits for.  (Round 4 before: every built picture
+        // enqueued at once, 1.5 pictures per chain on average, the scan streams saturated at 3 900 pictures/s without any
+        // reconstruction and 2 600 with it.)
         n_enq = 0;
-        for (auto& kv : p->ready) if (!kv.second.enqueued && !kv.second.rc && kv.second.pic && n_enq < p->batch) { enq_pic[n_enq] = kv.second.pic; enq_tk[n_enq++] = kv.first; }
-        if (n_enq) {
-          auto nx = p->ready.find(p->next_launch);
-          const bool next_waits_for_us = nx == p->ready.end() || !nx->second.enqueued;
-          if (n_enq >= p->batch || next_waits_for_us || p->in_flight <= n_enq || held > 3) { have_enq = true; held = 0; break; }
-          held++;
-        }
+        if ((int)open_chains.size() < p->chains)
+          for (auto& kv : p->ready) if (!kv.second.enqueued && !kv.second.rc && kv.second.pic && n_enq < p->batch) { enq_pic[n_enq] = kv.second.pic; enq_tk[n_enq++] = kv.first; }
+        if (n_enq) { have_enq = true; break; }
         auto it = p->ready.find(p->next_launch);
-        if (it != p->ready.end()) {
+        if (it != p->ready.end() && (it->second.enqueued || it->second.rc || !it->second.pic)) {
           // its turn - if its scan has reported (or it failed: the turn passes on).  The launcher never blocks on a scan while
-          // pictures may arrive that want enqueueing: a launcher that waited 0.9 ms for picture n's scan enqueued picture n + 1
-          // only then, and no two scans ever overlapped (round 4: 1 000 pictures/s per decoder whatever the copy streams)
+          // pictures may arrive that want enqueueing
           if (it->second.rc || !it->second.pic || de265hip_picture_ready(it->second.pic) != 0) { todo = it->second; p->ready.erase(it); have_launch = true; break; }
           p->cv_launch.wait_for(lk, std::chrono::microseconds(20));
           continue;
         }
+        if (!open_chains.empty() || it != p->ready.end()) { p->cv_launch.wait_for(lk, std::chrono::microseconds(20)); continue; }
         if (p->stop) return;
         p->cv_launch.wait(lk);
       }
@@ -141,6 +149,7 @@ void launcher(de265hip_pipeline* p)
     const double t1 = now();
     if (have_enq) {
       const int rc = de265hip_picture_enqueue_batch(enq_pic, n_enq);
+      if (!rc) { open_chains.push_back(enq_pic[n_enq - 1]); open_since.push_back(now()); p->n_chains++; }
       std::lock_guard<std::mutex> lk(p->mu);
       for (int i = 0; i < n_enq; i++) {
         auto it = p->ready.find(enq_tk[i]);
@@ -151,7 +160,8 @@ void launcher(de265hip_pipeline* p)
     }
     if (have_launch) {
       int r = todo.rc;
-      if (!r) r = de265hip_picture_run(p->dec, todo.pic, DE265HIP_STAGE_FINAL);
+      static const bool no_run = getenv("DE265HIP_PIPE_NO_RUN") != nullptr;      // (experiment: builds, uploads and scans only)
+      if (!r && !no_run) r = de265hip_picture_run(p->dec, todo.pic, DE265HIP_STAGE_FINAL);
       for (int c = 0; c < 3 && !r; c++)
         if (todo.job.plane[c]) r = de265hip_dpb_download_async(p->dec, todo.job.slot, c, todo.job.plane[c], todo.job.stride[c]);
       if (todo.pic) de265hip_picture_free(todo.pic);          // never waits (de265_hip.h LIFETIME)
@@ -180,7 +190,8 @@ int de265hip_pipeline_new(de265hip_pipeline** out, de265hip_decoder* dec, int n_
   p->window = 4 * n_workers + 4;
   if (const char* w = getenv("DE265HIP_PIPE_WINDOW")) p->window = std::max(1, atoi(w));
   if (const char* b = getenv("DE265HIP_PIPE_BATCH")) p->batch = std::min(8, std::max(1, atoi(b)));
-  p->window = std::max(p->window, 3 * p->batch + 2);
+  if (const char* c = getenv("DE265HIP_PIPE_CHAINS")) p->chains = std::min(8, std::max(1, atoi(c)));
+  p->window = std::max(p->window, p->chains * p->batch + 2 * n_workers + 4);       // (the chains full, every worker busy, a few to spare)
   for (int i = 0; i < n_workers; i++) p->th.emplace_back(worker, p);
   p->launcher_th = std::thread(launcher, p);
   *out = p;
@@ -271,9 +282,9 @@ void de265hip_pipeline_free(de265hip_pipeline* p)
   for (auto& t : p->th) t.join();
   p->launcher_th.join();
   if (p->timing && p->n_jobs)
-    fprintf(stderr, "de265hip pipeline: %ld pictures, %d workers + 1 launcher; ms per picture: workers idle %.2f build (host stage) %.2f | launcher idle %.2f enqueue (upload + scan) %.2f launch %.2f\n",
+    fprintf(stderr, "de265hip pipeline: %ld pictures, %d workers + 1 launcher; ms per picture: workers idle %.2f build (host stage) %.2f | launcher idle %.2f enqueue (upload + scan) %.2f launch %.2f | %.2f pictures per scan chain, a chain reports after %.2f ms\n",
             p->n_jobs, p->n_workers, 1e3 * p->t_idle / p->n_jobs, 1e3 * p->t_build / p->n_jobs, 1e3 * p->t_lidle / p->n_jobs,
-            1e3 * p->t_enqueue / p->n_jobs, 1e3 * p->t_launch / p->n_jobs);
+            1e3 * p->t_enqueue / p->n_jobs, 1e3 * p->t_launch / p->n_jobs, (double)p->n_jobs / std::max(1L, p->n_chains), 1e3 * p->t_chain / std::max(1L, p->n_chains));
   if (p->tracing) for (auto& r : p->trace) fprintf(stderr, "pipetrace %p %.0f %.6f %.6f %.6f %.6f %.6f %.6f %.6f\n", (void*)p, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
   delete p;
 }

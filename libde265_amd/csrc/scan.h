@@ -23,6 +23,20 @@ struct ScanLayout {
 struct ScanJob { ScanParams P; ScanBufs B; uint32_t cap_resid, cap_levels; };
 struct ScanBatch { int n; int pad; ScanJob job[SCAN_BATCH]; };
 hipError_t scan_enqueue_batch(hipStream_t st, const ScanBatch& J);
+
+// what has to be set before the passes (and the picture's kernels) may run, for the pictures of a batch in ONE launch each:
+// the cleared region of the arena (k_run's flags and mailboxes, the scan's counters and cell maps), the motion plane set to
+// "no reference" and then filled from the PU records.  (Round 4 first issued these per picture - two memsets and a kernel,
+// twelve launches ahead of a batch of four scans, each 50-150 us next to the reconstruction kernels of the other streams:
+// a third of the time a batch held its stream.)
+struct PrepJob {
+  uint8_t* zero; unsigned long long zero_bytes;      // multiples of 16 bytes, 16-byte aligned
+  uint8_t* ff; unsigned long long ff_bytes;          // the motion plane (nullptr: the host supplied it)
+  const de265hip_pu* pus; const de265hip_slice_params* slices; de265hip_motion* motion;
+  int n_pus, n_slices, w4, h4;
+};
+struct PrepBatch { int n; int pad; PrepJob job[SCAN_BATCH]; };
+hipError_t prep_enqueue_batch(hipStream_t st, const PrepBatch& J);
 hipError_t scan_enqueue(hipStream_t st, const ScanParams& P, const ScanBufs& B, const ScanLayout& L, uint8_t* base, uint32_t cap_resid);
 void scan_host_run(const ScanParams& P, const ScanBufs& B, const ScanLayout& L, uint8_t* base, uint32_t cap_resid);
 
