@@ -284,6 +284,12 @@ int  de265hip_dpb_upload(de265hip_decoder*, int slot, int c_idx,
                          const void* src, ptrdiff_t stride_bytes);
 int  de265hip_dpb_download(de265hip_decoder*, int slot, int c_idx,
                            void* dst, ptrdiff_t stride_bytes);
+/* Set every sample of the picture in `slot` (allocated before: de265hip_dpb_alloc) to one value per component.  Replaces
+ * de265_image::fill_image (image.cc) where libde265 synthesises a reference picture that the stream does not contain -
+ * generate_unavailable_reference_picture, decctx.cc:1408-1434: 1 << (bitDepth - 1) in all three planes - so that pictures
+ * which predict from it find it in the device-resident DPB (a stream joined at a CRA picture, a lost picture).
+ * DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE for an unallocated slot or a value beyond the component's bit depth. */
+int  de265hip_dpb_fill(de265hip_decoder*, int slot, int y, int cb, int cr);
 /* Picture-level pipelining (the reference's parallel host side is decctx.cc:976-1178): copy a plane out
  * WITHOUT waiting on the host.  The copy is ordered behind everything enqueued on the decoder's stream so far (the
  * picture's kernels) and runs on the decoder's output stream, so the kernels of the pictures enqueued after it overlap

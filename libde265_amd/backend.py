@@ -18,7 +18,7 @@ SO_PATH = os.environ.get("DE265HIP_SO") or os.path.join(_HERE, "libde265_hip.so"
 EXPORTS = [
     "de265hip_version", "de265hip_device_count",
     "de265hip_decoder_new", "de265hip_decoder_free", "de265hip_decoder_set_lanes",
-    "de265hip_dpb_alloc", "de265hip_dpb_alloc_ex", "de265hip_dpb_chroma_format", "de265hip_dpb_upload", "de265hip_dpb_download", "de265hip_dpb_plane", "de265hip_dpb_info",
+    "de265hip_dpb_alloc", "de265hip_dpb_alloc_ex", "de265hip_dpb_chroma_format", "de265hip_dpb_upload", "de265hip_dpb_fill", "de265hip_dpb_download", "de265hip_dpb_plane", "de265hip_dpb_info",
     "de265hip_dpb_copy", "de265hip_dpb_download_async", "de265hip_dpb_wait", "de265hip_host_alloc", "de265hip_host_free",
     "de265hip_pipeline_new", "de265hip_pipeline_submit", "de265hip_pipeline_submit_desc", "de265hip_pipeline_wait", "de265hip_pipeline_drain", "de265hip_pipeline_free",
     "de265hip_debug_build_host_only", "de265hip_debug_last_build_hash", "de265hip_debug_build_host_only_ex",
@@ -66,6 +66,7 @@ def lib():
     L.de265hip_dpb_alloc_ex.argtypes = [vp, i32, i32, i32, i32, i32, i32]
     L.de265hip_dpb_chroma_format.argtypes = [vp, i32]
     L.de265hip_dpb_upload.argtypes = [vp, i32, i32, vp, C.c_ssize_t]
+    L.de265hip_dpb_fill.argtypes = [vp, i32, i32, i32, i32]
     L.de265hip_dpb_download.argtypes = [vp, i32, i32, vp, C.c_ssize_t]
     L.de265hip_dpb_plane.argtypes = [vp, i32, i32, pp(vp), pp(C.c_ssize_t)]
     L.de265hip_dpb_info.argtypes = [vp, i32, pp(i32), pp(i32), pp(i32), pp(i32)]
@@ -313,6 +314,10 @@ class Decoder:
         for c, p in enumerate(planes):
             p = np.ascontiguousarray(p)
             _chk(lib().de265hip_dpb_upload(self._h, slot, c, p.ctypes.data, p.strides[0]), "dpb_upload")
+
+    def fill(self, slot, y, cb, cr):
+        """every sample of the slot's planes set to one value per component (an unavailable reference picture, decctx.cc:1408-1434)"""
+        _chk(lib().de265hip_dpb_fill(self._h, slot, int(y), int(cb), int(cr)), "dpb_fill")
 
     def download(self, slot, width, height, bit_depth):
         dt = np.uint16 if bit_depth > 8 else np.uint8

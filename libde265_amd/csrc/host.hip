@@ -842,6 +842,32 @@ int de265hip_dpb_upload(de265hip_decoder* d, int slot, int c, const void* src, p
   return 0;
 }
 
+// de265hip_dpb_fill: every sample of the slot's three planes set to one value per component - what libde265 does on the host for a
+// reference picture the stream does not contain (generate_unavailable_reference_picture, decctx.cc:1408-1434:
+// fill_image(1 << (bitDepth - 1)), image.cc fill_image) before it decodes pictures that predict from it.  Device memsets on the
+// decoder's stream; like an upload, a synchronisation point of the decoder's lanes.
+int de265hip_dpb_fill(de265hip_decoder* d, int slot, int y, int cb, int cr)
+{
+  const int val[3] = { y, cb, cr };
+  for (int c = 0; c < 3; c++) {
+    Slot* s; int w, h; size_t bpp;
+    const int rc = plane_geom(d, slot, c, &s, &w, &h, &bpp); if (rc) return rc;
+    if (val[c] < 0 || val[c] >= (1 << (c ? s->bdC : s->bdY))) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+    if (w == 0 || h == 0) continue;                      // (a chroma plane of a monochrome picture)
+    if (c == 0) {
+      if (s->dl_done && s->dl_waited != s->dl_seq) HIPCHK(hipEventSynchronize(s->dl_done), DE265HIP_ERROR_DECODING);
+      HIPCHK(sync_all_lanes(d), DE265HIP_ERROR_DECODING);
+      std::lock_guard<std::mutex> lk(d->mu); slot_settled(*s);
+    }
+    // (the rows with their padding: the plane is one allocation of stride x height samples)
+    const size_t n = (size_t)s->pl[c].stride * (size_t)h;
+    if (bpp == 2) HIPCHK(hipMemsetD16Async((hipDeviceptr_t)s->pl[c].ptr, (unsigned short)val[c], n, d->stream), DE265HIP_ERROR_DECODING);
+    else HIPCHK(hipMemsetD8Async((hipDeviceptr_t)s->pl[c].ptr, (unsigned char)val[c], n, d->stream), DE265HIP_ERROR_DECODING);
+  }
+  HIPCHK(hipStreamSynchronize(d->stream), DE265HIP_ERROR_DECODING);
+  return 0;
+}
+
 int de265hip_dpb_download(de265hip_decoder* d, int slot, int c, void* dst, ptrdiff_t stride_bytes)
 {
   Slot* s; int w, h; size_t bpp;

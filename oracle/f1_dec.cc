@@ -44,25 +44,30 @@ int main(int argc, char** argv)
   f1_install_pinned_allocator(ctx);                        // offload mode only
   const auto t0 = std::chrono::steady_clock::now();
   unsigned char buf[65536];
-  int n_out = 0, more = 1;
+  int n_out = 0, more = 1, failed = 0;
   size_t n;
-  while ((n = fread(buf, 1, sizeof(buf), f)) > 0) {
-    if (de265_push_data(ctx, buf, (int)n, 0, NULL) != DE265_OK) return 3;
+  // a decode error (the reference's own, or - offload mode - the back end's, which de265_decode hands through) ends the loop;
+  // the decoder is still drained and freed, the exit code says that the decode failed
+  while (!failed && (n = fread(buf, 1, sizeof(buf), f)) > 0) {
+    if (de265_push_data(ctx, buf, (int)n, 0, NULL) != DE265_OK) { failed = 3; break; }
     for (;;) {
       de265_error e = de265_decode(ctx, &more);
+      if (e != DE265_OK && e != DE265_ERROR_WAITING_FOR_INPUT_DATA) { fprintf(stderr, "decode error %d: %s\n", (int)e, de265_get_error_text(e)); failed = 4; break; }
       while (const de265_image* im = de265_get_next_picture(ctx)) { n_out++; write_picture(out, im); }
       if (e == DE265_ERROR_WAITING_FOR_INPUT_DATA || !more) break;
-      if (e != DE265_OK) { fprintf(stderr, "decode error: %s\n", de265_get_error_text(e)); return 4; }
     }
   }
-  de265_flush_data(ctx);
-  more = 1;
-  while (more) {
-    de265_error e = de265_decode(ctx, &more);
-    while (const de265_image* im = de265_get_next_picture(ctx)) { n_out++; write_picture(out, im); }
-    if (e != DE265_OK && e != DE265_ERROR_WAITING_FOR_INPUT_DATA) break;
+  if (!failed) {
+    de265_flush_data(ctx);
+    more = 1;
+    while (more) {
+      de265_error e = de265_decode(ctx, &more);
+      if (e != DE265_OK && e != DE265_ERROR_WAITING_FOR_INPUT_DATA) { fprintf(stderr, "decode error %d: %s\n", (int)e, de265_get_error_text(e)); failed = 4; break; }
+      while (const de265_image* im = de265_get_next_picture(ctx)) { n_out++; write_picture(out, im); }
+      if (e != DE265_OK) break;
+    }
   }
-  f1_drain();
+  if (const int frc = f1_drain()) { if (!failed) fprintf(stderr, "decode error %d (reported when the pipeline was drained)\n", frc); failed = 4; }
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   for (;;) {
     de265_error w = de265_get_warning(ctx);
@@ -74,5 +79,5 @@ int main(int argc, char** argv)
   if (out) fclose(out);
   printf("%d pictures\n", n_out);
   if ((e = getenv("F1_TIMING")) && atoi(e)) printf("%.3f s  %.2f pictures/s\n", secs, n_out / secs);
-  return 0;
+  return failed;
 }

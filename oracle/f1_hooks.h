@@ -26,7 +26,12 @@ void f1_record_pcm(thread_context* tctx, int x0, int y0, int log2CbSize);
 /* true: the picture was reconstructed, deblocked and SAO-filtered by the HIP back end and copied into img's planes (the
  * caller skips run_postprocessing_filters_*); false: dump mode, the caller carries on */
 bool f1_submit(de265_image* img);
-void f1_picture_done(de265_image* img);
+/* returns 0, or - offload mode - the error of the back end (a de265_error number, de265.h:82-139): decode_some returns it, so
+ * de265_decode does (errors reach the application through the decoder's own channel, not through exit) */
+int f1_picture_done(de265_image* img);
+/*   libde265/decctx.cc:1408  generate_unavailable_reference_picture -> f1_unavailable_reference: the grey picture libde265
+ *                             synthesises for a reference the stream does not contain goes into the device-resident DPB too */
+void f1_unavailable_reference(de265_image* img, int idx);
 /* SURVEY 8(f3), F1_MODE=hip F1_PIPELINE=1: f1_submit only ENQUEUES the picture (a submit thread builds the command buffers
  * and launches; the copy-out into libde265's pinned planes is asynchronous) and libde265 carries on parsing; the picture is
  * waited for where somebody is about to look at it: de265_peek_next_picture (de265.cc:392) -> f1_before_output. */
@@ -37,5 +42,5 @@ bool f1_offloading();
 /* for the application (oracle/f1_dec.cc): install the pinned-memory image allocator (de265.h:325-343) before decoding, and
  * drain the pipeline before the decoder is freed */
 void f1_install_pinned_allocator(void* de265_decoder_ctx);
-void f1_drain();
+int f1_drain();                        /* 0, or the back end's error (see f1_picture_done) */
 #endif

@@ -149,6 +149,8 @@ struct Hip {
   void (*picture_free)(de265hip_picture*);
   int  (*dpb_download_async)(de265hip_decoder*, int, int, void*, ptrdiff_t);
   int  (*dpb_wait)(de265hip_decoder*, int);
+  int  (*dpb_fill)(de265hip_decoder*, int, int, int, int);
+  int  (*dpb_upload)(de265hip_decoder*, int, int, const void*, ptrdiff_t);
   void* (*host_alloc)(size_t);
   void (*host_free)(void*);
   int  (*pipeline_new)(de265hip_pipeline**, de265hip_decoder*, int);
@@ -162,7 +164,19 @@ struct Hip {
 };
 Hip H;
 
-[[noreturn]] void hip_die(const char* what, int rc) { fprintf(stderr, "f1_recorder (hip mode): %s failed (%d)\n", what, rc); exit(6); }
+[[noreturn]] void hip_die(const char* what, int rc) { fprintf(stderr, "f1_recorder (hip mode): %s failed (%d)\n", what, rc); exit(6); }   // (start-up only: no library, no device)
+/* A back-end call failed while decoding: the first such error is kept and becomes the result of de265_decode (the hook behind
+ * the picture, f1_picture_done, returns it; de265.h:82-139 - the back end's codes are de265_error numbers), the picture is
+ * marked (image.h:57-61 integrity), and the hooks stop handing pictures over.  The decoder stays usable for de265_free_decoder. */
+std::mutex err_mu;
+int hip_error = 0;
+int hip_fail(const char* what, int rc)
+{
+  std::lock_guard<std::mutex> lk(err_mu);
+  if (!hip_error) { hip_error = rc ? rc : DE265HIP_ERROR_DECODING; fprintf(stderr, "f1_recorder (hip mode): %s failed (%d)\n", what, rc); }
+  return hip_error;
+}
+int hip_failed() { std::lock_guard<std::mutex> lk(err_mu); return hip_error; }
 
 bool hip_mode()
 {
@@ -176,7 +190,7 @@ bool hip_mode()
 #define SYM(f) do { *(void**)&H.f = dlsym(H.lib, "de265hip_" #f); if (!H.f) hip_die("dlsym de265hip_" #f, 0); } while (0)
   SYM(decoder_new); *(void**)&H.dpb_alloc = dlsym(H.lib, "de265hip_dpb_alloc_ex"); if (!H.dpb_alloc) hip_die("dlsym de265hip_dpb_alloc_ex", 0); SYM(dpb_download); SYM(recorder_new); SYM(recorder_free); SYM(record_tu); SYM(record_pu);
   SYM(record_pcm); SYM(record_slice); SYM(record_ctb); SYM(record_blk_planes); SYM(recorder_submit); SYM(picture_run);
-  SYM(decoder_sync); SYM(picture_free); SYM(dpb_download_async); SYM(dpb_wait); SYM(host_alloc); SYM(host_free);
+  SYM(decoder_sync); SYM(picture_free); SYM(dpb_fill); SYM(dpb_upload); SYM(dpb_download_async); SYM(dpb_wait); SYM(host_alloc); SYM(host_free);
   SYM(pipeline_new); SYM(pipeline_submit); SYM(pipeline_wait); SYM(pipeline_drain); SYM(pipeline_free);
 #undef SYM
   const char* pl = getenv("F1_PIPELINE");
@@ -184,6 +198,11 @@ bool hip_mode()
   H.n_workers = H.pipeline ? std::min(8, std::max(1, atoi(pl))) : 1;
   int rc = H.decoder_new(&H.dec, -1);
   if (rc) hip_die("de265hip_decoder_new", rc);
+  if (const char* fi = getenv("F1_FAULT")) {             // tests: the one failure the device side admits (a dependency wait that expires)
+    int (*inject)(de265hip_decoder*, int, uint32_t) = nullptr;
+    *(void**)&inject = dlsym(H.lib, "de265hip_debug_fault_injection");
+    if (!inject || inject(H.dec, 1, (uint32_t)std::max(1, atoi(fi)))) hip_die("de265hip_debug_fault_injection", 0);
+  }
   H.on = true;
   return true;
 }
@@ -343,51 +362,55 @@ void prepare_job(Job* job, bool hip)
  * to the MI355X.  build_job: the product's recorder + host stage (any thread, several pictures at once: de265_hip.h THREADS);
  * launch_job: kernels + copy-out, in decode order.  wait = true: ... and wait (the picture is in the decoder's planes on
  * return); wait = false: the copy-out into the (pinned) planes is only enqueued; f1_before_output waits. */
-void build_job(Job& j)
+bool build_job(Job& j)
 {
   int rc;
   const double t0 = now_s();
-  if ((rc = H.recorder_new(&j.rec, &j.P, j.scaling.empty() ? NULL : j.scaling.data()))) hip_die("recorder_new", rc);
+#define TRY(call, what) do { if ((rc = (call))) { hip_fail(what, rc); return false; } } while (0)
+  TRY(H.recorder_new(&j.rec, &j.P, j.scaling.empty() ? NULL : j.scaling.data()), "recorder_new");
   de265hip_recorder* rec = j.rec;
-  for (const auto& sl : j.slices) if ((rc = H.record_slice(rec, &sl))) hip_die("record_slice", rc);
-  for (size_t a=0;a<j.ctbs.size();a++) if ((rc = H.record_ctb(rec, (int)a, &j.ctbs[a]))) hip_die("record_ctb", rc);
-  for (const auto& t : j.M.tus) if ((rc = H.record_tu(rec, &t, j.M.cval.data()+t.coeff_offset, j.M.cpos.data()+t.coeff_offset))) hip_die("record_tu", rc);
-  for (const auto& pu : j.M.pus) if ((rc = H.record_pu(rec, &pu))) hip_die("record_pu", rc);
-  for (const auto& pc : j.M.pcms) if ((rc = H.record_pcm(rec, pc.x0, pc.y0, pc.log2_cb_size, j.M.pcm_samples.data()+pc.sample_offset))) hip_die("record_pcm", rc);
-  if ((rc = H.record_blk_planes(rec, j.flags.data(), j.qp.data(), j.mot.data()))) hip_die("record_blk_planes", rc);
+  for (const auto& sl : j.slices) TRY(H.record_slice(rec, &sl), "record_slice");
+  for (size_t a=0;a<j.ctbs.size();a++) TRY(H.record_ctb(rec, (int)a, &j.ctbs[a]), "record_ctb");
+  for (const auto& t : j.M.tus) TRY(H.record_tu(rec, &t, j.M.cval.data()+t.coeff_offset, j.M.cpos.data()+t.coeff_offset), "record_tu");
+  for (const auto& pu : j.M.pus) TRY(H.record_pu(rec, &pu), "record_pu");
+  for (const auto& pc : j.M.pcms) TRY(H.record_pcm(rec, pc.x0, pc.y0, pc.log2_cb_size, j.M.pcm_samples.data()+pc.sample_offset), "record_pcm");
+  TRY(H.record_blk_planes(rec, j.flags.data(), j.qp.data(), j.mot.data()), "record_blk_planes");
   const double t1 = now_s();
   {                                                                 // slot allocation belongs to one thread at a time
     static std::mutex am; std::lock_guard<std::mutex> lk(am);
-    if ((rc = H.dpb_alloc(H.dec, j.slot, j.P.width, j.P.height, j.P.bit_depth_luma, j.P.bit_depth_chroma, j.P.chroma_format_idc))) hip_die("dpb_alloc", rc);
+    TRY(H.dpb_alloc(H.dec, j.slot, j.P.width, j.P.height, j.P.bit_depth_luma, j.P.bit_depth_chroma, j.P.chroma_format_idc), "dpb_alloc");
   }
-  if ((rc = H.recorder_submit(H.dec, j.slot, rec, &j.pic))) hip_die("recorder_submit", rc);
+  TRY(H.recorder_submit(H.dec, j.slot, rec, &j.pic), "recorder_submit");
   static std::mutex pm; std::lock_guard<std::mutex> lk(pm);
   PR.record += t1-t0; PR.submit += now_s()-t1;
+  return true;
 }
 
-void launch_job(Job& j, bool wait)
+bool launch_job(Job& j, bool wait)
 {
   int rc;
   const double t2 = now_s();
-  if ((rc = H.picture_run(H.dec, j.pic, DE265HIP_STAGE_FINAL))) hip_die("picture_run", rc);
+  TRY(H.picture_run(H.dec, j.pic, DE265HIP_STAGE_FINAL), "picture_run");
   const double t3 = now_s();
   if (wait) {
-    if ((rc = H.decoder_sync(H.dec))) hip_die("decoder_sync", rc);
+    TRY(H.decoder_sync(H.dec), "decoder_sync");
     for (int c=0;c<3;c++)                                           // the GPU's picture becomes the decoder's picture
-      if ((rc = H.dpb_download(H.dec, j.slot, c, j.plane[c], j.stride_bytes[c]))) hip_die("dpb_download", rc);
+      TRY(H.dpb_download(H.dec, j.slot, c, j.plane[c], j.stride_bytes[c]), "dpb_download");
   } else {
     for (int c=0;c<3;c++)
-      if ((rc = H.dpb_download_async(H.dec, j.slot, c, j.plane[c], j.stride_bytes[c]))) hip_die("dpb_download_async", rc);
+      TRY(H.dpb_download_async(H.dec, j.slot, c, j.plane[c], j.stride_bytes[c]), "dpb_download_async");
   }
+#undef TRY
   static std::mutex pm; std::lock_guard<std::mutex> lk(pm);
   PR.run += t3-t2; PR.out += now_s()-t3;
+  return true;
 }
 
 void free_job(Job& j)
 {
   const double t0 = now_s();
-  H.picture_free(j.pic);                                            // never waits: the decoder owns the device side (de265_hip.h LIFETIME)
-  H.recorder_free(j.rec);
+  if (j.pic) H.picture_free(j.pic);                                 // never waits: the decoder owns the device side (de265_hip.h LIFETIME)
+  if (j.rec) H.recorder_free(j.rec);
   j.pic = NULL; j.rec = NULL;
   j.M = PicRec(); j.flags = std::vector<uint8_t>(); j.qp = std::vector<int8_t>(); j.mot = std::vector<de265hip_motion>();
   static std::mutex pm; std::lock_guard<std::mutex> lk(pm);
@@ -425,10 +448,10 @@ int prepare_cb(void* user, de265hip_recorder** out)
 void pipe_submit(const de265_image* img, std::shared_ptr<Job> j)
 {
   int rc;
-  if (!H.pipe && (rc = H.pipeline_new(&H.pipe, H.dec, H.n_workers))) hip_die("pipeline_new", rc);
+  if (!H.pipe && (rc = H.pipeline_new(&H.pipe, H.dec, H.n_workers))) { hip_fail("pipeline_new", rc); return; }
   uint64_t ticket = 0;
   const double t0 = now_s();
-  if ((rc = H.pipeline_submit(H.pipe, j->slot, prepare_cb, j.get(), j->plane, j->stride_bytes, &ticket))) hip_die("pipeline_submit", rc);
+  if ((rc = H.pipeline_submit(H.pipe, j->slot, prepare_cb, j.get(), j->plane, j->stride_bytes, &ticket))) { hip_fail("pipeline_submit", rc); return; }
   PR.w_queue += now_s()-t0;
   std::lock_guard<std::mutex> lk(pend_mu);
   pending[img] = Pend{ j, ticket };
@@ -446,7 +469,7 @@ void pipe_wait(const de265_image* img)
   }
   const double t0 = now_s();
   int rc = H.pipeline_wait(H.pipe, p.ticket);
-  if (rc) hip_die("pipeline_wait", rc);
+  if (rc) { hip_fail("pipeline_wait", rc); const_cast<de265_image*>(img)->integrity = INTEGRITY_DECODING_ERRORS; }      // (image.h:57-61)
   PR.w_out += now_s()-t0;
 }
 
@@ -495,17 +518,42 @@ bool f1_offloading() { return hip_mode(); }
 
 void f1_before_output(const de265_image* img) { if (H.on && H.pipeline) pipe_wait(img); }
 
-void f1_drain()
+int f1_drain()
 {
-  if (!(H.on && H.pipeline)) { prof_print(); return; }
+  if (!(H.on && H.pipeline)) { prof_print(); return H.on ? hip_failed() : 0; }
   if (H.pipe) {
     int rc = H.pipeline_drain(H.pipe);
-    if (rc) hip_die("pipeline_drain", rc);
+    if (rc) hip_fail("pipeline_drain", rc);
     H.pipeline_free(H.pipe);                             // joins the workers before the process tears its statics down
     H.pipe = nullptr;
   }
   { std::lock_guard<std::mutex> lk(pend_mu); pending.clear(); }
   prof_print();
+  return hip_failed();
+}
+
+/* decctx.cc:1408-1434 generate_unavailable_reference_picture: libde265 has just filled DPB entry `idx` with mid-grey on the host
+ * (a reference picture the stream does not contain: a lost picture, a stream joined at a CRA picture).  The pictures that
+ * predict from it are reconstructed on the device: the same picture goes into the device-resident DPB (the slot IS the
+ * index).  Pictures still on their way through the pipeline may read what the slot held before: they go first. */
+void f1_unavailable_reference(de265_image* img, int idx)
+{
+  if (passive() || !hip_mode() || hip_failed()) return;
+  if (idx < 0 || idx >= DE265HIP_MAX_DPB_SLOTS) { hip_fail("libde265 holds more pictures than the back end has DPB slots", idx); return; }
+  int rc;
+  if (H.pipe && (rc = H.pipeline_drain(H.pipe))) { hip_fail("pipeline_drain", rc); return; }
+  const seq_parameter_set& sps = img->get_sps();
+  if ((rc = H.dpb_alloc(H.dec, idx, img->get_width(0), img->get_height(0), sps.BitDepth_Y, sps.BitDepth_C, sps.chroma_format_idc))) { hip_fail("dpb_alloc", rc); return; }
+  if (sps.BitDepth_Y <= 8 && sps.BitDepth_C <= 8) {
+    if ((rc = H.dpb_fill(H.dec, idx, 1 << (sps.BitDepth_Y - 1), 1 << (sps.BitDepth_C - 1), 1 << (sps.BitDepth_C - 1)))) hip_fail("dpb_fill", rc);
+    return;
+  }
+  // Samples wider than 8 bits: the reference's fill_image is a BYTE memset over stride x height bytes (image.cc:510-523) - it
+  // writes the low byte of the value (0 for 1 << 8 and up) into the first half of each plane and leaves the second half as
+  // the allocator handed it out.  What libde265 predicts from is that picture, not the one 8.3.3.2 describes: it is
+  // mirrored as it is.
+  for (int c = 0; c < (sps.chroma_format_idc ? 3 : 1); c++)
+    if ((rc = H.dpb_upload(H.dec, idx, c, img->get_image_plane(c), (ptrdiff_t)img->get_image_stride(c) * img->get_bytes_per_pixel(c)))) { hip_fail("dpb_upload", rc); return; }
 }
 
 bool f1_record_tu(thread_context* tctx, int x0, int y0, int nT, int cIdx, int cuPredMode, bool cbf)
@@ -592,11 +640,16 @@ bool f1_submit(de265_image* img)
   take_records(job->recs);
   if (hip) {
     // ---- OFFLOAD
+    if (hip_failed()) { img->integrity = INTEGRITY_DECODING_ERRORS; return true; }      // (an earlier picture failed: de265_decode is about to say so)
     job->slot = dpb_index_of(img);                                  // reference lists name libde265's DPB indices: the slot IS the index
-    if (job->slot >= DE265HIP_MAX_DPB_SLOTS) hip_die("libde265 holds more pictures than the back end has DPB slots", job->slot);
+    if (job->slot >= DE265HIP_MAX_DPB_SLOTS) { hip_fail("libde265 holds more pictures than the back end has DPB slots", job->slot); return true; }
     for (int c=0;c<3;c++) { job->plane[c] = img->get_image_plane(c); job->stride_bytes[c] = (ptrdiff_t)img->get_image_stride(c)*img->get_bytes_per_pixel(c); }
     if (H.pipeline) pipe_submit(img, job);                          // the workers prepare, build and launch; libde265 goes on parsing
-    else { prepare_job(job.get(), true); build_job(*job); launch_job(*job, true); free_job(*job); }
+    else {
+      prepare_job(job.get(), true);
+      if (!(build_job(*job) && launch_job(*job, true))) img->integrity = INTEGRITY_DECODING_ERRORS;
+      free_job(*job);
+    }
     S.n_pictures++;
     return true;
   }
@@ -642,12 +695,12 @@ bool f1_submit(de265_image* img)
   return false;
 }
 
-void f1_picture_done(de265_image* img)
+int f1_picture_done(de265_image* img)
 {
-  if (passive()) return;
+  if (passive()) return 0;
   if (hip_mode()) {                                    // libde265 checks the picture hash SEI right after this hook (decctx.cc:768-778)
-    if (H.pipeline && img->decctx->param_sei_check_hash) pipe_wait(img);
-    return;
+    if (H.pipeline && img->decctx->param_sei_check_hash && !hip_failed()) pipe_wait(img);
+    return hip_failed();
   }
   const int w4 = (img->get_width(0)+3)/4, h4 = (img->get_height(0)+3)/4;
   std::vector<uint8_t> edges((size_t)w4*h4);
@@ -655,11 +708,12 @@ void f1_picture_done(de265_image* img)
   put(edges.data(), edges.size());
   put_planes(img);                                     // ... and after deblocking + SAO
   const char* dir = getenv("F1_OUT");
-  if (!dir) return;                                    // passive()
+  if (!dir) return 0;                                  // passive()
   char name[1024];
   snprintf(name, sizeof(name), "%s/pic_%03d.f1", dir, S.n_pictures++);
   FILE* f = fopen(name, "wb");
   if (!f || fwrite(S.file.data(), 1, S.file.size(), f) != S.file.size()) { fprintf(stderr, "f1_recorder: cannot write %s\n", name); exit(5); }
   fclose(f);
   S.file.clear();
+  return 0;
 }

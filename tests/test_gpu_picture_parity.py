@@ -1021,3 +1021,51 @@ def test_range_extension_pictures_against_the_oracle(seed, cf):
         pic.free()
     finally:
         d.close()
+
+
+@pytest.mark.parametrize("bd,cf", [(8, 1), (10, 1), (10, 3)])
+def test_dpb_fill_makes_the_unavailable_reference_picture_of_libde265(dec, bd, cf):
+    """de265hip_dpb_fill (generate_unavailable_reference_picture, decctx.cc:1408-1434: fill_image(1 << (bitDepth - 1)) on the
+    host): the slot holds the constant picture, a B picture that predicts from it equals the oracle's with that reference,
+    values beyond the bit depth and unallocated slots are refused."""
+    w, h = 416, 240
+    grey = 1 << (bd - 1)
+    dec.dpb_alloc(0, w, h, bd, chroma_format=cf)
+    dec.upload(0, pysynth.fill_planes(w, h, bd, 41, chroma_format=cf) if cf != 1 else pysynth.fill_planes(w, h, bd, 41))
+    dec.fill(0, grey, grey, grey)
+    got = dec.download(0, w, h, bd)
+    assert all((p == grey).all() for p in got)
+    dec.fill(0, 0, (1 << bd) - 1, 3)
+    got = dec.download(0, w, h, bd)
+    assert (got[0] == 0).all() and (got[1] == (1 << bd) - 1).all() and (got[2] == 3).all()
+    with pytest.raises(backend.De265HipError):
+        dec.fill(0, 1 << bd, 0, 0)
+    d2 = backend.Decoder()
+    try:
+        with pytest.raises(backend.De265HipError):
+            d2.fill(0, grey, grey, grey)                 # never allocated
+    finally:
+        d2.close()
+    if cf != 1:
+        return
+    # a picture predicted from the synthesised reference
+    sp = pysynth.SynthPicture(pysynth.default_config(w, h, bd, 0, seed=7100 + bd, intra_pct=10))
+    refs = {}
+    for slot in (0, 1):
+        dec.dpb_alloc(slot, w, h, bd)
+        dec.fill(slot, grey, grey, grey)
+        refs[slot] = [np.full_like(p, grey) for p in pysynth.fill_planes(w, h, bd, 1)]
+    init = pysynth.fill_planes(w, h, bd, 999)
+    exp = [p.copy() for p in init]
+    pyoracle.reconstruct(sp.desc, sp.order, refs, exp)
+    dec.dpb_alloc(2, w, h, bd)
+    dec.upload(2, init)
+    pic = dec.build(2, sp.desc)
+    try:
+        dec.run(pic, _abi.STAGE_FINAL)
+        dec.sync()
+        got = dec.download(2, w, h, bd)
+        for c in range(3):
+            assert np.array_equal(got[c], exp[c]), "component %d differs from the oracle" % c
+    finally:
+        pic.free()

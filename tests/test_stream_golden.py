@@ -213,3 +213,75 @@ def test_full_size_synthetic_streams_decode_identically_with_the_hip_back_end(na
                 first = int(np.nonzero(A != B)[0][0])
                 raise AssertionError("%s %s: HIP-backed decode differs from the CPU decode: %d bytes, first at offset %d of %d (picture %d)"
                                      % (name, mode, int((A != B).sum()), first, len(a), first // (len(a) // n)))
+
+
+# ---------------------------------------------------------------- f1 robustness (VERDICT r3 "What's missing" 1)
+# (8-bit streams: for wider samples the reference's synthesised picture is half undefined - image.cc:510-523 fill_image is a
+#  byte memset over stride x height BYTES -, so two runs of the reference itself need not agree behind the loss; the 10-bit
+#  case below checks that the decode goes through and that the pictures ahead of the loss are the same)
+LOSSY = [
+    ("lost_p_picture", "gop=P pics=7 nref=2 w=416 h=240 seed=5", 2),
+    ("lost_b_reference", "gop=B pics=9 w=416 h=240 seed=6 wp=1", 1),
+    ("lost_ldb_picture_tiles", "gop=LDB pics=6 nref=3 w=832 h=480 tile_cols=2 tile_rows=2 seed=7", 3),
+    ("lost_b_reference_10bit", "gop=B pics=9 bits=10 w=416 h=240 seed=6", 1),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (os.path.exists(F1_DEC) and os.path.exists(F2_WRITER)), reason="f1_dec / f2_writer (make -C oracle f1 f2) did not travel")
+@pytest.mark.parametrize("name,args,lost", LOSSY, ids=[n for n, _, _ in LOSSY])
+def test_a_stream_with_a_lost_picture_decodes_as_on_the_cpu(name, args, lost):
+    """A picture's slices never arrive: libde265 synthesises the missing reference (generate_unavailable_reference_picture,
+    decctx.cc:1408-1434: mid-grey planes) and decodes on.  With the HIP back end the recorder mirrors that picture into the
+    device-resident DPB (de265hip_dpb_fill); the output must be byte-identical to the CPU decode of the same damaged stream."""
+    import drop_picture
+    from libde265_amd import backend
+    assert backend.device_count() > 0
+    with tempfile.TemporaryDirectory() as td:
+        whole, bits, cpu, hip = (os.path.join(td, f) for f in ("w.bin", "s.bin", "cpu.yuv", "hip.yuv"))
+        subprocess.check_call([F2_WRITER, "out=" + whole] + args.split())
+        data, n_all = drop_picture.drop_picture(open(whole, "rb").read(), lost)
+        open(bits, "wb").write(data)
+        env = {k: v for k, v in os.environ.items() if k not in ("F1_OUT", "F1_MODE")}
+        env["F1_CHECK_HASH"] = "0"                       # (the hashes of the pictures behind the loss cannot match: not an error of the decoder)
+        r = subprocess.run([F1_DEC, bits, cpu], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        n = int(r.stdout.split()[0])
+        assert 0 < n < n_all
+        a = open(cpu, "rb").read()
+        for mode in ({}, dict(F1_PIPELINE="3", F1_THREADS="4")):
+            r = subprocess.run([F1_DEC, bits, hip], env=dict(env, F1_MODE="hip", F1_HIP_LIB=backend.SO_PATH, **mode), capture_output=True, text=True, timeout=120)
+            assert r.returncode == 0, r.stderr[-2000:]
+            assert int(r.stdout.split()[0]) == n
+            b = open(hip, "rb").read()
+            assert len(a) == len(b) and len(a) > 0
+            a_, b_ = a, b
+            if "bits=10" in args:                        # the first picture in output order is decoded ahead of the loss
+                a_, b_ = a[:len(a) // n], b[:len(b) // n]
+            if a_ != b_:
+                A, B = np.frombuffer(a_, np.uint8), np.frombuffer(b_, np.uint8)
+                first = int(np.nonzero(A != B)[0][0])
+                raise AssertionError("%s %s: HIP-backed decode differs from the CPU decode: %d bytes, first at offset %d of %d (picture %d)"
+                                     % (name, mode, int((A != B).sum()), first, len(a), first // (len(a) // n)))
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (os.path.exists(F1_DEC) and os.path.exists(F2_WRITER)), reason="f1_dec / f2_writer (make -C oracle f1 f2) did not travel")
+@pytest.mark.parametrize("mode", [{}, dict(F1_PIPELINE="2", F1_THREADS="2")], ids=["synchronous", "pipelined"])
+def test_a_back_end_failure_becomes_the_result_of_de265_decode(mode):
+    """The one failure the device side admits (a dependency wait of k_run that expires; injected with F1_FAULT): the patched
+    libde265 must hand it to the application as the result of de265_decode (de265.h:82-139) - f1_dec prints it, frees the
+    decoder and exits with 4 - instead of ending the process inside the library."""
+    from libde265_amd import backend
+    assert backend.device_count() > 0
+    with tempfile.TemporaryDirectory() as td:
+        bits, hip = os.path.join(td, "s.bin"), os.path.join(td, "hip.yuv")
+        subprocess.check_call([F2_WRITER, "out=" + bits] + "gop=I pics=4 w=832 h=480 seed=9".split())
+        env = {k: v for k, v in os.environ.items() if k not in ("F1_OUT", "F1_MODE")}
+        r = subprocess.run([F1_DEC, bits, hip], env=dict(env, F1_MODE="hip", F1_HIP_LIB=backend.SO_PATH, F1_FAULT="2000", F1_CHECK_HASH="0", **mode),
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 4, (r.returncode, r.stderr[-2000:])
+        assert "decode error" in r.stderr and "pictures" in r.stdout            # (reported, and the clean-up ran)
+        # ... and the same decoder binary still works without the fault
+        r = subprocess.run([F1_DEC, bits, hip], env=dict(env, F1_MODE="hip", F1_HIP_LIB=backend.SO_PATH, **mode), capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and not warnings_of(r.stderr), r.stderr[-2000:]
