@@ -127,7 +127,10 @@ typedef struct de265hip_slice_params {
 /* Per CTB (image.h:180-190 CTB_info + slice.h:267-275 sao_info). */
 typedef struct de265hip_ctb_info {
   uint16_t slice_addr_rs;             /* SliceAddrRS of the slice covering the CTB */
-  uint16_t slice_idx;                 /* SliceHeaderIndex into the slice table */
+  uint16_t slice_idx;                 /* SliceHeaderIndex into the slice table.  Every CTB needs one: a CTB that no slice covers (a
+                                         damaged stream; the reference's SAO skips it, sao.cc:140, decode_some marks it decoded,
+                                         decctx.cc:751-757) has no representation here - de265hip_picture_build refuses the picture
+                                         with DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE and the host conceals it as it sees fit */
   uint8_t  sao_type_idx;              /* (>>2*cIdx)&3: 0 off, 1 band, 2 edge */
   uint8_t  sao_eo_class;              /* (>>2*cIdx)&3 */
   uint8_t  sao_band_position[3];

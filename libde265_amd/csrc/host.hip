@@ -2452,12 +2452,8 @@ int de265hip_picture_enqueue_batch(de265hip_picture** pics, int n)
     const int m = std::min(SCAN_BATCH, n - i0);
     hipStream_t cs;
     { std::lock_guard<std::mutex> lk(dec->mu); cs = dec->copy_streams[dec->copy_turn++ % (uint64_t)dec->n_copy_streams]; reap_arenas(dec); }
-    static const int prefix_tail = getenv("DE265HIP_SCAN_PREFIX_TAIL") ? atoi(getenv("DE265HIP_SCAN_PREFIX_TAIL")) : 0;
     static const int own_prep = getenv("DE265HIP_OWN_PREP") ? atoi(getenv("DE265HIP_OWN_PREP")) : 1;
-    // (pad = 1: the last workgroup of the per-TU pass to finish computes the per-CTB bases instead of a launch of its own.  Off:
-    //  every workgroup has to publish its counts with an agent-scope fence first, and 400 of those per picture - each writes the
-    //  L2 back, the other kernels' dirty lines included - cost more than the launch: 2 500 against 3 060 pictures/s, round 4)
-    ScanBatch J; J.n = 0; J.pad = prefix_tail;
+    ScanBatch J; J.n = 0; J.pad = 0;
     PrepBatch PJ; PJ.n = 0; PJ.pad = 0;
     de265hip_picture* done[SCAN_BATCH]; int n_done = 0;
     auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };

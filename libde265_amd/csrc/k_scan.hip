@@ -36,8 +36,6 @@ __device__ __forceinline__ int wave_min_i(int v) { return 0x7FFFFFFF - wave_max_
 __device__ __forceinline__ uint64_t lanes_below(int lane) { return lane ? (~0ull >> (64 - lane)) : 0ull; }
 #define WAVE_ORDER() asm volatile("" ::: "memory")        // single-wavefront workgroups: LDS executes a wavefront's operations in order; only the compiler must not move them
 
-template <int NT> __device__ void scan_prefix_body(const ScanParams& P, const ScanBufs& B, uint32_t cap_resid);
-
 // The per-TU pass on the device.  scan_core.h scan_tu is the same pass as plain code (the CPU rehearsal); what differs here:
 // - the availability mask in closed form.  scan_tu asks MinTbAddrZS for every below-left and above-right unit (a dependent
 //   load each, up to 33 in a row: 90 us for a kernel of 100 000 threads).  The below-left units of a TU all lie in ONE block
@@ -46,7 +44,7 @@ template <int NT> __device__ void scan_prefix_body(const ScanParams& P, const Sc
 //   scan_tu's loops);
 // - the per-CTB counts by one atomic per counter, CTB and wavefront (the records of a CTB are contiguous: a wavefront sees one
 //   or two CTBs) instead of one to three per TU.
-__device__ __forceinline__ void scan_tu_dev(const ScanParams& P, const ScanBufs& B, int i, bool have, uint32_t& alg_resid, uint32_t& alg_intra, uint32_t& n_tasks)
+__device__ __forceinline__ void scan_tu_dev(const ScanParams& P, const ScanBufs& B, int i, bool have, uint32_t& alg_resid, uint32_t& alg_intra, uint32_t& n_tasks, uint32_t* s_tot)
 {
   const int lane = threadIdx.x & 63;
   int cls = 0, rx = 0, ctu = -1;
@@ -99,6 +97,11 @@ __device__ __forceinline__ void scan_tu_dev(const ScanParams& P, const ScanBufs&
     if (lane == lead) {
       ScanCtb& C = B.ctb[lctu];
       const uint32_t ni = n_intra_k[0] + n_intra_k[1] + n_intra_k[2] + n_intra_k[3];
+      // (the picture's totals: per workgroup first, in LDS)
+#pragma unroll
+      for (int k = 0; k < 4; k++) if (n_inter[k] + n_ro[k]) atomicAdd(&s_tot[k], n_inter[k] + n_ro[k]);
+      if (n_rext_inter + n_rext_ro) atomicAdd(&s_tot[4], n_rext_inter + n_rext_ro);
+      if (ni) { atomicAdd(&s_tot[5], ni); atomicAdd(&s_tot[6], 16 * n_intra_k[0] + 64 * n_intra_k[1] + 256 * n_intra_k[2] + 1024 * n_intra_k[3]); }
 #pragma unroll
       for (int k = 0; k < 4; k++) { if (n_inter[k]) atomicAdd(&C.n_inter[k], n_inter[k]); if (n_ro[k]) atomicAdd(&C.n_ro[k], n_ro[k]); }
       if (n_rext_inter) atomicAdd(&C.n_rext_inter, n_rext_inter);
@@ -189,14 +192,25 @@ void k_scan_tus(ScanBatch J)
   if (blockIdx.y >= (unsigned)J.n) return;
   const ScanParams& P = J.job[blockIdx.y].P; const ScanBufs& B = J.job[blockIdx.y].B;
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i == 0 && B.err_word) *B.err_word = 0;                  // (the picture's kernels that may raise it come behind the scan)
+  if (i == 0) { if (B.err_word) *B.err_word = 0; B.counts->victim = 0xFFFFFFFFu; }      // (the picture's kernels that may raise the word come behind the scan)
+  __shared__ uint32_t s_tot[7];                               // this workgroup's share of the list totals (scan_prefix's job until round 4)
+  if (threadIdx.x < 7) s_tot[threadIdx.x] = 0;
+  __syncthreads();
   uint32_t alg_resid = 0, alg_intra = 0, n_tasks = 0;
-  scan_tu_dev(P, B, i, i < P.n_tus, alg_resid, alg_intra, n_tasks);
+  scan_tu_dev(P, B, i, i < P.n_tus, alg_resid, alg_intra, n_tasks, s_tot);
   // one atomic per wavefront and sum
   alg_resid = wave_sum_u(alg_resid); alg_intra = wave_sum_u(alg_intra); n_tasks = wave_sum_u(n_tasks);
   if ((threadIdx.x & 63) == 0) {
     scan_add64(&B.counts->alg_resid, alg_resid); scan_add64(&B.counts->alg_intra, alg_intra);
     if (n_tasks) atomicAdd(&B.counts->n_tasks, n_tasks);
+  }
+  __syncthreads();
+  if (threadIdx.x < 7 && s_tot[threadIdx.x]) {
+    const uint32_t v = s_tot[threadIdx.x];
+    if (threadIdx.x < 4) atomicAdd(&B.counts->n_l0_size[threadIdx.x], v);
+    else if (threadIdx.x == 4) atomicAdd(&B.counts->n_l0_rext, v);
+    else if (threadIdx.x == 5) atomicAdd(&B.counts->n_intra, v);
+    else scan_add64(&B.counts->n_isamp, v);
   }
   // coefficient positions inside their TU's block (de265hip_picture_build's job on the host until round 3): the workgroup's 256
   // records sixteen at a time, sixteen lanes striding each list (a thread walking its own list alone took 7x as long); a
@@ -218,73 +232,6 @@ void k_scan_tus(ScanBatch J)
     }
     if (bad) scan_fail(B, DE265HIP_ERROR_DECODING);
   }
-  // ---- the last workgroup of this picture to get here computes the per-CTB bases (scan_prefix): every workgroup publishes its
-  // counts (agent-scope fence), then takes a number
-  if (P.n_tus == 0 || !J.pad) return;
-  __shared__ uint32_t s_last;
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) s_last = atomicAdd(&B.counts->pad1, 1u) == gridDim.x - 1 ? 1u : 0u;
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  scan_prefix_body<256>(P, B, J.job[blockIdx.y].cap_resid);
-}
-
-// exclusive prefix over the CTBs in tile-scan (decode) order of the seven per-CTB counts, by one workgroup of NT threads: every
-// thread sums a contiguous chunk of CTBs, the workgroup scans the chunk sums in LDS, every thread writes its chunk's bases.
-// Run by the LAST workgroup of k_scan_tus to finish (a launch of its own until round 4's second half: 16 us alone, 60-150 us
-// next to the reconstruction kernels, on a chain that everything behind it waits for).
-template <int NT>
-__device__ void scan_prefix_body(const ScanParams& P, const ScanBufs& B, uint32_t cap_resid)
-{
-  __shared__ uint32_t sums[7][NT];
-  __shared__ uint32_t tot[7];
-  const int tid = threadIdx.x, n = P.n_ctbs, chunk = (n + NT - 1) / NT;
-  const int t0 = min(n, tid * chunk), t1 = min(n, t0 + chunk);
-  uint32_t acc[7] = { 0, 0, 0, 0, 0, 0, 0 };
-  for (int t = t0; t < t1; t++) {
-    const ScanCtb& C = B.ctb[B.ts2rs[t]];
-    for (int k = 0; k < 4; k++) acc[k] += C.n_inter[k] + C.n_ro[k];
-    acc[4] += C.n_rext_inter + C.n_rext_ro; acc[5] += C.n_intra; acc[6] += C.n_isamp;
-  }
-  for (int k = 0; k < 7; k++) sums[k][tid] = acc[k];
-  __syncthreads();
-  for (int off = 1; off < NT; off <<= 1) {                   // inclusive Hillis-Steele scan of the chunk sums
-    uint32_t v[7];
-    for (int k = 0; k < 7; k++) v[k] = tid >= off ? sums[k][tid - off] : 0u;
-    __syncthreads();
-    for (int k = 0; k < 7; k++) sums[k][tid] += v[k];
-    __syncthreads();
-  }
-  if (tid == NT - 1) for (int k = 0; k < 7; k++) tot[k] = sums[k][NT - 1];
-  uint32_t base[7];
-  for (int k = 0; k < 7; k++) base[k] = sums[k][tid] - acc[k];
-  for (int t = t0; t < t1; t++) {
-    ScanCtb& C = B.ctb[B.ts2rs[t]];
-    for (int k = 0; k < 4; k++) { C.l0_base[k] = base[k]; base[k] += C.n_inter[k] + C.n_ro[k]; }
-    C.rext_base = base[4]; base[4] += C.n_rext_inter + C.n_rext_ro;
-    C.intra_base = base[5]; base[5] += C.n_intra;
-    C.isamp_base = base[6]; base[6] += C.n_isamp;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    scan_prefix_finish_totals(B, tot);
-    B.counts->victim = 0xFFFFFFFFu;
-    // (overlapping intra TUs - a malformed description - could ask for more residual samples than the picture has)
-    if (tot[6] > cap_resid || tot[5] > P.cap_runs) scan_fail(B, DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE);
-  }
-}
-
-// a picture without TU records: the bases (all zero) and the totals still have to be written
-__global__ __launch_bounds__(256)
-void k_scan_prefix(ScanBatch J)
-{
-  if (blockIdx.y >= (unsigned)J.n) return;
-  const ScanParams& P = J.job[blockIdx.y].P; const ScanBufs& B = J.job[blockIdx.y].B;
-  if (P.n_tus != 0 && J.pad) return;                         // (done by its k_scan_tus)
-  if (threadIdx.x == 0 && B.err_word) *B.err_word = 0;
-  scan_prefix_body<256>(P, B, J.job[blockIdx.y].cap_resid);
 }
 
 // The CTB pass, one WAVEFRONT per CTB (scan_core.h scan_ctb is the same pass as one thread's loop: the CPU rehearsal; the
@@ -306,12 +253,32 @@ void k_scan_ctbs(ScanBatch J)
   const int rs = blockIdx.x, lane = threadIdx.x;
   if (rs >= P.n_ctbs || B.counts->status) return;
   ScanCtb& C = B.ctb[rs];
-  const uint32_t first = C.first_tu, end = C.end_tu, seen = C.seen, n_intra = C.n_intra, ibase = C.intra_base;
+  const uint32_t first = C.first_tu, end = C.end_tu, seen = C.seen, n_intra = C.n_intra;
   if (seen == 0) { if (lane == 0) C.n_runs = 0; return; }
   if (seen != 1 || end <= first || end > (uint32_t)P.n_tus || n_intra > 768) {
     if (lane == 0) { C.n_runs = 0; scan_fail(B, DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE); }
     return;
   }
+  // ---- this CTB's share of the task lists, the run-ordered TU array (= its sparse run ids) and the residual samples: one
+  // atomic per list, a lane each (scan_core.h computes these bases as a prefix over the CTBs in decode order - a launch of
+  // its own on the device, 16 us alone and 60-150 us next to the reconstruction kernels, on a chain everything behind it waits
+  // for; nothing needs the lists in decode order)
+  uint32_t got = 0;
+  {
+    uint32_t take = 0;
+    if (lane < 4) take = C.n_inter[lane] + C.n_ro[lane];
+    else if (lane == 4) take = C.n_rext_inter + C.n_rext_ro;
+    else if (lane == 5) take = n_intra;
+    else if (lane == 6) take = C.n_isamp;
+    if (lane < 7 && take) got = atomicAdd(&B.counts->alloc[lane], take);
+    if (lane < 4) C.l0_base[lane] = got;
+    else if (lane == 4) C.rext_base = got;
+    else if (lane == 5) C.intra_base = got;
+    else if (lane == 6) C.isamp_base = got;
+  }
+  const uint32_t ibase = (uint32_t)__builtin_amdgcn_readlane((int)got, 5), my_rext_base = (uint32_t)__builtin_amdgcn_readlane((int)got, 4);
+  uint32_t my_l0_base[4];
+  for (int k = 0; k < 4; k++) my_l0_base[k] = (uint32_t)__builtin_amdgcn_readlane((int)got, k);
   const int cx0 = (rs % P.ctbs_w) << P.lc, cy0 = (rs / P.ctbs_w) << P.lc;      // luma origin of the CTB
   // ---- the window: own cells empty, the halo from the cell map of the per-TU pass
   for (int q = lane; q < 3 * SCW_W * SCW_H; q += 64) (&win[0][0])[q] = 0;
@@ -347,7 +314,7 @@ void k_scan_ctbs(ScanBatch J)
     // -- level-0 tasks of the inter TUs: a lane each, positions by ballot prefix per size class
     for (int k = 0; k < 4; k++) {
       const uint64_t m = __ballot(cls == 1 && tu.log2_size == k + 2);
-      if (cls == 1 && tu.log2_size == k + 2) B.l0[cls_start[k] + C.l0_base[k] + inter_at[k] + __popcll(m & lanes_below(lane))] = scan_task_of(tu);
+      if (cls == 1 && tu.log2_size == k + 2) B.l0[cls_start[k] + my_l0_base[k] + inter_at[k] + __popcll(m & lanes_below(lane))] = scan_task_of(tu);
       inter_at[k] += __popcll(m);
     }
     {
@@ -357,7 +324,7 @@ void k_scan_ctbs(ScanBatch J)
         uint64_t luma_info = 0; int rx_luma = 0;
         if (rx & D265_RX_XCC) scan_xcc_luma(P, B, (int)i, &luma_info, &rx_luma);
         t.pad3 = (uint8_t)(rx | rx_luma); t.angle = tu.res_scale_val; t.avail = luma_info;
-        B.l0x[C.rext_base + rext_at + __popcll(m & lanes_below(lane))] = t;
+        B.l0x[my_rext_base + rext_at + __popcll(m & lanes_below(lane))] = t;
       }
       rext_at += __popcll(m);
     }
@@ -463,21 +430,24 @@ __device__ __forceinline__ uint32_t wave_scan_incl_u(uint32_t x)
 // atomics into a table of the CTB's runs (64 runs at a time: a tile), a TU's place in its run's chain order by counting the
 // TUs of its run that sort before it (two loops over the CTB's TUs in LDS), the producers by one load per needed unit (the
 // cell's high word: the sparse id of the run that covers it, left there by the CTB pass) into one hash set per tile.
-#define SR_TMAX 768                      // intra TUs of a CTB (k_scan_ctbs refuses more)
-#define SR_HASH 1024
+#define SR_TMAX 768                      // intra TUs of a CTB (k_scan_ctbs refuses more; 4:2:0 and monochrome: at most 384)
+#define SR_HASH 512
+#define SR_TILE 32                       // runs per tile.  LDS per workgroup: 10 KB (4:2:0) / 13 KB - what decides how many CTBs
+                                         // are worked on at once next to k_run's 53 KB workgroups (with 21 KB: two per CU)
 enum { RF_FOREIGN = 1, RF_BIG = 2, RF_TOO_BIG = 4, RF_BAD = 8, RF_DENSE0 = 16, RF_MICRO = 32, RF_DENSE = 64, RF_MB = 128, RF_PHASED = 256 };
+template <int TMAX>
 __global__ __launch_bounds__(64)
 void k_scan_runs1(ScanBatch J)
 {
   if (blockIdx.y >= (unsigned)J.n) return;
   const ScanParams& P = J.job[blockIdx.y].P; const ScanBufs& B = J.job[blockIdx.y].B;
-  __shared__ uint32_t s_w[SR_TMAX];                    // per intra TU of the CTB (decode order): run | level << 10 | (log2 - 2) << 18 | residual-only task << 20 | rext << 21 | foreign << 22
-  __shared__ uint32_t s_key[SR_TMAX];                  // list << 20 | level << 8 | number inside its run
-  __shared__ uint16_t s_ix[SR_TMAX];                   // its record, relative to the CTB's first
+  __shared__ uint32_t s_w[TMAX];                       // per intra TU of the CTB (decode order): run | level << 10 | (log2 - 2) << 18 | residual-only task << 20 | rext << 21 | foreign << 22
+  __shared__ uint16_t s_key[TMAX];                     // list << 8 | level (ties inside a run: decode order)
+  __shared__ uint16_t s_ix[TMAX];                      // its record, relative to the CTB's first
   // the tile's runs
-  __shared__ uint32_t r_x0[64], r_y0[64], r_x1[64], r_y1[64], r_wx1[64], r_wy1[64], r_n[64], r_samp[64], r_nl[64], r_fl[64], r_c[64];
-  __shared__ uint32_t r_ro[4][64], r_rx[64], r_alg[64], r_cnt[5][64], r_nd[64], r_fill[64];
-  __shared__ uint32_t r_first[64], r_res[64], r_robase[4][64], r_rxbase[64], r_depoff[64], r_mb[64];
+  __shared__ uint32_t r_x0[SR_TILE], r_y0[SR_TILE], r_x1[SR_TILE], r_y1[SR_TILE], r_wx1[SR_TILE], r_wy1[SR_TILE], r_n[SR_TILE], r_samp[SR_TILE], r_nl[SR_TILE], r_fl[SR_TILE], r_c[SR_TILE];
+  __shared__ uint32_t r_ro[4][SR_TILE], r_rx[SR_TILE], r_alg[SR_TILE], r_cnt[5][SR_TILE], r_nd[SR_TILE], r_fill[SR_TILE];
+  __shared__ uint32_t r_first[SR_TILE], r_res[SR_TILE], r_robase[4][SR_TILE], r_rxbase[SR_TILE], r_depoff[SR_TILE], r_mb[SR_TILE];
   __shared__ uint32_t s_tab[SR_HASH];
   __shared__ uint8_t s_rdy[64];
   const int rs = blockIdx.x, lane = threadIdx.x;
@@ -490,7 +460,7 @@ void k_scan_runs1(ScanBatch J)
   for (int k = 0; k < 4; k++) l0_at[k] = scan_l0_class_start(B.counts->n_l0_size, k) + C.l0_base[k] + C.n_inter[k];
   const uint32_t pflags = P.flags;
   const int micro_tus = P.micro_tus, run_waves = P.run_waves;
-  if (end - first > 65535u || n_runs > SR_TMAX) { if (lane == 0) scan_fail(B, DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE); return; }
+  if (end - first > 65535u || n_runs > (uint32_t)TMAX) { if (lane == 0) scan_fail(B, DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE); return; }
   // ---- the CTB's intra TUs, compacted (decode order)
   int T = 0;
   for (uint32_t base = first; base < end; base += 64) {
@@ -500,7 +470,7 @@ void k_scan_runs1(ScanBatch J)
     const uint64_t m = __ballot(intra);
     if (intra) {
       const int t = T + __popcll(m & lanes_below(lane));
-      if (t < SR_TMAX) {
+      if (t < TMAX) {
         const de265hip_tu tu = B.tus[i];
         const int trx = scan_rx_bits(P, B, tu);
         const bool ro = ((tu.flags & DE265HIP_TU_CBF) && tu.n_coeff) || (trx & D265_RX_XCC);
@@ -510,25 +480,29 @@ void k_scan_runs1(ScanBatch J)
     }
     T += __popcll(m);
   }
-  if (T > SR_TMAX) { if (lane == 0) scan_fail(B, DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE); return; }
+  if (T > TMAX) { if (lane == 0) scan_fail(B, DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE); return; }
   WAVE_ORDER();
   uint32_t carry_n = 0, carry_samp = 0, carry_ro[4] = { 0, 0, 0, 0 }, carry_rx = 0;
-  for (uint32_t r0 = 0; r0 < n_runs; r0 += 64) {
-    const uint32_t n_tile = n_runs - r0 < 64u ? n_runs - r0 : 64u;
+  uint64_t tick_acc = 0, mic_acc = 0;
+  for (uint32_t r0 = 0; r0 < n_runs; r0 += SR_TILE) {
+    const uint32_t n_tile = n_runs - r0 < (uint32_t)SR_TILE ? n_runs - r0 : (uint32_t)SR_TILE;
     const bool have_run = (uint32_t)lane < n_tile;
+    const int rl = lane & (SR_TILE - 1);                                   // (the lanes beyond the tile mirror its entries: they only read)
     const uint32_t s = ibase + r0 + (uint32_t)lane;                      // the sparse id of this lane's run
     // ---- per-run sums
-    r_x0[lane] = 0xFFFFu; r_y0[lane] = 0xFFFFu; r_x1[lane] = 0; r_y1[lane] = 0; r_wx1[lane] = 0; r_wy1[lane] = 0; r_n[lane] = 0; r_samp[lane] = 0;
-    r_nl[lane] = 0; r_fl[lane] = 0; r_c[lane] = 0; r_rx[lane] = 0; r_alg[lane] = 0; r_nd[lane] = 0; r_fill[lane] = 0;
-    for (int k = 0; k < 4; k++) r_ro[k][lane] = 0;
-    for (int k = 0; k < 5; k++) r_cnt[k][lane] = 0;
+    if (lane < SR_TILE) {
+      r_x0[lane] = 0xFFFFu; r_y0[lane] = 0xFFFFu; r_x1[lane] = 0; r_y1[lane] = 0; r_wx1[lane] = 0; r_wy1[lane] = 0; r_n[lane] = 0; r_samp[lane] = 0;
+      r_nl[lane] = 0; r_fl[lane] = 0; r_c[lane] = 0; r_rx[lane] = 0; r_alg[lane] = 0; r_nd[lane] = 0; r_fill[lane] = 0;
+      for (int k = 0; k < 4; k++) r_ro[k][lane] = 0;
+      for (int k = 0; k < 5; k++) r_cnt[k][lane] = 0;
+    }
     for (int q = lane; q < SR_HASH; q += 64) s_tab[q] = 0xFFFFFFFFu;
     WAVE_ORDER();
     for (int cb = 0; cb < T; cb += 64) {
       const int t = cb + lane;
       if (t >= T) continue;
       const uint32_t w = s_w[t], jj = (w & 1023u) - r0;
-      if (jj >= 64u) continue;
+      if (jj >= (uint32_t)SR_TILE) continue;
       const de265hip_tu tu = B.tus[first + s_ix[t]];
       const uint32_t nT = 1u << tu.log2_size, bpp = (uint32_t)(tu.c_idx ? P.bppC : P.bppY);
       atomicMin(&r_x0[jj], (uint32_t)tu.x0); atomicMin(&r_y0[jj], (uint32_t)tu.y0);
@@ -541,9 +515,9 @@ void k_scan_runs1(ScanBatch J)
     }
     WAVE_ORDER();
     // ---- a lane per run: class
-    int x0 = (int)r_x0[lane], y0 = (int)r_y0[lane], x1 = (int)r_x1[lane], y1 = (int)r_y1[lane], wx1 = (int)r_wx1[lane], wy1 = (int)r_wy1[lane];
-    const int n = (int)r_n[lane], own_samples = (int)r_samp[lane], nl = (int)r_nl[lane], c = (int)r_c[lane];
-    uint32_t fl = r_fl[lane];
+    int x0 = (int)r_x0[rl], y0 = (int)r_y0[rl], x1 = (int)r_x1[rl], y1 = (int)r_y1[rl], wx1 = (int)r_wx1[rl], wy1 = (int)r_wy1[rl];
+    const int n = (int)r_n[rl], own_samples = (int)r_samp[rl], nl = (int)r_nl[rl], c = (int)r_c[rl];
+    uint32_t fl = r_fl[rl];
     if (__ballot(have_run && (n == 0 || n > 255 || n != (int)B.run_ntus[have_run ? s : ibase])) != 0) { if (lane == 0) scan_fail(B, DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE); return; }
     if (__ballot(have_run && nl > 256) != 0) { if (lane == 0) scan_fail(B, DE265HIP_ERROR_NOT_IMPLEMENTED); return; }
     bool micro = have_run && !(pflags & SCANF_MICRO_OFF) && n <= micro_tus && x1 - x0 <= 32 && y1 - y0 <= 32 && !(fl & RF_TOO_BIG);
@@ -556,7 +530,7 @@ void k_scan_runs1(ScanBatch J)
       }
     }
     const bool dense0 = have_run && own_samples == (x1 - x0) * (y1 - y0) && !(pflags & SCANF_NO_DENSE);
-    r_fl[lane] = fl | (micro ? RF_MICRO : 0u) | (dense0 ? RF_DENSE0 : 0u);
+    if (lane < SR_TILE) r_fl[lane] = fl | (micro ? RF_MICRO : 0u) | (dense0 ? RF_DENSE0 : 0u);
     WAVE_ORDER();
     // dense: every available neighbour outside the box lies on the row above it or the column left of it (a lane per TU)
     if (__ballot(dense0) != 0) {
@@ -564,7 +538,7 @@ void k_scan_runs1(ScanBatch J)
         const int t = cb + lane;
         if (t >= T) continue;
         const uint32_t w = s_w[t], jj = (w & 1023u) - r0;
-        if (jj >= 64u || !(r_fl[jj] & RF_DENSE0)) continue;
+        if (jj >= (uint32_t)SR_TILE || !(r_fl[jj] & RF_DENSE0)) continue;
         const uint32_t i = first + s_ix[t];
         const de265hip_tu tu = B.tus[i];
         const uint64_t avail = B.tu_avail[i];
@@ -582,19 +556,21 @@ void k_scan_runs1(ScanBatch J)
       }
       WAVE_ORDER();
     }
-    fl = r_fl[lane];
+    fl = r_fl[rl];
     const bool dense = dense0 && !(fl & RF_BAD);
     // ---- what the runs before it take of the CTB's lists: prefix over the runs (three packed sums), carried across tiles
     const uint32_t pa = have_run ? ((uint32_t)n | ((uint32_t)own_samples << 16)) : 0u;
-    const uint32_t pb = have_run ? (r_ro[0][lane] | (r_ro[1][lane] << 10) | (r_ro[2][lane] << 20)) : 0u;
-    const uint32_t pc = have_run ? (r_ro[3][lane] | (r_rx[lane] << 16)) : 0u;
+    const uint32_t pb = have_run ? (r_ro[0][rl] | (r_ro[1][rl] << 10) | (r_ro[2][rl] << 20)) : 0u;
+    const uint32_t pc = have_run ? (r_ro[3][rl] | (r_rx[rl] << 16)) : 0u;
     const uint32_t ia = wave_scan_incl_u(pa), ib = wave_scan_incl_u(pb), ic = wave_scan_incl_u(pc);
     const uint32_t ea = ia - pa, eb = ib - pb, ec = ic - pc;
     const uint32_t first_tu = ibase + carry_n + (ea & 0xFFFFu), res_offset = isamp_base + carry_samp + (ea >> 16);
-    r_first[lane] = first_tu; r_res[lane] = res_offset;
-    r_robase[0][lane] = l0_at[0] + carry_ro[0] + (eb & 1023u); r_robase[1][lane] = l0_at[1] + carry_ro[1] + ((eb >> 10) & 1023u);
-    r_robase[2][lane] = l0_at[2] + carry_ro[2] + ((eb >> 20) & 1023u); r_robase[3][lane] = l0_at[3] + carry_ro[3] + (ec & 0xFFFFu);
-    r_rxbase[lane] = rext_base + n_rext_inter + carry_rx + (ec >> 16);
+    if (lane < SR_TILE) {
+      r_first[lane] = first_tu; r_res[lane] = res_offset;
+      r_robase[0][lane] = l0_at[0] + carry_ro[0] + (eb & 1023u); r_robase[1][lane] = l0_at[1] + carry_ro[1] + ((eb >> 10) & 1023u);
+      r_robase[2][lane] = l0_at[2] + carry_ro[2] + ((eb >> 20) & 1023u); r_robase[3][lane] = l0_at[3] + carry_ro[3] + (ec & 0xFFFFu);
+      r_rxbase[lane] = rext_base + n_rext_inter + carry_rx + (ec >> 16);
+    }
     {
       const uint32_t ta = (uint32_t)__builtin_amdgcn_readlane((int)ia, 63), tb = (uint32_t)__builtin_amdgcn_readlane((int)ib, 63), tc = (uint32_t)__builtin_amdgcn_readlane((int)ic, 63);
       carry_n += ta & 0xFFFFu; carry_samp += ta >> 16; carry_ro[0] += tb & 1023u; carry_ro[1] += (tb >> 10) & 1023u; carry_ro[2] += (tb >> 20) & 1023u;
@@ -617,25 +593,23 @@ void k_scan_runs1(ScanBatch J)
         }
       }
     }
-    r_mb[lane] = mb_id;
-    r_fl[lane] = fl | (dense ? RF_DENSE : 0u) | (phased ? RF_PHASED : 0u);
+    if (lane < SR_TILE) { r_mb[lane] = mb_id; r_fl[lane] = fl | (dense ? RF_DENSE : 0u) | (phased ? RF_PHASED : 0u); }
     WAVE_ORDER();
     // ---- chain order.  First loop: the TU's number inside its run (decode order) and its rank among the non-collective TUs of
     // its in-run level before it -> its list; second loop: how many TUs of its run sort before it, their samples, and how many
     // residual-only copies of its class
     for (int cb = 0; cb < T; cb += 64) {
       const int t = cb + lane;
-      uint32_t key = 0xFFFFFFFFu;
+      uint32_t key = 0xFFFFu;
       const uint32_t w = t < T ? s_w[t] : 0xFFFFFFFFu, jj = (w & 1023u) - r0;
-      const bool mine = t < T && jj < 64u;
+      const bool mine = t < T && jj < (uint32_t)SR_TILE;
       const bool rmicro = mine && (r_fl[mine ? jj : 0] & RF_MICRO);
       if (__ballot(mine) != 0) {
-        uint32_t k_in = 0, rank = 0;
+        uint32_t rank = 0;
         const int u_end = cb + 64 < T ? cb + 64 : T;
         for (int u = 0; u < u_end; u++) {
           const uint32_t wu = s_w[u];
           if (u < t && ((wu ^ w) & 1023u) == 0) {
-            k_in++;
             const bool coll_u = ((wu >> 18) & 3u) > 1u && !rmicro;
             if (((wu ^ w) & (0xFFu << 10)) == 0 && !coll_u) rank++;
           }
@@ -643,23 +617,23 @@ void k_scan_runs1(ScanBatch J)
         if (mine) {
           const bool coll = ((w >> 18) & 3u) > 1u && !rmicro;
           const uint32_t list = coll ? 4u : rank % (uint32_t)(rmicro ? 1 : run_waves);
-          key = (list << 20) | (((w >> 10) & 0xFFu) << 8) | k_in;
+          key = (list << 8) | ((w >> 10) & 0xFFu);
           atomicAdd(&r_cnt[list][jj], 1u);
         }
       }
-      if (t < T) s_key[t] = mine ? key : 0xFFFFFFFFu;
+      if (t < T && mine) s_key[t] = (uint16_t)key;       // (the entries of other tiles' TUs are never compared: the run number differs)
     }
     WAVE_ORDER();
     for (int cb = 0; cb < T; cb += 64) {
       const int t = cb + lane;
       const uint32_t w = t < T ? s_w[t] : 0xFFFFFFFFu, jj = (w & 1023u) - r0;
-      const bool mine = t < T && jj < 64u;
+      const bool mine = t < T && jj < (uint32_t)SR_TILE;
       if (__ballot(mine) == 0) continue;
       const uint32_t key = mine ? s_key[t] : 0u;
       uint32_t pos = 0, samp = 0, ro_rank = 0;
       for (int u = 0; u < T; u++) {
         const uint32_t wu = s_w[u], ku = s_key[u];
-        if (((wu ^ w) & 1023u) == 0 && ku < key) {
+        if (((wu ^ w) & 1023u) == 0 && (ku < key || (ku == key && u < t))) {
           pos++; samp += 16u << (2 * ((wu >> 18) & 3u));
           // the same list of residual-only tasks: both with a range-extension tool, or both without and of one size
           if (((wu >> 20) & 1u) && ((wu ^ w) & (1u << 21)) == 0 && (((w >> 21) & 1u) || ((wu ^ w) & (3u << 18)) == 0)) ro_rank++;
@@ -706,7 +680,7 @@ void k_scan_runs1(ScanBatch J)
         for (int q = 0; q < 4; q++) {
           if (ps[q] == 0 || ps[q] - 1 == own) continue;
           const uint32_t e = (jj << 24) | (ps[q] - 1);
-          uint32_t hsh = (e * 2654435761u) >> 22;
+          uint32_t hsh = (e * 2654435761u) >> 23;
           int probe = 0;
           for (; probe < SR_HASH; probe++, hsh = (hsh + 1) & (SR_HASH - 1)) {
             const uint32_t old = atomicCAS(&s_tab[hsh], 0xFFFFFFFFu, e);
@@ -720,7 +694,7 @@ void k_scan_runs1(ScanBatch J)
     WAVE_ORDER();
     if (B.counts->status) return;
     // ---- the producer lists: room from the pool (one request per tile), the table's entries to their runs
-    const uint32_t nd = have_run ? r_nd[lane] : 0u;
+    const uint32_t nd = have_run ? r_nd[rl] : 0u;
     {
       const uint32_t incl = wave_scan_incl_u(nd), total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
       uint32_t at = 0;
@@ -729,7 +703,7 @@ void k_scan_runs1(ScanBatch J)
         at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
         if (at + total > P.cap_deps) { if (lane == 0) scan_fail(B, DE265HIP_ERROR_NOT_IMPLEMENTED); return; }
       }
-      r_depoff[lane] = at + incl - nd;
+      if (lane < SR_TILE) r_depoff[lane] = at + incl - nd;
       WAVE_ORDER();
       if (total)
         for (int q = lane; q < SR_HASH; q += 64) {
@@ -768,9 +742,9 @@ void k_scan_runs1(ScanBatch J)
       o.wx1 = (uint16_t)(wx1 < x1 + 32 ? wx1 : x1 + 32); o.wy1 = (uint16_t)(wy1 < y1 + 32 ? wy1 : y1 + 32);
       o.c_idx = (uint8_t)c; o.micro = (uint8_t)((micro ? 1 : 0) | (dense ? 2 : 0) | (front ? RUN_MICRO_FRONT : 0)); o.n_tus = (uint16_t)n;
       o.first_tu = first_tu; o.res_offset = res_offset;
-      o.dep_offset = nd ? r_depoff[lane] : 0u; o.n_deps = (uint16_t)nd;
+      o.dep_offset = nd ? r_depoff[rl] : 0u; o.n_deps = (uint16_t)nd;
       uint32_t acc = 0;
-      for (int wv = 0; wv < 4; wv++) { acc += r_cnt[wv][lane]; o.wave_end[wv] = (uint16_t)acc; }
+      for (int wv = 0; wv < 4; wv++) { acc += r_cnt[wv][rl]; o.wave_end[wv] = (uint16_t)acc; }
       o.n_lvls = (uint16_t)(nl > 0 ? nl - 1 : 0);
       o.n_samples = (uint32_t)own_samples;
       B.runs[s] = o;
@@ -786,11 +760,14 @@ void k_scan_runs1(ScanBatch J)
         at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
         if (front) B.front_idx[at + (uint32_t)__popcll(fm & lanes_below(lane))] = s;
       }
-      const uint32_t alg = wave_sum_u(front ? r_alg[lane] : 0u), lv = wave_sum_u(have_run ? (uint32_t)nl : 0u);
+      // what the ticket pass needs of this CTB's runs, in two words (more than 64 runs: it reads the run records)
+      if (r0 < 64) { tick_acc |= __ballot(have_run && !front) << r0; mic_acc |= __ballot(have_run && micro) << r0; }
+      const uint32_t alg = wave_sum_u(front ? r_alg[rl] : 0u), lv = wave_sum_u(have_run ? (uint32_t)nl : 0u);
       if (lane == 0) { if (alg) scan_add64(&B.counts->alg_intra_front, alg); atomicAdd(&B.counts->sum_lvls, lv); }
     }
     WAVE_ORDER();
   }
+  if (lane == 0) { B.ctb[rs].tick_mask = tick_acc; B.ctb[rs].micro_mask = mic_acc; B.ctb[rs].slow = n_runs > 64 ? 1u : 0u; }
 }
 
 // The second run pass, a wavefront per run: the run's chain-ordered TU records are staged in LDS by all lanes, then ONE lane
@@ -807,6 +784,7 @@ void k_scan_runs2(ScanBatch J)
   const int lane = threadIdx.x;
   if (B.counts->status) return;
   const uint32_t n_listed = B.counts->n_listed;
+  uint32_t n_ready = 0;
   for (uint32_t qrun = blockIdx.x; qrun < n_listed; qrun += gridDim.x) {
     const uint32_t s = B.run_list[qrun];
     const RunTask* R = B.runs + s;
@@ -821,9 +799,13 @@ void k_scan_runs2(ScanBatch J)
       for (uint32_t q = lane; q < 2 * n; q += 64) dst[q] = src[q];
     }
     WAVE_ORDER();
-    if (lane == 0) scan_run2(P, B, s, cand ? s_tus : nullptr);
+    if (lane == 0) {
+      scan_run2(P, B, s, cand ? s_tus : nullptr);
+      if (!(mic & RUN_MICRO_FRONT) && B.runs[s].n_deps == 0) n_ready++;      // (a ticketed run that waits for nothing: scan_order's worker count)
+    }
     WAVE_ORDER();
   }
+  if (lane == 0 && n_ready) atomicAdd(&B.counts->n_ready, n_ready);
 }
 
 // Ticket slots (scan_core.h "tickets"), one workgroup: the CTBs in ctb_order are dealt to the threads in contiguous chunks; how
@@ -831,7 +813,7 @@ void k_scan_runs2(ScanBatch J)
 // chunk's effect for each of the eight possible fill states (a table), the tables are composed by a prefix scan (composition
 // of such tables is associative), and every thread then walks its chunk again from its true start state and writes the slots.
 #define SCO_THREADS 1024
-__device__ void scan_order_body(const ScanParams& P, const ScanBufs& B, uint32_t cap_levels);
+__device__ void scan_order_body(const ScanParams& P, const ScanBufs& B, uint32_t cap_levels, uint32_t cap_resid);
 __global__ __launch_bounds__(SCO_THREADS)
 void k_scan_order(ScanBatch J)
 {
@@ -846,7 +828,7 @@ void k_scan_order(ScanBatch J)
   // (one workgroup, one CU: what its threads have stored is visible to each other behind a barrier.  An agent-scope fence here -
   //  __threadfence() - writes the whole L2 back, the reconstruction kernels' dirty lines included, once per wavefront: round 4)
   __syncthreads();
-  scan_order_body(P, B, cap_levels);
+  scan_order_body(P, B, cap_levels, J.job[blockIdx.y].cap_resid);
   // ---- the scan's verdict and counts to the host: into the picture's pinned record, then its ready word (system scope)
   __syncthreads();
   if (threadIdx.x < sizeof(ScanCounts) / 4 - 2 && B.host_counts)
@@ -854,31 +836,42 @@ void k_scan_order(ScanBatch J)
   __syncthreads();
   if (threadIdx.x == 0 && B.host_counts) __hip_atomic_store(&B.host_counts->ready, B.ready_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__device__ void scan_order_body(const ScanParams& P, const ScanBufs& B, uint32_t cap_levels)
+__device__ void scan_order_body(const ScanParams& P, const ScanBufs& B, uint32_t cap_levels, uint32_t cap_resid)
 {
   __shared__ uint32_t tab[SCO_THREADS][RUN_TICKET_SLOTS];          // per chunk and fill state at its start: tickets it opens | fill state at its end << 28
   __shared__ uint32_t s_diag[4096];
-  __shared__ uint32_t s_widest, s_ready, s_ndiag;
+  __shared__ uint32_t s_widest, s_ndiag;
   const int tid = threadIdx.x;
   ScanCounts& K = *B.counts;
   if (K.status) return;
   const int n = P.n_ctbs, chunk = (n + SCO_THREADS - 1) / SCO_THREADS;
   const int t0 = min(n, tid * chunk), t1 = min(n, t0 + chunk);
   const uint32_t victim = K.victim;
+  const bool by_records = (P.flags & SCANF_DROP_PRODUCER) != 0;       // (the fault injection's victim is only known by its id)
   const int n_diag = P.ctbs_w + 2 * P.ctbs_h;
   uint32_t* diag = n_diag <= 4096 ? s_diag : B.lvl_cnt;          // ticketed runs per anti-diagonal (for the worker count)
   for (int q = tid; q < n_diag; q += SCO_THREADS) diag[q] = 0;
-  if (tid == 0) { s_widest = 0; s_ready = 0; s_ndiag = 0; }
+  if (tid == 0) { s_widest = 0; s_ndiag = 0; }
   __syncthreads();
   // ---- phase 1: the chunk's table
   ScanTicketState st[RUN_TICKET_SLOTS];
   for (int o = 0; o < RUN_TICKET_SLOTS; o++) { st[o].tickets = 0; st[o].fill = (uint32_t)o; }
-  uint32_t ready = 0;
   for (int t = t0; t < t1; t++) {
     const int rs = B.ctb_order[t];
     const ScanCtb& C = B.ctb[rs];
     const uint32_t nr = C.n_runs, ib = C.intra_base;
     uint32_t cnt = 0;
+    if (!by_records && !C.slow) {
+      // (the run pass left which runs take a ticket and which are micro runs in two words of the CTB's record: no run record
+      //  is read here - 2 x 8 dependent loads per thread were this kernel's 100 us)
+      const uint64_t mm = C.micro_mask;
+      for (uint64_t tm = C.tick_mask; tm; tm &= tm - 1) {
+        const bool micro = (mm >> __builtin_ctzll(tm)) & 1;
+        uint32_t tk, sl;
+        for (int o = 0; o < RUN_TICKET_SLOTS; o++) scan_ticket_step(st[o], micro, &tk, &sl);
+        cnt++;
+      }
+    } else
     for (uint32_t r = 0; r < nr; r++) {
       const uint32_t s = ib + r;
       const uint32_t mic = B.runs[s].micro;
@@ -886,11 +879,9 @@ __device__ void scan_order_body(const ScanParams& P, const ScanBufs& B, uint32_t
       uint32_t tk, sl;
       for (int o = 0; o < RUN_TICKET_SLOTS; o++) scan_ticket_step(st[o], mic & 1, &tk, &sl);
       cnt++;
-      if (B.runs[s].n_deps == 0) ready++;
     }
     if (cnt) atomicAdd(&diag[rs % P.ctbs_w + 2 * (rs / P.ctbs_w)], cnt);
   }
-  if (ready) atomicAdd(&s_ready, ready);
   for (int o = 0; o < RUN_TICKET_SLOTS; o++) tab[tid][o] = st[o].tickets | (st[o].fill << 28);
   __syncthreads();
   // ---- phase 2: inclusive prefix composition (Hillis-Steele): tab[i] := tab[i - off] then tab[i]
@@ -923,6 +914,16 @@ __device__ void scan_order_body(const ScanParams& P, const ScanBufs& B, uint32_t
     const int rs = B.ctb_order[t];
     const ScanCtb& C = B.ctb[rs];
     const uint32_t nr = C.n_runs, ib = C.intra_base;
+    if (!by_records && !C.slow) {
+      const uint64_t mm = C.micro_mask;
+      for (uint64_t tm = C.tick_mask; tm; tm &= tm - 1) {
+        const uint32_t r = (uint32_t)__builtin_ctzll(tm), s = ib + r;
+        const bool micro = (mm >> r) & 1;
+        uint32_t tk, sl;
+        scan_ticket_step(me, micro, &tk, &sl);
+        B.slots[tk * RUN_TICKET_SLOTS + sl] = micro ? (s | 0x80000000u) : s;
+      }
+    } else
     for (uint32_t r = 0; r < nr; r++) {
       const uint32_t s = ib + r;
       const uint32_t mic = B.runs[s].micro;
@@ -935,7 +936,8 @@ __device__ void scan_order_body(const ScanParams& P, const ScanBufs& B, uint32_t
   if (tid == 0) {
     K.n_batches = total;
     // workers: as many runs as can be in flight together - an anti-diagonal of the picture, or the runs that wait for nothing
-    K.widest = max(s_widest, s_ready);
+    K.widest = max(s_widest, K.n_ready);
+    if (K.n_isamp > cap_resid) scan_fail(B, DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE);      // (overlapping intra TUs - a malformed description - could ask for more residual samples than the picture has)
     K.max_rl = s_ndiag;
   }
 }
@@ -1049,16 +1051,17 @@ hipError_t scan_enqueue_batch(hipStream_t st, const ScanBatch& J)
   for (int i = 0; i < J.n; i++) { max_tus = std::max(max_tus, J.job[i].P.n_tus); max_ctbs = std::max(max_ctbs, J.job[i].P.n_ctbs); }
   const unsigned ny = (unsigned)J.n;
   if (max_tus > 0) hipLaunchKernelGGL(k_scan_tus, dim3((max_tus + 255) / 256, ny), dim3(256), 0, st, J);
-  bool any_empty = false;
-  for (int i = 0; i < J.n; i++) any_empty = any_empty || J.job[i].P.n_tus == 0;
-  if (any_empty || !J.pad) hipLaunchKernelGGL(k_scan_prefix, dim3(1, ny), dim3(256), 0, st, J);
   if (max_tus > 0) {
     hipLaunchKernelGGL(k_scan_ctbs, dim3(max_ctbs, ny), dim3(64), 0, st, J);
     // (the number of runs is only known on the device: fixed grids of wavefronts walk the run lists)
     // (512 wavefronts: with 128 / 256 / 512 / 1024 the product path of the bench made 1 860 / 2 310 / 2 630 / 2 380 pictures/s -
     //  fewer leave the run passes' latency chains too long, more crowd the reconstruction kernels of the other streams)
-    static const int run_grid = getenv("DE265HIP_SCAN_RUN_GRID") ? atoi(getenv("DE265HIP_SCAN_RUN_GRID")) : 512;
-    hipLaunchKernelGGL(k_scan_runs1, dim3(max_ctbs, ny), dim3(64), 0, st, J);        // (a wavefront per CTB)
+    static const int run_grid = getenv("DE265HIP_SCAN_RUN_GRID") ? atoi(getenv("DE265HIP_SCAN_RUN_GRID")) : 2048;
+    // (a wavefront per CTB; 4:2:0 and monochrome pictures have at most 384 intra TUs in a CTB: the smaller LDS arrays)
+    bool small_ctbs = true;
+    for (int i = 0; i < J.n; i++) small_ctbs = small_ctbs && J.job[i].P.cf <= 1;
+    if (small_ctbs) hipLaunchKernelGGL(k_scan_runs1<384>, dim3(max_ctbs, ny), dim3(64), 0, st, J);
+    else hipLaunchKernelGGL(k_scan_runs1<SR_TMAX>, dim3(max_ctbs, ny), dim3(64), 0, st, J);
     hipLaunchKernelGGL(k_scan_runs2, dim3(run_grid, ny), dim3(64), 0, st, J);
   }
   hipLaunchKernelGGL(k_scan_order, dim3(1, ny), dim3(SCO_THREADS), 0, st, J);      // (always: it reports to the host)

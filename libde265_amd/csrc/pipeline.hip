@@ -47,6 +47,7 @@ struct de265hip_pipeline {
   std::map<uint64_t, int> slot_of;              // launched, copy-out possibly still in flight: ticket -> slot
   std::map<uint64_t, int> failed;               // ticket -> error of prepare / build / run
   struct Built { PipeJob job; de265hip_picture* pic; int rc; bool enqueued; double t_sub, t_b0, t_b1, t_enq, t_ready; };
+  std::vector<std::array<double, 4>> chain_trace;   // DE265HIP_PIPE_TRACE: per scan chain: enqueued, reported, pictures built / in flight then
   std::vector<std::array<double, 8>> trace;     // DE265HIP_PIPE_TRACE: per picture: ticket, submitted, build start / end, enqueued, launch start / end
   std::map<uint64_t, Built> ready;              // built (or failed), waiting for their turn to be launched
   uint64_t next_ticket = 0, next_launch = 0;    // tickets are handed out and launched in submission order
@@ -108,6 +109,8 @@ void launcher(de265hip_pipeline* p)
   // pictures of the chains (upload + scan launched together) whose scans have not reported yet: the last picture of each
   std::vector<de265hip_picture*> open_chains;
   std::vector<double> open_since;
+  static const bool in_order = !getenv("DE265HIP_PIPE_ANY_ORDER");
+  static const int poll_us = getenv("DE265HIP_PIPE_POLL_US") ? std::max(1, atoi(getenv("DE265HIP_PIPE_POLL_US"))) : 50;
   for (;;) {
     de265hip_pipeline::Built todo; bool have_enq = false, have_launch = false;
     de265hip_picture* enq_pic[8]; uint64_t enq_tk[8]; int n_enq = 0;
@@ -119,6 +122,7 @@ void launcher(de265hip_pipeline* p)
         for (size_t i = 0; i < open_chains.size();)
           if (de265hip_picture_ready(open_chains[i]) != 0) {
             if (p->timing) p->t_chain += now() - open_since[i];
+            if (p->tracing) p->chain_trace.push_back({ open_since[i], now(), (double)p->ready.size(), (double)p->in_flight });
             open_chains.erase(open_chains.begin() + i); open_since.erase(open_since.begin() + i);
           } else i++;
         // Uploads and scans first: they run ahead of the launches on the copy streams.  The scan of a picture is a chain of
@@ -129,19 +133,29 @@ void launcher(de265hip_pipeline* p)
         // the device is idle, full batches when the scans are what everybody waits for.  (Round 4 before: every built picture
         // enqueued at once, 1.5 pictures per chain on average, the scan streams saturated at 3 900 pictures/s without any
         // reconstruction and 2 600 with it.)
+        // ... and only pictures in decode order without a gap: a chain that takes pictures 6-8 while picture 5 is still being
+        // built finishes for nothing - they are launched behind picture 5, whose chain comes later - and holds a chain slot
         n_enq = 0;
-        if ((int)open_chains.size() < p->chains)
+        if ((int)open_chains.size() < p->chains && !in_order) {
           for (auto& kv : p->ready) if (!kv.second.enqueued && !kv.second.rc && kv.second.pic && n_enq < p->batch) { enq_pic[n_enq] = kv.second.pic; enq_tk[n_enq++] = kv.first; }
+        } else if ((int)open_chains.size() < p->chains) {
+          for (uint64_t tk = p->next_launch; n_enq < p->batch; tk++) {
+            auto e = p->ready.find(tk);
+            if (e == p->ready.end()) break;                              // (not built yet: the chain waits for it)
+            if (e->second.enqueued || e->second.rc || !e->second.pic) continue;
+            enq_pic[n_enq] = e->second.pic; enq_tk[n_enq++] = tk;
+          }
+        }
         if (n_enq) { have_enq = true; break; }
         auto it = p->ready.find(p->next_launch);
         if (it != p->ready.end() && (it->second.enqueued || it->second.rc || !it->second.pic)) {
           // its turn - if its scan has reported (or it failed: the turn passes on).  The launcher never blocks on a scan while
           // pictures may arrive that want enqueueing
           if (it->second.rc || !it->second.pic || de265hip_picture_ready(it->second.pic) != 0) { todo = it->second; p->ready.erase(it); have_launch = true; break; }
-          p->cv_launch.wait_for(lk, std::chrono::microseconds(20));
+          p->cv_launch.wait_for(lk, std::chrono::microseconds(poll_us));
           continue;
         }
-        if (!open_chains.empty() || it != p->ready.end()) { p->cv_launch.wait_for(lk, std::chrono::microseconds(20)); continue; }
+        if (!open_chains.empty() || it != p->ready.end()) { p->cv_launch.wait_for(lk, std::chrono::microseconds(poll_us)); continue; }
         if (p->stop) return;
         p->cv_launch.wait(lk);
       }
@@ -285,6 +299,7 @@ void de265hip_pipeline_free(de265hip_pipeline* p)
     fprintf(stderr, "de265hip pipeline: %ld pictures, %d workers + 1 launcher; ms per picture: workers idle %.2f build (host stage) %.2f | launcher idle %.2f enqueue (upload + scan) %.2f launch %.2f | %.2f pictures per scan chain, a chain reports after %.2f ms\n",
             p->n_jobs, p->n_workers, 1e3 * p->t_idle / p->n_jobs, 1e3 * p->t_build / p->n_jobs, 1e3 * p->t_lidle / p->n_jobs,
             1e3 * p->t_enqueue / p->n_jobs, 1e3 * p->t_launch / p->n_jobs, (double)p->n_jobs / std::max(1L, p->n_chains), 1e3 * p->t_chain / std::max(1L, p->n_chains));
+  if (p->tracing) for (auto& r : p->chain_trace) fprintf(stderr, "chaintrace %p %.6f %.6f %.0f %.0f\n", (void*)p, r[0], r[1], r[2], r[3]);
   if (p->tracing) for (auto& r : p->trace) fprintf(stderr, "pipetrace %p %.0f %.6f %.6f %.6f %.6f %.6f %.6f %.6f\n", (void*)p, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
   delete p;
 }

@@ -57,7 +57,8 @@ struct ScanCtb {
   uint32_t n_intra, n_isamp;           // intra TUs and their samples
   uint32_t l0_base[4], rext_base, intra_base, isamp_base;      // scan_prefix: where this CTB's share of each list starts
   uint32_t n_runs;                     // scan_ctb
-  uint32_t pad;
+  uint32_t slow;                       // (device) more than 64 runs: scan_order walks the run records instead of the masks
+  unsigned long long tick_mask, micro_mask;      // (device, the run pass) bit r: run r of the CTB takes a ticket (it is not a front run) / is a micro run
 };
 static_assert(sizeof(ScanCtb) % 8 == 0, "ScanCtb layout");
 
@@ -68,6 +69,8 @@ struct ScanCounts {
   uint32_t n_runs, n_front, n_batches, widest, max_rl, n_mailboxes;
   uint32_t n_deps_alloc, n_segs_alloc, n_tasks, victim, sum_lvls, n_intra;
   uint32_t n_listed;                   // runs in run_list
+  uint32_t alloc[7];                   // (device) how far the task lists, the run-ordered TU array and the residual samples are given out (scan_ctb: a CTB takes its share with one atomic per list)
+  uint32_t n_ready;                    // (device) ticketed runs that wait for nothing
   unsigned long long alg_resid, alg_intra, alg_intra_front, n_isamp;
   uint32_t ready, pad1;                // (the host's copy only) the tag of the build, stored after everything else
 };

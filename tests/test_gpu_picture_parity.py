@@ -136,6 +136,14 @@ def test_empty_picture_and_errors(dec):
         dec.build(2, sp.desc)
     assert e.value.code == _abi.ERROR_NOT_IMPLEMENTED
     d.params.extended_precision_processing_flag = 0
+    # a CTB that no slice covers (a damaged stream: the reference's SAO returns for it, sao.cc:140, and decode_some marks it done,
+    # decctx.cc:751-757): de265hip_ctb_info has no "no slice" state, the description is refused - defined, not undefined
+    keep = d.ctbs[1].slice_idx
+    d.ctbs[1].slice_idx = 0xFFFF
+    with pytest.raises(backend.De265HipError) as e:
+        dec.build(2, sp.desc)
+    assert e.value.code == _abi.ERROR_PARAMETER_OUT_OF_RANGE
+    d.ctbs[1].slice_idx = keep
     d.tus[0].x0 = 4000
     with pytest.raises(backend.De265HipError) as e:      # (a malformed TU record: found by the device-side scan, reported when
         bad = dec.build(2, sp.desc)                      #  the picture is launched - or asked for its statistics)
