@@ -475,6 +475,24 @@ def main():
     dom = max(ktimes_all, key=lambda k: ktimes_all[k][0])
     for d in decs:
         d.set_profiling(True, only=None if args.events == "all" else [dom])
+    # (experiment, DE265HIP_BENCH_NOISE=n: n host threads launch tiny torch kernels on streams of their own during the replay -
+    #  how much do kernel boundaries of OTHER streams, with their cache write-backs and invalidates, cost the reconstruction?)
+    noise_n, noise_stop, noise_threads, noise_count = int(os.environ.get("DE265HIP_BENCH_NOISE", "0")), [False], [], [0]
+    if noise_n:
+        import threading
+
+        def noise():
+            st = torch.cuda.Stream()
+            x = torch.zeros(int(os.environ.get("DE265HIP_BENCH_NOISE_ELEMS", "64")), device="cuda")
+            with torch.cuda.stream(st):
+                while not noise_stop[0]:
+                    for _ in range(64):
+                        x.add_(1.0)
+                    noise_count[0] += 64
+                    st.synchronize()
+        noise_threads = [threading.Thread(target=noise) for _ in range(noise_n)]
+        for t_ in noise_threads:
+            t_.start()
     timer = farm.RankTimer(dist, sync, device=red_dev)
     timer.start()                       # barrier + synchronize
     t_host = time.perf_counter()
@@ -482,6 +500,11 @@ def main():
         step()
     t_host = time.perf_counter() - t_host   # host time spent enqueueing (the device runs behind it)
     replay_elapsed = timer.stop()       # synchronize + barrier, MAX over ranks
+    if noise_n:
+        noise_stop[0] = True
+        for t_ in noise_threads:
+            t_.join()
+        sys.stderr.write("noise: %d tiny launches during the replay (%.0f per second)\n" % (noise_count[0], noise_count[0] / replay_elapsed))
     ktimes_replay = collect()           # the dominant kernel's launches of that region (all kernels' with --events all)
     for d in decs:
         d.set_profiling(False)

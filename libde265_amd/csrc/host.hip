@@ -92,6 +92,7 @@ struct de265hip_decoder {
   hipStream_t upload_streams[2] = {};
   uint64_t upload_turn = 0;
   hipStream_t out_stream = nullptr;   // de265hip_dpb_download_async: decoded pictures leave on their own stream, behind an event of `stream`
+  bool out_pooled = false;            // ... one of the process's two (DeviceStreams)
   hipEvent_t out_fence = nullptr;
   std::mutex mu;                      // guards live, the two pools and slot allocation: build()/free() may come from several host threads
   std::vector<de265hip_picture*> live;        // pictures built on this decoder and not yet freed (decoder_free orphans them)
@@ -596,7 +597,8 @@ constexpr int kKernelStreams = 4;
 // tools/exp/r4b_window.sh).  Copy-out streams stay per decoder (created when first used).
 constexpr int kScanStreams = 4, kUploadStreams = 2;
 struct DeviceStreams {
-  hipStream_t kernel[kKernelStreams] = {}, scan[kScanStreams] = {}, upload[kUploadStreams] = {};
+  hipStream_t kernel[kKernelStreams] = {}, scan[kScanStreams] = {}, upload[kUploadStreams] = {}, out[2] = {}, spare = nullptr;
+  int n_scan = kScanStreams, next_out = 0;
   int next_kernel = 0, next_scan = 0, next_upload = 0;
   bool ok = false;
 };
@@ -617,9 +619,27 @@ static DeviceStreams* device_streams(int device)
     if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return nullptr;      // (numerically: lowest, greatest priority)
     if (const char* e = getenv("DE265HIP_FLAT_PRIORITIES")) if (atoi(e)) lo = hi = 0;
     bool ok = true;
-    for (int i = 0; i < kKernelStreams && ok; i++) ok = hipStreamCreateWithPriority(&D.kernel[i], hipStreamNonBlocking, 0) == hipSuccess;      // back to back: four pipes
-    for (int i = 0; i < kScanStreams && ok; i++) ok = hipStreamCreateWithPriority(&D.scan[i], hipStreamNonBlocking, hi) == hipSuccess;
-    for (int i = 0; i < kUploadStreams && ok; i++) ok = hipStreamCreateWithPriority(&D.upload[i], hipStreamNonBlocking, lo) == hipSuccess;
+    // The order of creation decides the dispatch pipe of each stream's hardware queue (pipe = number of the queue % 4).  Three
+    // kernel streams on three pipes, and the fourth pipe for the scan streams: a kernel of the reconstruction with a grid of
+    // tens of thousands of workgroups keeps its pipe for as long as it runs, and a scan kernel queued on that pipe - seven
+    // dependent ones per scan - waited behind it each time (and the other way round).  Every fourth queue created is a scan
+    // stream; in between come the two upload streams, the fourth kernel stream (a fourth decoder shares a pipe with the third:
+    // there are only four) and two streams for copy-outs.  At most four new queues per priority (GPU_MAX_HW_QUEUES defaults to
+    // 4 per priority pool; a stream beyond that re-uses a queue and the count would slip).  DE265HIP_SCAN_PIPES=0: the round's
+    // first order (kernel x 4, scan x 4, upload x 2: a scan stream on every pipe).
+    const bool own_pipe = !(getenv("DE265HIP_SCAN_PIPES") && atoi(getenv("DE265HIP_SCAN_PIPES")) == 0);
+    auto mk = [&](hipStream_t* st_, int prio) { if (ok) ok = hipStreamCreateWithPriority(st_, hipStreamNonBlocking, prio) == hipSuccess; };
+    if (own_pipe) {
+      mk(&D.kernel[0], 0); mk(&D.kernel[1], 0); mk(&D.kernel[2], 0); mk(&D.scan[0], hi);
+      mk(&D.upload[0], lo); mk(&D.upload[1], lo); mk(&D.kernel[3], 0); mk(&D.scan[1], hi);
+      mk(&D.out[0], lo); mk(&D.out[1], lo); mk(&D.spare, hi); mk(&D.scan[2], hi);
+      D.n_scan = 3;
+    } else {
+      for (int i = 0; i < kKernelStreams; i++) mk(&D.kernel[i], 0);
+      for (int i = 0; i < kScanStreams; i++) mk(&D.scan[i], hi);
+      for (int i = 0; i < kUploadStreams; i++) mk(&D.upload[i], lo);
+      D.n_scan = kScanStreams;
+    }
     if (!ok) return nullptr;                             // (leaves what was created: the process is about to fail anyway)
     D.ok = true;
     it = g_streams.emplace(device, D).first;
@@ -640,7 +660,14 @@ static hipStream_t pooled_scan_stream(int device)
   if (own_streams()) return nullptr;
   std::lock_guard<std::mutex> lk(g_streams_mu);
   DeviceStreams* D = device_streams(device);
-  return D ? D->scan[D->next_scan++ % kScanStreams] : nullptr;
+  return D ? D->scan[D->next_scan++ % D->n_scan] : nullptr;
+}
+static hipStream_t pooled_out_stream(int device)
+{
+  if (own_streams()) return nullptr;
+  std::lock_guard<std::mutex> lk(g_streams_mu);
+  DeviceStreams* D = device_streams(device);
+  return (D && D->out[0]) ? D->out[D->next_out++ & 1] : nullptr;
 }
 static hipStream_t pooled_upload_stream(int device)
 {
@@ -695,7 +722,7 @@ int de265hip_decoder_new(de265hip_decoder** out, int device)
   d->n_copy_streams = 4;               // (pooled: every decoder takes turns on all four; 2 / 3 / 4: 2 570 / 2 770 / 2 900 pictures/s, three decoders)
   if (const char* e = getenv("DE265HIP_COPY_STREAMS")) d->n_copy_streams = std::min((int)de265hip_decoder::kMaxCopyStreams, std::max(1, atoi(e)));
   d->streams_pooled = d->kstream_index >= 0;
-  if (d->streams_pooled) d->n_copy_streams = std::min(d->n_copy_streams, kScanStreams);
+  if (d->streams_pooled) d->n_copy_streams = std::min(d->n_copy_streams, 3);
   for (int i = 0; i < d->n_copy_streams; i++) {
     if (d->streams_pooled) d->copy_streams[i] = pooled_scan_stream(d->device);
     else HIPCHK(hipStreamCreateWithPriority(&d->copy_streams[i], hipStreamNonBlocking, d->prio_high), DE265HIP_ERROR_INIT_FAILED);
@@ -768,7 +795,7 @@ void de265hip_decoder_free(de265hip_decoder* d)
   for (int i = 0; i < 2; i++) if (d->upload_streams[i]) (void)hipStreamSynchronize(d->upload_streams[i]);
   for (int i = 0; i < d->n_copy_streams; i++) if (d->copy_streams[i]) (void)hipStreamSynchronize(d->copy_streams[i]);
   (void)sync_all_lanes(d);
-  if (d->out_stream) { (void)hipStreamSynchronize(d->out_stream); (void)hipStreamDestroy(d->out_stream); }
+  if (d->out_stream) { (void)hipStreamSynchronize(d->out_stream); if (!d->out_pooled) (void)hipStreamDestroy(d->out_stream); }
   if (d->out_fence) (void)hipEventDestroy(d->out_fence);
   {
     std::lock_guard<std::mutex> lk(d->mu);
@@ -897,7 +924,8 @@ int de265hip_dpb_download_async(de265hip_decoder* d, int slot, int c, void* dst,
   if (w == 0 || h == 0) return DE265HIP_OK;               // (a chroma plane of a monochrome picture)
   std::lock_guard<std::mutex> lk(d->mu);
   if (!d->out_stream) {
-    HIPCHK(hipStreamCreateWithPriority(&d->out_stream, hipStreamNonBlocking, d->prio_low), DE265HIP_ERROR_DECODING);
+    if (d->streams_pooled && (d->out_stream = pooled_out_stream(d->device)) != nullptr) d->out_pooled = true;
+    else HIPCHK(hipStreamCreateWithPriority(&d->out_stream, hipStreamNonBlocking, d->prio_low), DE265HIP_ERROR_DECODING);
     HIPCHK(hipEventCreateWithFlags(&d->out_fence, hipEventDisableTiming), DE265HIP_ERROR_DECODING);
   }
   if (!s->dl_done) HIPCHK(hipEventCreateWithFlags(&s->dl_done, hipEventDisableTiming), DE265HIP_ERROR_DECODING);

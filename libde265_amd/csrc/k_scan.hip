@@ -34,6 +34,14 @@ __device__ __forceinline__ uint32_t wave_sum_u(uint32_t x)
 }
 __device__ __forceinline__ int wave_min_i(int v) { return 0x7FFFFFFF - wave_max_i(0x7FFFFFFF - v); }      // (v >= 0)
 __device__ __forceinline__ uint64_t lanes_below(int lane) { return lane ? (~0ull >> (64 - lane)) : 0ull; }
+// The scan's kernels are chains of dependent steps in a few wavefronts, and what the decoder's launches wait for; next to them
+// on the CUs run the reconstruction kernels of the other decoders, thousands of wavefronts that fill every issue slot.  At the
+// default wave priority a scan wavefront gets its turn once per round of the resident wavefronts: its chains ran 2-4x slower
+// than alone.  (DE265HIP_SCAN_PRIO compiled as a constant: s_setprio takes an immediate.)
+#ifndef D265_SCAN_PRIO
+#define D265_SCAN_PRIO 3
+#endif
+#define SCAN_PRIO() __builtin_amdgcn_s_setprio(D265_SCAN_PRIO)
 #define WAVE_ORDER() asm volatile("" ::: "memory")        // single-wavefront workgroups: LDS executes a wavefront's operations in order; only the compiler must not move them
 
 // The per-TU pass on the device.  scan_core.h scan_tu is the same pass as plain code (the CPU rehearsal); what differs here:
@@ -190,14 +198,38 @@ __global__ __launch_bounds__(256)
 void k_scan_tus(ScanBatch J)
 {
   if (blockIdx.y >= (unsigned)J.n) return;
+  SCAN_PRIO();
   const ScanParams& P = J.job[blockIdx.y].P; const ScanBufs& B = J.job[blockIdx.y].B;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i == 0) { if (B.err_word) *B.err_word = 0; B.counts->victim = 0xFFFFFFFFu; }      // (the picture's kernels that may raise the word come behind the scan)
+  if (blockIdx.x == 0 && threadIdx.x == 0) { if (B.err_word) *B.err_word = 0; B.counts->victim = 0xFFFFFFFFu; }      // (the picture's kernels that may raise the word come behind the scan)
   __shared__ uint32_t s_tot[7];                               // this workgroup's share of the list totals (scan_prefix's job until round 4)
   if (threadIdx.x < 7) s_tot[threadIdx.x] = 0;
   __syncthreads();
   uint32_t alg_resid = 0, alg_intra = 0, n_tasks = 0;
-  scan_tu_dev(P, B, i, i < P.n_tus, alg_resid, alg_intra, n_tasks, s_tot);
+  bool bad = false;
+  // (a bounded grid that walks the records: see scan_enqueue_batch)
+  for (int blk = blockIdx.x; blk * 256 < P.n_tus; blk += gridDim.x) {
+    const int i = blk * 256 + threadIdx.x;
+    scan_tu_dev(P, B, i, i < P.n_tus, alg_resid, alg_intra, n_tasks, s_tot);
+    // coefficient positions inside their TU's block (de265hip_picture_build's job on the host until round 3): the workgroup's 256
+    // records sixteen at a time, sixteen lanes striding each list (a thread walking its own list alone took 7x as long); a
+    // position beyond the block is folded into it and the picture fails
+    if (P.flags & SCANF_CHECK_POS) {
+      const int sub = threadIdx.x & 15;
+      for (int g = 0; g < 16; g++) {
+        const int j = blk * 256 + g * 16 + (threadIdx.x >> 4);
+        if (j >= P.n_tus) break;
+        const de265hip_tu tu = B.tus[j];
+        if (!(tu.flags & DE265HIP_TU_CBF) || !scan_tu_valid(P, tu)) continue;
+        const unsigned nS = 1u << (2 * tu.log2_size), n = tu.n_coeff;
+        uint16_t* p = B.coeff_pos + tu.coeff_offset;
+        for (unsigned k = sub; k < n; k += 16) {
+          const unsigned q = p[k];
+          if (q >= nS) { p[k] = (uint16_t)(q & (nS - 1)); bad = true; }
+        }
+      }
+    }
+  }
+  if (bad) scan_fail(B, DE265HIP_ERROR_DECODING);
   // one atomic per wavefront and sum
   alg_resid = wave_sum_u(alg_resid); alg_intra = wave_sum_u(alg_intra); n_tasks = wave_sum_u(n_tasks);
   if ((threadIdx.x & 63) == 0) {
@@ -212,26 +244,6 @@ void k_scan_tus(ScanBatch J)
     else if (threadIdx.x == 5) atomicAdd(&B.counts->n_intra, v);
     else scan_add64(&B.counts->n_isamp, v);
   }
-  // coefficient positions inside their TU's block (de265hip_picture_build's job on the host until round 3): the workgroup's 256
-  // records sixteen at a time, sixteen lanes striding each list (a thread walking its own list alone took 7x as long); a
-  // position beyond the block is folded into it and the picture fails
-  if (P.flags & SCANF_CHECK_POS) {
-    const int sub = threadIdx.x & 15;
-    bool bad = false;
-    for (int g = 0; g < 16; g++) {
-      const int j = blockIdx.x * 256 + g * 16 + (threadIdx.x >> 4);
-      if (j >= P.n_tus) break;
-      const de265hip_tu tu = B.tus[j];
-      if (!(tu.flags & DE265HIP_TU_CBF) || !scan_tu_valid(P, tu)) continue;
-      const unsigned nS = 1u << (2 * tu.log2_size), n = tu.n_coeff;
-      uint16_t* p = B.coeff_pos + tu.coeff_offset;
-      for (unsigned k = sub; k < n; k += 16) {
-        const unsigned q = p[k];
-        if (q >= nS) { p[k] = (uint16_t)(q & (nS - 1)); bad = true; }
-      }
-    }
-    if (bad) scan_fail(B, DE265HIP_ERROR_DECODING);
-  }
 }
 
 // The CTB pass, one WAVEFRONT per CTB (scan_core.h scan_ctb is the same pass as one thread's loop: the CPU rehearsal; the
@@ -243,15 +255,21 @@ void k_scan_tus(ScanBatch J)
 #define SCW_W 25                         // window columns: cell x in [-1, 23] relative to the CTB
 #define SCW_H 17                         // window rows:    cell y in [-1, 15]
 #define SCW_NONLOCAL 0x40000000u         // an intra TU of another CTB covers the cell
+__device__ void scan_ctb_wave(const ScanParams& P, const ScanBufs& B, const int rs, const int lane);
 __global__ __launch_bounds__(64)
 void k_scan_ctbs(ScanBatch J)
 {
   if (blockIdx.y >= (unsigned)J.n) return;
+  SCAN_PRIO();
   const ScanParams& P = J.job[blockIdx.y].P; const ScanBufs& B = J.job[blockIdx.y].B;
+  if (B.counts->status) return;
+  // (a bounded grid: every wavefront takes CTBs in turn, see scan_enqueue_batch)
+  for (int rs = blockIdx.x; rs < P.n_ctbs; rs += gridDim.x) { scan_ctb_wave(P, B, rs, threadIdx.x); __syncthreads(); }
+}
+__device__ void scan_ctb_wave(const ScanParams& P, const ScanBufs& B, const int rs, const int lane)
+{
   __shared__ uint32_t win[3][SCW_W * SCW_H];
   __shared__ uint8_t s_ntus[768];
-  const int rs = blockIdx.x, lane = threadIdx.x;
-  if (rs >= P.n_ctbs || B.counts->status) return;
   ScanCtb& C = B.ctb[rs];
   const uint32_t first = C.first_tu, end = C.end_tu, seen = C.seen, n_intra = C.n_intra;
   if (seen == 0) { if (lane == 0) C.n_runs = 0; return; }
@@ -298,8 +316,14 @@ void k_scan_ctbs(ScanBatch J)
   uint32_t cls_start[4];
   for (int k = 0; k < 4; k++) cls_start[k] = scan_l0_class_start(B.counts->n_l0_size, k);
   uint32_t inter_at[4] = { 0, 0, 0, 0 }, rext_at = 0;
-  int cur_run[3] = { -1, -1, -1 };
+  int cur_run0 = -1, cur_run1 = -1, cur_run2 = -1;      // the current run of each colour component
   int n_local = 0;
+  // (kernel arguments the per-TU loop needs, once)
+  const int sws = P.subw == 2 ? 1 : 0, shs = P.subh == 2 ? 1 : 0;
+  const int ox4_y = cx0 >> 2, oy4_y = cy0 >> 2, ox4_c = (cx0 >> sws) >> 2, oy4_c = (cy0 >> shs) >> 2;
+  const int cwid = P.cwid, chei = P.chei, width = P.width, height = P.height;
+  const bool merge_on = (P.flags & SCANF_MERGE) != 0;
+  uint32_t* const tu_info_out = B.tu_info;
   for (uint32_t base = first; base < end; base += 64) {
     const uint32_t i = base + lane;
     const bool have = i < end;
@@ -328,7 +352,8 @@ void k_scan_ctbs(ScanBatch J)
       }
       rext_at += __popcll(m);
     }
-    // -- the intra TUs of the chunk, one after the other
+    // -- the intra TUs of the chunk, one after the other (everything that does not change from TU to TU is in registers by now:
+    // a lone wavefront pays a dozen cycles per dependent instruction, a scalar load from the kernel's arguments a few hundred)
     const uint32_t pos = (uint32_t)tu.x0 | ((uint32_t)tu.y0 << 16), shape = (uint32_t)tu.log2_size | ((uint32_t)tu.c_idx << 8);
     for (uint64_t im = __ballot(cls == 3); im; im &= im - 1) {
       const int src = __builtin_ctzll(im);
@@ -336,38 +361,37 @@ void k_scan_ctbs(ScanBatch J)
       const uint64_t mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(av >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)av, src);
       const uint64_t need0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(nd >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)nd, src);
       const int xB = pos_u & 0xFFFF, yB = pos_u >> 16, log2 = shape_u & 0xFF, c = shape_u >> 8, nT = 1 << log2, corner = nT >> 1;
-      const int sw = c ? P.subw : 1, sh = c ? P.subh : 1;
-      const int ox4 = (cx0 / sw) >> 2, oy4 = (cy0 / sh) >> 2;
-      const int cw = c ? P.cwid : P.width, ch = c ? P.chei : P.height;
+      const int ox4 = c ? ox4_c : ox4_y, oy4 = c ? oy4_c : oy4_y;
       const int wx0 = (xB >> 2) - ox4, wy0 = (yB >> 2) - oy4;                 // the TU's first cell in window coordinates
       uint32_t* W = win[c];
       auto look = [&](int wx, int wy) -> uint32_t {
-        return (wx >= -1 && wx < SCW_W - 1 && wy >= -1 && wy < SCW_H - 1) ? W[(wy + 1) * SCW_W + (wx + 1)] : 0u;
+        return ((unsigned)(wx + 1) < (unsigned)SCW_W && (unsigned)(wy + 1) < (unsigned)SCW_H) ? W[(wy + 1) * SCW_W + (wx + 1)] : 0u;
       };
       // a lane per neighbour unit: left column bottom -> top, corner, top row left -> right
       const bool in_mask = (mask >> lane) & 1, in_need = (need0 >> lane) & 1;
       uint32_t v = 0;
       if (in_mask) {
-        const int wx = lane < corner ? wx0 - 1 : (lane == corner ? wx0 - 1 : wx0 + (lane - corner - 1));
+        const int wx = lane <= corner ? wx0 - 1 : wx0 + (lane - corner - 1);
         const int wy = lane < corner ? wy0 + corner - 1 - lane : wy0 - 1;
         v = look(wx, wy);
       }
       const bool local = v >> 31, nonlocal = v == SCW_NONLOCAL;
       const int vrun = (int)(v & 0xFFFF), vlev = (int)((v >> 16) & 0xFF);
-      const int crun = cur_run[c];
+      const int crun = c == 0 ? cur_run0 : (c == 1 ? cur_run1 : cur_run2);
       const bool foreign = __ballot(in_need && !local && !nonlocal) != 0;
       const bool any_nonlocal = __ballot(in_need && nonlocal) != 0;
       const uint64_t loc_m = __ballot(in_need && local);
       const bool reads_cur = __ballot(in_need && local && vrun == crun) != 0;
-      int llev = wave_max_i((in_need && local && vrun == crun) ? vlev : 0) + 1;
+      int llev = 1;
+      if (reads_cur) llev = wave_max_i((in_need && local && vrun == crun) ? vlev : 0) + 1;
       const int p0 = loc_m ? __builtin_amdgcn_readlane(vrun, __builtin_ctzll(loc_m)) : -1;
-      const bool multi = __ballot(in_need && local && vrun != p0) != 0;
       int r = crun;
       bool extends = r >= 0 && s_ntus[r] < 255;
       if (extends && !reads_cur) extends = __ballot(in_mask && !in_need && local && vrun == r) != 0;
       bool merged = false;
-      if (!extends && (P.flags & SCANF_MERGE) && p0 >= 0 && !multi && !any_nonlocal && s_ntus[p0] < 255) {
+      if (!extends && merge_on && p0 >= 0 && !any_nonlocal && __ballot(in_need && local && vrun != p0) == 0 && s_ntus[p0] < 255) {
         // in-run level: behind everything of that run in the row above and the column to the left of the TU's neighbourhood
+        const int cw = c ? cwid : width, ch = c ? chei : height;
         const int ux0 = (xB - 4 > 0 ? xB - 4 : 0) >> 2, uy0 = (yB - 4 > 0 ? yB - 4 : 0) >> 2;
         const int ux1 = (cw - 1 < xB + 2 * nT + 3 ? cw - 1 : xB + 2 * nT + 3) >> 2, uy1 = (ch - 1 < yB + 2 * nT + 3 ? ch - 1 : yB + 2 * nT + 3) >> 2;
         int lv = 0;
@@ -376,15 +400,17 @@ void k_scan_ctbs(ScanBatch J)
         const int lx = wave_max_i(lv);
         if (lx + 1 <= 250) { r = p0; llev = lx + 1; merged = true; }
       }
-      if (!extends && !merged) { r = n_local++; cur_run[c] = r; llev = 1; }
+      if (!extends && !merged) {
+        r = n_local++; llev = 1;
+        if (c == 0) cur_run0 = r; else if (c == 1) cur_run1 = r; else cur_run2 = r;
+      }
       WAVE_ORDER();                                      // (every lane has read s_ntus and the window)
       if (lane == 0) {
         s_ntus[r]++;
-        B.tu_info[base + src] = (uint32_t)r | ((uint32_t)llev << 16) | (foreign ? SCAN_TI_FOREIGN : 0u) | SCAN_TI_INTRA;
-        B.tu_run[base + src] = ibase + (uint32_t)r;
+        tu_info_out[base + src] = (uint32_t)r | ((uint32_t)llev << 16) | (foreign ? SCAN_TI_FOREIGN : 0u) | SCAN_TI_INTRA;
       }
-      const int n4 = nT >> 2;
-      if (lane < n4 * n4) W[(wy0 + lane / n4 + 1) * SCW_W + (wx0 + lane % n4 + 1)] = (uint32_t)r | ((uint32_t)llev << 16) | (1u << 31);
+      const int l4 = log2 - 2;
+      if (lane < (1 << (2 * l4))) W[(wy0 + (lane >> l4) + 1) * SCW_W + (wx0 + (lane & ((1 << l4) - 1)) + 1)] = (uint32_t)r | ((uint32_t)llev << 16) | (1u << 31);
       WAVE_ORDER();
     }
   }
@@ -435,12 +461,23 @@ __device__ __forceinline__ uint32_t wave_scan_incl_u(uint32_t x)
 #define SR_TILE 32                       // runs per tile.  LDS per workgroup: 10 KB (4:2:0) / 13 KB - what decides how many CTBs
                                          // are worked on at once next to k_run's 53 KB workgroups (with 21 KB: two per CU)
 enum { RF_FOREIGN = 1, RF_BIG = 2, RF_TOO_BIG = 4, RF_BAD = 8, RF_DENSE0 = 16, RF_MICRO = 32, RF_DENSE = 64, RF_MB = 128, RF_PHASED = 256 };
+template <int TMAX> __device__ void scan_runs1_wave(const ScanParams& P, const ScanBufs& B, const int rs, const int lane);
 template <int TMAX>
 __global__ __launch_bounds__(64)
 void k_scan_runs1(ScanBatch J)
 {
   if (blockIdx.y >= (unsigned)J.n) return;
+  SCAN_PRIO();
   const ScanParams& P = J.job[blockIdx.y].P; const ScanBufs& B = J.job[blockIdx.y].B;
+  for (int rs = blockIdx.x; rs < P.n_ctbs; rs += gridDim.x) {
+    if (B.counts->status) return;
+    scan_runs1_wave<TMAX>(P, B, rs, threadIdx.x);
+    __syncthreads();
+  }
+}
+template <int TMAX>
+__device__ void scan_runs1_wave(const ScanParams& P, const ScanBufs& B, const int rs, const int lane)
+{
   __shared__ uint32_t s_w[TMAX];                       // per intra TU of the CTB (decode order): run | level << 10 | (log2 - 2) << 18 | residual-only task << 20 | rext << 21 | foreign << 22
   __shared__ uint16_t s_key[TMAX];                     // list << 8 | level (ties inside a run: decode order)
   __shared__ uint16_t s_ix[TMAX];                      // its record, relative to the CTB's first
@@ -450,8 +487,6 @@ void k_scan_runs1(ScanBatch J)
   __shared__ uint32_t r_first[SR_TILE], r_res[SR_TILE], r_robase[4][SR_TILE], r_rxbase[SR_TILE], r_depoff[SR_TILE], r_mb[SR_TILE];
   __shared__ uint32_t s_tab[SR_HASH];
   __shared__ uint8_t s_rdy[64];
-  const int rs = blockIdx.x, lane = threadIdx.x;
-  if (rs >= P.n_ctbs || B.counts->status) return;
   const ScanCtb& C = B.ctb[rs];
   const uint32_t n_runs = C.n_runs;
   if (n_runs == 0) return;
@@ -779,6 +814,7 @@ __global__ __launch_bounds__(64)
 void k_scan_runs2(ScanBatch J)
 {
   if (blockIdx.y >= (unsigned)J.n) return;
+  SCAN_PRIO();
   const ScanParams& P = J.job[blockIdx.y].P; const ScanBufs& B = J.job[blockIdx.y].B;
   __shared__ TuTask s_tus[SCR_MAX];
   const int lane = threadIdx.x;
@@ -818,6 +854,7 @@ __global__ __launch_bounds__(SCO_THREADS)
 void k_scan_order(ScanBatch J)
 {
   if (blockIdx.y >= (unsigned)J.n) return;
+  SCAN_PRIO();
   const ScanParams& P = J.job[blockIdx.y].P; const ScanBufs& B = J.job[blockIdx.y].B;
   const uint32_t cap_levels = J.job[blockIdx.y].cap_levels;
   // the third run pass first (a thread per listed run, scan_core.h scan_run3: the runs somebody reads through their mailbox)
@@ -947,6 +984,7 @@ __global__ __launch_bounds__(256)
 void k_build_prep(PrepBatch J)
 {
   if (blockIdx.y >= (unsigned)J.n) return;
+  SCAN_PRIO();
   const PrepJob& Q = J.job[blockIdx.y];
   const unsigned long long step = (unsigned long long)gridDim.x * 256 * 16, first = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 16;
   {
@@ -969,11 +1007,12 @@ __global__ __launch_bounds__(256)
 void k_motion_batch(PrepBatch J)
 {
   if (blockIdx.y >= (unsigned)J.n) return;
+  SCAN_PRIO();
   const PrepJob& Q = J.job[blockIdx.y];
-  const int i = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
-  if (i >= Q.n_pus) return;
+  const int sub = threadIdx.x & 15;
+  for (int i = blockIdx.x * 16 + (threadIdx.x >> 4); i < Q.n_pus; i += gridDim.x * 16) {
   const de265hip_pu pu = Q.pus[i];
-  if (pu.slice_idx >= Q.n_slices) return;
+  if (pu.slice_idx >= Q.n_slices) continue;
   de265hip_motion m;
   for (int l = 0; l < 2; l++) {
     const bool on = (pu.pred_flag >> l) & 1;
@@ -987,6 +1026,7 @@ void k_motion_batch(PrepBatch J)
     const int x = (pu.x >> 2) + q % bw, y = (pu.y >> 2) + q / bw;
     if (x < Q.w4 && y < Q.h4) Q.motion[x + y * Q.w4] = m;
   }
+  }
 }
 
 hipError_t prep_enqueue_batch(hipStream_t st, const PrepBatch& J)
@@ -995,9 +1035,11 @@ hipError_t prep_enqueue_batch(hipStream_t st, const PrepBatch& J)
   unsigned long long most = 0; int most_pus = 0;
   for (int i = 0; i < J.n; i++) { most = std::max(most, std::max(J.job[i].zero_bytes, J.job[i].ff ? J.job[i].ff_bytes : 0ull)); most_pus = std::max(most_pus, J.job[i].ff ? J.job[i].n_pus : 0); }
   // (a thread stores 16 bytes per step; 2048 workgroups at most: a grid that is resident at once)
-  const unsigned blocks = (unsigned)std::min<unsigned long long>(2048, (most + 256 * 16 - 1) / (256 * 16));
+  // (bounded grids: see scan_enqueue_batch)
+  const unsigned cap = std::max(64u, 1024u / (unsigned)J.n);
+  const unsigned blocks = (unsigned)std::min<unsigned long long>(cap, (most + 256 * 16 - 1) / (256 * 16));
   if (blocks) hipLaunchKernelGGL(k_build_prep, dim3(blocks, (unsigned)J.n), dim3(256), 0, st, J);
-  if (most_pus > 0) hipLaunchKernelGGL(k_motion_batch, dim3((most_pus + 15) / 16, (unsigned)J.n), dim3(256), 0, st, J);
+  if (most_pus > 0) hipLaunchKernelGGL(k_motion_batch, dim3(std::min<unsigned>((most_pus + 15) / 16, cap), (unsigned)J.n), dim3(256), 0, st, J);
   return hipGetLastError();
 }
 
@@ -1050,19 +1092,25 @@ hipError_t scan_enqueue_batch(hipStream_t st, const ScanBatch& J)
   int max_tus = 0, max_ctbs = 0;
   for (int i = 0; i < J.n; i++) { max_tus = std::max(max_tus, J.job[i].P.n_tus); max_ctbs = std::max(max_ctbs, J.job[i].P.n_ctbs); }
   const unsigned ny = (unsigned)J.n;
-  if (max_tus > 0) hipLaunchKernelGGL(k_scan_tus, dim3((max_tus + 255) / 256, ny), dim3(256), 0, st, J);
+  // Bounded grids that walk their units (records, CTBs, runs): a dispatch pipe hands out ONE kernel's workgroups at a time, and a
+  // grid that does not fit the device at once keeps its pipe until its last workgroup has found a place - a batch of four
+  // pictures' per-CTB passes (8 160 one-wavefront workgroups) for most of its run time.  The kernel stream of some decoder
+  // lives on the same pipe (there are four pipes): its next kernel waited behind the scan's.  (DE265HIP_SCAN_GRID: the
+  // wavefronts of a launch, all pictures of the batch together.)
+  static const int scan_grid = getenv("DE265HIP_SCAN_GRID") ? std::max(64, atoi(getenv("DE265HIP_SCAN_GRID"))) : 1024;
+  const unsigned per_pic = (unsigned)std::max(32, scan_grid / (int)ny);
+  if (max_tus > 0) hipLaunchKernelGGL(k_scan_tus, dim3(std::min<unsigned>((max_tus + 255) / 256, std::max(8u, per_pic / 4)), ny), dim3(256), 0, st, J);
   if (max_tus > 0) {
-    hipLaunchKernelGGL(k_scan_ctbs, dim3(max_ctbs, ny), dim3(64), 0, st, J);
+    hipLaunchKernelGGL(k_scan_ctbs, dim3(std::min<unsigned>(max_ctbs, per_pic), ny), dim3(64), 0, st, J);
     // (the number of runs is only known on the device: fixed grids of wavefronts walk the run lists)
     // (512 wavefronts: with 128 / 256 / 512 / 1024 the product path of the bench made 1 860 / 2 310 / 2 630 / 2 380 pictures/s -
     //  fewer leave the run passes' latency chains too long, more crowd the reconstruction kernels of the other streams)
-    static const int run_grid = getenv("DE265HIP_SCAN_RUN_GRID") ? atoi(getenv("DE265HIP_SCAN_RUN_GRID")) : 2048;
     // (a wavefront per CTB; 4:2:0 and monochrome pictures have at most 384 intra TUs in a CTB: the smaller LDS arrays)
     bool small_ctbs = true;
     for (int i = 0; i < J.n; i++) small_ctbs = small_ctbs && J.job[i].P.cf <= 1;
-    if (small_ctbs) hipLaunchKernelGGL(k_scan_runs1<384>, dim3(max_ctbs, ny), dim3(64), 0, st, J);
-    else hipLaunchKernelGGL(k_scan_runs1<SR_TMAX>, dim3(max_ctbs, ny), dim3(64), 0, st, J);
-    hipLaunchKernelGGL(k_scan_runs2, dim3(run_grid, ny), dim3(64), 0, st, J);
+    if (small_ctbs) hipLaunchKernelGGL(k_scan_runs1<384>, dim3(std::min<unsigned>(max_ctbs, per_pic), ny), dim3(64), 0, st, J);
+    else hipLaunchKernelGGL(k_scan_runs1<SR_TMAX>, dim3(std::min<unsigned>(max_ctbs, per_pic), ny), dim3(64), 0, st, J);
+    hipLaunchKernelGGL(k_scan_runs2, dim3(per_pic, ny), dim3(64), 0, st, J);
   }
   hipLaunchKernelGGL(k_scan_order, dim3(1, ny), dim3(SCO_THREADS), 0, st, J);      // (always: it reports to the host)
   return hipGetLastError();

@@ -1,0 +1,6 @@
+#!/bin/bash
+for cfg in "768 2 9" "1024 2 9" "1024 1 9" "1536 2 9" "1024 2 6" "1024 2 12" "1024 2 9 8"; do set -- $cfg
+  DE265HIP_SCAN_GRID=$1 DE265HIP_PIPE_CHAINS=$2 DE265HIP_PIPE_BATCH=${4:-4} DE265HIP_PIPE_TIMING=1 python bench.py --streams 3 --steps 20 --host-threads $3 --no-cpu-baseline --no-copy-out 2>/tmp/err.txt | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('scan grid $1 chains $2 host-threads $3 batch ${4:-4}: value', d['value'], 'replay', d['device_replay']['value'])"
+  grep "de265hip pipeline: [0-9][0-9][0-9]" /tmp/err.txt | head -1 | sed -e 's/.*ms per picture: //'
+done
