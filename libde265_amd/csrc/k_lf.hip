@@ -836,7 +836,8 @@ void k_sao_ctb(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, Pla
   //  plain round-robin dispatch that line went into a second L2: the kernel fetched 3.3x the picture)
   const XcdBlk B = xcd_block(G.x, G.y, G.z);
   if (!B.ok) return;
-  const int comp = B.z, cs = comp ? 1 : 0;
+  // (4:4:4: the chroma planes have luma's geometry - the same strips, only the parameters are the component's)
+  const int comp = B.z, cs = (comp && P.chroma_format != 3) ? 1 : 0;
   const int width = P.width >> cs, height = P.height >> cs;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ctbshift = P.log2_ctb - cs;
