@@ -2828,7 +2828,7 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
     } else
       hipLaunchKernelGGL(k_mc<PX>, dim3(xcd_grid((unsigned)pic->n_mc)), dim3(64), 0, st, P, tab, d0, d1, d2, pic->d_mc, pic->d_slices, pic->n_mc);
     if (P.chroma_format != 1)                          // 4:2:2 / 4:4:4: k_mc predicts luma only, the chroma planes by the plain kernel
-      hipLaunchKernelGGL(k_mc_chroma_any<PX>, dim3(pic->n_mc, 2), dim3(64), 0, st, P, tab, d1, d2, pic->d_mc, pic->d_slices, pic->n_mc);
+      hipLaunchKernelGGL(k_mc_chroma_any<PX>, dim3(pic->n_mc), dim3(64), 0, st, P, tab, d1, d2, pic->d_mc, pic->d_slices, pic->n_mc);
   }
   if (pic->n_pcm) {
     KTimer t(dec, DE265HIP_K_PCM, 1);

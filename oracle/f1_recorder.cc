@@ -240,6 +240,38 @@ void put_planes(const de265_image* img)
   }
 }
 
+/* offload mode: the same merge straight into the product's recorder (de265hip_record_*), without the intermediate copy:
+ * the per-thread buffers are walked in tile-scan order of their CTBs and every record is handed over where it lies */
+int merge_into_recorder(std::vector<Rec>& recs, de265hip_recorder* rec,
+                        int (*record_tu)(de265hip_recorder*, const de265hip_tu*, const int16_t*, const uint16_t*),
+                        int (*record_pu)(de265hip_recorder*, const de265hip_pu*),
+                        int (*record_pcm)(de265hip_recorder*, int, int, int, const uint16_t*))
+{
+  struct Ref { uint32_t ts; uint16_t rec; uint32_t idx; };
+  std::vector<Ref> order;
+  auto sorted = [&](std::vector<uint32_t> Rec::* key) {
+    order.clear();
+    for (size_t r=0;r<recs.size();r++) { const auto& k = recs[r].*key; for (size_t i=0;i<k.size();i++) order.push_back(Ref{k[i],(uint16_t)r,(uint32_t)i}); }
+    std::stable_sort(order.begin(), order.end(), [](const Ref& a, const Ref& b) { return a.ts < b.ts; });
+  };
+  int rc;
+  // (one thread's records are in decode order already: nothing to sort)
+  if (recs.size() == 1) {
+    const Rec& R = recs[0];
+    for (const auto& t : R.tus) if ((rc = record_tu(rec, &t, R.cval.data()+t.coeff_offset, R.cpos.data()+t.coeff_offset))) return rc;
+    for (const auto& pu : R.pus) if ((rc = record_pu(rec, &pu))) return rc;
+    for (size_t i=0;i<R.pcms.size();i++) if ((rc = record_pcm(rec, R.pcms[i].x0, R.pcms[i].y0, R.pcms[i].log2_cb_size, R.pcm_samples.data()+R.pcms[i].sample_offset))) return rc;
+    return 0;
+  }
+  sorted(&Rec::tu_ts);
+  for (const Ref& o : order) { const Rec& R = recs[o.rec]; const de265hip_tu& t = R.tus[o.idx]; if ((rc = record_tu(rec, &t, R.cval.data()+t.coeff_offset, R.cpos.data()+t.coeff_offset))) return rc; }
+  sorted(&Rec::pu_ts);
+  for (const Ref& o : order) if ((rc = record_pu(rec, &recs[o.rec].pus[o.idx]))) return rc;
+  sorted(&Rec::pcm_ts);
+  for (const Ref& o : order) { const Rec& R = recs[o.rec]; const de265hip_pcm& pc = R.pcms[o.idx]; if ((rc = record_pcm(rec, pc.x0, pc.y0, pc.log2_cb_size, R.pcm_samples.data()+pc.sample_offset))) return rc; }
+  return 0;
+}
+
 int dpb_index_of(const de265_image* img)
 {
   decoder_context* ctx = img->decctx;
@@ -272,7 +304,7 @@ void prepare_job(Job* job, bool hip)
   const seq_parameter_set& sps = img->get_sps();
   const pic_parameter_set& pps = img->get_pps();
   const double tp0 = now_s();
-  merge_records(job->recs, job->M);
+  if (!hip) merge_records(job->recs, job->M);         // (offload mode: merged straight into the recorder, merge_into_recorder)
   const double tp1 = now_s();
   de265hip_pic_params& P = job->P; memset(&P,0,sizeof(P));
   P.width = sps.pic_width_in_luma_samples; P.height = sps.pic_height_in_luma_samples;
@@ -330,13 +362,16 @@ void prepare_job(Job* job, bool hip)
   }
   // flattened per-4x4 views (include/de265_hip.h DE265HIP_BLK_*), without the edge bits
   std::vector<uint8_t>& flags = job->flags; std::vector<int8_t>& qp = job->qp; std::vector<de265hip_motion>& mot = job->mot;
-  flags.resize((size_t)w4*h4); qp.resize((size_t)w4*h4); mot.resize((size_t)w4*h4);
+  // (offload mode: no motion plane - de265hip_picture_desc::blk_motion = NULL, the device derives it from the PU records;
+  //  flattening 518 000 PBMotion records per 4K picture was half of this function)
+  flags.resize((size_t)w4*h4); qp.resize((size_t)w4*h4); if (!hip) mot.resize((size_t)w4*h4);
   for (int y=0;y<h4;y++) for (int x=0;x<w4;x++) {
     const int xl = x<<2, yl = y<<2;
     const bool intra = img->get_pred_mode(xl,yl)==MODE_INTRA;
     flags[x+y*w4] = (uint8_t)((intra ? DE265HIP_BLK_INTRA : 0) | (img->get_nonzero_coefficient(xl,yl) ? DE265HIP_BLK_NONZERO : 0) |
                               (img->get_pcm_flag(xl,yl) ? DE265HIP_BLK_PCM : 0) | (img->get_cu_transquant_bypass(xl,yl) ? DE265HIP_BLK_BYPASS : 0));
     qp[x+y*w4] = (int8_t)img->get_QPY(xl,yl);
+    if (hip) continue;
     de265hip_motion m; memset(&m,0,sizeof(m)); m.ref_slot[0] = m.ref_slot[1] = -1;
     if (!intra) {
       const PBMotion& pb = img->get_mv_info(xl,yl);
@@ -371,10 +406,8 @@ bool build_job(Job& j)
   de265hip_recorder* rec = j.rec;
   for (const auto& sl : j.slices) TRY(H.record_slice(rec, &sl), "record_slice");
   for (size_t a=0;a<j.ctbs.size();a++) TRY(H.record_ctb(rec, (int)a, &j.ctbs[a]), "record_ctb");
-  for (const auto& t : j.M.tus) TRY(H.record_tu(rec, &t, j.M.cval.data()+t.coeff_offset, j.M.cpos.data()+t.coeff_offset), "record_tu");
-  for (const auto& pu : j.M.pus) TRY(H.record_pu(rec, &pu), "record_pu");
-  for (const auto& pc : j.M.pcms) TRY(H.record_pcm(rec, pc.x0, pc.y0, pc.log2_cb_size, j.M.pcm_samples.data()+pc.sample_offset), "record_pcm");
-  TRY(H.record_blk_planes(rec, j.flags.data(), j.qp.data(), j.mot.data()), "record_blk_planes");
+  TRY(merge_into_recorder(j.recs, rec, H.record_tu, H.record_pu, H.record_pcm), "record_tu / _pu / _pcm");
+  TRY(H.record_blk_planes(rec, j.flags.data(), j.qp.data(), j.mot.empty() ? NULL : j.mot.data()), "record_blk_planes");
   const double t1 = now_s();
   {                                                                 // slot allocation belongs to one thread at a time
     static std::mutex am; std::lock_guard<std::mutex> lk(am);
@@ -434,10 +467,9 @@ int prepare_cb(void* user, de265hip_recorder** out)
   if ((rc = H.recorder_new(&rec, &j.P, j.scaling.empty() ? NULL : j.scaling.data()))) return rc;
   for (const auto& sl : j.slices) if ((rc = H.record_slice(rec, &sl))) return rc;
   for (size_t a=0;a<j.ctbs.size();a++) if ((rc = H.record_ctb(rec, (int)a, &j.ctbs[a]))) return rc;
-  for (const auto& t : j.M.tus) if ((rc = H.record_tu(rec, &t, j.M.cval.data()+t.coeff_offset, j.M.cpos.data()+t.coeff_offset))) return rc;
-  for (const auto& pu : j.M.pus) if ((rc = H.record_pu(rec, &pu))) return rc;
-  for (const auto& pc : j.M.pcms) if ((rc = H.record_pcm(rec, pc.x0, pc.y0, pc.log2_cb_size, j.M.pcm_samples.data()+pc.sample_offset))) return rc;
-  if ((rc = H.record_blk_planes(rec, j.flags.data(), j.qp.data(), j.mot.data()))) return rc;
+  if ((rc = merge_into_recorder(j.recs, rec, H.record_tu, H.record_pu, H.record_pcm))) return rc;
+  { std::lock_guard<std::mutex> lk(reg_mu); for (Rec& r : j.recs) { r.clear(); spare_recs.push_back(std::move(r)); } j.recs.clear(); }      // (the buffers keep their capacity for the parse threads)
+  if ((rc = H.record_blk_planes(rec, j.flags.data(), j.qp.data(), j.mot.empty() ? NULL : j.mot.data()))) return rc;
   j.M = PicRec(); j.flags = std::vector<uint8_t>(); j.qp = std::vector<int8_t>(); j.mot = std::vector<de265hip_motion>();
   *out = rec;
   static std::mutex pm; std::lock_guard<std::mutex> lk(pm);
