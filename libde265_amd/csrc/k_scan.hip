@@ -816,28 +816,67 @@ void k_scan_runs2(ScanBatch J)
   if (blockIdx.y >= (unsigned)J.n) return;
   SCAN_PRIO();
   const ScanParams& P = J.job[blockIdx.y].P; const ScanBufs& B = J.job[blockIdx.y].B;
-  __shared__ TuTask s_tus[SCR_MAX];
   const int lane = threadIdx.x;
   if (B.counts->status) return;
   const uint32_t n_listed = B.counts->n_listed;
   uint32_t n_ready = 0;
-  for (uint32_t qrun = blockIdx.x; qrun < n_listed; qrun += gridDim.x) {
-    const uint32_t s = B.run_list[qrun];
-    const RunTask* R = B.runs + s;
-    const uint32_t mic = R->micro, n = R->n_tus, first = R->first_tu;
-    const uint32_t n_all = B.run_nall[s] & 0x7FFFFFFFu;
-    const bool foreign = B.run_nall[s] >> 31;
-    // (only a run that can become a mailbox reader looks at its TU records)
-    const bool cand = (P.flags & SCANF_MAILBOX) && !(mic & 1) && (mic & 2) && !foreign && n_all > 0 && n_all <= 8 && n <= SCR_MAX;
-    if (cand) {
-      const uint4* src = reinterpret_cast<const uint4*>(B.run_tus + first);
-      uint4* dst = reinterpret_cast<uint4*>(s_tus);
-      for (uint32_t q = lane; q < 2 * n; q += 64) dst[q] = src[q];
+  // A lane per run for what every run needs (front runs leave its producer list: a handful of dependent loads - 25 runs in a row
+  // per wavefront took 460 us next to the other kernels); the runs that may become mailbox readers (dense, ordinary, few
+  // producers: the CTB runs of an all-intra picture) one after the other with the wavefront staging their TU records
+  for (uint32_t base = blockIdx.x * 64; base < n_listed; base += gridDim.x * 64) {
+    const uint32_t q = base + lane;
+    const bool have = q < n_listed;
+    uint32_t s = 0, mic = 0, n = 0, n_all = 0; bool foreign = false;
+    if (have) {
+      s = B.run_list[q];
+      const RunTask* R = B.runs + s;
+      mic = R->micro; n = R->n_tus;
+      const uint32_t na = B.run_nall[s];
+      n_all = na & 0x7FFFFFFFu; foreign = na >> 31;
     }
+    // (only a run that can become a mailbox reader looks at its TU records)
+    const bool cand = have && (P.flags & SCANF_MAILBOX) && !(mic & 1) && (mic & 2) && !foreign && n_all > 0 && n_all <= 8 && n <= SCR_MAX;
+    if (have && !cand) {
+      scan_run2(P, B, s, nullptr);
+      if (!(mic & RUN_MICRO_FRONT) && B.runs[s].n_deps == 0) n_ready++;      // (a ticketed run that waits for nothing: scan_order's worker count)
+    }
+    // (the candidates: a wavefront each, in k_scan_runs2b - here, one after the other behind a lane, an all-intra picture's
+    //  6 000 of them took 2.8 ms)
+    const uint64_t cm = __ballot(cand);
+    if (cm) {
+      uint32_t at = 0;
+      if (lane == 0) at = atomicAdd(&B.counts->n_cand, (uint32_t)__popcll(cm));
+      at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+      if (cand) B.run_level[at + (uint32_t)__popcll(cm & lanes_below(lane))] = s;
+    }
+  }
+  n_ready = wave_sum_u(n_ready);
+  if (lane == 0 && n_ready) atomicAdd(&B.counts->n_ready, n_ready);
+}
+
+// ... and the runs that may become mailbox readers, a wavefront per run: its chain-ordered TU records staged in LDS by all
+// lanes, then ONE lane runs scan_run2 on them (a few thousand scalar steps on ~40 records)
+__global__ __launch_bounds__(64)
+void k_scan_runs2b(ScanBatch J)
+{
+  if (blockIdx.y >= (unsigned)J.n) return;
+  SCAN_PRIO();
+  const ScanParams& P = J.job[blockIdx.y].P; const ScanBufs& B = J.job[blockIdx.y].B;
+  __shared__ TuTask s_tus[SCR_MAX];
+  const int lane = threadIdx.x;
+  if (B.counts->status) return;
+  const uint32_t n_cand = B.counts->n_cand;
+  uint32_t n_ready = 0;
+  for (uint32_t q = blockIdx.x; q < n_cand; q += gridDim.x) {
+    const uint32_t s = B.run_level[q];
+    const uint32_t n = B.runs[s].n_tus, first = B.runs[s].first_tu;
+    const uint4* srcp = reinterpret_cast<const uint4*>(B.run_tus + first);
+    uint4* dst = reinterpret_cast<uint4*>(s_tus);
+    for (uint32_t k = lane; k < 2 * n && k < 2 * SCR_MAX; k += 64) dst[k] = srcp[k];
     WAVE_ORDER();
     if (lane == 0) {
-      scan_run2(P, B, s, cand ? s_tus : nullptr);
-      if (!(mic & RUN_MICRO_FRONT) && B.runs[s].n_deps == 0) n_ready++;      // (a ticketed run that waits for nothing: scan_order's worker count)
+      scan_run2(P, B, s, s_tus);
+      if (B.runs[s].n_deps == 0) n_ready++;
     }
     WAVE_ORDER();
   }
@@ -1099,7 +1138,7 @@ hipError_t scan_enqueue_batch(hipStream_t st, const ScanBatch& J)
   // wavefronts of a launch, all pictures of the batch together.)
   static const int scan_grid = getenv("DE265HIP_SCAN_GRID") ? std::max(64, atoi(getenv("DE265HIP_SCAN_GRID"))) : 1024;
   const unsigned per_pic = (unsigned)std::max(32, scan_grid / (int)ny);
-  if (max_tus > 0) hipLaunchKernelGGL(k_scan_tus, dim3(std::min<unsigned>((max_tus + 255) / 256, std::max(8u, per_pic / 4)), ny), dim3(256), 0, st, J);
+  if (max_tus > 0) hipLaunchKernelGGL(k_scan_tus, dim3(std::min<unsigned>((max_tus + 255) / 256, per_pic), ny), dim3(256), 0, st, J);
   if (max_tus > 0) {
     hipLaunchKernelGGL(k_scan_ctbs, dim3(std::min<unsigned>(max_ctbs, per_pic), ny), dim3(64), 0, st, J);
     // (the number of runs is only known on the device: fixed grids of wavefronts walk the run lists)
@@ -1110,7 +1149,8 @@ hipError_t scan_enqueue_batch(hipStream_t st, const ScanBatch& J)
     for (int i = 0; i < J.n; i++) small_ctbs = small_ctbs && J.job[i].P.cf <= 1;
     if (small_ctbs) hipLaunchKernelGGL(k_scan_runs1<384>, dim3(std::min<unsigned>(max_ctbs, per_pic), ny), dim3(64), 0, st, J);
     else hipLaunchKernelGGL(k_scan_runs1<SR_TMAX>, dim3(std::min<unsigned>(max_ctbs, per_pic), ny), dim3(64), 0, st, J);
-    hipLaunchKernelGGL(k_scan_runs2, dim3(per_pic, ny), dim3(64), 0, st, J);
+    hipLaunchKernelGGL(k_scan_runs2, dim3(std::min<unsigned>(per_pic, 256u), ny), dim3(64), 0, st, J);
+    hipLaunchKernelGGL(k_scan_runs2b, dim3(2 * per_pic, ny), dim3(64), 0, st, J);      // (a B picture has a few dozen candidates, an all-intra picture some 6 000 at ~130 us each)
   }
   hipLaunchKernelGGL(k_scan_order, dim3(1, ny), dim3(SCO_THREADS), 0, st, J);      // (always: it reports to the host)
   return hipGetLastError();

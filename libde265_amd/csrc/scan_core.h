@@ -71,6 +71,7 @@ struct ScanCounts {
   uint32_t n_listed;                   // runs in run_list
   uint32_t alloc[7];                   // (device) how far the task lists, the run-ordered TU array and the residual samples are given out (scan_ctb: a CTB takes its share with one atomic per list)
   uint32_t n_ready;                    // (device) ticketed runs that wait for nothing
+  uint32_t n_cand;                     // (device) runs that may become mailbox readers (their list: run_level)
   unsigned long long alg_resid, alg_intra, alg_intra_front, n_isamp;
   uint32_t ready, pad1;                // (the host's copy only) the tag of the build, stored after everything else
 };
