@@ -53,8 +53,8 @@ struct de265hip_pipeline {
   uint64_t next_ticket = 0, next_launch = 0;    // tickets are handed out and launched in submission order
   int in_flight = 0;                            // queued or being built, not yet launched
   int window = 4;                               // bound of in_flight (submit blocks)
-  int batch = 4;                                // pictures enqueued together at most (their scans share their launches)
-  int chains = 2;                               // scans in flight at most (each a chain of kernels over up to `batch` pictures)
+  int batch = 8;                                // pictures enqueued together at most (their scans share their launches, four pictures per set)
+  int chains = 1;                               // enqueues in flight at most (each up to `batch` pictures: two sets of launches on two scan streams)
   bool stop = false;
   // DE265HIP_PIPE_TIMING=1: where the threads' time goes (seconds, summed; printed when the pipeline is freed)
   bool timing = false, tracing = false;
@@ -127,8 +127,8 @@ void launcher(de265hip_pipeline* p)
           } else i++;
         // Uploads and scans first: they run ahead of the launches on the copy streams.  The scan of a picture is a chain of
         // six dependent kernels, ~0.6 ms alone and 1-2 ms next to the reconstruction kernels, whatever the number of pictures
-        // it works on (grid.y = picture), and the device runs only so many chains at once (four scan streams per device): what
-        // counts is pictures per chain.  So a decoder keeps at most `chains` (DE265HIP_PIPE_CHAINS, default 2) in flight and
+        // it works on (grid.y = picture), and the device runs only so many chains at once (three scan streams per device): what
+        // counts is pictures per chain.  So a decoder keeps at most `chains` (DE265HIP_PIPE_CHAINS, default 1) in flight and
         // hands the next one every picture that has been built meanwhile (up to DE265HIP_PIPE_BATCH): one picture at once when
         // the device is idle, full batches when the scans are what everybody waits for.  (Round 4 before: every built picture
         // enqueued at once, 1.5 pictures per chain on average, the scan streams saturated at 3 900 pictures/s without any
