@@ -255,7 +255,8 @@ void k_scan_tus(ScanBatch J)
 #define SCW_W 25                         // window columns: cell x in [-1, 23] relative to the CTB
 #define SCW_H 17                         // window rows:    cell y in [-1, 15]
 #define SCW_NONLOCAL 0x40000000u         // an intra TU of another CTB covers the cell
-__device__ void scan_ctb_wave(const ScanParams& P, const ScanBufs& B, const int rs, const int lane);
+struct ScanCtbHead { uint32_t first, end, seen, n_intra, take; };      // what a wavefront needs of a CTB's record before anything else (take: lane k's list)
+__device__ __forceinline__ void scan_ctb_wave(const ScanParams& P, const ScanBufs& B, const int rs, const int lane, const ScanCtbHead& H, const uint32_t (&cls_start)[4]);
 __global__ __launch_bounds__(64)
 void k_scan_ctbs(ScanBatch J)
 {
@@ -263,15 +264,39 @@ void k_scan_ctbs(ScanBatch J)
   SCAN_PRIO();
   const ScanParams& P = J.job[blockIdx.y].P; const ScanBufs& B = J.job[blockIdx.y].B;
   if (B.counts->status) return;
-  // (a bounded grid: every wavefront takes CTBs in turn, see scan_enqueue_batch)
-  for (int rs = blockIdx.x; rs < P.n_ctbs; rs += gridDim.x) { scan_ctb_wave(P, B, rs, threadIdx.x); __syncthreads(); }
+  const int lane = threadIdx.x;
+  uint32_t cls_start[4];
+  for (int k = 0; k < 4; k++) cls_start[k] = scan_l0_class_start(B.counts->n_l0_size, k);
+  // (a bounded grid: every wavefront takes CTBs in turn, see scan_enqueue_batch.  A CTB is a chain of dependent round trips -
+  //  its record, its share of the lists, its TU records, their masks -, a few microseconds each next to the other kernels: the
+  //  record of the NEXT CTB is fetched while this one is worked on, and inside a CTB everything that depends on the record
+  //  alone is requested before anything is waited for)
+  auto load_head = [&](int rs) -> ScanCtbHead {
+    ScanCtbHead h; const ScanCtb& C = B.ctb[rs];
+    h.first = C.first_tu; h.end = C.end_tu; h.seen = C.seen; h.n_intra = C.n_intra;
+    h.take = 0;
+    if (lane < 4) h.take = C.n_inter[lane] + C.n_ro[lane];
+    else if (lane == 4) h.take = C.n_rext_inter + C.n_rext_ro;
+    else if (lane == 5) h.take = C.n_intra;
+    else if (lane == 6) h.take = C.n_isamp;
+    return h;
+  };
+  ScanCtbHead h = {};
+  if ((int)blockIdx.x < P.n_ctbs) h = load_head(blockIdx.x);
+  for (int rs = blockIdx.x; rs < P.n_ctbs; rs += gridDim.x) {
+    ScanCtbHead hn = {};
+    if (rs + (int)gridDim.x < P.n_ctbs) hn = load_head(rs + gridDim.x);
+    scan_ctb_wave(P, B, rs, lane, h, cls_start);
+    h = hn;
+    __syncthreads();
+  }
 }
-__device__ void scan_ctb_wave(const ScanParams& P, const ScanBufs& B, const int rs, const int lane)
+__device__ __forceinline__ void scan_ctb_wave(const ScanParams& P, const ScanBufs& B, const int rs, const int lane, const ScanCtbHead& H, const uint32_t (&cls_start)[4])
 {
   __shared__ uint32_t win[3][SCW_W * SCW_H];
   __shared__ uint8_t s_ntus[768];
   ScanCtb& C = B.ctb[rs];
-  const uint32_t first = C.first_tu, end = C.end_tu, seen = C.seen, n_intra = C.n_intra;
+  const uint32_t first = H.first, end = H.end, seen = H.seen, n_intra = H.n_intra;
   if (seen == 0) { if (lane == 0) C.n_runs = 0; return; }
   if (seen != 1 || end <= first || end > (uint32_t)P.n_tus || n_intra > 768) {
     if (lane == 0) { C.n_runs = 0; scan_fail(B, DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE); }
@@ -281,40 +306,43 @@ __device__ void scan_ctb_wave(const ScanParams& P, const ScanBufs& B, const int 
   // atomic per list, a lane each (scan_core.h computes these bases as a prefix over the CTBs in decode order - a launch of
   // its own on the device, 16 us alone and 60-150 us next to the reconstruction kernels, on a chain everything behind it waits
   // for; nothing needs the lists in decode order)
+  // (requested now, waited for where they are first used: the list shares, the halo cells, the first 64 TU records with their masks)
   uint32_t got = 0;
-  {
-    uint32_t take = 0;
-    if (lane < 4) take = C.n_inter[lane] + C.n_ro[lane];
-    else if (lane == 4) take = C.n_rext_inter + C.n_rext_ro;
-    else if (lane == 5) take = n_intra;
-    else if (lane == 6) take = C.n_isamp;
-    if (lane < 7 && take) got = atomicAdd(&B.counts->alloc[lane], take);
-    if (lane < 4) C.l0_base[lane] = got;
-    else if (lane == 4) C.rext_base = got;
-    else if (lane == 5) C.intra_base = got;
-    else if (lane == 6) C.isamp_base = got;
-  }
-  const uint32_t ibase = (uint32_t)__builtin_amdgcn_readlane((int)got, 5), my_rext_base = (uint32_t)__builtin_amdgcn_readlane((int)got, 4);
-  uint32_t my_l0_base[4];
-  for (int k = 0; k < 4; k++) my_l0_base[k] = (uint32_t)__builtin_amdgcn_readlane((int)got, k);
+  if (lane < 7 && H.take) got = atomicAdd(&B.counts->alloc[lane], H.take);
   const int cx0 = (rs % P.ctbs_w) << P.lc, cy0 = (rs / P.ctbs_w) << P.lc;      // luma origin of the CTB
-  // ---- the window: own cells empty, the halo from the cell map of the per-TU pass
-  for (int q = lane; q < 3 * SCW_W * SCW_H; q += 64) (&win[0][0])[q] = 0;
-  __syncthreads();
+  bool halo_nonlocal[3] = { false, false, false };
   for (int c = 0; c < (P.cf ? 3 : 1); c++) {
     const int sw = c ? P.subw : 1, sh = c ? P.subh : 1, mw = P.map_w[c], mh = P.map_h[c];
     const int ox4 = (cx0 / sw) >> 2, oy4 = (cy0 / sh) >> 2;
     if (lane < SCW_W + SCW_H - 1) {
       const int wx = lane < SCW_W ? lane - 1 : -1, wy = lane < SCW_W ? -1 : lane - SCW_W;
       const int gx = ox4 + wx, gy = oy4 + wy;
-      if (gx >= 0 && gy >= 0 && gx < mw && gy < mh && (uint32_t)B.cell[c][gx + (size_t)gy * mw] != 0)
-        win[c][(wy + 1) * SCW_W + (wx + 1)] = SCW_NONLOCAL;
+      halo_nonlocal[c] = gx >= 0 && gy >= 0 && gx < mw && gy < mh && (uint32_t)B.cell[c][gx + (size_t)gy * mw] != 0;
     }
   }
+  de265hip_tu tu0; memset(&tu0, 0, sizeof(tu0));
+  uint64_t av0 = 0, nd0 = 0;
+  if (first + lane < end) { tu0 = B.tus[first + lane]; av0 = B.tu_avail[first + lane]; nd0 = B.tu_need[first + lane]; }      // (the masks of a TU that is not intra are never looked at)
+  // ---- the window: own cells empty, the halo from the cell map of the per-TU pass
+  for (int q = lane; q < 3 * SCW_W * SCW_H; q += 64) (&win[0][0])[q] = 0;
   for (int q = lane; q < 768; q += 64) s_ntus[q] = 0;
   __syncthreads();
-  uint32_t cls_start[4];
-  for (int k = 0; k < 4; k++) cls_start[k] = scan_l0_class_start(B.counts->n_l0_size, k);
+  if (lane < SCW_W + SCW_H - 1) {
+    const int wx = lane < SCW_W ? lane - 1 : -1, wy = lane < SCW_W ? -1 : lane - SCW_W;
+    for (int c = 0; c < 3; c++) if (halo_nonlocal[c]) win[c][(wy + 1) * SCW_W + (wx + 1)] = SCW_NONLOCAL;
+  }
+  __syncthreads();
+  // ---- this CTB's share of the task lists, the run-ordered TU array (= its sparse run ids) and the residual samples: one
+  // atomic per list, a lane each (scan_core.h computes these bases as a prefix over the CTBs in decode order - a launch of
+  // its own on the device, 16 us alone and 60-150 us next to the reconstruction kernels, on a chain everything behind it waits
+  // for; nothing needs the lists in decode order)
+  if (lane < 4) C.l0_base[lane] = got;
+  else if (lane == 4) C.rext_base = got;
+  else if (lane == 5) C.intra_base = got;
+  else if (lane == 6) C.isamp_base = got;
+  const uint32_t ibase = (uint32_t)__builtin_amdgcn_readlane((int)got, 5), my_rext_base = (uint32_t)__builtin_amdgcn_readlane((int)got, 4);
+  uint32_t my_l0_base[4];
+  for (int k = 0; k < 4; k++) my_l0_base[k] = (uint32_t)__builtin_amdgcn_readlane((int)got, k);
   uint32_t inter_at[4] = { 0, 0, 0, 0 }, rext_at = 0;
   int cur_run0 = -1, cur_run1 = -1, cur_run2 = -1;      // the current run of each colour component
   int n_local = 0;
@@ -327,14 +355,14 @@ __device__ void scan_ctb_wave(const ScanParams& P, const ScanBufs& B, const int 
   for (uint32_t base = first; base < end; base += 64) {
     const uint32_t i = base + lane;
     const bool have = i < end;
-    de265hip_tu tu; memset(&tu, 0, sizeof(tu));
-    uint64_t av = 0, nd = 0;
+    de265hip_tu tu = tu0;
+    uint64_t av = av0, nd = nd0;
     int cls = 0, rx = 0;
-    if (have) {
-      tu = B.tus[i];
-      cls = scan_tu_class(P, B, tu, &rx);
-      if (cls == 3) { av = B.tu_avail[i]; nd = B.tu_need[i]; }
+    if (base != first) {
+      memset(&tu, 0, sizeof(tu)); av = 0; nd = 0;
+      if (have) { tu = B.tus[i]; av = B.tu_avail[i]; nd = B.tu_need[i]; }
     }
+    if (have) cls = scan_tu_class(P, B, tu, &rx);
     // -- level-0 tasks of the inter TUs: a lane each, positions by ballot prefix per size class
     for (int k = 0; k < 4; k++) {
       const uint64_t m = __ballot(cls == 1 && tu.log2_size == k + 2);
@@ -461,7 +489,8 @@ __device__ __forceinline__ uint32_t wave_scan_incl_u(uint32_t x)
 #define SR_TILE 32                       // runs per tile.  LDS per workgroup: 10 KB (4:2:0) / 13 KB - what decides how many CTBs
                                          // are worked on at once next to k_run's 53 KB workgroups (with 21 KB: two per CU)
 enum { RF_FOREIGN = 1, RF_BIG = 2, RF_TOO_BIG = 4, RF_BAD = 8, RF_DENSE0 = 16, RF_MICRO = 32, RF_DENSE = 64, RF_MB = 128, RF_PHASED = 256 };
-template <int TMAX> __device__ void scan_runs1_wave(const ScanParams& P, const ScanBufs& B, const int rs, const int lane);
+struct ScanRunsHead { uint32_t n_runs, first, end, ibase, isamp_base, rext_base, n_rext_inter, l0_at[4]; };
+template <int TMAX> __device__ void scan_runs1_wave(const ScanParams& P, const ScanBufs& B, const int rs, const int lane, const ScanRunsHead& H, const uint32_t (&cls_start)[4]);
 template <int TMAX>
 __global__ __launch_bounds__(64)
 void k_scan_runs1(ScanBatch J)
@@ -469,14 +498,27 @@ void k_scan_runs1(ScanBatch J)
   if (blockIdx.y >= (unsigned)J.n) return;
   SCAN_PRIO();
   const ScanParams& P = J.job[blockIdx.y].P; const ScanBufs& B = J.job[blockIdx.y].B;
+  uint32_t cls_start[4];
+  for (int k = 0; k < 4; k++) cls_start[k] = scan_l0_class_start(B.counts->n_l0_size, k);
+  // (the next CTB's record is fetched while this one is worked on: see k_scan_ctbs)
+  auto load_head = [&](int rs) -> ScanRunsHead {
+    ScanRunsHead h; const ScanCtb& C = B.ctb[rs];
+    h.n_runs = C.n_runs; h.first = C.first_tu; h.end = C.end_tu; h.ibase = C.intra_base; h.isamp_base = C.isamp_base; h.rext_base = C.rext_base; h.n_rext_inter = C.n_rext_inter;
+    for (int k = 0; k < 4; k++) h.l0_at[k] = C.l0_base[k] + C.n_inter[k];
+    return h;
+  };
+  ScanRunsHead h = {};
+  if ((int)blockIdx.x < P.n_ctbs) h = load_head(blockIdx.x);
   for (int rs = blockIdx.x; rs < P.n_ctbs; rs += gridDim.x) {
+    ScanRunsHead hn = {};
+    if (rs + (int)gridDim.x < P.n_ctbs) hn = load_head(rs + gridDim.x);
     if (B.counts->status) return;
-    scan_runs1_wave<TMAX>(P, B, rs, threadIdx.x);
-    __syncthreads();
+    if (h.n_runs) { scan_runs1_wave<TMAX>(P, B, rs, threadIdx.x, h, cls_start); __syncthreads(); }
+    h = hn;
   }
 }
 template <int TMAX>
-__device__ void scan_runs1_wave(const ScanParams& P, const ScanBufs& B, const int rs, const int lane)
+__device__ void scan_runs1_wave(const ScanParams& P, const ScanBufs& B, const int rs, const int lane, const ScanRunsHead& H, const uint32_t (&cls_start)[4])
 {
   __shared__ uint32_t s_w[TMAX];                       // per intra TU of the CTB (decode order): run | level << 10 | (log2 - 2) << 18 | residual-only task << 20 | rext << 21 | foreign << 22
   __shared__ uint16_t s_key[TMAX];                     // list << 8 | level (ties inside a run: decode order)
@@ -487,12 +529,10 @@ __device__ void scan_runs1_wave(const ScanParams& P, const ScanBufs& B, const in
   __shared__ uint32_t r_first[SR_TILE], r_res[SR_TILE], r_robase[4][SR_TILE], r_rxbase[SR_TILE], r_depoff[SR_TILE], r_mb[SR_TILE];
   __shared__ uint32_t s_tab[SR_HASH];
   __shared__ uint8_t s_rdy[64];
-  const ScanCtb& C = B.ctb[rs];
-  const uint32_t n_runs = C.n_runs;
-  if (n_runs == 0) return;
-  const uint32_t first = C.first_tu, end = C.end_tu, ibase = C.intra_base, isamp_base = C.isamp_base, rext_base = C.rext_base, n_rext_inter = C.n_rext_inter;
+  const uint32_t n_runs = H.n_runs;
+  const uint32_t first = H.first, end = H.end, ibase = H.ibase, isamp_base = H.isamp_base, rext_base = H.rext_base, n_rext_inter = H.n_rext_inter;
   uint32_t l0_at[4];                                   // where the residual-only copies of this CTB's intra TUs start, per size class
-  for (int k = 0; k < 4; k++) l0_at[k] = scan_l0_class_start(B.counts->n_l0_size, k) + C.l0_base[k] + C.n_inter[k];
+  for (int k = 0; k < 4; k++) l0_at[k] = cls_start[k] + H.l0_at[k];
   const uint32_t pflags = P.flags;
   const int micro_tus = P.micro_tus, run_waves = P.run_waves;
   if (end - first > 65535u || n_runs > (uint32_t)TMAX) { if (lane == 0) scan_fail(B, DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE); return; }
@@ -500,13 +540,13 @@ __device__ void scan_runs1_wave(const ScanParams& P, const ScanBufs& B, const in
   int T = 0;
   for (uint32_t base = first; base < end; base += 64) {
     const uint32_t i = base + lane;
-    const uint32_t ti = i < end ? B.tu_info[i] : 0u;
+    uint32_t ti = 0; de265hip_tu tu; memset(&tu, 0, sizeof(tu));
+    if (i < end) { ti = B.tu_info[i]; tu = B.tus[i]; }       // (the record with its info word: one round trip, not two)
     const bool intra = ti & SCAN_TI_INTRA;
     const uint64_t m = __ballot(intra);
     if (intra) {
       const int t = T + __popcll(m & lanes_below(lane));
       if (t < TMAX) {
-        const de265hip_tu tu = B.tus[i];
         const int trx = scan_rx_bits(P, B, tu);
         const bool ro = ((tu.flags & DE265HIP_TU_CBF) && tu.n_coeff) || (trx & D265_RX_XCC);
         s_ix[t] = (uint16_t)(i - first);
