@@ -938,8 +938,8 @@ void k_scan_order(ScanBatch J)
   const uint32_t cap_levels = J.job[blockIdx.y].cap_levels;
   // the third run pass first (a thread per listed run, scan_core.h scan_run3: the runs somebody reads through their mailbox)
   if (!B.counts->status && (P.flags & SCANF_MAILBOX)) {
-    const uint32_t n = B.counts->n_listed;
-    for (uint32_t q = threadIdx.x; q < n; q += SCO_THREADS) scan_run3(P, B, B.run_list[q]);
+    const uint32_t n = B.counts->n_pub;
+    for (uint32_t q = threadIdx.x; q < n; q += SCO_THREADS) scan_run3(P, B, B.lvl_cnt[q]);
   }
   // (one workgroup, one CU: what its threads have stored is visible to each other behind a barrier.  An agent-scope fence here -
   //  __threadfence() - writes the whole L2 back, the reconstruction kernels' dirty lines included, once per wavefront: round 4)

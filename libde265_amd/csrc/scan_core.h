@@ -72,6 +72,7 @@ struct ScanCounts {
   uint32_t alloc[7];                   // (device) how far the task lists, the run-ordered TU array and the residual samples are given out (scan_ctb: a CTB takes its share with one atomic per list)
   uint32_t n_ready;                    // (device) ticketed runs that wait for nothing
   uint32_t n_cand;                     // (device) runs that may become mailbox readers (their list: run_level)
+  uint32_t n_pub;                      // (device) runs somebody reads through their mailbox (their list: lvl_cnt)
   unsigned long long alg_resid, alg_intra, alg_intra_front, n_isamp;
   uint32_t ready, pad1;                // (the host's copy only) the tag of the build, stored after everything else
 };
@@ -775,7 +776,18 @@ SCAN_FN void scan_run2(const ScanParams& P, const ScanBufs& B, uint32_t s, const
     if (ok && nseg > 0) {
       o.micro |= 4;
       for (int q = 0; q < nseg; q++) {                    // producer run -> its mailbox; it learns that it is read (scan_run3)
+#if SCAN_DEVICE
+        {
+          // (the first reader that flags a run puts it on the publishers' list - lvl_cnt's memory -, which is all the ticket pass
+          //  then walks: looking at every listed run's flag was eight pairs of dependent loads per thread of its one workgroup)
+          const uint32_t pr = seg_run[q];
+          uint32_t* word = reinterpret_cast<uint32_t*>(B.pub_flag + (pr & ~3u));
+          const uint32_t bit = 1u << (8 * (pr & 3u));
+          if (!(atomicOr(word, bit) & bit)) B.lvl_cnt[atomicAdd(&B.counts->n_pub, 1u)] = pr;
+        }
+#else
         B.pub_flag[seg_run[q]] = 1;
+#endif
         seg[2 * q] |= B.mbx[3 * (size_t)seg_run[q]] & 0xFFFFFFu;
       }
       // -- when is each neighbour sample first needed?  Only TUs on the box's left column / top row read outside it (dense run)
