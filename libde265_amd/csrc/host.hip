@@ -597,7 +597,7 @@ constexpr int kKernelStreams = 4;
 // tools/exp/r4b_window.sh).  Copy-out streams stay per decoder (created when first used).
 constexpr int kScanStreams = 4, kUploadStreams = 2;
 struct DeviceStreams {
-  hipStream_t kernel[kKernelStreams] = {}, scan[kScanStreams] = {}, upload[kUploadStreams] = {}, out[2] = {}, spare = nullptr;
+  hipStream_t kernel[kKernelStreams] = {}, scan[kScanStreams] = {}, upload[kUploadStreams] = {}, out[2] = {}, spare = nullptr, pad[3] = {};
   int n_scan = kScanStreams, next_out = 0;
   int next_kernel = 0, next_scan = 0, next_upload = 0;
   bool ok = false;
@@ -634,6 +634,16 @@ static DeviceStreams* device_streams(int device)
       mk(&D.upload[0], lo); mk(&D.upload[1], lo); mk(&D.kernel[3], 0); mk(&D.scan[1], hi);
       mk(&D.out[0], lo); mk(&D.out[1], lo); mk(&D.spare, hi); mk(&D.scan[2], hi);
       D.n_scan = 3;
+      // A fourth scan stream on the scan pipe - three more queues in between - where the runtime may create that many
+      // (GPU_MAX_HW_QUEUES >= 8 per priority; with the default of 4 the new streams would re-use queues and land elsewhere):
+      // 3 640-3 810 -> 3 910-3 960 pictures/s, three decoders.  Sixteen hardware queues in all; the device's scheduler began to
+      // time-slice somewhere beyond that (DE265HIP_SCAN_STREAMS=3 / 4 overrides).
+      const char* qenv = getenv("GPU_MAX_HW_QUEUES");
+      const int want_scan = getenv("DE265HIP_SCAN_STREAMS") ? atoi(getenv("DE265HIP_SCAN_STREAMS")) : ((qenv && atoi(qenv) >= 8) ? 4 : 3);
+      if (want_scan >= 4) {
+        mk(&D.pad[0], 0); mk(&D.pad[1], lo); mk(&D.pad[2], lo); mk(&D.scan[3], hi);
+        D.n_scan = 4;
+      }
     } else {
       for (int i = 0; i < kKernelStreams; i++) mk(&D.kernel[i], 0);
       for (int i = 0; i < kScanStreams; i++) mk(&D.scan[i], hi);
@@ -722,7 +732,7 @@ int de265hip_decoder_new(de265hip_decoder** out, int device)
   d->n_copy_streams = 4;               // (pooled: every decoder takes turns on all four; 2 / 3 / 4: 2 570 / 2 770 / 2 900 pictures/s, three decoders)
   if (const char* e = getenv("DE265HIP_COPY_STREAMS")) d->n_copy_streams = std::min((int)de265hip_decoder::kMaxCopyStreams, std::max(1, atoi(e)));
   d->streams_pooled = d->kstream_index >= 0;
-  if (d->streams_pooled) d->n_copy_streams = std::min(d->n_copy_streams, 3);
+  if (d->streams_pooled) d->n_copy_streams = std::min(d->n_copy_streams, 4);
   for (int i = 0; i < d->n_copy_streams; i++) {
     if (d->streams_pooled) d->copy_streams[i] = pooled_scan_stream(d->device);
     else HIPCHK(hipStreamCreateWithPriority(&d->copy_streams[i], hipStreamNonBlocking, d->prio_high), DE265HIP_ERROR_INIT_FAILED);
