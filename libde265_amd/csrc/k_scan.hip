@@ -903,6 +903,7 @@ void k_scan_runs2b(ScanBatch J)
   SCAN_PRIO();
   const ScanParams& P = J.job[blockIdx.y].P; const ScanBufs& B = J.job[blockIdx.y].B;
   __shared__ TuTask s_tus[SCR_MAX];
+  __shared__ uint32_t s_need[81];
   const int lane = threadIdx.x;
   if (B.counts->status) return;
   const uint32_t n_cand = B.counts->n_cand;
@@ -913,9 +914,41 @@ void k_scan_runs2b(ScanBatch J)
     const uint4* srcp = reinterpret_cast<const uint4*>(B.run_tus + first);
     uint4* dst = reinterpret_cast<uint4*>(s_tus);
     for (uint32_t k = lane; k < 2 * n && k < 2 * SCR_MAX; k += 64) dst[k] = srcp[k];
+    // when is each neighbour unit of the box first needed?  Only the TUs on the box's left column and top row read outside it
+    // (a dense run): a lane per TU (scan_run2's loop over them, half of its ~15 000 scalar steps, as one thread's work)
+    if (lane < 40) { s_need[lane] = 255; s_need[40 + lane] = 255; }
+    if (lane == 0) s_need[80] = 255;
+    WAVE_ORDER();
+    {
+      const RunTask o = B.runs[s];
+      if ((P.flags & SCANF_MB_PHASES) && o.c_idx == 0 && (int)o.n_lvls + 1 >= 4)
+        for (uint32_t k = lane; k < n && k < SCR_MAX; k += 64) {
+          const TuTask tt = s_tus[k];
+          const int xB = tt.x0, yB = tt.y0;
+          if (xB != (int)o.x0 && yB != (int)o.y0) continue;
+          const int nT = 1 << tt.log2_size, corner = nT >> 1, m = tt.intra_mode < 35 ? tt.intra_mode : 1;
+          const uint32_t ep = tt.run_level;
+          uint64_t need = (P.flags & SCANF_MODE_DEPS) ? scan_needed_units(B.used_units[((tt.log2_size - 2) * 35 + m) * 2 + 1], tt.avail) : tt.avail;
+          for (; need; need &= need - 1) {
+            const int u = __builtin_ctzll(need);
+            if (u < corner) {
+              if (xB != (int)o.x0) continue;
+              const int j = (yB + 2 * nT - 4 * u - 4 - (int)o.y0) >> 2;
+              if (j >= 0 && j < 40) atomicMin(&s_need[40 + j], ep);
+            } else if (u == corner) {
+              if (yB == (int)o.y0) { if (xB == (int)o.x0) atomicMin(&s_need[80], ep); else { const int j = (xB - 1 - (int)o.x0) >> 2; if (j < 40) atomicMin(&s_need[j], ep); } }
+              else if (xB == (int)o.x0) { const int j = (yB - 1 - (int)o.y0) >> 2; if (j >= 0 && j < 40) atomicMin(&s_need[40 + j], ep); }
+            } else {
+              if (yB != (int)o.y0) continue;
+              const int j = (xB + 4 * (u - corner - 1) - (int)o.x0) >> 2;
+              if (j >= 0 && j < 40) atomicMin(&s_need[j], ep);
+            }
+          }
+        }
+    }
     WAVE_ORDER();
     if (lane == 0) {
-      scan_run2(P, B, s, s_tus);
+      scan_run2(P, B, s, s_tus, s_need);
       if (B.runs[s].n_deps == 0) n_ready++;
     }
     WAVE_ORDER();

@@ -721,7 +721,9 @@ SCAN_FN void scan_run(const ScanParams& P, const ScanBufs& B, uint32_t s)
 // producers that are front runs leave the list (the kernel boundary orders them); a dense ordinary run whose every neighbour
 // sample comes from the bottom row / right column of dense ordinary runs takes them from those runs' mailboxes: its segment
 // list and - phased hand-over - when each neighbour sample is first needed (host.hip, round 3: "Edge mailboxes")
-SCAN_FN void scan_run2(const ScanParams& P, const ScanBufs& B, uint32_t s, const TuTask* own_tus = nullptr)
+// (pre_need: 40 + 40 + 1 need epochs of the units on the row above, the column beside and the corner of the run's box, where
+//  the caller has computed them already - the device does, a lane per TU -; else the loop below does)
+SCAN_FN void scan_run2(const ScanParams& P, const ScanBufs& B, uint32_t s, const TuTask* own_tus = nullptr, const uint32_t* pre_need = nullptr)
 {
   // (own_tus: the run's TU records where the caller has staged them - LDS on the device -, else they are read from run_tus)
   if (B.counts->status || B.run_ntus[s] == 0) return;
@@ -798,6 +800,8 @@ SCAN_FN void scan_run2(const ScanParams& P, const ScanBufs& B, uint32_t s, const
       if (phased) {
         uint8_t nru[40], ncu[40], ncorner = 255;
         for (int q = 0; q < 40; q++) { nru[q] = 255; ncu[q] = 255; }
+        if (pre_need) { for (int q = 0; q < 40; q++) { nru[q] = (uint8_t)pre_need[q]; ncu[q] = (uint8_t)pre_need[40 + q]; } ncorner = (uint8_t)pre_need[80]; }
+        else
         for (int k = 0; k < n; k++) {
           const TuTask tt = own_tus ? own_tus[k] : B.run_tus[o.first_tu + (uint32_t)k];
           const int xB = tt.x0, yB = tt.y0;
