@@ -31,11 +31,16 @@ import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
 
-# The ROCm runtime maps HIP streams onto a few hardware queues (4 by default), round-robin in order of creation; streams that
-# share a queue run their kernels one after the other.  Three decoders with a kernel stream and two copy streams each would
-# put all three kernel streams on one queue: eight queues keep them apart ("host placement").  Must be set
-# before the runtime initialises.
+# The ROCm runtime maps HIP streams onto a few hardware queues PER PRIORITY (4 by default), the least used one of a stream's
+# priority; streams that share a queue run their kernels one after the other.  The library creates its streams in pools of the
+# process, in an order that puts the decoders' kernel streams and its scan streams on different dispatch pipes:
+# that order needs a queue of its own per stream - eight per priority leave room ("host placement").  Must be
+# set before the runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# a fourth scan stream on the scan pipe (libde265_amd/csrc/host.hip, DeviceStreams): sixteen hardware queues in the process - only
+# where no collective library adds queues of its own (a single rank)
+if int(os.environ.get("WORLD_SIZE", "1")) == 1 and "--gpus" not in " ".join(sys.argv[1:]).replace("--gpus 1", ""):
+    os.environ.setdefault("DE265HIP_SCAN_STREAMS", "4")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):

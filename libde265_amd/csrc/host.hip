@@ -637,9 +637,9 @@ static DeviceStreams* device_streams(int device)
       // A fourth scan stream on the scan pipe - three more queues in between - where the runtime may create that many
       // (GPU_MAX_HW_QUEUES >= 8 per priority; with the default of 4 the new streams would re-use queues and land elsewhere):
       // 3 640-3 810 -> 3 910-3 960 pictures/s, three decoders.  Sixteen hardware queues in all; the device's scheduler began to
-      // time-slice somewhere beyond that (DE265HIP_SCAN_STREAMS=3 / 4 overrides).
-      const char* qenv = getenv("GPU_MAX_HW_QUEUES");
-      const int want_scan = getenv("DE265HIP_SCAN_STREAMS") ? atoi(getenv("DE265HIP_SCAN_STREAMS")) : ((qenv && atoi(qenv) >= 8) ? 4 : 3);
+      // time-slice somewhere beyond that: DE265HIP_SCAN_STREAMS=4 asks for it (bench.py does for a single rank).
+      // (opt-in: a process that creates queues of its own - RCCL does - may be closer to that edge than this library can see)
+      const int want_scan = getenv("DE265HIP_SCAN_STREAMS") ? atoi(getenv("DE265HIP_SCAN_STREAMS")) : 3;
       if (want_scan >= 4) {
         mk(&D.pad[0], 0); mk(&D.pad[1], lo); mk(&D.pad[2], lo); mk(&D.scan[3], hi);
         D.n_scan = 4;
