@@ -2491,7 +2491,8 @@ int de265hip_picture_enqueue_batch(de265hip_picture** pics, int n)
     hipStream_t cs;
     { std::lock_guard<std::mutex> lk(dec->mu); cs = dec->copy_streams[dec->copy_turn++ % (uint64_t)dec->n_copy_streams]; reap_arenas(dec); }
     static const int own_prep = getenv("DE265HIP_OWN_PREP") ? atoi(getenv("DE265HIP_OWN_PREP")) : 1;
-    ScanBatch J; J.n = 0; J.pad = 0;
+    static const int run2_lane0 = getenv("DE265HIP_SCAN_RUN2_LANE0") ? atoi(getenv("DE265HIP_SCAN_RUN2_LANE0")) : 0;
+    ScanBatch J; J.n = 0; J.pad = run2_lane0 ? 1 : 0;      // (pad bit 0: the mailbox readers' pass on one lane, scan_core.h's loop: the parity variant)
     PrepBatch PJ; PJ.n = 0; PJ.pad = 0;
     de265hip_picture* done[SCAN_BATCH]; int n_done = 0;
     auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };

@@ -903,8 +903,10 @@ void k_scan_runs2b(ScanBatch J)
   SCAN_PRIO();
   const ScanParams& P = J.job[blockIdx.y].P; const ScanBufs& B = J.job[blockIdx.y].B;
   __shared__ TuTask s_tus[SCR_MAX];
-  __shared__ uint32_t s_need[81];
+  __shared__ uint32_t s_need[81], s_dl[8], s_seg[32], s_segrun[16], s_nb[16], s_seen[8], s_sub[96];
+  __shared__ uint8_t s_nrow[168], s_ncol[168], s_subg[48];
   const int lane = threadIdx.x;
+  const bool by_one_lane = J.pad & 1;
   if (B.counts->status) return;
   const uint32_t n_cand = B.counts->n_cand;
   uint32_t n_ready = 0;
@@ -947,9 +949,174 @@ void k_scan_runs2b(ScanBatch J)
         }
     }
     WAVE_ORDER();
+    if (by_one_lane) {                                   // (DE265HIP_SCAN_RUN2_LANE0=1: scan_core.h's loop on one lane, the parity variant)
+      if (lane == 0) { scan_run2(P, B, s, s_tus, s_need); if (B.runs[s].n_deps == 0) n_ready++; }
+      WAVE_ORDER();
+      continue;
+    }
+    // ---- scan_core.h scan_run2 for a candidate, by the wavefront (a lane per producer, per segment, per neighbour sample):
+    // on one lane its ~8 000 remaining scalar steps on private arrays in scratch memory were 190 us per run, 570 us of an
+    // all-intra 4K picture's scan
+    const RunTask o = B.runs[s];
+    const uint32_t n_all = B.run_nall[s] & 0x7FFFFFFFu;                 // (a candidate: 1..8, not foreign, dense, ordinary)
+    uint32_t* dl = B.deps + o.dep_offset;
+    uint32_t p = 0; bool front = false;
+    if ((uint32_t)lane < n_all) { p = dl[lane]; front = B.runs[p].micro & RUN_MICRO_FRONT; }
+    const uint64_t keep_m = __ballot((uint32_t)lane < n_all && !front), front_m = __ballot((uint32_t)lane < n_all && front);
+    const uint32_t nd = (uint32_t)__popcll(keep_m);
+    if ((uint32_t)lane < n_all) {
+      const uint32_t pos = front ? nd + (uint32_t)__popcll(front_m & lanes_below(lane)) : (uint32_t)__popcll(keep_m & lanes_below(lane));
+      dl[pos] = p; s_dl[pos] = p;
+    }
+    if ((P.flags & SCANF_DROP_PRODUCER) && nd) {           // fault injection: the smallest run somebody waits for is never executed
+      const int v = wave_min_i(((uint32_t)lane < n_all && !front) ? (int)p : 0x7FFFFFFF);
+      if (lane == 0) atomicMin(&B.counts->victim, (uint32_t)v);
+    }
+    WAVE_ORDER();
+    bool reader = false;
+    uint32_t new_micro = o.micro;
+    if ((P.flags & SCANF_MAILBOX) && nd > 0 && nd == n_all) {
+      const int c = o.c_idx;
+      const int ax0 = ((int)o.x0 - 1) & ~7, wy0 = (int)o.y0 - 1, tile_p = (64 + 40 + 7) & ~7;      // RUN_TILE_P_OF(64) of k_run
+      const int cw_ = c ? P.cwid : P.width, ch_ = c ? P.chei : P.height;
+      const int wx1c = (int)o.wx1 < cw_ ? (int)o.wx1 : cw_, wy1c = (int)o.wy1 < ch_ ? (int)o.wy1 : ch_;
+      // -- a lane per producer: its segment of the row above the box, its segment of the column left of it
+      bool bad = false; uint32_t sg[4] = { 0, 0, 0, 0 }; int have_row = 0, have_col = 0; uint32_t pk = 0; int px0 = 0, py0 = 0;
+      if ((uint32_t)lane < nd) {
+        pk = s_dl[lane];
+        const RunTask Pq = B.runs[pk];
+        px0 = Pq.x0; py0 = Pq.y0;
+        if ((Pq.micro & 3) != 2) bad = true;                          // producer: ordinary and dense
+        if ((int)Pq.y0 <= wy0 && wy0 < (int)Pq.y1) {
+          const int xs = (int)Pq.x0 > (int)o.x0 - 1 ? (int)Pq.x0 : (int)o.x0 - 1, xe = (int)Pq.x1 < wx1c ? (int)Pq.x1 : wx1c;
+          if (xs < xe) {
+            if ((int)Pq.y1 - 1 != wy0) bad = true;
+            sg[0] = ((uint32_t)(xe - xs - 1) << 24); sg[1] = (uint32_t)(xs - Pq.x0) | ((uint32_t)(xs - ax0) << 8); have_row = 1;
+          }
+        }
+        if ((int)Pq.x0 <= (int)o.x0 - 1 && (int)o.x0 - 1 < (int)Pq.x1) {
+          const int ys = (int)Pq.y0 > (int)o.y0 ? (int)Pq.y0 : (int)o.y0, ye = (int)Pq.y1 < wy1c ? (int)Pq.y1 : wy1c;
+          if (ys < ye) {
+            if ((int)Pq.x1 != (int)o.x0) bad = true;
+            sg[2] = ((uint32_t)(ye - ys - 1) << 24) | 0x80000000u;
+            sg[3] = (uint32_t)(ys - Pq.y0) | ((uint32_t)((ys - wy0) * tile_p + ((int)o.x0 - 1 - ax0)) << 8); have_col = 1;
+          }
+        }
+        if (!have_row && !have_col) bad = true;
+      }
+      const bool ok = __ballot(bad) == 0;
+      const uint32_t cnt = (uint32_t)(have_row + have_col), incl = wave_scan_incl_u(cnt);
+      const int nseg = (int)__builtin_amdgcn_readlane((int)incl, 63);
+      if (ok && nseg > 0) {
+        reader = true; new_micro |= 4;
+        uint32_t at_seg = incl - cnt;
+        // (what each neighbour sample of a segment is: an entry of the row above the box (corner first) or of the column beside it)
+        if (have_row) { s_seg[2 * at_seg] = sg[0]; s_seg[2 * at_seg + 1] = sg[1]; s_segrun[at_seg] = pk; s_nb[at_seg] = (uint32_t)(px0 + (int)(sg[1] & 63) - ((int)o.x0 - 1)); at_seg++; }
+        if (have_col) { s_seg[2 * at_seg] = sg[2]; s_seg[2 * at_seg + 1] = sg[3]; s_segrun[at_seg] = pk; s_nb[at_seg] = 0x100u + (uint32_t)(py0 + (int)(sg[3] & 63) - (int)o.y0); }
+        WAVE_ORDER();
+        if (lane < nseg) {                                 // producer run -> its mailbox; it learns that it is read (scan_run3)
+          const uint32_t pr = s_segrun[lane];
+          uint32_t* word = reinterpret_cast<uint32_t*>(B.pub_flag + (pr & ~3u));
+          const uint32_t bit = 1u << (8 * (pr & 3u));
+          if (!(atomicOr(word, bit) & bit)) B.lvl_cnt[atomicAdd(&B.counts->n_pub, 1u)] = pr;
+          s_seg[2 * lane] |= B.mbx[3 * (size_t)pr] & 0xFFFFFFu;
+        }
+        WAVE_ORDER();
+        // -- when is each neighbour sample first needed?  need epochs -> at most four poll points (quantiles of the distinct values)
+        const int nl = (int)o.n_lvls + 1;
+        bool phased = (P.flags & SCANF_MB_PHASES) && c == 0 && nl >= 4;
+        int n_groups = 1, nsub = 0;
+        uint32_t polls[4] = { 0, 0, 0, 0 }, ends[4] = { 0, 0, 0, 0 }, tot = 0;
+        if (phased) {
+          for (int q2 = lane; q2 < 161; q2 += 64) s_nrow[q2] = (uint8_t)(q2 == 0 ? s_need[80] : s_need[(q2 - 1) >> 2]);
+          for (int q2 = lane; q2 < 160; q2 += 64) s_ncol[q2] = (uint8_t)s_need[40 + (q2 >> 2)];
+          if (lane < 8) s_seen[lane] = 0;
+          WAVE_ORDER();
+          auto need_of = [&](int sgi, int off) -> uint32_t { const uint32_t nb = s_nb[sgi]; return (nb & 0x100u) ? s_ncol[(nb & 0xFFu) + off] : s_nrow[nb + off]; };
+          for (int sgi = 0; sgi < nseg; sgi++) {
+            const int cnt_s = (int)((s_seg[2 * sgi] >> 24) & 63) + 1;
+            if (lane < cnt_s) { const uint32_t v = need_of(sgi, lane); atomicOr(&s_seen[v >> 5], 1u << (v & 31)); }
+          }
+          WAVE_ORDER();
+          uint32_t seen[8];
+          for (int k = 0; k < 8; k++) seen[k] = s_seen[k];
+          seen[7] &= 0x7FFFFFFFu;                          // (255: never read)
+          int nv = 0;
+          for (int k = 0; k < 8; k++) nv += __popc(seen[k]);
+          if (nv < 2) phased = false;
+          else {
+            n_groups = nv < 4 ? nv : 4;
+            for (int g2 = 0; g2 < n_groups; g2++) {        // polls[g] = the (g * nv / n_groups)-th distinct value
+              int k = (g2 * nv) / n_groups, wd = 0;
+              while (k >= __popc(seen[wd])) { k -= __popc(seen[wd]); wd++; }
+              uint32_t m = seen[wd];
+              for (; k > 0; k--) m &= m - 1;
+              polls[g2] = (uint32_t)(32 * wd + __builtin_ctz(m));
+            }
+            const int p1 = n_groups > 1 ? (int)polls[1] : 256, p2 = n_groups > 2 ? (int)polls[2] : 256, p3 = n_groups > 3 ? (int)polls[3] : 256;
+            auto grp_of_v = [&](int v) { return v == 255 ? 255 : (v >= p1) + (v >= p2) + (v >= p3); };
+            // every segment cut where the group of its samples changes (samples nobody reads, group 255, are left out)
+            for (int sgi = 0; sgi < nseg && phased; sgi++) {
+              const uint32_t s0 = s_seg[2 * sgi], s1 = s_seg[2 * sgi + 1];
+              const int cnt_s = (int)((s0 >> 24) & 63) + 1;
+              const bool col = s0 >> 31;
+              const int g = lane < cnt_s ? grp_of_v((int)need_of(sgi, lane)) : 254;
+              const int gprev = __shfl_up(g, 1, 64);
+              const bool boundary = lane < cnt_s && (lane == 0 || g != gprev);
+              const uint64_t bm = __ballot(boundary), sm = __ballot(boundary && g != 255);
+              if (nsub + __popcll(sm) > 48) { phased = false; break; }
+              if (boundary && g != 255) {
+                const uint64_t above = lane < 63 ? (bm >> (lane + 1)) : 0ull;
+                const int len = above ? __builtin_ctzll(above) + 1 : cnt_s - lane;
+                const int ix = nsub + __popcll(sm & lanes_below(lane));
+                s_sub[2 * ix] = (s0 & 0x80FFFFFFu) | ((uint32_t)(len - 1) << 24);
+                s_sub[2 * ix + 1] = ((s1 & 63u) + (uint32_t)lane) | (((s1 >> 8) + (uint32_t)(lane * (col ? tile_p : 1))) << 8);
+                s_subg[ix] = (uint8_t)g;
+              }
+              nsub += __popcll(sm);
+              WAVE_ORDER();
+            }
+          }
+        }
+        if (phased && nsub > 0) {
+          const int mylen = lane < nsub ? (int)((s_sub[2 * lane] >> 24) & 63) + 1 : 0, myg = lane < nsub ? (int)s_subg[lane] : 255;
+          for (int g2 = 0; g2 < n_groups; g2++) { tot += wave_sum_u(myg == g2 ? (uint32_t)mylen : 0u); ends[g2] = tot; }
+          if (tot > 255) phased = false;                   // (cannot happen with 64x64 boxes: <= 193 neighbour samples)
+        }
+        const bool use_sub = phased && nsub > 0;
+        const uint32_t words = 3u + 2u * (uint32_t)(use_sub ? nsub : nseg);
+        uint32_t at = 0;
+        if (lane == 0) at = atomicAdd(&B.counts->n_segs_alloc, words);
+        at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+        if (at + words > P.cap_segs) { if (lane == 0) scan_fail(B, DE265HIP_ERROR_NOT_IMPLEMENTED); return; }
+        uint32_t* ms = B.mb_segs + at;
+        if (use_sub) {
+          const int myg = lane < nsub ? (int)s_subg[lane] : 255;
+          uint32_t pos = 0;
+          for (int g2 = 0; g2 < n_groups; g2++) {
+            const uint64_t gm = __ballot(myg == g2);
+            if (myg > g2) pos += (uint32_t)__popcll(gm);
+            else if (myg == g2) pos += (uint32_t)__popcll(gm & lanes_below(lane));
+          }
+          if (lane < nsub) { ms[3 + 2 * pos] = s_sub[2 * lane]; ms[3 + 2 * pos + 1] = s_sub[2 * lane + 1]; }
+          if (lane == 0) {
+            for (int g2 = n_groups; g2 < 4; g2++) { ends[g2] = tot; polls[g2] = 255; }
+            ms[0] = (uint32_t)nsub | ((uint32_t)n_groups << 8);
+            ms[1] = ends[0] | (ends[1] << 8) | (ends[2] << 16) | (ends[3] << 24);
+            ms[2] = polls[0] | (polls[1] << 8) | (polls[2] << 16) | (polls[3] << 24);
+          }
+        } else {
+          if (lane == 0) { ms[0] = (uint32_t)nseg | (1u << 8); ms[1] = 0; ms[2] = 0; }      // (one group: everything at the start)
+          if (lane < 2 * nseg) ms[3 + lane] = s_seg[lane];
+        }
+        if (lane == 0) B.mbx[3 * (size_t)s + 1] = at;
+      }
+    }
+    // (only the fields that changed: other runs read this record's box and class bits in the same pass)
     if (lane == 0) {
-      scan_run2(P, B, s, s_tus, s_need);
-      if (B.runs[s].n_deps == 0) n_ready++;
+      B.runs[s].n_deps = (uint16_t)nd;
+      if (reader) B.runs[s].micro = (uint8_t)new_micro;
+      if (nd == 0) n_ready++;
     }
     WAVE_ORDER();
   }
