@@ -101,7 +101,10 @@ typedef struct de265hip_pic_params {
 } de265hip_pic_params;
 
 /* Size of the flat scaling-factor blob: ScalingFactor_Size0[6][4][4],
- * Size1[6][8][8], Size2[6][16][16], Size3[2][32][32] back to back (sps.h:51-58). */
+ * Size1[6][8][8], Size2[6][16][16], Size3[2][32][32] back to back (sps.h:51-58).
+ * Limitation: a 32x32 CHROMA transform unit (4:4:4 only) with scaling lists makes the reference index Size3 beyond its two
+ * matrices (undefined behaviour upstream); this library takes matrix 0 for intra and 1 for inter units there.  No fixture of
+ * the reference defines the case: parity unpinned. */
 #define DE265HIP_SCALING_BLOB_BYTES (6*16 + 6*64 + 6*256 + 2*1024)
 
 /* Per slice segment values read by MC weighting, deblocking and SAO

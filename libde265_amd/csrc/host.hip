@@ -2936,7 +2936,8 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
                          P, d0, d1, d2, sp.pl[0], sp.pl[1], sp.pl[2], LM, SM, want_deblock ? 1 : 0);
     }
     for (int c = 0; c < 3; c++) std::swap(dst.pl[c], sp.pl[c]);      // output picture now lives in the slot
-    if (!lanes_epilogue() || hipGetLastError() != hipSuccess) return DE265HIP_ERROR_DECODING;
+    { const bool launched_ok = hipGetLastError() == hipSuccess, epilogue_ok = lanes_epilogue();      // (the slot's events are recorded whatever the launches said: later pictures wait for what IS queued)
+    if (!launched_ok || !epilogue_ok) return DE265HIP_ERROR_DECODING; }
     return DE265HIP_OK;
   }
   if (want_deblock) {
@@ -2995,7 +2996,8 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
     }
     for (int c = 0; c < 3; c++) std::swap(dst.pl[c], sp.pl[c]);      // output picture now lives in the slot
   }
-  if (!lanes_epilogue() || hipGetLastError() != hipSuccess) return DE265HIP_ERROR_DECODING;
+  { const bool launched_ok = hipGetLastError() == hipSuccess, epilogue_ok = lanes_epilogue();      // (the slot's events are recorded whatever the launches said: later pictures wait for what IS queued)
+    if (!launched_ok || !epilogue_ok) return DE265HIP_ERROR_DECODING; }
   return DE265HIP_OK;
 }
 
