@@ -294,6 +294,9 @@ def main():
                     help="chroma_format_idc of the workload: 1 = 4:2:0 (the headline), 2 = 4:2:2, 3 = 4:4:4 (range extensions, SURVEY 8 f4)")
     ap.add_argument("--motion-plane", action="store_true",
                     help="hand the flattened per-4x4 motion plane over with every picture (default: the device makes it from the PU records)")
+    ap.add_argument("--copy-out-ring", type=int, default=int(os.environ.get("DE265HIP_BENCH_RING", "8")),
+                    help="with_copy_out: pinned output pictures per stream (an application's output queue; a picture's buffer is "
+                         "reused once its ticket has been waited for).  4 holds the pipeline to four pictures in flight per decoder")
     ap.add_argument("--no-copy-out", action="store_true",
                     help="skip the with_copy_out leg (product path with every picture copied out to pinned host memory)")
     ap.add_argument("--no-affinity", action="store_true", help="N > 1: do not pin the rank to its share of the host's CPUs")
@@ -555,7 +558,7 @@ def main():
         # into pinned host planes inside the timed region (what de265_get_image_plane hands an application), PCIe included
         copy_out = None
         if not args.no_copy_out:
-            ring_n = 4
+            ring_n = max(1, args.copy_out_ring)
             rings = [[backend.PinnedPlanes(W, H, BD, chroma_format=CF) for _ in range(ring_n)] for _ in range(S)]
             product_pass(pipes, gops, args.stagger, pinned=rings)
             drain()

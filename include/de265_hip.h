@@ -305,6 +305,19 @@ int  de265hip_dpb_fill(de265hip_decoder*, int slot, int y, int cb, int cr);
  * de265hip_dpb_wait() may be called from another thread than the one that enqueues pictures. */
 int  de265hip_dpb_download_async(de265hip_decoder*, int slot, int c_idx,
                                  void* dst, ptrdiff_t stride_bytes);
+/* The same for all three planes of the picture in ONE call (what de265_get_image_plane hands out for c = 0, 1, 2,
+ * de265.h:173-178): dst[c] == NULL skips plane c.  Planes in pinned memory leave by one kernel that stores into them (one launch
+ * per picture, a few dozen workgroups: the link's rate without the runtime's per-plane blit kernels next to the decoder's own
+ * kernels); planes in pageable memory, or with strides / addresses that are not multiples of 16, leave by hipMemcpy2DAsync as with
+ * the call above, which is this one for a single plane. */
+int  de265hip_dpb_download_planes_async(de265hip_decoder*, int slot, void* const dst[3], const ptrdiff_t stride_bytes[3],
+                                        uint64_t* copy_out_id /* may be NULL */);
+/* Wait for ONE copy-out: the one de265hip_dpb_download_planes_async numbered `copy_out_id` (1, 2, .. per slot since its
+ * allocation).  de265hip_dpb_wait waits for the slot's LATEST copy-out - the wrong picture for an output queue that is
+ * deeper than the DPB's cycle, where the slot has been decoded into and copied out again by the time a picture is collected.
+ * Reports the picture's failure like de265hip_dpb_wait.  A number from before the slot's last re-allocation is not an error:
+ * that copy-out landed when the slot was re-allocated. */
+int  de265hip_dpb_wait_copy_out(de265hip_decoder*, int slot, uint64_t copy_out_id);
 int  de265hip_dpb_wait(de265hip_decoder*, int slot);
 /* Pinned host memory for the planes pictures are copied out to: what a libde265 host installs as its
  * de265_image_allocation (de265.h:325-343).  NULL when the allocation fails. */

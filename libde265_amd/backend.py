@@ -19,7 +19,7 @@ EXPORTS = [
     "de265hip_version", "de265hip_device_count",
     "de265hip_decoder_new", "de265hip_decoder_free", "de265hip_decoder_set_lanes",
     "de265hip_dpb_alloc", "de265hip_dpb_alloc_ex", "de265hip_dpb_chroma_format", "de265hip_dpb_upload", "de265hip_dpb_fill", "de265hip_dpb_download", "de265hip_dpb_plane", "de265hip_dpb_info",
-    "de265hip_dpb_copy", "de265hip_dpb_download_async", "de265hip_dpb_wait", "de265hip_host_alloc", "de265hip_host_free",
+    "de265hip_dpb_copy", "de265hip_dpb_download_async", "de265hip_dpb_download_planes_async", "de265hip_dpb_wait_copy_out", "de265hip_dpb_wait", "de265hip_host_alloc", "de265hip_host_free",
     "de265hip_pipeline_new", "de265hip_pipeline_submit", "de265hip_pipeline_submit_desc", "de265hip_pipeline_wait", "de265hip_pipeline_drain", "de265hip_pipeline_free",
     "de265hip_debug_build_host_only", "de265hip_debug_last_build_hash", "de265hip_debug_build_host_only_ex",
     "de265hip_debug_fault_injection", "de265hip_debug_picture_layout", "de265hip_debug_picture_read",
@@ -72,6 +72,8 @@ def lib():
     L.de265hip_dpb_info.argtypes = [vp, i32, pp(i32), pp(i32), pp(i32), pp(i32)]
     L.de265hip_dpb_copy.argtypes = [vp, i32, vp, i32]
     L.de265hip_dpb_download_async.argtypes = [vp, i32, i32, vp, C.c_ssize_t]
+    L.de265hip_dpb_download_planes_async.argtypes = [vp, i32, C.POINTER(C.c_void_p), C.POINTER(C.c_ssize_t), C.POINTER(C.c_uint64)]
+    L.de265hip_dpb_wait_copy_out.argtypes = [vp, i32, C.c_uint64]
     L.de265hip_dpb_wait.argtypes = [vp, i32]
     L.de265hip_host_alloc.argtypes = [C.c_size_t]
     L.de265hip_host_alloc.restype = vp
@@ -338,6 +340,20 @@ class Decoder:
         shapes = [(height, width), (ch, cw), (ch, cw)]
         self._check_planes(slot, [(sh, dt) for sh in shapes], "download_async")
         return _PendingDownload(self, slot, shapes, dt)
+
+    def download_planes_async(self, slot, ptrs, strides):
+        """de265hip_dpb_download_planes_async: all planes of the slot's picture in one call (ptrs[c] None skips plane c)."""
+        planes = (C.c_void_p * 3)(*ptrs)
+        st = (C.c_ssize_t * 3)(*strides)
+        cid = C.c_uint64()
+        _chk(lib().de265hip_dpb_download_planes_async(self._h, slot, planes, st, C.byref(cid)), "dpb_download_planes_async")
+        return cid.value
+
+    def wait_slot(self, slot, copy_out_id=None):
+        if copy_out_id is None:
+            _chk(lib().de265hip_dpb_wait(self._h, slot), "dpb_wait")
+        else:
+            _chk(lib().de265hip_dpb_wait_copy_out(self._h, slot, copy_out_id), "dpb_wait_copy_out")
 
     def plane(self, slot, c_idx):
         p, s = C.c_void_p(), C.c_ssize_t()

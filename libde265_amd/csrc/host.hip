@@ -13,6 +13,8 @@
 #include <new>
 #include <vector>
 #include <mutex>
+#include <condition_variable>
+#include <thread>
 #include <chrono>
 
 #include <deque>
@@ -43,8 +45,17 @@ struct Slot {
   int ch() const { return cf == 0 ? 0 : cf == 1 ? h / 2 : h; }
   // de265hip_dpb_download_async: recorded on the output stream behind the slot's latest copy-out; whoever writes the
   // slot next (a new picture, an upload) or frees it waits for it.  dl_seq counts the copy-outs (dpb_wait compares it).
-  hipEvent_t dl_done = nullptr;
+  hipEvent_t dl_done = nullptr;                    // (= the event of the latest copy-out, one of dl_ev)
   uint64_t dl_seq = 0, dl_waited = 0;
+  // the last four copy-outs of the slot, each with its own event and the error-ring entry of the picture it delivers: a
+  // pipeline's ticket is waited for long after the slot's NEXT picture has been copied out (de265hip_dpb_wait_copy_out)
+  // deferred copy-outs (OutThread below): how many of the slot's copy-outs have been asked for / handed to the runtime.  Whoever
+  // is about to use dl_done - wait for it, make a stream wait for it - first waits until the two are equal (out_settle).
+  uint64_t out_queued = 0, out_issued = 0;         // (guarded by g_out_mu)
+  static constexpr int kDlRing = 4;
+  hipEvent_t dl_ev[kDlRing] = {};
+  uint64_t dl_ev_seq[kDlRing] = {};
+  int dl_ev_err_idx[kDlRing] = { -1, -1, -1, -1 }; uint64_t dl_ev_err_seq[kDlRing] = {};
   int err_idx = -1; uint64_t err_seq = 0;          // error-ring entry of the picture last decoded into the slot
   // Lanes (de265hip_decoder_set_lanes > 1): who wrote the slot's picture and who reads it, as events on the lanes' streams.
   // written: recorded behind the picture that was decoded into the slot (writer_lane >= 0) or behind a copy into it from
@@ -94,6 +105,11 @@ struct de265hip_decoder {
   hipStream_t out_stream = nullptr;   // de265hip_dpb_download_async: decoded pictures leave on their own stream, behind an event of `stream`
   bool out_pooled = false;            // ... one of the process's two (DeviceStreams)
   hipEvent_t out_fence = nullptr;
+  // deferred copy-outs: jobs for the output thread (guarded by g_out_mu), the events their pictures are waited for by
+  struct OutJobRec { Slot* s; uint64_t id; int ring; hipEvent_t picture_done; void* dst[3]; const void* src[3]; size_t dpitch[3], spitch[3], row_bytes[3], rows[3]; };
+  std::deque<OutJobRec> out_jobs;
+  std::thread out_thread; bool out_thread_started = false, out_stop = false, out_failed = false;
+  std::vector<hipEvent_t> out_events;           // (guarded by mu) blocking-sync events, re-used
   std::mutex mu;                      // guards live, the two pools and slot allocation: build()/free() may come from several host threads
   std::vector<de265hip_picture*> live;        // pictures built on this decoder and not yet freed (decoder_free orphans them)
   std::vector<ArenaBuf> free_arenas;
@@ -231,9 +247,29 @@ namespace {
 
 size_t px_bytes(int bd) { return bd > 8 ? 2 : 1; }
 
+// Deferred copy-outs.  The runtime performs a device-to-pinned-host hipMemcpyAsync with its DMA engines only when the stream it
+// is enqueued on has nothing pending; behind a hipStreamWaitEvent (the picture's kernels on the decoder's stream) it launches a
+// blit kernel instead - 256 workgroups x 512 threads per plane that store across PCIe through the same L2 write paths the
+// reconstruction kernels use: a streaming kernel next to such a copy runs 3x longer, next to a DMA copy unchanged
+// (tools/exp/sdmaprobe.hip; in bench.py's with_copy_out leg k_mc_all took 115-330 us instead of 59).  So a thread of the decoder
+// waits for the picture ON THE HOST and then enqueues the copy on the idle output stream.
+// (never destroyed: a process that exits without freeing its decoders leaves output threads waiting on the condition variable,
+//  and destroying one that has waiters blocks for ever)
+std::mutex& g_out_mu = *new std::mutex;
+std::condition_variable& g_out_cv = *new std::condition_variable;
+void out_settle(Slot& s, uint64_t upto = ~0ull)
+{
+  std::unique_lock<std::mutex> lk(g_out_mu);
+  g_out_cv.wait(lk, [&] { return s.out_issued >= std::min(upto, s.out_queued); });
+}
+
 int free_slot(Slot& s)
 {
-  if (s.dl_done) { (void)hipEventSynchronize(s.dl_done); (void)hipEventDestroy(s.dl_done); s.dl_done = nullptr; }
+  out_settle(s);
+  { std::lock_guard<std::mutex> lk(g_out_mu); s.out_queued = s.out_issued = 0; }
+  if (s.dl_done) (void)hipEventSynchronize(s.dl_done);
+  for (int r = 0; r < Slot::kDlRing; r++) { if (s.dl_ev[r]) (void)hipEventDestroy(s.dl_ev[r]); s.dl_ev[r] = nullptr; s.dl_ev_seq[r] = 0; s.dl_ev_err_idx[r] = -1; }
+  s.dl_done = nullptr;
   s.dl_seq = s.dl_waited = 0;
   // (hipFree below waits for the device: nobody is left to wait for)
   if (s.written) { (void)hipEventDestroy(s.written); s.written = nullptr; }
@@ -677,7 +713,13 @@ static hipStream_t pooled_out_stream(int device)
   if (own_streams()) return nullptr;
   std::lock_guard<std::mutex> lk(g_streams_mu);
   DeviceStreams* D = device_streams(device);
-  return (D && D->out[0]) ? D->out[D->next_out++ & 1] : nullptr;
+  if (!D || !D->out[0]) return nullptr;
+  // two copy-out streams; with the sixteen-queue layout (DE265HIP_SCAN_STREAMS=4) its two low-priority fillers as well: a
+  // decoder's copy-outs wait for ITS pictures, and two decoders on one stream wait for each other's
+  hipStream_t all[4] = { D->out[0], D->out[1], D->pad[1], D->pad[2] };
+  static const int want = getenv("DE265HIP_OUT_STREAMS") ? std::max(1, std::min(4, atoi(getenv("DE265HIP_OUT_STREAMS")))) : 4;
+  const int n = std::min(want, (D->pad[1] && D->pad[2]) ? 4 : 2);
+  return all[D->next_out++ % n];
 }
 static hipStream_t pooled_upload_stream(int device)
 {
@@ -802,6 +844,12 @@ void de265hip_decoder_free(de265hip_decoder* d)
     for (int k = 0; k < 8; k++) fprintf(stderr, " %s %.1f (%.0f)", nm[k], 1e6 * d->t_sec[k] / d->n_sec, 1e6 * d->t_sec_max[k]);
     fprintf(stderr, "\n");
   }
+  if (d->out_thread_started) {                       // (the output thread hands over what it still holds, then ends)
+    { std::lock_guard<std::mutex> lo(g_out_mu); d->out_stop = true; }
+    g_out_cv.notify_all();
+    d->out_thread.join();
+  }
+  for (hipEvent_t e : d->out_events) (void)hipEventDestroy(e);
   for (int i = 0; i < 2; i++) if (d->upload_streams[i]) (void)hipStreamSynchronize(d->upload_streams[i]);
   for (int i = 0; i < d->n_copy_streams; i++) if (d->copy_streams[i]) (void)hipStreamSynchronize(d->copy_streams[i]);
   (void)sync_all_lanes(d);
@@ -871,6 +919,7 @@ int de265hip_dpb_upload(de265hip_decoder* d, int slot, int c, const void* src, p
   Slot* s; int w, h; size_t bpp;
   int rc = plane_geom(d, slot, c, &s, &w, &h, &bpp); if (rc) return rc;
   if (w == 0 || h == 0) return DE265HIP_OK;               // (a chroma plane of a monochrome picture)
+  out_settle(*s);
   if (s->dl_done && s->dl_waited != s->dl_seq) HIPCHK(hipEventSynchronize(s->dl_done), DE265HIP_ERROR_DECODING);
   HIPCHK(sync_all_lanes(d), DE265HIP_ERROR_DECODING);
   { std::lock_guard<std::mutex> lk(d->mu); slot_settled(*s); }
@@ -892,6 +941,7 @@ int de265hip_dpb_fill(de265hip_decoder* d, int slot, int y, int cb, int cr)
     if (val[c] < 0 || val[c] >= (1 << (c ? s->bdC : s->bdY))) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
     if (w == 0 || h == 0) continue;                      // (a chroma plane of a monochrome picture)
     if (c == 0) {
+      out_settle(*s);
       if (s->dl_done && s->dl_waited != s->dl_seq) HIPCHK(hipEventSynchronize(s->dl_done), DE265HIP_ERROR_DECODING);
       HIPCHK(sync_all_lanes(d), DE265HIP_ERROR_DECODING);
       std::lock_guard<std::mutex> lk(d->mu); slot_settled(*s);
@@ -927,18 +977,78 @@ void* de265hip_host_alloc(size_t bytes)
 
 void de265hip_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
-int de265hip_dpb_download_async(de265hip_decoder* d, int slot, int c, void* dst, ptrdiff_t stride_bytes)
+// Copy-out by a kernel that stores into the pinned planes (device-accessible host memory).  Why not hipMemcpyAsync: with the
+// uploads of the next pictures keeping the DMA engines busy the runtime performs a device-to-pinned-host copy as a blit kernel
+// of 256 workgroups x 512 threads PER PLANE (rocprofv3 kernel trace of bench.py's with_copy_out leg: __amd_rocclr_copyBuffer,
+// 3 per picture, 2 048 wavefronts each parked on PCIe writes next to the reconstruction kernels); 40 workgroups of 256 threads
+// carry the link as well (tools/exp/d2hprobe.hip: 16 workgroups 47 GB/s, 32: 52, 64: 54, the runtime's copy 54-55), and one
+// launch takes all three planes.
+struct OutJob {
+  const uint8_t* src[3]; uint8_t* dst[3];
+  uint32_t row_bytes[3], rows[3], spitch[3], dpitch[3];      // a plane whose rows are contiguous on both sides: ONE row of all its bytes
+};
+
+__global__ __launch_bounds__(256) void k_copy_out(OutJob J)
 {
-  Slot* s; int w, h; size_t bpp;
-  int rc = plane_geom(d, slot, c, &s, &w, &h, &bpp); if (rc) return rc;
-  if (w == 0 || h == 0) return DE265HIP_OK;               // (a chroma plane of a monochrome picture)
-  std::lock_guard<std::mutex> lk(d->mu);
+  const uint32_t tid = blockIdx.x * 256 + threadIdx.x, nthr = gridDim.x * 256;
+  __builtin_amdgcn_s_setprio(3);                                 // (a handful of wavefronts among thousands: let them issue)
+  for (int c = 0; c < 3; c++) {
+    const uint32_t rb = J.row_bytes[c], rows = J.rows[c];
+    if (!rb || !rows) continue;
+    const uint32_t upr = rb >> 4, tail = rb & 15;              // 16-byte units per row; a tail only where rows == 1 (checked by the host)
+    const uint64_t n = (uint64_t)upr * rows;
+    if (rows == 1) {
+      const uint4* sp = reinterpret_cast<const uint4*>(J.src[c]); uint4* dp = reinterpret_cast<uint4*>(J.dst[c]);
+      uint64_t i = tid;
+      for (; i + 3ull * nthr < n; i += 4ull * nthr) {            // four loads in flight per lane: few wavefronts carry the link
+        const uint4 a = sp[i], b = sp[i + nthr], c4 = sp[i + 2ull * nthr], e = sp[i + 3ull * nthr];
+        dp[i] = a; dp[i + nthr] = b; dp[i + 2ull * nthr] = c4; dp[i + 3ull * nthr] = e;
+      }
+      for (; i < n; i += nthr) dp[i] = sp[i];
+      if (tid < tail) J.dst[c][(size_t)upr * 16 + tid] = J.src[c][(size_t)upr * 16 + tid];
+    } else {
+      for (uint64_t i = tid; i < n; i += nthr) {
+        const uint32_t r = (uint32_t)(i / upr), k = (uint32_t)(i - (uint64_t)r * upr);
+        *reinterpret_cast<uint4*>(J.dst[c] + (size_t)r * J.dpitch[c] + (size_t)k * 16) =
+            *reinterpret_cast<const uint4*>(J.src[c] + (size_t)r * J.spitch[c] + (size_t)k * 16);
+      }
+    }
+  }
+}
+
+// The upload of a picture's staged records by a kernel that READS the pinned staging buffer (DE265HIP_UPLOAD=kernel): leaves the
+// DMA engines to the copy-outs, and returns to the build thread at once (hipMemcpyAsync of pinned memory holds its caller)
+static hipError_t upload_by_kernel(void* dev_dst, const void* pinned_src, size_t bytes, hipStream_t st, int grid)
+{
+  OutJob J; memset(&J, 0, sizeof(J));
+  J.src[0] = static_cast<const uint8_t*>(pinned_src); J.dst[0] = static_cast<uint8_t*>(dev_dst);
+  J.row_bytes[0] = (uint32_t)bytes; J.rows[0] = 1;
+  hipLaunchKernelGGL(k_copy_out, dim3(grid), dim3(256), 0, st, J);
+  return hipGetLastError();
+}
+static int upload_kernel_grid()
+{
+  static const int g = [] { const char* e = getenv("DE265HIP_UPLOAD"); if (!e || strncmp(e, "kernel", 6)) return 0; const int n = e[6] == ':' ? atoi(e + 7) : 16; return std::max(1, std::min(512, n)); }();
+  return g;
+}
+
+// can the device store into [dst, dst + bytes)?  (pinned by de265hip_host_alloc / hipHostMalloc / hipHostRegister: yes, at the
+// device pointer returned; pageable memory: no - and the runtime says so with an error that must not stay behind)
+static uint8_t* device_view_of_host(void* dst)
+{
+  hipPointerAttribute_t a; memset(&a, 0, sizeof(a));
+  if (hipPointerGetAttributes(&a, dst) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (a.type != hipMemoryTypeHost || !a.devicePointer) return nullptr;
+  return static_cast<uint8_t*>(a.devicePointer);
+}
+
+static int out_stream_behind_picture(de265hip_decoder* d, Slot* s)
+{
   if (!d->out_stream) {
     if (d->streams_pooled && (d->out_stream = pooled_out_stream(d->device)) != nullptr) d->out_pooled = true;
     else HIPCHK(hipStreamCreateWithPriority(&d->out_stream, hipStreamNonBlocking, d->prio_low), DE265HIP_ERROR_DECODING);
     HIPCHK(hipEventCreateWithFlags(&d->out_fence, hipEventDisableTiming), DE265HIP_ERROR_DECODING);
   }
-  if (!s->dl_done) HIPCHK(hipEventCreateWithFlags(&s->dl_done, hipEventDisableTiming), DE265HIP_ERROR_DECODING);
   // behind everything enqueued on the decoder's stream so far (the picture's kernels), but not in FRONT of what comes next
   if (d->n_lanes > 1) {                                   // (lanes: behind the picture that was decoded into the slot)
     if (s->writer_lane != -1 && s->written) HIPCHK(hipStreamWaitEvent(d->out_stream, s->written, 0), DE265HIP_ERROR_DECODING);
@@ -946,22 +1056,148 @@ int de265hip_dpb_download_async(de265hip_decoder* d, int slot, int c, void* dst,
     HIPCHK(hipEventRecord(d->out_fence, d->stream), DE265HIP_ERROR_DECODING);
     HIPCHK(hipStreamWaitEvent(d->out_stream, d->out_fence, 0), DE265HIP_ERROR_DECODING);
   }
-  // rows that are contiguous on both sides leave as ONE linear DMA: enqueueing a pitched copy costs the host about 2 us per row
-  // (4.3 ms for the three planes of a 4K picture, tools/exp/e2e_profile.sh), more than the whole host stage can afford
-  if ((size_t)stride_bytes == w * bpp && s->pl[c].stride * bpp == w * bpp)
-    HIPCHK(hipMemcpyAsync(dst, s->pl[c].ptr, (size_t)w * bpp * h, hipMemcpyDeviceToHost, d->out_stream), DE265HIP_ERROR_DECODING);
-  else
-    HIPCHK(hipMemcpy2DAsync(dst, (size_t)stride_bytes, s->pl[c].ptr, s->pl[c].stride * bpp, w * bpp, h, hipMemcpyDeviceToHost, d->out_stream),
-           DE265HIP_ERROR_DECODING);
-  HIPCHK(hipEventRecord(s->dl_done, d->out_stream), DE265HIP_ERROR_DECODING);
-  s->dl_seq++;
   return 0;
+}
+
+// the decoder's output thread (deferred copy-outs; comment at g_out_mu)
+static void out_thread_main(de265hip_decoder* d)
+{
+  (void)hipSetDevice(d->device);
+  for (;;) {
+    de265hip_decoder::OutJobRec job;
+    {
+      std::unique_lock<std::mutex> lk(g_out_mu);
+      g_out_cv.wait(lk, [&] { return d->out_stop || !d->out_jobs.empty(); });
+      if (d->out_jobs.empty()) return;
+      job = d->out_jobs.front(); d->out_jobs.pop_front();
+    }
+    bool ok = hipEventSynchronize(job.picture_done) == hipSuccess;        // the picture is in its slot (blocking-sync event: no spinning)
+    for (int c = 0; c < 3 && ok; c++) {
+      if (!job.dst[c]) continue;
+      // rows that are contiguous on both sides leave as ONE linear DMA: enqueueing a pitched copy costs the host about 2 us per row
+      // (4.3 ms for the three planes of a 4K picture, tools/exp/e2e_profile.sh), more than the whole host stage can afford
+      if (job.dpitch[c] == job.row_bytes[c] && job.spitch[c] == job.row_bytes[c])
+        ok = hipMemcpyAsync(job.dst[c], job.src[c], job.row_bytes[c] * job.rows[c], hipMemcpyDeviceToHost, d->out_stream) == hipSuccess;
+      else
+        ok = hipMemcpy2DAsync(job.dst[c], job.dpitch[c], job.src[c], job.spitch[c], job.row_bytes[c], job.rows[c], hipMemcpyDeviceToHost, d->out_stream) == hipSuccess;
+    }
+    // (recorded also when a call failed: whoever waits for this copy-out must not wait for ever; the failure is kept)
+    if (hipEventRecord(job.s->dl_ev[job.ring], d->out_stream) != hipSuccess) ok = false;
+    {
+      std::lock_guard<std::mutex> lk(g_out_mu);
+      if (!ok) d->out_failed = true;
+      job.s->out_issued++;
+      d->out_events.push_back(job.picture_done);
+    }
+    g_out_cv.notify_all();
+  }
+}
+
+int de265hip_dpb_download_planes_async(de265hip_decoder* d, int slot, void* const dst[3], const ptrdiff_t stride_bytes[3], uint64_t* copy_out_id)
+{
+  if (copy_out_id) *copy_out_id = 0;
+  if (!dst || !stride_bytes) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  Slot* s = nullptr; int w[3], h[3]; size_t bpp[3];
+  for (int c = 0; c < 3; c++) { const int rc = plane_geom(d, slot, c, &s, &w[c], &h[c], &bpp[c]); if (rc) return rc; }
+  // DE265HIP_OUT_COPY: "deferred" (default): the output thread enqueues a DMA copy once the picture is done; "dma": hipMemcpyAsync
+  // behind a stream wait, at once (the round-3 form: the runtime makes blit kernels of it); "kernel": k_copy_out behind a stream
+  // wait; "none": the events without the bytes (experiments; results invalid)
+  static const char* mode_env = getenv("DE265HIP_OUT_COPY");
+  static const int out_grid = [] { const char* e = getenv("DE265HIP_OUT_GRID"); const int g = e ? atoi(e) : 16; return std::max(1, std::min(1024, g)); }();
+  const bool use_kernel = mode_env && !strcmp(mode_env, "kernel");
+  const bool deferred = !mode_env || !strcmp(mode_env, "deferred");
+  static const bool no_copy = mode_env && !strcmp(mode_env, "none");
+  OutJob J; memset(&J, 0, sizeof(J));
+  de265hip_decoder::OutJobRec R; memset(&R, 0, sizeof(R));
+  bool by_kernel[3] = { false, false, false }; bool any_kernel = false, any = false;
+  for (int c = 0; c < 3; c++) {
+    if (!dst[c] || w[c] == 0 || h[c] == 0) continue;       // (not wanted; a chroma plane of a monochrome picture)
+    any = true;
+    const size_t rb = (size_t)w[c] * bpp[c], sp = s->pl[c].stride * bpp[c], dp = (size_t)stride_bytes[c];
+    if (stride_bytes[c] < (ptrdiff_t)rb) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+    R.dst[c] = dst[c]; R.src[c] = s->pl[c].ptr; R.dpitch[c] = dp; R.spitch[c] = sp; R.row_bytes[c] = rb; R.rows[c] = (size_t)h[c];
+    if (!use_kernel) continue;
+    uint8_t* dv = device_view_of_host(dst[c]);
+    if (!dv) continue;
+    const uint8_t* sv = reinterpret_cast<const uint8_t*>(s->pl[c].ptr);
+    const bool flat = sp == rb && dp == rb;
+    if (((uintptr_t)dv | (uintptr_t)sv) & 15) continue;
+    if (!flat && ((rb | sp | dp) & 15)) continue;
+    if ((flat ? rb * (size_t)h[c] : std::max(sp, dp)) > 0xFFFFFFFFu) continue;
+    J.src[c] = sv; J.dst[c] = dv;
+    if (flat) { J.row_bytes[c] = (uint32_t)(rb * (size_t)h[c]); J.rows[c] = 1; }
+    else { J.row_bytes[c] = (uint32_t)rb; J.rows[c] = (uint32_t)h[c]; J.spitch[c] = (uint32_t)sp; J.dpitch[c] = (uint32_t)dp; }
+    by_kernel[c] = any_kernel = true;
+  }
+  if (!any) return DE265HIP_OK;
+  std::lock_guard<std::mutex> lk(d->mu);
+  if (!d->out_stream) {
+    if (d->streams_pooled && (d->out_stream = pooled_out_stream(d->device)) != nullptr) d->out_pooled = true;
+    else HIPCHK(hipStreamCreateWithPriority(&d->out_stream, hipStreamNonBlocking, d->prio_low), DE265HIP_ERROR_DECODING);
+    HIPCHK(hipEventCreateWithFlags(&d->out_fence, hipEventDisableTiming), DE265HIP_ERROR_DECODING);
+  }
+  const int r = (int)(s->dl_seq % Slot::kDlRing);
+  if (!s->dl_ev[r]) HIPCHK(hipEventCreateWithFlags(&s->dl_ev[r], hipEventDisableTiming), DE265HIP_ERROR_DECODING);
+  if (deferred) {
+    // an event behind the picture's kernels for the output thread to wait for on the host
+    hipEvent_t pd = nullptr;
+    { std::lock_guard<std::mutex> lo(g_out_mu); if (!d->out_events.empty()) { pd = d->out_events.back(); d->out_events.pop_back(); } }
+    if (!pd) HIPCHK(hipEventCreateWithFlags(&pd, hipEventDisableTiming | hipEventBlockingSync), DE265HIP_ERROR_DECODING);
+    hipStream_t ws = d->stream;
+    if (d->n_lanes > 1) {
+      if (s->writer_lane >= 0) ws = lane_st(d, s->writer_lane);
+      else if (s->writer_lane == kForeignWriter && s->written) HIPCHK(hipStreamWaitEvent(ws, s->written, 0), DE265HIP_ERROR_DECODING);
+    }
+    HIPCHK(hipEventRecord(pd, ws), DE265HIP_ERROR_DECODING);
+    R.s = s; R.ring = r; R.picture_done = pd;
+    s->dl_done = s->dl_ev[r];                             // (recorded by the output thread: out_settle before anybody uses it)
+    s->dl_seq++;
+    R.id = s->dl_seq;
+    s->dl_ev_seq[r] = s->dl_seq; s->dl_ev_err_idx[r] = s->err_idx; s->dl_ev_err_seq[r] = s->err_seq;
+    if (copy_out_id) *copy_out_id = s->dl_seq;
+    {
+      std::lock_guard<std::mutex> lo(g_out_mu);
+      s->out_queued++;
+      d->out_jobs.push_back(R);
+      if (!d->out_thread_started) { d->out_thread_started = true; d->out_thread = std::thread(out_thread_main, d); }
+    }
+    g_out_cv.notify_all();
+    return 0;
+  }
+  { const int rc = out_stream_behind_picture(d, s); if (rc) return rc; }
+  if (any_kernel && !no_copy) {
+    hipLaunchKernelGGL(k_copy_out, dim3(out_grid), dim3(256), 0, d->out_stream, J);
+    HIPCHK(hipGetLastError(), DE265HIP_ERROR_DECODING);
+  }
+  for (int c = 0; c < 3 && !no_copy; c++) {
+    if (!R.dst[c] || by_kernel[c]) continue;
+    if (R.dpitch[c] == R.row_bytes[c] && R.spitch[c] == R.row_bytes[c])
+      HIPCHK(hipMemcpyAsync(R.dst[c], R.src[c], R.row_bytes[c] * R.rows[c], hipMemcpyDeviceToHost, d->out_stream), DE265HIP_ERROR_DECODING);
+    else
+      HIPCHK(hipMemcpy2DAsync(R.dst[c], R.dpitch[c], R.src[c], R.spitch[c], R.row_bytes[c], R.rows[c], hipMemcpyDeviceToHost, d->out_stream), DE265HIP_ERROR_DECODING);
+  }
+  HIPCHK(hipEventRecord(s->dl_ev[r], d->out_stream), DE265HIP_ERROR_DECODING);
+  s->dl_done = s->dl_ev[r];
+  s->dl_seq++;
+  s->dl_ev_seq[r] = s->dl_seq; s->dl_ev_err_idx[r] = s->err_idx; s->dl_ev_err_seq[r] = s->err_seq;
+  if (copy_out_id) *copy_out_id = s->dl_seq;
+  return 0;
+}
+
+int de265hip_dpb_download_async(de265hip_decoder* d, int slot, int c, void* dst, ptrdiff_t stride_bytes)
+{
+  if (c < 0 || c > 2) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  void* planes[3] = { nullptr, nullptr, nullptr }; ptrdiff_t strides[3] = { 0, 0, 0 };
+  planes[c] = dst; strides[c] = stride_bytes;
+  if (!dst) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  return de265hip_dpb_download_planes_async(d, slot, planes, strides, nullptr);
 }
 
 int de265hip_dpb_wait(de265hip_decoder* d, int slot)
 {
   if (!d || slot < 0 || slot >= DE265HIP_MAX_DPB_SLOTS || !d->slots[slot].valid) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   hipEvent_t ev; uint64_t seq;
+  out_settle(d->slots[slot]);
   { std::lock_guard<std::mutex> lk(d->mu); Slot& s = d->slots[slot]; ev = s.dl_done; seq = s.dl_seq; if (!ev || s.dl_waited == seq) return 0; }
   HIPCHK(hipEventSynchronize(ev), DE265HIP_ERROR_DECODING);        // outside the lock: another thread may be enqueueing the next picture
   // the error word of the picture that was decoded into the slot (a k_run dependency wait that expired): its own word, so a
@@ -971,6 +1207,31 @@ int de265hip_dpb_wait(de265hip_decoder* d, int slot)
   { std::lock_guard<std::mutex> lk(d->mu); Slot& s = d->slots[slot]; if (s.err_idx >= 0 && d->ring_owner[s.err_idx] == s.err_seq) eidx = s.err_idx; }
   if (eidx >= 0) HIPCHK(hipMemcpy(&err, d->d_err_ring + eidx, 4, hipMemcpyDeviceToHost), DE265HIP_ERROR_DECODING);
   { std::lock_guard<std::mutex> lk(d->mu); Slot& s = d->slots[slot]; if (s.dl_seq == seq) s.dl_waited = seq; }
+  { std::lock_guard<std::mutex> lo(g_out_mu); if (d->out_failed) err = 1; }
+  return err ? DE265HIP_ERROR_DECODING : 0;
+}
+
+int de265hip_dpb_wait_copy_out(de265hip_decoder* d, int slot, uint64_t copy_out_id)
+{
+  if (!d || slot < 0 || slot >= DE265HIP_MAX_DPB_SLOTS || !d->slots[slot].valid || copy_out_id == 0) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
+  hipEvent_t ev = nullptr; int eidx = -1;
+  out_settle(d->slots[slot], copy_out_id);
+  {
+    std::lock_guard<std::mutex> lk(d->mu);
+    Slot& s = d->slots[slot];
+    if (copy_out_id > s.dl_seq) return 0;                    // (from before the slot's re-allocation, which waited for it: free_slot)
+    const int r = (int)((copy_out_id - 1) % Slot::kDlRing);
+    // its own event; one that has been recorded again since belongs to a LATER copy-out on the same stream: waiting for it waits
+    // for this one too (and the picture's error word has long been handed on: decoder_sync reports it)
+    ev = s.dl_ev[r];
+    if (s.dl_ev_seq[r] == copy_out_id && s.dl_ev_err_idx[r] >= 0 && d->ring_owner[s.dl_ev_err_idx[r]] == s.dl_ev_err_seq[r]) eidx = s.dl_ev_err_idx[r];
+    if (!ev) return 0;
+  }
+  HIPCHK(hipEventSynchronize(ev), DE265HIP_ERROR_DECODING);
+  uint32_t err = 0;
+  if (eidx >= 0) HIPCHK(hipMemcpy(&err, d->d_err_ring + eidx, 4, hipMemcpyDeviceToHost), DE265HIP_ERROR_DECODING);
+  { std::lock_guard<std::mutex> lk(d->mu); Slot& s = d->slots[slot]; if (s.dl_seq == copy_out_id) s.dl_waited = copy_out_id; }
+  { std::lock_guard<std::mutex> lo(g_out_mu); if (d->out_failed) err = 1; }
   return err ? DE265HIP_ERROR_DECODING : 0;
 }
 
@@ -1033,6 +1294,7 @@ int de265hip_dpb_copy(de265hip_decoder* sd, int ss, de265hip_decoder* dd, int ds
   }
   {
     std::lock_guard<std::mutex> lk(dd->mu);
+    out_settle(D);
     if (!rc && D.dl_done && D.dl_waited != D.dl_seq && hipStreamWaitEvent(sd->stream, D.dl_done, 0) != hipSuccess) rc = DE265HIP_ERROR_DECODING;
   }
   for (int c = 0; c < 3 && !rc; c++) {
@@ -2455,7 +2717,10 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
     hipStream_t us;
     { std::lock_guard<std::mutex> lk(dec->mu); us = dec->upload_streams[dec->upload_turn++ & 1]; }
     bool ok = !pic->arena_buf.used || hipStreamWaitEvent(us, pic->arena_buf.last_use, 0) == hipSuccess;
-    ok = ok && hipMemcpyAsync(pic->arena, E.host_base, E.upload_bytes, hipMemcpyHostToDevice, us) == hipSuccess;
+    if (upload_kernel_grid() && E.upload_bytes < 0xFFFFFFFFu && !(((uintptr_t)pic->arena | (uintptr_t)E.host_base) & 15))
+      ok = ok && upload_by_kernel(pic->arena, E.host_base, E.upload_bytes, us, upload_kernel_grid()) == hipSuccess;
+    else
+      ok = ok && hipMemcpyAsync(pic->arena, E.host_base, E.upload_bytes, hipMemcpyHostToDevice, us) == hipSuccess;
     ok = ok && hipEventRecord(E.stage_event, us) == hipSuccess;
     if (!ok) { de265hip_picture_free(pic); return DE265HIP_ERROR_DECODING; }
     E.uploaded_by_builder = true;
@@ -2785,6 +3050,8 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
   dec->cur_stream = st;
   pic->lane = lane;
   // a copy-out of the picture this slot held before must have left (de265hip_dpb_download_async)
+  // (a deferred one has to be handed to the runtime first: on the host, until the slot's previous picture is done)
+  out_settle(dst);
   if (dst.dl_done && dst.dl_waited != dst.dl_seq && hipStreamWaitEvent(st, dst.dl_done, 0) != hipSuccess) return DE265HIP_ERROR_DECODING;
   if (!((pic->upload_waited >> lane) & 1u)) {            // the command buffers arrive on the copy stream
     if (hipStreamWaitEvent(st, pic->uploaded, 0) != hipSuccess) return DE265HIP_ERROR_DECODING;

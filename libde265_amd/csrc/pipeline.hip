@@ -44,7 +44,7 @@ struct de265hip_pipeline {
   std::condition_variable cv;                   // submit / wait / drain
   std::condition_variable cv_launch;            // the launcher: a picture has been built
   std::deque<PipeJob> q;                        // submitted, not yet taken by a worker
-  std::map<uint64_t, int> slot_of;              // launched, copy-out possibly still in flight: ticket -> slot
+  std::map<uint64_t, std::pair<int, uint64_t>> slot_of;   // launched, copy-out possibly still in flight: ticket -> slot, number of its copy-out (0: none)
   std::map<uint64_t, int> failed;               // ticket -> error of prepare / build / run
   struct Built { PipeJob job; de265hip_picture* pic; int rc; bool enqueued; double t_sub, t_b0, t_b1, t_enq, t_ready; };
   std::vector<std::array<double, 4>> chain_trace;   // DE265HIP_PIPE_TRACE: per scan chain: enqueued, reported, pictures built / in flight then
@@ -174,14 +174,15 @@ void launcher(de265hip_pipeline* p)
     }
     if (have_launch) {
       int r = todo.rc;
+      uint64_t copy_out_id = 0;
       static const bool no_run = getenv("DE265HIP_PIPE_NO_RUN") != nullptr;      // (experiment: builds, uploads and scans only)
       if (!r && !no_run) r = de265hip_picture_run(p->dec, todo.pic, DE265HIP_STAGE_FINAL);
-      for (int c = 0; c < 3 && !r; c++)
-        if (todo.job.plane[c]) r = de265hip_dpb_download_async(p->dec, todo.job.slot, c, todo.job.plane[c], todo.job.stride[c]);
+      if (!r && (todo.job.plane[0] || todo.job.plane[1] || todo.job.plane[2]))
+        r = de265hip_dpb_download_planes_async(p->dec, todo.job.slot, todo.job.plane, todo.job.stride, &copy_out_id);
       if (todo.pic) de265hip_picture_free(todo.pic);          // never waits (de265_hip.h LIFETIME)
       {
         std::lock_guard<std::mutex> lk(p->mu);
-        if (r) p->failed[todo.job.ticket] = r; else p->slot_of[todo.job.ticket] = todo.job.slot;
+        if (r) p->failed[todo.job.ticket] = r; else p->slot_of[todo.job.ticket] = { todo.job.slot, copy_out_id };
         p->next_launch++; p->in_flight--;
         if (p->timing) { p->t_lidle += t1 - t0; p->t_launch += now() - t1; }
         if (p->tracing) p->trace.push_back({ (double)todo.job.ticket, todo.t_sub, todo.t_b0, todo.t_b1, todo.t_enq, t1, now(), todo.t_ready });
@@ -252,7 +253,7 @@ int de265hip_pipeline_submit_desc(de265hip_pipeline* p, int dst_slot, const de26
 int de265hip_pipeline_wait(de265hip_pipeline* p, uint64_t ticket)
 {
   if (!p) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
-  int slot = -1;
+  std::pair<int, uint64_t> so;
   {
     std::unique_lock<std::mutex> lk(p->mu);
     if (ticket >= p->next_ticket) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
@@ -261,10 +262,12 @@ int de265hip_pipeline_wait(de265hip_pipeline* p, uint64_t ticket)
     if (f != p->failed.end()) { const int rc = f->second; p->failed.erase(f); return rc; }
     auto s = p->slot_of.find(ticket);
     if (s == p->slot_of.end()) return 0;                                  // waited for before
-    slot = s->second;
+    so = s->second;
     p->slot_of.erase(s);
   }
-  return de265hip_dpb_wait(p->dec, slot);                                 // outside the lock: the workers go on launching
+  // outside the lock: the workers go on launching.  THIS picture's copy-out, not the slot's latest: the slot may have been
+  // decoded into and copied out again since (an output queue deeper than the DPB's cycle)
+  return so.second ? de265hip_dpb_wait_copy_out(p->dec, so.first, so.second) : de265hip_dpb_wait(p->dec, so.first);
 }
 
 int de265hip_pipeline_drain(de265hip_pipeline* p)
@@ -278,7 +281,7 @@ int de265hip_pipeline_drain(de265hip_pipeline* p)
   std::vector<int> slots;
   {
     std::lock_guard<std::mutex> lk(p->mu);
-    for (auto& kv : p->slot_of) slots.push_back(kv.second);
+    for (auto& kv : p->slot_of) slots.push_back(kv.second.first);
     p->slot_of.clear();
     if (!rc && !p->failed.empty()) rc = p->failed.begin()->second;
     p->failed.clear();

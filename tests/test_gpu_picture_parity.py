@@ -635,6 +635,55 @@ def test_async_copy_out_overlaps_later_pictures_and_survives_slot_reuse(dec):
             p.free()
 
 
+def test_copy_out_of_all_planes_in_one_call(dec):
+    """de265hip_dpb_download_planes_async: pinned planes leave by the library's copy-out kernel (contiguous rows, padded rows,
+    a plane whose byte count is no multiple of 16), pageable planes and odd strides by the runtime's copy - every form must
+    deliver what de265hip_dpb_download does, and bytes outside the rows stay as they were."""
+    import ctypes as C
+    from libde265_amd import backend
+    L = backend.lib()
+    for (w, h, bd, cf) in [(352, 288, 10, 1), (200, 104, 8, 1), (64, 72, 8, 3), (136, 64, 10, 2), (72, 40, 8, 0)]:
+        planes = pysynth.fill_planes(w, h, bd, 77) if cf == 1 else None
+        dec.dpb_alloc(5, w, h, bd, chroma_format=cf)
+        if planes is None:
+            rng = np.random.default_rng(w * h + cf)
+            cw, ch = dec._chroma_dims(5, w, h)
+            dt = np.uint16 if bd > 8 else np.uint8
+            planes = [rng.integers(0, 1 << bd, size=sh, dtype=dt) for sh in ((h, w), (ch, cw), (ch, cw))]
+        dec.upload(5, planes)
+        bpp = planes[0].dtype.itemsize
+        for pad, pinned in [(0, True), (32, True), (6, True), (0, False), (10, False)]:
+            bufs, views, ptrs, strides = [], [], [], []
+            for pl in planes:
+                rows, cols = pl.shape
+                if rows == 0 or cols == 0:
+                    ptrs.append(None); strides.append(0); views.append(None); bufs.append(None); continue
+                stride = cols * bpp + pad
+                nbytes = stride * rows
+                if pinned:
+                    ptr = L.de265hip_host_alloc(nbytes); assert ptr
+                    raw = np.frombuffer((C.c_uint8 * nbytes).from_address(ptr), np.uint8)
+                else:
+                    raw = np.empty(nbytes, np.uint8); ptr = raw.ctypes.data
+                raw[:] = 0xA5
+                bufs.append((ptr, raw)); ptrs.append(ptr); strides.append(stride); views.append(raw.reshape(rows, stride))
+            try:
+                dec.download_planes_async(5, ptrs, strides)
+                dec.wait_slot(5)
+                for c, pl in enumerate(planes):
+                    if views[c] is None:
+                        continue
+                    rb = pl.shape[1] * bpp
+                    got = views[c][:, :rb].copy().view(pl.dtype)
+                    assert np.array_equal(got, pl), (w, h, bd, cf, pad, pinned, c)
+                    assert (views[c][:, rb:] == 0xA5).all(), "bytes behind the rows were written"
+            finally:
+                for b in bufs:
+                    if b is not None and pinned:
+                        L.de265hip_host_free(b[0])
+    dec.dpb_alloc(5, 64, 64, 8)
+
+
 def test_pipeline_builds_concurrently_and_launches_in_order(dec):
     """SURVEY 8(f3) through the C ABI's own pipeline (de265hip_pipeline_*): a chain of pictures in which every picture
     predicts from the one before it (its DPB slot) is submitted without waiting; three worker threads prepare and build them
@@ -670,6 +719,49 @@ def test_pipeline_builds_concurrently_and_launches_in_order(dec):
             pipe.wait(tickets[k])
             assert all(np.array_equal(g, e) for g, e in zip(pins[k].planes, exps[k])), k
         pipe.drain()
+    finally:
+        pipe.close()
+        for p in pins:
+            p.free()
+
+
+def test_pipeline_output_queue_deeper_than_the_dpb_cycle(dec):
+    """A chain of ten pictures that cycles through three DPB slots, each copied out into pinned planes of its own, collected only
+    after all have been submitted: by then every slot has been decoded into and copied out again up to three times.  A ticket
+    waits for ITS picture's copy-out (de265hip_dpb_wait_copy_out), and every picture arrives as the oracle computes it."""
+    from libde265_amd import backend
+    w, h, bd = 352, 288, 10
+    n = 10
+    first = pysynth.fill_planes(w, h, bd, 41)
+    dec.dpb_alloc(0, w, h, bd); dec.upload(0, first)
+    for s in (1, 2, 3):
+        dec.dpb_alloc(s, w, h, bd)
+    slot_of = lambda k: 1 + k % 3
+    sps, exps, prev = [], [], first
+    for k in range(n):
+        ref = 0 if k == 0 else slot_of(k - 1)
+        sp = pysynth.SynthPicture(pysynth.default_config(w, h, bd, 1, seed=1950 + k, ref_slots=[ref]))
+        exp = pyoracle.alloc_planes(w, h, bd)
+        pyoracle.reconstruct(sp.desc, sp.order, {ref: prev}, exp)
+        sps.append(sp); exps.append(exp); prev = exp
+    pipe = backend.Pipeline(dec, 3)
+    pins = [backend.PinnedPlanes(w, h, bd) for _ in range(n)]
+    try:
+        tickets = [pipe.submit(slot_of(k), _recorder_maker(sps[k]), pins[k]) for k in range(n)]
+        for k in range(n):
+            pipe.wait(tickets[k])
+            assert all(np.array_equal(g, e) for g, e in zip(pins[k].planes, exps[k])), k
+        pipe.drain()
+        # the numbered wait by itself: two copy-outs of one slot, the first one waited for by its number
+        a, b = backend.PinnedPlanes(w, h, bd), backend.PinnedPlanes(w, h, bd)
+        id1 = dec.download_planes_async(1, a.ptrs, a.strides)
+        id2 = dec.download_planes_async(1, b.ptrs, b.strides)
+        assert id2 == id1 + 1
+        dec.wait_slot(1, id1)
+        assert all(np.array_equal(g, e) for g, e in zip(a.planes, exps[9]))      # slot 1 holds picture 9
+        dec.wait_slot(1, id2)
+        assert all(np.array_equal(g, e) for g, e in zip(b.planes, exps[9]))
+        a.free(); b.free()
     finally:
         pipe.close()
         for p in pins:
