@@ -3104,9 +3104,8 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
       for (int b = 0; b < 8; b++) most = std::max(most, B.n_entries[b]);
       hipLaunchKernelGGL(k_mc_all<PX>, dim3(8 * most), dim3(64), 0, st, P, tab, d0, d1, d2, pic->d_mc, pic->d_slices, pic->d_mc_order, B);
     } else
-      hipLaunchKernelGGL(k_mc<PX>, dim3(xcd_grid((unsigned)pic->n_mc)), dim3(64), 0, st, P, tab, d0, d1, d2, pic->d_mc, pic->d_slices, pic->n_mc);
-    if (P.chroma_format != 1)                          // 4:2:2 / 4:4:4: k_mc predicts luma only, the chroma planes by the plain kernel
-      hipLaunchKernelGGL(k_mc_chroma_any<PX>, dim3(pic->n_mc), dim3(64), 0, st, P, tab, d1, d2, pic->d_mc, pic->d_slices, pic->n_mc);
+      // (4:2:2 / 4:4:4: the tile body predicts luma only; the chroma planes of a task by a second wavefront, blockIdx.y == 1)
+      hipLaunchKernelGGL(k_mc<PX>, dim3(xcd_grid((unsigned)pic->n_mc), (P.chroma_format == 2 || P.chroma_format == 3) ? 2 : 1), dim3(64), 0, st, P, tab, d0, d1, d2, pic->d_mc, pic->d_slices, pic->n_mc);
   }
   if (pic->n_pcm) {
     KTimer t(dec, DE265HIP_K_PCM, 1);

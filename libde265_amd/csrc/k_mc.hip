@@ -52,19 +52,34 @@ __device__ __forceinline__ int mc_clip3(int lo, int hi, int v) { return min(max(
 // plane into out[] (sample s = lane + 64*k, row-major over w).  Intermediates are
 // truncated to int16 after each stage (fallback-motion.cc:346,:377,:508-545).
 template <typename PX, int NT, int KMAX = (NT == 8 ? 4 : 1)>     // KMAX: outputs per lane (chroma blocks beyond 8x8: 4)
+__device__ __forceinline__ void mc_block_filter(int xF, int yF, int w, int h, int bd, const uint16_t* in, int16_t* tmp, int lane, int16_t* out);
+
+template <typename PX, int NT, int KMAX = (NT == 8 ? 4 : 1)>
 __device__ void mc_block(const PX* __restrict__ ref, int rstride, int picW, int picH,
                          int xInt, int yInt, int xF, int yF, int w, int h, int bd,
                          uint16_t* in, int16_t* tmp, int lane, int16_t* out)
 {
   constexpr int before = NT == 8 ? 3 : 1;
   const int IW = w + NT - 1, IH = h + NT - 1;
+  // idx / IW and idx / w as multiplications (exact for divisors up to 23 and idx < 600: every block here)
+  const uint32_t invIW = 65536u / (uint32_t)IW + 1u;
   for (int idx = lane; idx < IW * IH; idx += 64) {
-    int r = idx / IW, c = idx - r * IW;
+    int r = (int)(((uint32_t)idx * invIW) >> 16), c = idx - r * IW;
     int xA = mc_clip3(0, picW - 1, xInt - before + c);
     int yA = mc_clip3(0, picH - 1, yInt - before + r);
     in[r * MC_IWP + c] = ref[xA + yA * rstride];
   }
   __syncthreads();
+  mc_block_filter<PX, NT, KMAX>(xF, yF, w, h, bd, in, tmp, lane, out);
+}
+
+// the two filter stages on a staged input tile (rows of MC_IWP samples, the block's first sample at [before][before])
+template <typename PX, int NT, int KMAX>
+__device__ __forceinline__ void mc_block_filter(int xF, int yF, int w, int h, int bd, const uint16_t* in, int16_t* tmp, int lane, int16_t* out)
+{
+  constexpr int before = NT == 8 ? 3 : 1;
+  const int IH = h + NT - 1;
+  const uint32_t invW = 65536u / (uint32_t)w + 1u;
   const int shift1 = bd - 8;
   const int nOut = w * h;
   if (xF == 0 && yF == 0) {
@@ -73,7 +88,7 @@ __device__ void mc_block(const PX* __restrict__ ref, int rstride, int picW, int 
     for (int k = 0; k < KMAX; k++) {
       int s = lane + 64 * k;
       if (s < nOut) {
-        int y = s / w, x = s - y * w;
+        int y = (int)(((uint32_t)s * invW) >> 16), x = s - y * w;
         out[k] = (int16_t)(in[(y + before) * MC_IWP + x + before] << shift3);
       }
     }
@@ -81,7 +96,7 @@ __device__ void mc_block(const PX* __restrict__ ref, int rstride, int picW, int 
     return;
   }
   for (int idx = lane; idx < IH * w; idx += 64) {
-    int r = idx / w, x = idx - r * w;
+    int r = (int)(((uint32_t)idx * invW) >> 16), x = idx - r * w;
     int v;
     if (xF == 0) v = in[r * MC_IWP + x + before];
     else {
@@ -101,7 +116,7 @@ __device__ void mc_block(const PX* __restrict__ ref, int rstride, int picW, int 
   for (int k = 0; k < KMAX; k++) {
     int s = lane + 64 * k;
     if (s < nOut) {
-      int y = s / w, x = s - y * w;
+      int y = (int)(((uint32_t)s * invW) >> 16), x = s - y * w;
       int v;
       if (yF == 0) v = tmp[(y + before) * 16 + x];
       else {
@@ -193,7 +208,7 @@ __device__ __forceinline__ void mc_tile_body(const PicDev& P, const DpbTable& dp
   const int l_uni = use0 ? 0 : 1;
   const int w = t.w, h = t.h, wc = w >> 1, hc = h >> 1;
   const int cW = P.width >> 1, cH = P.height >> 1;
-  const bool c420 = P.chroma_format == 1;           // (4:2:2 / 4:4:4: the chroma planes are predicted by k_mc_chroma_any)
+  const bool c420 = P.chroma_format == 1;           // (4:2:2 / 4:4:4: the chroma planes are predicted by mc_chroma_any_body, k_mc's blockIdx.y == 1)
 
   int mode;                                         // motion.cc:440-620
   if (sh->slice_type == 1) mode = P.weighted_pred ? 1 : 0;
@@ -468,18 +483,26 @@ __device__ __forceinline__ void mc_tile_body(const PicDev& P, const DpbTable& dp
   }
 }
 
+#define MC_CHROMA_ANY_LDS (4 * 19 * MC_IWP * 2 + 23 * 16 * 2)
+template <typename PX>
+__device__ __forceinline__ void mc_chroma_any_body(const PicDev& P, const DpbTable& dpb, const PlaneRef& d1, const PlaneRef& d2, const McTask* __restrict__ tasks,
+                                                   const de265hip_slice_params* __restrict__ slices, int tix, char* smem);
+
+// blockIdx.y == 1 (4:2:2 / 4:4:4 pictures, where the tile body predicts luma only): the task's chroma planes, in the same launch -
+// a kernel of its own behind this one paid its own ramp and tail, and took its tasks in list order across the XCDs
 template <typename PX>
 __global__ __launch_bounds__(64)
 void k_mc(PicDev P, DpbTable dpb, PlaneRef d0, PlaneRef d1, PlaneRef d2,
           const McTask* __restrict__ tasks, const de265hip_slice_params* __restrict__ slices, int n_tasks)
 {
-  __shared__ __attribute__((aligned(16))) char smem[MC_TILE_LDS];
+  __shared__ __attribute__((aligned(16))) char smem[MC_TILE_LDS > MC_CHROMA_ANY_LDS ? MC_TILE_LDS : MC_CHROMA_ANY_LDS];
   // XCD-aware mapping: workgroups b and b+8 share an XCD (and its L2); give every XCD one contiguous
   // eighth of the task list (tasks are in decode order, i.e. spatial neighbours) so that the
   // overlapping filter margins of neighbouring tiles hit in the same L2.  Speed only, never correctness.
   const int per = (n_tasks + 7) >> 3;
   const int tix = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   if (tix >= n_tasks) return;
+  if (blockIdx.y == 1) { mc_chroma_any_body<PX>(P, dpb, d1, d2, tasks, slices, tix, smem); return; }
   mc_tile_body<PX>(P, dpb, d0, d1, d2, tasks, slices, tix, smem);
 }
 template __global__ void k_mc<uint8_t>(PicDev, DpbTable, PlaneRef, PlaneRef, PlaneRef, const McTask*,
@@ -1085,36 +1108,69 @@ template __global__ void k_mc_all<uint8_t>(PicDev, DpbTable, PlaneRef, PlaneRef,
 template __global__ void k_mc_all<uint16_t>(PicDev, DpbTable, PlaneRef, PlaneRef, PlaneRef, const McTask*, const de265hip_slice_params*, const uint32_t*, McBands);
 
 // ---- chroma prediction of one MC task for any chroma format (4:2:2 / 4:4:4 pictures; mc_chroma, motion.cc:175-273: the
-// vector scaled by 2 / SubWidthC, 2 / SubHeightC, eighth-sample fractions).  One wavefront per task and plane
-// (blockIdx.y), the tile of at most 16x16 chroma samples through the function-level block interpolator.
+// vector scaled by 2 / SubWidthC, 2 / SubHeightC, eighth-sample fractions).  One wavefront per task (k_mc's blockIdx.y == 1),
+// the tile of at most 16x16 chroma samples through the filter stages of the function-level block interpolator.
 template <typename PX>
-__global__ __launch_bounds__(64)
-void k_mc_chroma_any(PicDev P, DpbTable dpb, PlaneRef d1, PlaneRef d2, const McTask* __restrict__ tasks,
-                     const de265hip_slice_params* __restrict__ slices, int n_tasks)
+__device__ __forceinline__ void mc_chroma_any_body(const PicDev& P, const DpbTable& dpb, const PlaneRef& d1, const PlaneRef& d2, const McTask* __restrict__ tasks,
+                                                   const de265hip_slice_params* __restrict__ slices, int tix, char* smem)
 {
-  __shared__ uint16_t s_in[23 * MC_IWP];
-  __shared__ int16_t s_tmp[23 * 16];
+  uint16_t (*s_in)[19 * MC_IWP] = reinterpret_cast<uint16_t (*)[19 * MC_IWP]>(smem);      // [list * 2 + plane]: the staged input tiles of the task
+  int16_t* s_tmp = reinterpret_cast<int16_t*>(smem + 4 * 19 * MC_IWP * 2);
   const int lane = threadIdx.x;
-  if ((int)blockIdx.x >= n_tasks) return;
-  const McTask t = tasks[blockIdx.x];
+  const McTask t = tasks[tix];
   const de265hip_slice_params* sh = &slices[t.slice_idx];
   const bool use0 = t.slot[0] >= 0, use1 = t.slot[1] >= 0, bi = use0 && use1;
   const int wc = t.w >> P.csw, hc = t.h >> P.csh, xc = t.x >> P.csw, yc = t.y >> P.csh;
+  const uint32_t invWc = 65536u / (uint32_t)max(wc, 1) + 1u;             // (s / wc for s < 256, wc <= 16: exact)
   int mode;
   if (sh->slice_type == 1) mode = P.weighted_pred ? 1 : 0;
   else if (bi) mode = P.weighted_bipred ? 3 : 2;
   else mode = P.weighted_bipred ? 1 : 0;
-  // (both chroma planes by the one wavefront that decoded the task: a workgroup per task AND plane was twice as many one-wavefront
-  //  workgroups as the luma kernel has - 87 us against luma's 34 per 4K10 4:4:4 picture, with half the filter taps)
+  // Both chroma planes and both lists by the one wavefront that decoded the task, and EVERY reference sample of the task
+  // requested before anything is filtered: plane after plane, list after list, each with its own fetch -> LDS -> filter round,
+  // a tile was four dependent memory round trips (87 us per 4K10 4:4:4 picture against luma's 34, with half the filter taps)
+  constexpr int NLD = 6;                                 // (16 + 3)^2 = 361 input samples of a tile at most: six per lane
+  const int IW = wc + 3, IH = hc + 3, nIn = IW * IH;
+  const uint32_t invIW = 65536u / (uint32_t)IW + 1u;
+  int xI[2] = { 0, 0 }, yI[2] = { 0, 0 }, xF[2] = { 0, 0 }, yF[2] = { 0, 0 };
+  PX v[2][2][NLD];                                       // [list][plane][k]
+#pragma unroll
+  for (int l = 0; l < 2; l++) {
+    if (t.slot[l] < 0) continue;
+    const int mvx = t.mv[l][0] * (2 >> P.csw), mvy = t.mv[l][1] * (2 >> P.csh);
+    xI[l] = xc + (mvx >> 3); yI[l] = yc + (mvy >> 3); xF[l] = mvx & 7; yF[l] = mvy & 7;
+    const PlaneRef r1 = dpb.p[t.slot[l]][1], r2 = dpb.p[t.slot[l]][2];
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+      const int idx = lane + 64 * k;
+      if (idx < nIn) {
+        const int r = (int)(((uint32_t)idx * invIW) >> 16), c = idx - r * IW;
+        const int xA = mc_clip3(0, P.cwidth - 1, xI[l] - 1 + c), yA = mc_clip3(0, P.cheight - 1, yI[l] - 1 + r);
+        v[l][0][k] = ((const PX*)r1.ptr)[xA + yA * r1.stride];
+        v[l][1][k] = ((const PX*)r2.ptr)[xA + yA * r2.stride];
+      }
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < 2; l++) {
+    if (t.slot[l] < 0) continue;
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+      const int idx = lane + 64 * k;
+      if (idx < nIn) {
+        const int r = (int)(((uint32_t)idx * invIW) >> 16), c = idx - r * IW;
+        s_in[l * 2 + 0][r * MC_IWP + c] = v[l][0][k];
+        s_in[l * 2 + 1][r * MC_IWP + c] = v[l][1][k];
+      }
+    }
+  }
+  __syncthreads();
   for (int cp = 0; cp < 2; cp++) {
     int16_t pr[2][4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
 #pragma unroll
     for (int l = 0; l < 2; l++) {
       if (t.slot[l] < 0) continue;
-      const int mvx = t.mv[l][0] * (2 >> P.csw), mvy = t.mv[l][1] * (2 >> P.csh);
-      const PlaneRef r = dpb.p[t.slot[l]][cp + 1];
-      mc_block<PX, 4, 4>((const PX*)r.ptr, r.stride, P.cwidth, P.cheight, xc + (mvx >> 3), yc + (mvy >> 3), mvx & 7, mvy & 7,
-                      wc, hc, P.bd_chroma, s_in, s_tmp, lane, pr[l]);
+      mc_block_filter<PX, 4, 4>(xF[l], yF[l], wc, hc, P.bd_chroma, s_in[l * 2 + cp], s_tmp, lane, pr[l]);
     }
     int w0 = 0, o0 = 0, w1 = 0, o1 = 0, log2WD = 1;
     if (mode == 1 || mode == 3) {
@@ -1128,16 +1184,13 @@ void k_mc_chroma_any(PicDev P, DpbTable dpb, PlaneRef d1, PlaneRef d2, const McT
     for (int k = 0; k < 4; k++) {
       const int s = lane + 64 * k;
       if (s < wc * hc) {
-        const int y = s / wc, x = s - y * wc;
+        const int y = (int)(((uint32_t)s * invWc) >> 16), x = s - y * wc;
         const int a = bi ? pr[0][k] : (use0 ? pr[0][k] : pr[1][k]);
         ((PX*)dc.ptr)[xc + x + (yc + y) * dc.stride] = mc_combine<PX>(mode, a, pr[1][k], P.bd_chroma, w0, o0, w1, o1, log2WD);
       }
     }
-    __syncthreads();                                     // (the LDS tiles are reused by the next plane)
   }
 }
-template __global__ void k_mc_chroma_any<uint8_t>(PicDev, DpbTable, PlaneRef, PlaneRef, const McTask*, const de265hip_slice_params*, int);
-template __global__ void k_mc_chroma_any<uint16_t>(PicDev, DpbTable, PlaneRef, PlaneRef, const McTask*, const de265hip_slice_params*, int);
 
 // ---- PCM sample copy (slice.cc:4143-4183), one workgroup per PCM CU
 template <typename PX>

@@ -79,15 +79,13 @@ __global__ void k_sao_ctb(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneR
 template <typename PX>
 __global__ void k_lf_tile(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, PlaneRef, LfMeta, SaoMeta, int);
 
-// range-extension paths (k_rext.hip; k_mc_chroma_any in k_mc.hip)
+// range-extension paths (k_rext.hip; the chroma planes of 4:2:2 / 4:4:4 MC tasks: k_mc's blockIdx.y == 1, k_mc.hip)
 template <typename PX>
 __global__ void k_resid_rext(PicDev, PlaneRef, PlaneRef, PlaneRef, const TuTask*, int, const int16_t*, const uint16_t*, const uint8_t*, int16_t*);
 template <typename PX>
 __global__ void k_deblock_chroma_any(PicDev, PlaneRef, PlaneRef, LfMeta, int);
 template <typename PX>
 __global__ void k_sao_chroma_any(PicDev, PlaneRef, PlaneRef, PlaneRef, PlaneRef, SaoMeta);
-template <typename PX>
-__global__ void k_mc_chroma_any(PicDev, DpbTable, PlaneRef, PlaneRef, const McTask*, const de265hip_slice_params*, int);
 
 // function-level kernels (k_fn.hip)
 template <typename PX>
