@@ -148,6 +148,7 @@ struct Hip {
   int  (*decoder_sync)(de265hip_decoder*);
   void (*picture_free)(de265hip_picture*);
   int  (*dpb_download_async)(de265hip_decoder*, int, int, void*, ptrdiff_t);
+  int  (*dpb_download_planes_async)(de265hip_decoder*, int, void* const*, const ptrdiff_t*, uint64_t*);
   int  (*dpb_wait)(de265hip_decoder*, int);
   int  (*dpb_fill)(de265hip_decoder*, int, int, int, int);
   int  (*dpb_upload)(de265hip_decoder*, int, int, const void*, ptrdiff_t);
@@ -190,7 +191,7 @@ bool hip_mode()
 #define SYM(f) do { *(void**)&H.f = dlsym(H.lib, "de265hip_" #f); if (!H.f) hip_die("dlsym de265hip_" #f, 0); } while (0)
   SYM(decoder_new); *(void**)&H.dpb_alloc = dlsym(H.lib, "de265hip_dpb_alloc_ex"); if (!H.dpb_alloc) hip_die("dlsym de265hip_dpb_alloc_ex", 0); SYM(dpb_download); SYM(recorder_new); SYM(recorder_free); SYM(record_tu); SYM(record_pu);
   SYM(record_pcm); SYM(record_slice); SYM(record_ctb); SYM(record_blk_planes); SYM(recorder_submit); SYM(picture_run);
-  SYM(decoder_sync); SYM(picture_free); SYM(dpb_fill); SYM(dpb_upload); SYM(dpb_download_async); SYM(dpb_wait); SYM(host_alloc); SYM(host_free);
+  SYM(decoder_sync); SYM(picture_free); SYM(dpb_fill); SYM(dpb_upload); SYM(dpb_download_async); SYM(dpb_download_planes_async); SYM(dpb_wait); SYM(host_alloc); SYM(host_free);
   SYM(pipeline_new); SYM(pipeline_submit); SYM(pipeline_wait); SYM(pipeline_drain); SYM(pipeline_free);
 #undef SYM
   const char* pl = getenv("F1_PIPELINE");
@@ -430,8 +431,7 @@ bool launch_job(Job& j, bool wait)
     for (int c=0;c<3;c++)                                           // the GPU's picture becomes the decoder's picture
       TRY(H.dpb_download(H.dec, j.slot, c, j.plane[c], j.stride_bytes[c]), "dpb_download");
   } else {
-    for (int c=0;c<3;c++)
-      TRY(H.dpb_download_async(H.dec, j.slot, c, j.plane[c], j.stride_bytes[c]), "dpb_download_async");
+    TRY(H.dpb_download_planes_async(H.dec, j.slot, j.plane, j.stride_bytes, NULL), "dpb_download_planes_async");   // the three planes in one call
   }
 #undef TRY
   static std::mutex pm; std::lock_guard<std::mutex> lk(pm);
