@@ -417,7 +417,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # DE265HIP_BENCH_FORCE_RCCL=1: a communicator also for a single rank (rehearsal on the one-GPU box of what a rank of an N-GPU
+    # run has in its process: RCCL's streams and hardware queues next to the library's, the timer's all-reduce on the device)
+    force_dist = world == 1 and os.environ.get("DE265HIP_BENCH_FORCE_RCCL") == "1"
+    if force_dist:
+        for k_, v_ in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")):
+            os.environ.setdefault(k_, v_)
+    if world > 1 or force_dist:
         import torch.distributed as dist
         with _stdout_to_stderr():
             if args.backend == "nccl":
