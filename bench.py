@@ -36,6 +36,7 @@ from concurrent.futures import ThreadPoolExecutor
 # process, in an order that puts the decoders' kernel streams and its scan streams on different dispatch pipes:
 # that order needs a queue of its own per stream - eight per priority leave room ("host placement").  Must be
 # set before the runtime initialises.
+os.environ.setdefault("DE265HIP_TUNING", "1")      # (the library reads its DE265HIP_* switches only in a process that sets this: csrc/env.h)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # a fourth scan stream on the scan pipe (libde265_amd/csrc/host.hip, DeviceStreams): sixteen hardware queues in the process - only
 # where no collective library adds queues of its own (a single rank)

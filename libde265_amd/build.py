@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SO = os.path.join(_HERE, "libde265_hip.so")
 SOURCES = ["k_tu.hip", "k_mc.hip", "k_lf.hip", "k_rext.hip", "k_scan.hip", "host.hip", "vtable.hip", "pipeline.hip"]
-HEADERS = ["dev_common.h", "kernels.h", "scan.h", "scan_core.h", "dct_table.inc", os.path.join("..", "..", "include", "de265_hip.h"),
+HEADERS = ["dev_common.h", "kernels.h", "scan.h", "scan_core.h", "env.h", "dct_table.inc", os.path.join("..", "..", "include", "de265_hip.h"),
            os.path.join("..", "..", "include", "de265_hip_vtable.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + \

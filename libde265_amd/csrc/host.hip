@@ -22,6 +22,7 @@
 #include <map>
 
 #include "kernels.h"
+#include "env.h"
 #include "scan.h"
 
 using namespace d265;
@@ -607,7 +608,7 @@ int acquire_stage(de265hip_decoder* dec, size_t bytes, int* index)
 // DE265HIP_BUILD_TIMING=1: where the host stage of a picture goes (stderr, one line per build)
 struct PhaseTimer {
   bool on; std::chrono::steady_clock::time_point t0; char buf[512]; int len = 0;
-  PhaseTimer() : on(getenv("DE265HIP_BUILD_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
+  PhaseTimer() : on(d265_env("DE265HIP_BUILD_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
   void mark(const char* name) {
     if (!on) return;
     const auto t1 = std::chrono::steady_clock::now();
@@ -642,7 +643,7 @@ static std::mutex g_streams_mu;
 static std::map<int, DeviceStreams> g_streams;
 static bool own_streams()
 {
-  static const bool own = getenv("DE265HIP_OWN_STREAMS") && atoi(getenv("DE265HIP_OWN_STREAMS"));
+  static const bool own = d265_env("DE265HIP_OWN_STREAMS") && atoi(d265_env("DE265HIP_OWN_STREAMS"));
   return own;
 }
 // (caller holds g_streams_mu)
@@ -653,7 +654,7 @@ static DeviceStreams* device_streams(int device)
     DeviceStreams D;
     int lo = 0, hi = 0;
     if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return nullptr;      // (numerically: lowest, greatest priority)
-    if (const char* e = getenv("DE265HIP_FLAT_PRIORITIES")) if (atoi(e)) lo = hi = 0;
+    if (const char* e = d265_env("DE265HIP_FLAT_PRIORITIES")) if (atoi(e)) lo = hi = 0;
     bool ok = true;
     // The order of creation decides the dispatch pipe of each stream's hardware queue (pipe = number of the queue % 4).  Three
     // kernel streams on three pipes, and the fourth pipe for the scan streams: a kernel of the reconstruction with a grid of
@@ -663,7 +664,7 @@ static DeviceStreams* device_streams(int device)
     // there are only four) and two streams for copy-outs.  At most four new queues per priority (GPU_MAX_HW_QUEUES defaults to
     // 4 per priority pool; a stream beyond that re-uses a queue and the count would slip).  DE265HIP_SCAN_PIPES=0: the round's
     // first order (kernel x 4, scan x 4, upload x 2: a scan stream on every pipe).
-    const bool own_pipe = !(getenv("DE265HIP_SCAN_PIPES") && atoi(getenv("DE265HIP_SCAN_PIPES")) == 0);
+    const bool own_pipe = !(d265_env("DE265HIP_SCAN_PIPES") && atoi(d265_env("DE265HIP_SCAN_PIPES")) == 0);
     auto mk = [&](hipStream_t* st_, int prio) { if (ok) ok = hipStreamCreateWithPriority(st_, hipStreamNonBlocking, prio) == hipSuccess; };
     if (own_pipe) {
       mk(&D.kernel[0], 0); mk(&D.kernel[1], 0); mk(&D.kernel[2], 0); mk(&D.scan[0], hi);
@@ -675,7 +676,7 @@ static DeviceStreams* device_streams(int device)
       // 3 640-3 810 -> 3 910-3 960 pictures/s, three decoders.  Sixteen hardware queues in all; the device's scheduler began to
       // time-slice somewhere beyond that: DE265HIP_SCAN_STREAMS=4 asks for it (bench.py does for a single rank).
       // (opt-in: a process that creates queues of its own - RCCL does - may be closer to that edge than this library can see)
-      const int want_scan = getenv("DE265HIP_SCAN_STREAMS") ? atoi(getenv("DE265HIP_SCAN_STREAMS")) : 3;
+      const int want_scan = d265_env("DE265HIP_SCAN_STREAMS") ? atoi(d265_env("DE265HIP_SCAN_STREAMS")) : 3;
       if (want_scan >= 4) {
         mk(&D.pad[0], 0); mk(&D.pad[1], lo); mk(&D.pad[2], lo); mk(&D.scan[3], hi);
         D.n_scan = 4;
@@ -717,7 +718,7 @@ static hipStream_t pooled_out_stream(int device)
   // two copy-out streams; with the sixteen-queue layout (DE265HIP_SCAN_STREAMS=4) its two low-priority fillers as well: a
   // decoder's copy-outs wait for ITS pictures, and two decoders on one stream wait for each other's
   hipStream_t all[4] = { D->out[0], D->out[1], D->pad[1], D->pad[2] };
-  static const int want = getenv("DE265HIP_OUT_STREAMS") ? std::max(1, std::min(4, atoi(getenv("DE265HIP_OUT_STREAMS")))) : 4;
+  static const int want = d265_env("DE265HIP_OUT_STREAMS") ? std::max(1, std::min(4, atoi(d265_env("DE265HIP_OUT_STREAMS")))) : 4;
   const int n = std::min(want, (D->pad[1] && D->pad[2]) ? 4 : 2);
   return all[D->next_out++ % n];
 }
@@ -768,11 +769,11 @@ int de265hip_decoder_new(de265hip_decoder** out, int device)
   int prio_lo = 0, prio_hi = 0;
   HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi), DE265HIP_ERROR_INIT_FAILED);      // (numerically: lowest, greatest)
   d->prio_low = prio_lo; d->prio_high = prio_hi;
-  if (const char* e = getenv("DE265HIP_FLAT_PRIORITIES")) if (atoi(e)) d->prio_low = d->prio_high = 0;
+  if (const char* e = d265_env("DE265HIP_FLAT_PRIORITIES")) if (atoi(e)) d->prio_low = d->prio_high = 0;
   d->stream = pooled_kernel_stream(d->device, &d->kstream_index);
   if (!d->stream) { d->kstream_index = -1; HIPCHK(hipStreamCreateWithPriority(&d->stream, hipStreamNonBlocking, 0), DE265HIP_ERROR_INIT_FAILED); }
   d->n_copy_streams = 4;               // (pooled: every decoder takes turns on all four; 2 / 3 / 4: 2 570 / 2 770 / 2 900 pictures/s, three decoders)
-  if (const char* e = getenv("DE265HIP_COPY_STREAMS")) d->n_copy_streams = std::min((int)de265hip_decoder::kMaxCopyStreams, std::max(1, atoi(e)));
+  if (const char* e = d265_env("DE265HIP_COPY_STREAMS")) d->n_copy_streams = std::min((int)de265hip_decoder::kMaxCopyStreams, std::max(1, atoi(e)));
   d->streams_pooled = d->kstream_index >= 0;
   if (d->streams_pooled) d->n_copy_streams = std::min(d->n_copy_streams, 4);
   for (int i = 0; i < d->n_copy_streams; i++) {
@@ -794,18 +795,18 @@ int de265hip_decoder_new(de265hip_decoder** out, int device)
   ensure_used_units();
   HIPCHK(hipMalloc((void**)&d->d_used_units, sizeof(g_used_units)), DE265HIP_ERROR_OUT_OF_MEMORY);
   HIPCHK(hipMemcpy(d->d_used_units, g_used_units, sizeof(g_used_units), hipMemcpyHostToDevice), DE265HIP_ERROR_INIT_FAILED);
-  if (const char* e = getenv("DE265HIP_HOST_SCAN")) d->dev_scan = atoi(e) == 0;
-  const char* mode = getenv("DE265HIP_INTRA_MODE");
+  if (const char* e = d265_env("DE265HIP_HOST_SCAN")) d->dev_scan = atoi(e) == 0;
+  const char* mode = d265_env("DE265HIP_INTRA_MODE");
   d->intra_levels = mode && !strcmp(mode, "levels");
-  if (const char* dbg = getenv("DE265HIP_DEBUG")) d->dbg = atoi(dbg);
-  if (const char* e = getenv("DE265HIP_SEPARATE_BS")) d->separate_bs = atoi(e) != 0;
-  if (const char* e = getenv("DE265HIP_SAO_STRIPS")) d->sao_strips = atoi(e) != 0;
-  if (const char* e = getenv("DE265HIP_TWO_PASS_DEBLOCK")) d->two_pass_deblock = atoi(e) != 0;
-  if (const char* e = getenv("DE265HIP_LF_TILE")) d->lf_tile = atoi(e) != 0;
-  if (const char* e = getenv("DE265HIP_RESID16_BIG")) d->resid16_big = atoi(e) != 0;
-  if (const char* e = getenv("DE265HIP_RESID_ONE_LAUNCH")) d->resid_one_launch = atoi(e) != 0;
-  if (const char* rw = getenv("DE265HIP_RUN_WAVES")) d->run_waves = std::min(RUN_WAVES, std::max(1, atoi(rw)));
-  if (const char* e = getenv("DE265HIP_LANES")) {
+  if (const char* dbg = d265_env("DE265HIP_DEBUG")) d->dbg = atoi(dbg);
+  if (const char* e = d265_env("DE265HIP_SEPARATE_BS")) d->separate_bs = atoi(e) != 0;
+  if (const char* e = d265_env("DE265HIP_SAO_STRIPS")) d->sao_strips = atoi(e) != 0;
+  if (const char* e = d265_env("DE265HIP_TWO_PASS_DEBLOCK")) d->two_pass_deblock = atoi(e) != 0;
+  if (const char* e = d265_env("DE265HIP_LF_TILE")) d->lf_tile = atoi(e) != 0;
+  if (const char* e = d265_env("DE265HIP_RESID16_BIG")) d->resid16_big = atoi(e) != 0;
+  if (const char* e = d265_env("DE265HIP_RESID_ONE_LAUNCH")) d->resid_one_launch = atoi(e) != 0;
+  if (const char* rw = d265_env("DE265HIP_RUN_WAVES")) d->run_waves = std::min(RUN_WAVES, std::max(1, atoi(rw)));
+  if (const char* e = d265_env("DE265HIP_LANES")) {
     const int rc = de265hip_decoder_set_lanes(d, std::min(kMaxLanes, std::max(1, atoi(e))));
     if (rc) { de265hip_decoder_free(d); return rc; }
   }
@@ -835,10 +836,10 @@ int de265hip_decoder_set_lanes(de265hip_decoder* d, int n_lanes)
 void de265hip_decoder_free(de265hip_decoder* d)
 {
   if (!d) return;
-  if (getenv("DE265HIP_PIPE_TIMING") && d->n_scan_wait)
+  if (d265_env("DE265HIP_PIPE_TIMING") && d->n_scan_wait)
     fprintf(stderr, "de265hip decoder: %ld launches; ms per picture: waiting for the scan %.3f, run_picture (kernel launches) %.3f\n",
             d->n_scan_wait, 1e3 * d->t_scan_wait / d->n_scan_wait, 1e3 * d->t_run / d->n_scan_wait);
-  if (getenv("DE265HIP_PIPE_TIMING") && d->n_sec) {
+  if (d265_env("DE265HIP_PIPE_TIMING") && d->n_sec) {
     static const char* nm[8] = { "wait-arena-event", "event-pool", "memset", "memcpy-h2d", "stage-event", "motion+clear", "scan-launches", "uploaded-events" };
     fprintf(stderr, "de265hip enqueue sections, us per picture (max of one call):");
     for (int k = 0; k < 8; k++) fprintf(stderr, " %s %.1f (%.0f)", nm[k], 1e6 * d->t_sec[k] / d->n_sec, 1e6 * d->t_sec_max[k]);
@@ -1028,7 +1029,7 @@ static hipError_t upload_by_kernel(void* dev_dst, const void* pinned_src, size_t
 }
 static int upload_kernel_grid()
 {
-  static const int g = [] { const char* e = getenv("DE265HIP_UPLOAD"); if (!e || strncmp(e, "kernel", 6)) return 0; const int n = e[6] == ':' ? atoi(e + 7) : 16; return std::max(1, std::min(512, n)); }();
+  static const int g = [] { const char* e = d265_env("DE265HIP_UPLOAD"); if (!e || strncmp(e, "kernel", 6)) return 0; const int n = e[6] == ':' ? atoi(e + 7) : 16; return std::max(1, std::min(512, n)); }();
   return g;
 }
 
@@ -1102,8 +1103,8 @@ int de265hip_dpb_download_planes_async(de265hip_decoder* d, int slot, void* cons
   // DE265HIP_OUT_COPY: "deferred" (default): the output thread enqueues a DMA copy once the picture is done; "dma": hipMemcpyAsync
   // behind a stream wait, at once (the round-3 form: the runtime makes blit kernels of it); "kernel": k_copy_out behind a stream
   // wait; "none": the events without the bytes (experiments; results invalid)
-  static const char* mode_env = getenv("DE265HIP_OUT_COPY");
-  static const int out_grid = [] { const char* e = getenv("DE265HIP_OUT_GRID"); const int g = e ? atoi(e) : 16; return std::max(1, std::min(1024, g)); }();
+  static const char* mode_env = d265_env("DE265HIP_OUT_COPY");
+  static const int out_grid = [] { const char* e = d265_env("DE265HIP_OUT_GRID"); const int g = e ? atoi(e) : 16; return std::max(1, std::min(1024, g)); }();
   const bool use_kernel = mode_env && !strcmp(mode_env, "kernel");
   const bool deferred = !mode_env || !strcmp(mode_env, "deferred");
   static const bool no_copy = mode_env && !strcmp(mode_env, "none");
@@ -1457,8 +1458,8 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
   pic->level_start.assign(2, 0);
   if (!dev_scan) {
   // dependencies between intra TUs from the units each mode reads (DE265HIP_NO_MODE_DEPS: from every available unit)
-  const bool mode_deps = getenv("DE265HIP_NO_MODE_DEPS") == nullptr;
-  const bool merge_runs = getenv("DE265HIP_NO_MERGE") == nullptr;
+  const bool mode_deps = d265_env("DE265HIP_NO_MODE_DEPS") == nullptr;
+  const bool merge_runs = d265_env("DE265HIP_NO_MERGE") == nullptr;
   ensure_used_units();
   // ---- TU scan: tasks, intra availability, dependency levels, runs.  One linear pass over the TU records on flat,
   // reused arrays (BuildScratch): no allocation and no page fault in the steady state.
@@ -1541,7 +1542,7 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
   // the run decision of the Cb TU hold for it (run ids through SC.mirror), and the Cr cell map is never consulted.  A
   // descriptor that breaks the pattern (a Cr intra TU without its Cb twin right before it, or the other way round) makes the
   // build start over without the shortcut.  DE265HIP_NO_CR_MIRROR=1: always the long way (the arenas are identical).
-  const bool cr_mirror = cf != 0 && !g_no_cr_mirror && getenv("DE265HIP_NO_CR_MIRROR") == nullptr;
+  const bool cr_mirror = cf != 0 && !g_no_cr_mirror && d265_env("DE265HIP_NO_CR_MIRROR") == nullptr;
   int cbq_head = 0, cbq_n = 0;
   bool mirror_broken = false;
   SC.mirror.clear();
@@ -1832,20 +1833,20 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
   // (runs, run_deps, slots, run_tus: hoisted above)
 
   run_tus.reserve(SC.it.size());
-  const bool micro_off = getenv("DE265HIP_NO_MICRO") != nullptr;
-  const bool no_dense = getenv("DE265HIP_NO_DENSE") != nullptr;    // (not per run: getenv walks the whole environment)
-  const int micro_tus = getenv("DE265HIP_MICRO_TUS") ? std::min(16, atoi(getenv("DE265HIP_MICRO_TUS"))) : 16;   // MICRO_TUS of k_run
+  const bool micro_off = d265_env("DE265HIP_NO_MICRO") != nullptr;
+  const bool no_dense = d265_env("DE265HIP_NO_DENSE") != nullptr;    // (not per run: getenv walks the whole environment)
+  const int micro_tus = d265_env("DE265HIP_MICRO_TUS") ? std::min(16, atoi(d265_env("DE265HIP_MICRO_TUS"))) : 16;   // MICRO_TUS of k_run
   int64_t dbg_foreign = 0, dbg_w[4] = { 0, 0, 0, 0 };
 
 
-  const bool mailbox_on = getenv("DE265HIP_NO_MAILBOX") == nullptr;
+  const bool mailbox_on = d265_env("DE265HIP_NO_MAILBOX") == nullptr;
   // (mbx, mb_segs: hoisted above)  per run: (own mailbox, first dword of its segments); the segments
   mbx.assign(3 * rb.size(), 0xFFFFFFFFu); mb_segs.clear(); SC.mb_owner.clear();      // (+ first dword of its packets' ready epochs, phased hand-over)
   // Phased hand-over between luma runs (DE265HIP_NO_MB_PHASES=1: off): a publishing run stores each packet behind the barrier
   // epoch that completes the TU under it (its table of ready epochs), and a reading run fetches each neighbour sample at the
   // latest of at most four points of its chain that still precedes the first TU needing it - the right column's upper half
   // of the CTB to the left is there when that CTB is half done, its own lower half needs the lower half only later.
-  const bool mb_phases = mailbox_on && getenv("DE265HIP_NO_MB_PHASES") == nullptr;
+  const bool mb_phases = mailbox_on && d265_env("DE265HIP_NO_MB_PHASES") == nullptr;
   {
     for (auto& R : rb) { int l = 0; for (int e = R.dep_head; e >= 0; e = SC.dep_next[e]) l = std::max(l, rb[SC.dep_val[e]].level); R.level = l + 1; max_rl = std::max(max_rl, R.level); }
     std::vector<int>& order = SC.order; std::vector<int>& newidx = SC.newidx;
@@ -1857,7 +1858,7 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
     // micro runs: <= 16 TUs of <= 8x8 in a 32x32 box; 16x16 TUs too (DE265HIP_MICRO16=0: not) when the run's samples
     // fit the wavefront's residual slice (1024) and its window the wavefront's slice of the window array (k_tu.hip:
     // MICRO_P 56 columns from the 8-aligned left edge, MICRO_H 41 rows, 256 chunks of 8 samples)
-    const bool micro16 = !getenv("DE265HIP_MICRO16") || atoi(getenv("DE265HIP_MICRO16")) != 0;
+    const bool micro16 = !d265_env("DE265HIP_MICRO16") || atoi(d265_env("DE265HIP_MICRO16")) != 0;
     auto is_micro = [&](const RunB& R) {
       if (micro_off || R.n_tus > micro_tus || R.x1 - R.x0 > 32 || R.y1 - R.y0 > 32) return false;
       int samples = 0; bool big = false;
@@ -1882,7 +1883,7 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
     // Front runs: the micro runs of level 1 (no producer among the intra runs) - the first block of the run order.  They are
     // reconstructed by k_intra_front, one small workgroup each, ahead of k_run: no ticket, no flag, and the runs that read
     // from them do not list them as producers (the kernel boundary orders them).  DE265HIP_NO_FRONT=1: through k_run as all others.
-    const bool front_off = getenv("DE265HIP_NO_FRONT") != nullptr;
+    const bool front_off = d265_env("DE265HIP_NO_FRONT") != nullptr;
     n_front = 0;
     if (!front_off && !dec->intra_levels)
       while ((size_t)n_front < rb.size() && micro[order[n_front]] && rb[order[n_front]].level == 1) n_front++;
@@ -2181,7 +2182,7 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
               mb_segs[at + 2] = (uint32_t)polls[0] | ((uint32_t)polls[1] << 8) | ((uint32_t)polls[2] << 16) | ((uint32_t)polls[3] << 24);
             }
           }
-          if (getenv("DE265HIP_PRINT_PHASES") && R.c == 0 && k % 97 == 0) {
+          if (d265_env("DE265HIP_PRINT_PHASES") && R.c == 0 && k % 97 == 0) {
             fprintf(stderr, "run %zu (%d,%d) nl %d phased %d groups %d polls %d %d %d %d nsub %d | need_col:", k, (int)o.x0, (int)o.y0, nl, (int)phased, n_groups, polls[0], polls[1], polls[2], polls[3], nsub);
             if (phased) { for (int q = 0; q < 96; q += 4) fprintf(stderr, " %d", need_col[q]); fprintf(stderr, " | need_row:"); for (int q = 0; q < 100; q += 4) fprintf(stderr, " %d", need_row[q]); }
             fprintf(stderr, "\n");
@@ -2206,23 +2207,23 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
     for (auto& R : rb) width[R.level]++;
     if (max_rl >= 1) width[1] -= n_front;
     int widest = 0; for (int wv : width) widest = std::max(widest, wv);
-    const char* wenv = getenv("DE265HIP_RUN_WORKERS");
+    const char* wenv = d265_env("DE265HIP_RUN_WORKERS");
     // LDS-limited residency is 3 workgroups per CU (768); 2 per CU leave LDS for the kernels of the other GOP streams:
     // bench with 3 streams 5304 vs 5173 frames/s, one stream alone 2317 vs 2353
     int cap = wenv ? atoi(wenv) : 512;
     pic->n_batches = (int)(slots.size() / RUN_TICKET_SLOTS);
-    const char* menv = getenv("DE265HIP_RUN_WORKER_PCT");     // workers as a percentage of the widest level (experiments)
+    const char* menv = d265_env("DE265HIP_RUN_WORKER_PCT");     // workers as a percentage of the widest level (experiments)
     const int pct = menv ? atoi(menv) : 125;
     pic->n_workers = std::min(pic->n_batches, std::max(64, std::min(cap, (int)((int64_t)widest * pct / 100))));
     // direct mode (see k_run): when the picture is wide rather than deep - most of its runs sit in its widest level
     // (a B picture: isolated intra CUs, 8 levels; an I picture: 126+ levels of ~100 runs)
-    const char* denv = getenv("DE265HIP_RUN_DIRECT");
+    const char* denv = d265_env("DE265HIP_RUN_DIRECT");
     // Measured (4K Main10, tools/exp/ab_env.sh): a B picture alone 96-104 us either way (its time is the 7-level chain of
     // run hand-overs, not the ticket loop), but with three GOP streams in flight direct mode for B pictures costs 6 % and
     // for all pictures 23 % (6 390 -> 6 010 -> 4 890 frames/s): thousands of resident workgroups hold LDS the other
     // streams' kernels need.  Off unless asked for.
     pic->run_direct = denv ? atoi(denv) != 0 : false;
-    if (getenv("DE265HIP_PRINT_CRIT")) {               // diagnostic: run counts per level, longest path through the run DAG
+    if (d265_env("DE265HIP_PRINT_CRIT")) {               // diagnostic: run counts per level, longest path through the run DAG
       std::vector<int> wm(max_rl + 2, 0), wo(max_rl + 2, 0);
       for (size_t i = 0; i < rb.size(); i++) (SC.micro[i] ? wm : wo)[rb[i].level]++;
       fprintf(stderr, "de265hip runs %zu (front %d); per level (micro/ordinary):", rb.size(), n_front);
@@ -2255,7 +2256,7 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
     }
     // tickets per draw: 1 (DE265HIP_TICKET_BATCH for experiments: several per draw relieve the single device-scope
     // counter, ~12 ns per add, but serialise dependants: +46 % at 4 on a 4K B picture)
-    const char* benv = getenv("DE265HIP_TICKET_BATCH");
+    const char* benv = d265_env("DE265HIP_TICKET_BATCH");
     pic->ticket_batch = benv ? std::max(1, std::min(64, atoi(benv))) : 1;
   }
   }                                                     // (!dev_scan)
@@ -2267,7 +2268,7 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
   pt.mark("l0");
   // ---- MC tasks: resolve references, bi->uni shortcut, split into <=16x16 tiles
   std::vector<McTask>& mcs = SC.mcs; mcs.clear();
-  const char* mc_env = getenv("DE265HIP_MC_PATHS");
+  const char* mc_env = d265_env("DE265HIP_MC_PATHS");
   const int mc_paths = mc_env ? atoi(mc_env) : 3;   // bit 0: the quad form (mc_micro_body), bit 1: the chunk form (mc_chunk_body) (experiments)
   const bool mc_all = cf == 1 && mc_paths != 0;        // k_mc_all (tiles, chunks and quads in bands, one launch); else k_mc over 16x16 tiles
   int64_t alg_mc = 0;
@@ -2536,13 +2537,13 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
     SP.ctbs_w = g.ctbs_w; SP.ctbs_h = g.ctbs_h; SP.n_ctbs = d->n_ctbs;
     for (int c = 0; c < 3; c++) { SP.map_w[c] = c ? (cwid + 3) / 4 : g.w4; SP.map_h[c] = c ? (chei + 3) / 4 : g.h4; }
     SP.n_tus = d->n_tus; SP.n_coeffs = d->n_coeffs; SP.bppY = (int)px_bytes(p.bit_depth_luma); SP.bppC = (int)px_bytes(p.bit_depth_chroma);
-    const bool mailbox_on = getenv("DE265HIP_NO_MAILBOX") == nullptr;
-    SP.flags = (p.constrained_intra_pred_flag ? SCANF_CIP : 0) | (getenv("DE265HIP_NO_MODE_DEPS") ? 0 : SCANF_MODE_DEPS) | (getenv("DE265HIP_NO_MERGE") ? 0 : SCANF_MERGE) |
-               (mailbox_on ? SCANF_MAILBOX : 0) | ((mailbox_on && !getenv("DE265HIP_NO_MB_PHASES")) ? SCANF_MB_PHASES : 0) | (getenv("DE265HIP_NO_MICRO") ? SCANF_MICRO_OFF : 0) |
-               (getenv("DE265HIP_NO_DENSE") ? SCANF_NO_DENSE : 0) | ((!getenv("DE265HIP_MICRO16") || atoi(getenv("DE265HIP_MICRO16")) != 0) ? SCANF_MICRO16 : 0) |
-               (getenv("DE265HIP_NO_FRONT") ? SCANF_FRONT_OFF : 0) | (p.implicit_rdpcm_enabled_flag ? SCANF_IMPLICIT_RDPCM : 0) |
+    const bool mailbox_on = d265_env("DE265HIP_NO_MAILBOX") == nullptr;
+    SP.flags = (p.constrained_intra_pred_flag ? SCANF_CIP : 0) | (d265_env("DE265HIP_NO_MODE_DEPS") ? 0 : SCANF_MODE_DEPS) | (d265_env("DE265HIP_NO_MERGE") ? 0 : SCANF_MERGE) |
+               (mailbox_on ? SCANF_MAILBOX : 0) | ((mailbox_on && !d265_env("DE265HIP_NO_MB_PHASES")) ? SCANF_MB_PHASES : 0) | (d265_env("DE265HIP_NO_MICRO") ? SCANF_MICRO_OFF : 0) |
+               (d265_env("DE265HIP_NO_DENSE") ? SCANF_NO_DENSE : 0) | ((!d265_env("DE265HIP_MICRO16") || atoi(d265_env("DE265HIP_MICRO16")) != 0) ? SCANF_MICRO16 : 0) |
+               (d265_env("DE265HIP_NO_FRONT") ? SCANF_FRONT_OFF : 0) | (p.implicit_rdpcm_enabled_flag ? SCANF_IMPLICIT_RDPCM : 0) |
                (p.transform_skip_rotation_enabled_flag ? SCANF_ROTATION : 0) | (dec->drop_producer ? SCANF_DROP_PRODUCER : 0) | SCANF_CHECK_POS;
-    SP.micro_tus = getenv("DE265HIP_MICRO_TUS") ? std::min(16, atoi(getenv("DE265HIP_MICRO_TUS"))) : 16;
+    SP.micro_tus = d265_env("DE265HIP_MICRO_TUS") ? std::min(16, atoi(d265_env("DE265HIP_MICRO_TUS"))) : 16;
     SP.run_waves = dec->run_waves;
     SP.cap_runs = (uint32_t)d->n_tus;
     SP.cap_deps = (uint32_t)std::min<int64_t>(33 * (int64_t)d->n_tus, 5 * total_samples / 16 + d->n_tus) + 64;
@@ -2634,7 +2635,7 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
     pic->cap_resid = cap_resid;
     if (dec->dry && dec->dry_scan) scan_host_run(SP, SB, SL, base, cap_resid);      // the CPU rehearsal of the passes (tests only)
   }
-  if (dec->dry && !getenv("DE265HIP_DRY_NO_HASH") && !dev_scan) { // FNV-1a over everything the device would receive (tools/exp/build_hash.py)
+  if (dec->dry && !d265_env("DE265HIP_DRY_NO_HASH") && !dev_scan) { // FNV-1a over everything the device would receive (tools/exp/build_hash.py)
     uint64_t hsh = 1469598103934665603ull;
     auto mix = [&](const void* ptr, size_t n) { const uint8_t* b = (const uint8_t*)ptr; for (size_t i = 0; i < n; i++) { hsh ^= b[i]; hsh *= 1099511628211ull; } };
     const size_t offs[] = { o_tus, o_cval, o_cpos, o_scal, o_mc, o_pcm, o_pcms, o_sl, o_ctb, o_tile, o_sao, o_flags, o_qp, o_mot, o_runs, o_rdeps, o_rtus, o_slots, o_l0, upload_bytes };
@@ -2755,8 +2756,8 @@ int de265hip_picture_enqueue_batch(de265hip_picture** pics, int n)
     const int m = std::min(SCAN_BATCH, n - i0);
     hipStream_t cs;
     { std::lock_guard<std::mutex> lk(dec->mu); cs = dec->copy_streams[dec->copy_turn++ % (uint64_t)dec->n_copy_streams]; reap_arenas(dec); }
-    static const int own_prep = getenv("DE265HIP_OWN_PREP") ? atoi(getenv("DE265HIP_OWN_PREP")) : 1;
-    static const int run2_lane0 = getenv("DE265HIP_SCAN_RUN2_LANE0") ? atoi(getenv("DE265HIP_SCAN_RUN2_LANE0")) : 0;
+    static const int own_prep = d265_env("DE265HIP_OWN_PREP") ? atoi(d265_env("DE265HIP_OWN_PREP")) : 1;
+    static const int run2_lane0 = d265_env("DE265HIP_SCAN_RUN2_LANE0") ? atoi(d265_env("DE265HIP_SCAN_RUN2_LANE0")) : 0;
     ScanBatch J; J.n = 0; J.pad = run2_lane0 ? 1 : 0;      // (pad bit 0: the mailbox readers' pass on one lane, scan_core.h's loop: the parity variant)
     PrepBatch PJ; PJ.n = 0; PJ.pad = 0;
     de265hip_picture* done[SCAN_BATCH]; int n_done = 0;
@@ -2875,7 +2876,7 @@ int de265hip_debug_build_host_only_ex(const de265hip_picture_desc* d, int reps, 
   if (keep) *keep = nullptr;
   de265hip_decoder* dec = new de265hip_decoder();
   dec->dry = true; dec->dev_scan = mode != 0; dec->dry_scan = mode == 2;
-  if (getenv("DE265HIP_TEST_DROP_PRODUCER")) dec->drop_producer = true;      // (dry decoders only: the equivalence test of the fault injection)
+  if (d265_env("DE265HIP_TEST_DROP_PRODUCER")) dec->drop_producer = true;      // (dry decoders only: the equivalence test of the fault injection)
   for (auto& sl : dec->slots) { sl.valid = true; sl.w = d->params.width; sl.h = d->params.height; sl.bdY = d->params.bit_depth_luma; sl.bdC = d->params.bit_depth_chroma; sl.cf = d->params.chroma_format_idc; }
   int rc = 0;
   for (int i = 0; i < reps && !rc; i++) {
@@ -2927,14 +2928,14 @@ static int finish_scan(de265hip_picture* pic)
   pic->n_runs = (int)K->n_runs; pic->n_front = (int)K->n_front; pic->n_batches = (int)K->n_batches; pic->n_tus = (int)K->n_tasks;
   {
     // worker count = widest dependency level (more workers would only wait), within [64, 2 per CU] (see the host scan)
-    const char* wenv = getenv("DE265HIP_RUN_WORKERS");
+    const char* wenv = d265_env("DE265HIP_RUN_WORKERS");
     const int cap = wenv ? atoi(wenv) : 512;
-    const char* menv = getenv("DE265HIP_RUN_WORKER_PCT");
+    const char* menv = d265_env("DE265HIP_RUN_WORKER_PCT");
     const int pct = menv ? atoi(menv) : 125;
     pic->n_workers = std::min(pic->n_batches, std::max(64, std::min(cap, (int)((int64_t)K->widest * pct / 100))));
-    const char* denv = getenv("DE265HIP_RUN_DIRECT");
+    const char* denv = d265_env("DE265HIP_RUN_DIRECT");
     pic->run_direct = denv ? atoi(denv) != 0 : false;
-    const char* benv = getenv("DE265HIP_TICKET_BATCH");
+    const char* benv = d265_env("DE265HIP_TICKET_BATCH");
     pic->ticket_batch = benv ? std::max(1, std::min(64, atoi(benv))) : 1;
   }
   pic->stats.n_tu_tasks = pic->n_tus; pic->stats.n_runs = pic->n_runs; pic->stats.n_run_levels = (int)K->max_rl;

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "scan.h"
+#include "env.h"
 
 namespace d265 {
 
@@ -1376,7 +1377,7 @@ hipError_t scan_enqueue_batch(hipStream_t st, const ScanBatch& J)
   // pictures' per-CTB passes (8 160 one-wavefront workgroups) for most of its run time.  The kernel stream of some decoder
   // lives on the same pipe (there are four pipes): its next kernel waited behind the scan's.  (DE265HIP_SCAN_GRID: the
   // wavefronts of a launch, all pictures of the batch together.)
-  static const int scan_grid = getenv("DE265HIP_SCAN_GRID") ? std::max(64, atoi(getenv("DE265HIP_SCAN_GRID"))) : 1024;
+  static const int scan_grid = d265_env("DE265HIP_SCAN_GRID") ? std::max(64, atoi(d265_env("DE265HIP_SCAN_GRID"))) : 1024;
   const unsigned per_pic = (unsigned)std::max(32, scan_grid / (int)ny);
   if (max_tus > 0) hipLaunchKernelGGL(k_scan_tus, dim3(std::min<unsigned>((max_tus + 255) / 256, per_pic), ny), dim3(256), 0, st, J);
   if (max_tus > 0) {

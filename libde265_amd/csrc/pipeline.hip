@@ -7,6 +7,7 @@
 // threads and the ordering rule: pictures are BUILT concurrently and LAUNCHED in submission order (a picture's kernels read the
 // DPB slots its references were launched into).  Host-only code: no kernel lives here.
 #include "../../include/de265_hip.h"
+#include "env.h"
 
 #include <array>
 #include <chrono>
@@ -109,8 +110,8 @@ void launcher(de265hip_pipeline* p)
   // pictures of the chains (upload + scan launched together) whose scans have not reported yet: the last picture of each
   std::vector<de265hip_picture*> open_chains;
   std::vector<double> open_since;
-  static const bool in_order = !getenv("DE265HIP_PIPE_ANY_ORDER");
-  static const int poll_us = getenv("DE265HIP_PIPE_POLL_US") ? std::max(1, atoi(getenv("DE265HIP_PIPE_POLL_US"))) : 50;
+  static const bool in_order = !d265_env("DE265HIP_PIPE_ANY_ORDER");
+  static const int poll_us = d265_env("DE265HIP_PIPE_POLL_US") ? std::max(1, atoi(d265_env("DE265HIP_PIPE_POLL_US"))) : 50;
   for (;;) {
     de265hip_pipeline::Built todo; bool have_enq = false, have_launch = false;
     de265hip_picture* enq_pic[8]; uint64_t enq_tk[8]; int n_enq = 0;
@@ -175,7 +176,7 @@ void launcher(de265hip_pipeline* p)
     if (have_launch) {
       int r = todo.rc;
       uint64_t copy_out_id = 0;
-      static const bool no_run = getenv("DE265HIP_PIPE_NO_RUN") != nullptr;      // (experiment: builds, uploads and scans only)
+      static const bool no_run = d265_env("DE265HIP_PIPE_NO_RUN") != nullptr;      // (experiment: builds, uploads and scans only)
       if (!r && !no_run) r = de265hip_picture_run(p->dec, todo.pic, DE265HIP_STAGE_FINAL);
       if (!r && (todo.job.plane[0] || todo.job.plane[1] || todo.job.plane[2]))
         r = de265hip_dpb_download_planes_async(p->dec, todo.job.slot, todo.job.plane, todo.job.stride, &copy_out_id);
@@ -201,11 +202,11 @@ int de265hip_pipeline_new(de265hip_pipeline** out, de265hip_decoder* dec, int n_
   if (!out || !dec || n_workers < 1 || n_workers > 16) return DE265HIP_ERROR_PARAMETER_OUT_OF_RANGE;
   de265hip_pipeline* p = new (std::nothrow) de265hip_pipeline();
   if (!p) return DE265HIP_ERROR_OUT_OF_MEMORY;
-  p->dec = dec; p->n_workers = n_workers; p->timing = getenv("DE265HIP_PIPE_TIMING") != nullptr; p->tracing = getenv("DE265HIP_PIPE_TRACE") != nullptr;
+  p->dec = dec; p->n_workers = n_workers; p->timing = d265_env("DE265HIP_PIPE_TIMING") != nullptr; p->tracing = d265_env("DE265HIP_PIPE_TRACE") != nullptr;
   p->window = 4 * n_workers + 4;
-  if (const char* w = getenv("DE265HIP_PIPE_WINDOW")) p->window = std::max(1, atoi(w));
-  if (const char* b = getenv("DE265HIP_PIPE_BATCH")) p->batch = std::min(8, std::max(1, atoi(b)));
-  if (const char* c = getenv("DE265HIP_PIPE_CHAINS")) p->chains = std::min(8, std::max(1, atoi(c)));
+  if (const char* w = d265_env("DE265HIP_PIPE_WINDOW")) p->window = std::max(1, atoi(w));
+  if (const char* b = d265_env("DE265HIP_PIPE_BATCH")) p->batch = std::min(8, std::max(1, atoi(b)));
+  if (const char* c = d265_env("DE265HIP_PIPE_CHAINS")) p->chains = std::min(8, std::max(1, atoi(c)));
   p->window = std::max(p->window, p->chains * p->batch + 2 * n_workers + 4);       // (the chains full, every worker busy, a few to spare)
   for (int i = 0; i < n_workers; i++) p->th.emplace_back(worker, p);
   p->launcher_th = std::thread(launcher, p);

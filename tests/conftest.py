@@ -2,6 +2,9 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the library's tuning / experiment switches (DE265HIP_*; csrc/env.h) are read only in a process that asks for them: the
+# schedule variants and fault injections of these tests are such switches (child processes inherit the variable)
+os.environ.setdefault("DE265HIP_TUNING", "1")
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
     if p not in sys.path:
         sys.path.insert(0, p)

@@ -1,6 +1,8 @@
 """GPU parity tests proper: whole-picture reconstruction through the C ABI
 (de265hip_picture_build/run) against the CPU oracle on the same seeded
 synthetic command buffers.  Bit-exact at every stage."""
+import os
+
 import numpy as np
 import pytest
 
@@ -723,6 +725,48 @@ def test_pipeline_builds_concurrently_and_launches_in_order(dec):
         pipe.close()
         for p in pins:
             p.free()
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_UNGATED_SCRIPT = r"""
+import os, sys
+sys.path[:0] = [ROOT, ROOT + "/oracle", ROOT + "/tools"]
+import torch, numpy as np
+import pysynth, pyoracle
+from libde265_amd import backend
+w, h, bd = 352, 288, 10
+refs = {0: pysynth.fill_planes(w, h, bd, 21), 1: pysynth.fill_planes(w, h, bd, 22)}
+sp = pysynth.SynthPicture(pysynth.default_config(w, h, bd, 0, seed=4242))
+exp = pyoracle.alloc_planes(w, h, bd)
+pyoracle.reconstruct(sp.desc, sp.order, refs, exp)
+dec = backend.Decoder()
+for s_, pl in refs.items():
+    dec.dpb_alloc(s_, w, h, bd); dec.upload(s_, pl)
+dec.dpb_alloc(2, w, h, bd)
+pipe = backend.Pipeline(dec, 2)
+pin = backend.PinnedPlanes(w, h, bd)
+t = pipe.submit_desc(2, sp.desc, pin)
+pipe.wait(t)
+ok = all(np.array_equal(g, e) for g, e in zip(pin.planes, exp))
+pipe.drain(); pipe.close(); pin.free(); dec.close()
+print("UNGATED_OK" if ok else "UNGATED_MISMATCH")
+"""
+
+
+def test_switches_are_ignored_without_the_tuning_gate():
+    """csrc/env.h: the DE265HIP_* switches - some of which make a decoder's results invalid - are honoured only in a process that
+    sets DE265HIP_TUNING=1.  A process WITHOUT it, with three such switches in its environment, decodes and delivers a picture
+    exactly as the oracle computes it (with the gate open the same switches skip the reconstruction and the copy-out)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k != "DE265HIP_TUNING"}
+    env.update(DE265HIP_PIPE_NO_RUN="1", DE265HIP_OUT_COPY="none", DE265HIP_NO_FRONT="1")
+    script = "ROOT = %r\n" % ROOT + _UNGATED_SCRIPT
+    r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+    assert "UNGATED_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+    env["DE265HIP_TUNING"] = "1"                            # ... and with the gate open they do what they say
+    r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+    assert "UNGATED_MISMATCH" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
 
 def test_pipeline_output_queue_deeper_than_the_dpb_cycle(dec):

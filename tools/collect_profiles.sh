@@ -1,4 +1,5 @@
 #!/bin/bash
+export DE265HIP_TUNING=1      # the library reads its DE265HIP_* switches only in a process that sets this (csrc/env.h)
 # Collects the round's profiling evidence on the GPU box (run through gpurun from the repo root):
 #   tools/collect_profiles.sh <tag>        e.g. r01_d
 # 1. rocprofv3 --kernel-trace --stats of the default bench (3 GOP streams) and of --streams 1

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DE265HIP_TUNING=1      # the library reads its DE265HIP_* switches only in a process that sets this (csrc/env.h)
 # SURVEY 8(f1)+(f2)+(f3) end to end on the GPU box: the SAME libde265 binary (oracle/_ref/f1_dec) decodes the SAME synthetic
 # 4K Main10 / 1080p bitstreams (oracle/_ref/f2_writer) (a) entirely on the host CPU, 1 and N worker threads, and (b) with every
 # reconstruction call offloaded to the MI355X, synchronous and pipelined (F1_PIPELINE=n: n host worker threads between parser and device).  Pictures/s of the decode loop, no

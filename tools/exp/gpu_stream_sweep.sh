@@ -1,4 +1,5 @@
 #!/bin/bash
+export DE265HIP_TUNING=1      # the library reads its DE265HIP_* switches only in a process that sets this (csrc/env.h)
 # GPU box: many small synthetic streams (oracle/_ref/f2_writer, all features, several configurations x seeds) decoded by the patched
 # libde265 on the CPU and with the MI355X back end (synchronous and pipelined with worker threads); outputs must be byte-identical.
 #   tools/exp/gpu_stream_sweep.sh [seeds_per_config] [out_file] [config_file: one f2_writer argument list per line; default: the list below]

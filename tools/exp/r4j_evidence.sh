@@ -1,4 +1,5 @@
 #!/bin/bash
+export DE265HIP_TUNING=1      # the library reads its DE265HIP_* switches only in a process that sets this (csrc/env.h)
 # round 4: the cheap evidence items (f4 bench line + kernel stats, end-to-end stream bench, F1_PROFILE, two-rank rehearsal)
 export TMPDIR=/tmp
 O=gpurun_out/r4j; mkdir -p $O

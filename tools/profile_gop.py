@@ -3,6 +3,7 @@
     python tools/profile_gop.py [--pictures 4] [--reps 5]"""
 import argparse
 import os
+os.environ.setdefault("DE265HIP_TUNING", "1")      # (the library reads its DE265HIP_* switches only then: csrc/env.h)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -3,6 +3,7 @@
     python tools/time_build.py              on the GPU box: the real call (host stage + staging + async upload)
     python tools/time_build.py --host-only  anywhere: de265hip_debug_build_host_only (no HIP call at all)"""
 import os
+os.environ.setdefault("DE265HIP_TUNING", "1")      # (the library reads its DE265HIP_* switches only then: csrc/env.h)
 import sys
 import time
 
