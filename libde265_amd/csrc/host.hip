@@ -707,7 +707,10 @@ static hipStream_t pooled_scan_stream(int device)
   if (own_streams()) return nullptr;
   std::lock_guard<std::mutex> lk(g_streams_mu);
   DeviceStreams* D = device_streams(device);
-  return D ? D->scan[D->next_scan++ % D->n_scan] : nullptr;
+  if (!D) return nullptr;
+  static const bool io_on_scan_pipe = d265_env("DE265HIP_UPLOAD_PIPE") && atoi(d265_env("DE265HIP_UPLOAD_PIPE")) == 3;
+  const int n = (io_on_scan_pipe && D->n_scan == 4) ? 3 : D->n_scan;
+  return D->scan[D->next_scan++ % n];
 }
 static hipStream_t pooled_out_stream(int device)
 {
@@ -727,7 +730,13 @@ static hipStream_t pooled_upload_stream(int device)
   if (own_streams()) return nullptr;
   std::lock_guard<std::mutex> lk(g_streams_mu);
   DeviceStreams* D = device_streams(device);
-  return D ? D->upload[D->next_upload++ % kUploadStreams] : nullptr;
+  if (!D) return nullptr;
+  // (experiments, DESIGN §10 "pipes": DE265HIP_UPLOAD_PIPE=2: both upload streams on the third kernel stream's pipe; =3: the fourth
+  //  queue of the scan pipe carries the uploads, three scan streams)
+  static const int up_pipe = d265_env("DE265HIP_UPLOAD_PIPE") ? atoi(d265_env("DE265HIP_UPLOAD_PIPE")) : -1;
+  if (up_pipe == 2 && D->spare && D->pad[2]) return (D->next_upload++ & 1) ? D->pad[2] : D->spare;
+  if (up_pipe == 3 && D->n_scan == 4) return D->scan[3];
+  return D->upload[D->next_upload++ % kUploadStreams];
 }
 
 struct ArenaLayout {

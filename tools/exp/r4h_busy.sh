@@ -1,7 +1,7 @@
 #!/bin/bash
 export TMPDIR=/tmp
 rm -rf gpurun_out/r4h_prof
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/r4h_prof -o b -- python3 bench.py --streams 3 --steps 12 --warmup 2 --host-threads 9 --no-cpu-baseline --no-copy-out > gpurun_out/r4h_prof.json 2> gpurun_out/r4h_prof.err
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/r4h_prof -o b -- python3 bench.py --streams 3 --steps 12 --warmup 2 --host-threads 9 --no-cpu-baseline --no-copy-out $BUSY_EXTRA > gpurun_out/r4h_prof.json 2> gpurun_out/r4h_prof.err
 python3 - <<'PY'
 import csv,collections,glob,json
 f=glob.glob('gpurun_out/r4h_prof/**/b_kernel_trace.csv',recursive=True)[0]
