@@ -48,7 +48,7 @@ def build(force=False, verbose=False):
             list(ex.map(cc, jobs))
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or not os.path.exists(SO):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-o", SO] + objs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-o", SO] + objs + ["-L/opt/rocm/lib", "-lhsa-runtime64"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

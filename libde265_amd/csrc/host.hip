@@ -21,6 +21,8 @@
 #include <array>
 #include <map>
 
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
 #include "kernels.h"
 #include "env.h"
 #include "scan.h"
@@ -81,7 +83,8 @@ struct ArenaBuf { void* ptr = nullptr; size_t bytes = 0; hipEvent_t last_use = n
                   uint64_t release_seq = 0; }; // the decoder's count of released arenas when this one came back to the pool
 // Pinned staging buffer the host stage assembles the command buffers in.  copied: recorded on the copy stream
 // behind the upload; the buffer is handed out again once it has completed.
-struct StageBuf { void* ptr = nullptr; size_t bytes = 0; hipEvent_t copied = nullptr; int state = 0; uint64_t owner = 0; };   // state: 0 idle, 1 being filled by a host thread, 2 upload in flight
+struct StageBuf { void* ptr = nullptr; size_t bytes = 0; hipEvent_t copied = nullptr; int state = 0; uint64_t owner = 0;
+                  uint64_t sig = 0; };      // sig: (state 2) the completion signal of an upload issued through the HSA runtime (0: `copied` tells)   // state: 0 idle, 1 being filled by a host thread, 2 upload in flight
 
 }  // namespace
 
@@ -111,6 +114,7 @@ struct de265hip_decoder {
   std::deque<OutJobRec> out_jobs;
   std::thread out_thread; bool out_thread_started = false, out_stop = false, out_failed = false;
   std::vector<hipEvent_t> out_events;           // (guarded by mu) blocking-sync events, re-used
+  std::vector<uint64_t> free_sigs;              // (guarded by mu) completion signals of uploads through the HSA runtime, re-used
   std::mutex mu;                      // guards live, the two pools and slot allocation: build()/free() may come from several host threads
   std::vector<de265hip_picture*> live;        // pictures built on this decoder and not yet freed (decoder_free orphans them)
   std::vector<ArenaBuf> free_arenas;
@@ -234,6 +238,7 @@ struct de265hip_picture {
   // another thread than the host stage: the pipeline issues every HIP call of a decoder from one thread)
   struct Enq {
     bool pending = false, uploaded_by_builder = false;
+    uint64_t up_sig = 0;                      // upload issued through the HSA runtime: its completion signal (hsa_signal_t::handle)
     uint8_t* host_base = nullptr; size_t upload_bytes = 0; hipEvent_t stage_event = nullptr;
     size_t o_sync = 0, clear_bytes = 0, o_mot = 0, o_pus = 0, o_sl = 0, o_l0 = 0, o_l0x = 0, o_cpos = 0, nblk = 0;
     bool mot_given = true, check_on_device = false;
@@ -582,7 +587,8 @@ int acquire_stage(de265hip_decoder* dec, size_t bytes, int* index)
   };
   int best = pick();
   if (best < 0) {
-    for (auto& b : dec->stage_pool) if (b.state == 2 && hipEventQuery(b.copied) == hipSuccess) b.state = 0;
+    for (auto& b : dec->stage_pool)
+      if (b.state == 2 && (b.sig ? hsa_signal_load_scacquire(hsa_signal_t{ b.sig }) < 1 : hipEventQuery(b.copied) == hipSuccess)) b.state = 0;
     best = pick();
   }
   if (best < 0) {
@@ -739,6 +745,59 @@ static hipStream_t pooled_upload_stream(int device)
   return D->upload[D->next_upload++ % kUploadStreams];
 }
 
+// ---- uploads through the HSA runtime (the DMA engines, no compute queue).  hipMemcpyAsync on an upload stream puts barrier
+// packets around every copy into that stream's hardware queue, and a kernel stream whose queue shares the dispatch pipe with it
+// runs its kernels a third slower.  hsa_amd_memory_async_copy has no queue: a copy and its completion signal.
+struct HsaDev { bool tried = false, ok = false; hsa_agent_t gpu{}, cpu{}; };
+static std::map<int, HsaDev> g_hsa;
+struct HsaFind { uint32_t domain, bdf; HsaDev* out; bool have_cpu; };
+static hsa_status_t hsa_agent_cb(hsa_agent_t a, void* p)
+{
+  HsaFind* f = static_cast<HsaFind*>(p);
+  hsa_device_type_t t;
+  if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+  if (t == HSA_DEVICE_TYPE_CPU && !f->have_cpu) { f->out->cpu = a; f->have_cpu = true; }
+  if (t == HSA_DEVICE_TYPE_GPU) {
+    uint32_t bdf = 0, dom = 0;
+    (void)hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf);
+    (void)hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &dom);
+    if (bdf == f->bdf && dom == f->domain) { f->out->gpu = a; f->out->ok = true; }
+  }
+  return HSA_STATUS_SUCCESS;
+}
+// (the HIP device's agent by its PCI address; nullptr: no such agent, and the uploads go through hipMemcpyAsync as before)
+static HsaDev* hsa_dev(int device)
+{
+  std::lock_guard<std::mutex> lk(g_streams_mu);
+  HsaDev& H = g_hsa[device];
+  if (!H.tried) {
+    H.tried = true;
+    char bus[64] = "";
+    unsigned dom = 0, b = 0, dv = 0, fn = 0;
+    if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) == hipSuccess && sscanf(bus, "%x:%x:%x.%x", &dom, &b, &dv, &fn) == 4 &&
+        hsa_init() == HSA_STATUS_SUCCESS) {
+      HsaFind f{ dom, (b << 8) | (dv << 3) | fn, &H, false };
+      (void)hsa_iterate_agents(hsa_agent_cb, &f);
+      H.ok = H.ok && f.have_cpu;
+    }
+    (void)hipGetLastError();
+  }
+  return H.ok ? &H : nullptr;
+}
+static bool uploads_by_hsa()
+{
+  static const bool off = d265_env("DE265HIP_UPLOAD") && !strcmp(d265_env("DE265HIP_UPLOAD"), "stream");      // the round's earlier form
+  return !off;
+}
+// wait for an upload's signal; false: the copy failed (the runtime sets the signal negative)
+static bool hsa_upload_wait(uint64_t sig)
+{
+  if (!sig) return true;
+  hsa_signal_value_t v;
+  while ((v = hsa_signal_wait_scacquire(hsa_signal_t{ sig }, HSA_SIGNAL_CONDITION_LT, 1, 2000000000ull, HSA_WAIT_STATE_BLOCKED)) >= 1) {}
+  return v == 0;
+}
+
 struct ArenaLayout {
   size_t total = 0;
   size_t add(size_t bytes) { size_t o = total; total = (total + bytes + 255) & ~(size_t)255; return o; }
@@ -860,6 +919,7 @@ void de265hip_decoder_free(de265hip_decoder* d)
     d->out_thread.join();
   }
   for (hipEvent_t e : d->out_events) (void)hipEventDestroy(e);
+  for (uint64_t sg : d->free_sigs) (void)hsa_signal_destroy(hsa_signal_t{ sg });
   for (int i = 0; i < 2; i++) if (d->upload_streams[i]) (void)hipStreamSynchronize(d->upload_streams[i]);
   for (int i = 0; i < d->n_copy_streams; i++) if (d->copy_streams[i]) (void)hipStreamSynchronize(d->copy_streams[i]);
   (void)sync_all_lanes(d);
@@ -1339,8 +1399,13 @@ int de265hip_dpb_copy(de265hip_decoder* sd, int ss, de265hip_decoder* dd, int ds
 void de265hip_picture_free(de265hip_picture* p)
 {
   if (!p) return;
+  if (p->enq.up_sig) (void)hsa_upload_wait(p->enq.up_sig);      // (freed before it was enqueued: the DMA engine may still be writing its arena)
   if (de265hip_decoder* dec = p->dec) {                   // (an orphan has no device side left: only the handle goes)
     std::lock_guard<std::mutex> lk(dec->mu);
+    if (p->enq.up_sig) {
+      for (auto& b : dec->stage_pool) if (b.sig == p->enq.up_sig) { b.sig = 0; if (b.state == 2) b.state = 0; }      // (it has arrived: the staging buffer is free)
+      dec->free_sigs.push_back(p->enq.up_sig); p->enq.up_sig = 0;
+    }
     dec->live.erase(std::remove(dec->live.begin(), dec->live.end(), p), dec->live.end());
     // no synchronisation: the arena goes back to the pool behind an event on the decoder's stream, and its next
     // upload waits for that event on the copy stream
@@ -2724,6 +2789,28 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
   if (!dec->dry && g_defer_enqueue) {
     // (a pipeline's build: the upload goes out from this thread, on an upload stream; the launcher's copy stream waits for it)
     de265hip_picture::Enq& E = pic->enq;
+    if (HsaDev* H = uploads_by_hsa() ? hsa_dev(dec->device) : nullptr) {
+      // (the arena: recycled only when known free - its last user's event, if there is one, has normally long completed)
+      bool ok = !pic->arena_buf.used || hipEventQuery(pic->arena_buf.last_use) == hipSuccess || hipEventSynchronize(pic->arena_buf.last_use) == hipSuccess;
+      (void)hipGetLastError();
+      hsa_signal_t sg{ 0 };
+      { std::lock_guard<std::mutex> lk(dec->mu); if (!dec->free_sigs.empty()) { sg.handle = dec->free_sigs.back(); dec->free_sigs.pop_back(); } }
+      if (ok && !sg.handle) ok = hsa_signal_create(1, 0, nullptr, &sg) == HSA_STATUS_SUCCESS;
+      if (ok) {
+        hsa_signal_store_relaxed(sg, 1);
+        ok = hsa_amd_memory_async_copy(pic->arena, H->gpu, E.host_base, H->cpu, E.upload_bytes, 0, nullptr, sg) == HSA_STATUS_SUCCESS;
+      }
+      if (!ok) { if (sg.handle) { std::lock_guard<std::mutex> lk(dec->mu); dec->free_sigs.push_back(sg.handle); } de265hip_picture_free(pic); return DE265HIP_ERROR_DECODING; }
+      E.uploaded_by_builder = true; E.up_sig = sg.handle;
+      {
+        std::lock_guard<std::mutex> lk(dec->mu);
+        for (auto& b : dec->stage_pool) if (b.ptr == E.host_base && b.owner == pic->ring_seq) { b.state = 2; b.sig = sg.handle; }
+      }
+      pt.mark("enqueue");
+      pt.done();
+      *out = pic;
+      return DE265HIP_OK;
+    }
     hipStream_t us;
     { std::lock_guard<std::mutex> lk(dec->mu); us = dec->upload_streams[dec->upload_turn++ & 1]; }
     bool ok = !pic->arena_buf.used || hipStreamWaitEvent(us, pic->arena_buf.last_use, 0) == hipSuccess;
@@ -2735,7 +2822,7 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
     if (!ok) { de265hip_picture_free(pic); return DE265HIP_ERROR_DECODING; }
     E.uploaded_by_builder = true;
     std::lock_guard<std::mutex> lk(dec->mu);
-    for (auto& b : dec->stage_pool) if (b.ptr == E.host_base && b.owner == pic->ring_seq) b.state = 2;
+    for (auto& b : dec->stage_pool) if (b.ptr == E.host_base && b.owner == pic->ring_seq) { b.state = 2; b.sig = 0; }
   }
   if (!dec->dry && !g_defer_enqueue) {
     const int erc = de265hip_picture_enqueue(pic);
@@ -2794,13 +2881,15 @@ int de265hip_picture_enqueue_batch(de265hip_picture** pics, int n)
       const size_t clear_to = pic->dev_scan ? pic->SL.clear_end : E.o_sync + E.clear_bytes;
       sec(1);
       sec(2);
-      if (E.uploaded_by_builder) HIPCHK(hipStreamWaitEvent(cs, E.stage_event, 0), DE265HIP_ERROR_DECODING);      // (the builder's thread sent it)
+      if (E.uploaded_by_builder && E.up_sig) {             // (through the HSA runtime: on the host - the builds run ahead, it has normally long arrived)
+        if (!hsa_upload_wait(E.up_sig)) return DE265HIP_ERROR_DECODING;
+      } else if (E.uploaded_by_builder) HIPCHK(hipStreamWaitEvent(cs, E.stage_event, 0), DE265HIP_ERROR_DECODING);      // (the builder's thread sent it)
       else {
         HIPCHK(hipMemcpyAsync(base, E.host_base, E.upload_bytes, hipMemcpyHostToDevice, cs), DE265HIP_ERROR_DECODING);
         sec(3);
         HIPCHK(hipEventRecord(E.stage_event, cs), DE265HIP_ERROR_DECODING);
         std::lock_guard<std::mutex> lk(dec->mu);
-        for (auto& b : dec->stage_pool) if (b.ptr == E.host_base && b.owner == pic->ring_seq) b.state = 2;      // reusable once `copied` has completed
+        for (auto& b : dec->stage_pool) if (b.ptr == E.host_base && b.owner == pic->ring_seq) { b.state = 2; b.sig = 0; }      // reusable once `copied` has completed
       }
       E.pending = false;
       sec(4);

@@ -72,6 +72,34 @@ int main()
     printf("%-48s: streaming kernel %.1f us per launch (%.0f GB/s), copy-out %.0f pictures/s = %.1f GB/s\n", names[mode], 1e6 * dt / KREP, 2.0 * big * KREP / dt / 1e9,
            (p1 - p0) / dt, (p1 - p0) * (double)bytes / dt / 1e9);
   }
+  // ---- uploads (8 MB, host -> device) through the HSA runtime, no compute queue involved: rate with 1 / 2 / 4 copies in flight, on
+  // the default engine and spread over the engines the runtime reports free; alone and next to the streaming kernel
+  {
+    const size_t up = 8u << 20; const int NS = 4, N = 200;
+    hsa_signal_t sg[NS]; for (auto& x : sg) HK(hsa_signal_create(0, 0, nullptr, &x));
+    uint32_t mask = 0; hsa_status_t es = hsa_amd_memory_copy_engine_status(g_gpu, g_cpu, &mask);
+    printf("copy engines free for host->device: status %d mask 0x%x\n", (int)es, mask);
+    uint32_t eng[16]; int ne = 0; for (uint32_t b = 1; b && ne < 16; b <<= 1) if (mask & b) eng[ne++] = b;
+    for (int loaded = 0; loaded < 2; loaded++)
+      for (int spread = 0; spread < (ne > 1 ? 2 : 1); spread++)
+        for (int inflight : {1, 2, 4}) {
+          std::atomic<bool> stop{false};
+          std::thread bg([&] { while (loaded && !stop.load()) { for (int i = 0; i < 20; i++) hipLaunchKernelGGL(k_copy, dim3(4096), dim3(256), 0, ks, (const uint4*)A, (uint4*)B, big / 16); CK(hipStreamSynchronize(ks)); } });
+          const double t0 = now();
+          for (int r = 0; r < N; r++) {
+            const int k = r % inflight;
+            if (r >= inflight && hsa_signal_wait_scacquire(sg[k], HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) != 0) { fprintf(stderr, "copy failed\n"); exit(1); }
+            hsa_signal_store_relaxed(sg[k], 1);
+            if (spread) HK(hsa_amd_memory_async_copy_on_engine((char*)d[k % NB], g_gpu, (char*)h[k % NB], g_cpu, up, 0, nullptr, sg[k], (hsa_amd_sdma_engine_id_t)eng[r % ne], false));
+            else HK(hsa_amd_memory_async_copy((char*)d[k % NB], g_gpu, (char*)h[k % NB], g_cpu, up, 0, nullptr, sg[k]));
+          }
+          for (int k = 0; k < inflight; k++) hsa_signal_wait_scacquire(sg[k], HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED);
+          const double dt = now() - t0;
+          stop = true; bg.join();
+          printf("H2D 8 MB by %s, %d in flight, %s: %.1f GB/s (%.0f us per copy)\n", spread ? "copy_on_engine (engines in turn)" : "hsa_amd_memory_async_copy", inflight,
+                 loaded ? "next to the streaming kernel" : "alone", N * (double)up / dt / 1e9, 1e6 * dt / N);
+        }
+  }
   unsigned char* p = (unsigned char*)h[1]; printf("check %d %d\n", p[0], p[bytes - 1]);
   return 0;
 }
