@@ -2373,6 +2373,7 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
       acc += roww[r];
     }
   }
+  pt.mark("mc_bands");
   for (int i = 0; i < d->n_pus; i++) {
     const de265hip_pu& pu = d->pus[i];
     if (pu.slice_idx >= d->n_slices || pu.w == 0 || pu.h == 0 || (pu.w & 3) || (pu.h & 3) || pu.w > 64 || pu.h > 64 ||
@@ -2406,7 +2407,7 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
     }
     const int nref = (t.slot[0] >= 0) + (t.slot[1] >= 0);
     const int64_t bppY = px_bytes(p.bit_depth_luma);
-    alg_mc += ((int64_t)pu.w * pu.h + 2 * (int64_t)(pu.w / subw) * (pu.h / subh)) * bppY * (nref + 1);
+    alg_mc += ((int64_t)pu.w * pu.h + 2 * (int64_t)(pu.w >> (subw - 1)) * (pu.h >> (subh - 1))) * bppY * (nref + 1);      // (SubWidthC, SubHeightC are 1 or 2: two divisions per PU were a tenth of this loop)
     // 4:2:0, reference blocks (filter margins included) inside the picture for every list:
     //   PUs narrower or lower than 16 -> blocks of at most 8x8 for the quad form (mc_micro_body) (four blocks per wavefront, sorted by slot pair);
     //   other PUs -> chunks of up to 32x16 for the chunk form (mc_chunk_body) (one wavefront walks the chunk's 16x16 tiles).
@@ -2465,6 +2466,7 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
         } else tiles16(X, Y, cw_, ch_);
       }
   }
+  pt.mark("mc_loop");
   // band by band: [k_mc's tiles | the chunk form's chunks | the quad form's blocks, four per wavefront, every four of one slot pair]
   std::sort(SC.micro_keys.begin(), SC.micro_keys.end());
   {
@@ -2521,11 +2523,15 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
   pic->n_pcm = (int)pcms.size();
 
   const size_t nblk = (size_t)g.w4 * g.h4;
-  for (size_t i = 0; i < nblk && !pic->any_edges; i++) pic->any_edges = (d->blk_flags[i] & 0xF0) != 0;
-  P.has_exempt = 0;
-  for (size_t i = 0; i < nblk && !P.has_exempt; i++)
-    P.has_exempt = ((d->blk_flags[i] & DE265HIP_BLK_BYPASS) ||
-                    ((d->blk_flags[i] & DE265HIP_BLK_PCM) && p.pcm_loop_filter_disable_flag)) ? 1 : 0;
+  {
+    // which flags occur anywhere in the picture: one OR over the plane (vectorised; two loops with an early exit each read all
+    // 518 000 bytes of a 4K picture one by one whenever the answer was "none", 0.15 ms of a B picture's 1.6)
+    uint8_t any = 0;
+    const uint8_t* bf = d->blk_flags;
+    for (size_t i = 0; i < nblk; i++) any |= bf[i];
+    if (any & 0xF0) pic->any_edges = true;
+    P.has_exempt = ((any & DE265HIP_BLK_BYPASS) || ((any & DE265HIP_BLK_PCM) && p.pcm_loop_filter_disable_flag)) ? 1 : 0;
+  }
 
   // ---- per-CTB SAO records: slice flags applied, slice / tile permissions of the 3x3 neighbourhood
   // (sao.cc:127-163) evaluated once here instead of per sample on the device
