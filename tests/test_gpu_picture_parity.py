@@ -767,6 +767,14 @@ def test_switches_are_ignored_without_the_tuning_gate():
     env["DE265HIP_TUNING"] = "1"                            # ... and with the gate open they do what they say
     r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
     assert "UNGATED_MISMATCH" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+    # the earlier forms of upload and copy-out (streams instead of the HSA runtime / the output thread) stay selectable and correct
+    env = {k: v for k, v in os.environ.items()}
+    env.update(DE265HIP_TUNING="1", DE265HIP_UPLOAD="stream", DE265HIP_OUT_COPY="dma")
+    r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+    assert "UNGATED_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+    env.update(DE265HIP_OUT_COPY="kernel")
+    r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+    assert "UNGATED_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
 
 def test_pipeline_output_queue_deeper_than_the_dpb_cycle(dec):
