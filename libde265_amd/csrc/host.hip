@@ -793,8 +793,10 @@ static bool uploads_by_hsa()
 static bool hsa_upload_wait(uint64_t sig)
 {
   if (!sig) return true;
-  hsa_signal_value_t v;
-  while ((v = hsa_signal_wait_scacquire(hsa_signal_t{ sig }, HSA_SIGNAL_CONDITION_LT, 1, 2000000000ull, HSA_WAIT_STATE_BLOCKED)) >= 1) {}
+  // (a copy of a few megabytes takes a fraction of a millisecond; one that has not arrived after half a minute never will)
+  hsa_signal_value_t v = 1;
+  for (int tries = 0; tries < 15 && v >= 1; tries++)
+    v = hsa_signal_wait_scacquire(hsa_signal_t{ sig }, HSA_SIGNAL_CONDITION_LT, 1, 2000000000ull, HSA_WAIT_STATE_BLOCKED);
   return v == 0;
 }
 
