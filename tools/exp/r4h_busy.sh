@@ -36,6 +36,9 @@ cur=0; last=t0; hist=collections.Counter()
 for t,dv in pts:
     hist[cur]+=t-last; last=t; cur+=dv
 print('concurrency histogram (%% of time): '+' '.join('%d:%.1f'%(k,100*v/tot) for k,v in sorted(hist.items())))
+byk=collections.defaultdict(list)
+for e in reg: byk[e[2]].append(e[1]-e[0])
+print('kernel durations inside the region (us): '+'  '.join('%s %.0f' % (k, sum(v)/len(v)/1e3) for k,v in sorted(byk.items(), key=lambda kv:-sum(kv[1]))))
 nrun=sum(1 for e in reg if e[2]=='k_run')
 print('pictures (k_run launches) in region', nrun, '-> %.0f pictures/s'%(nrun/(tot/1e9)))
 PY
