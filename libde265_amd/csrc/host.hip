@@ -2862,7 +2862,7 @@ int de265hip_picture_enqueue_batch(de265hip_picture** pics, int n)
     { std::lock_guard<std::mutex> lk(dec->mu); cs = dec->copy_streams[dec->copy_turn++ % (uint64_t)dec->n_copy_streams]; reap_arenas(dec); }
     static const int own_prep = d265_env("DE265HIP_OWN_PREP") ? atoi(d265_env("DE265HIP_OWN_PREP")) : 1;
     static const int run2_lane0 = d265_env("DE265HIP_SCAN_RUN2_LANE0") ? atoi(d265_env("DE265HIP_SCAN_RUN2_LANE0")) : 0;
-    ScanBatch J; J.n = 0; J.pad = run2_lane0 ? 1 : 0;      // (pad bit 0: the mailbox readers' pass on one lane, scan_core.h's loop: the parity variant)
+    ScanBatch J; memset(&J, 0, sizeof(J)); J.pad = run2_lane0 ? 1 : 0;      // (pad bit 0: the mailbox readers' pass on one lane, scan_core.h's loop: the parity variant)
     PrepBatch PJ; PJ.n = 0; PJ.pad = 0;
     de265hip_picture* done[SCAN_BATCH]; int n_done = 0;
     auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -2917,6 +2917,13 @@ int de265hip_picture_enqueue_batch(de265hip_picture** pics, int n)
         pic->SB.host_counts = hc; pic->SB.err_word = dec->d_err_ring + pic->ring_idx; pic->SB.ready_tag = (uint32_t)pic->ring_seq | 0x80000000u;
         ScanJob& jb = J.job[J.n++];
         jb.P = pic->SP; jb.B = pic->SB; jb.cap_resid = pic->cap_resid; jb.cap_levels = pic->SL.cap_levels;
+        // the motion plane by the per-TU pass's launch instead of a launch of its own (behind k_build_prep, which sets it to "no reference")
+        static const bool motion_merged = !(d265_env("DE265HIP_MOTION_LAUNCH") && atoi(d265_env("DE265HIP_MOTION_LAUNCH")));
+        PrepJob& q = PJ.job[PJ.n - 1];
+        if (motion_merged && own_prep && q.ff && q.n_pus > 0) {
+          jb.mo_pus = q.pus; jb.mo_slices = q.slices; jb.mo_plane = q.motion; jb.mo_n_pus = q.n_pus; jb.mo_n_slices = q.n_slices; jb.mo_w4 = q.w4; jb.mo_h4 = q.h4;
+          q.n_pus = 0;
+        }
         pic->scan_pending = true;
       } else {
         HIPCHK(hipMemsetAsync(dec->d_err_ring + pic->ring_idx, 0, 4, cs), DE265HIP_ERROR_DECODING);

@@ -195,11 +195,41 @@ __device__ __forceinline__ void scan_tu_dev(const ScanParams& P, const ScanBufs&
     for (int x = xB >> 2; x < (xB + nT) >> 2; x++) cells[x + (size_t)y * mw] = (ScanCell)(uint32_t)(i + 1);
 }
 
+// the motion plane of a picture from its PU records (k_lf.hip k_motion_from_pus, the same body): sixteen lanes per PU, sixteen
+// PUs per workgroup and step; workgroup `wg` of `n_wg`
+__device__ __forceinline__ void motion_from_pus_body(const de265hip_pu* __restrict__ pus, int n_pus, const de265hip_slice_params* __restrict__ slices, int n_slices,
+                                                     de265hip_motion* __restrict__ motion, int w4, int h4, int wg, int n_wg)
+{
+  const int sub = threadIdx.x & 15;
+  for (int i = wg * 16 + (threadIdx.x >> 4); i < n_pus; i += n_wg * 16) {
+    const de265hip_pu pu = pus[i];
+    if (pu.slice_idx >= n_slices) continue;
+    de265hip_motion m;
+    for (int l = 0; l < 2; l++) {
+      const bool on = (pu.pred_flag >> l) & 1;
+      const int ri = pu.ref_idx[l];
+      m.ref_slot[l] = (on && ri >= 0 && ri < DE265HIP_MAX_REFS) ? slices[pu.slice_idx].ref_pic_list[l][ri] : (int8_t)-1;
+      m.mv[l][0] = on ? pu.mv[l][0] : (int16_t)0; m.mv[l][1] = on ? pu.mv[l][1] : (int16_t)0;
+    }
+    m.pad[0] = m.pad[1] = 0;
+    const int bw = pu.w >> 2, bh = pu.h >> 2;
+    for (int q = sub; q < bw * bh; q += 16) {
+      const int x = (pu.x >> 2) + q % bw, y = (pu.y >> 2) + q / bw;
+      if (x < w4 && y < h4) motion[x + y * w4] = m;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256)
 void k_scan_tus(ScanBatch J)
 {
   if (blockIdx.y >= (unsigned)J.n) return;
   SCAN_PRIO();
+  if ((int)blockIdx.x >= J.tus_blocks) {                    // the workgroups behind the pass's own: the picture's motion plane
+    const ScanJob& Q = J.job[blockIdx.y];
+    if (Q.mo_plane) motion_from_pus_body(Q.mo_pus, Q.mo_n_pus, Q.mo_slices, Q.mo_n_slices, Q.mo_plane, Q.mo_w4, Q.mo_h4, (int)blockIdx.x - J.tus_blocks, (int)gridDim.x - J.tus_blocks);
+    return;
+  }
   const ScanParams& P = J.job[blockIdx.y].P; const ScanBufs& B = J.job[blockIdx.y].B;
   if (blockIdx.x == 0 && threadIdx.x == 0) { if (B.err_word) *B.err_word = 0; B.counts->victim = 0xFFFFFFFFu; }      // (the picture's kernels that may raise the word come behind the scan)
   __shared__ uint32_t s_tot[7];                               // this workgroup's share of the list totals (scan_prefix's job until round 4)
@@ -208,7 +238,7 @@ void k_scan_tus(ScanBatch J)
   uint32_t alg_resid = 0, alg_intra = 0, n_tasks = 0;
   bool bad = false;
   // (a bounded grid that walks the records: see scan_enqueue_batch)
-  for (int blk = blockIdx.x; blk * 256 < P.n_tus; blk += gridDim.x) {
+  for (int blk = blockIdx.x; blk * 256 < P.n_tus; blk += J.tus_blocks) {
     const int i = blk * 256 + threadIdx.x;
     scan_tu_dev(P, B, i, i < P.n_tus, alg_resid, alg_intra, n_tasks, s_tot);
     // coefficient positions inside their TU's block (de265hip_picture_build's job on the host until round 3): the workgroup's 256
@@ -1289,24 +1319,7 @@ void k_motion_batch(PrepBatch J)
   if (blockIdx.y >= (unsigned)J.n) return;
   SCAN_PRIO();
   const PrepJob& Q = J.job[blockIdx.y];
-  const int sub = threadIdx.x & 15;
-  for (int i = blockIdx.x * 16 + (threadIdx.x >> 4); i < Q.n_pus; i += gridDim.x * 16) {
-  const de265hip_pu pu = Q.pus[i];
-  if (pu.slice_idx >= Q.n_slices) continue;
-  de265hip_motion m;
-  for (int l = 0; l < 2; l++) {
-    const bool on = (pu.pred_flag >> l) & 1;
-    const int ri = pu.ref_idx[l];
-    m.ref_slot[l] = (on && ri >= 0 && ri < DE265HIP_MAX_REFS) ? Q.slices[pu.slice_idx].ref_pic_list[l][ri] : (int8_t)-1;
-    m.mv[l][0] = on ? pu.mv[l][0] : (int16_t)0; m.mv[l][1] = on ? pu.mv[l][1] : (int16_t)0;
-  }
-  m.pad[0] = m.pad[1] = 0;
-  const int bw = pu.w >> 2, bh = pu.h >> 2;
-  for (int q = sub; q < bw * bh; q += 16) {
-    const int x = (pu.x >> 2) + q % bw, y = (pu.y >> 2) + q / bw;
-    if (x < Q.w4 && y < Q.h4) Q.motion[x + y * Q.w4] = m;
-  }
-  }
+  motion_from_pus_body(Q.pus, Q.n_pus, Q.slices, Q.n_slices, Q.motion, Q.w4, Q.h4, (int)blockIdx.x, (int)gridDim.x);
 }
 
 hipError_t prep_enqueue_batch(hipStream_t st, const PrepBatch& J)
@@ -1379,7 +1392,13 @@ hipError_t scan_enqueue_batch(hipStream_t st, const ScanBatch& J)
   // wavefronts of a launch, all pictures of the batch together.)
   static const int scan_grid = d265_env("DE265HIP_SCAN_GRID") ? std::max(64, atoi(d265_env("DE265HIP_SCAN_GRID"))) : 1024;
   const unsigned per_pic = (unsigned)std::max(32, scan_grid / (int)ny);
-  if (max_tus > 0) hipLaunchKernelGGL(k_scan_tus, dim3(std::min<unsigned>((max_tus + 255) / 256, per_pic), ny), dim3(256), 0, st, J);
+  // (the per-TU pass's launch also carries the motion planes, behind its own workgroups: ScanJob::mo_*)
+  int most_pus = 0;
+  for (int i = 0; i < J.n; i++) if (J.job[i].mo_plane) most_pus = std::max(most_pus, J.job[i].mo_n_pus);
+  ScanBatch K = J;
+  K.tus_blocks = max_tus > 0 ? (int)std::min<unsigned>((max_tus + 255) / 256, per_pic) : 0;
+  const unsigned mo_blocks = most_pus > 0 ? std::min<unsigned>((most_pus + 15) / 16, std::max(16u, per_pic / 2)) : 0u;
+  if (K.tus_blocks + mo_blocks > 0) hipLaunchKernelGGL(k_scan_tus, dim3((unsigned)K.tus_blocks + mo_blocks, ny), dim3(256), 0, st, K);
   if (max_tus > 0) {
     hipLaunchKernelGGL(k_scan_ctbs, dim3(std::min<unsigned>(max_ctbs, per_pic), ny), dim3(64), 0, st, J);
     // (the number of runs is only known on the device: fixed grids of wavefronts walk the run lists)
@@ -1400,7 +1419,7 @@ hipError_t scan_enqueue_batch(hipStream_t st, const ScanBatch& J)
 hipError_t scan_enqueue(hipStream_t st, const ScanParams& P, const ScanBufs& B, const ScanLayout& L, uint8_t* base, uint32_t cap_resid)
 {
   (void)base;
-  ScanBatch J; J.n = 1; J.pad = 0;
+  ScanBatch J; memset(&J, 0, sizeof(J)); J.n = 1;
   J.job[0].P = P; J.job[0].B = B; J.job[0].cap_resid = cap_resid; J.job[0].cap_levels = L.cap_levels;
   return scan_enqueue_batch(st, J);
 }

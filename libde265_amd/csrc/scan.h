@@ -20,8 +20,13 @@ struct ScanLayout {
 
 // up to SCAN_BATCH pictures whose passes share their launches (kernel arguments by value: < 4 KB)
 #define SCAN_BATCH 4
-struct ScanJob { ScanParams P; ScanBufs B; uint32_t cap_resid, cap_levels; };
-struct ScanBatch { int n; int pad; ScanJob job[SCAN_BATCH]; };
+// mo_*: the picture's motion plane from its PU records, by extra workgroups of the per-TU pass's launch (nullptr / 0: not asked
+// for).  A launch of its own - 9 us alone - shows as 90 us in the kernel trace of the product path, like every small kernel of the
+// chain; one launch fewer per batch, but no measurable change of the product's rate (4 250-4 290 against 4 310-4 370 pictures/s with
+// DE265HIP_MOTION_LAUNCH=1, box noise): what those 90 us are is time in the stream's queue, not work.
+struct ScanJob { ScanParams P; ScanBufs B; uint32_t cap_resid, cap_levels;
+                 const de265hip_pu* mo_pus; const de265hip_slice_params* mo_slices; de265hip_motion* mo_plane; int mo_n_pus, mo_n_slices, mo_w4, mo_h4, mo_pad; };
+struct ScanBatch { int n; int pad; int tus_blocks; int pad2; ScanJob job[SCAN_BATCH]; };      // tus_blocks: the per-TU pass's workgroups per picture (the rest of its grid: the motion plane)
 hipError_t scan_enqueue_batch(hipStream_t st, const ScanBatch& J);
 
 // what has to be set before the passes (and the picture's kernels) may run, for the pictures of a batch in ONE launch each:
