@@ -930,6 +930,7 @@ void de265hip_decoder_free(de265hip_decoder* d)
   {
     std::lock_guard<std::mutex> lk(d->mu);
     for (de265hip_picture* p : d->live) {
+      if (p->enq.up_sig) { (void)hsa_upload_wait(p->enq.up_sig); (void)hsa_signal_destroy(hsa_signal_t{ p->enq.up_sig }); p->enq.up_sig = 0; }      // (an upload still on its way into the arena)
       destroy_arena(p->arena_buf);
       p->arena = nullptr;
       if (p->uploaded) { (void)hipEventDestroy(p->uploaded); p->uploaded = nullptr; }
