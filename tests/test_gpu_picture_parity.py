@@ -772,9 +772,10 @@ def test_switches_are_ignored_without_the_tuning_gate():
     env.update(DE265HIP_TUNING="1", DE265HIP_UPLOAD="stream", DE265HIP_OUT_COPY="dma")
     r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
     assert "UNGATED_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
-    env.update(DE265HIP_OUT_COPY="kernel")
-    r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
-    assert "UNGATED_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+    for form in ("kernel", "deferred"):
+        env.update(DE265HIP_OUT_COPY=form)
+        r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+        assert "UNGATED_OK" in r.stdout, (form, r.stdout[-500:], r.stderr[-1500:])
 
 
 def test_pipeline_output_queue_deeper_than_the_dpb_cycle(dec):

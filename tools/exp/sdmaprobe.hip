@@ -100,6 +100,41 @@ int main()
                  loaded ? "next to the streaming kernel" : "alone", N * (double)up / dt / 1e9, 1e6 * dt / N);
         }
   }
+  // ---- copy-outs (24.9 MB pictures as three planes 16.6 + 4.1 + 4.1 MB, device -> host) through the HSA runtime
+  {
+    const size_t pl[3] = { 3840u * 2160u * 2u, 1920u * 1080u * 2u, 1920u * 1080u * 2u }; const int N = 60;
+    hsa_signal_t sg[2]; for (auto& x : sg) HK(hsa_signal_create(0, 0, nullptr, &x));
+    uint32_t mask = 0; (void)hsa_amd_memory_copy_engine_status(g_cpu, g_gpu, &mask);
+    uint32_t pref = 0; hsa_status_t ps = hsa_amd_memory_get_preferred_copy_engine(g_cpu, g_gpu, &pref);
+    printf("copy engines free for device->host: mask 0x%x, preferred (status %d) 0x%x\n", mask, (int)ps, pref);
+    uint32_t eng[16]; int ne = 0; for (uint32_t b = 1; b && ne < 16; b <<= 1) if (mask & b) eng[ne++] = b;
+    uint32_t pe[16]; int npe = 0; for (uint32_t b = 1; b && npe < 16; b <<= 1) if (pref & b) pe[npe++] = b;
+    for (int loaded = 0; loaded < 2; loaded++)
+      for (int how = 0; how < 3; how++) {                   // 0: plain call; 1: free engines in turn; 2: preferred engines in turn
+        if (how == 1 && ne < 2) continue;
+        if (how == 2 && npe < 1) continue;
+        std::atomic<bool> stop{false};
+        std::thread bg([&] { while (loaded && !stop.load()) { for (int i = 0; i < 20; i++) hipLaunchKernelGGL(k_copy, dim3(4096), dim3(256), 0, ks, (const uint4*)A, (uint4*)B, big / 16); CK(hipStreamSynchronize(ks)); } });
+        const double t0 = now();
+        int ecount = 0;
+        for (int r = 0; r < N; r++) {                         // two pictures in flight, three copies each on one signal
+          const int k = r & 1;
+          if (r >= 2 && hsa_signal_wait_scacquire(sg[k], HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) != 0) { fprintf(stderr, "copy failed\n"); exit(1); }
+          hsa_signal_store_relaxed(sg[k], 3);
+          size_t off = 0;
+          for (int c = 0; c < 3; c++) {
+            char* dst = (char*)h[k] + off; const char* src = (const char*)d[k] + off; off += pl[c];
+            if (how == 0) HK(hsa_amd_memory_async_copy(dst, g_cpu, src, g_gpu, pl[c], 0, nullptr, sg[k]));
+            else { const uint32_t e = how == 1 ? eng[ecount++ % ne] : pe[ecount++ % npe]; HK(hsa_amd_memory_async_copy_on_engine(dst, g_cpu, src, g_gpu, pl[c], 0, nullptr, sg[k], (hsa_amd_sdma_engine_id_t)e, false)); }
+          }
+        }
+        for (int k = 0; k < 2; k++) hsa_signal_wait_scacquire(sg[k], HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED);
+        const double dt = now() - t0;
+        stop = true; bg.join();
+        static const char* nm[3] = { "hsa_amd_memory_async_copy", "copy_on_engine, free engines in turn", "copy_on_engine, preferred engines in turn" };
+        printf("D2H pictures by %s, %s: %.1f GB/s (%.0f pictures/s)\n", nm[how], loaded ? "next to the streaming kernel" : "alone", N * (double)bytes / dt / 1e9, N / dt);
+      }
+  }
   unsigned char* p = (unsigned char*)h[1]; printf("check %d %d\n", p[0], p[bytes - 1]);
   return 0;
 }
