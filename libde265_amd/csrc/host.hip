@@ -3334,7 +3334,8 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
       // the "deblock_v" kernel id
       KTimer t(dec, DE265HIP_K_DEBLOCK_V, 1);
       const int nbx = (P.width + 3) / 8 + 1, nby = (P.height + 3) / 8 + 1;
-      hipLaunchKernelGGL((k_deblock_fused<PX>), dim3((nbx + 255) / 256, nby, c420 ? 3 : 1), dim3(256), 0, st, P, d0, d1, d2, M);
+      static const int lf_wg = d265_env("DE265HIP_LF_WG") ? std::max(64, std::min(256, atoi(d265_env("DE265HIP_LF_WG")) & ~63)) : 64;       // (a thread per 8x8 block, no LDS: any workgroup size; one-wavefront workgroups find their place sooner next to the other streams' kernels: 34-35 us against 40 in the product path, 22 alone either way)
+      hipLaunchKernelGGL((k_deblock_fused<PX>), dim3((nbx + lf_wg - 1) / lf_wg, nby, c420 ? 3 : 1), dim3(lf_wg), 0, st, P, d0, d1, d2, M);
       if (!c420 && P.chroma_format)
         for (int vertical = 1; vertical >= 0; vertical--) {       // vertical edges of the whole plane before any horizontal one
           const int xi = (vertical ? 2 : 1) << P.csw, yi = (vertical ? 1 : 2) << P.csh;
