@@ -3369,9 +3369,11 @@ int run_picture(de265hip_decoder* dec, de265hip_picture* pic, int last_stage)
         //  k_sao_chroma_any took 101 us per 4K10 picture against 11 for the luma plane; 4:2:2 keeps the plain kernel)
         const bool c444 = P.chroma_format == 3;
         const int gx = c444 ? (P.width + tw - 1) / tw : std::max((P.width + tw - 1) / tw, (P.width / 2 + twc - 1) / twc);
-        const int gy = c444 ? (P.height + 4 * th - 1) / (4 * th) : std::max((P.height + 4 * th - 1) / (4 * th), (P.height / 2 + 4 * thc - 1) / (4 * thc));
+        // (wavefronts per workgroup: no LDS, no barrier - any number; DE265HIP_SAO_WG)
+        static const int sw = d265_env("DE265HIP_SAO_WG") ? std::max(1, std::min(4, atoi(d265_env("DE265HIP_SAO_WG")) / 64)) : 1;      // (one: 38 us against 44-48 next to the other streams' kernels, 24 alone either way)
+        const int gy = c444 ? (P.height + sw * th - 1) / (sw * th) : std::max((P.height + sw * th - 1) / (sw * th), (P.height / 2 + sw * thc - 1) / (sw * thc));
         const uint3 G = make_uint3((unsigned)gx, (unsigned)gy, (c420 || c444) ? 3u : 1u);
-        hipLaunchKernelGGL(k_sao_ctb<PX>, dim3(xcd_grid(G.x * G.y * G.z)), dim3(256), 0, st, P, d0, d1, d2, sp.pl[0], sp.pl[1], sp.pl[2], M, G);
+        hipLaunchKernelGGL(k_sao_ctb<PX>, dim3(xcd_grid(G.x * G.y * G.z)), dim3(64 * sw), 0, st, P, d0, d1, d2, sp.pl[0], sp.pl[1], sp.pl[2], M, G);
         if (!c420 && !c444 && P.chroma_format)
           hipLaunchKernelGGL(k_sao_chroma_any<PX>, dim3((P.cwidth + 255) / 256, P.cheight, 2), dim3(256), 0, st, P, d1, d2, sp.pl[1], sp.pl[2], M);
       }

@@ -845,7 +845,7 @@ void k_sao_ctb(PicDev P, PlaneRef s0, PlaneRef s1, PlaneRef s2, PlaneRef d0, Pla
   const int sx = lane & ((1 << lsw) - 1), sy = lane >> lsw;
   const int tw = 8 << lsw, th = (64 >> lsw) * SAO_ROWS;         // tile size in samples
   const int x0 = B.x * tw + sx * 8;
-  const int y0 = (B.y * 4 + wave) * th + sy * SAO_ROWS;
+  const int y0 = (B.y * (int)(blockDim.x >> 6) + wave) * th + sy * SAO_ROWS;      // (a workgroup's wavefronts: tile rows below each other; G.y counts workgroups)
   const PlaneRef sp = comp == 0 ? s0 : (comp == 1 ? s1 : s2);
   const PlaneRef dp = comp == 0 ? d0 : (comp == 1 ? d1 : d2);
   const PX* src = (const PX*)sp.ptr;
