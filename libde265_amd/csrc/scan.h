@@ -19,7 +19,11 @@ struct ScanLayout {
 };
 
 // up to SCAN_BATCH pictures whose passes share their launches (kernel arguments by value: < 4 KB)
-#define SCAN_BATCH 4
+// (2 / 4 / 8 pictures per set of launches: 3 840-3 940 / 4 450-4 530 / 4 510-4 660 pictures/s in the product path of the bench, same
+//  box - every launch of the chain costs its place in the queue of a busy device; 8 jobs are 3.7 KB of kernel arguments)
+#ifndef SCAN_BATCH
+#define SCAN_BATCH 8
+#endif
 // mo_*: the picture's motion plane from its PU records, by extra workgroups of the per-TU pass's launch (nullptr / 0: not asked
 // for).  A launch of its own - 9 us alone - shows as 90 us in the kernel trace of the product path, like every small kernel of the
 // chain; one launch fewer per batch, but no measurable change of the product's rate (4 250-4 290 against 4 310-4 370 pictures/s with
