@@ -2809,16 +2809,23 @@ static int picture_build_impl(de265hip_decoder* dec, int dst_slot, const de265hi
         hsa_signal_store_relaxed(sg, 1);
         ok = hsa_amd_memory_async_copy(pic->arena, H->gpu, E.host_base, H->cpu, E.upload_bytes, 0, nullptr, sg) == HSA_STATUS_SUCCESS;
       }
-      if (!ok) { if (sg.handle) { std::lock_guard<std::mutex> lk(dec->mu); dec->free_sigs.push_back(sg.handle); } de265hip_picture_free(pic); return DE265HIP_ERROR_DECODING; }
-      E.uploaded_by_builder = true; E.up_sig = sg.handle;
-      {
-        std::lock_guard<std::mutex> lk(dec->mu);
-        for (auto& b : dec->stage_pool) if (b.ptr == E.host_base && b.owner == pic->ring_seq) { b.state = 2; b.sig = sg.handle; }
+      if (ok) {
+        E.uploaded_by_builder = true; E.up_sig = sg.handle;
+        {
+          std::lock_guard<std::mutex> lk(dec->mu);
+          for (auto& b : dec->stage_pool) if (b.ptr == E.host_base && b.owner == pic->ring_seq) { b.state = 2; b.sig = sg.handle; }
+        }
+        pt.mark("enqueue");
+        pt.done();
+        *out = pic;
+        return DE265HIP_OK;
       }
-      pt.mark("enqueue");
-      pt.done();
-      *out = pic;
-      return DE265HIP_OK;
+      // the runtime refused the copy (an agent pair it does not take, a machine this was not tried on): this picture and all later
+      // ones go the other way, through an upload stream - slower, never wrong
+      if (sg.handle) { std::lock_guard<std::mutex> lk(dec->mu); dec->free_sigs.push_back(sg.handle); }
+      { std::lock_guard<std::mutex> lk(g_streams_mu); H->ok = false; }
+      static bool told = false;
+      if (!told) { told = true; fprintf(stderr, "de265hip: uploads through the HSA runtime are not available here; using upload streams\n"); }
     }
     hipStream_t us;
     { std::lock_guard<std::mutex> lk(dec->mu); us = dec->upload_streams[dec->upload_turn++ & 1]; }
